@@ -1,0 +1,77 @@
+"""ctypes binding of libeps_hip.so (include/eps_abi.h).  No fallback: if the HIP library is
+missing or a tensor is not on a GPU, the call raises -- the product path never routes through
+a CPU implementation."""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libeps_hip.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+_c = ctypes
+_vp, _i64, _i32, _int = _c.c_void_p, _c.c_int64, _c.c_int32, _c.c_int
+
+# name -> (restype, argtypes); mirrors include/eps_abi.h one to one
+SIGNATURES = {
+    "eps_version": (_int, []),
+    "eps_last_error": (_c.c_char_p, []),
+    "eps_device_info": (_int, [_c.POINTER(_int), _c.c_char_p, _int]),
+    "eps_col_sums": (_int, [_vp, _vp, _vp, _i64, _i64, _vp, _vp]),
+    "eps_node_weights": (_int, [_vp, _i64, _int, _vp, _vp]),
+    "eps_node_weights_f64": (_int, [_vp, _i64, _int, _vp, _vp]),
+    "eps_pair_scores": (_int, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
+    "eps_pair_scores_f64": (_int, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp]),
+    "eps_spmm_csr": (_int, [_vp, _vp, _vp, _i64, _vp, _i64, _i32, _vp, _int, _int, _vp, _i64, _vp]),
+    "eps_gcn_norm": (_int, [_vp, _vp, _vp, _i64, _vp, _vp, _vp]),
+    "eps_gemm_f32": (_int, [_vp, _i64, _vp, _i64, _vp, _int, _int, _vp, _i64, _i64, _i32, _i32, _vp]),
+    "eps_mlp_decode": (_int, [_vp, _i64, _i32, _vp, _vp, _i64, _c.POINTER(_vp), _c.POINTER(_vp), _i32, _int, _vp, _vp]),
+    "eps_pack_keys": (_int, [_vp, _vp, _i64, _i64, _vp, _vp]),
+    "eps_unpack_keys": (_int, [_vp, _i64, _vp, _vp, _vp]),
+}
+
+_lib = None
+
+
+class EpsError(RuntimeError):
+    pass
+
+
+def build(force: bool = False) -> str:
+    """Compile every HIP source for gfx950 into libeps_hip.so (hipcc cross-compiles without a GPU)."""
+    if force:
+        subprocess.check_call(["make", "-C", CSRC, "-s", "clean"])
+    subprocess.check_call(["make", "-C", CSRC, "-s", "-j8"])
+    if not os.path.exists(LIB_PATH):
+        raise EpsError(f"build did not produce {LIB_PATH}")
+    return LIB_PATH
+
+
+def load() -> ctypes.CDLL:
+    """Load libeps_hip.so.  torch is imported first so that the HIP runtime torch ships
+    (same soname, libamdhip64.so.7) is the one the library binds to -- device pointers are
+    only meaningful inside one runtime."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    import torch  # noqa: F401  (loads torch's libamdhip64 before ours resolves it)
+    if not os.path.exists(LIB_PATH):
+        raise EpsError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                       f"or `make -C {CSRC}`.  There is no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError here == ABI drift, fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    if lib.eps_version() != 1:
+        raise EpsError(f"libeps_hip.so ABI version {lib.eps_version()} != 1")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().eps_last_error().decode("utf-8", "replace")
+        raise EpsError(f"{what} failed (rc={rc}): {msg}")

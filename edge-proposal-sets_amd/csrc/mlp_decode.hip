@@ -1,0 +1,227 @@
+// Fused LinkPredictor decode on the f32-input MFMA, gfx950.
+//
+// Replaces h[edges[0]] / h[edges[1]] gathers (models.py:506) + LinkPredictor.forward
+// (models.py:478-485): Hadamard -> (L-1) x [Linear, ReLU] -> Linear(H,1) -> sigmoid, one float
+// per candidate edge out.  Dropout is the identity in eval mode (models.py:483 with
+// training=False), which is the only mode the scoring path runs in.
+//
+// One 256-thread workgroup per CU walks 64-edge tiles (persistent, grid-stride):
+//   1. gather: each wave builds 16 rows of X = h[u] (.) h[v] straight into LDS (one coalesced
+//      1-KiB row read per endpoint, float4 per lane);
+//   2. hidden layers: X[64,H] stays in LDS; W_l streams through LDS in K-chunks of 32
+//      (register-staged double buffer, one barrier per chunk); each wave owns H/4 output
+//      columns as 2x2 MFMA 32x32 tiles (64 accumulator registers); bias + ReLU are applied in
+//      the accumulators and written back over X -- activations never leave the CU;
+//   3. last layer (H -> 1) is a 4-lanes-per-row dot product over the LDS tile + sigmoid.
+// f32 in, f32 accumulate (v_mfma_f32_32x32x2_f32 == fmaf chain): the 1e-5 parity gate rules out
+// bf16/"xf32" shortcuts (and gfx950 has no xf32).
+#include "eps_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float v4f __attribute__((ext_vector_type(4)));  // native vector: stays in VGPRs (HIP's float4 struct copies lower to memcpy -> scratch)
+
+#define D_BM 64        // edges per tile
+#define D_HMAX 256     // widest hidden size held in LDS
+#define D_XLD (D_HMAX + 4)
+#define D_BK 32
+#define D_WLD 36
+#define D_MAXL 8
+
+struct DecodeParams {
+    const float *w[D_MAXL];
+    const float *b[D_MAXL];
+};
+
+// Static-index select: a runtime index into the by-value kernel argument would force the
+// struct into scratch memory.
+__device__ __forceinline__ const float *pick(const float *const (&a)[D_MAXL], int l)
+{
+    const float *p = a[0];
+#pragma unroll
+    for (int i = 1; i < D_MAXL; ++i) p = (i == l) ? a[i] : p;
+    return p;
+}
+
+__device__ __forceinline__ void w_gload(v4f (&rw)[8], const float *__restrict__ W, int H, int tid, int kc)
+{
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int q = tid + 256 * i;
+        const int row = q >> 3, c4 = q & 7;
+        const int rowc = row < H ? row : H - 1;  // clamped duplicate read instead of a guarded def
+        rw[i] = *reinterpret_cast<const v4f *>(W + (int64_t)rowc * H + kc * D_BK + c4 * 4);
+    }
+}
+
+__device__ __forceinline__ void w_lstore(const v4f (&rw)[8], float (*Wb)[D_WLD], int H, int tid)
+{
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int q = tid + 256 * i;
+        const int row = q >> 3, c4 = q & 7;
+        if (row < H) *reinterpret_cast<v4f *>(&Wb[row][c4 * 4]) = rw[i];
+    }
+}
+
+__global__ __launch_bounds__(256) void mlp_decode_kernel(const float *__restrict__ hmat, int32_t H,
+                                                         const int32_t *__restrict__ pu,
+                                                         const int32_t *__restrict__ pv, int64_t n_pairs,
+                                                         DecodeParams prm, int32_t n_layers, int apply_sigmoid,
+                                                         float *__restrict__ out)
+{
+    __shared__ __attribute__((aligned(16))) float Xs[D_BM][D_XLD];
+    __shared__ __attribute__((aligned(16))) float Ws[2][D_HMAX][D_WLD];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, w = tid >> 6;
+    const int r = lane & 31, hh = lane >> 5;
+    const int n_ntiles = H >> 5;            // 32-column output tiles (<= 8)
+    const int t0 = w, t1 = w + 4;           // the (up to) two column tiles this wave owns
+    const bool has0 = t0 < n_ntiles, has1 = t1 < n_ntiles;
+    const int nk = H / D_BK;
+    const int64_t n_tiles = (n_pairs + D_BM - 1) / D_BM;
+    const int h4 = H >> 2;                  // float4 per row
+
+    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int64_t e0 = tile * D_BM;
+        // ---- 1. gather + Hadamard into LDS ------------------------------------------------
+        {
+            const int64_t p = e0 + lane;
+            const int32_t mu = p < n_pairs ? pu[p] : 0, mv = p < n_pairs ? pv[p] : 0;
+            for (int i = 0; i < 16; i += 2) {
+                const int row0 = w * 16 + i, row1 = row0 + 1;
+                const int64_t u0 = __builtin_amdgcn_readlane(mu, row0), v0 = __builtin_amdgcn_readlane(mv, row0);
+                const int64_t u1 = __builtin_amdgcn_readlane(mu, row1), v1 = __builtin_amdgcn_readlane(mv, row1);
+                for (int c = lane; c < h4; c += 64) {
+                    const float4 a0 = *reinterpret_cast<const float4 *>(hmat + u0 * H + 4 * c);
+                    const float4 b0 = *reinterpret_cast<const float4 *>(hmat + v0 * H + 4 * c);
+                    const float4 a1 = *reinterpret_cast<const float4 *>(hmat + u1 * H + 4 * c);
+                    const float4 b1 = *reinterpret_cast<const float4 *>(hmat + v1 * H + 4 * c);
+                    *reinterpret_cast<float4 *>(&Xs[row0][4 * c]) = make_float4(a0.x * b0.x, a0.y * b0.y, a0.z * b0.z, a0.w * b0.w);
+                    *reinterpret_cast<float4 *>(&Xs[row1][4 * c]) = make_float4(a1.x * b1.x, a1.y * b1.y, a1.z * b1.z, a1.w * b1.w);
+                }
+            }
+        }
+        __syncthreads();
+
+        // ---- 2. hidden layers -------------------------------------------------------------
+        for (int l = 0; l + 1 < n_layers; ++l) {
+            const float *__restrict__ W = pick(prm.w, l);
+            const float *__restrict__ Bv = pick(prm.b, l);
+            f32x16 acc[2][2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+            v4f rw[8];
+            // W chunk = rows [0,H) x cols [kc*32, kc*32+32): H*8 float4, 8 per thread at H = 256
+            w_gload(rw, W, H, tid, 0);
+            w_lstore(rw, Ws[0], H, tid);
+            __syncthreads();
+            for (int kc = 0; kc < nk; ++kc) {
+                const int buf = kc & 1;
+                if (kc + 1 < nk) w_gload(rw, W, H, tid, kc + 1);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int ko = 8 * j + 4 * hh;
+                    const float4 a0 = *reinterpret_cast<const float4 *>(&Xs[r][kc * D_BK + ko]);
+                    const float4 a1 = *reinterpret_cast<const float4 *>(&Xs[32 + r][kc * D_BK + ko]);
+                    const float av0[4] = {a0.x, a0.y, a0.z, a0.w}, av1[4] = {a1.x, a1.y, a1.z, a1.w};
+                    if (has0) {
+                        const float4 b0 = *reinterpret_cast<const float4 *>(&Ws[buf][t0 * 32 + r][ko]);
+                        const float bv0[4] = {b0.x, b0.y, b0.z, b0.w};
+#pragma unroll
+                        for (int s = 0; s < 4; ++s) {
+                            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[s], bv0[s], acc[0][0], 0, 0, 0);
+                            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[s], bv0[s], acc[1][0], 0, 0, 0);
+                        }
+                    }
+                    if (has1) {
+                        const float4 b1 = *reinterpret_cast<const float4 *>(&Ws[buf][t1 * 32 + r][ko]);
+                        const float bv1[4] = {b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+                        for (int s = 0; s < 4; ++s) {
+                            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[s], bv1[s], acc[0][1], 0, 0, 0);
+                            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[s], bv1[s], acc[1][1], 0, 0, 0);
+                        }
+                    }
+                }
+                if (kc + 1 < nk) w_lstore(rw, Ws[buf ^ 1], H, tid);
+                __syncthreads();
+            }
+            // every wave has finished reading X (barrier above): overwrite it with relu(acc + b)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+                const bool has = ni == 0 ? has0 : has1;
+                if (!has) continue;
+                const int cc = (ni == 0 ? t0 : t1) * 32 + r;
+                const float bv = Bv[cc];
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int rr = mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+                        const float t = acc[mi][ni][e] + bv;
+                        Xs[rr][cc] = t > 0.f ? t : 0.f;
+                    }
+            }
+            __syncthreads();
+        }
+
+        // ---- 3. last layer: H -> 1, sigmoid ---------------------------------------------------
+        {
+            const float *__restrict__ wl = pick(prm.w, n_layers - 1);
+            const int row = tid >> 2, part = tid & 3;
+            float s = 0.f;
+            for (int c = part; c < h4; c += 4) {
+                const float4 x = *reinterpret_cast<const float4 *>(&Xs[row][4 * c]);
+                const float4 q = *reinterpret_cast<const float4 *>(wl + 4 * c);
+                s = fmaf(x.x, q.x, s);
+                s = fmaf(x.y, q.y, s);
+                s = fmaf(x.z, q.z, s);
+                s = fmaf(x.w, q.w, s);
+            }
+            s += eps_dpp_f<0xB1>(s);  // quad_perm [1,0,3,2]
+            s += eps_dpp_f<0x4E>(s);  // quad_perm [2,3,0,1]
+            const int64_t p = e0 + row;
+            if (part == 0 && p < n_pairs) {
+                float z = s + pick(prm.b, n_layers - 1)[0];
+                if (apply_sigmoid) z = 1.0f / (1.0f + expf(-z));
+                out[p] = z;
+            }
+        }
+        __syncthreads();  // X is rebuilt by the next tile's gather
+    }
+}
+
+extern "C" int eps_mlp_decode(const float *h, int64_t n_nodes, int32_t hdim, const int32_t *u, const int32_t *v,
+                              int64_t n_pairs, const float *const *w, const float *const *b, int32_t n_layers,
+                              int apply_sigmoid, float *out, void *stream)
+{
+    EPS_REQUIRE(n_pairs >= 0 && n_nodes >= 0, "eps_mlp_decode: negative size");
+    EPS_REQUIRE(hdim > 0 && hdim % 32 == 0 && hdim <= D_HMAX, "eps_mlp_decode: hdim=%d unsupported (need %%32==0, <=%d)",
+                hdim, D_HMAX);
+    EPS_REQUIRE(n_layers >= 1 && n_layers <= D_MAXL, "eps_mlp_decode: n_layers=%d unsupported (1..%d)", n_layers, D_MAXL);
+    if (n_pairs == 0) return EPS_OK;
+    EPS_REQUIRE(h && u && v && w && b && out, "eps_mlp_decode: null pointer");
+    EPS_REQUIRE((uintptr_t)h % 16 == 0, "eps_mlp_decode: h must be 16-byte aligned");
+    DecodeParams prm;
+    for (int l = 0; l < D_MAXL; ++l) {
+        prm.w[l] = l < n_layers ? w[l] : nullptr;
+        prm.b[l] = l < n_layers ? b[l] : nullptr;
+        if (l < n_layers) {
+            EPS_REQUIRE(w[l] && b[l], "eps_mlp_decode: null weight/bias pointer at layer %d", l);
+            EPS_REQUIRE((uintptr_t)w[l] % 16 == 0, "eps_mlp_decode: weight %d must be 16-byte aligned", l);
+        }
+    }
+    const int64_t n_tiles = (n_pairs + D_BM - 1) / D_BM;
+    int64_t blocks = eps_num_cus();
+    if (blocks > n_tiles) blocks = n_tiles;
+    hipLaunchKernelGGL(mlp_decode_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, h, hdim, u, v,
+                       n_pairs, prm, n_layers, apply_sigmoid, out);
+    EPS_CHECK_LAUNCH("eps_mlp_decode");
+    return EPS_OK;
+}

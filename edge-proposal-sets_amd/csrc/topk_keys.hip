@@ -1,0 +1,73 @@
+// (score, id) <-> uint64 sort keys realising the declared tie rule, gfx950.
+//
+// Replaces `all_scores[:,2].sort(descending=True)` + row gather (filter.py:160-161) for the
+// rows rank.py ever consumes (rank.py:294).  The reference's torch.sort is unstable on ties
+// (SURVEY 8 trap 9), so the order is DECLARED: score descending, then candidate id ascending
+// (== torch.sort(descending=True, stable=True) over the reference's candidate order).
+// key (int64, SIGNED order) = (ordered_bits(score) ^ 0x80000000) << 32 | (0xFFFFFFFF - id); a plain descending sort of the keys
+// (any algorithm, any sharding) then yields exactly that order, which is what makes the
+// multi-GPU top-K merge shard-count invariant.
+#include "eps_common.h"
+
+__device__ __forceinline__ uint32_t ordered_bits(float f)
+{
+    f = f + 0.0f;  // -0.0 -> +0.0 so that the two zeros tie, as they do in torch.sort
+    const uint32_t b = __builtin_bit_cast(uint32_t, f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float unordered_bits(uint32_t o)
+{
+    const uint32_t b = (o & 0x80000000u) ? (o & 0x7fffffffu) : ~o;
+    return __builtin_bit_cast(float, b);
+}
+
+__global__ void pack_keys_kernel(const float *__restrict__ score, const int64_t *__restrict__ id, int64_t id_base,
+                                 int64_t n, int64_t *__restrict__ keys)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const uint64_t gid = (uint64_t)(id ? id[i] : id_base + i);
+        keys[i] = (int64_t)(((uint64_t)(ordered_bits(score[i]) ^ 0x80000000u) << 32) | (uint64_t)(0xFFFFFFFFu - (uint32_t)gid));
+    }
+}
+
+__global__ void unpack_keys_kernel(const int64_t *__restrict__ keys, int64_t n, float *__restrict__ score,
+                                   int64_t *__restrict__ id)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const uint64_t k = (uint64_t)keys[i];
+        if (score) score[i] = unordered_bits((uint32_t)(k >> 32) ^ 0x80000000u);
+        if (id) id[i] = (int64_t)(0xFFFFFFFFu - (uint32_t)(k & 0xFFFFFFFFu));
+    }
+}
+
+static unsigned ew_blocks(int64_t n)
+{
+    int64_t b = (n + 255) / 256;
+    const int64_t cap = (int64_t)eps_num_cus() * 8;
+    return (unsigned)(b > cap ? cap : b);
+}
+
+extern "C" int eps_pack_keys(const float *score, const int64_t *id_or_null, int64_t id_base, int64_t n,
+                             int64_t *keys, void *stream)
+{
+    EPS_REQUIRE(n >= 0 && id_base >= 0, "eps_pack_keys: negative size");
+    if (n == 0) return EPS_OK;
+    EPS_REQUIRE(score && keys, "eps_pack_keys: null pointer");
+    EPS_REQUIRE(id_or_null || id_base + n <= (1ll << 32), "eps_pack_keys: ids must stay below 2^32");
+    hipLaunchKernelGGL(pack_keys_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, score, id_or_null,
+                       id_base, n, keys);
+    EPS_CHECK_LAUNCH("eps_pack_keys");
+    return EPS_OK;
+}
+
+extern "C" int eps_unpack_keys(const int64_t *keys, int64_t n, float *score, int64_t *id, void *stream)
+{
+    EPS_REQUIRE(n >= 0, "eps_unpack_keys: negative size");
+    if (n == 0) return EPS_OK;
+    EPS_REQUIRE(keys && (score || id), "eps_unpack_keys: null pointer");
+    hipLaunchKernelGGL(unpack_keys_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, keys, n, score, id);
+    EPS_CHECK_LAUNCH("eps_unpack_keys");
+    return EPS_OK;
+}

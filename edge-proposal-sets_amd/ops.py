@@ -1,0 +1,188 @@
+"""Thin torch-tensor wrappers over the C ABI (include/eps_abi.h).  Every function requires its
+tensors on a HIP device and launches on torch's current stream; nothing here computes on the
+CPU."""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+
+W_AA, W_RA = 0, 1
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _stream(dev: torch.device):
+    return ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+
+def _need_gpu(*tensors: Optional[torch.Tensor]) -> torch.device:
+    dev = None
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise _lib.EpsError("edge-proposal-sets_amd ops run on the MI355X only: got a CPU tensor "
+                                "(there is no CPU fallback; move inputs to 'cuda')")
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise _lib.EpsError(f"tensors on different devices: {dev} vs {t.device}")
+        if not t.is_contiguous():
+            raise _lib.EpsError("non-contiguous tensor passed to the C ABI")
+    if dev is None:
+        raise _lib.EpsError("no tensor given")
+    return dev
+
+
+def _chk(t: Optional[torch.Tensor], dtype: torch.dtype, name: str):
+    if t is not None and t.dtype != dtype:
+        raise _lib.EpsError(f"{name}: expected {dtype}, got {t.dtype}")
+
+
+def device_info() -> Tuple[int, str]:
+    lib = _lib.load()
+    n = ctypes.c_int(0)
+    buf = ctypes.create_string_buffer(256)
+    _lib.check(lib.eps_device_info(ctypes.byref(n), buf, 256), "eps_device_info")
+    return n.value, buf.value.decode()
+
+
+def col_sums(rowptr, col, val, n_cols: int) -> torch.Tensor:
+    dev = _need_gpu(rowptr, col, val)
+    _chk(rowptr, torch.int64, "rowptr"); _chk(col, torch.int32, "col"); _chk(val, torch.float32, "val")
+    out = torch.empty(n_cols, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.load().eps_col_sums(_ptr(rowptr), _ptr(col), _ptr(val), rowptr.numel() - 1, n_cols,
+                                            _ptr(out), _stream(dev)), "eps_col_sums")
+    return out
+
+
+def node_weights(colsum: torch.Tensor, mode: int, f64: bool = False) -> torch.Tensor:
+    dev = _need_gpu(colsum)
+    _chk(colsum, torch.float32, "colsum")
+    out = torch.empty(colsum.numel(), dtype=torch.float64 if f64 else torch.float32, device=dev)
+    fn = _lib.load().eps_node_weights_f64 if f64 else _lib.load().eps_node_weights
+    with torch.cuda.device(dev):
+        _lib.check(fn(_ptr(colsum), colsum.numel(), mode, _ptr(out), _stream(dev)), "eps_node_weights")
+    return out
+
+
+def pair_scores(rowptr, col, val, node_w, n_nodes: int, u, v, want_count=True, want_cn=True, want_wsum=None):
+    """-> (count int32[E] | None, cn float32[E] | None, wsum float32/float64[E] | None).
+    node_w float64 selects the float64-accumulate kernel (cn is then not produced)."""
+    dev = _need_gpu(rowptr, col, val, node_w, u, v)
+    _chk(rowptr, torch.int64, "rowptr"); _chk(col, torch.int32, "col"); _chk(val, torch.float32, "val")
+    _chk(u, torch.int32, "u"); _chk(v, torch.int32, "v")
+    if u.numel() != v.numel():
+        raise _lib.EpsError("u and v differ in length")
+    if want_wsum is None:
+        want_wsum = node_w is not None
+    n = u.numel()
+    lib = _lib.load()
+    count = torch.empty(n, dtype=torch.int32, device=dev) if want_count else None
+    with torch.cuda.device(dev):
+        if node_w is not None and node_w.dtype == torch.float64:
+            ws = torch.empty(n, dtype=torch.float64, device=dev) if want_wsum else None
+            _lib.check(lib.eps_pair_scores_f64(_ptr(rowptr), _ptr(col), _ptr(val), _ptr(node_w), n_nodes, _ptr(u),
+                                               _ptr(v), n, _ptr(count), _ptr(ws), _stream(dev)), "eps_pair_scores_f64")
+            return count, None, ws
+        _chk(node_w, torch.float32, "node_w")
+        cn = torch.empty(n, dtype=torch.float32, device=dev) if want_cn else None
+        ws = torch.empty(n, dtype=torch.float32, device=dev) if want_wsum else None
+        _lib.check(lib.eps_pair_scores(_ptr(rowptr), _ptr(col), _ptr(val), _ptr(node_w), n_nodes, _ptr(u), _ptr(v),
+                                       n, _ptr(count), _ptr(cn), _ptr(ws), _stream(dev)), "eps_pair_scores")
+    return count, cn, ws
+
+
+def spmm_csr(rowptr, col, val, x: torch.Tensor, bias=None, relu=False, mean=False, out=None) -> torch.Tensor:
+    dev = _need_gpu(rowptr, col, val, x, bias, out)
+    _chk(rowptr, torch.int64, "rowptr"); _chk(col, torch.int32, "col"); _chk(val, torch.float32, "val")
+    _chk(x, torch.float32, "x"); _chk(bias, torch.float32, "bias")
+    n_rows = rowptr.numel() - 1
+    f = x.shape[1]
+    if out is None:
+        out = torch.empty((n_rows, f), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.load().eps_spmm_csr(_ptr(rowptr), _ptr(col), _ptr(val), n_rows, _ptr(x), x.stride(0), f,
+                                            _ptr(bias), int(relu), int(mean), _ptr(out), out.stride(0),
+                                            _stream(dev)), "eps_spmm_csr")
+    return out
+
+
+def gcn_norm(rowptr, col, val) -> torch.Tensor:
+    dev = _need_gpu(rowptr, col, val)
+    n_rows = rowptr.numel() - 1
+    dis = torch.empty(n_rows, dtype=torch.float32, device=dev)
+    out = torch.empty(col.numel(), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.load().eps_gcn_norm(_ptr(rowptr), _ptr(col), _ptr(val), n_rows, _ptr(dis), _ptr(out),
+                                            _stream(dev)), "eps_gcn_norm")
+    return out
+
+
+def gemm(a: torch.Tensor, b_nk: torch.Tensor, bias=None, relu=False, out=None, accumulate=False) -> torch.Tensor:
+    """C = act(a @ b_nk.T + bias (+ C)); b_nk is [N,K] (torch.nn.Linear layout)."""
+    dev = _need_gpu(a, b_nk, bias, out)
+    _chk(a, torch.float32, "a"); _chk(b_nk, torch.float32, "b"); _chk(bias, torch.float32, "bias")
+    m, k = a.shape
+    n = b_nk.shape[0]
+    if b_nk.shape[1] != k:
+        raise _lib.EpsError(f"gemm: inner dims differ ({k} vs {b_nk.shape[1]})")
+    if out is None:
+        if accumulate:
+            raise _lib.EpsError("gemm: accumulate needs out")
+        out = torch.empty((m, n), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.load().eps_gemm_f32(_ptr(a), a.stride(0), _ptr(b_nk), b_nk.stride(0), _ptr(bias), int(relu),
+                                            int(accumulate), _ptr(out), out.stride(0), m, n, k, _stream(dev)),
+                   "eps_gemm_f32")
+    return out
+
+
+def mlp_decode(h: torch.Tensor, u, v, weights: Sequence[torch.Tensor], biases: Sequence[torch.Tensor],
+               apply_sigmoid=True) -> torch.Tensor:
+    dev = _need_gpu(h, u, v, *weights, *biases)
+    _chk(h, torch.float32, "h"); _chk(u, torch.int32, "u"); _chk(v, torch.int32, "v")
+    L = len(weights)
+    hd = h.shape[1]
+    for i, (w, b) in enumerate(zip(weights, biases)):
+        _chk(w, torch.float32, f"w{i}"); _chk(b, torch.float32, f"b{i}")
+        exp = (1 if i == L - 1 else hd, hd)
+        if tuple(w.shape) != exp:
+            raise _lib.EpsError(f"mlp_decode: layer {i} weight {tuple(w.shape)} != {exp} "
+                                f"(hidden width must equal the embedding width, last layer out=1)")
+    n = u.numel()
+    out = torch.empty(n, dtype=torch.float32, device=dev)
+    wp = (ctypes.c_void_p * L)(*[w.data_ptr() for w in weights])
+    bp = (ctypes.c_void_p * L)(*[b.data_ptr() for b in biases])
+    with torch.cuda.device(dev):
+        _lib.check(_lib.load().eps_mlp_decode(_ptr(h), h.shape[0], hd, _ptr(u), _ptr(v), n, wp, bp, L,
+                                              int(apply_sigmoid), _ptr(out), _stream(dev)), "eps_mlp_decode")
+    return out
+
+
+def pack_keys(score: torch.Tensor, ids: Optional[torch.Tensor] = None, id_base: int = 0) -> torch.Tensor:
+    dev = _need_gpu(score, ids)
+    _chk(score, torch.float32, "score"); _chk(ids, torch.int64, "ids")
+    keys = torch.empty(score.numel(), dtype=torch.int64, device=dev)  # bit pattern of the uint64 key
+    with torch.cuda.device(dev):
+        _lib.check(_lib.load().eps_pack_keys(_ptr(score), _ptr(ids), id_base, score.numel(), _ptr(keys),
+                                             _stream(dev)), "eps_pack_keys")
+    return keys
+
+
+def unpack_keys(keys: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    dev = _need_gpu(keys)
+    n = keys.numel()
+    score = torch.empty(n, dtype=torch.float32, device=dev)
+    ids = torch.empty(n, dtype=torch.int64, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.load().eps_unpack_keys(_ptr(keys), n, _ptr(score), _ptr(ids), _stream(dev)),
+                   "eps_unpack_keys")
+    return score, ids

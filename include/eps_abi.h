@@ -1,0 +1,132 @@
+/*
+ * eps_abi.h -- C ABI of libeps_hip.so, the MI355X (gfx950) edge-scoring engine.
+ *
+ * This is the drop-in boundary for the Filter-and-Rank hot path of CUAI/Edge-Proposal-Sets.
+ * The reference has no FFI of its own for this path: the work is done by third-party
+ * kernels (SciPy sparsetools, torch_sparse, cuBLAS) behind plain Python call sites.  Each
+ * entry point below names the reference call site(s) (file:line under /root/reference)
+ * whose arithmetic it replaces.  The Python host (edge-proposal-sets_amd/) binds these
+ * with ctypes and keeps the reference's own signatures on top.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer borrowed from the caller (the caller keeps the
+ *     buffer alive until the stream has been synchronised); nothing is allocated inside;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the legacy default stream); all
+ *     calls are asynchronous on it and re-entrant; no global mutable state;
+ *   - return value: EPS_OK (0) or a negative EPS_E* code; the message for the calling
+ *     thread's last failure is returned by eps_last_error();
+ *   - CSR graphs: rowptr int64[N+1], col int32[nnz] strictly ascending inside a row
+ *     (coalesced), val float32[nnz] or NULL (NULL == every stored value is 1.0f).
+ */
+#ifndef EPS_ABI_H
+#define EPS_ABI_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EPS_ABI_VERSION 1
+
+#define EPS_OK 0
+#define EPS_EINVAL (-1)   /* bad argument (null pointer, negative size, unsupported shape) */
+#define EPS_ELAUNCH (-2)  /* HIP launch / runtime error */
+#define EPS_ENODEV (-3)   /* no usable gfx950 device */
+
+/* node-weight modes for eps_node_weights */
+#define EPS_W_AA 0 /* 1/log(colsum), inf -> 0   (adamic_utils.py:15-16)     */
+#define EPS_W_RA 1 /* 1/colsum,      inf -> 0   (train_and_eval.py:203-204) */
+
+int eps_version(void);
+const char *eps_last_error(void);
+
+/* Number of compute units / name of the current device (host query; for launch sizing
+ * reports in bench.py).  name may be NULL. */
+int eps_device_info(int *n_cu, char *name, int name_len);
+
+/* ---- K2: per-node weight table ------------------------------------------------------
+ * Replaces `A.sum(0)`, `1/np.log(.)`, inf->0 (adamic_utils.py:15-16) and `1/A.sum(axis=0)`,
+ * inf->0 (train_and_eval.py:203-204).
+ * eps_col_sums: colsum[c] = sum_r A[r,c]  (float32 atomics; exact for integer-valued A).
+ *               colsum must be zero-filled by the caller is NOT required: it is cleared here.
+ * eps_node_weights: w[i] = mode==AA ? 1/logf(colsum[i]) : 1/colsum[i]; +-inf -> 0.
+ * The _f64 flavour serves filter.py:130-141, where A is int64 and the math is float64. */
+int eps_col_sums(const int64_t *rowptr, const int32_t *col, const float *val, int64_t n_rows,
+                 int64_t n_cols, float *colsum, void *stream);
+int eps_node_weights(const float *colsum, int64_t n, int mode, float *w, void *stream);
+int eps_node_weights_f64(const float *colsum, int64_t n, int mode, double *w, void *stream);
+
+/* ---- K1/K3: pair scores by CSR neighbour-list intersection ------------------------------
+ * Replaces `np.sum(A[src].multiply(A_[dst]), 1)` (adamic_utils.py:22, train_and_eval.py:212)
+ * and `adj[e0] (.) adj[e1]` + sparse row-sum (models.py:536-542).  For each pair p:
+ *   count[p] = |N(u) ^ N(v)|                                   (int32, exact)
+ *   cn[p]    = sum_w A[u,w] * A[v,w]                           (float32; == count if val NULL)
+ *   wsum[p]  = sum_w A[u,w] * (A[v,w] * node_w[w])             (float32; AA / RA)
+ * Any of the three outputs may be NULL (skipped); wsum needs node_w != NULL.
+ * u, v: int32[n_pairs] node ids in [0, n_nodes).  One wavefront scores one pair at a time. */
+int eps_pair_scores(const int64_t *rowptr, const int32_t *col, const float *val,
+                    const float *node_w, int64_t n_nodes, const int32_t *u, const int32_t *v,
+                    int64_t n_pairs, int32_t *count, float *cn, float *wsum, void *stream);
+
+/* float64 accumulate with float64 node weights; wsum is float64 (filter.py:141 RA path). */
+int eps_pair_scores_f64(const int64_t *rowptr, const int32_t *col, const float *val,
+                        const double *node_w, int64_t n_nodes, const int32_t *u,
+                        const int32_t *v, int64_t n_pairs, int32_t *count, double *wsum,
+                        void *stream);
+
+/* ---- K4/K5: CSR x dense SpMM with fused epilogue -----------------------------------------
+ * Replaces torch_sparse spmm_sum / spmm_mean inside GCNConv / SAGEConv (models.py:183-186,
+ * :436-439) plus the bias add and the ReLU of the layer loop.
+ *   mean == 0:  Y[i,:] = sum_k val[k] * X[col[k],:]
+ *   mean != 0:  Y[i,:] = (sum_k X[col[k],:]) / max(rowlen(i), 1)      (values ignored)
+ *   then  + bias[:] (if non-NULL), then ReLU (if relu != 0).
+ * X is row-major [n_cols, ldx] (first f columns used), Y row-major [n_rows, ldy]. */
+int eps_spmm_csr(const int64_t *rowptr, const int32_t *col, const float *val, int64_t n_rows,
+                 const float *x, int64_t ldx, int32_t f, const float *bias, int relu, int mean,
+                 float *y, int64_t ldy, void *stream);
+
+/* gcn_norm (torch_geometric 1.7.0 GCNConv, third-party): given A^ (diagonal already set to 1)
+ * compute dis = rowsum^-1/2 (inf -> 0) and val_out[k] = (val[k]*dis[row])*dis[col[k]].
+ * dis is an n_rows scratch/output buffer. */
+int eps_gcn_norm(const int64_t *rowptr, const int32_t *col, const float *val, int64_t n_rows,
+                 float *dis, float *val_out, void *stream);
+
+/* ---- dense f32 GEMM on the f32-input MFMA (exact f32) -------------------------------------
+ * C[M,N] = act(A[M,K] * B[N,K]^T + bias[N] (+ C if accumulate)); B is row-major [N,K]
+ * (torch.nn.Linear layout; GCNConv.weight [in,out] is passed transposed by the host).
+ * Serves `x @ W` of GCNConv and lin_l / lin_r of SAGEConv (models.py:183, :436). */
+int eps_gemm_f32(const float *a, int64_t lda, const float *b, int64_t ldb, const float *bias,
+                 int relu, int accumulate, float *c, int64_t ldc, int64_t m, int32_t n, int32_t k,
+                 void *stream);
+
+/* ---- K6: fused LinkPredictor decode ------------------------------------------------------
+ * Replaces h[edges[0]], h[edges[1]] gathers (models.py:506) + LinkPredictor.forward
+ * (models.py:478-485): out[p] = sigmoid(W_L ... relu(W_1 (h[u_p] (.) h[v_p]) + b_1) ... + b_L).
+ * h: [n_nodes, hdim] row-major (ld = hdim).  w[l]: device pointers to row-major [out_l, in_l]
+ * matrices (torch.nn.Linear layout), b[l]: [out_l]; hidden width == hdim for every hidden
+ * layer, last layer out == 1.  w / b are HOST arrays of n_layers device pointers.
+ * apply_sigmoid == 0 returns the pre-sigmoid logit.  Supported: hdim % 32 == 0, hdim <= 256,
+ * 1 <= n_layers <= 8. */
+int eps_mlp_decode(const float *h, int64_t n_nodes, int32_t hdim, const int32_t *u,
+                   const int32_t *v, int64_t n_pairs, const float *const *w,
+                   const float *const *b, int32_t n_layers, int apply_sigmoid, float *out,
+                   void *stream);
+
+/* ---- top-K selection with the declared tie rule ------------------------------------------
+ * Replaces `all_scores[:,2].sort(descending=True)` (filter.py:160-161) for the K rows rank.py
+ * ever reads (rank.py:294).  Declared order: score descending, then `id` ascending (== a stable
+ * descending sort over the reference's candidate order; the reference's own torch.sort is
+ * unstable on ties).  (score, id) is packed into an int64 whose SIGNED order realises the rule:
+ *   key = (ordered_bits(score) ^ 0x80000000) << 32 | (0xFFFFFFFF - id),   id < 2^32,
+ * so a plain descending sort / top-K / k-way merge of keys -- on one GPU or across shards --
+ * gives the same result.  id = ids[i] if ids != NULL else id_base + i. */
+int eps_pack_keys(const float *score, const int64_t *ids_or_null, int64_t id_base, int64_t n,
+                  int64_t *keys, void *stream);
+int eps_unpack_keys(const int64_t *keys, int64_t n, float *score_or_null, int64_t *id_or_null,
+                    void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EPS_ABI_H */

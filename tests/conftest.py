@@ -1,0 +1,49 @@
+import glob
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def golden_pair_files():
+    return sorted(glob.glob(os.path.join(GOLDEN, "pairs_*.npz")))
+
+
+def rel_err(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    den = np.maximum(np.abs(a), np.abs(b))
+    den[den == 0] = 1.0
+    return float((np.abs(a - b) / den).max()) if a.size else 0.0
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from oracle import eps_oracle
+    eps_oracle.build()
+    return eps_oracle
+
+
+@pytest.fixture(scope="session")
+def eps():
+    import eps_amd
+    return eps_amd
+
+
+@pytest.fixture(scope="session")
+def dev():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda:0")

@@ -1,0 +1,138 @@
+"""GPU parity of the dense / SpMM kernels through the C ABI vs the oracle (float32, tolerances stated)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _close(a, b, rtol=1e-5, scale=None):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    scale = scale if scale is not None else max(1.0, float(np.abs(b).max()))
+    return float(np.abs(a - b).max()) <= rtol * scale
+
+
+@pytest.mark.parametrize("m,n,k", [(128, 128, 32), (300, 256, 384), (1000, 256, 58), (77, 40, 19), (4096, 256, 256),
+                                   (5, 1, 7)])
+def test_gemm_vs_float64(eps, dev, m, n, k):
+    """eps_gemm_f32 (f32-input MFMA == fmaf chain): error vs float64 bounded by k * eps * sum|a||b|."""
+    g = torch.Generator().manual_seed(m * 7 + n + k)
+    a = torch.randn(m, k, generator=g)
+    b = torch.randn(n, k, generator=g)
+    bias = torch.randn(n, generator=g)
+    ref = a.double() @ b.double().t() + bias.double()
+    out = eps.ops.gemm(a.to(dev), b.to(dev), bias=bias.to(dev))
+    bound = (a.abs().double() @ b.abs().double().t() + bias.abs().double()) * (k + 2) * 2.0 ** -24
+    assert bool(((out.cpu().double() - ref).abs() <= bound + 1e-30).all())
+    out_r = eps.ops.gemm(a.to(dev), b.to(dev), bias=bias.to(dev), relu=True)
+    assert torch.equal(out_r, out.clamp_min(0))
+    # accumulate: C += A B^T (SAGEConv lin_r added onto lin_l)
+    acc = eps.ops.gemm(a.to(dev), b.to(dev), out=out.clone(), accumulate=True)
+    assert _close(acc.cpu().numpy(), (2 * ref - bias.double()).numpy(), rtol=2e-5, scale=float(bound.max() * 2 ** 24 / (k + 2)))
+
+
+def test_gemm_strided_rows(eps, dev):
+    g = torch.Generator().manual_seed(5)
+    big = torch.randn(200, 100, generator=g).to(dev)
+    a = big[:, :58]  # lda = 100, K = 58 (ppa feature width): non-contiguous view with row stride
+    assert a.stride(0) == 100
+    b = torch.randn(64, 58, generator=g).to(dev)
+    lib_out = torch.empty(200, 64, device=dev)
+    import ctypes
+    from eps_amd import _lib
+    rc = _lib.load().eps_gemm_f32(ctypes.c_void_p(a.data_ptr()), 100, ctypes.c_void_p(b.data_ptr()), 58, None, 0, 0,
+                                  ctypes.c_void_p(lib_out.data_ptr()), 64, 200, 64, 58,
+                                  ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0
+    ref = a.double() @ b.double().t()
+    assert _close(lib_out.cpu().numpy(), ref.cpu().numpy(), rtol=1e-5, scale=float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("f", [256, 64, 37, 300])
+@pytest.mark.parametrize("mode", ["sum", "sum_unit", "mean"])
+def test_spmm_vs_oracle(eps, oracle, dev, f, mode):
+    import scipy.sparse as ssp
+    rng = np.random.default_rng(f)
+    n = 3000
+    A = ssp.random(n, n, density=0.01, random_state=rng, dtype=np.float32, format="csr")
+    A.data[:] = rng.integers(1, 4, A.nnz)
+    A[5, :] = 0; A.eliminate_zeros()          # an empty row
+    hub = np.zeros(n, np.float32); hub[rng.choice(n, 900, replace=False)] = 1
+    A = ssp.vstack([A[:7], ssp.csr_matrix(hub), A[8:]]).tocsr(); A.sort_indices()   # one long row (> 64 * 4)
+    x = rng.standard_normal((n, f)).astype(np.float32)
+    bias = rng.standard_normal(f).astype(np.float32)
+    val = None if mode != "sum" else A.data
+    ref = oracle.spmm_csr(A.indptr, A.indices, val, x, bias=bias, relu=True, mean=(mode == "mean"))
+    rp = torch.from_numpy(A.indptr.astype(np.int64)).to(dev)
+    ci = torch.from_numpy(A.indices.astype(np.int32)).to(dev)
+    vv = None if val is None else torch.from_numpy(val).to(dev)
+    out = eps.ops.spmm_csr(rp, ci, vv, torch.from_numpy(x).to(dev), bias=torch.from_numpy(bias).to(dev), relu=True,
+                           mean=(mode == "mean"))
+    # sequential ascending-neighbour float32 accumulation on both sides (fmaf vs mul+add differ by <= 1 ulp/term)
+    rowabs = oracle.spmm_csr(A.indptr, A.indices, val, np.abs(x), mean=(mode == "mean"))
+    assert float(np.abs(out.cpu().numpy() - ref).max()) <= 1e-5 * max(1.0, float(rowabs.max()))
+    assert out[5].abs().max().item() == pytest.approx(float(np.maximum(bias, 0).max()), rel=1e-6)
+
+
+def test_gcn_norm_vs_oracle(eps, oracle, dev):
+    d = np.load(os.path.join(GOLDEN, "pairs_collab_like.npz"))
+    rp, ci, va = oracle.with_self_loops(d["rowptr"], d["col"], d["val"], 1.0)
+    ref = oracle.gcn_norm_values(rp, ci, va)
+    n = len(rp) - 1
+    g = eps.CSRGraph(torch.from_numpy(d["rowptr"]), torch.from_numpy(d["col"]), torch.from_numpy(d["val"]), n, n).to(dev)
+    gn = g.gcn_normalized()
+    assert np.array_equal(gn.rowptr.cpu().numpy(), rp) and np.array_equal(gn.col.cpu().numpy(), ci)
+    assert rel_err(gn.val.cpu().numpy(), ref) <= 1e-6
+
+
+@pytest.mark.parametrize("tag", ["H256_L2", "H256_L3", "H64_L2"])
+def test_decode_golden(eps, dev, tag):
+    """eps_mlp_decode vs the imported reference's LinkPredictor output (probabilities AND logits:
+    sigmoid flattens relative error, so the logit is the sharper check)."""
+    d = np.load(os.path.join(GOLDEN, f"linkpred_{tag}.npz"))
+    L = sum(1 for k in d.files if k.startswith("w"))
+    ws = [torch.from_numpy(d[f"w{i}"]).to(dev) for i in range(L)]
+    bs = [torch.from_numpy(d[f"b{i}"]).to(dev) for i in range(L)]
+    h = torch.from_numpy(d["h"]).to(dev)
+    u = torch.from_numpy(d["edges"][0]).to(dev); v = torch.from_numpy(d["edges"][1]).to(dev)
+    prob = eps.ops.mlp_decode(h, u, v, ws, bs)
+    logit = eps.ops.mlp_decode(h, u, v, ws, bs, apply_sigmoid=False)
+    assert rel_err(prob.cpu().numpy(), d["prob"]) <= 1e-5
+    assert float(np.abs(logit.cpu().numpy() - d["logit"]).max()) <= 1e-5 * max(1.0, float(np.abs(d["logit"]).max()))
+
+
+@pytest.mark.parametrize("H,L,E", [(256, 3, 100_003), (256, 2, 64), (128, 3, 5000), (32, 1, 999), (96, 4, 1000)])
+def test_decode_vs_oracle_seeded(eps, oracle, dev, H, L, E):
+    g = torch.Generator().manual_seed(H + L)
+    n = 2000
+    h = torch.randn(n, H, generator=g)
+    ws = [torch.randn(H if i < L - 1 else 1, H, generator=g) / H ** 0.5 for i in range(L)]
+    bs = [torch.randn(H if i < L - 1 else 1, generator=g) * 0.1 for i in range(L)]
+    u = torch.randint(0, n, (E,), generator=g, dtype=torch.int32)
+    v = torch.randint(0, n, (E,), generator=g, dtype=torch.int32)
+    Eo = min(E, 3000)  # the float64 oracle is O(E * H^2): check a prefix and the ragged tail
+    sel = np.r_[0:Eo - 100, E - 100:E]
+    logit_o, prob_o = oracle.mlp_decode(h.numpy(), u.numpy()[sel], v.numpy()[sel], [w.numpy() for w in ws],
+                                        [b.numpy() for b in bs])
+    dw = [w.to(dev) for w in ws]; db = [b.to(dev) for b in bs]
+    prob = eps.ops.mlp_decode(h.to(dev), u.to(dev), v.to(dev), dw, db).cpu().numpy()
+    logit = eps.ops.mlp_decode(h.to(dev), u.to(dev), v.to(dev), dw, db, apply_sigmoid=False).cpu().numpy()
+    assert rel_err(prob[sel], prob_o) <= 1e-5
+    assert float(np.abs(logit[sel] - logit_o).max()) <= 2e-5 * max(1.0, float(np.abs(logit_o).max()))
+
+
+def test_pack_keys_order(eps, dev):
+    """Declared tie rule: score descending, then candidate id ascending."""
+    g = torch.Generator().manual_seed(0)
+    score = torch.randint(0, 50, (100000,), generator=g).float()
+    score[::7] = -score[::7]; score[3] = 0.0; score[4] = -0.0
+    keys = eps.ops.pack_keys(score.to(dev), id_base=1000)
+    order = torch.argsort(keys, descending=True)
+    ref = torch.sort(score, descending=True, stable=True).indices
+    assert torch.equal(order.cpu(), ref)
+    s2, ids = eps.ops.unpack_keys(keys)
+    assert torch.equal(s2.cpu(), score + 0.0) and torch.equal(ids.cpu(), torch.arange(100000) + 1000)

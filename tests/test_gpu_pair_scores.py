@@ -1,0 +1,127 @@
+"""GPU parity: eps_pair_scores (through the C ABI) vs the golden vectors of the imported reference
+and vs the oracle on seeded inputs.  CN/count bit-exact; AA/RA within 1e-5 relative."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden_pair_files, rel_err
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5  # north_star: AA / RA float scores within 1e-5 relative
+
+
+def _graph(eps, d, dev, with_val=True):
+    val = torch.from_numpy(d["val"]) if with_val and not bool((d["val"] == 1).all()) else None
+    n = len(d["rowptr"]) - 1
+    return eps.CSRGraph(torch.from_numpy(d["rowptr"]), torch.from_numpy(d["col"]), val, n, n).to(dev)
+
+
+@pytest.mark.parametrize("path", golden_pair_files(), ids=lambda p: os.path.basename(p)[6:-4])
+def test_golden_facades(eps, dev, path):
+    """AA / resource_allocation / common_neighbors with the reference's signatures."""
+    d = np.load(path)
+    g = _graph(eps, d, dev)
+    pairs = torch.from_numpy(d["pairs"].astype(np.int64))
+    aa, ei = eps.AA(eps.get_A(g, g.n_rows), pairs)
+    assert ei is pairs and aa.dtype == torch.float32 and aa.device.type == "cpu"
+    assert rel_err(aa.numpy(), d["aa"]) <= TOL
+    ra = eps.resource_allocation(g, pairs.t(), batch_size=1024)
+    assert rel_err(ra.numpy(), d["ra_f32"]) <= TOL
+    cn = eps.common_neighbors(g, pairs.to(dev))
+    assert np.array_equal(cn.cpu().numpy(), d["cn"]), "CN must be bit-exact"
+
+
+@pytest.mark.parametrize("path", golden_pair_files(), ids=lambda p: os.path.basename(p)[6:-4])
+def test_golden_int64_adjacency_ra(eps, dev, path):
+    """filter.py:130-141: SciPy int64 adjacency -> float64 math -> FloatTensor."""
+    import scipy.sparse as ssp
+    d = np.load(path)
+    n = len(d["rowptr"]) - 1
+    Ai = ssp.csr_matrix((np.ones(len(d["col"]), dtype=np.int64), d["col"], d["rowptr"]), shape=(n, n))
+    ra = eps.resource_allocation(Ai, torch.from_numpy(d["pairs"].astype(np.int64)).t(), batch_size=8192)
+    assert rel_err(ra.numpy(), d["ra_i64"]) <= TOL
+
+
+def _random_graph(rng, n, avg_deg, weighted=False, hub=None):
+    m = int(n * avg_deg / 2)
+    # skewed endpoints: square of uniform -> low ids are hubs
+    r = (rng.random(m) ** 2 * n).astype(np.int64)
+    c = rng.integers(0, n, m)
+    if hub:
+        r = np.concatenate([r, np.zeros(hub, dtype=np.int64)])
+        c = np.concatenate([c, rng.choice(n, hub, replace=False)])
+    import scipy.sparse as ssp
+    w = rng.integers(1, 4, len(r)).astype(np.float32) if weighted else np.ones(len(r), np.float32)
+    keep = r != c
+    A = ssp.coo_matrix((w[keep], (r[keep], c[keep])), shape=(n, n)).tocsr()
+    A = (A + A.T).tocsr()
+    A.sum_duplicates(); A.sort_indices()
+    if not weighted:
+        A.data[:] = 1
+    return A.astype(np.float32)
+
+
+@pytest.mark.parametrize("n,deg,weighted,hub", [(3000, 40, False, None), (3000, 40, True, None),
+                                                (20000, 12, False, 15000),   # hub row >> LDS pass, in-place path
+                                                (6000, 700, False, None)])   # rows > 1024: multi-pass staging
+def test_vs_oracle_seeded(eps, oracle, dev, n, deg, weighted, hub):
+    rng = np.random.default_rng(n + deg)
+    A = _random_graph(rng, n, deg, weighted, hub)
+    g = eps.CSRGraph.from_scipy(A, device=dev)
+    E = 70001  # ragged: not a multiple of 64
+    pairs = rng.integers(0, n, (2, E)).astype(np.int32)
+    pairs[:, :500] = np.stack([np.zeros(500, np.int32), rng.integers(0, n, 500)])  # hub rows
+    pairs[:, 500:600] = pairs[0, 500:600]                                            # self pairs
+    rp, col = A.indptr.astype(np.int64), A.indices.astype(np.int32)
+    val = A.data if weighted else None
+    cs = oracle.col_sums(rp, col, val, n)
+    w = oracle.node_weights(cs, oracle.W_AA)
+    cnt_o, cn_o, ws_o = oracle.pair_scores(rp, col, val, w, pairs[0], pairs[1])
+    u, v = torch.from_numpy(pairs[0]).to(dev), torch.from_numpy(pairs[1]).to(dev)
+    from eps_amd.heuristics import node_weight_table
+    wt = node_weight_table(g, eps.ops.W_AA)
+    assert rel_err(wt.cpu().numpy(), w) <= 1e-6
+    cnt, cn, ws = eps.ops.pair_scores(g.rowptr, g.col, g.val, wt, n, u, v)
+    assert np.array_equal(cnt.cpu().numpy(), cnt_o)
+    assert np.array_equal(cn.cpu().numpy(), cn_o)
+    assert rel_err(ws.cpu().numpy(), ws_o) <= TOL
+    assert cnt_o.max() > 0
+
+
+def test_empty_and_tiny(eps, dev):
+    g = eps.add_edges("ddi", torch.tensor([[0, 1], [1, 2]]), torch.ones(2), torch.zeros(2, 0, dtype=torch.long), 5).to(dev)
+    aa, _ = eps.AA(g, torch.zeros(2, 0, dtype=torch.long))
+    assert aa.shape == (0,)
+    cn = eps.common_neighbors(g, torch.tensor([[0, 3, 4, 0], [2, 4, 4, 0]]))
+    assert cn.cpu().tolist() == [1.0, 0.0, 0.0, 1.0]      # isolated nodes, self pair
+    with pytest.raises(eps.EpsError):
+        eps.ops.pair_scores(g.rowptr, g.col, None, None, 5, torch.zeros(3, dtype=torch.int32, device=dev),
+                            torch.zeros(2, dtype=torch.int32, device=dev))
+
+
+def test_full_size_properties(eps, dev):
+    """Size-independent checks at a BASELINE-like scale (no oracle run): symmetry CN(u,v)==CN(v,u),
+    CN(u,u)==deg(u), AA symmetric within tolerance, CN <= min degree, linearity in the value scale."""
+    from eps_amd import synth
+    g = synth.rmat_graph(scale=17, edge_factor=16, seed=3, device=dev)
+    n = g.n_rows
+    gen = torch.Generator(device="cpu").manual_seed(1)
+    E = 2_000_000
+    u = torch.randint(0, n, (E,), generator=gen, dtype=torch.int32).to(dev)
+    v = torch.randint(0, n, (E,), generator=gen, dtype=torch.int32).to(dev)
+    from eps_amd.heuristics import node_weight_table
+    w = node_weight_table(g, eps.ops.W_AA)
+    c1, _, a1 = eps.ops.pair_scores(g.rowptr, g.col, None, w, n, u, v, want_cn=False)
+    c2, _, a2 = eps.ops.pair_scores(g.rowptr, g.col, None, w, n, v, u, want_cn=False)
+    assert torch.equal(c1, c2)
+    assert rel_err(a1.cpu().numpy(), a2.cpu().numpy()) <= TOL
+    deg = g.degree().to(torch.int32)
+    assert bool((c1 <= torch.minimum(deg[u.long()], deg[v.long()])).all())
+    cs, _, _ = eps.ops.pair_scores(g.rowptr, g.col, None, None, n, u, u, want_cn=False)
+    assert torch.equal(cs, deg[u.long()])
+    # linearity: scaling every stored value by 2 scales CN by 4 (exact in float32: powers of two)
+    g2 = g.fill_value(2.0)
+    _, cn2, _ = eps.ops.pair_scores(g2.rowptr, g2.col, g2.val, None, n, u[:200000], v[:200000])
+    assert torch.equal(cn2, 4.0 * c1[:200000].to(torch.float32))

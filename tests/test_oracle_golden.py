@@ -1,0 +1,132 @@
+"""CPU: pin the oracle (C restatement + SciPy mirrors) to the golden vectors produced by the
+imported reference (oracle/gen_golden.py).  CN exact; AA/RA <= 1e-6 relative (the GPU gate is 1e-5)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import scipy.sparse as ssp
+
+from conftest import GOLDEN, golden_pair_files, rel_err
+
+
+@pytest.mark.parametrize("path", golden_pair_files(), ids=lambda p: os.path.basename(p)[6:-4])
+def test_pair_scores_match_reference(oracle, path):
+    d = np.load(path)
+    rp, col, val, pairs = d["rowptr"], d["col"], d["val"], d["pairs"]
+    n = len(rp) - 1
+    cs = oracle.col_sums(rp, col, val, n)
+    w_aa = oracle.node_weights(cs, oracle.W_AA)
+    w_ra = oracle.node_weights(cs, oracle.W_RA)
+    cnt, cn, aa = oracle.pair_scores(rp, col, val, w_aa, pairs[0], pairs[1])
+    _, _, ra = oracle.pair_scores(rp, col, val, w_ra, pairs[0], pairs[1])
+    assert np.array_equal(cn, d["cn"]), "CN must be bit-exact"
+    unit = bool((val == 1).all())
+    if unit:
+        assert np.array_equal(cnt.astype(np.float32), d["cn"])
+    assert rel_err(aa, d["aa"]) <= 1e-6
+    assert rel_err(ra, d["ra_f32"]) <= 1e-6
+    # filter.py:130-141 flavour: integer adjacency -> float64 math -> FloatTensor
+    cs64 = oracle.col_sums(rp, col, None, n).astype(np.float64)
+    w64 = oracle.node_weights(cs64, oracle.W_RA)
+    _, ra64 = oracle.pair_scores_f64(rp, col, None, w64, pairs[0], pairs[1])
+    assert rel_err(ra64.astype(np.float32), d["ra_i64"]) <= 1e-6
+
+
+@pytest.mark.parametrize("path", golden_pair_files(), ids=lambda p: os.path.basename(p)[6:-4])
+def test_scipy_mirror_is_bit_exact(oracle, path):
+    """The SciPy mirror (what bench.py times as the reference CPU path) reproduces the imported
+    reference bit for bit."""
+    d = np.load(path)
+    n = len(d["rowptr"]) - 1
+    A = ssp.csr_matrix((d["val"], d["col"], d["rowptr"]), shape=(n, n))
+    pairs = d["pairs"].astype(np.int64)
+    with np.errstate(divide="ignore"):
+        assert np.array_equal(oracle.scipy_AA(A, pairs), d["aa"])
+        assert np.array_equal(oracle.scipy_RA(A, pairs.T, batch_size=1024), d["ra_f32"])
+    assert np.array_equal(oracle.scipy_CN(A, pairs), d["cn"])
+
+
+@pytest.mark.parametrize("tag", ["H256_L2", "H256_L3", "H8_L3", "H64_L2"])
+def test_decode_matches_reference(oracle, tag):
+    d = np.load(os.path.join(GOLDEN, f"linkpred_{tag}.npz"))
+    L = sum(1 for k in d.files if k.startswith("w"))
+    ws = [d[f"w{i}"] for i in range(L)]
+    bs = [d[f"b{i}"] for i in range(L)]
+    logit, prob = oracle.mlp_decode(d["h"], d["edges"][0], d["edges"][1], ws, bs)
+    assert rel_err(prob, d["prob"]) <= 1e-5
+    assert np.abs(logit - d["logit"]).max() <= 1e-5 * max(1.0, np.abs(d["logit"]).max())
+
+
+@pytest.mark.parametrize("kind,L", [("gcn", 2), ("gcn", 3), ("sage", 2), ("sage", 3)])
+def test_gnn_stack_structure(oracle, kind, L):
+    """Layer-loop structure (ReLU placement, no activation after the last layer, emb-first concat,
+    decode) as executed by the reference's own GCN/SAGE/LinkGNN.forward over the oracle's conv."""
+    d = np.load(os.path.join(GOLDEN, f"gnn_stack_{kind}_L{L}.npz"))
+    sd = {k[4:]: d[k] for k in d.files if k.startswith("sd::")}
+    A = d["A"]
+    x = np.concatenate([sd["emb.weight"], d["x"]], 1)       # models.py:503-504: embedding first
+    if kind == "gcn":
+        h = oracle.gcn_dense_forward(A, x, [sd[f"gnn.convs.{i}.weight"] for i in range(L)],
+                                     [sd[f"gnn.convs.{i}.bias"] for i in range(L)])
+    else:
+        h = oracle.sage_dense_forward(A, x, [sd[f"gnn.convs.{i}.lin_l.weight"] for i in range(L)],
+                                      [sd[f"gnn.convs.{i}.lin_l.bias"] for i in range(L)],
+                                      [sd[f"gnn.convs.{i}.lin_r.weight"] for i in range(L)])
+    assert np.abs(h - d["h"]).max() <= 1e-4 * max(1.0, np.abs(d["h"]).max())
+    # CSR float32 restatement agrees with the dense float64 formula
+    Acsr = ssp.csr_matrix(A)
+    Acsr.sort_indices()
+    if kind == "gcn":
+        h32 = oracle.gcn_forward_csr(Acsr.indptr, Acsr.indices, Acsr.data, x,
+                                     [sd[f"gnn.convs.{i}.weight"] for i in range(L)],
+                                     [sd[f"gnn.convs.{i}.bias"] for i in range(L)])
+    else:
+        h32 = oracle.sage_forward_csr(Acsr.indptr, Acsr.indices, x,
+                                      [sd[f"gnn.convs.{i}.lin_l.weight"] for i in range(L)],
+                                      [sd[f"gnn.convs.{i}.lin_l.bias"] for i in range(L)],
+                                      [sd[f"gnn.convs.{i}.lin_r.weight"] for i in range(L)])
+    assert np.abs(h32 - h).max() <= 1e-4 * max(1.0, np.abs(h).max())
+    ws = [sd[f"linkpred.lins.{i}.weight"] for i in range(L)]
+    bs = [sd[f"linkpred.lins.{i}.bias"] for i in range(L)]
+    _, prob = oracle.mlp_decode(d["h"], d["edges"][0], d["edges"][1], ws, bs)
+    assert rel_err(prob, d["prob"]) <= 1e-5
+
+
+def test_hits_at_k(oracle):
+    rng = np.random.default_rng(0)
+    pos = rng.random(1000).astype(np.float32)
+    neg = rng.random(500).astype(np.float32)
+    for k in (1, 10, 100, 500):
+        kth = np.sort(neg)[::-1][k - 1]
+        assert oracle.hits_at_k(pos, neg, k) == pytest.approx(float((pos > kth).mean()))
+    assert oracle.hits_at_k(pos, neg, 501) == 1.0           # fewer negatives than K -> 1.0
+    # strict '>' : a positive tied with the K-th negative is NOT a hit
+    assert oracle.hits_at_k(np.array([0.5], np.float32), np.array([0.5, 0.1], np.float32), 1) == 0.0
+    # permutation invariance
+    assert oracle.hits_at_k(pos[::-1].copy(), rng.permutation(neg), 10) == oracle.hits_at_k(pos, neg, 10)
+
+
+def test_candidates_order_and_cn(oracle):
+    """filter.py:96-109 restated: column-major order, both directions, no diagonal, no known edges;
+    the discarded A^2 value equals CN(u,v)."""
+    d = np.load(os.path.join(GOLDEN, "pairs_er500.npz"))
+    n = len(d["rowptr"]) - 1
+    A = ssp.csr_matrix((d["val"], d["col"], d["rowptr"]), shape=(n, n))
+    pairs, a2 = oracle.candidates_scipy(A)
+    key = pairs[:, 1] * n + pairs[:, 0]
+    assert np.all(np.diff(key) > 0), "column-major, strictly ascending"
+    assert not np.any(pairs[:, 0] == pairs[:, 1])
+    assert A[pairs[:, 0], pairs[:, 1]].sum() == 0
+    s = set(map(tuple, pairs.tolist()))
+    assert all((v, u) in s for u, v in list(s)[:2000])
+    cnt, _, _ = oracle.pair_scores(d["rowptr"], d["col"], None, None, pairs[:, 0], pairs[:, 1])
+    assert np.array_equal(cnt, a2.astype(np.int32))
+    assert cnt.min() >= 1
+
+
+def test_model_configs_fixture_shape():
+    with open(os.path.join(GOLDEN, "model_configs.json")) as f:
+        table = json.load(f)
+    assert table["ddi/gcn"]["batch_size"] == 65536 and table["ddi/simple"]["batch_size"] == 1024
+    assert table["ppa/gcn"]["hidden_channels"] is None      # no ppa block in the reference
