@@ -1,0 +1,194 @@
+#!/usr/bin/env python3
+"""Headline benchmark: candidate edges scored per second on a ppa-like graph (BASELINE.json
+configs[2]: "ogbl-ppa Adamic-Adar scoring of full non-edge candidate set, 1xMI355X").
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+Workload (synthetic, seeded; no dataset / network exists on either box)
+  graph : S3 "ppa-like" -- N = 576,289 nodes, ~21.2 M undirected edges (nnz ~42.5 M, avg degree
+          ~74), R-MAT skew, unit weights; replicated on every GPU (0.35 GB).
+  pairs : the reference's own candidate set for this graph -- 2-hop non-edges in column-major
+          order (filter.py:96-109) -- for a contiguous block of columns, truncated to exactly
+          2**25 = 33,554,432 pairs per GPU.  Rank r takes its own block of columns (weak scaling:
+          per-GPU work fixed; candidate pairs are independent, no data-path collective).
+  step  : one pass of the hot path over that batch: eps_pair_scores -> common-neighbour count +
+          Adamic-Adar score for every pair (adamic_utils.py:13-25 / models.py:536-542), inputs and
+          outputs resident in HBM.
+Reported: whole-job pairs/s (max-over-ranks time), the intersection kernel's achieved
+algorithmic HBM GB/s (HIP events on the launch stream) against the 8 TB/s peak, and the
+reference's CPU path (SciPy mirror of adamic_utils.AA, 1 thread) timed on a bounded sample of
+the same pairs.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PAIRS_PER_GPU = 1 << 25
+HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable by a float4 copy)
+CPU_SAMPLE = 6_000_000   # pairs timed through the SciPy mirror (~10-30 s on one core)
+
+
+def build_pairs(g, rank, target, synth, torch):
+    """2-hop non-edge candidates, column-major, from rank-specific column blocks, exactly `target` pairs."""
+    n = g.n_rows
+    cols_per_rank = n // 64  # room for up to 64 disjoint rank blocks
+    v = rank * cols_per_rank
+    v_end = (rank + 1) * cols_per_rank
+    out, have = [], 0
+    while have < target and v < v_end:
+        blk = synth.two_hop_candidates(g, v, min(v + 128, v_end))
+        out.append(blk)
+        have += blk.shape[1]
+        v += 128
+    pairs = torch.cat(out, 1)[:, :target]
+    if pairs.shape[1] < target:
+        raise RuntimeError(f"only {pairs.shape[1]} candidates in the rank's column block")
+    return pairs[0].to(torch.int32).contiguous(), pairs[1].to(torch.int32).contiguous(), (rank * cols_per_rank, v)
+
+
+def algorithmic_bytes(g, u, v, count, torch):
+    """bytes(u,v) = 4*(d_u+d_v) + 4*CN_uv + 32 (rowptr) + 8 (u,v) + 8 (int32 CN + f32 score)."""
+    deg = g.degree()
+    du = deg[u.long()].sum().item()
+    dv = deg[v.long()].sum().item()
+    return 4 * (du + dv) + 4 * int(count.sum().item()) + 48 * u.numel(), (du + dv) / u.numel()
+
+
+def cpu_baseline(g, u, v, ws_gpu, torch):
+    """Reference CPU path on the host cores: SciPy mirror of adamic_utils.AA (bit-exact to the imported
+    reference, tests/test_oracle_golden.py), single thread like the reference (SciPy sparse ops + a
+    0-worker DataLoader), on a strided sample of this step's pairs; the GPU scores are checked on it."""
+    import numpy as np
+    from oracle import eps_oracle as orc
+    A = g.to_scipy()
+    n = u.numel()
+    idx = torch.arange(0, n, max(1, n // CPU_SAMPLE), device=u.device)[:CPU_SAMPLE]
+    pu, pv = u[idx].cpu().numpy().astype(np.int64), v[idx].cpu().numpy().astype(np.int64)
+    with np.errstate(divide="ignore"):
+        mult = 1 / np.log(A.sum(0))
+        mult[np.isinf(mult)] = 0
+        A_ = A.multiply(mult).tocsr()
+        t0 = time.perf_counter()
+        scores = []
+        for s in range(0, len(pu), 2000):  # adamic_utils.py:18-24, batch_size 2000
+            scores.append(np.array(np.sum(A[pu[s:s + 2000]].multiply(A_[pv[s:s + 2000]]), 1)).flatten())
+        dt = time.perf_counter() - t0
+    ref = np.concatenate(scores).astype(np.float32)
+    got = ws_gpu[idx].cpu().numpy()
+    den = np.maximum(np.abs(ref), np.abs(got))
+    den[den == 0] = 1
+    rel = float((np.abs(ref - got) / den).max())
+    # the scalar C port too, for a second CPU data point
+    rp, col = g.rowptr.cpu().numpy(), g.col.cpu().numpy()
+    w = orc.node_weights(orc.col_sums(rp, col, None, g.n_rows), orc.W_AA)
+    t1 = time.perf_counter()
+    orc.pair_scores(rp, col, None, w, pu, pv)
+    dt_c = time.perf_counter() - t1
+    return {"value": len(pu) / dt, "unit": "edges/s", "cores": 1, "kind": "port",
+            "sample": f"{len(pu)} of the step's {n} pairs (every {max(1, n // CPU_SAMPLE)}-th), SciPy mirror of "
+                      f"adamic_utils.AA batch 2000, per-batch loop only (weight prologue excluded), "
+                      f"host has {os.cpu_count()} cores, 1 used",
+            "c_port_value": len(pu) / dt_c, "gpu_vs_sample_max_rel_err": rel}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--pairs", type=int, default=PAIRS_PER_GPU, help="pairs per GPU and step")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import eps_amd
+    from eps_amd import ops, synth
+    from eps_amd.heuristics import node_weight_table
+
+    g = synth.ppa_like(seed=3, device=dev)
+    u, v, col_range = build_pairs(g, rank, args.pairs, synth, torch)
+    w = node_weight_table(g, ops.W_AA)
+    torch.cuda.synchronize(dev)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    def step():
+        return ops.pair_scores(g.rowptr, g.col, g.val, w, g.n_rows, u, v, want_count=True, want_cn=False)
+
+    for _ in range(args.warmup):
+        step()
+    stream = torch.cuda.current_stream(dev)
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    barrier()
+    t0 = time.perf_counter()
+    for a, b in evs:
+        a.record(stream)           # same stream the kernel is launched on (ops use torch's current stream)
+        count, _, ws = step()
+        b.record(stream)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+    kern_ms = sum(a.elapsed_time(b) for a, b in evs) / args.steps
+
+    if rank == 0:
+        n_cu, dev_name = ops.device_info()
+        abytes, mean_len = algorithmic_bytes(g, u, v, count, torch)
+        achieved = abytes / (kern_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            traffic = json.load(open(tpath)).get(f"pair_scores/ppa_like/{args.pairs}")
+        line = {
+            "metric": "candidate edges scored/sec on ogbl-ppa (ppa-like synthetic); CN + Adamic-Adar per pair",
+            "value": world * args.pairs * args.steps / dt,
+            "unit": "edges/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "configs[2] ppa-like S3: N=576289, nnz=%d, AA+CN over 2-hop non-edge candidates "
+                                   "(column-major, filter.py:96-109 order)" % g.nnz(),
+                       "pairs_per_gpu_per_step": args.pairs, "columns_rank0": list(col_range),
+                       "mean_du_plus_dv": mean_len, "mean_cn": float(count.float().mean().item()),
+                       "graph_replicated": True, "device": dev_name, "n_cu": n_cu},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                         "kernel": "pair_scores_kernel<false,true,float>", "kernel_ms": kern_ms,
+                         "algorithmic_bytes_per_launch": abytes},
+        }
+        if world == 1 and not args.no_cpu:
+            line["cpu_baseline"] = cpu_baseline(g, u, v, ws, torch)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -44,7 +44,7 @@ def ppa_like(seed: int = 3, device="cuda", n_nodes: int = 576_289, n_undirected:
     R-MAT skew softened (a=.45,b=.22,c=.22) so the maximum degree lands in the low thousands like ppa's
     (~3.2 k) instead of Graph500's tens of thousands."""
     scale = 20
-    draw = int(n_undirected * 1.06)  # head-room for duplicates / loops removed by coalescing
+    draw = int(n_undirected * 1.003)  # head-room for duplicates / loops removed by coalescing
     ei = rmat_edges(scale, draw, seed, device, a=0.45, b=0.22, c=0.22)
     gen = torch.Generator(device=device).manual_seed(seed + 1)
     perm = torch.randperm(1 << scale, generator=gen, device=device)
