@@ -35,7 +35,7 @@ HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s ach
 CPU_SAMPLE = 6_000_000   # pairs timed through the SciPy mirror (~10-30 s on one core)
 
 
-def build_pairs(g, rank, target, synth, torch):
+def build_pairs(g, rank, target, candidates, torch):
     """2-hop non-edge candidates, column-major, from rank-specific column blocks, exactly `target` pairs."""
     n = g.n_rows
     cols_per_rank = n // 64  # room for up to 64 disjoint rank blocks
@@ -43,7 +43,7 @@ def build_pairs(g, rank, target, synth, torch):
     v_end = (rank + 1) * cols_per_rank
     out, have = [], 0
     while have < target and v < v_end:
-        blk = synth.two_hop_candidates(g, v, min(v + 128, v_end))
+        blk = candidates.two_hop_block(g, v, min(v + 128, v_end))
         out.append(blk)
         have += blk.shape[1]
         v += 128
@@ -122,11 +122,11 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     import eps_amd
-    from eps_amd import ops, synth
+    from eps_amd import candidates, ops, synth
     from eps_amd.heuristics import node_weight_table
 
     g = synth.ppa_like(seed=3, device=dev)
-    u, v, col_range = build_pairs(g, rank, args.pairs, synth, torch)
+    u, v, col_range = build_pairs(g, rank, args.pairs, candidates, torch)
     w = node_weight_table(g, ops.W_AA)
     torch.cuda.synchronize(dev)
 

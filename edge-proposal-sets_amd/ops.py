@@ -21,7 +21,9 @@ def _stream(dev: torch.device):
     return ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
 
 
-def _need_gpu(*tensors: Optional[torch.Tensor]) -> torch.device:
+def _need_gpu(*tensors: Optional[torch.Tensor], row_strided=()) -> torch.device:
+    """All tensors on one HIP device and contiguous; those listed in ``row_strided`` may be 2-D views
+    with unit column stride and an arbitrary row stride (passed to the ABI as the leading dimension)."""
     dev = None
     for t in tensors:
         if t is None:
@@ -33,7 +35,10 @@ def _need_gpu(*tensors: Optional[torch.Tensor]) -> torch.device:
             dev = t.device
         elif t.device != dev:
             raise _lib.EpsError(f"tensors on different devices: {dev} vs {t.device}")
-        if not t.is_contiguous():
+        if any(t is r for r in row_strided):
+            if t.dim() != 2 or (t.shape[1] > 1 and t.stride(1) != 1):
+                raise _lib.EpsError("2-D operand must have unit column stride")
+        elif not t.is_contiguous():
             raise _lib.EpsError("non-contiguous tensor passed to the C ABI")
     if dev is None:
         raise _lib.EpsError("no tensor given")
@@ -101,7 +106,7 @@ def pair_scores(rowptr, col, val, node_w, n_nodes: int, u, v, want_count=True, w
 
 
 def spmm_csr(rowptr, col, val, x: torch.Tensor, bias=None, relu=False, mean=False, out=None) -> torch.Tensor:
-    dev = _need_gpu(rowptr, col, val, x, bias, out)
+    dev = _need_gpu(rowptr, col, val, x, bias, out, row_strided=(x, out))
     _chk(rowptr, torch.int64, "rowptr"); _chk(col, torch.int32, "col"); _chk(val, torch.float32, "val")
     _chk(x, torch.float32, "x"); _chk(bias, torch.float32, "bias")
     n_rows = rowptr.numel() - 1
@@ -128,7 +133,7 @@ def gcn_norm(rowptr, col, val) -> torch.Tensor:
 
 def gemm(a: torch.Tensor, b_nk: torch.Tensor, bias=None, relu=False, out=None, accumulate=False) -> torch.Tensor:
     """C = act(a @ b_nk.T + bias (+ C)); b_nk is [N,K] (torch.nn.Linear layout)."""
-    dev = _need_gpu(a, b_nk, bias, out)
+    dev = _need_gpu(a, b_nk, bias, out, row_strided=(a, b_nk, out))
     _chk(a, torch.float32, "a"); _chk(b_nk, torch.float32, "b"); _chk(bias, torch.float32, "bias")
     m, k = a.shape
     n = b_nk.shape[0]

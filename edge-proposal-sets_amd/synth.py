@@ -51,33 +51,3 @@ def ppa_like(seed: int = 3, device="cuda", n_nodes: int = 576_289, n_undirected:
     ei = perm[ei] % n_nodes
     ei = ei[:, ei[0] != ei[1]]
     return CSRGraph.from_edge_index(ei, None, sparse_sizes=(n_nodes, n_nodes)).to_symmetric()
-
-
-def two_hop_candidates(g: CSRGraph, v_lo: int, v_hi: int) -> torch.Tensor:
-    """All 2-hop non-edges (u, v) with v in [v_lo, v_hi): the slice of filter.py:96-109's candidate
-    set for those columns, in the reference's column-major order (v ascending, then u ascending).
-    torch ops on the graph's device (bench/test input generation)."""
-    dev = g.device
-    rowptr, col = g.rowptr, g.col.to(torch.int64)
-    deg = rowptr[1:] - rowptr[:-1]
-    vs = torch.arange(v_lo, v_hi, device=dev, dtype=torch.int64)
-    # level 1: (v, w) for w in N(v)
-    cnt1 = deg[vs]
-    v1 = torch.repeat_interleave(vs, cnt1)
-    off1 = torch.arange(v1.numel(), device=dev) - torch.repeat_interleave(torch.cumsum(cnt1, 0) - cnt1, cnt1)
-    w1 = col[rowptr[v1] + off1]
-    # level 2: (v, u) for u in N(w)
-    cnt2 = deg[w1]
-    v2 = torch.repeat_interleave(v1, cnt2)
-    w2 = torch.repeat_interleave(w1, cnt2)
-    off2 = torch.arange(v2.numel(), device=dev) - torch.repeat_interleave(torch.cumsum(cnt2, 0) - cnt2, cnt2)
-    u2 = col[rowptr[w2] + off2]
-    n = g.n_rows
-    key = torch.unique(v2 * n + u2)  # column-major key, sorted, deduplicated
-    vv = torch.div(key, n, rounding_mode="floor")
-    uu = key - vv * n
-    keep = uu != vv
-    # drop known edges: (u,v) present in A  <=>  key present among A's own (row=v, col=u) keys
-    akey = v1 * n + w1
-    keep &= ~torch.isin(key, akey)
-    return torch.stack([uu[keep], vv[keep]])

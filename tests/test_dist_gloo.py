@@ -1,0 +1,109 @@
+"""CPU, world_size 2, gloo: the multi-GPU sharding / all-gather / top-K-merge logic, with the oracle
+injected as the scorer (the product path injects the HIP scorers)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _pack_keys_cpu(score: torch.Tensor, base: int) -> torch.Tensor:
+    """numpy restatement of csrc/topk_keys.hip (test-side only)."""
+    f = (score.numpy().astype(np.float32) + np.float32(0.0))
+    b = f.view(np.uint32).astype(np.uint64)
+    o = np.where(b & 0x80000000, (~b) & 0xFFFFFFFF, b | 0x80000000)
+    ids = np.arange(base, base + len(f), dtype=np.uint64)
+    key = ((o ^ 0x80000000) << np.uint64(32)) | (np.uint64(0xFFFFFFFF) - ids)
+    return torch.from_numpy(key.view(np.int64).copy())
+
+
+def _worker(rank, world, port, tmp):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    import eps_amd  # noqa: F401
+    from eps_amd import dist as epd, synth
+    from oracle import eps_oracle as orc
+    r, w, dev = epd.init_from_env(backend="gloo")
+    assert (r, w) == (rank, world) and dev.type == "cpu"
+    g = synth.rmat_graph(10, 8, 5, "cpu")
+    n = g.n_rows
+    gen = torch.Generator().manual_seed(7)
+    u = torch.randint(0, n, (20000,), generator=gen, dtype=torch.int32)
+    v = torch.randint(0, n, (20000,), generator=gen, dtype=torch.int32)
+    rp, col = g.rowptr.numpy(), g.col.numpy()
+    wts = orc.node_weights(orc.col_sums(rp, col, None, n), orc.W_AA)
+
+    def score(uu, vv):
+        return torch.from_numpy(orc.pair_scores(rp, col, None, wts, uu.numpy(), vv.numpy())[2])
+
+    keys, (lo, hi), local = epd.score_pairs_sharded(g.degree(), u, v, score, _pack_keys_cpu, k=500)
+    # 1. the merged top-k equals the single-process answer
+    full = score(u, v)
+    want = torch.topk(_pack_keys_cpu(full, 0), 500, largest=True, sorted=True).values
+    assert torch.equal(keys, want)
+    # 2. shards are contiguous, disjoint, cover everything, and are work-balanced
+    bounds = epd.balanced_bounds(epd.pair_work(g.degree(), u, v), world)
+    assert bounds[0] == 0 and bounds[-1] == 20000 and (lo, hi) == (bounds[rank], bounds[rank + 1])
+    work = epd.pair_work(g.degree(), u, v)
+    share = float(work[lo:hi].sum() / work.sum())
+    assert abs(share - 1.0 / world) < 0.02
+    # 3. all-gather of a ragged row partition
+    x = torch.arange(7 * 3, dtype=torch.float32).view(7, 3)
+    b = [0, 4, 7]
+    got = epd.all_gather_rows(x[b[rank]:b[rank + 1]].clone(), b)
+    assert torch.equal(got, x)
+    # 4. row-sharded GNN forward == unsharded (mean-aggregate layer restated with the oracle)
+    feats = torch.randn(n, 8, generator=torch.Generator().manual_seed(1))
+
+    def layer(xf, lo_, hi_):
+        return torch.from_numpy(orc.spmm_csr(rp, col, None, xf.numpy(), mean=True)[lo_:hi_].copy())
+
+    h = epd.sharded_gnn_forward([layer, layer], feats, n)
+    ref = orc.spmm_csr(rp, col, None, orc.spmm_csr(rp, col, None, feats.numpy(), mean=True), mean=True)
+    assert np.array_equal(h.numpy(), ref)
+    torch.save(keys, os.path.join(tmp, f"keys_{rank}.pt"))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_world2_gloo(tmp_path):
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    k0 = torch.load(tmp_path / "keys_0.pt")
+    k1 = torch.load(tmp_path / "keys_1.pt")
+    assert torch.equal(k0, k1) and k0.numel() == 500
+
+
+def test_shard_count_invariance():
+    """1 / 2 / 4 / 8 logical shards merge to the identical top-K (no process group needed)."""
+    sys.path.insert(0, ROOT)
+    import eps_amd  # noqa: F401
+    from eps_amd import dist as epd, proposals
+    g = torch.Generator().manual_seed(3)
+    score = torch.randint(0, 30, (50000,), generator=g).float()      # heavy ties, like CN
+    work = torch.rand(50000, generator=g) + 0.1
+    ref = None
+    for world in (1, 2, 4, 8):
+        b = epd.balanced_bounds(work, world)
+        lists = [torch.topk(_pack_keys_cpu(score[b[r]:b[r + 1]], b[r]), min(1000, b[r + 1] - b[r])).values
+                 for r in range(world)]
+        merged = torch.topk(torch.cat(lists), 1000).values
+        ref = merged if ref is None else ref
+        assert torch.equal(merged, ref)
+    ids = (0xFFFFFFFF - (ref.numpy().view(np.uint64) & np.uint64(0xFFFFFFFF))).astype(np.int64)
+    want = torch.sort(score, descending=True, stable=True).indices[:1000]
+    assert np.array_equal(ids, want.numpy())

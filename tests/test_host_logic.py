@@ -1,0 +1,145 @@
+"""CPU: host logic that needs no GPU -- graph construction (rank.py:28-36), candidate order
+(filter.py:96-109), model config table / state-dict keys / factory (models.py:578-790), Hits@K."""
+import argparse
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+
+KEYS = ["num_layers", "hidden_channels", "dropout", "batch_size", "lr", "epochs", "use_feature",
+        "use_learnable_embedding"]
+
+
+def test_default_model_configs_match_reference_table(eps):
+    from eps_amd import models
+    table = json.load(open(os.path.join(GOLDEN, "model_configs.json")))
+    for key, want in table.items():
+        if key.startswith("override:"):
+            continue
+        d, m = key.split("/")
+        args = argparse.Namespace(dataset=d, model=m, **{k: None for k in KEYS})
+        got = models.default_model_configs(args)
+        assert {k: getattr(got, k) for k in KEYS} == want, key
+    args = argparse.Namespace(dataset="collab", model="simple", num_layers=5, hidden_channels=32, dropout=0.1,
+                              batch_size=77, lr=0.5, epochs=3, use_feature=True, use_learnable_embedding=True)
+    got = models.default_model_configs(args)
+    assert {k: getattr(got, k) for k in KEYS} == table["override:collab/simple"]
+
+
+def test_state_dict_keys_match_reference(eps):
+    from eps_amd import models
+    want = json.load(open(os.path.join(GOLDEN, "state_dict_keys.json")))
+    assert list(models.LinkPredictor(4, 4, 1, 2, 0.0).state_dict()) == want["LinkPredictor_L2"]
+    assert list(models.LinkPredictor(4, 4, 1, 3, 0.0).state_dict()) == want["LinkPredictor_L3"]
+    for kind, cls in (("gcn", models.GCN), ("sage", models.SAGE)):
+        d = np.load(os.path.join(GOLDEN, f"gnn_stack_{kind}_L3.npz"))
+        ref_keys = [k[4:] for k in d.files if k.startswith("sd::")]
+        model = models.LinkGNN(torch.nn.Embedding(40, 16), cls(28, 16, 16, 3, 0.5), models.LinkPredictor(16, 16, 1, 3, 0.5))
+        assert sorted(model.state_dict()) == sorted(ref_keys)
+        model.load_state_dict({k: torch.from_numpy(d["sd::" + k]) for k in ref_keys})  # shapes agree too
+
+
+def test_gcnconv_loads_pyg2_checkpoint_layout(eps):
+    from eps_amd import models
+    conv = models.GCNConv(5, 3)
+    w = torch.randn(3, 5)
+    conv.load_state_dict({"lin.weight": w, "bias": torch.zeros(3)})
+    assert torch.equal(conv.weight.data, w.t())
+
+
+def test_build_model_factory(eps):
+    from eps_amd import models
+    data = argparse.Namespace(num_nodes=30, x=torch.randn(30, 7))
+    args = models.default_model_configs(argparse.Namespace(dataset="collab", model="gcn", **{k: None for k in KEYS}))
+    m = models.build_model(args, data, torch.device("cpu"))
+    assert isinstance(m, models.LinkGNN) and m.emb.weight.shape == (30, 256)
+    assert m.gnn.convs[0].weight.shape == (256 + 7, 256) and len(m.gnn.convs) == 3 and len(m.linkpred.lins) == 3
+    args = models.default_model_configs(argparse.Namespace(dataset="ddi", model="simple", **{k: None for k in KEYS}))
+    m = models.build_model(args, data, torch.device("cpu"))
+    assert isinstance(m, models.CommonNeighborsPredictor) and m.type == "simple" and m.emb is None
+    args = models.default_model_configs(argparse.Namespace(dataset="ppa", model="adamic_ogb", **{k: None for k in KEYS}))
+    assert models.build_model(args, data, torch.device("cpu"))(None, None, None) is None     # models.py:534-535
+    with pytest.raises(NotImplementedError):
+        models.build_model(argparse.Namespace(model="dea", use_learnable_embedding=False, use_feature=False,
+                                              hidden_channels=8, num_layers=2, dropout=0.0), data, torch.device("cpu"))
+
+
+def test_training_mode_is_refused(eps):
+    from eps_amd import models
+    gnn = models.GCN(4, 4, 4, 2, 0.5)
+    gnn.train()
+    with pytest.raises(NotImplementedError):
+        gnn(torch.zeros(3, 4), None)
+
+
+@pytest.mark.parametrize("dataset", ["ddi", "collab"])
+def test_add_edges_matches_restatement(eps, oracle, dataset):
+    """rank.py:28-36: duplicates summed by to_symmetric; values reset to 1 unless collab."""
+    rng = np.random.default_rng(1)
+    n = 50
+    ei = rng.integers(0, n, (2, 300))
+    ei = np.concatenate([ei, ei[::-1][:, :100]], 1)           # some edges listed in both directions
+    w = rng.integers(1, 4, ei.shape[1]).astype(np.float32)
+    extra = rng.integers(0, n, (2, 40))
+    A = oracle.add_edges_scipy(dataset, ei, w, extra, n)
+    g = eps.add_edges(dataset, torch.from_numpy(ei), torch.from_numpy(w), torch.from_numpy(extra), n)
+    assert np.array_equal(g.rowptr.numpy(), A.indptr) and np.array_equal(g.col.numpy(), A.indices)
+    assert np.array_equal(g.values_or_ones().numpy(), A.data)
+    assert (g.val is None) == (dataset != "collab")
+    B = g.to_scipy()
+    assert (B != B.T).nnz == 0
+
+
+def test_graph_api_subset(eps):
+    g = eps.CSRGraph.from_edge_index(torch.tensor([[0, 0, 1, 3], [1, 1, 2, 3]]), torch.tensor([1., 2., 5., 7.]), (4, 4))
+    assert g.nnz() == 3 and g.val.tolist() == [3., 5., 7.]                        # duplicates summed
+    row, col, val = g.coo()
+    assert row.tolist() == [0, 1, 3] and col.tolist() == [1, 2, 3]
+    assert g.sum(-1).tolist() == [3., 5., 0., 7.] and g.sum(0).tolist() == [0., 3., 5., 7.]
+    s = g.to_symmetric()
+    assert s.to_scipy().toarray()[3, 3] == 14.0 and s.to_scipy().toarray()[1, 0] == 3.0
+    l = g.with_self_loops(1.0).to_scipy().toarray()
+    assert np.array_equal(np.diag(l), np.ones(4)) and l[0, 1] == 3.0               # diagonal SET, not added
+    assert g.fill_value(1.).val is None and g.sparse_sizes() == (4, 4)
+    r = eps.CSRGraph.from_scipy(g.to_scipy())
+    assert torch.equal(r.rowptr, g.rowptr) and torch.equal(r.val, g.val)
+
+
+def test_candidate_blocks_match_restatement(eps, oracle):
+    from eps_amd import candidates, synth
+    g = synth.rmat_graph(9, 6, 2, "cpu")
+    want, _ = oracle.candidates_scipy(g.to_scipy())
+    got = candidates.all_candidates(g, max_paths=15000)          # forces many column blocks
+    assert np.array_equal(got.t().numpy(), want)
+    # empty graph / isolated nodes
+    e = eps.CSRGraph.from_edge_index(torch.zeros((2, 0), dtype=torch.long), None, (5, 5))
+    assert candidates.all_candidates(e).shape == (2, 0)
+
+
+def test_evaluator_hits_semantics(eps, oracle):
+    from eps_amd import evaluate
+    ev = evaluate.Evaluator("ogbl-ppa")
+    assert ev.K == 100 and evaluate.hits["ppa"] == [10, 100, 200] and evaluate.hits["ddi"] == [10, 20, 30]
+    g = torch.Generator().manual_seed(0)
+    pos, neg = torch.rand(5000, generator=g), torch.rand(3000, generator=g)
+    neg[:50] = neg[50:100]                                       # ties among negatives
+    for k in (10, 100, 200):
+        ev.K = k
+        assert ev.eval({"y_pred_pos": pos, "y_pred_neg": neg})[f"hits@{k}"] == oracle.hits_at_k(pos.numpy(), neg.numpy(), k)
+    ev.K = 5000
+    assert ev.eval({"y_pred_pos": pos, "y_pred_neg": neg})["hits@5000"] == 1.0
+    ev.K = 1
+    assert ev.eval({"y_pred_pos": torch.tensor([.5]), "y_pred_neg": torch.tensor([.5, .1])})["hits@1"] == 0.0
+
+
+def test_get_pos_neg_edges_permutation(eps):
+    from eps_amd import evaluate
+    split = {"valid": {"edge": torch.arange(20).view(10, 2), "edge_neg": torch.arange(40).view(20, 2)}}
+    pos, neg = evaluate.get_pos_neg_edges("valid", split, None, 100)
+    np.random.seed(123)
+    assert torch.equal(pos, split["valid"]["edge"].t()[:, np.random.permutation(10)])
+    assert pos.shape == (2, 10) and neg.shape == (2, 20)
