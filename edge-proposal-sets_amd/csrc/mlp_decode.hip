@@ -49,17 +49,21 @@ __device__ __forceinline__ void w_gload(v4f (&rw)[8], const float *__restrict__ 
         const int q = tid + 256 * i;
         const int row = q >> 3, c4 = q & 7;
         const int rowc = row < H ? row : H - 1;  // clamped duplicate read instead of a guarded def
-        rw[i] = *reinterpret_cast<const v4f *>(W + (int64_t)rowc * H + kc * D_BK + c4 * 4);
+        const int kcol = kc * D_BK + c4 * 4;     // H % 4 == 0: a float4 is entirely inside or outside [0,H)
+        const int kc_ = kcol < H ? kcol : 0;
+        v4f t = *reinterpret_cast<const v4f *>(W + (int64_t)rowc * H + kc_);
+        if (kcol >= H || row >= H) t = (v4f){0.f, 0.f, 0.f, 0.f};  // zero padding up to the next multiple of 32
+        rw[i] = t;
     }
 }
 
-__device__ __forceinline__ void w_lstore(const v4f (&rw)[8], float (*Wb)[D_WLD], int H, int tid)
+__device__ __forceinline__ void w_lstore(const v4f (&rw)[8], float (*Wb)[D_WLD], int Hp, int tid)
 {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int q = tid + 256 * i;
         const int row = q >> 3, c4 = q & 7;
-        if (row < H) *reinterpret_cast<v4f *>(&Wb[row][c4 * 4]) = rw[i];
+        if (row < Hp) *reinterpret_cast<v4f *>(&Wb[row][c4 * 4]) = rw[i];
     }
 }
 
@@ -75,12 +79,14 @@ __global__ __launch_bounds__(256) void mlp_decode_kernel(const float *__restrict
     const int tid = threadIdx.x;
     const int lane = tid & 63, w = tid >> 6;
     const int r = lane & 31, hh = lane >> 5;
-    const int n_ntiles = H >> 5;            // 32-column output tiles (<= 8)
+    const int Hp = (H + 31) & ~31;          // H padded to the MFMA tile width; pad columns are kept at zero
+    const int n_ntiles = Hp >> 5;           // 32-column output tiles (<= 8)
     const int t0 = w, t1 = w + 4;           // the (up to) two column tiles this wave owns
     const bool has0 = t0 < n_ntiles, has1 = t1 < n_ntiles;
-    const int nk = H / D_BK;
+    const int nk = Hp / D_BK;
     const int64_t n_tiles = (n_pairs + D_BM - 1) / D_BM;
     const int h4 = H >> 2;                  // float4 per row
+    const int hp4 = Hp >> 2;
 
     for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const int64_t e0 = tile * D_BM;
@@ -92,6 +98,10 @@ __global__ __launch_bounds__(256) void mlp_decode_kernel(const float *__restrict
                 const int row0 = w * 16 + i, row1 = row0 + 1;
                 const int64_t u0 = __builtin_amdgcn_readlane(mu, row0), v0 = __builtin_amdgcn_readlane(mv, row0);
                 const int64_t u1 = __builtin_amdgcn_readlane(mu, row1), v1 = __builtin_amdgcn_readlane(mv, row1);
+                for (int c = h4 + lane; c < hp4; c += 64) {
+                    *reinterpret_cast<float4 *>(&Xs[row0][4 * c]) = make_float4(0.f, 0.f, 0.f, 0.f);
+                    *reinterpret_cast<float4 *>(&Xs[row1][4 * c]) = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
                 for (int c = lane; c < h4; c += 64) {
                     const float4 a0 = *reinterpret_cast<const float4 *>(hmat + u0 * H + 4 * c);
                     const float4 b0 = *reinterpret_cast<const float4 *>(hmat + v0 * H + 4 * c);
@@ -119,7 +129,7 @@ __global__ __launch_bounds__(256) void mlp_decode_kernel(const float *__restrict
             v4f rw[8];
             // W chunk = rows [0,H) x cols [kc*32, kc*32+32): H*8 float4, 8 per thread at H = 256
             w_gload(rw, W, H, tid, 0);
-            w_lstore(rw, Ws[0], H, tid);
+            w_lstore(rw, Ws[0], Hp, tid);
             __syncthreads();
             for (int kc = 0; kc < nk; ++kc) {
                 const int buf = kc & 1;
@@ -149,7 +159,7 @@ __global__ __launch_bounds__(256) void mlp_decode_kernel(const float *__restrict
                         }
                     }
                 }
-                if (kc + 1 < nk) w_lstore(rw, Ws[buf ^ 1], H, tid);
+                if (kc + 1 < nk) w_lstore(rw, Ws[buf ^ 1], Hp, tid);
                 __syncthreads();
             }
             // every wave has finished reading X (barrier above): overwrite it with relu(acc + b)
@@ -158,7 +168,7 @@ __global__ __launch_bounds__(256) void mlp_decode_kernel(const float *__restrict
                 const bool has = ni == 0 ? has0 : has1;
                 if (!has) continue;
                 const int cc = (ni == 0 ? t0 : t1) * 32 + r;
-                const float bv = Bv[cc];
+                const float bv = cc < H ? Bv[cc] : 0.f;
 #pragma unroll
                 for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
@@ -202,7 +212,7 @@ extern "C" int eps_mlp_decode(const float *h, int64_t n_nodes, int32_t hdim, con
                               int apply_sigmoid, float *out, void *stream)
 {
     EPS_REQUIRE(n_pairs >= 0 && n_nodes >= 0, "eps_mlp_decode: negative size");
-    EPS_REQUIRE(hdim > 0 && hdim % 32 == 0 && hdim <= D_HMAX, "eps_mlp_decode: hdim=%d unsupported (need %%32==0, <=%d)",
+    EPS_REQUIRE(hdim > 0 && hdim % 4 == 0 && hdim <= D_HMAX, "eps_mlp_decode: hdim=%d unsupported (need %%4==0, <=%d)",
                 hdim, D_HMAX);
     EPS_REQUIRE(n_layers >= 1 && n_layers <= D_MAXL, "eps_mlp_decode: n_layers=%d unsupported (1..%d)", n_layers, D_MAXL);
     if (n_pairs == 0) return EPS_OK;

@@ -106,7 +106,7 @@ int eps_gemm_f32(const float *a, int64_t lda, const float *b, int64_t ldb, const
  * h: [n_nodes, hdim] row-major (ld = hdim).  w[l]: device pointers to row-major [out_l, in_l]
  * matrices (torch.nn.Linear layout), b[l]: [out_l]; hidden width == hdim for every hidden
  * layer, last layer out == 1.  w / b are HOST arrays of n_layers device pointers.
- * apply_sigmoid == 0 returns the pre-sigmoid logit.  Supported: hdim % 32 == 0, hdim <= 256,
+ * apply_sigmoid == 0 returns the pre-sigmoid logit.  Supported: hdim % 4 == 0, hdim <= 256,
  * 1 <= n_layers <= 8. */
 int eps_mlp_decode(const float *h, int64_t n_nodes, int32_t hdim, const int32_t *u,
                    const int32_t *v, int64_t n_pairs, const float *const *w,

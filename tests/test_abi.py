@@ -39,7 +39,7 @@ def test_argument_validation_without_gpu(eps):
     lib = eps.load()
     rc = lib.eps_pair_scores(None, None, None, None, 10, None, None, 5, None, None, None, None)
     assert rc == -1 and b"null" in lib.eps_last_error()
-    rc = lib.eps_mlp_decode(None, 0, 100, None, None, 0, None, None, 2, 1, None, None)
+    rc = lib.eps_mlp_decode(None, 0, 102, None, None, 0, None, None, 2, 1, None, None)
     assert rc == -1 and b"hdim" in lib.eps_last_error()
     rc = lib.eps_spmm_csr(None, None, None, -1, None, 0, 0, None, 0, 0, None, 0, None)
     assert rc == -1

@@ -89,7 +89,7 @@ def test_gcn_norm_vs_oracle(eps, oracle, dev):
     assert rel_err(gn.val.cpu().numpy(), ref) <= 1e-6
 
 
-@pytest.mark.parametrize("tag", ["H256_L2", "H256_L3", "H64_L2"])
+@pytest.mark.parametrize("tag", ["H256_L2", "H256_L3", "H64_L2", "H8_L3"])
 def test_decode_golden(eps, dev, tag):
     """eps_mlp_decode vs the imported reference's LinkPredictor output (probabilities AND logits:
     sigmoid flattens relative error, so the logit is the sharper check)."""
@@ -105,7 +105,7 @@ def test_decode_golden(eps, dev, tag):
     assert float(np.abs(logit.cpu().numpy() - d["logit"]).max()) <= 1e-5 * max(1.0, float(np.abs(d["logit"]).max()))
 
 
-@pytest.mark.parametrize("H,L,E", [(256, 3, 100_003), (256, 2, 64), (128, 3, 5000), (32, 1, 999), (96, 4, 1000)])
+@pytest.mark.parametrize("H,L,E", [(256, 3, 100_003), (256, 2, 64), (128, 3, 5000), (32, 1, 999), (96, 4, 1000), (16, 2, 777), (100, 3, 500)])
 def test_decode_vs_oracle_seeded(eps, oracle, dev, H, L, E):
     g = torch.Generator().manual_seed(H + L)
     n = 2000
