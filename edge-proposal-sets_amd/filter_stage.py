@@ -1,0 +1,141 @@
+"""The filter stage (drop-in for filter.py:26-166): score every 2-hop non-edge with the filter model,
+order the candidates, save the proposal file.
+
+Same command line (filter.py:27-47), same checkpoint-name protocol ``spec|edges|num|run.pt`` (:72-76), same
+output ``filtered_edges/{spec}_{edges}_{num}_{run}_sorted_edges.pt`` = float32 [E,3] rows (u, v, score)
+(:160-165).  Differences, all on purpose:
+  * candidates are generated in column blocks on the device and streamed to the scoring kernels; A @ A is
+    never materialised on the host;
+  * GNN filters compute the node embeddings once, not once per scoring batch;
+  * the order is the declared rule (score desc, candidate index asc) instead of an unstable sort;
+  * extensions: ``--synthetic`` (seeded stand-in data), ``--keep_top K`` (save only the best K rows -- rank.py
+    never reads past ``num_sorted_edge``).
+"""
+from __future__ import annotations
+
+import argparse
+import time
+from pathlib import Path
+
+import torch
+
+from . import candidates, ops, proposals
+from .datasets import get_data
+from .graph import CSRGraph, add_edges
+from .heuristics import node_weight_table, pair_scores_streamed
+from .models import build_model, default_model_configs
+
+
+def make_parser():
+    parser = argparse.ArgumentParser(description='filter stage (MI355X)')
+    parser.add_argument('--dataset', type=str, required=True)
+    parser.add_argument('--model', type=str, required=True)
+    parser.add_argument('--checkpoint', type=str, required=True)
+    parser.add_argument('--num_layers', type=int)
+    parser.add_argument('--hidden_channels', type=int)
+    parser.add_argument('--dropout', type=float)
+    parser.add_argument('--batch_size', type=int)
+    parser.add_argument('--lr', type=float)
+    parser.add_argument('--epochs', type=int)
+    parser.add_argument('--use_feature', type=bool)
+    parser.add_argument('--use_learnable_embedding', type=bool)
+    parser.add_argument('--device', type=int, default=0)
+    # extensions
+    parser.add_argument('--synthetic', action="store_true", default=False)
+    parser.add_argument('--keep_top', type=int, default=0)
+    return parser
+
+
+def train_only_graph(split_edge, num_nodes: int, device) -> CSRGraph:
+    """filter.py:130-139: the RA filter scores on a graph built from the TRAIN edges only (both directions,
+    integer ones, duplicates summed by the csr_matrix constructor), ignoring proposal edges and adj_t."""
+    e = split_edge['train']['edge'].t().to(device)
+    both = torch.cat([e, e.flip(0)], 1)
+    return CSRGraph.from_edge_index(both, torch.ones(both.shape[1], device=device), (num_nodes, num_nodes))
+
+
+def score_block(args, model, data, pairs: torch.Tensor, ra_graph=None) -> torch.Tensor:
+    """Scores of one candidate block [2,E_blk] (int64, on device) -> float32 [E_blk] on device."""
+    u = pairs[0].to(torch.int32).contiguous()
+    v = pairs[1].to(torch.int32).contiguous()
+    if args.model == "adamic_ogb":                       # filter.py:122-126
+        g = data.adj_t
+        return pair_scores_streamed(g, u, v, node_weight_table(g, ops.W_AA))[2]
+    if args.model == "resource_allocation":              # filter.py:127-142 (float64 math, FloatTensor out)
+        w = node_weight_table(ra_graph, ops.W_RA, f64=True)
+        return pair_scores_streamed(ra_graph, u, v, w)[2].to(torch.float32)
+    return model(data.x, pairs, data.adj_t).reshape(-1)  # filter.py:116-121
+
+
+def run(args) -> str:
+    args = default_model_configs(args)
+    print(args)
+    Path("filtered_edges").mkdir(exist_ok=True)
+    if not torch.cuda.is_available():
+        raise RuntimeError("filter stage needs a HIP device: the scoring path has no CPU fallback")
+    device = torch.device(f'cuda:{args.device}')
+
+    edge_index, edge_weight, split_edge, data = get_data(args)
+    data = data.to(device)
+    model = build_model(args, data, device)
+    print(f'using model {model}')
+    use_params = sum(p.numel() for p in model.parameters() if p.requires_grad) > 0
+    print('using params?', use_params)
+    if use_params:
+        model.load_state_dict(torch.load(f'models/{args.checkpoint}', map_location=device))
+
+    parts = args.checkpoint.split("|")
+    spec, sorted_edge_path, num_sorted_edge = parts[0], parts[1], int(parts[2])
+    run_id = parts[3].split(".")[0]
+    if sorted_edge_path:
+        print("Loading corresponding extra edges from ", sorted_edge_path)
+        extra_edges = proposals.load_proposals(f"filtered_edges/{sorted_edge_path}.pt", num_sorted_edge)
+        assert extra_edges.size(0) == 2 and extra_edges.size(1) == num_sorted_edge
+    else:
+        extra_edges = torch.zeros([2, 0], dtype=torch.long)
+    data.adj_t = add_edges(args.dataset, edge_index.to(device), edge_weight.to(device), extra_edges.to(device),
+                           data.num_nodes)
+    model.eval()
+    ra_graph = train_only_graph(split_edge, data.num_nodes, device) if args.model == "resource_allocation" else None
+
+    t0 = time.perf_counter()
+    n_seen = 0
+    keep = int(args.keep_top)
+    all_pairs, all_scores, best_keys, best_pairs = [], [], None, None
+    with torch.no_grad():
+        for v_lo, v_hi, pairs in candidates.iter_candidate_blocks(data.adj_t):
+            if pairs.shape[1] == 0:
+                continue
+            score = score_block(args, model, data, pairs, ra_graph)
+            if keep:
+                keys = proposals.top_k_keys(score, keep, id_base=n_seen)          # sorted, global candidate ids
+                _, ids = ops.unpack_keys(keys)
+                kept = pairs[:, ids - n_seen]
+                if best_keys is not None:
+                    keys, kept = torch.cat([best_keys, keys]), torch.cat([best_pairs, kept], 1)
+                top = torch.topk(keys, min(keep, keys.numel()), largest=True, sorted=True)
+                best_keys, best_pairs = top.values, kept[:, top.indices]
+            else:
+                all_pairs.append(pairs)
+                all_scores.append(score)
+            n_seen += pairs.shape[1]
+    torch.cuda.synchronize(device)
+    dt = time.perf_counter() - t0
+    print(f'using {n_seen} edges; scored in {dt:.2f} s ({n_seen / max(dt, 1e-9):.3e} candidate edges/s incl. generation)')
+
+    if keep:
+        score, _ = ops.unpack_keys(best_keys)
+        sorted_edges = torch.cat([best_pairs.t().to(torch.float32), score.unsqueeze(1)], 1)
+    else:
+        pairs = torch.cat(all_pairs, 1)
+        scores = torch.cat(all_scores)
+        sorted_edges = proposals.sorted_edges_tensor(pairs, scores)          # filter.py:160-161
+    print(sorted_edges)
+    filename = f'filtered_edges/{spec}_{sorted_edge_path}_{num_sorted_edge}_{run_id}_sorted_edges.pt'
+    proposals.save_sorted_edges(filename, sorted_edges)                        # filter.py:164-165
+    print("Saving to ", filename)
+    return filename
+
+
+def main(argv=None):
+    return run(make_parser().parse_args(argv))

@@ -1,0 +1,218 @@
+"""The rank stage (drop-in for rank.py:129-391): evaluate a rank model on the graph augmented with the top-k
+proposal edges, over the reference's sweep schedule, and write the curve points.
+
+Same flags (rank.py:130-163), same proposal consumption (``[:k,:2].t().long()``, :294), same adjacency
+construction (:300, :307-314), same eval dispatch (:337-349), same stdout lines (:364-369) and ``curves/`` files
+(:381-385).  Training of parametrised rank models (rank.py:331-333, train_and_eval.py:31-96) is outside the
+accelerated path: such models are evaluated from ``--load_model <state_dict.pt>``.
+"""
+from __future__ import annotations
+
+import argparse
+import os
+from datetime import datetime
+from pathlib import Path
+
+import numpy as np
+import torch
+
+from .datasets import get_data
+from .evaluate import evaluators, hits, test, test_adamic, test_resource_allocation
+from .graph import add_edges
+from .logger import Logger
+from .models import build_model, default_model_configs
+
+
+def make_parser():
+    parser = argparse.ArgumentParser(description='rank stage (MI355X)')
+    parser.add_argument('--dataset', type=str, required=True)
+    parser.add_argument('--model', type=str)
+    parser.add_argument('--runs', type=int, default=10)
+    parser.add_argument('--sorted_edge_path', type=str, default="")
+    parser.add_argument('--num_sorted_edge', type=int)
+    parser.add_argument('--sweep_max', type=int)
+    parser.add_argument('--sweep_min', type=int)
+    parser.add_argument('--sweep_num', type=int)
+    parser.add_argument('--only_supervision', action="store_true", default=False)
+    parser.add_argument('--also_supervision', action="store_true", default=False)
+    parser.add_argument('--gen_dataset_only', action="store_true", default=False)
+    parser.add_argument('--valid_proposal', action="store_true", default=False)
+    parser.add_argument('--out_name', type=str)
+    parser.add_argument('--save_models', action="store_true", default=False)
+    parser.add_argument('--num_layers', type=int)
+    parser.add_argument('--hidden_channels', type=int)
+    parser.add_argument('--dropout', type=float)
+    parser.add_argument('--batch_size', type=int)
+    parser.add_argument('--lr', type=float)
+    parser.add_argument('--epochs', type=int)
+    parser.add_argument('--use_feature', type=bool)
+    parser.add_argument('--use_learnable_embedding', type=bool)
+    parser.add_argument('--device', type=int, default=0)
+    parser.add_argument('--log_steps', type=int, default=1)
+    parser.add_argument('--eval_steps', type=int, default=1)
+    # extensions
+    parser.add_argument('--synthetic', action="store_true", default=False)
+    parser.add_argument('--load_model', type=str, default="")
+    return parser
+
+
+def to_undirected(edge_index: torch.Tensor) -> torch.Tensor:
+    """torch_geometric.utils.to_undirected [third-party]: both directions, coalesced (sorted, unique)."""
+    both = torch.cat([edge_index, edge_index.flip(0)], 1)
+    n = int(both.max()) + 1 if both.numel() else 1
+    key = torch.unique(both[0] * n + both[1])
+    return torch.stack([torch.div(key, n, rounding_mode="floor"), key % n])
+
+
+def splice_valid_proposals(sorted_test_edges: torch.Tensor, valid_pos: torch.Tensor) -> torch.Tensor:
+    """rank.py:222-251 (--valid_proposal): both directions of every validation edge go on top with score
+    100000, and proposal rows that are validation edges are dropped.  (The reference builds the top block from a
+    Python set, whose iteration order is arbitrary; here it is sorted -- the adjacency built from it is the same.)"""
+    v = valid_pos.numpy()
+    top = sorted({(int(a), int(b)) for a, b in v} | {(int(b), int(a)) for a, b in v})
+    d = {tuple(sorted((int(a), int(b)))) for a, b in v}
+    rows = [np.array([a, b, 100000.0]) for a, b in top]
+    for t in sorted_test_edges.numpy():
+        a, b = int(t[0]), int(t[1])
+        if (a, b) in d or (b, a) in d:
+            continue
+        rows.append(t[:3].astype(np.float64) if len(t) >= 3 else np.array([t[0], t[1], 0.0]))
+    return torch.tensor(np.stack(rows))
+
+
+def sweep_schedule(args):
+    """rank.py:260-272."""
+    index_ends = []
+    if args.sweep_num:
+        if args.sweep_min is None:
+            args.sweep_min = 0
+        if args.sweep_max is None:
+            args.sweep_max = (args.sweep_num - 1) * 1000
+        for i in range(args.sweep_num + 1):
+            index_ends.append(args.sweep_min + int(i * (args.sweep_max - args.sweep_min) / args.sweep_num))
+    elif args.num_sorted_edge:
+        index_ends.append(args.num_sorted_edge)
+    else:
+        index_ends.append(0)
+    return index_ends
+
+
+def run(args):
+    args = default_model_configs(args)
+    print(args)
+    if not torch.cuda.is_available():
+        raise RuntimeError("rank stage needs a HIP device: the scoring path has no CPU fallback")
+    device = torch.device(f'cuda:{args.device}')
+    Path("curves").mkdir(exist_ok=True)
+    Path("models").mkdir(exist_ok=True)
+    assert not (args.only_supervision and args.also_supervision)
+    if args.out_name is None:
+        args.out_name = args.dataset + "_" + str(args.model)
+        if args.only_supervision:
+            args.out_name += "_onlys"
+        elif args.also_supervision:
+            args.out_name += "_alsos"
+        elif args.valid_proposal:
+            args.out_name += "_validproposal"
+
+    edge_index, edge_weight, split_edge, data = get_data(args)
+    if args.gen_dataset_only:
+        return []
+    if args.model is None:
+        raise ValueError("Model not specified")
+    data = data.to(device)
+    model = build_model(args, data, device)
+    print(f'using model {model}')
+    evaluator = evaluators[args.dataset]
+    K = hits[args.dataset]
+    print("Evaluating at hits: ", K)
+
+    if args.sorted_edge_path:
+        sorted_test_edges = torch.load(f"filtered_edges/{args.sorted_edge_path}")
+        print('sorted test edges', sorted_test_edges.size())
+        if args.valid_proposal:
+            sorted_test_edges = splice_valid_proposals(sorted_test_edges, split_edge['valid']['edge'])
+    else:
+        sorted_test_edges = torch.zeros(42, 2)
+
+    index_ends = sweep_schedule(args)
+    print(f"Scheduled extra edges sweep: {index_ends} x {args.runs}")
+    use_params = sum(p.numel() for p in model.parameters() if p.requires_grad) > 0
+    if use_params:
+        if not args.load_model:
+            raise NotImplementedError(
+                "rank models with trainable parameters need training (train_and_eval.py:31-96), which is outside the "
+                "accelerated path; pass --load_model <state_dict.pt> to evaluate a trained model")
+        model.load_state_dict(torch.load(args.load_model, map_location=device))
+    ei_dev, ew_dev = edge_index.to(device), edge_weight.to(device)
+
+    curves = []
+    for index_end in index_ends:
+        loggers = {f'Hits@{k}': Logger(args.runs, args) for k in K}
+        print('---------------------')
+        print(f'Using {index_end} highest scoring edges')
+        print('---------------------')
+        extra_edges = sorted_test_edges[:int(index_end), :2].t().long()
+        assert extra_edges.size(0) == 2 and extra_edges.size(1) == index_end
+        if not args.only_supervision:
+            data.adj_t = add_edges(args.dataset, ei_dev, ew_dev, extra_edges.to(device), data.num_nodes)
+        if args.dataset in ["collab", "email", "reddit"]:
+            val_edge_index = to_undirected(split_edge['valid']['edge'].t())
+            full_extra_edges = torch.cat([extra_edges, val_edge_index], dim=-1)
+            data.full_adj_t = add_edges(args.dataset, ei_dev, ew_dev, full_extra_edges.to(device), data.num_nodes)
+        else:
+            data.full_adj_t = data.adj_t
+
+        curve_point = []
+        for run_i in range(args.runs):
+            if not use_params:
+                model.reset_parameters()
+                args.epochs = 1
+            highest_eval = 0
+            for epoch in range(1, 1 + (args.epochs or 1)):
+                loss = -1
+                if epoch % args.eval_steps == 0:
+                    if args.model == "adamic_ogb":
+                        results = test_adamic(model, data, split_edge, evaluator, args.batch_size, args, device)
+                    elif args.model == "resource_allocation":
+                        results = test_resource_allocation(model, data, split_edge, evaluator, args.batch_size, args,
+                                                           device)
+                    elif args.model == "katz":
+                        raise NotImplementedError("katz (sparse inverse) is outside the accelerated path")
+                    else:
+                        results = test(model, data, split_edge, evaluator, args.batch_size or (1 << 16), args, device)
+                    for key, result in results.items():
+                        loggers[key].add_result(run_i, result)
+                    if epoch % args.log_steps == 0:
+                        for key, result in results.items():
+                            train_hits, valid_hits, test_hits = result
+                            if key == f"Hits@{K[1]}" and valid_hits >= highest_eval:
+                                highest_eval = valid_hits
+                            print(key)
+                            print(f'Run: {run_i + 1:02d}, Epoch: {epoch:02d}, Loss: {loss:.4f}, '
+                                  f'Train: {100 * train_hits:.2f}%, Valid: {100 * valid_hits:.2f}%, '
+                                  f'Test: {100 * test_hits:.2f}%')
+                        print('---')
+                if use_params:
+                    break  # a loaded model is evaluated once
+            for key in loggers.keys():
+                print(key)
+                loggers[key].print_statistics(run_i)
+                if key == f"Hits@{K[1]}":                          # model selection on the MIDDLE K (rank.py:376)
+                    result = 100 * torch.tensor(loggers[key].results[run_i])
+                    argmax = result[:, 1].argmax().item()
+                    curve_point = [index_end, result[argmax, 1], result[argmax, 2]]
+            stamp = datetime.now().strftime('%Y-%m-%d-%H:%M:%S')
+            filename = f'{args.out_name}|{args.sorted_edge_path.split(".")[0]}|{index_end}|{stamp}.pt'
+            print(curve_point)
+            print("Saving curve to ", filename)
+            torch.save(curve_point, os.path.join('curves', filename))
+            curves.append(curve_point)
+        for key in loggers.keys():
+            print(key)
+            loggers[key].print_statistics()
+    return curves
+
+
+def main(argv=None):
+    return run(make_parser().parse_args(argv))

@@ -1,0 +1,124 @@
+"""GPU end-to-end: the filter.py -> rank.py drop-ins on synthetic stand-in data vs the oracle pipeline
+(candidates -> scores -> declared order -> proposal file -> augmented graph -> Hits@K)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def workdir(tmp_path, monkeypatch):
+    monkeypatch.chdir(tmp_path)
+    monkeypatch.setenv("EPS_SYNTH_SCALE", "0.004")
+    return tmp_path
+
+
+def _oracle_filter(oracle, eps, dataset, mode):
+    """Restated filter.py for AA / RA on the same synthetic data (torch RNG is seeded by the generator)."""
+    import argparse
+    from eps_amd import datasets
+    args = argparse.Namespace(dataset=dataset, synthetic=True, use_feature=False)
+    edge_index, edge_weight, split_edge, data = datasets.get_data(args)
+    A = oracle.add_edges_scipy(dataset, edge_index.numpy(), edge_weight.numpy(), np.zeros((2, 0), np.int64), data.num_nodes)
+    pairs, _ = oracle.candidates_scipy(A)
+    rp, col = A.indptr.astype(np.int64), A.indices.astype(np.int32)
+    val = None if dataset != "collab" else A.data
+    n = data.num_nodes
+    if mode == "aa":
+        w = oracle.node_weights(oracle.col_sums(rp, col, val, n), oracle.W_AA)
+        score = oracle.pair_scores(rp, col, val, w, pairs[:, 0], pairs[:, 1])[2]
+    else:  # filter.py:130-141: train edges only, integer ones, float64
+        e = split_edge['train']['edge'].numpy()
+        import scipy.sparse as ssp
+        both = np.concatenate([e, e[:, ::-1]], 0)
+        At = ssp.csr_matrix((np.ones(len(both), dtype=np.int64), (both[:, 0], both[:, 1])), shape=(n, n))
+        At.sum_duplicates(); At.sort_indices()
+        cs = np.asarray(At.sum(0)).reshape(-1).astype(np.float64)
+        w = oracle.node_weights(cs, oracle.W_RA)
+        score = oracle.pair_scores_f64(At.indptr.astype(np.int64), At.indices.astype(np.int32),
+                                       At.data.astype(np.float32), w, pairs[:, 0], pairs[:, 1])[1].astype(np.float32)
+    return pairs, score, split_edge, data, A
+
+
+@pytest.mark.parametrize("dataset,model,mode", [("ppa", "adamic_ogb", "aa"), ("collab", "adamic_ogb", "aa"),
+                                                ("ppa", "resource_allocation", "ra")])
+def test_filter_cli_matches_oracle(eps, oracle, workdir, dataset, model, mode):
+    from eps_amd import filter_stage
+    fname = filter_stage.main(["--dataset", dataset, "--model", model, "--checkpoint", f"{dataset}_{model}||0|0.pt",
+                               "--synthetic"])
+    assert fname == f"filtered_edges/{dataset}_{model}__0_0_sorted_edges.pt"
+    got = torch.load(fname)
+    pairs, score, *_ = _oracle_filter(oracle, eps, dataset, mode)
+    assert got.dtype == torch.float32 and got.shape == (len(pairs), 3)
+    # (i) same score multiset within tolerance, in descending order
+    ref_sorted = np.sort(score)[::-1]
+    assert np.all(np.diff(got[:, 2].numpy()) <= 0)
+    den = np.maximum(np.abs(ref_sorted), 1e-30)
+    assert float((np.abs(got[:, 2].numpy() - ref_sorted) / den).max()) <= 1e-5
+    # (ii) same candidate set
+    key = lambda a: a[:, 0].astype(np.int64) * (1 << 24) + a[:, 1].astype(np.int64)  # noqa: E731
+    assert np.array_equal(np.sort(key(got[:, :2].numpy())), np.sort(key(pairs)))
+    # (iii) --keep_top K gives the first K rows of the full file (same declared order)
+    fname2 = filter_stage.main(["--dataset", dataset, "--model", model, "--checkpoint", f"{dataset}_{model}||0|1.pt",
+                                "--synthetic", "--keep_top", "500"])
+    top = torch.load(fname2)
+    assert torch.equal(top, got[:500])
+
+
+def test_rank_cli_hits_match_oracle(eps, oracle, workdir):
+    """AA-filter -> AA-rank (the published collab recipe, minus --valid_proposal) on the ppa stand-in:
+    Hits@K printed by rank.py == Hits@K of oracle scores on the oracle-built augmented graph."""
+    from eps_amd import filter_stage, rank_stage
+    filter_stage.main(["--dataset", "ppa", "--model", "adamic_ogb", "--checkpoint", "ppa_adamic_ogb||0|0.pt", "--synthetic"])
+    curves = rank_stage.main(["--dataset", "ppa", "--model", "adamic_ogb", "--sorted_edge_path",
+                              "ppa_adamic_ogb__0_0_sorted_edges.pt", "--num_sorted_edge", "300", "--runs", "1", "--synthetic"])
+    assert len(curves) == 1 and curves[0][0] == 300
+    files = os.listdir("curves")
+    assert len(files) == 1 and files[0].startswith("ppa_adamic_ogb|ppa_adamic_ogb__0_0_sorted_edges|300|")
+    # oracle side
+    pairs, score, split_edge, data, A0 = _oracle_filter(oracle, eps, "ppa", "aa")
+    prop = torch.load("filtered_edges/ppa_adamic_ogb__0_0_sorted_edges.pt")[:300, :2].t().long().numpy()
+    import argparse
+    from eps_amd import datasets
+    edge_index, edge_weight, *_ = datasets.get_data(argparse.Namespace(dataset="ppa", synthetic=True, use_feature=False))
+    A = oracle.add_edges_scipy("ppa", edge_index.numpy(), edge_weight.numpy(), prop, data.num_nodes)
+    rp, col = A.indptr.astype(np.int64), A.indices.astype(np.int32)
+    w = oracle.node_weights(oracle.col_sums(rp, col, None, data.num_nodes), oracle.W_AA)
+    sc = lambda e: oracle.pair_scores(rp, col, None, w, e[:, 0].numpy(), e[:, 1].numpy())[2]  # noqa: E731
+    valid = oracle.hits_at_k(sc(split_edge["valid"]["edge"]), sc(split_edge["valid"]["edge_neg"]), 100)
+    test_h = oracle.hits_at_k(sc(split_edge["test"]["edge"]), sc(split_edge["test"]["edge_neg"]), 100)
+    assert float(curves[0][1]) == pytest.approx(100 * valid, abs=1e-4)
+    assert float(curves[0][2]) == pytest.approx(100 * test_h, abs=1e-4)
+
+
+def test_gnn_filter_cli(eps, oracle, workdir):
+    """GCN filter (collab recipe): checkpoint round trip through models/<spec>|<edges>|<num>|<run>.pt, embeddings
+    computed once, decode over all candidates; scores checked against the oracle GCN + decode on a sample."""
+    import argparse
+    from eps_amd import datasets, filter_stage, models
+    args = models.default_model_configs(argparse.Namespace(
+        dataset="collab", model="gcn", synthetic=True, num_layers=None, hidden_channels=32, dropout=None,
+        batch_size=None, lr=None, epochs=None, use_feature=None, use_learnable_embedding=None))
+    edge_index, edge_weight, split_edge, data = datasets.get_data(args)
+    torch.manual_seed(0)
+    model = models.build_model(args, data, torch.device("cpu"))
+    os.makedirs("models", exist_ok=True)
+    torch.save(model.state_dict(), "models/collab_gcn||0|0.pt")
+    fname = filter_stage.main(["--dataset", "collab", "--model", "gcn", "--checkpoint", "collab_gcn||0|0.pt",
+                               "--synthetic", "--hidden_channels", "32"])
+    got = torch.load(fname)
+    A = oracle.add_edges_scipy("collab", edge_index.numpy(), edge_weight.numpy(), np.zeros((2, 0), np.int64), data.num_nodes)
+    sd = {k: v.numpy() for k, v in model.state_dict().items()}
+    x = np.concatenate([sd["emb.weight"], data.x.numpy()], 1)
+    h = oracle.gcn_forward_csr(A.indptr, A.indices, A.data, x, [sd[f"gnn.convs.{i}.weight"] for i in range(3)],
+                               [sd[f"gnn.convs.{i}.bias"] for i in range(3)])
+    sel = np.r_[0:300, len(got) - 300:len(got)]
+    e = got[sel, :2].numpy().astype(np.int32)
+    _, prob = oracle.mlp_decode(h, e[:, 0], e[:, 1], [sd[f"linkpred.lins.{i}.weight"] for i in range(3)],
+                                [sd[f"linkpred.lins.{i}.bias"] for i in range(3)])
+    assert float(np.abs(got[sel, 2].numpy() - prob).max()) <= 2e-5
+    pairs, _ = oracle.candidates_scipy(A)
+    assert len(got) == len(pairs)
