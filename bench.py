@@ -136,7 +136,8 @@ def main():
         torch.cuda.synchronize(dev)
 
     def step():
-        return ops.pair_scores(g.rowptr, g.col, g.val, w, g.n_rows, u, v, want_count=True, want_cn=False)
+        # candidates come column-major from the generator (filter.py:96-109 order): the column-run kernel applies
+        return ops.pair_scores(g.rowptr, g.col, g.val, w, g.n_rows, u, v, want_count=True, want_cn=False, grouped=True)
 
     for _ in range(args.warmup):
         step()
@@ -179,7 +180,7 @@ def main():
                        "graph_replicated": True, "device": dev_name, "n_cu": n_cu},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "kernel": "pair_scores_kernel<false,true,float>", "kernel_ms": kern_ms,
+                         "kernel": "pair_scores_grouped_kernel<false,true,float,true>", "kernel_ms": kern_ms,
                          "algorithmic_bytes_per_launch": abytes},
         }
         if world == 1 and not args.no_cpu:

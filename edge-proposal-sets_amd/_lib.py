@@ -8,7 +8,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libeps_hip.so")
+LIB_PATH = os.environ.get("EPS_LIB_PATH") or os.path.join(_HERE, "libeps_hip.so")  # override: kernel A/B experiments
 CSRC = os.path.join(_HERE, "csrc")
 
 _c = ctypes
@@ -24,6 +24,8 @@ SIGNATURES = {
     "eps_node_weights_f64": (_int, [_vp, _i64, _int, _vp, _vp]),
     "eps_pair_scores": (_int, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
     "eps_pair_scores_f64": (_int, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp]),
+    "eps_pair_scores_grouped": (_int, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
+    "eps_pair_scores_grouped_f64": (_int, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp]),
     "eps_spmm_csr": (_int, [_vp, _vp, _vp, _i64, _vp, _i64, _i32, _vp, _int, _int, _vp, _i64, _vp]),
     "eps_gcn_norm": (_int, [_vp, _vp, _vp, _i64, _vp, _vp, _vp]),
     "eps_gemm_f32": (_int, [_vp, _i64, _vp, _i64, _vp, _int, _int, _vp, _i64, _i64, _i32, _i32, _vp]),

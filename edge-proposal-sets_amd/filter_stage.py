@@ -60,10 +60,10 @@ def score_block(args, model, data, pairs: torch.Tensor, ra_graph=None) -> torch.
     v = pairs[1].to(torch.int32).contiguous()
     if args.model == "adamic_ogb":                       # filter.py:122-126
         g = data.adj_t
-        return pair_scores_streamed(g, u, v, node_weight_table(g, ops.W_AA))[2]
+        return pair_scores_streamed(g, u, v, node_weight_table(g, ops.W_AA), grouped=True)[2]   # column-major blocks
     if args.model == "resource_allocation":              # filter.py:127-142 (float64 math, FloatTensor out)
         w = node_weight_table(ra_graph, ops.W_RA, f64=True)
-        return pair_scores_streamed(ra_graph, u, v, w)[2].to(torch.float32)
+        return pair_scores_streamed(ra_graph, u, v, w, grouped=True)[2].to(torch.float32)
     return model(data.x, pairs, data.adj_t).reshape(-1)  # filter.py:116-121
 
 

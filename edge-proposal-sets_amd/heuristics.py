@@ -77,15 +77,17 @@ def node_weight_table(g: CSRGraph, mode: int, f64: bool = False) -> torch.Tensor
 
 
 def pair_scores_streamed(g: CSRGraph, u: torch.Tensor, v: torch.Tensor, node_w: Optional[torch.Tensor],
-                         want_count=False, want_cn=False):
+                         want_count=False, want_cn=False, grouped=None):
     """Run eps_pair_scores over an arbitrarily long pair list in HBM-sized pieces."""
     n = u.numel()
     if n <= _STREAM_CHUNK:
-        return ops.pair_scores(g.rowptr, g.col, g.val, node_w, g.n_rows, u, v, want_count=want_count, want_cn=want_cn)
+        return ops.pair_scores(g.rowptr, g.col, g.val, node_w, g.n_rows, u, v, want_count=want_count, want_cn=want_cn,
+                               grouped=grouped)
     outs = [[], [], []]
     for s in range(0, n, _STREAM_CHUNK):
         r = ops.pair_scores(g.rowptr, g.col, g.val, node_w, g.n_rows, u[s:s + _STREAM_CHUNK].contiguous(),
-                            v[s:s + _STREAM_CHUNK].contiguous(), want_count=want_count, want_cn=want_cn)
+                            v[s:s + _STREAM_CHUNK].contiguous(), want_count=want_count, want_cn=want_cn,
+                            grouped=grouped)
         for k in range(3):
             if r[k] is not None:
                 outs[k].append(r[k])

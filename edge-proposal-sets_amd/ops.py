@@ -78,9 +78,25 @@ def node_weights(colsum: torch.Tensor, mode: int, f64: bool = False) -> torch.Te
     return out
 
 
-def pair_scores(rowptr, col, val, node_w, n_nodes: int, u, v, want_count=True, want_cn=True, want_wsum=None):
+GROUPED_MIN_RUN = 256  # mean pairs per run of equal v above which the column-run kernel is used
+
+
+def v_runs_are_long(v: torch.Tensor) -> bool:
+    """True when ``v`` (the reference's column-major candidate order) has runs long enough for the
+    column-run kernel to pay: one elementwise pass + a reduction on the device."""
+    n = v.numel()
+    if n < 4 * GROUPED_MIN_RUN:
+        return False
+    n_runs = int((v[1:] != v[:-1]).sum().item()) + 1
+    return n >= n_runs * GROUPED_MIN_RUN
+
+
+def pair_scores(rowptr, col, val, node_w, n_nodes: int, u, v, want_count=True, want_cn=True, want_wsum=None,
+                grouped=None):
     """-> (count int32[E] | None, cn float32[E] | None, wsum float32/float64[E] | None).
-    node_w float64 selects the float64-accumulate kernel (cn is then not produced)."""
+    node_w float64 selects the float64-accumulate kernel (cn is then not produced).
+    ``grouped``: True -> column-run kernel (pair list sorted by v), False -> generic kernel, None -> decide
+    from the run statistics of ``v``.  Results are identical either way."""
     dev = _need_gpu(rowptr, col, val, node_w, u, v)
     _chk(rowptr, torch.int64, "rowptr"); _chk(col, torch.int32, "col"); _chk(val, torch.float32, "val")
     _chk(u, torch.int32, "u"); _chk(v, torch.int32, "v")
@@ -90,18 +106,22 @@ def pair_scores(rowptr, col, val, node_w, n_nodes: int, u, v, want_count=True, w
         want_wsum = node_w is not None
     n = u.numel()
     lib = _lib.load()
+    if grouped is None:
+        grouped = v_runs_are_long(v)
     count = torch.empty(n, dtype=torch.int32, device=dev) if want_count else None
     with torch.cuda.device(dev):
         if node_w is not None and node_w.dtype == torch.float64:
             ws = torch.empty(n, dtype=torch.float64, device=dev) if want_wsum else None
-            _lib.check(lib.eps_pair_scores_f64(_ptr(rowptr), _ptr(col), _ptr(val), _ptr(node_w), n_nodes, _ptr(u),
-                                               _ptr(v), n, _ptr(count), _ptr(ws), _stream(dev)), "eps_pair_scores_f64")
+            fn = lib.eps_pair_scores_grouped_f64 if grouped else lib.eps_pair_scores_f64
+            _lib.check(fn(_ptr(rowptr), _ptr(col), _ptr(val), _ptr(node_w), n_nodes, _ptr(u), _ptr(v), n, _ptr(count),
+                          _ptr(ws), _stream(dev)), "eps_pair_scores_f64")
             return count, None, ws
         _chk(node_w, torch.float32, "node_w")
         cn = torch.empty(n, dtype=torch.float32, device=dev) if want_cn else None
         ws = torch.empty(n, dtype=torch.float32, device=dev) if want_wsum else None
-        _lib.check(lib.eps_pair_scores(_ptr(rowptr), _ptr(col), _ptr(val), _ptr(node_w), n_nodes, _ptr(u), _ptr(v),
-                                       n, _ptr(count), _ptr(cn), _ptr(ws), _stream(dev)), "eps_pair_scores")
+        fn = lib.eps_pair_scores_grouped if grouped else lib.eps_pair_scores
+        _lib.check(fn(_ptr(rowptr), _ptr(col), _ptr(val), _ptr(node_w), n_nodes, _ptr(u), _ptr(v), n, _ptr(count),
+                      _ptr(cn), _ptr(ws), _stream(dev)), "eps_pair_scores")
     return count, cn, ws
 
 

@@ -75,6 +75,20 @@ int eps_pair_scores_f64(const int64_t *rowptr, const int32_t *col, const float *
                         const int32_t *v, int64_t n_pairs, int32_t *count, double *wsum,
                         void *stream);
 
+/* Column-run variant of the two calls above, same arguments and results, for pair lists in the
+ * reference's candidate order (filter.py:96-109: column-major, long runs of equal v): the
+ * neighbourhood of the run's v is kept as an LDS bitmap and every pair costs one read of row u.
+ * Correct for ANY list (pairs off the chunk's run take an in-place search) but only fast when v
+ * has runs of hundreds of pairs or more; the Python host picks it from the run statistics. */
+int eps_pair_scores_grouped(const int64_t *rowptr, const int32_t *col, const float *val,
+                            const float *node_w, int64_t n_nodes, const int32_t *u,
+                            const int32_t *v, int64_t n_pairs, int32_t *count, float *cn,
+                            float *wsum, void *stream);
+int eps_pair_scores_grouped_f64(const int64_t *rowptr, const int32_t *col, const float *val,
+                                const double *node_w, int64_t n_nodes, const int32_t *u,
+                                const int32_t *v, int64_t n_pairs, int32_t *count, double *wsum,
+                                void *stream);
+
 /* ---- K4/K5: CSR x dense SpMM with fused epilogue -----------------------------------------
  * Replaces torch_sparse spmm_sum / spmm_mean inside GCNConv / SAGEConv (models.py:183-186,
  * :436-439) plus the bias add and the ReLU of the layer loop.

@@ -83,11 +83,57 @@ def test_vs_oracle_seeded(eps, oracle, dev, n, deg, weighted, hub):
     from eps_amd.heuristics import node_weight_table
     wt = node_weight_table(g, eps.ops.W_AA)
     assert rel_err(wt.cpu().numpy(), w) <= 1e-6
-    cnt, cn, ws = eps.ops.pair_scores(g.rowptr, g.col, g.val, wt, n, u, v)
-    assert np.array_equal(cnt.cpu().numpy(), cnt_o)
-    assert np.array_equal(cn.cpu().numpy(), cn_o)
-    assert rel_err(ws.cpu().numpy(), ws_o) <= TOL
+    for grouped in (False, True):       # the column-run kernel must be right on an UNSORTED list too
+        cnt, cn, ws = eps.ops.pair_scores(g.rowptr, g.col, g.val, wt, n, u, v, grouped=grouped)
+        assert np.array_equal(cnt.cpu().numpy(), cnt_o)
+        assert np.array_equal(cn.cpu().numpy(), cn_o)
+        assert rel_err(ws.cpu().numpy(), ws_o) <= TOL
     assert cnt_o.max() > 0
+    # sorted by v (the reference's candidate order): long runs -> auto-selects the column-run kernel
+    order = np.lexsort((pairs[0], pairs[1] % 37))   # 37 distinct columns -> runs of ~1900 pairs
+    ps = pairs[:, order].copy(); ps[1] = ps[1] % 37
+    cnt_s, cn_s, ws_s = oracle.pair_scores(rp, col, val, w, ps[0], ps[1])
+    us, vs = torch.from_numpy(ps[0]).to(dev), torch.from_numpy(ps[1]).to(dev)
+    assert eps.ops.v_runs_are_long(vs) and not eps.ops.v_runs_are_long(v)
+    cnt, cn, ws = eps.ops.pair_scores(g.rowptr, g.col, g.val, wt, n, us, vs)
+    assert np.array_equal(cnt.cpu().numpy(), cnt_s) and np.array_equal(cn.cpu().numpy(), cn_s)
+    # this list pairs the 15000-neighbour hub with itself: a 15000-term float32 sum, where the ORACLE's sequential
+    # accumulation is itself ~7e-5 off.  Gate the kernel against the float64-accumulated value instead, and the
+    # float32 oracle only where both agree (short sums).
+    _, truth = oracle.pair_scores_f64(rp, col, val, w.astype(np.float64), ps[0], ps[1])
+    assert rel_err(ws.cpu().numpy(), truth.astype(np.float32)) <= TOL
+    short = cnt_s <= 512
+    assert rel_err(ws.cpu().numpy()[short], ws_s[short]) <= TOL
+    w64 = oracle.node_weights(cs.astype(np.float64), oracle.W_RA)
+    _, ws64_o = oracle.pair_scores_f64(rp, col, val, w64, ps[0], ps[1])
+    _, _, ws64 = eps.ops.pair_scores(g.rowptr, g.col, g.val, torch.from_numpy(w64).to(dev), n, us, vs, grouped=True)
+    assert rel_err(ws64.cpu().numpy(), ws64_o) <= 1e-12
+
+
+def test_grouped_hashed_bitmap_large_id_space(eps, oracle, dev):
+    """N > 2^20 nodes: the LDS bitmap is hashed (w & mask) and every positive is verified in row v."""
+    from eps_amd import synth
+    g = synth.rmat_graph(scale=21, edge_factor=2, seed=11, device=dev)
+    n = g.n_rows
+    assert n > (1 << 20)
+    rng = np.random.default_rng(0)
+    deg = g.degree().cpu().numpy()
+    hubs = np.argsort(-deg)[:8].astype(np.int32)                    # columns with large neighbourhoods
+    u = rng.integers(0, n, 40000).astype(np.int32)
+    u[:4000] = rng.choice(np.argsort(-deg)[:2000], 4000)            # some high-degree rows too
+    v = np.repeat(hubs, 5000)
+    rp, col = g.rowptr.cpu().numpy(), g.col.cpu().numpy()
+    w = oracle.node_weights(oracle.col_sums(rp, col, None, n), oracle.W_AA)
+    cnt_o, _, ws_o = oracle.pair_scores(rp, col, None, w, u, v)
+    cnt, _, ws = eps.ops.pair_scores(g.rowptr, g.col, None, torch.from_numpy(w).to(dev), n, torch.from_numpy(u).to(dev),
+                                     torch.from_numpy(v).to(dev), want_cn=False, grouped=True)
+    assert np.array_equal(cnt.cpu().numpy(), cnt_o) and cnt_o.sum() > 0
+    # hub x hub intersections are thousands of terms long: gate against the float64-accumulated value
+    # (the float32 sequential oracle is itself ~1e-4 off there), and against the float32 oracle on short sums
+    _, truth = oracle.pair_scores_f64(rp, col, None, w.astype(np.float64), u, v)
+    assert rel_err(ws.cpu().numpy(), truth.astype(np.float32)) <= TOL
+    short = cnt_o <= 512
+    assert rel_err(ws.cpu().numpy()[short], ws_o[short]) <= TOL
 
 
 def test_empty_and_tiny(eps, dev):
