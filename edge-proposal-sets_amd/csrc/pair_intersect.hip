@@ -295,7 +295,7 @@ extern "C" int eps_node_weights_f64(const float *colsum, int64_t n, int mode, do
 // =====================================================================================
 #define PG_THREADS 1024
 #define PG_WAVES (PG_THREADS / 64)
-#define PG_CHUNK 4096
+#define PG_CHUNK 16384
 #define PG_QCAP 512             // per-wave hit queue entries (2 KiB)
 #define PG_MAX_WORDS (1 << 15)  // 2^20 bits = 128 KiB
 #ifndef PG_RING
@@ -471,18 +471,44 @@ __global__ __launch_bounds__(PG_THREADS) void pair_scores_grouped_kernel(
     STAMP(t_begin);
 #endif
 
-    // Chunks are handed out dynamically (one device-scope atomic per 4096 pairs): a column's cost follows the degrees
+    // Chunks are handed out dynamically (one device-scope atomic per chunk): a column's cost follows the degrees
     // of its candidates, so a static split leaves the slowest workgroup running ~1.5x longer than the average one.
-    __shared__ unsigned int s_chunk;
+    // Inside a chunk the 64-pair groups are handed out dynamically too (LDS counter): group costs are heavy-tailed
+    // (a few rows hold >10k entries), and a static split left the waves idle at the chunk barrier half of the time.
+    __shared__ unsigned int s_chunk, s_group, s_first;
     for (;;) {
-        __syncthreads();  // every wave is done with the previous chunk (bitmap + s_chunk)
+        __syncthreads();  // every wave is done with the previous chunk
         if (tid == 0) s_chunk = atomicAdd(next_chunk, 1u);
         __syncthreads();
         const int64_t chunk = s_chunk;
         if (chunk >= n_chunks) break;
         const int64_t c0 = chunk * PG_CHUNK;
-        const int64_t c1 = (c0 + PG_CHUNK) < n_pairs ? (c0 + PG_CHUNK) : n_pairs;
-        const int32_t v0 = pv[c0];
+        const int64_t cend = (c0 + PG_CHUNK) < n_pairs ? (c0 + PG_CHUNK) : n_pairs;
+      // A chunk is cut into SEGMENTS at the column boundaries it contains (runs of equal v): each segment gets its own
+      // bitmap, so a pair only leaves the bitmap path when the list is not grouped by v at all.
+      for (int64_t seg = c0; seg < cend;) {
+        const int32_t v0 = pv[seg];
+        __syncthreads();  // every wave is done with the previous segment (bitmap, s_group, s_first)
+        if (tid == 0) {
+            s_group = 0u;
+            s_first = (unsigned int)(cend - seg);
+        }
+        __syncthreads();
+        {   // first index of the segment whose v differs from v0: every thread scans a short stretch
+            const int len = (int)(cend - seg);
+            const int stride = (len + PG_THREADS - 1) / PG_THREADS;
+            for (int k = 0; k < stride; ++k) {
+                const int off = tid * stride + k;
+                if (off < len && pv[seg + off] != v0) {
+                    atomicMin(&s_first, (unsigned int)off);
+                    break;
+                }
+            }
+        }
+        __syncthreads();
+        const int64_t c0s = seg;                 // this segment: pairs [c0s, c1)
+        const int64_t c1 = seg + (int64_t)s_first;
+        seg = c1;
         const int64_t vb = rowptr[v0];
         const int32_t dv = (int32_t)(rowptr[v0 + 1] - vb);
         const int32_t *__restrict__ vcol = col + vb;
@@ -502,7 +528,11 @@ __global__ __launch_bounds__(PG_THREADS) void pair_scores_grouped_kernel(
         STAMP(tb2);
         STAMP_ADD(1, tb1, tb2);  // 1: bitmap rebuild
 
-        for (int64_t g0 = c0 + wib * 64; g0 < c1; g0 += PG_WAVES * 64) {
+        for (;;) {
+            unsigned int gi = 0;
+            if (lane == 0) gi = atomicAdd(&s_group, 1u);
+            const int64_t g0 = c0s + (int64_t)__builtin_amdgcn_readfirstlane(gi) * 64;
+            if (g0 >= c1) break;
             STAMP(tg0);
             const int64_t p = g0 + lane;
             const bool valid = p < c1;
@@ -695,6 +725,7 @@ __global__ __launch_bounds__(PG_THREADS) void pair_scores_grouped_kernel(
                 if (HAS_W && out_ws) out_ws[p] = my_ws;
             }
         }
+      }
     }
 #ifdef PG_STAMP
     STAMP(t_end);
