@@ -181,7 +181,11 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "kernel": "pair_scores_grouped_kernel<false,true,float,true>", "kernel_ms": kern_ms,
-                         "algorithmic_bytes_per_launch": abytes},
+                         "algorithmic_bytes_per_launch": abytes,
+                         "note": "algorithmic bytes (SURVEY 8d) charge BOTH adjacency rows to every pair; the column-run "
+                                 "kernel keeps N(v) as an LDS bitmap and reads row v once per column segment, so frac can "
+                                 "exceed 1; `traffic` is the measured fabric-side bytes per launch (rocprofv3 PMC, "
+                                 "profiles/r01/pair_scores_grouped_pmc.json)"},
         }
         if world == 1 and not args.no_cpu:
             line["cpu_baseline"] = cpu_baseline(g, u, v, ws, torch)

@@ -295,7 +295,9 @@ extern "C" int eps_node_weights_f64(const float *colsum, int64_t n, int mode, do
 // =====================================================================================
 #define PG_THREADS 1024
 #define PG_WAVES (PG_THREADS / 64)
+#ifndef PG_CHUNK
 #define PG_CHUNK 16384
+#endif
 #define PG_QCAP 512             // per-wave hit queue entries (2 KiB)
 #define PG_MAX_WORDS (1 << 15)  // 2^20 bits = 128 KiB
 #ifndef PG_RING
