@@ -5,20 +5,21 @@
 // per candidate edge out.  Dropout is the identity in eval mode (models.py:483 with
 // training=False), which is the only mode the scoring path runs in.
 //
-// One 256-thread workgroup per CU walks 64-edge tiles (persistent, grid-stride):
-//   1. gather: each wave builds 16 rows of X = h[u] (.) h[v] straight into LDS (one coalesced
-//      1-KiB row read per endpoint, float4 per lane);
+// One 512-thread workgroup (8 waves, two per SIMD) per CU walks 64-edge tiles (persistent):
+//   1. gather: each wave builds 8 rows of X = h[u] (.) h[v] straight into LDS (one coalesced
+//      1-KiB row read per endpoint, float4 per lane, all 16 reads of a wave in flight at once);
 //   2. hidden layers: X[64,H] stays in LDS; W_l streams through LDS in K-chunks of 32
-//      (register-staged double buffer, one barrier per chunk); each wave owns H/4 output
-//      columns as 2x2 MFMA 32x32 tiles (64 accumulator registers); bias + ReLU are applied in
-//      the accumulators and written back over X -- activations never leave the CU;
-//   3. last layer (H -> 1) is a 4-lanes-per-row dot product over the LDS tile + sigmoid.
+//      (register-staged double buffer, one barrier per chunk); each wave owns 32 rows x 2 MFMA
+//      32x32 column tiles (32 accumulator registers); bias + ReLU are applied in the
+//      accumulators and written back over X -- activations never leave the CU;
+//   3. last layer (H -> 1) is an 8-lanes-per-row dot product over the LDS tile + sigmoid.
 // f32 in, f32 accumulate (v_mfma_f32_32x32x2_f32 == fmaf chain): the 1e-5 parity gate rules out
 // bf16/"xf32" shortcuts (and gfx950 has no xf32).
 #include "eps_common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float v4f __attribute__((ext_vector_type(4)));  // native vector: stays in VGPRs (HIP's float4 struct copies lower to memcpy -> scratch)
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef int v4i __attribute__((ext_vector_type(4)));  // native vector: stays in VGPRs (HIP's float4 struct copies lower to memcpy -> scratch)
 
 #define D_BM 64        // edges per tile
 #define D_HMAX 256     // widest hidden size held in LDS
@@ -42,46 +43,52 @@ __device__ __forceinline__ const float *pick(const float *const (&a)[D_MAXL], in
     return p;
 }
 
-__device__ __forceinline__ void w_gload(v4f (&rw)[8], const float *__restrict__ W, int H, int tid, int kc)
+#define D_THREADS 512  // 8 waves = two per SIMD: one wave's LDS/barrier stalls are covered by its SIMD partner's MFMAs
+#define D_WREGS (D_HMAX * (D_BK / 4) / D_THREADS)  // float4 of a W chunk staged per thread (4)
+
+// W chunk kc = rows [0,Hp) x cols [kc*32, kc*32+32) of the row-major [H,H] weight, staged global -> registers ->
+// LDS.  Raw buffer loads over the H*H matrix: rows >= H fall outside the descriptor and read as zeros with no branch;
+// columns >= H (only when H is not a multiple of 32) are pushed out of range by a select on the offset.  Keeping
+// the staging free of exec-mask branches is what lets hipcc issue the loads back to back instead of load-wait pairs.
+__device__ __forceinline__ void w_gload(v4f (&rw)[D_WREGS], __amdgpu_buffer_rsrc_t wr, int H, int tid, int kc)
 {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int q = tid + 256 * i;
+    for (int i = 0; i < D_WREGS; ++i) {
+        const int q = tid + D_THREADS * i;
         const int row = q >> 3, c4 = q & 7;
-        const int rowc = row < H ? row : H - 1;  // clamped duplicate read instead of a guarded def
         const int kcol = kc * D_BK + c4 * 4;     // H % 4 == 0: a float4 is entirely inside or outside [0,H)
-        const int kc_ = kcol < H ? kcol : 0;
-        v4f t = *reinterpret_cast<const v4f *>(W + (int64_t)rowc * H + kc_);
-        if (kcol >= H || row >= H) t = (v4f){0.f, 0.f, 0.f, 0.f};  // zero padding up to the next multiple of 32
-        rw[i] = t;
+        const int off = (row * H + kcol) * 4;
+        rw[i] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(wr, kcol < H ? off : 0x7ffffff0, 0, 0));
     }
 }
 
-__device__ __forceinline__ void w_lstore(const v4f (&rw)[8], float (*Wb)[D_WLD], int Hp, int tid)
+__device__ __forceinline__ void w_lstore(const v4f (&rw)[D_WREGS], float (*Wb)[D_WLD], int tid)
 {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int q = tid + 256 * i;
+    for (int i = 0; i < D_WREGS; ++i) {
+        const int q = tid + D_THREADS * i;
         const int row = q >> 3, c4 = q & 7;
-        if (row < Hp) *reinterpret_cast<v4f *>(&Wb[row][c4 * 4]) = rw[i];
+        *reinterpret_cast<v4f *>(&Wb[row][c4 * 4]) = rw[i];  // all D_HMAX rows: rows >= H carry zeros
     }
 }
 
-__global__ __launch_bounds__(256) void mlp_decode_kernel(const float *__restrict__ hmat, int32_t H,
-                                                         const int32_t *__restrict__ pu,
-                                                         const int32_t *__restrict__ pv, int64_t n_pairs,
-                                                         DecodeParams prm, int32_t n_layers, int apply_sigmoid,
-                                                         float *__restrict__ out)
+__global__ __launch_bounds__(D_THREADS) void mlp_decode_kernel(const float *__restrict__ hmat, int32_t H,
+                                                               const int32_t *__restrict__ pu,
+                                                               const int32_t *__restrict__ pv, int64_t n_pairs,
+                                                               DecodeParams prm, int32_t n_layers, int apply_sigmoid,
+                                                               float *__restrict__ out)
 {
     __shared__ __attribute__((aligned(16))) float Xs[D_BM][D_XLD];
     __shared__ __attribute__((aligned(16))) float Ws[2][D_HMAX][D_WLD];
 
     const int tid = threadIdx.x;
-    const int lane = tid & 63, w = tid >> 6;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform -> scalar branches, no exec masking
     const int r = lane & 31, hh = lane >> 5;
+    const int wm = w >> 2, wn = w & 3;      // wave -> rows [32*wm, +32), column tiles wn and wn+4
     const int Hp = (H + 31) & ~31;          // H padded to the MFMA tile width; pad columns are kept at zero
     const int n_ntiles = Hp >> 5;           // 32-column output tiles (<= 8)
-    const int t0 = w, t1 = w + 4;           // the (up to) two column tiles this wave owns
+    const int t0 = wn, t1 = wn + 4;
     const bool has0 = t0 < n_ntiles, has1 = t1 < n_ntiles;
     const int nk = Hp / D_BK;
     const int64_t n_tiles = (n_pairs + D_BM - 1) / D_BM;
@@ -90,25 +97,24 @@ __global__ __launch_bounds__(256) void mlp_decode_kernel(const float *__restrict
 
     for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const int64_t e0 = tile * D_BM;
-        // ---- 1. gather + Hadamard into LDS ------------------------------------------------
+        // ---- 1. gather + Hadamard into LDS: wave w builds rows 8w..8w+7, all 16 row reads in flight at once ----
         {
             const int64_t p = e0 + lane;
             const int32_t mu = p < n_pairs ? pu[p] : 0, mv = p < n_pairs ? pv[p] : 0;
-            for (int i = 0; i < 16; i += 2) {
-                const int row0 = w * 16 + i, row1 = row0 + 1;
-                const int64_t u0 = __builtin_amdgcn_readlane(mu, row0), v0 = __builtin_amdgcn_readlane(mv, row0);
-                const int64_t u1 = __builtin_amdgcn_readlane(mu, row1), v1 = __builtin_amdgcn_readlane(mv, row1);
-                for (int c = h4 + lane; c < hp4; c += 64) {
-                    *reinterpret_cast<float4 *>(&Xs[row0][4 * c]) = make_float4(0.f, 0.f, 0.f, 0.f);
-                    *reinterpret_cast<float4 *>(&Xs[row1][4 * c]) = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int c = lane; c < hp4; c += 64) {
+                v4f a[8], b[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int64_t un = __builtin_amdgcn_readlane(mu, w * 8 + i), vn = __builtin_amdgcn_readlane(mv, w * 8 + i);
+                    const int cc = c < h4 ? c : 0;
+                    a[i] = *reinterpret_cast<const v4f *>(hmat + un * H + 4 * cc);
+                    b[i] = *reinterpret_cast<const v4f *>(hmat + vn * H + 4 * cc);
                 }
-                for (int c = lane; c < h4; c += 64) {
-                    const float4 a0 = *reinterpret_cast<const float4 *>(hmat + u0 * H + 4 * c);
-                    const float4 b0 = *reinterpret_cast<const float4 *>(hmat + v0 * H + 4 * c);
-                    const float4 a1 = *reinterpret_cast<const float4 *>(hmat + u1 * H + 4 * c);
-                    const float4 b1 = *reinterpret_cast<const float4 *>(hmat + v1 * H + 4 * c);
-                    *reinterpret_cast<float4 *>(&Xs[row0][4 * c]) = make_float4(a0.x * b0.x, a0.y * b0.y, a0.z * b0.z, a0.w * b0.w);
-                    *reinterpret_cast<float4 *>(&Xs[row1][4 * c]) = make_float4(a1.x * b1.x, a1.y * b1.y, a1.z * b1.z, a1.w * b1.w);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    v4f pr = a[i] * b[i];
+                    if (c >= h4) pr = (v4f){0.f, 0.f, 0.f, 0.f};  // pad columns
+                    *reinterpret_cast<v4f *>(&Xs[w * 8 + i][4 * c]) = pr;
                 }
             }
         }
@@ -118,48 +124,48 @@ __global__ __launch_bounds__(256) void mlp_decode_kernel(const float *__restrict
         for (int l = 0; l + 1 < n_layers; ++l) {
             const float *__restrict__ W = pick(prm.w, l);
             const float *__restrict__ Bv = pick(prm.b, l);
-            f32x16 acc[2][2];
+            f32x16 acc[2];
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+                for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
 
-            v4f rw[8];
-            // W chunk = rows [0,H) x cols [kc*32, kc*32+32): H*8 float4, 8 per thread at H = 256
-            w_gload(rw, W, H, tid, 0);
-            w_lstore(rw, Ws[0], Hp, tid);
+            const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void *)W, 0, H * H * 4, 0x00020000);
+            v4f rw[D_WREGS];
+            w_gload(rw, wr, H, tid, 0);
+            w_lstore(rw, Ws[0], tid);
             __syncthreads();
             for (int kc = 0; kc < nk; ++kc) {
                 const int buf = kc & 1;
-                if (kc + 1 < nk) w_gload(rw, W, H, tid, kc + 1);
+                if (kc + 1 < nk) w_gload(rw, wr, H, tid, kc + 1);
+                // all fragment reads of the chunk are issued up front (A: 4, B: 4 per column tile); the MFMAs then
+                // drain them in order behind counted lgkmcnt waits
+                float4 af[4], bf0[4], bf1[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) af[j] = *reinterpret_cast<const float4 *>(&Xs[wm * 32 + r][kc * D_BK + 8 * j + 4 * hh]);
+                if (has0) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) bf0[j] = *reinterpret_cast<const float4 *>(&Ws[buf][t0 * 32 + r][8 * j + 4 * hh]);
+                }
+                if (has1) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) bf1[j] = *reinterpret_cast<const float4 *>(&Ws[buf][t1 * 32 + r][8 * j + 4 * hh]);
+                }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const int ko = 8 * j + 4 * hh;
-                    const float4 a0 = *reinterpret_cast<const float4 *>(&Xs[r][kc * D_BK + ko]);
-                    const float4 a1 = *reinterpret_cast<const float4 *>(&Xs[32 + r][kc * D_BK + ko]);
-                    const float av0[4] = {a0.x, a0.y, a0.z, a0.w}, av1[4] = {a1.x, a1.y, a1.z, a1.w};
+                    const float av[4] = {af[j].x, af[j].y, af[j].z, af[j].w};
                     if (has0) {
-                        const float4 b0 = *reinterpret_cast<const float4 *>(&Ws[buf][t0 * 32 + r][ko]);
-                        const float bv0[4] = {b0.x, b0.y, b0.z, b0.w};
+                        const float bv[4] = {bf0[j].x, bf0[j].y, bf0[j].z, bf0[j].w};
 #pragma unroll
-                        for (int s = 0; s < 4; ++s) {
-                            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[s], bv0[s], acc[0][0], 0, 0, 0);
-                            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[s], bv0[s], acc[1][0], 0, 0, 0);
-                        }
+                        for (int ss = 0; ss < 4; ++ss) acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ss], bv[ss], acc[0], 0, 0, 0);
                     }
                     if (has1) {
-                        const float4 b1 = *reinterpret_cast<const float4 *>(&Ws[buf][t1 * 32 + r][ko]);
-                        const float bv1[4] = {b1.x, b1.y, b1.z, b1.w};
+                        const float bv[4] = {bf1[j].x, bf1[j].y, bf1[j].z, bf1[j].w};
 #pragma unroll
-                        for (int s = 0; s < 4; ++s) {
-                            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[s], bv1[s], acc[0][1], 0, 0, 0);
-                            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[s], bv1[s], acc[1][1], 0, 0, 0);
-                        }
+                        for (int ss = 0; ss < 4; ++ss) acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ss], bv[ss], acc[1], 0, 0, 0);
                     }
                 }
-                if (kc + 1 < nk) w_lstore(rw, Ws[buf ^ 1], Hp, tid);
+                if (kc + 1 < nk) w_lstore(rw, Ws[buf ^ 1], tid);
                 __syncthreads();
             }
             // every wave has finished reading X (barrier above): overwrite it with relu(acc + b)
@@ -170,23 +176,21 @@ __global__ __launch_bounds__(256) void mlp_decode_kernel(const float *__restrict
                 const int cc = (ni == 0 ? t0 : t1) * 32 + r;
                 const float bv = cc < H ? Bv[cc] : 0.f;
 #pragma unroll
-                for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        const int rr = mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
-                        const float t = acc[mi][ni][e] + bv;
-                        Xs[rr][cc] = t > 0.f ? t : 0.f;
-                    }
+                for (int e = 0; e < 16; ++e) {
+                    const int rr = wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+                    const float t = acc[ni][e] + bv;
+                    Xs[rr][cc] = t > 0.f ? t : 0.f;
+                }
             }
             __syncthreads();
         }
 
-        // ---- 3. last layer: H -> 1, sigmoid ---------------------------------------------------
+        // ---- 3. last layer: H -> 1, sigmoid (8 lanes per row) ---------------------------------------
         {
             const float *__restrict__ wl = pick(prm.w, n_layers - 1);
-            const int row = tid >> 2, part = tid & 3;
+            const int row = tid >> 3, part = tid & 7;
             float s = 0.f;
-            for (int c = part; c < h4; c += 4) {
+            for (int c = part; c < h4; c += 8) {
                 const float4 x = *reinterpret_cast<const float4 *>(&Xs[row][4 * c]);
                 const float4 q = *reinterpret_cast<const float4 *>(wl + 4 * c);
                 s = fmaf(x.x, q.x, s);
@@ -194,8 +198,9 @@ __global__ __launch_bounds__(256) void mlp_decode_kernel(const float *__restrict
                 s = fmaf(x.z, q.z, s);
                 s = fmaf(x.w, q.w, s);
             }
-            s += eps_dpp_f<0xB1>(s);  // quad_perm [1,0,3,2]
-            s += eps_dpp_f<0x4E>(s);  // quad_perm [2,3,0,1]
+            s += eps_dpp_f<0xB1>(s);   // quad_perm [1,0,3,2]
+            s += eps_dpp_f<0x4E>(s);   // quad_perm [2,3,0,1]
+            s += eps_dpp_f<0x141>(s);  // row_half_mirror: the other quad of the 8-lane group
             const int64_t p = e0 + row;
             if (part == 0 && p < n_pairs) {
                 float z = s + pick(prm.b, n_layers - 1)[0];
@@ -230,7 +235,7 @@ extern "C" int eps_mlp_decode(const float *h, int64_t n_nodes, int32_t hdim, con
     const int64_t n_tiles = (n_pairs + D_BM - 1) / D_BM;
     int64_t blocks = eps_num_cus();
     if (blocks > n_tiles) blocks = n_tiles;
-    hipLaunchKernelGGL(mlp_decode_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, h, hdim, u, v,
+    hipLaunchKernelGGL(mlp_decode_kernel, dim3((unsigned)blocks), dim3(D_THREADS), 0, (hipStream_t)stream, h, hdim, u, v,
                        n_pairs, prm, n_layers, apply_sigmoid, out);
     EPS_CHECK_LAUNCH("eps_mlp_decode");
     return EPS_OK;

@@ -1,0 +1,77 @@
+#!/usr/bin/env python3
+"""Secondary measurements (BASELINE configs[1]/[3]): SpMM (GCN/SAGE aggregate), f32-MFMA GEMM, fused decode,
+and the whole GCN-filter scoring pass on the ppa-like graph (N=576,289, H=256, L=3).  One JSON line each."""
+import json, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import eps_amd
+from eps_amd import models, ops, synth
+
+dev = torch.device("cuda:0")
+g = synth.ppa_like(seed=3, device=dev)
+N, nnz, H, L = g.n_rows, g.nnz(), 256, 3
+gen = torch.Generator(device=dev).manual_seed(0)
+
+
+def timeit(fn, iters=10, warm=2):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / iters
+
+
+x = torch.randn(N, H, generator=gen, device=dev)
+gn = g.gcn_normalized()
+bias = torch.randn(H, generator=gen, device=dev)
+ms = timeit(lambda: ops.spmm_csr(gn.rowptr, gn.col, gn.val, x, bias=bias, relu=True))
+comp = gn.nnz() * 8 + (N + 1) * 8 + 2 * N * H * 4
+gath = gn.nnz() * H * 4 + gn.nnz() * 8 + N * H * 4
+print(json.dumps({"kernel": "spmm_csr (GCN aggregate, F=256, ppa-like)", "ms": ms, "compulsory_GBps": comp / ms / 1e6,
+                  "gather_model_GBps": gath / ms / 1e6, "frac_of_8TBps_compulsory": comp / ms / 1e6 / 8000,
+                  "frac_of_8TBps_gather": gath / ms / 1e6 / 8000, "nnz": gn.nnz()}))
+ms = timeit(lambda: ops.spmm_csr(g.rowptr, g.col, None, x, mean=True))
+comp = nnz * 4 + (N + 1) * 8 + 2 * N * H * 4
+gath = nnz * H * 4 + nnz * 4 + N * H * 4
+print(json.dumps({"kernel": "spmm_csr (SAGE mean, F=256)", "ms": ms, "compulsory_GBps": comp / ms / 1e6,
+                  "gather_model_GBps": gath / ms / 1e6, "frac_of_8TBps_gather": gath / ms / 1e6 / 8000}))
+
+for K in (256, 316):
+    a = torch.randn(N, K, generator=gen, device=dev)
+    w = torch.randn(H, K, generator=gen, device=dev)
+    ms = timeit(lambda: ops.gemm(a, w, bias=bias, relu=True))
+    fl = 2.0 * N * H * K
+    print(json.dumps({"kernel": f"gemm_f32 [{N}x{K}]x[{K}x{H}]", "ms": ms, "TFLOPs": fl / ms / 1e9, "frac_of_157.3": fl / ms / 1e9 / 157.3}))
+
+E = 1 << 22
+u = torch.randint(0, N, (E,), generator=gen, device=dev, dtype=torch.int32)
+v = torch.randint(0, N, (E,), generator=gen, device=dev, dtype=torch.int32)
+for nl in (2, 3):
+    ws = [torch.randn(H if i < nl - 1 else 1, H, generator=gen, device=dev) / 16 for i in range(nl)]
+    bs = [torch.randn(H if i < nl - 1 else 1, generator=gen, device=dev) for i in range(nl)]
+    ms = timeit(lambda: ops.mlp_decode(x, u, v, ws, bs))
+    fl = E * (H + 2.0 * H * H * (nl - 1) + 2 * H)
+    print(json.dumps({"kernel": f"mlp_decode H=256 L={nl} ({E} random edges)", "ms": ms, "edges_per_s": E / ms * 1e3,
+                      "TFLOPs": fl / ms / 1e9, "frac_of_157.3": fl / ms / 1e9 / 157.3}))
+
+# whole GCN forward (3 layers, in = 58 one-hot + 256 emb) + decode of 2^22 candidate edges
+feat = torch.nn.functional.one_hot(torch.randint(0, 58, (N,), generator=gen, device=dev), 58).float()
+torch.manual_seed(0)
+model = models.LinkGNN(torch.nn.Embedding(N, H), models.GCN(58 + H, H, H, L, 0.0), models.LinkPredictor(H, H, 1, L, 0.0)).to(dev).eval()
+edges = torch.stack([u, v]).long()
+def full():
+    model._h_key = None
+    return model(feat, edges, g)
+ms = timeit(full, iters=3, warm=1)
+print(json.dumps({"pipeline": "GCN(L=3,H=256) embeddings + decode of 2^22 edges, ppa-like", "ms": ms}))
+for kind in (models.GCN, models.SAGE):
+    net = kind(58 + H, H, H, L, 0.0).to(dev).eval()
+    xin = torch.cat([model.emb.weight.detach(), feat], 1)
+    ms = timeit(lambda: net(xin, g), iters=3, warm=1)
+    print(json.dumps({"pipeline": f"{kind.__name__} forward L=3 H=256 in=314, ppa-like", "ms": ms}))
