@@ -21,22 +21,39 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define G_BK 32
 #define G_LD 36
 
-__device__ __forceinline__ float4 load4_guard(const float *__restrict__ base, int64_t row, int64_t nrows, int64_t ld,
-                                              int k, int kmax, bool fast)
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+// One float4 of an operand tile through a raw buffer descriptor that covers rows [row0, nrows) of the matrix:
+// rows past the end fall outside the descriptor and read as zeros (no exec-mask branch), the K tail is pushed out
+// of range by a select on the offset.  `fast` == rows 16-byte aligned (ld % 4 == 0); otherwise four dword loads.
+__device__ __forceinline__ v4f tile_load4(__amdgpu_buffer_rsrc_t rs, int row, int ld, int k, int kmax, bool fast)
 {
-    float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (row < nrows) {
-        const float *p = base + row * ld + k;
-        if (fast && k + 3 < kmax) {
-            r = *reinterpret_cast<const float4 *>(p);
-        } else {
-            if (k + 0 < kmax) r.x = p[0];
-            if (k + 1 < kmax) r.y = p[1];
-            if (k + 2 < kmax) r.z = p[2];
-            if (k + 3 < kmax) r.w = p[3];
+    const int off = (row * ld + k) * 4;
+    if (fast) {
+        v4f t = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rs, k + 3 < kmax ? off : 0x7ffffff0, 0, 0));
+        if (k < kmax && k + 3 >= kmax) {  // straddling float4 of the K tail (K % 4 != 0): element-wise
+            t.x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, off, 0, 0));
+            t.y = k + 1 < kmax ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, off + 4, 0, 0)) : 0.f;
+            t.z = k + 2 < kmax ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, off + 8, 0, 0)) : 0.f;
+            t.w = 0.f;
         }
+        return t;
     }
-    return r;
+    v4f t;
+    t.x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, k + 0 < kmax ? off : 0x7ffffff0, 0, 0));
+    t.y = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, k + 1 < kmax ? off + 4 : 0x7ffffff0, 0, 0));
+    t.z = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, k + 2 < kmax ? off + 8 : 0x7ffffff0, 0, 0));
+    t.w = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, k + 3 < kmax ? off + 12 : 0x7ffffff0, 0, 0));
+    return t;
+}
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t tile_rsrc(const float *base, int64_t row0, int64_t nrows, int64_t ld)
+{
+    int64_t bytes = (nrows - row0) * ld * 4;          // rows [row0, nrows): only the block's 128 rows are ever addressed
+    const int64_t cap = (int64_t)G_BM * ld * 4 + 64;  // ... so the descriptor never needs to exceed one tile (+ slack)
+    if (bytes > cap) bytes = cap;
+    if (bytes < 0) bytes = 0;
+    return __builtin_amdgcn_make_buffer_rsrc((void *)(base + row0 * ld), 0, (int)bytes, 0x00020000);
 }
 
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const float *__restrict__ A, int64_t lda,
@@ -49,12 +66,16 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float *__restrict__
     __shared__ __attribute__((aligned(16))) float Bs[2][G_BN][G_LD];
 
     const int tid = threadIdx.x;
-    const int lane = tid & 63, w = tid >> 6;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
     const int wm = w >> 1, wn = w & 1;
     const int n_nblk = (N + G_BN - 1) / G_BN;
     const int64_t m0 = (int64_t)(blockIdx.x / n_nblk) * G_BM;
     const int n0 = (blockIdx.x % n_nblk) * G_BN;
+    const __amdgpu_buffer_rsrc_t ra_rs = tile_rsrc(A, m0, M, lda);
+    const __amdgpu_buffer_rsrc_t rb_rs = tile_rsrc(B, n0, N, ldb);
+    const int ilda = (int)lda, ildb = (int)ldb;
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -65,43 +86,46 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float *__restrict__
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     const int nk = (K + G_BK - 1) / G_BK;
-    float4 ra[4], rb[4];
+    v4f ra[4], rb[4];
 
-    auto gload = [&](int kc) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int q = tid + 256 * i;
-            const int row = q >> 3, c4 = q & 7;
-            ra[i] = load4_guard(A, m0 + row, M, lda, kc * G_BK + c4 * 4, K, fastA);
-            rb[i] = load4_guard(B, n0 + row, N, ldb, kc * G_BK + c4 * 4, K, fastB);
-        }
-    };
-    auto lstore = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int q = tid + 256 * i;
-            const int row = q >> 3, c4 = q & 7;
-            *reinterpret_cast<float4 *>(&As[buf][row][c4 * 4]) = ra[i];
-            *reinterpret_cast<float4 *>(&Bs[buf][row][c4 * 4]) = rb[i];
-        }
-    };
+#define G_GLOAD(kc)                                                                             \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                               \
+    {                                                                                           \
+        const int q = tid + 256 * i;                                                            \
+        const int row = q >> 3, c4 = q & 7;                                                     \
+        ra[i] = tile_load4(ra_rs, row, ilda, (kc)*G_BK + c4 * 4, K, fastA);                     \
+        rb[i] = tile_load4(rb_rs, row, ildb, (kc)*G_BK + c4 * 4, K, fastB);                     \
+    }
+#define G_LSTORE(buf)                                                                           \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                               \
+    {                                                                                           \
+        const int q = tid + 256 * i;                                                            \
+        const int row = q >> 3, c4 = q & 7;                                                     \
+        *reinterpret_cast<v4f *>(&As[buf][row][c4 * 4]) = ra[i];                                \
+        *reinterpret_cast<v4f *>(&Bs[buf][row][c4 * 4]) = rb[i];                                \
+    }
 
-    gload(0);
-    lstore(0);
+    G_GLOAD(0);
+    G_LSTORE(0);
     __syncthreads();
 
     for (int kc = 0; kc < nk; ++kc) {
         const int buf = kc & 1;
-        if (kc + 1 < nk) gload(kc + 1);
+        if (kc + 1 < nk) { G_GLOAD(kc + 1); }
+        // all 16 fragment reads of the chunk up front; MFMAs drain them behind counted lgkmcnt waits
+        float4 a0[4], a1[4], b0[4], b1[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int ko = 8 * j + 4 * h;
-            const float4 a0 = *reinterpret_cast<const float4 *>(&As[buf][wm * 64 + r][ko]);
-            const float4 a1 = *reinterpret_cast<const float4 *>(&As[buf][wm * 64 + 32 + r][ko]);
-            const float4 b0 = *reinterpret_cast<const float4 *>(&Bs[buf][wn * 64 + r][ko]);
-            const float4 b1 = *reinterpret_cast<const float4 *>(&Bs[buf][wn * 64 + 32 + r][ko]);
-            const float av0[4] = {a0.x, a0.y, a0.z, a0.w}, av1[4] = {a1.x, a1.y, a1.z, a1.w};
-            const float bv0[4] = {b0.x, b0.y, b0.z, b0.w}, bv1[4] = {b1.x, b1.y, b1.z, b1.w};
+            a0[j] = *reinterpret_cast<const float4 *>(&As[buf][wm * 64 + r][ko]);
+            a1[j] = *reinterpret_cast<const float4 *>(&As[buf][wm * 64 + 32 + r][ko]);
+            b0[j] = *reinterpret_cast<const float4 *>(&Bs[buf][wn * 64 + r][ko]);
+            b1[j] = *reinterpret_cast<const float4 *>(&Bs[buf][wn * 64 + 32 + r][ko]);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float av0[4] = {a0[j].x, a0[j].y, a0[j].z, a0[j].w}, av1[4] = {a1[j].x, a1[j].y, a1[j].z, a1[j].w};
+            const float bv0[4] = {b0[j].x, b0[j].y, b0[j].z, b0[j].w}, bv1[4] = {b1[j].x, b1[j].y, b1[j].z, b1[j].w};
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[s], bv0[s], acc[0][0], 0, 0, 0);
@@ -110,9 +134,11 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float *__restrict__
                 acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[s], bv1[s], acc[1][1], 0, 0, 0);
             }
         }
-        if (kc + 1 < nk) lstore(buf ^ 1);
+        if (kc + 1 < nk) { G_LSTORE(buf ^ 1); }
         __syncthreads();
     }
+#undef G_GLOAD
+#undef G_LSTORE
 
     // epilogue: C/D map of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
 #pragma unroll
@@ -149,6 +175,7 @@ extern "C" int eps_gemm_f32(const float *a, int64_t lda, const float *b, int64_t
     const int64_t mblk = (m + G_BM - 1) / G_BM;
     const int64_t nblk = (n + G_BN - 1) / G_BN;
     EPS_REQUIRE(mblk * nblk < (1ll << 31), "eps_gemm_f32: grid too large");
+    EPS_REQUIRE(lda < (1 << 22) && ldb < (1 << 22), "eps_gemm_f32: leading dimension too large for 32-bit tile offsets");
     hipLaunchKernelGGL(gemm_f32_kernel, dim3((unsigned)(mblk * nblk)), dim3(256), 0, (hipStream_t)stream, a, lda, b,
                        ldb, bias, relu, accumulate, c, ldc, m, n, k, fastA, fastB);
     EPS_CHECK_LAUNCH("eps_gemm_f32");

@@ -35,16 +35,22 @@ def _require_eval(module: torch.nn.Module):
             "scoring path (SURVEY 8(f) row 5); call model.eval() as filter.py:90 / train_and_eval.py:100 do")
 
 
-def _pad4(x: torch.Tensor) -> torch.Tensor:
-    """Row-major [N,K] view whose row stride is a multiple of 4 floats (16-B aligned rows let the
-    GEMM stage its A operand with 16-byte loads); K itself is unchanged."""
+def _pad4_full(x: torch.Tensor):
+    """-> (view [N,K], full [N,ld]) with ld = K rounded up to a multiple of 4 floats and zero pad columns:
+    16-B aligned rows let the GEMM / SpMM kernels use 16-byte loads; K itself is unchanged."""
     n, k = x.shape
-    if x.stride(1) == 1 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0:
-        return x
     ld = (k + 3) // 4 * 4
+    if ld == k and x.is_contiguous() and x.data_ptr() % 16 == 0:
+        return x, x
     buf = torch.zeros((n, ld), dtype=torch.float32, device=x.device)
     buf[:, :k] = x
-    return buf[:, :k]
+    return buf[:, :k], buf
+
+
+def _pad4(x: torch.Tensor) -> torch.Tensor:
+    if x.dim() == 2 and x.stride(1) == 1 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0:
+        return x
+    return _pad4_full(x)[0]
 
 
 # ----------------------------------------------------------------------------------- convs
@@ -102,8 +108,9 @@ class SAGEConv(torch.nn.Module):
     @torch.no_grad()
     def forward(self, x: torch.Tensor, adj_t: CSRGraph, relu: bool = False) -> torch.Tensor:
         _require_eval(self)
-        x = _pad4(x)
-        agg = ops.spmm_csr(adj_t.rowptr, adj_t.col, None, x, mean=True)
+        k = x.shape[1]
+        x, x_full = _pad4_full(x)                      # pad columns are zero: aggregate the padded width (float4 path)
+        agg = ops.spmm_csr(adj_t.rowptr, adj_t.col, None, x_full, mean=True)[:, :k]
         out = ops.gemm(agg, self.lin_l.weight.detach(), bias=self.lin_l.bias.detach())
         return ops.gemm(x, self.lin_r.weight.detach(), out=out, accumulate=True, relu=relu)
 
