@@ -2,14 +2,16 @@
 (A @ A)[u,v] != 0, u != v, A[u,v] == 0 -- in the reference's order: column-major (v ascending,
 then u ascending), both directions present.
 
-This is SURVEY 8(f) row 1 (the step immediately before the hot path).  Round-1 form: a blocked
-expansion on device tensor ops (sort/unique per column block) that streams column blocks to the
-scoring kernels, so the full candidate set never has to exist at once (the reference materialises
-A @ A on the host: the memory wall on ppa).
+This is SURVEY 8(f) row 1 (the step immediately before the hot path).  Column blocks are streamed,
+so the full candidate set never has to exist at once (the reference materialises A @ A on the host:
+the memory wall on ppa).  On the GPU a block is produced by the fused expansion kernels
+(csrc/expand_score.hip: candidates + common-neighbour counts + weighted scores in one pass over the
+2-hop paths); graphs whose id space does not fit the LDS bitmap, and CPU tensors (tests), take the
+tensor-op expansion ``two_hop_block``.
 """
 from __future__ import annotations
 
-from typing import Iterator, Tuple
+from typing import Iterator, Optional, Tuple
 
 import torch
 
@@ -39,9 +41,57 @@ def two_hop_block(g: CSRGraph, v_lo: int, v_hi: int) -> torch.Tensor:
     return torch.stack([uu[keep], vv[keep]])
 
 
+def hip_expand_available(g: CSRGraph) -> bool:
+    if g.device.type != "cuda":
+        return False
+    from . import ops
+    return g.n_rows == g.n_cols and g.n_rows <= ops.expand_max_nodes()
+
+
+def expand_block(g: CSRGraph, v_lo: int, v_hi: int, node_w: Optional[torch.Tensor] = None, want_cn: bool = False,
+                 want_score: bool = False):
+    """Candidates of columns [v_lo, v_hi) of a SYMMETRIC adjacency, with (optionally) the common-neighbour count
+    and sum_w A[u,w]*(A[v,w]*node_w[w]) of every candidate, from ONE fused expansion.
+    -> (pairs int64 [2,E] column-major, cn int32[E] | None, score float32[E] | None)."""
+    from . import ops
+    if hip_expand_available(g):
+        _, cu, cv, cn, sc = ops.expand_candidates(g.rowptr, g.col, g.val, node_w, g.n_rows, v_lo, v_hi,
+                                                  want_cn=want_cn, want_score=want_score)
+        return torch.stack([cu, cv]).long(), cn, sc
+    pairs = two_hop_block(g, v_lo, v_hi)
+    cn = sc = None
+    if (want_cn or want_score) and pairs.shape[1]:
+        u, v = pairs[0].to(torch.int32).contiguous(), pairs[1].to(torch.int32).contiguous()
+        cnt, _, ws = ops.pair_scores(g.rowptr, g.col, g.val, node_w if want_score else None, g.n_rows, u, v,
+                                     want_count=want_cn, want_cn=False, grouped=True)
+        cn, sc = cnt, ws
+    return pairs, cn, sc
+
+
+def column_blocks(g: CSRGraph, max_paths: int = 1 << 27) -> Iterator[Tuple[int, int]]:
+    """Column ranges whose 2-hop path count stays below ``max_paths`` (bounds a block's memory: a block never
+    holds more candidates than paths)."""
+    deg = (g.rowptr[1:] - g.rowptr[:-1])
+    rows = g.row_index()
+    paths = torch.zeros(g.n_rows, dtype=torch.int64, device=g.device)
+    paths.index_add_(0, rows, deg[g.col.to(torch.int64)])                    # paths(v) = sum_{w in N(v)} deg(w)
+    cum = torch.cumsum(paths, 0).cpu()
+    n = g.n_rows
+    v = 0
+    while v < n:
+        base = int(cum[v - 1]) if v > 0 else 0
+        hi = int(torch.searchsorted(cum, torch.tensor(base + max_paths), right=True))
+        hi = min(max(hi, v + 1), n)
+        yield v, hi
+        v = hi
+
+
 def iter_candidate_blocks(g: CSRGraph, max_paths: int = 1 << 27) -> Iterator[Tuple[int, int, torch.Tensor]]:
-    """Yield (v_lo, v_hi, pairs[2,E_blk]) over all columns; blocks are sized so that the number of 2-hop
-    paths expanded at once stays below ``max_paths`` (bounds the temporary memory)."""
+    """Yield (v_lo, v_hi, pairs[2,E_blk]) over all columns."""
+    if hip_expand_available(g):
+        for lo, hi in column_blocks(g, max_paths):
+            yield lo, hi, expand_block(g, lo, hi)[0]
+        return
     deg = (g.rowptr[1:] - g.rowptr[:-1])
     rows = g.row_index()
     paths = torch.zeros(g.n_rows, dtype=torch.int64, device=g.device)

@@ -1,0 +1,278 @@
+// Fused candidate generation + scoring of the filter stage, gfx950.
+//
+// Replaces filter.py:96-109 -- `A2 = adj_t @ adj_t` (host SpGEMM), remove diagonal, zero the
+// known edges, take the nonzeros in column-major order -- AND the scoring pass that follows it
+// for the heuristic filters (adamic_utils.py:13-25, train_and_eval.py:195-216, models.py:536-542).
+// The reference throws away the value of A @ A, which already is CN(u,v), and then re-derives it
+// pair by pair; here one expansion of the 2-hop paths v - w - u of a column v yields, for every
+// candidate u at once, the common-neighbour count and sum_w A[u,w] * (A[v,w] * node_w[w]):
+// work proportional to the number of PATHS (~1.3 per candidate on the ppa-like graph) instead of
+// the sum of row lengths (~500 per candidate) an intersection per pair costs.
+//
+// One 1024-thread workgroup per column v (columns handed out dynamically):
+//   A. mark: for every w in N(v) (one wave each) and every u in N(w): set bit u of an LDS bitmap
+//      over the node ids; then clear the bits of N(v) and of v itself (known edges, diagonal).
+//   B. rank: per-word popcounts -> block-wide exclusive scan -> prefix[] in LDS; the total is the
+//      column's candidate count (kernel 1 stops here: counts -> host cumsum -> colptr).
+//   C. emit: set bits in ascending order -> cand_u[colptr[v] + rank] (ascending u: the
+//      reference's column-major order for free).
+//   D. score: walk the same paths again; a path whose u is a candidate adds its term to the
+//      candidate's slot with a global atomic.  Terms are accumulated in 64-bit FIXED POINT
+//      (2^-40): integer addition is associative, so the result is bit-reproducible whatever the
+//      arrival order (float atomics are not), and exact up to the final rounding to float32.
+// Requires a SYMMETRIC adjacency (filter.py's always is: rank.py:33 to_symmetric) and
+// N <= 655,360 node ids (bitmap + prefix array in the 160 KiB LDS); the host falls back to the
+// tensor-op expansion above that.
+#include "eps_common.h"
+
+#include <atomic>
+
+#define EX_THREADS 1024
+#define EX_WAVES (EX_THREADS / 64)
+#define EX_FIXED_SHIFT 40
+#define EX_MAX_WORDS 40448  // bitmap + prefix words: 40448 * 4 B = 158 KiB (the rest of the 160 KiB is static LDS)
+
+#define EX_COUNTER_SLOTS 64
+__device__ unsigned int g_expand_counter[EX_COUNTER_SLOTS];
+static std::atomic<unsigned int> g_expand_turn{0};
+
+__device__ __forceinline__ int wave_incl_scan(int x, int lane)
+{
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int y = __shfl_up(x, o);
+        if (lane >= o) x += y;
+    }
+    return x;
+}
+
+template <bool FILL, bool HAS_VAL, bool HAS_W>
+__global__ __launch_bounds__(EX_THREADS) void expand_kernel(
+    const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col, const float *__restrict__ val,
+    const float *__restrict__ node_w, int32_t v_lo, int32_t v_hi, int32_t wpt, unsigned int *__restrict__ next_col,
+    int64_t *__restrict__ cand_count, const int64_t *__restrict__ colptr, int32_t *__restrict__ cand_u,
+    int32_t *__restrict__ cand_v, int32_t *__restrict__ out_cn, unsigned long long *__restrict__ out_acc)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const int words = wpt * EX_THREADS;
+    uint32_t *bm = lds;
+    uint32_t *pre = lds + words;  // FILL only
+    __shared__ int s_wave_tot[EX_WAVES];
+    __shared__ unsigned int s_col;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wib = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    // the bitmap is all-zero between columns: every column clears exactly the words it scanned
+    for (int i = tid; i < words; i += EX_THREADS) bm[i] = 0u;
+
+    for (;;) {
+        __syncthreads();
+        if (tid == 0) s_col = atomicAdd(next_col, 1u);
+        __syncthreads();
+        const int64_t v = (int64_t)v_lo + s_col;
+        if (v >= v_hi) break;
+        const int64_t vb = rowptr[v];
+        const int32_t dv = (int32_t)(rowptr[v + 1] - vb);
+        const int32_t *__restrict__ vcol = col + vb;
+        if (dv == 0) {  // no neighbours -> no candidates
+            if (!FILL && tid == 0) cand_count[v - v_lo] = 0;
+            continue;
+        }
+
+        // ---- A. mark every 2-hop endpoint --------------------------------------------------
+        for (int k = wib; k < dv; k += EX_WAVES) {
+            const int32_t w = vcol[k];
+            const int64_t wb = rowptr[w];
+            const int32_t dw = (int32_t)(rowptr[w + 1] - wb);
+            const int32_t *__restrict__ wcol = col + wb;
+            for (int i = lane; i < dw; i += 64) {
+                const uint32_t u = (uint32_t)wcol[i];
+                atomicOr(&bm[u >> 5], 1u << (u & 31));
+            }
+        }
+        __syncthreads();
+        for (int k = tid; k < dv; k += EX_THREADS) {  // known edges out
+            const uint32_t u = (uint32_t)vcol[k];
+            atomicAnd(&bm[u >> 5], ~(1u << (u & 31)));
+        }
+        if (tid == 0) atomicAnd(&bm[(uint32_t)v >> 5], ~(1u << ((uint32_t)v & 31)));  // diagonal out
+        __syncthreads();
+
+        // ---- B. rank: exclusive prefix of the per-word popcounts ---------------------------------
+        const int w0 = tid * wpt;
+        int local = 0;
+        for (int i = 0; i < wpt; ++i) local += __popc(bm[w0 + i]);
+        const int incl = wave_incl_scan(local, lane);
+        if (lane == 63) s_wave_tot[wib] = incl;
+        __syncthreads();
+        int wave_base = 0, total = 0;
+#pragma unroll
+        for (int i = 0; i < EX_WAVES; ++i) {
+            const int t = s_wave_tot[i];
+            if (i < wib) wave_base += t;
+            total += t;
+        }
+        int run = wave_base + incl - local;  // exclusive prefix of this thread's first word
+
+        if (!FILL) {
+            if (tid == 0) cand_count[v - v_lo] = total;
+            for (int i = 0; i < wpt; ++i) bm[w0 + i] = 0u;
+            continue;
+        }
+
+        // ---- C. emit the candidates of this column in ascending u ---------------------------------
+        const int64_t base = colptr[v - v_lo];
+        for (int i = 0; i < wpt; ++i) {
+            uint32_t bits = bm[w0 + i];
+            pre[w0 + i] = (uint32_t)run;
+            while (bits) {
+                const int b = __builtin_ctz(bits);
+                bits &= bits - 1;
+                cand_u[base + run] = (w0 + i) * 32 + b;
+                if (cand_v) cand_v[base + run] = (int32_t)v;
+                ++run;
+            }
+        }
+        __syncthreads();
+
+        // ---- D. score: walk the paths again, add each term to its candidate's slot -------------------
+        if (out_acc || out_cn) {
+            for (int k = wib; k < dv; k += EX_WAVES) {
+                const int32_t w = vcol[k];
+                const int64_t wb = rowptr[w];
+                const int32_t dw = (int32_t)(rowptr[w + 1] - wb);
+                const int32_t *__restrict__ wcol = col + wb;
+                float vw = 1.0f;                          // A[v,w] * node_w[w]: the A_ entry (adamic_utils.py:17)
+                if (HAS_VAL) vw = val[vb + k];
+                if (HAS_W) vw = vw * node_w[w];
+                for (int i = lane; i < dw; i += 64) {
+                    const uint32_t u = (uint32_t)wcol[i];
+                    const uint32_t word = bm[u >> 5];
+                    if ((word >> (u & 31)) & 1u) {
+                        const int64_t slot = base + pre[u >> 5] + __popc(word & ((1u << (u & 31)) - 1u));
+                        if (out_cn) atomicAdd(&out_cn[slot], 1);
+                        if (out_acc) {
+                            float term = vw;              // A[u,w] * (A[v,w] * node_w[w]), float32 like the reference
+                            if (HAS_VAL) term = val[wb + i] * vw;
+                            const long long fx = __double2ll_rn((double)term * (double)(1ll << EX_FIXED_SHIFT));
+                            atomicAdd(&out_acc[slot], (unsigned long long)fx);
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        for (int i = 0; i < wpt; ++i) bm[w0 + i] = 0u;
+    }
+}
+
+__global__ void fixed_to_float_kernel(const long long *__restrict__ acc, int64_t n, float *__restrict__ out)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        out[i] = (float)((double)acc[i] * (1.0 / (double)(1ll << EX_FIXED_SHIFT)));
+}
+
+static int expand_words_per_thread(int64_t n_nodes)
+{
+    const int64_t words = (n_nodes + 31) / 32;
+    return (int)((words + EX_THREADS - 1) / EX_THREADS);
+}
+
+static int expand_counter(unsigned int **counter, hipStream_t stream, const char *who)
+{
+    if (hipGetSymbolAddress((void **)counter, HIP_SYMBOL(g_expand_counter)) != hipSuccess) {
+        eps_set_error("%s: cannot resolve the work counter", who);
+        return EPS_ELAUNCH;
+    }
+    *counter += g_expand_turn.fetch_add(1) % EX_COUNTER_SLOTS;
+    if (hipMemsetAsync(*counter, 0, sizeof(unsigned int), stream) != hipSuccess) {
+        eps_set_error("%s: cannot reset the work counter", who);
+        return EPS_ELAUNCH;
+    }
+    return EPS_OK;
+}
+
+extern "C" int eps_expand_max_nodes(void) { return (EX_MAX_WORDS / 2) * 32; }
+
+extern "C" int eps_expand_count(const int64_t *rowptr, const int32_t *col, int64_t n_nodes, int64_t v_lo, int64_t v_hi,
+                                int64_t *cand_count, void *stream)
+{
+    EPS_REQUIRE(n_nodes >= 0 && v_lo >= 0 && v_hi >= v_lo && v_hi <= n_nodes, "eps_expand_count: bad column range");
+    if (v_hi == v_lo) return EPS_OK;
+    EPS_REQUIRE(rowptr && col && cand_count, "eps_expand_count: null pointer");
+    const int wpt = expand_words_per_thread(n_nodes);
+    EPS_REQUIRE((int64_t)wpt * EX_THREADS * 2 <= EX_MAX_WORDS, "eps_expand_count: %lld nodes exceed the LDS bitmap (max %d)",
+                (long long)n_nodes, eps_expand_max_nodes());
+    hipStream_t s = (hipStream_t)stream;
+    unsigned int *counter = nullptr;
+    int rc = expand_counter(&counter, s, "eps_expand_count");
+    if (rc) return rc;
+    const size_t lds = (size_t)wpt * EX_THREADS * 4;
+    auto kern = expand_kernel<false, false, false>;
+    if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+        eps_set_error("eps_expand_count: cannot reserve %zu bytes of LDS", lds);
+        return EPS_ELAUNCH;
+    }
+    int64_t blocks = (int64_t)eps_num_cus() * (lds * 2 + 1024 <= 163840 ? 2 : 1);
+    if (blocks > v_hi - v_lo) blocks = v_hi - v_lo;
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(EX_THREADS), lds, s, rowptr, col, (const float *)nullptr,
+                       (const float *)nullptr, (int32_t)v_lo, (int32_t)v_hi, wpt, counter, cand_count,
+                       (const int64_t *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr,
+                       (unsigned long long *)nullptr);
+    EPS_CHECK_LAUNCH("eps_expand_count");
+    return EPS_OK;
+}
+
+extern "C" int eps_expand_fill(const int64_t *rowptr, const int32_t *col, const float *val, const float *node_w,
+                               int64_t n_nodes, int64_t v_lo, int64_t v_hi, const int64_t *colptr, int32_t *cand_u,
+                               int32_t *cand_v, int32_t *cn, int64_t *acc, void *stream)
+{
+    EPS_REQUIRE(n_nodes >= 0 && v_lo >= 0 && v_hi >= v_lo && v_hi <= n_nodes, "eps_expand_fill: bad column range");
+    if (v_hi == v_lo) return EPS_OK;
+    EPS_REQUIRE(rowptr && col && colptr && cand_u, "eps_expand_fill: null pointer");
+    const int wpt = expand_words_per_thread(n_nodes);
+    EPS_REQUIRE((int64_t)wpt * EX_THREADS * 2 <= EX_MAX_WORDS, "eps_expand_fill: %lld nodes exceed the LDS bitmap (max %d)",
+                (long long)n_nodes, eps_expand_max_nodes());
+    hipStream_t s = (hipStream_t)stream;
+    unsigned int *counter = nullptr;
+    int rc = expand_counter(&counter, s, "eps_expand_fill");
+    if (rc) return rc;
+    const size_t lds = (size_t)wpt * EX_THREADS * 4 * 2;
+    int64_t blocks = eps_num_cus();
+    if (blocks > v_hi - v_lo) blocks = v_hi - v_lo;
+    const bool hv = val != nullptr, hw = node_w != nullptr;
+#define EX_LAUNCH(HV, HW)                                                                                              \
+    do {                                                                                                               \
+        auto kern = expand_kernel<true, HV, HW>;                                                                       \
+        if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=           \
+            hipSuccess) {                                                                                              \
+            eps_set_error("eps_expand_fill: cannot reserve %zu bytes of LDS", lds);                                    \
+            return EPS_ELAUNCH;                                                                                        \
+        }                                                                                                              \
+        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(EX_THREADS), lds, s, rowptr, col, val, node_w,           \
+                           (int32_t)v_lo, (int32_t)v_hi, wpt, counter, (int64_t *)nullptr, colptr, cand_u, cand_v, cn, \
+                           (unsigned long long *)acc);                                                                 \
+    } while (0)
+    if (hv && hw) EX_LAUNCH(true, true);
+    else if (hv) EX_LAUNCH(true, false);
+    else if (hw) EX_LAUNCH(false, true);
+    else EX_LAUNCH(false, false);
+#undef EX_LAUNCH
+    EPS_CHECK_LAUNCH("eps_expand_fill");
+    return EPS_OK;
+}
+
+extern "C" int eps_fixed_to_float(const int64_t *acc, int64_t n, float *out, void *stream)
+{
+    EPS_REQUIRE(n >= 0, "eps_fixed_to_float: negative size");
+    if (n == 0) return EPS_OK;
+    EPS_REQUIRE(acc && out, "eps_fixed_to_float: null pointer");
+    int64_t b = (n + 255) / 256;
+    const int64_t cap = (int64_t)eps_num_cus() * 8;
+    if (b > cap) b = cap;
+    hipLaunchKernelGGL(fixed_to_float_kernel, dim3((unsigned)b), dim3(256), 0, (hipStream_t)stream, (const long long *)acc, n,
+                       out);
+    EPS_CHECK_LAUNCH("eps_fixed_to_float");
+    return EPS_OK;
+}

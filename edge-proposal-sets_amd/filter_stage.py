@@ -67,6 +67,25 @@ def score_block(args, model, data, pairs: torch.Tensor, ra_graph=None) -> torch.
     return model(data.x, pairs, data.adj_t).reshape(-1)  # filter.py:116-121
 
 
+def scored_blocks(args, model, data, ra_graph):
+    """(v_lo, v_hi, pairs, scores) per column block.  Heuristic filters whose scoring graph IS the candidate graph
+    (AA: filter.py:122-126; CN 'simple': :116-121 with models.py:536-542) come out of the fused expansion already
+    scored; RA scores on the train-only graph (filter.py:130-141) and GNN filters decode the block's pairs."""
+    g = data.adj_t
+    fused = candidates.hip_expand_available(g) and args.model in ("adamic_ogb", "simple")
+    if not fused:
+        for v_lo, v_hi, pairs in candidates.iter_candidate_blocks(g):
+            yield v_lo, v_hi, pairs, (score_block(args, model, data, pairs, ra_graph) if pairs.shape[1] else None)
+        return
+    if args.model == "adamic_ogb":
+        node_w = node_weight_table(g, ops.W_AA)
+    else:  # CN = sum_w A[u,w]*A[v,w]: the same accumulator with unit node weights
+        node_w = torch.ones(g.n_rows, dtype=torch.float32, device=g.device)
+    for v_lo, v_hi in candidates.column_blocks(g):
+        pairs, _, score = candidates.expand_block(g, v_lo, v_hi, node_w, want_score=True)
+        yield v_lo, v_hi, pairs, score
+
+
 def run(args) -> str:
     args = default_model_configs(args)
     print(args)
@@ -103,10 +122,9 @@ def run(args) -> str:
     keep = int(args.keep_top)
     all_pairs, all_scores, best_keys, best_pairs = [], [], None, None
     with torch.no_grad():
-        for v_lo, v_hi, pairs in candidates.iter_candidate_blocks(data.adj_t):
+        for v_lo, v_hi, pairs, score in scored_blocks(args, model, data, ra_graph):
             if pairs.shape[1] == 0:
                 continue
-            score = score_block(args, model, data, pairs, ra_graph)
             if keep:
                 keys = proposals.top_k_keys(score, keep, id_base=n_seen)          # sorted, global candidate ids
                 _, ids = ops.unpack_keys(keys)

@@ -125,6 +125,42 @@ def pair_scores(rowptr, col, val, node_w, n_nodes: int, u, v, want_count=True, w
     return count, cn, ws
 
 
+def expand_max_nodes() -> int:
+    return int(_lib.load().eps_expand_max_nodes())
+
+
+def expand_candidates(rowptr, col, val, node_w, n_nodes: int, v_lo: int, v_hi: int, want_cn=True, want_score=True,
+                      want_v=True):
+    """Fused 2-hop expansion of columns [v_lo, v_hi) of a SYMMETRIC adjacency (filter.py:96-109 + scoring).
+    -> (colptr int64[n_cols+1], cand_u int32[E], cand_v int32[E] | None, cn int32[E] | None, score float32[E] | None);
+    candidates are column-major, u ascending inside a column (the reference's order)."""
+    dev = _need_gpu(rowptr, col, val, node_w)
+    _chk(rowptr, torch.int64, "rowptr"); _chk(col, torch.int32, "col"); _chk(val, torch.float32, "val")
+    _chk(node_w, torch.float32, "node_w")
+    lib = _lib.load()
+    n_cols = v_hi - v_lo
+    colptr = torch.zeros(n_cols + 1, dtype=torch.int64, device=dev)
+    with torch.cuda.device(dev):
+        counts = torch.empty(n_cols, dtype=torch.int64, device=dev)
+        _lib.check(lib.eps_expand_count(_ptr(rowptr), _ptr(col), n_nodes, v_lo, v_hi, _ptr(counts), _stream(dev)),
+                   "eps_expand_count")
+        torch.cumsum(counts, 0, out=colptr[1:])
+        total = int(colptr[-1].item())
+        cand_u = torch.empty(total, dtype=torch.int32, device=dev)
+        cand_v = torch.empty(total, dtype=torch.int32, device=dev) if want_v else None
+        cn = torch.zeros(total, dtype=torch.int32, device=dev) if want_cn else None
+        acc = torch.zeros(total, dtype=torch.int64, device=dev) if want_score else None
+        if total:
+            _lib.check(lib.eps_expand_fill(_ptr(rowptr), _ptr(col), _ptr(val), _ptr(node_w), n_nodes, v_lo, v_hi,
+                                           _ptr(colptr), _ptr(cand_u), _ptr(cand_v), _ptr(cn), _ptr(acc), _stream(dev)),
+                       "eps_expand_fill")
+        score = None
+        if want_score:
+            score = torch.empty(total, dtype=torch.float32, device=dev)
+            _lib.check(lib.eps_fixed_to_float(_ptr(acc), total, _ptr(score), _stream(dev)), "eps_fixed_to_float")
+    return colptr, cand_u, cand_v, cn, score
+
+
 def spmm_csr(rowptr, col, val, x: torch.Tensor, bias=None, relu=False, mean=False, out=None) -> torch.Tensor:
     dev = _need_gpu(rowptr, col, val, x, bias, out, row_strided=(x, out))
     _chk(rowptr, torch.int64, "rowptr"); _chk(col, torch.int32, "col"); _chk(val, torch.float32, "val")

@@ -89,6 +89,29 @@ int eps_pair_scores_grouped_f64(const int64_t *rowptr, const int32_t *col, const
                                 const int32_t *v, int64_t n_pairs, int32_t *count, double *wsum,
                                 void *stream);
 
+/* ---- K7 (+K1): fused candidate generation and scoring of the filter stage ------------------
+ * Replaces filter.py:96-109 (`A2 = adj_t @ adj_t`, remove diagonal, zero known edges, nonzeros in
+ * column-major order) together with the heuristic scoring that follows it (adamic_utils.py:13-25,
+ * train_and_eval.py:195-216, models.py:536-542): one expansion of the 2-hop paths of a column
+ * yields every candidate of the column with its common-neighbour count and
+ * sum_w A[u,w]*(A[v,w]*node_w[w]).  The adjacency must be symmetric (rank.py:33) and have at
+ * most eps_expand_max_nodes() nodes (LDS bitmap).
+ *   eps_expand_count: cand_count[v - v_lo] = number of 2-hop non-edges (u, v), v in [v_lo, v_hi).
+ *   eps_expand_fill : colptr = exclusive prefix of cand_count (int64[n_cols+1], device); writes
+ *                     cand_u (ascending inside a column == the reference's order), cand_v (column
+ *                     id per candidate; optional), cn (int32 count; optional, ZEROED by the
+ *                     caller) and acc (optional, ZEROED by the caller): the weighted sum in
+ *                     2^-40 fixed point -- integer atomics make the result independent of the
+ *                     accumulation order; eps_fixed_to_float converts it to float32. */
+int eps_expand_max_nodes(void);
+int eps_expand_count(const int64_t *rowptr, const int32_t *col, int64_t n_nodes, int64_t v_lo,
+                     int64_t v_hi, int64_t *cand_count, void *stream);
+int eps_expand_fill(const int64_t *rowptr, const int32_t *col, const float *val,
+                    const float *node_w, int64_t n_nodes, int64_t v_lo, int64_t v_hi,
+                    const int64_t *colptr, int32_t *cand_u, int32_t *cand_v, int32_t *cn,
+                    int64_t *acc, void *stream);
+int eps_fixed_to_float(const int64_t *acc, int64_t n, float *out, void *stream);
+
 /* ---- K4/K5: CSR x dense SpMM with fused epilogue -----------------------------------------
  * Replaces torch_sparse spmm_sum / spmm_mean inside GCNConv / SAGEConv (models.py:183-186,
  * :436-439) plus the bias add and the ReLU of the layer loop.

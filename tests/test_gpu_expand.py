@@ -1,0 +1,83 @@
+"""GPU parity of the fused candidate-generation + scoring kernels (eps_expand_count / eps_expand_fill) vs the
+restated filter.py:96-109 candidate set (oracle.candidates_scipy) and the oracle pair scores."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, golden_pair_files, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _check(eps, oracle, dev, A, weighted):
+    import scipy.sparse as ssp
+    n = A.shape[0]
+    g = eps.CSRGraph.from_scipy(A, device=dev)
+    rp, col = A.indptr.astype(np.int64), A.indices.astype(np.int32)
+    val = A.data.astype(np.float32) if weighted else None
+    want_pairs, a2 = oracle.candidates_scipy(A)
+    w = oracle.node_weights(oracle.col_sums(rp, col, val, n), oracle.W_AA)
+    from eps_amd.heuristics import node_weight_table
+    wt = node_weight_table(g, eps.ops.W_AA)
+    got_u, got_v, got_cn, got_sc = [], [], [], []
+    step = max(1, n // 3)
+    for lo in range(0, n, step):                 # several column blocks: colptr / offsets per block
+        hi = min(n, lo + step)
+        colptr, cu, cv, cn, sc = eps.ops.expand_candidates(g.rowptr, g.col, g.val, wt, n, lo, hi)
+        assert colptr.numel() == hi - lo + 1 and int(colptr[-1]) == cu.numel()
+        got_u.append(cu); got_v.append(cv); got_cn.append(cn); got_sc.append(sc)
+    u = torch.cat(got_u).cpu().numpy(); v = torch.cat(got_v).cpu().numpy()
+    cn = torch.cat(got_cn).cpu().numpy(); sc = torch.cat(got_sc).cpu().numpy()
+    assert np.array_equal(np.stack([u, v], 1), want_pairs), "candidate set / column-major order"
+    cnt_o, cn_o, ws_o = oracle.pair_scores(rp, col, val, w, want_pairs[:, 0], want_pairs[:, 1])
+    assert np.array_equal(cn, cnt_o), "common-neighbour counts bit-exact"
+    _, truth = oracle.pair_scores_f64(rp, col, val, w.astype(np.float64), want_pairs[:, 0], want_pairs[:, 1])
+    assert rel_err(sc, truth.astype(np.float32)) <= 1e-6          # fixed-point accumulation: ~exact
+    assert rel_err(sc, ws_o) <= 1e-5                               # and within the gate of the float32 oracle
+    return len(u)
+
+
+@pytest.mark.parametrize("path", golden_pair_files(), ids=lambda p: os.path.basename(p)[6:-4])
+def test_expand_on_golden_graphs(eps, oracle, dev, path):
+    import scipy.sparse as ssp
+    d = np.load(path)
+    n = len(d["rowptr"]) - 1
+    A = ssp.csr_matrix((d["val"], d["col"], d["rowptr"]), shape=(n, n))
+    _check(eps, oracle, dev, A, weighted=not bool((d["val"] == 1).all()))
+
+
+def test_expand_rmat_and_determinism(eps, oracle, dev):
+    from eps_amd import synth
+    g = synth.rmat_graph(12, 10, 5, "cpu")
+    A = g.to_scipy()
+    n_cand = _check(eps, oracle, dev, A, weighted=False)
+    assert n_cand > 100000
+    gd = g.to(dev)
+    from eps_amd.heuristics import node_weight_table
+    wt = node_weight_table(gd, eps.ops.W_AA)
+    a = eps.ops.expand_candidates(gd.rowptr, gd.col, None, wt, gd.n_rows, 0, gd.n_rows)
+    b = eps.ops.expand_candidates(gd.rowptr, gd.col, None, wt, gd.n_rows, 0, gd.n_rows)
+    assert torch.equal(a[4], b[4]) and torch.equal(a[1], b[1]), "fixed-point accumulation is order-independent"
+
+
+def test_expand_matches_pair_kernel_at_scale(eps, dev):
+    """ppa-like graph, a block of columns: fused expansion == candidate block + column-run pair kernel."""
+    from eps_amd import candidates, synth
+    from eps_amd.heuristics import node_weight_table
+    g = synth.ppa_like(seed=3, device=dev, n_nodes=200_000, n_undirected=4_000_000)
+    wt = node_weight_table(g, eps.ops.W_AA)
+    colptr, cu, cv, cn, sc = eps.ops.expand_candidates(g.rowptr, g.col, None, wt, g.n_rows, 1000, 1400)
+    pairs = candidates.two_hop_block(g, 1000, 1400)
+    assert torch.equal(torch.stack([cu, cv]).long(), pairs)
+    cnt, _, ws = eps.ops.pair_scores(g.rowptr, g.col, None, wt, g.n_rows, cu, cv, want_cn=False, grouped=True)
+    assert torch.equal(cnt, cn)
+    assert rel_err(sc.cpu().numpy(), ws.cpu().numpy()) <= 1e-5
+
+
+def test_expand_rejects_oversized_id_space(eps, dev):
+    n = eps.ops.expand_max_nodes() + 1
+    rp = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+    with pytest.raises(eps.EpsError):
+        eps.ops.expand_candidates(rp, torch.zeros(0, dtype=torch.int32, device=dev), None, None, n, 0, 10)

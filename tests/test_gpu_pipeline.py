@@ -68,6 +68,28 @@ def test_filter_cli_matches_oracle(eps, oracle, workdir, dataset, model, mode):
     assert torch.equal(top, got[:500])
 
 
+@pytest.mark.parametrize("dataset", ["ddi", "collab"])
+def test_cn_filter_cli_matches_oracle(eps, oracle, workdir, dataset, monkeypatch):
+    """`--model simple` (configs[0]: ddi Common-Neighbours filter; weighted on collab): fused expansion with unit
+    node weights == CN(u,v) = sum_w A[u,w]*A[v,w] (models.py:536-542), exact for integer-valued weights."""
+    from eps_amd import filter_stage
+    if dataset == "ddi":
+        monkeypatch.setenv("EPS_SYNTH_SCALE", "0.15")
+    fname = filter_stage.main(["--dataset", dataset, "--model", "simple", "--checkpoint", f"{dataset}_simple||0|0.pt",
+                               "--synthetic"])
+    got = torch.load(fname)
+    import argparse
+    from eps_amd import datasets
+    edge_index, edge_weight, split_edge, data = datasets.get_data(argparse.Namespace(dataset=dataset, synthetic=True, use_feature=False))
+    A = oracle.add_edges_scipy(dataset, edge_index.numpy(), edge_weight.numpy(), np.zeros((2, 0), np.int64), data.num_nodes)
+    pairs, _ = oracle.candidates_scipy(A)
+    val = None if dataset != "collab" else A.data
+    cn = oracle.pair_scores(A.indptr.astype(np.int64), A.indices.astype(np.int32), val, None, pairs[:, 0], pairs[:, 1])[1]
+    order = oracle.sort_desc_stable(cn)          # declared rule: score desc, candidate index asc
+    assert np.array_equal(got[:, 2].numpy(), cn[order])
+    assert np.array_equal(got[:, :2].numpy().astype(np.int64), pairs[order]), "top-K ids bit-exact under the tie rule"
+
+
 def test_rank_cli_hits_match_oracle(eps, oracle, workdir):
     """AA-filter -> AA-rank (the published collab recipe, minus --valid_proposal) on the ppa stand-in:
     Hits@K printed by rank.py == Hits@K of oracle scores on the oracle-built augmented graph."""
