@@ -157,6 +157,36 @@ def main():
         dt = t.item()
     kern_ms = sum(a.elapsed_time(b) for a, b in evs) / args.steps
 
+    # Second leg, same columns: the FUSED filter path (csrc/expand_score.hip) -- candidate generation + CN + AA in one
+    # expansion of the 2-hop paths (what filter.py runs for heuristic filters).  Timed end to end on the host clock:
+    # count kernel + cumsum + zero-fill + fill kernel + fixed->float, outputs left in HBM.
+    fused = None
+    if candidates.hip_expand_available(g):
+        c_lo, c_hi = col_range
+        for _ in range(2):
+            r = ops.expand_candidates(g.rowptr, g.col, g.val, w, g.n_rows, c_lo, c_hi)
+        barrier()
+        t1 = time.perf_counter()
+        fsteps = max(3, args.steps // 4)
+        for _ in range(fsteps):
+            r = ops.expand_candidates(g.rowptr, g.col, g.val, w, g.n_rows, c_lo, c_hi)
+        barrier()
+        fdt = time.perf_counter() - t1
+        if world > 1:
+            t = torch.tensor([fdt], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            fdt = t.item()
+        n_cand = torch.tensor([r[1].numel()], device=dev, dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(n_cand)
+        deg = g.degree()
+        paths = int(deg[g.col[g.rowptr[c_lo]:g.rowptr[c_hi]].long()].sum().item())
+        fused = {"value": n_cand.item() * fsteps / fdt, "unit": "edges/s", "ms_per_step": fdt / fsteps * 1e3,
+                 "candidates_per_step_all_ranks": int(n_cand.item()), "steps": fsteps,
+                 "two_hop_paths_rank0": paths,
+                 "what": "candidate generation (filter.py:96-109) + CN + AA for every candidate of the rank's column block, "
+                         "one fused expansion; host clock incl. count pass, cumsum, zero-fill, fill pass, fixed->float"}
+
     if rank == 0:
         n_cu, dev_name = ops.device_info()
         abytes, mean_len = algorithmic_bytes(g, u, v, count, torch)
@@ -187,6 +217,8 @@ def main():
                                  "exceed 1; `traffic` is the measured fabric-side bytes per launch (rocprofv3 PMC, "
                                  "profiles/r01/pair_scores_grouped_pmc.json)"},
         }
+        if fused is not None:
+            line["fused_filter"] = fused
         if world == 1 and not args.no_cpu:
             line["cpu_baseline"] = cpu_baseline(g, u, v, ws, torch)
         print(json.dumps(line), flush=True)
