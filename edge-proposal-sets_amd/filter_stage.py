@@ -67,21 +67,33 @@ def score_block(args, model, data, pairs: torch.Tensor, ra_graph=None) -> torch.
     return model(data.x, pairs, data.adj_t).reshape(-1)  # filter.py:116-121
 
 
-def scored_blocks(args, model, data, ra_graph):
+def rank_column_range(g: CSRGraph, rank: int, world: int):
+    """Contiguous column shard of this rank, balanced by 2-hop path counts (the cost of generating + scoring a column)."""
+    if world == 1:
+        return 0, g.n_rows
+    from . import dist as epd
+    b = epd.balanced_bounds(epd.column_work(g.rowptr, g.col), world)
+    return b[rank], b[rank + 1]
+
+
+def scored_blocks(args, model, data, ra_graph, col_lo: int = 0, col_hi: int = None):
     """(v_lo, v_hi, pairs, scores) per column block.  Heuristic filters whose scoring graph IS the candidate graph
     (AA: filter.py:122-126; CN 'simple': :116-121 with models.py:536-542) come out of the fused expansion already
     scored; RA scores on the train-only graph (filter.py:130-141) and GNN filters decode the block's pairs."""
     g = data.adj_t
+    col_hi = g.n_rows if col_hi is None else col_hi
+    blocks = [(max(lo, col_lo), min(hi, col_hi)) for lo, hi in candidates.column_blocks(g) if lo < col_hi and hi > col_lo]
     fused = candidates.hip_expand_available(g) and args.model in ("adamic_ogb", "simple")
     if not fused:
-        for v_lo, v_hi, pairs in candidates.iter_candidate_blocks(g):
+        for v_lo, v_hi in blocks:
+            pairs = candidates.expand_block(g, v_lo, v_hi)[0]
             yield v_lo, v_hi, pairs, (score_block(args, model, data, pairs, ra_graph) if pairs.shape[1] else None)
         return
     if args.model == "adamic_ogb":
         node_w = node_weight_table(g, ops.W_AA)
     else:  # CN = sum_w A[u,w]*A[v,w]: the same accumulator with unit node weights
         node_w = torch.ones(g.n_rows, dtype=torch.float32, device=g.device)
-    for v_lo, v_hi in candidates.column_blocks(g):
+    for v_lo, v_hi in blocks:
         pairs, _, score = candidates.expand_block(g, v_lo, v_hi, node_w, want_score=True)
         yield v_lo, v_hi, pairs, score
 
@@ -92,7 +104,13 @@ def run(args) -> str:
     Path("filtered_edges").mkdir(exist_ok=True)
     if not torch.cuda.is_available():
         raise RuntimeError("filter stage needs a HIP device: the scoring path has no CPU fallback")
-    device = torch.device(f'cuda:{args.device}')
+    # one process per GPU under torchrun (WORLD_SIZE > 1): candidate COLUMNS are sharded, the graph is replicated, the
+    # only exchange is the final top-K merge (needs --keep_top: rank.py never reads past num_sorted_edge rows anyway)
+    from . import dist as epd
+    rank, world, dist_dev = epd.init_from_env()
+    device = dist_dev if world > 1 else torch.device(f'cuda:{args.device}')
+    if world > 1 and not args.keep_top:
+        raise ValueError("multi-GPU filter needs --keep_top K (the full [E,3] list is not gathered)")
 
     edge_index, edge_weight, split_edge, data = get_data(args)
     data = data.to(device)
@@ -118,11 +136,25 @@ def run(args) -> str:
     ra_graph = train_only_graph(split_edge, data.num_nodes, device) if args.model == "resource_allocation" else None
 
     t0 = time.perf_counter()
-    n_seen = 0
     keep = int(args.keep_top)
+    col_lo, col_hi = rank_column_range(data.adj_t, rank, world)
+    n_seen = 0
+    if world > 1:
+        # global candidate index of this rank's first candidate = candidates in all lower columns (one count pass)
+        counts = torch.zeros(world, dtype=torch.int64, device=device)
+        mine = 0
+        for lo, hi in candidates.column_blocks(data.adj_t):
+            lo, hi = max(lo, col_lo), min(hi, col_hi)
+            if lo < hi:
+                mine += candidates.expand_block(data.adj_t, lo, hi)[0].shape[1]
+        counts[rank] = mine
+        torch.distributed.all_reduce(counts)
+        n_seen = int(counts[:rank].sum().item())
+        if n_seen + mine >= (1 << 32):
+            raise ValueError("more than 2^32 candidates: the packed top-K keys carry 32-bit candidate ids")
     all_pairs, all_scores, best_keys, best_pairs = [], [], None, None
     with torch.no_grad():
-        for v_lo, v_hi, pairs, score in scored_blocks(args, model, data, ra_graph):
+        for v_lo, v_hi, pairs, score in scored_blocks(args, model, data, ra_graph, col_lo, col_hi):
             if pairs.shape[1] == 0:
                 continue
             if keep:
@@ -141,6 +173,23 @@ def run(args) -> str:
     dt = time.perf_counter() - t0
     print(f'using {n_seen} edges; scored in {dt:.2f} s ({n_seen / max(dt, 1e-9):.3e} candidate edges/s incl. generation)')
 
+    if keep and world > 1:
+        # merge the per-rank sorted key lists (K x 8 B each); the winners' (u, v) travel with a second small gather
+        kk = keep
+        if best_keys is None:
+            best_keys = torch.zeros(0, dtype=torch.int64, device=device)
+            best_pairs = torch.zeros((2, 0), dtype=torch.int64, device=device)
+        pad_pairs = torch.zeros((2, kk), dtype=torch.int64, device=device)
+        pad_pairs[:, :best_pairs.shape[1]] = best_pairs
+        lists = epd.all_gather_keys(best_keys, kk)
+        gathered = [torch.empty_like(pad_pairs) for _ in range(world)]
+        torch.distributed.all_gather(gathered, pad_pairs)
+        allk = torch.cat(lists)
+        allp = torch.cat(gathered, 1)
+        valid = allk != torch.iinfo(torch.int64).min
+        allk, allp = allk[valid], allp[:, valid]
+        top = torch.topk(allk, min(kk, allk.numel()), largest=True, sorted=True)
+        best_keys, best_pairs = top.values, allp[:, top.indices]
     if keep:
         score, _ = ops.unpack_keys(best_keys)
         sorted_edges = torch.cat([best_pairs.t().to(torch.float32), score.unsqueeze(1)], 1)
@@ -148,10 +197,13 @@ def run(args) -> str:
         pairs = torch.cat(all_pairs, 1)
         scores = torch.cat(all_scores)
         sorted_edges = proposals.sorted_edges_tensor(pairs, scores)          # filter.py:160-161
-    print(sorted_edges)
     filename = f'filtered_edges/{spec}_{sorted_edge_path}_{num_sorted_edge}_{run_id}_sorted_edges.pt'
-    proposals.save_sorted_edges(filename, sorted_edges)                        # filter.py:164-165
-    print("Saving to ", filename)
+    if rank == 0:
+        print(sorted_edges)
+        proposals.save_sorted_edges(filename, sorted_edges)                    # filter.py:164-165
+        print("Saving to ", filename)
+    if world > 1:
+        torch.distributed.barrier()
     return filename
 
 

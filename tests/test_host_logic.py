@@ -143,3 +143,36 @@ def test_get_pos_neg_edges_permutation(eps):
     np.random.seed(123)
     assert torch.equal(pos, split["valid"]["edge"].t()[:, np.random.permutation(10)])
     assert pos.shape == (2, 10) and neg.shape == (2, 20)
+
+
+def test_rank_stage_helpers(eps):
+    """rank.py:260-272 sweep schedule, :222-251 --valid_proposal splice, to_undirected (PyG, restated)."""
+    from eps_amd import rank_stage
+    ns = argparse.Namespace
+    assert rank_stage.sweep_schedule(ns(sweep_num=4, sweep_min=None, sweep_max=None, num_sorted_edge=None)) == [0, 750, 1500, 2250, 3000]
+    assert rank_stage.sweep_schedule(ns(sweep_num=2, sweep_min=100, sweep_max=300, num_sorted_edge=7)) == [100, 200, 300]
+    assert rank_stage.sweep_schedule(ns(sweep_num=None, sweep_min=None, sweep_max=None, num_sorted_edge=530000)) == [530000]
+    assert rank_stage.sweep_schedule(ns(sweep_num=None, sweep_min=None, sweep_max=None, num_sorted_edge=None)) == [0]
+    und = rank_stage.to_undirected(torch.tensor([[3, 1, 1], [1, 3, 2]]))
+    assert und.t().tolist() == [[1, 2], [1, 3], [2, 1], [3, 1]]
+    # splice: both directions of the validation edges on top with score 100000, proposals that are validation edges dropped
+    props = torch.tensor([[5., 6., .9], [1., 2., .8], [2., 1., .7], [7., 8., .6]])
+    valid = torch.tensor([[1, 2], [3, 4]])
+    out = rank_stage.splice_valid_proposals(props, valid)
+    assert out[:4, :2].long().tolist() == [[1, 2], [2, 1], [3, 4], [4, 3]] and bool((out[:4, 2] == 100000.0).all())
+    assert out[4:, :2].long().tolist() == [[5, 6], [7, 8]]
+    top = {tuple(r) for r in out[:4, :2].long().tolist()}
+    assert top == {(1, 2), (2, 1), (3, 4), (4, 3)}       # rank.py:249 assertion: the top block covers valid_pos_set
+
+
+def test_filter_rank_argument_surface(eps):
+    """Same flags as the reference parsers (filter.py:27-47, rank.py:130-163) + the documented extensions."""
+    from eps_amd import filter_stage, rank_stage
+    f = {a.dest for a in filter_stage.make_parser()._actions}
+    assert {"dataset", "model", "checkpoint", "num_layers", "hidden_channels", "dropout", "batch_size", "lr", "epochs",
+            "use_feature", "use_learnable_embedding", "device"} <= f
+    r = {a.dest for a in rank_stage.make_parser()._actions}
+    assert {"dataset", "model", "runs", "sorted_edge_path", "num_sorted_edge", "sweep_max", "sweep_min", "sweep_num",
+            "only_supervision", "also_supervision", "gen_dataset_only", "valid_proposal", "out_name", "save_models",
+            "num_layers", "hidden_channels", "dropout", "batch_size", "lr", "epochs", "use_feature",
+            "use_learnable_embedding", "device", "log_steps", "eval_steps"} <= r
