@@ -30,6 +30,9 @@ void eps_set_error(const char *fmt, ...);
 // Number of CUs of the current device (cached per process; 256 on MI355X).
 int eps_num_cus();
 
+// A zeroed device word for a kernel's dynamic work hand-out (see eps_common.hip).
+int eps_take_counter(unsigned int **counter, hipStream_t stream, const char *who);
+
 #if defined(__HIPCC__)
 // ---- wave-level reductions (all 64 lanes receive the total) --------------------------
 // quad_perm / row_mirror DPP for the first four butterfly steps (VALU rate, no LDS traffic),

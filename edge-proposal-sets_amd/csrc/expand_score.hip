@@ -25,16 +25,11 @@
 // tensor-op expansion above that.
 #include "eps_common.h"
 
-#include <atomic>
-
 #define EX_THREADS 1024
 #define EX_WAVES (EX_THREADS / 64)
 #define EX_FIXED_SHIFT 40
 #define EX_MAX_WORDS 40448  // bitmap + prefix words: 40448 * 4 B = 158 KiB (the rest of the 160 KiB is static LDS)
 
-#define EX_COUNTER_SLOTS 64
-__device__ unsigned int g_expand_counter[EX_COUNTER_SLOTS];
-static std::atomic<unsigned int> g_expand_turn{0};
 
 __device__ __forceinline__ int wave_incl_scan(int x, int lane)
 {
@@ -179,20 +174,6 @@ static int expand_words_per_thread(int64_t n_nodes)
     return (int)((words + EX_THREADS - 1) / EX_THREADS);
 }
 
-static int expand_counter(unsigned int **counter, hipStream_t stream, const char *who)
-{
-    if (hipGetSymbolAddress((void **)counter, HIP_SYMBOL(g_expand_counter)) != hipSuccess) {
-        eps_set_error("%s: cannot resolve the work counter", who);
-        return EPS_ELAUNCH;
-    }
-    *counter += g_expand_turn.fetch_add(1) % EX_COUNTER_SLOTS;
-    if (hipMemsetAsync(*counter, 0, sizeof(unsigned int), stream) != hipSuccess) {
-        eps_set_error("%s: cannot reset the work counter", who);
-        return EPS_ELAUNCH;
-    }
-    return EPS_OK;
-}
-
 extern "C" int eps_expand_max_nodes(void) { return (EX_MAX_WORDS / 2) * 32; }
 
 extern "C" int eps_expand_count(const int64_t *rowptr, const int32_t *col, int64_t n_nodes, int64_t v_lo, int64_t v_hi,
@@ -206,7 +187,7 @@ extern "C" int eps_expand_count(const int64_t *rowptr, const int32_t *col, int64
                 (long long)n_nodes, eps_expand_max_nodes());
     hipStream_t s = (hipStream_t)stream;
     unsigned int *counter = nullptr;
-    int rc = expand_counter(&counter, s, "eps_expand_count");
+    int rc = eps_take_counter(&counter, s, "eps_expand_count");
     if (rc) return rc;
     const size_t lds = (size_t)wpt * EX_THREADS * 4;
     auto kern = expand_kernel<false, false, false>;
@@ -236,7 +217,7 @@ extern "C" int eps_expand_fill(const int64_t *rowptr, const int32_t *col, const 
                 (long long)n_nodes, eps_expand_max_nodes());
     hipStream_t s = (hipStream_t)stream;
     unsigned int *counter = nullptr;
-    int rc = expand_counter(&counter, s, "eps_expand_fill");
+    int rc = eps_take_counter(&counter, s, "eps_expand_fill");
     if (rc) return rc;
     const size_t lds = (size_t)wpt * EX_THREADS * 4 * 2;
     int64_t blocks = eps_num_cus();

@@ -1,0 +1,473 @@
+// Column-run pair scoring (candidate lists in the reference's column-major order), gfx950.
+// See pair_intersect.hip for the generic kernel and the entry points' semantics (include/eps_abi.h).
+#include "pair_common.h"
+
+// =====================================================================================
+// Column-run variant: candidate lists in the reference's order (filter.py:96-109: column-major,
+// v ascending) hold long runs of pairs that share v (~24 k pairs per column on the ppa-like
+// graph).  A workgroup takes a 4096-pair chunk, turns N(v) of the chunk's column into an LDS
+// BITMAP over node ids once, and every pair (u, v) of the chunk then costs one coalesced read
+// of row u plus one ds_read + bit test per element -- no staging of row v per pair, no log
+// factor.  Node-id spaces that do not fit the LDS bitmap (N > 2^20) hash into it (w & mask) and
+// every positive is verified by a binary search in row v (exactness kept; the same search
+// yields the position of w in row v, which weighted graphs need for A[v,w]).  Pairs of the chunk
+// whose v differs from the chunk's first v (run boundaries; rare in sorted lists) take an
+// in-place global-memory search, so ANY pair list is scored correctly -- the host picks this
+// kernel only when the list actually has long runs.
+// =====================================================================================
+#define PG_THREADS 1024
+#define PG_WAVES (PG_THREADS / 64)
+#ifndef PG_CHUNK
+#define PG_CHUNK 16384
+#endif
+#define PG_QCAP 512             // per-wave hit queue entries (2 KiB)
+#define PG_MAX_WORDS (1 << 15)  // 2^20 bits = 128 KiB
+#ifndef PG_RING
+#define PG_RING 4               // pairs whose row loads are kept in flight per wave
+#endif
+
+// Bitmap test of one row u against the chunk's column v with the weights gathered INLINE (a dependent
+// global load per hit): used for weighted graphs, float64 weights, hashed bitmaps and oversized pairs.
+template <bool HAS_VAL, bool HAS_W, typename WT, bool EXACT>
+__device__ __forceinline__ void test_row_inline(const uint8_t *bm8, uint32_t bm_mask, const int32_t *__restrict__ vcol,
+                                                int32_t dv, int64_t vb, bool v_has0, __amdgpu_buffer_rsrc_t rj,
+                                                int64_t bju, int32_t dju, v4i cur0, v4i cur1,
+                                                const float *__restrict__ val, const WT *__restrict__ node_w, int lane,
+                                                int &cnt, float &r_cn, WT &r_ws)
+{
+    int h = 0;  // per-lane hit count over the whole row
+    float acc_cn = 0.0f;
+    WT acc_ws = 0;
+    for (int k0 = 0; k0 < dju; k0 += 256) {
+        v4i wv;
+        if (k0 == 0) wv = cur0;
+        else if (k0 == 256) wv = cur1;
+        else wv = __builtin_amdgcn_raw_buffer_load_b128(rj, lane * 16 + k0 * 4, 0, 0);
+        uint32_t b[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const uint32_t w = (uint32_t)wv[e];
+            const uint32_t idx = EXACT ? w : (w & bm_mask);
+            b[e] = ((uint32_t)bm8[idx >> 3] >> (idx & 7)) & 1u;
+            if (!EXACT) b[e] = (k0 + 4 * lane + e < dju) ? b[e] : 0u;  // 0-filled tail lanes
+        }
+        const uint32_t any = b[0] | b[1] | b[2] | b[3];
+        if (__ballot(any != 0) != 0ull) {  // wave-uniform; taken for a minority of the units
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                bool hit = b[e] != 0;
+                const uint32_t w = (uint32_t)wv[e];
+                int pos = 0;
+                if (!EXACT || HAS_VAL) {  // verify hashed positives / locate w inside row v
+                    if (__ballot(hit) != 0ull) {
+                        pos = lower_bound_uniform(vcol, dv, hit ? (int)w : 0);
+                        const int pc = pos < dv ? pos : dv - 1;
+                        hit = hit && pos < dv && vcol[pc] == (int)w;
+                        pos = pc;
+                    }
+                }
+                if (hit) {
+                    ++h;
+                    if (HAS_VAL || HAS_W) {
+                        float va = 1.0f, vbv = 1.0f;
+                        if (HAS_VAL) { va = val[bju + k0 + 4 * lane + e]; vbv = val[vb + pos]; }
+                        if (HAS_VAL) acc_cn += va * vbv;
+                        if (HAS_W) acc_ws += (WT)va * ((WT)vbv * node_w[w]);
+                    }
+                }
+            }
+        }
+    }
+    if (v_has0 && __builtin_amdgcn_readlane(cur0[0], 0) == 0 && lane == 0) {  // node 0: see the kernel comment
+        ++h;
+        if (HAS_VAL || HAS_W) {
+            float va = 1.0f, vbv = 1.0f;
+            if (HAS_VAL) { va = val[bju]; vbv = val[vb]; }
+            if (HAS_VAL) acc_cn += va * vbv;
+            if (HAS_W) acc_ws += (WT)va * ((WT)vbv * node_w[0]);
+        }
+    }
+    const uint64_t hm = __ballot(h != 0);
+    if (hm) {
+        cnt = sparse_lane_sum<int>(hm, h);
+        r_cn = HAS_VAL ? sparse_lane_sum<float>(hm, acc_cn) : (float)cnt;
+        if (HAS_W) r_ws = sparse_lane_sum<WT>(hm, acc_ws);
+    }
+}
+
+#ifdef PG_STAMP  // diagnostic build only: per-segment s_memtime sums (never in the shipped library)
+__device__ unsigned long long g_stamp[16];
+#define STAMP(var) unsigned long long var; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory")
+#define STAMP_ADD(i, a, b) st[i] += (b) - (a)
+extern "C" int eps_debug_stamps(unsigned long long *out16, int reset)
+{
+    hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_stamp), sizeof(unsigned long long) * 16);
+    if (reset) { unsigned long long z[16] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(g_stamp), z, sizeof(z)); }
+    return 0;
+}
+#else
+#define STAMP(var)
+#define STAMP_ADD(i, a, b)
+#endif
+
+template <bool HAS_VAL, bool HAS_W, typename WT, bool EXACT>
+__global__ __launch_bounds__(PG_THREADS) void pair_scores_grouped_kernel(
+    const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col, const float *__restrict__ val,
+    const WT *__restrict__ node_w, const int32_t *__restrict__ pu, const int32_t *__restrict__ pv, int64_t n_pairs,
+    int32_t bm_words, uint32_t bm_mask, unsigned int *__restrict__ next_chunk, int32_t *__restrict__ out_count,
+    float *__restrict__ out_cn, WT *__restrict__ out_ws)
+{
+    // Unit-weight float32 AA/RA (every dataset but collab): the per-hit weight gather node_w[w] is the only
+    // dependent global load left on a pair's critical path, so it is DEFERRED: hits are appended to a per-wave
+    // LDS queue (deterministic order: pair, then position in row u) and resolved for the whole 64-pair group at
+    // once -- one parallel gather, then lane i adds up pair i's segment.  A pair costs no memory round trip.
+    constexpr bool DEFER = EXACT && HAS_W && !HAS_VAL && sizeof(WT) == 4;
+    extern __shared__ __attribute__((aligned(16))) uint32_t bm[];
+    const uint8_t *bm8 = reinterpret_cast<const uint8_t *>(bm);
+    const int tid = threadIdx.x, lane = tid & 63, wib = tid >> 6;
+    uint32_t *q = bm + bm_words + wib * PG_QCAP;  // this wave's hit queue
+    const int64_t n_chunks = (n_pairs + PG_CHUNK - 1) / PG_CHUNK;
+#ifdef PG_STAMP
+    unsigned long long st[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    STAMP(t_begin);
+#endif
+
+    // Chunks are handed out dynamically (one device-scope atomic per chunk): a column's cost follows the degrees
+    // of its candidates, so a static split leaves the slowest workgroup running ~1.5x longer than the average one.
+    // Inside a chunk the 64-pair groups are handed out dynamically too (LDS counter): group costs are heavy-tailed
+    // (a few rows hold >10k entries), and a static split left the waves idle at the chunk barrier half of the time.
+    __shared__ unsigned int s_chunk, s_group, s_first;
+    for (;;) {
+        __syncthreads();  // every wave is done with the previous chunk
+        if (tid == 0) s_chunk = atomicAdd(next_chunk, 1u);
+        __syncthreads();
+        const int64_t chunk = s_chunk;
+        if (chunk >= n_chunks) break;
+        const int64_t c0 = chunk * PG_CHUNK;
+        const int64_t cend = (c0 + PG_CHUNK) < n_pairs ? (c0 + PG_CHUNK) : n_pairs;
+      // A chunk is cut into SEGMENTS at the column boundaries it contains (runs of equal v): each segment gets its own
+      // bitmap, so a pair only leaves the bitmap path when the list is not grouped by v at all.
+      for (int64_t seg = c0; seg < cend;) {
+        const int32_t v0 = pv[seg];
+        __syncthreads();  // every wave is done with the previous segment (bitmap, s_group, s_first)
+        if (tid == 0) {
+            s_group = 0u;
+            s_first = (unsigned int)(cend - seg);
+        }
+        __syncthreads();
+        {   // first index of the segment whose v differs from v0: every thread scans a short stretch
+            const int len = (int)(cend - seg);
+            const int stride = (len + PG_THREADS - 1) / PG_THREADS;
+            for (int k = 0; k < stride; ++k) {
+                const int off = tid * stride + k;
+                if (off < len && pv[seg + off] != v0) {
+                    atomicMin(&s_first, (unsigned int)off);
+                    break;
+                }
+            }
+        }
+        __syncthreads();
+        const int64_t c0s = seg;                 // this segment: pairs [c0s, c1)
+        const int64_t c1 = seg + (int64_t)s_first;
+        seg = c1;
+        const int64_t vb = rowptr[v0];
+        const int32_t dv = (int32_t)(rowptr[v0 + 1] - vb);
+        const int32_t *__restrict__ vcol = col + vb;
+        // EXACT mode: out-of-range lanes of a row load read as node id 0, so bit 0 is never set and membership of
+        // node 0 (which, rows being sorted, can only be the FIRST element of a row) is settled on the side.
+        const bool v_has0 = EXACT && dv > 0 && vcol[0] == 0;
+
+        STAMP(tb1);
+        for (int i = tid * 4; i < bm_words; i += PG_THREADS * 4) *reinterpret_cast<uint4 *>(&bm[i]) = make_uint4(0, 0, 0, 0);
+        __syncthreads();
+        for (int k = tid; k < dv; k += PG_THREADS) {
+            const uint32_t w = (uint32_t)vcol[k];
+            const uint32_t idx = EXACT ? w : (w & bm_mask);
+            if (!EXACT || w != 0) atomicOr(&bm[idx >> 5], 1u << (idx & 31));
+        }
+        __syncthreads();
+        STAMP(tb2);
+        STAMP_ADD(1, tb1, tb2);  // 1: bitmap rebuild
+
+        for (;;) {
+            unsigned int gi = 0;
+            if (lane == 0) gi = atomicAdd(&s_group, 1u);
+            const int64_t g0 = c0s + (int64_t)__builtin_amdgcn_readfirstlane(gi) * 64;
+            if (g0 >= c1) break;
+            STAMP(tg0);
+            const int64_t p = g0 + lane;
+            const bool valid = p < c1;
+            const int32_t nu = valid ? pu[p] : 0;
+            const int32_t nv = valid ? pv[p] : v0;
+            const int64_t ub = rowptr[nu];
+            const int32_t du = valid ? (int32_t)(rowptr[nu + 1] - ub) : 0;
+            const uint64_t same_mask = __ballot(nv == v0);
+            int64_t vb2 = vb;
+            int32_t dv2 = dv;
+            if (same_mask != ~0ull) {  // a run boundary inside this group (rare)
+                vb2 = rowptr[nv];
+                dv2 = (int32_t)(rowptr[nv + 1] - vb2);
+            }
+
+            int32_t my_count = 0;
+            float my_cn = 0.0f;
+            WT my_ws = 0;
+            int my_qstart = 0, my_qcnt = 0;  // this lane's pair: its segment of the hit queue
+            int qlen = 0;                    // wave-uniform
+            const int here = (c1 - g0) < 64 ? (int)(c1 - g0) : 64;
+
+            // Resolve the queue: one parallel gather of node_w over all queued hits, then lane i adds up pair i's
+            // segment in queue order.  ``open_j`` >= 0: pair open_j is still being tested (queue nearly full in the
+            // middle of a row); its partial segment [open_q0, qlen) is folded in and the pair carries on from 0.
+            auto flush = [&](int open_j, int open_q0) {
+                if (!DEFER) return;
+                if (open_j >= 0 && lane == open_j) { my_qstart = open_q0; my_qcnt = qlen - open_q0; }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                for (int t = lane; t < qlen; t += 64) q[t] = __builtin_bit_cast(uint32_t, (float)node_w[q[t]]);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                float sacc = 0.0f;
+                for (int t = 0; t < my_qcnt; ++t) sacc += __builtin_bit_cast(float, q[my_qstart + t]);
+                my_ws += (WT)sacc;
+                my_qcnt = 0;
+                qlen = 0;
+                __builtin_amdgcn_wave_barrier();
+            };
+
+            // Every ring register is written by exactly one UNCONDITIONAL load per trip (pairs past the end of the
+            // group get a zero-length descriptor: no traffic, zeros back): a conditional refill turns the ring into
+            // phi copies, and hipcc then waits for the in-flight loads right after issuing them.
+            v4i ring0[PG_RING], ring1[PG_RING];
+#pragma unroll
+            for (int r = 0; r < PG_RING; ++r) {
+                const __amdgpu_buffer_rsrc_t r0 = row_rsrc(col + bcast64(ub, r), __builtin_amdgcn_readlane(du, r));
+                ring0[r] = __builtin_amdgcn_raw_buffer_load_b128(r0, lane * 16, 0, 0);
+                ring1[r] = __builtin_amdgcn_raw_buffer_load_b128(r0, lane * 16 + 1024, 0, 0);
+            }
+#ifdef PG_STAMP
+            asm volatile("" ::"v"(du), "v"(ub));
+            STAMP(tg1);
+            STAMP_ADD(2, tg0, tg1);  // 2: group metadata
+#endif
+            for (int jb = 0; jb < 64; jb += PG_RING) {
+#pragma unroll
+                for (int r = 0; r < PG_RING; ++r) {
+                    const int j = jb + r;
+                    STAMP(tp0);
+                    const int32_t dju = __builtin_amdgcn_readlane(du, j);   // 0 for lanes past the end of the chunk
+                    const int64_t bju = bcast64(ub, j);
+                    const __amdgpu_buffer_rsrc_t rj = row_rsrc(col + bju, dju);
+                    const v4i cur0 = ring0[r], cur1 = ring1[r];
+                    {
+                        const int jn = (j + PG_RING) & 63;
+                        const int32_t dn = (j + PG_RING) < 64 ? __builtin_amdgcn_readlane(du, jn) : 0;
+                        const __amdgpu_buffer_rsrc_t rn = row_rsrc(col + bcast64(ub, jn), dn);
+                        ring0[r] = __builtin_amdgcn_raw_buffer_load_b128(rn, lane * 16, 0, 0);
+                        ring1[r] = __builtin_amdgcn_raw_buffer_load_b128(rn, lane * 16 + 1024, 0, 0);
+                    }
+#if defined(PG_ABLATE) && PG_ABLATE == 3   // timing-only: metadata + ring loads only
+                    asm volatile("" ::"v"(cur0), "v"(cur1));
+                    continue;
+#endif
+#ifdef PG_STAMP
+                    STAMP(tp05);
+                    STAMP_ADD(9, tp0, tp05);  // 9: readlanes + descriptors + refill issue
+                    asm volatile("" ::"v"(cur0), "v"(cur1));
+                    STAMP(tp1);
+                    STAMP_ADD(3, tp05, tp1);  // 3: wait for this pair's ring data
+#endif
+                    if (dju == 0) continue;
+                    int cnt = 0;
+                    float r_cn = 0.0f;
+                    WT r_ws = 0;
+                    if ((same_mask >> j) & 1) {
+                        if (dv == 0) continue;
+                        if (DEFER) {
+                            int q0 = qlen;
+                            // units 0 and 1 come from the prefetch ring, later ones (rows > 512) are fetched on demand in
+                            // a loop of their own: merging the two sources in one loop makes hipcc wait vmcnt(0) -- i.e.
+                            // for the whole ring -- before every unit.
+                            auto test_unit = [&](v4i wv) {
+#if defined(PG_ABLATE) && PG_ABLATE == 1   // timing-only: no dependence on the row loads (they become dead)
+                                wv = (v4i){lane * 4 + j, lane * 4 + 1 + 7 * j, lane * 4 + 2 + 13 * j, lane * 4 + 3 + j};
+#endif
+#if defined(PG_ABLATE) && PG_ABLATE == 2   // timing-only: row loads kept alive, no bitmap test
+                                asm volatile("" ::"v"(wv));
+                                return;
+#endif
+                                uint32_t b[4];
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) {
+                                    const uint32_t w = (uint32_t)wv[e];
+                                    b[e] = ((uint32_t)bm8[w >> 3] >> (w & 7)) & 1u;
+                                }
+                                const uint32_t any = b[0] | b[1] | b[2] | b[3];
+                                if (__ballot(any != 0) != 0ull) {
+                                    if (qlen > PG_QCAP - 256) {  // a unit adds at most 256 hits
+                                        flush(j, q0);
+                                        q0 = 0;
+                                    }
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) {
+                                        const uint64_t m = __ballot(b[e] != 0);
+                                        const int below = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
+                                        if (b[e]) q[qlen + below] = (uint32_t)wv[e];
+                                        const int c = __popcll(m);
+                                        qlen += c;
+                                        cnt += c;
+                                    }
+                                }
+                            };
+                            STAMP(tu0);
+                            test_unit(cur0);
+                            if (dju > 256) test_unit(cur1);
+                            STAMP(tu1);
+                            STAMP_ADD(4, tu0, tu1);  // 4: first two units
+                            // rows beyond 512 entries: four loads in flight per trip (a load-use-load chain would
+                            // pay one full memory latency per 256 entries; out-of-range units read as zeros = no hit)
+#if defined(PG_ABLATE) && PG_ABLATE == 4   // timing-only: rows truncated to their first 512 entries
+                            if (false)
+#endif
+                            for (int k0 = 512; k0 < dju; k0 += 1024) {
+                                const v4i x0 = __builtin_amdgcn_raw_buffer_load_b128(rj, lane * 16 + k0 * 4, 0, 0);
+                                const v4i x1 = __builtin_amdgcn_raw_buffer_load_b128(rj, lane * 16 + k0 * 4 + 1024, 0, 0);
+                                const v4i x2 = __builtin_amdgcn_raw_buffer_load_b128(rj, lane * 16 + k0 * 4 + 2048, 0, 0);
+                                const v4i x3 = __builtin_amdgcn_raw_buffer_load_b128(rj, lane * 16 + k0 * 4 + 3072, 0, 0);
+                                test_unit(x0);
+                                if (k0 + 256 < dju) test_unit(x1);
+                                if (k0 + 512 < dju) test_unit(x2);
+                                if (k0 + 768 < dju) test_unit(x3);
+                            }
+                            STAMP(tu2);
+                            STAMP_ADD(5, tu1, tu2);  // 5: on-demand units of long rows
+                            if (v_has0 && __builtin_amdgcn_readlane(cur0[0], 0) == 0) {  // node 0 is a common neighbour
+                                if (qlen >= PG_QCAP) {
+                                    flush(j, q0);
+                                    q0 = 0;
+                                }
+                                if (lane == 0) q[qlen] = 0u;
+                                qlen += 1;
+                                cnt += 1;
+                            }
+                            if (cnt != 0 && lane == j) { my_count = cnt; my_cn = (float)cnt; my_qstart = q0; my_qcnt = qlen - q0; }
+#ifdef PG_STAMP
+                            asm volatile("" ::"v"(my_count), "v"(my_qstart), "v"(my_qcnt), "s"(qlen));
+                            STAMP(tu3);
+                            STAMP_ADD(8, tu2, tu3);  // 8: node-0 check + result select
+#endif
+                            continue;
+                        }
+                        test_row_inline<HAS_VAL, HAS_W, WT, EXACT>(bm8, bm_mask, vcol, dv, vb, v_has0, rj, bju, dju, cur0, cur1,
+                                                                   val, node_w, lane, cnt, r_cn, r_ws);
+                    } else {
+                        const int32_t djv = __builtin_amdgcn_readlane(dv2, j);
+                        if (djv != 0) {
+                            float acc_cn = 0.0f;
+                            WT acc_ws = 0;
+                            score_pair_inplace<HAS_VAL, HAS_W, WT>(col, val, node_w, bju, dju, bcast64(vb2, j), djv, lane,
+                                                                   cnt, acc_cn, acc_ws);
+                            if (cnt != 0) {
+                                r_cn = HAS_VAL ? eps_wave_sum(acc_cn) : (float)cnt;
+                                if (HAS_W) r_ws = eps_wave_sum(acc_ws);
+                            }
+                        }
+                    }
+                    if (cnt != 0 && lane == j) { my_count = cnt; my_cn = r_cn; my_ws = r_ws; }
+                }
+            }
+            STAMP(tf0);
+            flush(-1, 0);
+            STAMP(tf1);
+            STAMP_ADD(6, tf0, tf1);  // 6: final flush of the group
+            if (valid) {
+                if (out_count) out_count[p] = my_count;
+                if (out_cn) out_cn[p] = my_cn;
+                if (HAS_W && out_ws) out_ws[p] = my_ws;
+            }
+        }
+      }
+    }
+#ifdef PG_STAMP
+    STAMP(t_end);
+    st[7] = t_end - t_begin;  // 7: whole wave
+    if (lane == 0)
+        for (int i = 0; i < 10; ++i) atomicAdd(&g_stamp[i], st[i]);
+#endif
+}
+
+template <typename WT>
+static int launch_pair_scores_grouped(const int64_t *rowptr, const int32_t *col, const float *val, const WT *node_w,
+                                      int64_t n_nodes, const int32_t *u, const int32_t *v, int64_t n_pairs,
+                                      int32_t *count, float *cn, WT *wsum, hipStream_t stream)
+{
+    if (n_pairs == 0) return EPS_OK;
+    // bitmap: exact (one bit per node id) when it fits 2^20 bits, hashed (w & mask) + verified otherwise
+    int64_t words = (n_nodes + 31) / 32;
+    words = (words + PG_THREADS * 4 - 1) / (PG_THREADS * 4) * (PG_THREADS * 4);  // whole uint4 sweeps
+    const bool exact = words <= PG_MAX_WORDS;
+    if (!exact) words = PG_MAX_WORDS;
+    const uint32_t mask = (uint32_t)(words * 32 - 1);
+    // the per-wave hit queues exist only for the deferred-gather (exact bitmap) variants
+    const size_t lds = (size_t)words * 4 + (exact ? (size_t)PG_WAVES * PG_QCAP * 4 : 0);
+    const int64_t n_chunks = (n_pairs + PG_CHUNK - 1) / PG_CHUNK;
+    int per_cu = (int)(163840 / (lds + 256));
+    if (per_cu > 4) per_cu = 4;
+    if (per_cu < 1) per_cu = 1;
+    int64_t blocks = (int64_t)eps_num_cus() * per_cu;
+    if (blocks > n_chunks) blocks = n_chunks;
+    unsigned int *counter = nullptr;
+    const int crc = eps_take_counter(&counter, stream, "eps_pair_scores_grouped");
+    if (crc) return crc;
+    const bool hv = val != nullptr, hw = node_w != nullptr && wsum != nullptr;
+#define PG_LAUNCH(HV, HW, EX)                                                                                        \
+    do {                                                                                                             \
+        auto kern = pair_scores_grouped_kernel<HV, HW, WT, EX>;                                                      \
+        if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=         \
+            hipSuccess) {                                                                                            \
+            eps_set_error("eps_pair_scores_grouped: cannot reserve %zu bytes of LDS", lds);                          \
+            return EPS_ELAUNCH;                                                                                      \
+        }                                                                                                            \
+        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(PG_THREADS), lds, stream, rowptr, col, val, node_w, u, \
+                           v, n_pairs, (int32_t)words, mask, counter, count, cn, wsum);                                       \
+    } while (0)
+    if (exact) {
+        if (hv && hw) PG_LAUNCH(true, true, true);
+        else if (hv) PG_LAUNCH(true, false, true);
+        else if (hw) PG_LAUNCH(false, true, true);
+        else PG_LAUNCH(false, false, true);
+    } else {
+        if (hv && hw) PG_LAUNCH(true, true, false);
+        else if (hv) PG_LAUNCH(true, false, false);
+        else if (hw) PG_LAUNCH(false, true, false);
+        else PG_LAUNCH(false, false, false);
+    }
+#undef PG_LAUNCH
+    EPS_CHECK_LAUNCH("eps_pair_scores_grouped");
+    return EPS_OK;
+}
+
+extern "C" int eps_pair_scores_grouped(const int64_t *rowptr, const int32_t *col, const float *val,
+                                       const float *node_w, int64_t n_nodes, const int32_t *u, const int32_t *v,
+                                       int64_t n_pairs, int32_t *count, float *cn, float *wsum, void *stream)
+{
+    EPS_REQUIRE(n_pairs >= 0 && n_nodes >= 0, "eps_pair_scores_grouped: negative size");
+    EPS_REQUIRE(n_pairs == 0 || (rowptr && col && u && v), "eps_pair_scores_grouped: null graph or pair pointer");
+    EPS_REQUIRE(!(wsum && !node_w), "eps_pair_scores_grouped: wsum requested without node_w");
+    EPS_REQUIRE(count || cn || wsum || n_pairs == 0, "eps_pair_scores_grouped: no output requested");
+    return launch_pair_scores_grouped<float>(rowptr, col, val, node_w, n_nodes, u, v, n_pairs, count, cn, wsum,
+                                             (hipStream_t)stream);
+}
+
+extern "C" int eps_pair_scores_grouped_f64(const int64_t *rowptr, const int32_t *col, const float *val,
+                                           const double *node_w, int64_t n_nodes, const int32_t *u, const int32_t *v,
+                                           int64_t n_pairs, int32_t *count, double *wsum, void *stream)
+{
+    EPS_REQUIRE(n_pairs >= 0 && n_nodes >= 0, "eps_pair_scores_grouped_f64: negative size");
+    EPS_REQUIRE(n_pairs == 0 || (rowptr && col && u && v), "eps_pair_scores_grouped_f64: null graph or pair pointer");
+    EPS_REQUIRE(!(wsum && !node_w), "eps_pair_scores_grouped_f64: wsum requested without node_w");
+    EPS_REQUIRE(count || wsum || n_pairs == 0, "eps_pair_scores_grouped_f64: no output requested");
+    return launch_pair_scores_grouped<double>(rowptr, col, val, node_w, n_nodes, u, v, n_pairs, count, nullptr, wsum,
+                                              (hipStream_t)stream);
+}
+

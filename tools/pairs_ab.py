@@ -40,3 +40,18 @@ print("P(du>256)", (du > 256).float().mean().item(), "P(du>512)", (du > 512).flo
       "P(du>1536)", (du > 1536).float().mean().item(),
       "mean extra units (>512)", ((du - 512).clamp(min=0) / 256).ceil().mean().item(),
       "mean trips x4", ((du - 512).clamp(min=0) / 1024).ceil().mean().item())
+# eval-like lists: positive-like (actual edges) and uniform random negatives, through the generic kernel
+gen = torch.Generator(device=dev).manual_seed(1)
+row, colx, _ = g.coo()
+sel = torch.randint(0, row.numel(), (6_000_000,), generator=gen, device=dev)
+pos_u, pos_v = row[sel].to(torch.int32).contiguous(), colx[sel].to(torch.int32).contiguous()
+neg_u = torch.randint(0, g.n_rows, (3_000_000,), generator=gen, device=dev, dtype=torch.int32)
+neg_v = torch.randint(0, g.n_rows, (3_000_000,), generator=gen, device=dev, dtype=torch.int32)
+for name, (a_, b_) in {"pos-like 6M": (pos_u, pos_v), "neg-uniform 3M": (neg_u, neg_v)}.items():
+    ts = []
+    for r in range(4):
+        torch.cuda.synchronize(); e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); ops.pair_scores(g.rowptr, g.col, None, w, g.n_rows, a_, b_, want_cn=False, grouped=False); e1.record()
+        torch.cuda.synchronize(); ts.append(e0.elapsed_time(e1))
+    print(f"generic on {name}: min {min(ts):.3f} ms -> {a_.numel() / min(ts) / 1e6:.2f} G pairs/s, mean deg sum "
+          f"{(deg[a_.long()] + deg[b_.long()]).float().mean().item():.0f}")
