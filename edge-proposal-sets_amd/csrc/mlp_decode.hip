@@ -95,29 +95,59 @@ __global__ __launch_bounds__(D_THREADS) void mlp_decode_kernel(const float *__re
     const int h4 = H >> 2;                  // float4 per row
     const int hp4 = Hp >> 2;
 
+    // The rows of h a tile gathers (2 x 64 KiB-rows) are PREFETCHED into registers during the previous tile's MFMA
+    // phase: 16 float4 per lane (8 rows x 2 endpoints; a row is one float4 per lane at H <= 256).  Every prefetch
+    // register is written by one unconditional load per tile (tiles past the end re-read row 0: no phi copies, so
+    // hipcc keeps counted vmcnt waits instead of draining the queue).
+    const int cl = lane < h4 ? lane : 0;  // this lane's float4 column of a row (clamped for H < 256)
+    auto tile_ids = [&](int64_t t, int32_t &mu, int32_t &mv) {
+        const int64_t p = t * D_BM + lane;
+        const bool ok = t < n_tiles && p < n_pairs;
+        const int64_t pc = ok ? p : 0;
+        mu = pu[pc];
+        mv = pv[pc];
+        if (!ok) { mu = 0; mv = 0; }
+    };
+    v4f ga[8], gb[8];
+    int32_t mu, mv;
+    tile_ids(blockIdx.x, mu, mv);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int64_t un = __builtin_amdgcn_readlane(mu, w * 8 + i), vn = __builtin_amdgcn_readlane(mv, w * 8 + i);
+        ga[i] = *reinterpret_cast<const v4f *>(hmat + un * H + 4 * cl);
+        gb[i] = *reinterpret_cast<const v4f *>(hmat + vn * H + 4 * cl);
+    }
+
     for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const int64_t e0 = tile * D_BM;
-        // ---- 1. gather + Hadamard into LDS: wave w builds rows 8w..8w+7, all 16 row reads in flight at once ----
-        {
-            const int64_t p = e0 + lane;
-            const int32_t mu = p < n_pairs ? pu[p] : 0, mv = p < n_pairs ? pv[p] : 0;
-            for (int c = lane; c < hp4; c += 64) {
-                v4f a[8], b[8];
+        int32_t nmu, nmv;                       // ids of the NEXT tile of this workgroup: in flight during the X build
+        tile_ids(tile + gridDim.x, nmu, nmv);
+        // ---- 1. Hadamard of the prefetched rows into LDS: wave w owns rows 8w..8w+7 ---------------------------
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const int64_t un = __builtin_amdgcn_readlane(mu, w * 8 + i), vn = __builtin_amdgcn_readlane(mv, w * 8 + i);
-                    const int cc = c < h4 ? c : 0;
-                    a[i] = *reinterpret_cast<const v4f *>(hmat + un * H + 4 * cc);
-                    b[i] = *reinterpret_cast<const v4f *>(hmat + vn * H + 4 * cc);
-                }
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    v4f pr = a[i] * b[i];
-                    if (c >= h4) pr = (v4f){0.f, 0.f, 0.f, 0.f};  // pad columns
-                    *reinterpret_cast<v4f *>(&Xs[w * 8 + i][4 * c]) = pr;
-                }
-            }
+        for (int i = 0; i < 8; ++i) {
+            v4f pr = ga[i] * gb[i];
+            if (lane >= h4) pr = (v4f){0.f, 0.f, 0.f, 0.f};  // pad columns (and idle lanes when H < 256)
+            if (lane < hp4) *reinterpret_cast<v4f *>(&Xs[w * 8 + i][4 * lane]) = pr;
         }
+        __syncthreads();
+        // first W chunk of the first hidden layer, THEN the next tile's row prefetch: the chunk's wait (counted vmcnt)
+        // leaves the younger prefetch loads in flight under the MFMA phase
+        v4f rw[D_WREGS];
+        {
+            const float *W0 = pick(prm.w, 0);
+            const __amdgpu_buffer_rsrc_t wr0 = __builtin_amdgcn_make_buffer_rsrc((void *)W0, 0, n_layers > 1 ? H * H * 4 : 0, 0x00020000);
+            w_gload(rw, wr0, H, tid, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);  // keep the W loads OLDER than the prefetch (vmcnt retires in issue order)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int64_t un = __builtin_amdgcn_readlane(nmu, w * 8 + i), vn = __builtin_amdgcn_readlane(nmv, w * 8 + i);
+            ga[i] = *reinterpret_cast<const v4f *>(hmat + un * H + 4 * cl);
+            gb[i] = *reinterpret_cast<const v4f *>(hmat + vn * H + 4 * cl);
+        }
+        // stage chunk 0 here, in straight-line code: inside the layer loop the wait would be merged with the back edge
+        // (where the W loads are the youngest) and degrade to vmcnt(0), draining the prefetch
+        w_lstore(rw, Ws[0], tid);
         __syncthreads();
 
         // ---- 2. hidden layers -------------------------------------------------------------
@@ -131,10 +161,7 @@ __global__ __launch_bounds__(D_THREADS) void mlp_decode_kernel(const float *__re
                 for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
 
             const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void *)W, 0, H * H * 4, 0x00020000);
-            v4f rw[D_WREGS];
-            w_gload(rw, wr, H, tid, 0);
-            w_lstore(rw, Ws[0], tid);
-            __syncthreads();
+            // (chunk 0 of this layer is already in Ws[0]: staged before the loop / at the end of the previous layer)
             for (int kc = 0; kc < nk; ++kc) {
                 const int buf = kc & 1;
                 if (kc + 1 < nk) w_gload(rw, wr, H, tid, kc + 1);
@@ -182,6 +209,14 @@ __global__ __launch_bounds__(D_THREADS) void mlp_decode_kernel(const float *__re
                     Xs[rr][cc] = t > 0.f ? t : 0.f;
                 }
             }
+            {   // request chunk 0 of the next hidden layer (zero-length descriptor after the last one: no traffic)
+                const bool more = l + 2 < n_layers;
+                const float *Wn = pick(prm.w, more ? l + 1 : 0);
+                const __amdgpu_buffer_rsrc_t wrn = __builtin_amdgcn_make_buffer_rsrc((void *)Wn, 0, more ? H * H * 4 : 0, 0x00020000);
+                w_gload(rw, wrn, H, tid, 0);
+            }
+            __syncthreads();
+            w_lstore(rw, Ws[0], tid);   // zeros after the last hidden layer (zero-length descriptor)
             __syncthreads();
         }
 
