@@ -139,32 +139,14 @@ def run(args) -> str:
     keep = int(args.keep_top)
     col_lo, col_hi = rank_column_range(data.adj_t, rank, world)
     n_seen = 0
-    if world > 1:
-        # global candidate index of this rank's first candidate = candidates in all lower columns (one count pass)
-        counts = torch.zeros(world, dtype=torch.int64, device=device)
-        mine = 0
-        for lo, hi in candidates.column_blocks(data.adj_t):
-            lo, hi = max(lo, col_lo), min(hi, col_hi)
-            if lo < hi:
-                mine += candidates.expand_block(data.adj_t, lo, hi)[0].shape[1]
-        counts[rank] = mine
-        torch.distributed.all_reduce(counts)
-        n_seen = int(counts[:rank].sum().item())
-        if n_seen + mine >= (1 << 32):
-            raise ValueError("more than 2^32 candidates: the packed top-K keys carry 32-bit candidate ids")
-    all_pairs, all_scores, best_keys, best_pairs = [], [], None, None
+    all_pairs, all_scores = [], []
+    top = proposals.StreamingTopK(keep) if keep else None
     with torch.no_grad():
         for v_lo, v_hi, pairs, score in scored_blocks(args, model, data, ra_graph, col_lo, col_hi):
             if pairs.shape[1] == 0:
                 continue
             if keep:
-                keys = proposals.top_k_keys(score, keep, id_base=n_seen)          # sorted, global candidate ids
-                _, ids = ops.unpack_keys(keys)
-                kept = pairs[:, ids - n_seen]
-                if best_keys is not None:
-                    keys, kept = torch.cat([best_keys, keys]), torch.cat([best_pairs, kept], 1)
-                top = torch.topk(keys, min(keep, keys.numel()), largest=True, sorted=True)
-                best_keys, best_pairs = top.values, kept[:, top.indices]
+                top.push(pairs, score)          # blocks arrive in candidate (column-major) order
             else:
                 all_pairs.append(pairs)
                 all_scores.append(score)
@@ -173,26 +155,27 @@ def run(args) -> str:
     dt = time.perf_counter() - t0
     print(f'using {n_seen} edges; scored in {dt:.2f} s ({n_seen / max(dt, 1e-9):.3e} candidate edges/s incl. generation)')
 
-    if keep and world > 1:
-        # merge the per-rank sorted key lists (K x 8 B each); the winners' (u, v) travel with a second small gather
-        kk = keep
-        if best_keys is None:
-            best_keys = torch.zeros(0, dtype=torch.int64, device=device)
-            best_pairs = torch.zeros((2, 0), dtype=torch.int64, device=device)
-        pad_pairs = torch.zeros((2, kk), dtype=torch.int64, device=device)
-        pad_pairs[:, :best_pairs.shape[1]] = best_pairs
-        lists = epd.all_gather_keys(best_keys, kk)
-        gathered = [torch.empty_like(pad_pairs) for _ in range(world)]
-        torch.distributed.all_gather(gathered, pad_pairs)
-        allk = torch.cat(lists)
-        allp = torch.cat(gathered, 1)
-        valid = allk != torch.iinfo(torch.int64).min
-        allk, allp = allk[valid], allp[:, valid]
-        top = torch.topk(allk, min(kk, allk.numel()), largest=True, sorted=True)
-        best_keys, best_pairs = top.values, allp[:, top.indices]
     if keep:
-        score, _ = ops.unpack_keys(best_keys)
-        sorted_edges = torch.cat([best_pairs.t().to(torch.float32), score.unsqueeze(1)], 1)
+        best_pairs, best_scores = top.result()
+        best_pairs, best_scores = best_pairs.to(device), best_scores.to(device)
+        if world > 1:
+            # ranks hold contiguous column ranges in rank order: gather the (padded) per-rank lists -- K x 20 B each --
+            # and stable-merge them in rank order
+            n_mine = torch.tensor([best_scores.numel()], dtype=torch.int64, device=device)
+            n_all = [torch.zeros_like(n_mine) for _ in range(world)]
+            torch.distributed.all_gather(n_all, n_mine)
+            pad_s = torch.full((keep,), float("-inf"), dtype=torch.float32, device=device)
+            pad_p = torch.zeros((2, keep), dtype=torch.int64, device=device)
+            pad_s[:best_scores.numel()] = best_scores
+            pad_p[:, :best_pairs.shape[1]] = best_pairs
+            gs = [torch.empty_like(pad_s) for _ in range(world)]
+            gp = [torch.empty_like(pad_p) for _ in range(world)]
+            torch.distributed.all_gather(gs, pad_s)
+            torch.distributed.all_gather(gp, pad_p)
+            cnt = [int(x.item()) for x in n_all]
+            best_pairs, best_scores = proposals.merge_ranked_lists([gp[r][:, :cnt[r]] for r in range(world)],
+                                                                   [gs[r][:cnt[r]] for r in range(world)], keep)
+        sorted_edges = torch.cat([best_pairs.t().to(torch.float32), best_scores.unsqueeze(1)], 1)
     else:
         pairs = torch.cat(all_pairs, 1)
         scores = torch.cat(all_scores)

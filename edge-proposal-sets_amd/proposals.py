@@ -54,3 +54,45 @@ def load_proposals(path: str, num: int) -> torch.Tensor:
     """rank.py:219 + :294: the first ``num`` proposal rows as a LongTensor [2,num]."""
     t = torch.load(path)
     return t[:int(num), :2].t().long()
+
+
+class StreamingTopK:
+    """Top-K of a candidate stream under the declared rule (score descending, candidate order ascending) when the
+    blocks ARRIVE in candidate order: a stable descending sort keeps earlier candidates first among equal scores, so
+    no candidate index has to be carried (the full ppa candidate set exceeds 2**32 entries).  Once K entries are held,
+    a block is first cut to the scores strictly above the current K-th one -- an equal score from a later block can
+    never displace an earlier candidate -- which leaves next to nothing to sort for most blocks."""
+
+    def __init__(self, k: int):
+        self.k = int(k)
+        self.scores = None     # float32 [<=k], descending
+        self.pairs = None      # int64 [2, <=k]
+
+    def push(self, pairs: torch.Tensor, scores: torch.Tensor) -> None:
+        if scores.numel() == 0:
+            return
+        if self.scores is not None and self.scores.numel() >= self.k:
+            m = scores > self.scores[-1]
+            if not bool(m.any()):
+                return
+            pairs, scores = pairs[:, m], scores[m]            # boolean indexing keeps candidate order
+        if self.scores is not None:
+            scores = torch.cat([self.scores, scores])          # held entries come first: they are earlier candidates
+            pairs = torch.cat([self.pairs, pairs], 1)
+        order = torch.sort(scores, descending=True, stable=True).indices[: self.k]
+        self.scores, self.pairs = scores[order], pairs[:, order]
+
+    def result(self):
+        if self.scores is None:
+            dev = "cpu"
+            return torch.zeros((2, 0), dtype=torch.int64, device=dev), torch.zeros(0, dtype=torch.float32, device=dev)
+        return self.pairs, self.scores
+
+
+def merge_ranked_lists(pair_lists, score_lists, k: int):
+    """Merge per-shard top-K lists whose shards are CONTIGUOUS candidate ranges given in shard order: concatenate
+    in that order and stable-sort -- the result equals the single-process top-K for any number of shards."""
+    scores = torch.cat(list(score_lists))
+    pairs = torch.cat(list(pair_lists), 1)
+    order = torch.sort(scores, descending=True, stable=True).indices[:k]
+    return pairs[:, order], scores[order]

@@ -107,3 +107,28 @@ def test_shard_count_invariance():
     ids = (0xFFFFFFFF - (ref.numpy().view(np.uint64) & np.uint64(0xFFFFFFFF))).astype(np.int64)
     want = torch.sort(score, descending=True, stable=True).indices[:1000]
     assert np.array_equal(ids, want.numpy())
+
+
+def test_streaming_topk_and_ranked_merge_cpu():
+    """StreamingTopK over blocks in candidate order == stable descending sort of everything; contiguous shards merged
+    in shard order give the same list for 1/2/4/8 shards (no candidate ids carried: works past 2**32 candidates)."""
+    sys.path.insert(0, ROOT)
+    import eps_amd  # noqa: F401
+    from eps_amd import proposals
+    g = torch.Generator().manual_seed(9)
+    n, k = 40000, 700
+    scores = torch.randint(0, 25, (n,), generator=g).float()          # CN-like ties
+    pairs = torch.stack([torch.arange(n), torch.arange(n) * 7 % 1000])
+    want = torch.sort(scores, descending=True, stable=True).indices[:k]
+    for world in (1, 2, 4, 8):
+        bounds = [n * r // world for r in range(world + 1)]
+        pl, sl = [], []
+        for r in range(world):
+            top = proposals.StreamingTopK(k)
+            for b in range(bounds[r], bounds[r + 1], 1777):            # ragged blocks
+                e = min(b + 1777, bounds[r + 1])
+                top.push(pairs[:, b:e], scores[b:e])
+            p, s = top.result()
+            pl.append(p); sl.append(s)
+        mp, ms = proposals.merge_ranked_lists(pl, sl, k)
+        assert torch.equal(mp[0], want) and torch.equal(ms, scores[want])
