@@ -6,9 +6,9 @@ hand-written HIP kernels (csrc/) instead of torch_geometric / torch_sparse / cuB
 Scoring signature kept: ``model(x, edges[2,B], adj_t) -> scores`` ([B,1] for LinkGNN, [B] for
 CommonNeighborsPredictor('simple')).
 
-Scope: inference (the scoring loops of filter.py:113-121 and train_and_eval.py:108-136 run under
-``model.eval()`` / ``torch.no_grad()``).  Training (train_and_eval.py:31-96) is SURVEY 8(f) row 5,
-outside the accelerated path: calling ``forward`` in training mode raises.
+Scope: the scoring loops (filter.py:113-121, train_and_eval.py:108-136: ``model.eval()`` / ``torch.no_grad()``)
+run entirely on the HIP kernels.  Training (train_and_eval.py:31-96) runs on torch autograd
+with the HIP SpMM as a custom autograd Function (forward and backward) and the dense layers on torch.
 
 What differs from the reference on purpose: ``LinkGNN`` computes the node embeddings ``h`` ONCE per
 (parameters, x, adjacency) and reuses them for every scoring batch; the reference re-runs the whole
@@ -28,11 +28,26 @@ from .graph import CSRGraph
 from . import heuristics
 
 
-def _require_eval(module: torch.nn.Module):
-    if module.training:
-        raise NotImplementedError(
-            f"{type(module).__name__}.forward in training mode: training/backward is outside the accelerated "
-            "scoring path (SURVEY 8(f) row 5); call model.eval() as filter.py:90 / train_and_eval.py:100 do")
+class _SpMM(torch.autograd.Function):
+    """Differentiable CSR x dense aggregate for TRAINING (train_and_eval.py:31-96): forward and backward both run
+    eps_spmm_csr.  The adjacency must be structurally symmetric with symmetric values (every adjacency the reference
+    builds is: rank.py:33), so the transposed product of the backward pass is a product with the same matrix:
+      sum : Y = A X          ->  dX = A dY
+      mean: Y = D^-1 A X     ->  dX = A (D^-1 dY)        (unit values)"""
+
+    @staticmethod
+    def forward(ctx, x, graph, mean):
+        ctx.graph, ctx.mean = graph, mean
+        return ops.spmm_csr(graph.rowptr, graph.col, None if mean else graph.val, x.contiguous(), mean=mean)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        g = ctx.graph
+        grad_out = grad_out.contiguous()
+        if ctx.mean:
+            inv = 1.0 / g.degree().clamp(min=1).to(torch.float32)
+            grad_out = (grad_out * inv[:, None]).contiguous()
+        return ops.spmm_csr(g.rowptr, g.col, None if ctx.mean else g.val, grad_out), None, None
 
 
 def _pad4_full(x: torch.Tensor):
@@ -78,10 +93,15 @@ class GCNConv(torch.nn.Module):
             state_dict[prefix + "weight"] = state_dict.pop(k_new).t()
         return super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
 
-    @torch.no_grad()
     def forward(self, x: torch.Tensor, adj_t: CSRGraph, relu: bool = False) -> torch.Tensor:
-        _require_eval(self)
         gn = adj_t.gcn_normalized()                      # cached per adjacency (eps_gcn_norm)
+        if torch.is_grad_enabled() and self.training:    # training: HIP SpMM inside autograd, dense part on torch
+            out = _SpMM.apply(x @ self.weight, gn, False) + self.bias
+            return F.relu(out) if relu else out
+        with torch.no_grad():
+            return self._forward_hip(x, gn, relu)
+
+    def _forward_hip(self, x, gn, relu):
         w_nk = self.weight.detach().t().contiguous()     # [out,in]: the GEMM takes Linear layout
         xw = ops.gemm(_pad4(x), w_nk)                    # transform ...
         return ops.spmm_csr(gn.rowptr, gn.col, gn.val, xw, bias=self.bias.detach(), relu=relu)   # ... then aggregate
@@ -105,9 +125,14 @@ class SAGEConv(torch.nn.Module):
         self.lin_l.reset_parameters()
         self.lin_r.reset_parameters()
 
-    @torch.no_grad()
     def forward(self, x: torch.Tensor, adj_t: CSRGraph, relu: bool = False) -> torch.Tensor:
-        _require_eval(self)
+        if torch.is_grad_enabled() and self.training:
+            out = self.lin_l(_SpMM.apply(x, adj_t, True)) + self.lin_r(x)
+            return F.relu(out) if relu else out
+        with torch.no_grad():
+            return self._forward_hip(x, adj_t, relu)
+
+    def _forward_hip(self, x, adj_t, relu):
         k = x.shape[1]
         x, x_full = _pad4_full(x)                      # pad columns are zero: aggregate the padded width (float4 path)
         agg = ops.spmm_csr(adj_t.rowptr, adj_t.col, None, x_full, mean=True)[:, :k]
@@ -139,6 +164,7 @@ class _ConvStack(torch.nn.Module):
         # the ReLU rides in the producing kernel's epilogue.
         for conv in self.convs[:-1]:
             x = conv(x, adj_t, relu=True)
+            x = F.dropout(x, p=self.dropout, training=self.training)   # identity in eval mode
         return self.convs[-1](x, adj_t)
 
 
@@ -171,8 +197,7 @@ class LinkPredictor(torch.nn.Module):
 
     @torch.no_grad()
     def decode(self, h: torch.Tensor, edges: torch.Tensor, apply_sigmoid: bool = True) -> torch.Tensor:
-        """Fused gather + MLP + sigmoid over edges [2,B] (eps_mlp_decode) -> float32 [B]."""
-        _require_eval(self)
+        """Fused gather + MLP + sigmoid over edges [2,B] (eps_mlp_decode) -> float32 [B].  Inference only."""
         e = edges.to(device=h.device, dtype=torch.int32)
         ws = [lin.weight.detach().contiguous() for lin in self.lins]
         bs = [lin.bias.detach().contiguous() for lin in self.lins]
@@ -181,6 +206,11 @@ class LinkPredictor(torch.nn.Module):
     def forward(self, x_i: torch.Tensor, x_j: torch.Tensor) -> torch.Tensor:
         """Reference signature: two gathered [B,H] blocks -> [B,1].  (LinkGNN uses decode(), which gathers
         inside the kernel instead of materialising the two blocks.)"""
+        if torch.is_grad_enabled() and self.training:   # models.py:478-485 on autograd
+            x = x_i * x_j
+            for lin in self.lins[:-1]:
+                x = F.dropout(F.relu(lin(x)), p=self.dropout, training=True)
+            return torch.sigmoid(self.lins[-1](x))
         b = x_i.shape[0]
         h2 = torch.cat([x_i, x_j], 0)
         idx = torch.arange(b, device=x_i.device, dtype=torch.int32)
@@ -209,7 +239,6 @@ class LinkGNN(torch.nn.Module):
     def embeddings(self, x: Optional[torch.Tensor], adj: CSRGraph) -> torch.Tensor:
         """h = gnn([emb.weight || x], adj), embedding FIRST (models.py:501-505); cached per
         (parameter versions, x, adjacency) -- the reference recomputes it for every scoring batch."""
-        _require_eval(self)
         key = (id(adj), None if x is None else (x.data_ptr(), x._version),
                tuple((p.data_ptr(), p._version) for p in self.parameters()))
         if key != self._h_key:
@@ -224,6 +253,13 @@ class LinkGNN(torch.nn.Module):
         return self._h
 
     def forward(self, x, edges, adj):
+        if torch.is_grad_enabled() and self.training:   # models.py:500-506 on autograd (no caching while training)
+            if x is None:
+                x = self.emb.weight
+            elif self.emb is not None:
+                x = torch.cat([self.emb.weight, x], dim=1)
+            h = self.gnn(x, adj)
+            return self.linkpred(h[edges[0]], h[edges[1]])
         h = self.embeddings(x, adj)
         return self.linkpred.decode(h, edges).unsqueeze(1)
 

@@ -2,9 +2,9 @@
 proposal edges, over the reference's sweep schedule, and write the curve points.
 
 Same flags (rank.py:130-163), same proposal consumption (``[:k,:2].t().long()``, :294), same adjacency
-construction (:300, :307-314), same eval dispatch (:337-349), same stdout lines (:364-369) and ``curves/`` files
-(:381-385).  Training of parametrised rank models (rank.py:331-333, train_and_eval.py:31-96) is outside the
-accelerated path: such models are evaluated from ``--load_model <state_dict.pt>``.
+construction (:300, :307-314), same eval dispatch (:337-349), same stdout lines (:364-369), ``models/`` checkpoints
+(:356-361) and ``curves/`` files (:381-385).  Parametrised rank models are trained per run like rank.py:317-333
+(training.py: torch autograd over the HIP SpMM), or evaluated from ``--load_model <state_dict.pt>``.
 """
 from __future__ import annotations
 
@@ -21,6 +21,8 @@ from .evaluate import evaluators, hits, test, test_adamic, test_resource_allocat
 from .graph import add_edges
 from .logger import Logger
 from .models import build_model, default_model_configs
+from .rank_helpers import to_undirected
+from .training import train
 
 
 def make_parser():
@@ -54,14 +56,6 @@ def make_parser():
     parser.add_argument('--synthetic', action="store_true", default=False)
     parser.add_argument('--load_model', type=str, default="")
     return parser
-
-
-def to_undirected(edge_index: torch.Tensor) -> torch.Tensor:
-    """torch_geometric.utils.to_undirected [third-party]: both directions, coalesced (sorted, unique)."""
-    both = torch.cat([edge_index, edge_index.flip(0)], 1)
-    n = int(both.max()) + 1 if both.numel() else 1
-    key = torch.unique(both[0] * n + both[1])
-    return torch.stack([torch.div(key, n, rounding_mode="floor"), key % n])
 
 
 def splice_valid_proposals(sorted_test_edges: torch.Tensor, valid_pos: torch.Tensor) -> torch.Tensor:
@@ -138,11 +132,8 @@ def run(args):
     index_ends = sweep_schedule(args)
     print(f"Scheduled extra edges sweep: {index_ends} x {args.runs}")
     use_params = sum(p.numel() for p in model.parameters() if p.requires_grad) > 0
-    if use_params:
-        if not args.load_model:
-            raise NotImplementedError(
-                "rank models with trainable parameters need training (train_and_eval.py:31-96), which is outside the "
-                "accelerated path; pass --load_model <state_dict.pt> to evaluate a trained model")
+    trained = use_params and not args.load_model     # rank.py:317-333: reset + train every run
+    if use_params and args.load_model:
         model.load_state_dict(torch.load(args.load_model, map_location=device))
     ei_dev, ew_dev = edge_index.to(device), edge_weight.to(device)
 
@@ -165,12 +156,19 @@ def run(args):
 
         curve_point = []
         for run_i in range(args.runs):
+            optimizer = None
             if not use_params:
                 model.reset_parameters()
                 args.epochs = 1
+            elif trained:
+                model.reset_parameters()                                    # rank.py:318
+                optimizer = torch.optim.Adam(model.parameters(), lr=args.lr)   # rank.py:322
             highest_eval = 0
             for epoch in range(1, 1 + (args.epochs or 1)):
                 loss = -1
+                if trained:
+                    loss = train(model, data, args.dataset, split_edge, optimizer, args.batch_size, use_params, args.model,
+                                 device)
                 if epoch % args.eval_steps == 0:
                     if args.model == "adamic_ogb":
                         results = test_adamic(model, data, split_edge, evaluator, args.batch_size, args, device)
@@ -188,12 +186,15 @@ def run(args):
                             train_hits, valid_hits, test_hits = result
                             if key == f"Hits@{K[1]}" and valid_hits >= highest_eval:
                                 highest_eval = valid_hits
+                                if args.save_models and use_params:          # rank.py:356-361
+                                    fn = f'{args.out_name}|{args.sorted_edge_path.split(".")[0]}|{index_end}|{run_i}.pt'
+                                    torch.save(model.state_dict(), os.path.join('models', fn))
                             print(key)
                             print(f'Run: {run_i + 1:02d}, Epoch: {epoch:02d}, Loss: {loss:.4f}, '
                                   f'Train: {100 * train_hits:.2f}%, Valid: {100 * valid_hits:.2f}%, '
                                   f'Test: {100 * test_hits:.2f}%')
                         print('---')
-                if use_params:
+                if use_params and not trained:
                     break  # a loaded model is evaluated once
             for key in loggers.keys():
                 print(key)

@@ -68,12 +68,14 @@ def test_build_model_factory(eps):
                                               hidden_channels=8, num_layers=2, dropout=0.0), data, torch.device("cpu"))
 
 
-def test_training_mode_is_refused(eps):
-    from eps_amd import models
-    gnn = models.GCN(4, 4, 4, 2, 0.5)
-    gnn.train()
-    with pytest.raises(NotImplementedError):
-        gnn(torch.zeros(3, 4), None)
+def test_negative_sampling_avoids_edges(eps):
+    from eps_amd import training
+    g = torch.Generator().manual_seed(0)
+    ei = torch.randint(0, 50, (2, 600), generator=g)
+    neg = training.negative_sampling(ei, 50, 1000)
+    assert neg.shape == (2, 1000)
+    edge_keys = set((ei[0] * 50 + ei[1]).tolist())
+    assert not (set((neg[0] * 50 + neg[1]).tolist()) & edge_keys)
 
 
 @pytest.mark.parametrize("dataset", ["ddi", "collab"])
@@ -153,7 +155,8 @@ def test_rank_stage_helpers(eps):
     assert rank_stage.sweep_schedule(ns(sweep_num=2, sweep_min=100, sweep_max=300, num_sorted_edge=7)) == [100, 200, 300]
     assert rank_stage.sweep_schedule(ns(sweep_num=None, sweep_min=None, sweep_max=None, num_sorted_edge=530000)) == [530000]
     assert rank_stage.sweep_schedule(ns(sweep_num=None, sweep_min=None, sweep_max=None, num_sorted_edge=None)) == [0]
-    und = rank_stage.to_undirected(torch.tensor([[3, 1, 1], [1, 3, 2]]))
+    from eps_amd.rank_helpers import to_undirected
+    und = to_undirected(torch.tensor([[3, 1, 1], [1, 3, 2]]))
     assert und.t().tolist() == [[1, 2], [1, 3], [2, 1], [3, 1]]
     # splice: both directions of the validation edges on top with score 100000, proposals that are validation edges dropped
     props = torch.tensor([[5., 6., .9], [1., 2., .8], [2., 1., .7], [7., 8., .6]])
