@@ -17,9 +17,12 @@ device the edge list lives on); the scoring kernels live in csrc/.
 """
 from __future__ import annotations
 
+import itertools
 from typing import Optional, Tuple
 
 import torch
+
+_UID = itertools.count(1)
 
 
 def _coalesce(row: torch.Tensor, col: torch.Tensor, val: Optional[torch.Tensor], n_rows: int, n_cols: int):
@@ -60,6 +63,7 @@ class CSRGraph:
         self.n_rows = int(n_rows)
         self.n_cols = int(n_cols)
         self._cache = {}
+        self.uid = next(_UID)   # identity for caches keyed on the adjacency (id() can be recycled after a free)
 
     # ------------------------------------------------------------------ construction
     @classmethod

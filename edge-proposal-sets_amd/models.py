@@ -239,7 +239,7 @@ class LinkGNN(torch.nn.Module):
     def embeddings(self, x: Optional[torch.Tensor], adj: CSRGraph) -> torch.Tensor:
         """h = gnn([emb.weight || x], adj), embedding FIRST (models.py:501-505); cached per
         (parameter versions, x, adjacency) -- the reference recomputes it for every scoring batch."""
-        key = (id(adj), None if x is None else (x.data_ptr(), x._version),
+        key = (adj.uid, None if x is None else (x.data_ptr(), x._version),
                tuple((p.data_ptr(), p._version) for p in self.parameters()))
         if key != self._h_key:
             if x is None:
