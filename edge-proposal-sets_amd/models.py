@@ -101,10 +101,16 @@ class GCNConv(torch.nn.Module):
         with torch.no_grad():
             return self._forward_hip(x, gn, relu)
 
-    def _forward_hip(self, x, gn, relu):
+    def _forward_hip(self, x, gn, relu, rows=None):
         w_nk = self.weight.detach().t().contiguous()     # [out,in]: the GEMM takes Linear layout
         xw = ops.gemm(_pad4(x), w_nk)                    # transform ...
-        return ops.spmm_csr(gn.rowptr, gn.col, gn.val, xw, bias=self.bias.detach(), relu=relu)   # ... then aggregate
+        rowptr = gn.rowptr if rows is None else gn.rowptr[rows[0]:rows[1] + 1]   # row block: absolute offsets into col
+        return ops.spmm_csr(rowptr, gn.col, gn.val, xw, bias=self.bias.detach(), relu=relu)   # ... then aggregate
+
+    @torch.no_grad()
+    def forward_rows(self, x: torch.Tensor, adj_t: CSRGraph, lo: int, hi: int, relu: bool = False) -> torch.Tensor:
+        """Rows [lo, hi) of the layer output from the FULL input (multi-GPU row sharding, dist.py)."""
+        return self._forward_hip(x, adj_t.gcn_normalized(), relu, rows=(lo, hi))
 
     def __repr__(self):
         return f"GCNConv({self.in_channels}, {self.out_channels})"
@@ -132,12 +138,19 @@ class SAGEConv(torch.nn.Module):
         with torch.no_grad():
             return self._forward_hip(x, adj_t, relu)
 
-    def _forward_hip(self, x, adj_t, relu):
+    def _forward_hip(self, x, adj_t, relu, rows=None):
         k = x.shape[1]
         x, x_full = _pad4_full(x)                      # pad columns are zero: aggregate the padded width (float4 path)
-        agg = ops.spmm_csr(adj_t.rowptr, adj_t.col, None, x_full, mean=True)[:, :k]
+        rowptr = adj_t.rowptr if rows is None else adj_t.rowptr[rows[0]:rows[1] + 1]
+        agg = ops.spmm_csr(rowptr, adj_t.col, None, x_full, mean=True)[:, :k]
         out = ops.gemm(agg, self.lin_l.weight.detach(), bias=self.lin_l.bias.detach())
-        return ops.gemm(x, self.lin_r.weight.detach(), out=out, accumulate=True, relu=relu)
+        x_rows = x if rows is None else x[rows[0]:rows[1]]
+        return ops.gemm(x_rows, self.lin_r.weight.detach(), out=out, accumulate=True, relu=relu)
+
+    @torch.no_grad()
+    def forward_rows(self, x: torch.Tensor, adj_t: CSRGraph, lo: int, hi: int, relu: bool = False) -> torch.Tensor:
+        """Rows [lo, hi) of the layer output from the FULL input (multi-GPU row sharding, dist.py)."""
+        return self._forward_hip(x, adj_t, relu, rows=(lo, hi))
 
     def __repr__(self):
         return f"SAGEConv({self.in_channels}, {self.out_channels})"
@@ -166,6 +179,20 @@ class _ConvStack(torch.nn.Module):
             x = conv(x, adj_t, relu=True)
             x = F.dropout(x, p=self.dropout, training=self.training)   # identity in eval mode
         return self.convs[-1](x, adj_t)
+
+
+    @torch.no_grad()
+    def forward_sharded(self, x, adj_t, rank: int, world: int, gather):
+        """Multi-GPU forward (inference): the last layer -- the one whose output every rank needs in full for the
+        decode -- is computed for this rank's row block only and exchanged with ONE all-gather (``gather(local,
+        bounds)``, dist.all_gather_rows: N x H x 4 B over xGMI); the layers before it are replicated (tens of ms at
+        these sizes: cheaper than an all-gather per layer)."""
+        for conv in self.convs[:-1]:
+            x = conv(x, adj_t, relu=True)
+        n = adj_t.n_rows
+        bounds = [n * r // world for r in range(world + 1)]
+        local = self.convs[-1].forward_rows(x, adj_t, bounds[rank], bounds[rank + 1])
+        return gather(local, bounds)
 
 
 class GCN(_ConvStack):
@@ -248,7 +275,12 @@ class LinkGNN(torch.nn.Module):
                 xin = torch.cat([self.emb.weight.detach(), x], dim=1)
             else:
                 xin = x
-            self._h = self.gnn(xin, adj)
+            from . import dist as epd
+            rank, world = epd.world_info()
+            if world > 1 and hasattr(self.gnn, "forward_sharded"):
+                self._h = self.gnn.forward_sharded(xin, adj, rank, world, epd.all_gather_rows)
+            else:
+                self._h = self.gnn(xin, adj)
             self._h_key = key
         return self._h
 
