@@ -4,19 +4,23 @@
 // Replaces, per pair (u,v):  np.sum(A[src].multiply(A_[dst]), 1)   adamic_utils.py:22,
 // train_and_eval.py:212 and  adj[e0] (.) adj[e1] -> sparse row-sum   models.py:536-542.
 //
+// This file: the GENERIC kernel (any pair list: the eval sets of train_and_eval.py:108-136, random negatives) and the
+// per-node weight table.  pair_grouped.hip holds the column-run kernel for lists in the reference's candidate order.
+//
 // Work decomposition (wave = 64 lanes):
-//   * a wave owns chunks of 64 consecutive pairs.  Lane i fetches pair i's (u,v) and the four
-//     rowptr words in parallel -- one coalesced metadata fetch per 64 pairs instead of a
-//     dependent scalar chain per pair -- and lane i finally stores pair i's results, so the
-//     output stores are coalesced too.
-//   * the 64 pairs are then scored one after the other by the whole wave: the LONGER adjacency
-//     row is staged in LDS with coalesced loads (PI_CAP entries per pass), the SHORTER row is
-//     spread one element per lane and every lane runs a branch-free lower_bound over the staged
-//     row.  Matches are counted with ballot+popcount (no reduction) and the weighted sums go
-//     through a DPP butterfly.
-//   * very lopsided pairs (long row >> short row) skip the staging and search the long row in
-//     place (L2-resident binary search), so a degree-100k hub costs log2(d) probes per element
-//     of the short row instead of a full read.
+//   * 64-pair chunks are handed to waves dynamically (one device-scope atomic per chunk, drawn one chunk ahead):
+//     pair costs are heavy-tailed, a static split leaves the slowest wave running long after the others.
+//   * lane i fetches pair i's (u,v) and the four rowptr words in parallel -- one coalesced metadata fetch per 64
+//     pairs instead of a dependent scalar chain per pair -- and lane i finally stores pair i's results (coalesced).
+//   * the 64 pairs are then scored one after the other by the whole wave: the LONGER adjacency row is staged in LDS
+//     (PI_CAP entries per pass) with 16-byte raw buffer loads, all issued before the first LDS write (out-of-range
+//     lanes read 0 and are replaced by INT_MAX sentinels up to the next power of two: no bounds branch); the SHORTER
+//     row is spread one element per lane and every lane runs a fully unrolled, branch-free lower bound over the
+//     padded row.  Matches are counted with ballot+popcount; for unit-weight graphs the node_w gathers of the hits are
+//     queued in LDS and resolved once per 64 pairs (no dependent global load on a pair's critical path); weighted
+//     graphs / float64 weights accumulate inline and reduce with a DPP butterfly.
+//   * very lopsided pairs (long row >> short row) skip the staging and search the long row in place (L2-resident
+//     binary search), so a degree-100k hub costs log2(d) probes per element of the short row instead of a full read.
 // HBM traffic is the algorithmic minimum: both rows once, coalesced; rowptr/pair/outputs once.
 #include "pair_common.h"
 
