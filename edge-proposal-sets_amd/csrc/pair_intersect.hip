@@ -132,8 +132,9 @@ __global__ __launch_bounds__(PI_WAVES * 64) void pair_scores_kernel(
                 inline_sums = true;
             } else {
                 int q0 = qlen;
+                int s_cursor = 0;
                 const __amdgpu_buffer_rsrc_t srs = row_rsrc(col + sbase, slen);
-                for (int l0 = 0; l0 < llen; l0 += PI_CAP) {
+                for (int l0 = 0; l0 < llen && s_cursor < slen; l0 += PI_CAP) {
                     const int n = (llen - l0) < PI_CAP ? (llen - l0) : PI_CAP;
                     const int lg = n > 1 ? 32 - __builtin_clz(n - 1) : 0;  // P = 2^lg >= n
                     const int P = 1 << lg;
@@ -155,12 +156,21 @@ __global__ __launch_bounds__(PI_WAVES * 64) void pair_scores_kernel(
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                    for (int s0 = 0; s0 < slen; s0 += 64) {
+                    // Long rows take several passes; both rows are sorted, so the passes co-iterate with the short row like
+                    // a merge: a cursor marks the first short element not yet settled, a pass only searches the short
+                    // elements <= its own last entry, and everything stops once the short row is used up.
+                    const bool multipass = llen > PI_CAP;
+                    const int last = multipass ? __builtin_amdgcn_readfirstlane(L[n - 1]) : 0x7fffffff;
+                    for (int s0 = s_cursor; s0 < slen; s0 += 64) {
                         const int si = s0 + lane;
                         const int t = __builtin_amdgcn_raw_buffer_load_b32(srs, si * 4, 0, 0);
+                        const bool mine = si < slen && t <= last;       // a prefix of the lanes (sorted row)
+                        const int n_mine = __popcll(__ballot(mine));
+                        s_cursor = s0 + n_mine;
                         const int pos = lb_pow2(L, lg, t);
-                        const bool found = si < slen && L[pos] == t;
+                        const bool found = mine && L[pos] == t;
                         const uint64_t m = __ballot(found);
+                        if (n_mine < 64 && s0 + 64 < slen) s0 = slen;  // the rest of the short row belongs to later passes
                         if (m == 0ull) continue;
                         const int c = __popcll(m);
                         cnt += c;
