@@ -15,7 +15,7 @@ it does not change results (the reference's batching does not either).  There is
 """
 from __future__ import annotations
 
-from typing import Optional, Tuple, Union
+from typing import Optional, Tuple
 
 import numpy as np
 import torch

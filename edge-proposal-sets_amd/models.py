@@ -23,7 +23,6 @@ import torch
 import torch.nn.functional as F
 
 from . import ops
-from ._lib import EpsError
 from .graph import CSRGraph
 from . import heuristics
 
