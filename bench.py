@@ -91,7 +91,27 @@ def cpu_baseline(g, u, v, ws_gpu, torch):
     t1 = time.perf_counter()
     orc.pair_scores(rp, col, None, w, pu, pv)
     dt_c = time.perf_counter() - t1
-    return {"value": len(pu) / dt, "unit": "edges/s", "cores": 1, "kind": "port",
+    # Hits@100 parity (the second half of BASELINE's metric): positive-like pairs (stored edges) against uniform random
+    # negatives, scored by the GPU engine and by the reference's CPU expression; Hits@K per ogb's rule (strict >).
+    gen = torch.Generator(device=u.device).manual_seed(7)
+    row, colx, _ = g.coo()
+    sel = torch.randint(0, row.numel(), (50_000,), generator=gen, device=u.device)
+    pe = torch.stack([row[sel], colx[sel]])
+    ne = torch.randint(0, g.n_rows, (2, 50_000), generator=gen, device=u.device)
+    import eps_amd
+    from eps_amd.evaluate import Evaluator
+    ev = Evaluator("ogbl-ppa")
+    ev.K = 100
+    gp, _ = eps_amd.AA(g, pe)
+    gn, _ = eps_amd.AA(g, ne)
+    with np.errstate(divide="ignore"):
+        cp = np.array(np.sum(A[pe[0].cpu().numpy()].multiply(A_[pe[1].cpu().numpy()]), 1)).flatten().astype(np.float32)
+        cneg = np.array(np.sum(A[ne[0].cpu().numpy()].multiply(A_[ne[1].cpu().numpy()]), 1)).flatten().astype(np.float32)
+    h_gpu = ev.eval({"y_pred_pos": gp, "y_pred_neg": gn})["hits@100"]
+    h_cpu = orc.hits_at_k(cp, cneg, 100)
+    hits = {"K": 100, "gpu": h_gpu, "cpu_reference_mirror": h_cpu, "identical": bool(h_gpu == h_cpu),
+            "pairs": "50,000 stored edges vs 50,000 uniform random pairs (seed 7)"}
+    return {"value": len(pu) / dt, "unit": "edges/s", "cores": 1, "kind": "port", "hits_at_100": hits,
             "sample": f"{len(pu)} of the step's {n} pairs (every {max(1, n // CPU_SAMPLE)}-th), SciPy mirror of "
                       f"adamic_utils.AA batch 2000, per-batch loop only (weight prologue excluded), "
                       f"host has {os.cpu_count()} cores, 1 used",
