@@ -48,7 +48,7 @@ __global__ __launch_bounds__(256) void spmm_csr_kernel(const int64_t *__restrict
 
     for (int64_t r = wave; r < n_rows; r += n_waves) {
         const int64_t b = rowptr[r], e = rowptr[r + 1];
-        const float inv = mean ? 1.0f / (float)((e - b) > 0 ? (e - b) : 1) : 1.0f;
+        const float cnt = (float)((e - b) > 0 ? (e - b) : 1);  // mean = sum / count (a true division, like the reference)
         for (int32_t c0 = 0; c0 < f; c0 += 64 * VEC) {
             const int32_t c = c0 + lane * VEC;
             const bool act = c < f;
@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256) void spmm_csr_kernel(const int64_t *__restrict
 #pragma unroll
                 for (int i = 0; i < VEC; ++i) {
                     float t = a[i];
-                    if (mean) t = t * inv;
+                    if (mean) t = t / cnt;
                     if (bias) t += bias[c + i];
                     if (relu) t = t > 0.f ? t : 0.f;
                     a[i] = t;

@@ -136,3 +136,44 @@ def test_pack_keys_order(eps, dev):
     assert torch.equal(order.cpu(), ref)
     s2, ids = eps.ops.unpack_keys(keys)
     assert torch.equal(s2.cpu(), score + 0.0) and torch.equal(ids.cpu(), torch.arange(100000) + 1000)
+
+
+def test_full_size_properties_spmm_decode(eps, dev):
+    """Size-independent checks at the BASELINE scale (ppa-like graph, F = H = 256), no oracle run:
+    SpMM of an all-ones matrix = row sums (exact); mean mode of ones = 1 (0 for empty rows); the GCN-normalised
+    adjacency maps sqrt(deg+1) to itself; linearity; decode is symmetric in (u,v) bit for bit and stays in (0,1)."""
+    from eps_amd import synth
+    g = synth.ppa_like(seed=3, device=dev)
+    n = g.n_rows
+    ones = torch.ones(n, 256, device=dev)
+    y = eps.ops.spmm_csr(g.rowptr, g.col, None, ones)
+    deg = g.degree().float()
+    assert torch.equal(y[:, 0], deg) and torch.equal(y[:, 255], deg)
+    ym = eps.ops.spmm_csr(g.rowptr, g.col, None, ones, mean=True)
+    assert torch.equal(ym[:, 7], (deg > 0).float())
+    gn = g.gcn_normalized()
+    s = torch.sqrt(deg + 1.0)                                  # D^1/2 1 is the fixed vector of D^-1/2 (A+I) D^-1/2
+    x = s[:, None].repeat(1, 4).contiguous()
+    z = eps.ops.spmm_csr(gn.rowptr, gn.col, gn.val, x)
+    # sequential float32 accumulation (the reference kernel's order): error grows like row length x 2^-24
+    assert bool(((z[:, 0] - s).abs() <= 2.0 ** -23 * (deg + 2.0) * s).all())
+    gen = torch.Generator(device=dev).manual_seed(0)
+    a = torch.randn(n, 64, generator=gen, device=dev)
+    b = torch.randn(n, 64, generator=gen, device=dev)
+    lhs = eps.ops.spmm_csr(gn.rowptr, gn.col, gn.val, a + b)
+    rhs = eps.ops.spmm_csr(gn.rowptr, gn.col, gn.val, a) + eps.ops.spmm_csr(gn.rowptr, gn.col, gn.val, b)
+    assert float((lhs - rhs).abs().max()) <= 1e-4
+    h = torch.randn(n, 256, generator=gen, device=dev)
+    ws = [torch.randn(256, 256, generator=gen, device=dev) / 16, torch.randn(256, 256, generator=gen, device=dev) / 16,
+          torch.randn(1, 256, generator=gen, device=dev) / 16]
+    bs = [torch.randn(256, generator=gen, device=dev), torch.randn(256, generator=gen, device=dev), torch.randn(1, generator=gen, device=dev)]
+    E = 3_000_001
+    u = torch.randint(0, n, (E,), generator=gen, device=dev, dtype=torch.int32)
+    v = torch.randint(0, n, (E,), generator=gen, device=dev, dtype=torch.int32)
+    p1 = eps.ops.mlp_decode(h, u, v, ws, bs)
+    p2 = eps.ops.mlp_decode(h, v, u, ws, bs)
+    assert torch.equal(p1, p2)                                  # Hadamard product commutes exactly
+    assert float(p1.min()) >= 0.0 and float(p1.max()) <= 1.0 and p1.isfinite().all()
+    # permuting the edge list permutes the outputs (tiles / workgroups are independent)
+    perm = torch.randperm(E, generator=gen, device=dev)
+    assert torch.equal(eps.ops.mlp_decode(h, u[perm].contiguous(), v[perm].contiguous(), ws, bs), p1[perm])
