@@ -135,11 +135,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    # smoke-test hooks for a 1-GPU box (never set by the driver): EPS_BENCH_ONE_DEVICE=1 maps every rank to cuda:0 and
+    # EPS_BENCH_BACKEND=gloo swaps RCCL for gloo, so the N > 1 control flow can be exercised without N GPUs
+    if os.environ.get("EPS_BENCH_ONE_DEVICE") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("EPS_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     import eps_amd
     from eps_amd import candidates, ops, synth
