@@ -19,7 +19,7 @@ import torch
 from .datasets import get_data
 from .evaluate import evaluators, hits, test, test_adamic, test_resource_allocation
 from .graph import add_edges
-from .logger import Logger
+from .runlog import Logger
 from .models import build_model, default_model_configs
 from .rank_helpers import to_undirected
 from .training import train

@@ -54,3 +54,19 @@ def test_ops_refuse_cpu_tensors(eps):
     if not torch.cuda.is_available():
         with pytest.raises(eps.EpsError):
             eps.AA(g, torch.tensor([[0], [2]]))
+
+
+def test_missing_library_fails_loudly(eps, monkeypatch, tmp_path):
+    """No HIP library -> the loader raises (there is no CPU fallback to slide onto)."""
+    from eps_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "libeps_hip.so"))
+    with pytest.raises(_lib.EpsError, match="no CPU fallback"):
+        _lib.load()
+
+
+def test_product_package_never_imports_the_oracle():
+    import glob
+    for f in glob.glob(os.path.join(ROOT, "edge-proposal-sets_amd", "*.py")) + [os.path.join(ROOT, n) for n in ("filter.py", "rank.py", "eps_amd.py")]:
+        src = open(f).read()
+        assert "import oracle" not in src and "from oracle" not in src and "eps_oracle" not in src, f
