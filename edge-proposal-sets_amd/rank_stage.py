@@ -13,7 +13,6 @@ import os
 from datetime import datetime
 from pathlib import Path
 
-import numpy as np
 import torch
 
 from .datasets import get_data
@@ -59,19 +58,22 @@ def make_parser():
 
 
 def splice_valid_proposals(sorted_test_edges: torch.Tensor, valid_pos: torch.Tensor) -> torch.Tensor:
-    """rank.py:222-251 (--valid_proposal): both directions of every validation edge go on top with score
-    100000, and proposal rows that are validation edges are dropped.  (The reference builds the top block from a
-    Python set, whose iteration order is arbitrary; here it is sorted -- the adjacency built from it is the same.)"""
-    v = valid_pos.numpy()
-    top = sorted({(int(a), int(b)) for a, b in v} | {(int(b), int(a)) for a, b in v})
-    d = {tuple(sorted((int(a), int(b)))) for a, b in v}
-    rows = [np.array([a, b, 100000.0]) for a, b in top]
-    for t in sorted_test_edges.numpy():
-        a, b = int(t[0]), int(t[1])
-        if (a, b) in d or (b, a) in d:
-            continue
-        rows.append(t[:3].astype(np.float64) if len(t) >= 3 else np.array([t[0], t[1], 0.0]))
-    return torch.tensor(np.stack(rows))
+    """rank.py:222-251 (--valid_proposal): both directions of every validation edge go on top with score 100000, and
+    proposal rows that are validation edges (either direction) are dropped.  Vectorised (the reference walks the
+    proposal file row by row in Python); the reference builds the top block from a Python set, whose iteration order
+    is arbitrary -- here it is sorted, which gives the same adjacency."""
+    v = valid_pos.long()
+    n = int(max(v.max().item() if v.numel() else 0, sorted_test_edges[:, :2].max().item() if sorted_test_edges.numel() else 0)) + 1
+    both = torch.cat([v, v.flip(1)], 0)
+    vkeys = torch.unique(both[:, 0] * n + both[:, 1])                     # directed keys of both directions, sorted
+    top = torch.stack([torch.div(vkeys, n, rounding_mode="floor"), vkeys % n], 1).to(torch.float64)
+    top = torch.cat([top, torch.full((top.shape[0], 1), 100000.0, dtype=torch.float64)], 1)
+    p = sorted_test_edges.to(torch.float64)
+    if p.shape[1] == 2:
+        p = torch.cat([p, torch.zeros((p.shape[0], 1), dtype=torch.float64)], 1)
+    pkeys = p[:, 0].long() * n + p[:, 1].long()
+    keep = ~torch.isin(pkeys, vkeys)                                       # vkeys holds both directions already
+    return torch.cat([top, p[keep, :3]], 0)
 
 
 def sweep_schedule(args):
