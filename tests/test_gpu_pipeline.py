@@ -144,3 +144,35 @@ def test_gnn_filter_cli(eps, oracle, workdir):
     assert float(np.abs(got[sel, 2].numpy() - prob).max()) <= 2e-5
     pairs, _ = oracle.candidates_scipy(A)
     assert len(got) == len(pairs)
+
+
+def test_collab_recipe_with_valid_proposal(eps, oracle, workdir):
+    """The published collab recipe (submit_job.py:199-205): AA-filter -> AA-rank with --valid_proposal.  The validation
+    edges are spliced on top of the proposal list (both directions), so with k >= 2*|valid| every validation edge is
+    in the rank graph and Hits on the validation positives are high; the run must also agree with the oracle when the
+    same spliced proposals are fed to the restated pipeline."""
+    import argparse
+    from eps_amd import datasets, filter_stage, rank_stage
+    filter_stage.main(["--dataset", "collab", "--model", "adamic_ogb", "--checkpoint", "collab_adamic_ogb||0|0.pt", "--synthetic"])
+    edge_index, edge_weight, split_edge, data = datasets.get_data(argparse.Namespace(dataset="collab", synthetic=True, use_feature=False))
+    n_valid = split_edge["valid"]["edge"].shape[0]
+    k = 2 * n_valid + 50
+    curves = rank_stage.main(["--dataset", "collab", "--model", "adamic_ogb", "--sorted_edge_path",
+                              "collab_adamic_ogb__0_0_sorted_edges.pt", "--num_sorted_edge", str(k), "--runs", "1",
+                              "--synthetic", "--valid_proposal"])
+    props = torch.load("filtered_edges/collab_adamic_ogb__0_0_sorted_edges.pt")
+    spliced = rank_stage.splice_valid_proposals(props, split_edge["valid"]["edge"])
+    extra = spliced[:k, :2].t().long().numpy()
+    n = data.num_nodes
+    A_eval = oracle.add_edges_scipy("collab", edge_index.numpy(), edge_weight.numpy(), extra, n)
+    und = rank_stage.to_undirected(split_edge["valid"]["edge"].t()).numpy()
+    A_full = oracle.add_edges_scipy("collab", edge_index.numpy(), edge_weight.numpy(), np.concatenate([extra, und], 1), n)
+
+    def sc(A, e):
+        rp, col, val = A.indptr.astype(np.int64), A.indices.astype(np.int32), A.data.astype(np.float32)
+        w = oracle.node_weights(oracle.col_sums(rp, col, val, n), oracle.W_AA)
+        return oracle.pair_scores(rp, col, val, w, e[:, 0].numpy(), e[:, 1].numpy())[2]
+
+    v = oracle.hits_at_k(sc(A_eval, split_edge["valid"]["edge"]), sc(A_eval, split_edge["valid"]["edge_neg"]), 50)
+    t = oracle.hits_at_k(sc(A_full, split_edge["test"]["edge"]), sc(A_full, split_edge["test"]["edge_neg"]), 50)
+    assert float(curves[0][1]) == pytest.approx(100 * v, abs=1e-4) and float(curves[0][2]) == pytest.approx(100 * t, abs=1e-4)
