@@ -1,0 +1,126 @@
+"""GPU: seeded randomised sweeps of the kernels' corner cases against the oracle -- row lengths around the staging
+boundaries (63/64/65, 255/256/257, 511..513, 1023..1025, multi-pass), empty rows, duplicate pairs, weighted and unit
+graphs, both pair kernels, ragged shapes for SpMM / GEMM / decode."""
+import numpy as np
+import pytest
+import scipy.sparse as ssp
+import torch
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _graph_with_row_lengths(rng, n, lengths, weighted):
+    """Symmetric graph in which node i (i < len(lengths)) has at least lengths[i] neighbours."""
+    rows, cols = [], []
+    for i, L in enumerate(lengths):
+        if L:
+            nb = rng.choice(np.setdiff1d(np.arange(n), [i]), size=min(L, n - 1), replace=False)
+            rows.append(np.full(len(nb), i)); cols.append(nb)
+    extra = rng.integers(0, n, (2, 4 * n))
+    rows.append(extra[0]); cols.append(extra[1])
+    r, c = np.concatenate(rows), np.concatenate(cols)
+    keep = r != c
+    w = rng.integers(1, 4, keep.sum()).astype(np.float32) if weighted else np.ones(keep.sum(), np.float32)
+    A = ssp.coo_matrix((w, (r[keep], c[keep])), shape=(n, n)).tocsr()
+    A = (A + A.T).tocsr(); A.sum_duplicates(); A.sort_indices()
+    if not weighted:
+        A.data[:] = 1
+    return A.astype(np.float32)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_pair_kernels_boundary_lengths(eps, oracle, dev, seed):
+    rng = np.random.default_rng(100 + seed)
+    n = 6000
+    lengths = [0, 1, 2, 63, 64, 65, 127, 128, 129, 255, 256, 257, 300, 511, 512, 513, 700, 1023, 1024, 1025, 1500, 2047,
+               2048, 2049, 3000, 4100, 5000]
+    weighted = seed % 2 == 1
+    A = _graph_with_row_lengths(rng, n, lengths, weighted)
+    g = eps.CSRGraph.from_scipy(A, device=dev)
+    special = np.arange(len(lengths))
+    uu, vv = np.meshgrid(special, special)                       # every boundary length against every other
+    pairs = np.concatenate([np.stack([uu.ravel(), vv.ravel()]), rng.integers(0, n, (2, 3000)),
+                            np.stack([rng.choice(special, 2000), rng.integers(0, n, 2000)])], 1).astype(np.int32)
+    pairs = np.concatenate([pairs, pairs[:, :200]], 1)            # duplicates
+    rp, col = A.indptr.astype(np.int64), A.indices.astype(np.int32)
+    val = A.data if weighted else None
+    w = oracle.node_weights(oracle.col_sums(rp, col, val, n), oracle.W_RA if seed % 3 == 0 else oracle.W_AA)
+    cnt_o, cn_o, _ = oracle.pair_scores(rp, col, val, w, pairs[0], pairs[1])
+    _, truth = oracle.pair_scores_f64(rp, col, val, w.astype(np.float64), pairs[0], pairs[1])
+    wt = torch.from_numpy(w).to(dev)
+    for order in ("given", "by_v"):
+        p = pairs if order == "given" else pairs[:, np.lexsort((pairs[0], pairs[1]))]
+        if order == "by_v":
+            cnt_o, cn_o, _ = oracle.pair_scores(rp, col, val, w, p[0], p[1])
+            _, truth = oracle.pair_scores_f64(rp, col, val, w.astype(np.float64), p[0], p[1])
+        u, v = torch.from_numpy(p[0].copy()).to(dev), torch.from_numpy(p[1].copy()).to(dev)
+        for grouped in (False, True):
+            cnt, cn, ws = eps.ops.pair_scores(g.rowptr, g.col, g.val, wt, n, u, v, grouped=grouped)
+            assert np.array_equal(cnt.cpu().numpy(), cnt_o), (order, grouped)
+            assert np.array_equal(cn.cpu().numpy(), cn_o), (order, grouped)
+            assert rel_err(ws.cpu().numpy(), truth.astype(np.float32)) <= 1e-5, (order, grouped)
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_expand_fuzz(eps, oracle, dev, seed):
+    rng = np.random.default_rng(200 + seed)
+    n = int(rng.integers(50, 3000))
+    A = _graph_with_row_lengths(rng, n, [0, 1, min(n - 1, 700), 3, 0, min(n - 1, 64)], weighted=seed % 2 == 0)
+    g = eps.CSRGraph.from_scipy(A, device=dev)
+    want, _ = oracle.candidates_scipy(A)
+    rp, col = A.indptr.astype(np.int64), A.indices.astype(np.int32)
+    val = A.data if seed % 2 == 0 else None
+    w = oracle.node_weights(oracle.col_sums(rp, col, val, n), oracle.W_AA)
+    lo = int(rng.integers(0, n // 2)); hi = int(rng.integers(lo, n + 1))
+    colptr, cu, cv, cn, sc = eps.ops.expand_candidates(g.rowptr, g.col, g.val, torch.from_numpy(w).to(dev), n, lo, hi)
+    sel = (want[:, 1] >= lo) & (want[:, 1] < hi)
+    assert np.array_equal(np.stack([cu.cpu().numpy(), cv.cpu().numpy()], 1), want[sel])
+    cnt_o, _, _ = oracle.pair_scores(rp, col, val, w, want[sel, 0], want[sel, 1])
+    _, truth = oracle.pair_scores_f64(rp, col, val, w.astype(np.float64), want[sel, 0], want[sel, 1])
+    assert np.array_equal(cn.cpu().numpy(), cnt_o)
+    assert rel_err(sc.cpu().numpy(), truth.astype(np.float32)) <= 1e-6
+    per_col = np.bincount(want[sel, 1] - lo, minlength=hi - lo)
+    assert np.array_equal(np.diff(colptr.cpu().numpy()), per_col)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_dense_kernels_ragged_shapes(eps, oracle, dev, seed):
+    rng = np.random.default_rng(300 + seed)
+    g = torch.Generator().manual_seed(300 + seed)
+    # GEMM
+    m, n_, k = int(rng.integers(1, 700)), int(rng.integers(1, 300)), int(rng.integers(1, 400))
+    a, b = torch.randn(m, k, generator=g), torch.randn(n_, k, generator=g)
+    bias = torch.randn(n_, generator=g)
+    out = eps.ops.gemm(a.to(dev), b.to(dev), bias=bias.to(dev)).cpu().double()
+    ref = a.double() @ b.double().t() + bias.double()
+    bound = (a.abs().double() @ b.abs().double().t() + bias.abs().double()) * (k + 2) * 2.0 ** -24
+    assert bool(((out - ref).abs() <= bound + 1e-30).all()), (m, n_, k)
+    # SpMM
+    nn, f = int(rng.integers(1, 800)), int(rng.integers(1, 520))
+    S = ssp.random(nn, nn, density=min(1.0, 8.0 / nn), random_state=rng, dtype=np.float32, format="csr")
+    S.data[:] = rng.integers(1, 5, S.nnz); S.sort_indices()
+    x = rng.standard_normal((nn, f)).astype(np.float32)
+    mode = seed % 3
+    val = S.data if mode == 0 else None
+    ref = oracle.spmm_csr(S.indptr, S.indices, val, x, mean=(mode == 2))
+    got = eps.ops.spmm_csr(torch.from_numpy(S.indptr.astype(np.int64)).to(dev), torch.from_numpy(S.indices.astype(np.int32)).to(dev),
+                           None if val is None else torch.from_numpy(val).to(dev), torch.from_numpy(x).to(dev), mean=(mode == 2))
+    scale = max(1.0, float(oracle.spmm_csr(S.indptr, S.indices, val, np.abs(x), mean=(mode == 2)).max()))
+    assert float(np.abs(got.cpu().numpy() - ref).max()) <= 1e-5 * scale, (nn, f, mode)
+    # decode
+    H = int(rng.integers(1, 65)) * 4
+    L = int(rng.integers(1, 5))
+    nodes, E = int(rng.integers(2, 500)), int(rng.integers(1, 4000))
+    h = torch.randn(nodes, H, generator=g)
+    ws = [torch.randn(H if i < L - 1 else 1, H, generator=g) / H ** 0.5 for i in range(L)]
+    bs = [torch.randn(H if i < L - 1 else 1, generator=g) * 0.1 for i in range(L)]
+    u = torch.randint(0, nodes, (E,), generator=g, dtype=torch.int32)
+    v = torch.randint(0, nodes, (E,), generator=g, dtype=torch.int32)
+    logit_o, prob_o = oracle.mlp_decode(h.numpy(), u.numpy(), v.numpy(), [w.numpy() for w in ws], [b.numpy() for b in bs])
+    prob = eps.ops.mlp_decode(h.to(dev), u.to(dev), v.to(dev), [w.to(dev) for w in ws], [b.to(dev) for b in bs]).cpu().numpy()
+    logit = eps.ops.mlp_decode(h.to(dev), u.to(dev), v.to(dev), [w.to(dev) for w in ws], [b.to(dev) for b in bs],
+                               apply_sigmoid=False).cpu().numpy()
+    assert rel_err(prob, prob_o) <= 1e-5, (H, L, E)
+    assert float(np.abs(logit - logit_o).max()) <= 2e-5 * max(1.0, float(np.abs(logit_o).max())), (H, L, E)
