@@ -51,7 +51,10 @@ def train_only_graph(split_edge, num_nodes: int, device) -> CSRGraph:
     integer ones, duplicates summed by the csr_matrix constructor), ignoring proposal edges and adj_t."""
     e = split_edge['train']['edge'].t().to(device)
     both = torch.cat([e, e.flip(0)], 1)
-    return CSRGraph.from_edge_index(both, torch.ones(both.shape[1], device=device), (num_nodes, num_nodes))
+    g = CSRGraph.from_edge_index(both, torch.ones(both.shape[1], device=device), (num_nodes, num_nodes))
+    if g.val is not None and bool((g.val == 1).all()):      # every undirected edge listed once (ddi, ppa): unit graph
+        g = g.fill_value(1.0)
+    return g
 
 
 def score_block(args, model, data, pairs: torch.Tensor, ra_graph=None) -> torch.Tensor:
@@ -84,6 +87,13 @@ def scored_blocks(args, model, data, ra_graph, col_lo: int = 0, col_hi: int = No
     col_hi = g.n_rows if col_hi is None else col_hi
     blocks = [(max(lo, col_lo), min(hi, col_hi)) for lo, hi in candidates.column_blocks(g) if lo < col_hi and hi > col_lo]
     fused = candidates.hip_expand_available(g) and args.model in ("adamic_ogb", "simple")
+    if (args.model == "resource_allocation" and candidates.hip_expand_available(g) and ra_graph is not None
+            and g.val is None and ra_graph.val is None and g.nnz() == ra_graph.nnz()
+            and torch.equal(g.rowptr, ra_graph.rowptr) and torch.equal(g.col, ra_graph.col)):
+        # filter.py:130-141 scores RA on the train-only graph; when no proposal edges were added that IS the candidate
+        # graph (unit values), so the scores come out of the same fused expansion.  Weights 1/deg are formed in float64
+        # like the reference's int64 adjacency makes them, then rounded once to float32.
+        fused = True
     if not fused:
         for v_lo, v_hi in blocks:
             pairs = candidates.expand_block(g, v_lo, v_hi)[0]
@@ -91,8 +101,11 @@ def scored_blocks(args, model, data, ra_graph, col_lo: int = 0, col_hi: int = No
         return
     if args.model == "adamic_ogb":
         node_w = node_weight_table(g, ops.W_AA)
+    elif args.model == "resource_allocation":
+        node_w = node_weight_table(ra_graph, ops.W_RA, f64=True).to(torch.float32)
     else:  # CN = sum_w A[u,w]*A[v,w]: the same accumulator with unit node weights
         node_w = torch.ones(g.n_rows, dtype=torch.float32, device=g.device)
+    print(f'fused candidate generation + scoring ({args.model})')
     for v_lo, v_hi in blocks:
         pairs, _, score = candidates.expand_block(g, v_lo, v_hi, node_w, want_score=True)
         yield v_lo, v_hi, pairs, score
