@@ -41,6 +41,61 @@ __device__ __forceinline__ int wave_incl_scan(int x, int lane)
     return x;
 }
 
+typedef int v4i __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ int64_t ex_bcast64(int64_t x, int j)
+{
+    const int lo = __builtin_amdgcn_readlane((int)(x & 0xffffffffll), j);
+    const int hi = __builtin_amdgcn_readlane((int)(x >> 32), j);
+    return ((int64_t)hi << 32) | (uint32_t)lo;
+}
+
+// Walk the 2-hop paths v - w - u of one column for this wave's share of N(v) (rows k = wib, wib+16, ...).
+// The row descriptors of up to 64 of the wave's rows are fetched lane-parallel (w, rowptr[w], rowptr[w+1]: one
+// latency for the batch instead of a dependent chain per row), and the first 256 entries of the next row are in
+// flight (16-byte raw buffer loads: out-of-range lanes read 0, no bounds branch) while the current row is consumed.
+// body(k, wb, base, u4, nvalid): entries [base, base+nvalid) of row w = vcol[k] (nvalid in 0..4 per lane).
+template <typename Body>
+__device__ __forceinline__ void for_each_path(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+                                              const int32_t *__restrict__ vcol, int32_t dv, int wib, int lane, Body body)
+{
+    for (int b0 = wib; b0 < dv; b0 += EX_WAVES * 64) {
+        const int k_mine = b0 + EX_WAVES * lane;
+        const bool ok = k_mine < dv;
+        const int32_t w_mine = ok ? vcol[k_mine] : 0;
+        const int64_t wb_mine = rowptr[w_mine];
+        const int32_t dw_mine = ok ? (int32_t)(rowptr[w_mine + 1] - wb_mine) : 0;
+        const int left = (dv - b0 + EX_WAVES - 1) / EX_WAVES;
+        const int nrows = left < 64 ? left : 64;
+        // ring of two rows: every ring register is written by one unconditional load per trip
+        __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(col + ex_bcast64(wb_mine, 0)), 0,
+                                                                       __builtin_amdgcn_readlane(dw_mine, 0) * 4, 0x00020000);
+        v4i nxt = __builtin_amdgcn_raw_buffer_load_b128(rs, lane * 16, 0, 0);
+        for (int j = 0; j < nrows; ++j) {
+            const int32_t dw = __builtin_amdgcn_readlane(dw_mine, j);
+            const int64_t wb = ex_bcast64(wb_mine, j);
+            const __amdgpu_buffer_rsrc_t rj = rs;
+            const v4i cur = nxt;
+            {
+                const int jn = (j + 1) & 63;
+                const int32_t dn = j + 1 < nrows ? __builtin_amdgcn_readlane(dw_mine, jn) : 0;
+                rs = __builtin_amdgcn_make_buffer_rsrc((void *)(col + ex_bcast64(wb_mine, jn)), 0, dn * 4, 0x00020000);
+                nxt = __builtin_amdgcn_raw_buffer_load_b128(rs, lane * 16, 0, 0);
+            }
+            const int k = b0 + EX_WAVES * j;
+            int nv = dw - 4 * lane;
+            body(k, wb, 4 * lane, cur, nv < 0 ? 0 : (nv > 4 ? 4 : nv));
+            for (int e0 = 256; e0 < dw; e0 += 512) {  // long rows: two more loads in flight per trip
+                const v4i x0 = __builtin_amdgcn_raw_buffer_load_b128(rj, lane * 16 + e0 * 4, 0, 0);
+                const v4i x1 = __builtin_amdgcn_raw_buffer_load_b128(rj, lane * 16 + e0 * 4 + 1024, 0, 0);
+                int n0 = dw - e0 - 4 * lane, n1 = n0 - 256;
+                body(k, wb, e0 + 4 * lane, x0, n0 < 0 ? 0 : (n0 > 4 ? 4 : n0));
+                if (e0 + 256 < dw) body(k, wb, e0 + 256 + 4 * lane, x1, n1 < 0 ? 0 : (n1 > 4 ? 4 : n1));
+            }
+        }
+    }
+}
+
 template <bool FILL, bool HAS_VAL, bool HAS_W>
 __global__ __launch_bounds__(EX_THREADS) void expand_kernel(
     const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col, const float *__restrict__ val,
@@ -75,16 +130,11 @@ __global__ __launch_bounds__(EX_THREADS) void expand_kernel(
         }
 
         // ---- A. mark every 2-hop endpoint --------------------------------------------------
-        for (int k = wib; k < dv; k += EX_WAVES) {
-            const int32_t w = vcol[k];
-            const int64_t wb = rowptr[w];
-            const int32_t dw = (int32_t)(rowptr[w + 1] - wb);
-            const int32_t *__restrict__ wcol = col + wb;
-            for (int i = lane; i < dw; i += 64) {
-                const uint32_t u = (uint32_t)wcol[i];
-                atomicOr(&bm[u >> 5], 1u << (u & 31));
-            }
-        }
+        for_each_path(rowptr, col, vcol, dv, wib, lane, [&](int, int64_t, int, v4i u4, int nvalid) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (e < nvalid) atomicOr(&bm[(uint32_t)u4[e] >> 5], 1u << ((uint32_t)u4[e] & 31));
+        });
         __syncthreads();
         for (int k = tid; k < dv; k += EX_THREADS) {  // known edges out
             const uint32_t u = (uint32_t)vcol[k];
@@ -117,6 +167,7 @@ __global__ __launch_bounds__(EX_THREADS) void expand_kernel(
 
         // ---- C. emit the candidates of this column in ascending u ---------------------------------
         const int64_t base = colptr[v - v_lo];
+        const int64_t base_off = base;
         for (int i = 0; i < wpt; ++i) {
             uint32_t bits = bm[w0 + i];
             pre[w0 + i] = (uint32_t)run;
@@ -132,29 +183,28 @@ __global__ __launch_bounds__(EX_THREADS) void expand_kernel(
 
         // ---- D. score: walk the paths again, add each term to its candidate's slot -------------------
         if (out_acc || out_cn) {
-            for (int k = wib; k < dv; k += EX_WAVES) {
-                const int32_t w = vcol[k];
-                const int64_t wb = rowptr[w];
-                const int32_t dw = (int32_t)(rowptr[w + 1] - wb);
-                const int32_t *__restrict__ wcol = col + wb;
+            for_each_path(rowptr, col, vcol, dv, wib, lane, [&](int k, int64_t wb, int base, v4i u4, int nvalid) {
+                if (nvalid == 0) return;
                 float vw = 1.0f;                          // A[v,w] * node_w[w]: the A_ entry (adamic_utils.py:17)
                 if (HAS_VAL) vw = val[vb + k];
-                if (HAS_W) vw = vw * node_w[w];
-                for (int i = lane; i < dw; i += 64) {
-                    const uint32_t u = (uint32_t)wcol[i];
+                if (HAS_W) vw = vw * node_w[vcol[k]];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (e >= nvalid) continue;
+                    const uint32_t u = (uint32_t)u4[e];
                     const uint32_t word = bm[u >> 5];
                     if ((word >> (u & 31)) & 1u) {
-                        const int64_t slot = base + pre[u >> 5] + __popc(word & ((1u << (u & 31)) - 1u));
+                        const int64_t slot = base_off + pre[u >> 5] + __popc(word & ((1u << (u & 31)) - 1u));
                         if (out_cn) atomicAdd(&out_cn[slot], 1);
                         if (out_acc) {
                             float term = vw;              // A[u,w] * (A[v,w] * node_w[w]), float32 like the reference
-                            if (HAS_VAL) term = val[wb + i] * vw;
+                            if (HAS_VAL) term = val[wb + base + e] * vw;
                             const long long fx = __double2ll_rn((double)term * (double)(1ll << EX_FIXED_SHIFT));
                             atomicAdd(&out_acc[slot], (unsigned long long)fx);
                         }
                     }
                 }
-            }
+            });
             __syncthreads();
         }
         for (int i = 0; i < wpt; ++i) bm[w0 + i] = 0u;
