@@ -48,6 +48,22 @@ def hip_expand_available(g: CSRGraph) -> bool:
     return g.n_rows == g.n_cols and g.n_rows <= ops.expand_max_nodes()
 
 
+def path_counts(g: CSRGraph) -> torch.Tensor:
+    """paths(v) = sum_{w in N(v)} deg(w): the 2-hop paths leaving column v = the cost of expanding it (cached)."""
+    if "paths" not in g._cache:
+        deg = g.rowptr[1:] - g.rowptr[:-1]
+        paths = torch.zeros(g.n_rows, dtype=torch.int64, device=g.device)
+        paths.index_add_(0, g.row_index(), deg[g.col.to(torch.int64)])
+        g._cache["paths"] = paths
+    return g._cache["paths"]
+
+
+def heaviest_first(g: CSRGraph, v_lo: int, v_hi: int) -> torch.Tensor:
+    """Columns of [v_lo, v_hi) by descending path count (int32, relative to v_lo): the hand-out order of the
+    expansion kernels -- a hub column is one workgroup's work for milliseconds and must not start last."""
+    return torch.argsort(path_counts(g)[v_lo:v_hi], descending=True, stable=True).to(torch.int32)
+
+
 def expand_block(g: CSRGraph, v_lo: int, v_hi: int, node_w: Optional[torch.Tensor] = None, want_cn: bool = False,
                  want_score: bool = False):
     """Candidates of columns [v_lo, v_hi) of a SYMMETRIC adjacency, with (optionally) the common-neighbour count
@@ -56,7 +72,8 @@ def expand_block(g: CSRGraph, v_lo: int, v_hi: int, node_w: Optional[torch.Tenso
     from . import ops
     if hip_expand_available(g):
         _, cu, cv, cn, sc = ops.expand_candidates(g.rowptr, g.col, g.val, node_w, g.n_rows, v_lo, v_hi,
-                                                  want_cn=want_cn, want_score=want_score)
+                                                  want_cn=want_cn, want_score=want_score,
+                                                  col_order=heaviest_first(g, v_lo, v_hi))
         return torch.stack([cu, cv]).long(), cn, sc
     pairs = two_hop_block(g, v_lo, v_hi)
     cn = sc = None
@@ -68,14 +85,10 @@ def expand_block(g: CSRGraph, v_lo: int, v_hi: int, node_w: Optional[torch.Tenso
     return pairs, cn, sc
 
 
-def column_blocks(g: CSRGraph, max_paths: int = 1 << 27) -> Iterator[Tuple[int, int]]:
+def column_blocks(g: CSRGraph, max_paths: int = 1 << 29) -> Iterator[Tuple[int, int]]:
     """Column ranges whose 2-hop path count stays below ``max_paths`` (bounds a block's memory: a block never
     holds more candidates than paths)."""
-    deg = (g.rowptr[1:] - g.rowptr[:-1])
-    rows = g.row_index()
-    paths = torch.zeros(g.n_rows, dtype=torch.int64, device=g.device)
-    paths.index_add_(0, rows, deg[g.col.to(torch.int64)])                    # paths(v) = sum_{w in N(v)} deg(w)
-    cum = torch.cumsum(paths, 0).cpu()
+    cum = torch.cumsum(path_counts(g), 0).cpu()
     n = g.n_rows
     v = 0
     while v < n:
@@ -86,29 +99,14 @@ def column_blocks(g: CSRGraph, max_paths: int = 1 << 27) -> Iterator[Tuple[int, 
         v = hi
 
 
-def iter_candidate_blocks(g: CSRGraph, max_paths: int = 1 << 27) -> Iterator[Tuple[int, int, torch.Tensor]]:
+def iter_candidate_blocks(g: CSRGraph, max_paths: int = 1 << 29) -> Iterator[Tuple[int, int, torch.Tensor]]:
     """Yield (v_lo, v_hi, pairs[2,E_blk]) over all columns."""
-    if hip_expand_available(g):
-        for lo, hi in column_blocks(g, max_paths):
-            yield lo, hi, expand_block(g, lo, hi)[0]
-        return
-    deg = (g.rowptr[1:] - g.rowptr[:-1])
-    rows = g.row_index()
-    paths = torch.zeros(g.n_rows, dtype=torch.int64, device=g.device)
-    paths.index_add_(0, rows, deg[g.col.to(torch.int64)])                    # paths(v) = sum_{w in N(v)} deg(w)
-    cum = torch.cumsum(paths, 0).cpu()
-    n = g.n_rows
-    v = 0
-    while v < n:
-        base = int(cum[v - 1]) if v > 0 else 0
-        hi = int(torch.searchsorted(cum, torch.tensor(base + max_paths), right=True))
-        hi = max(hi, v + 1)
-        hi = min(hi, n)
-        yield v, hi, two_hop_block(g, v, hi)
-        v = hi
+    fused = hip_expand_available(g)
+    for lo, hi in column_blocks(g, max_paths):
+        yield lo, hi, (expand_block(g, lo, hi)[0] if fused else two_hop_block(g, lo, hi))
 
 
-def all_candidates(g: CSRGraph, max_paths: int = 1 << 27) -> torch.Tensor:
+def all_candidates(g: CSRGraph, max_paths: int = 1 << 29) -> torch.Tensor:
     """The whole candidate list [2,E] (small graphs / tests)."""
     blocks = [b for _, _, b in iter_candidate_blocks(g, max_paths)]
     return torch.cat(blocks, 1) if blocks else torch.zeros((2, 0), dtype=torch.int64, device=g.device)

@@ -16,19 +16,25 @@
 //      column's candidate count (kernel 1 stops here: counts -> host cumsum -> colptr).
 //   C. emit: set bits in ascending order -> cand_u[colptr[v] + rank] (ascending u: the
 //      reference's column-major order for free).
+//      Columns may be handed out in a caller-given order (heaviest first keeps the tail of a
+//      launch short: a hub column is one workgroup's work for milliseconds).
 //   D. score: walk the same paths again; a path whose u is a candidate adds its term to the
-//      candidate's slot with a global atomic.  Terms are accumulated in 64-bit FIXED POINT
-//      (2^-40): integer addition is associative, so the result is bit-reproducible whatever the
-//      arrival order (float atomics are not), and exact up to the final rounding to float32.
+//      candidate's slot.  Terms are accumulated in 64-bit FIXED POINT (2^-40): integer addition
+//      is associative, so the result is bit-reproducible whatever the arrival order (float
+//      atomics are not), and exact up to the final rounding to float32.  Most candidates are
+//      reached by ONE path (72% on the ppa-like graph): pass A records, in a second bitmap at
+//      half resolution, which ids were marked more than once, and a candidate outside it gets
+//      its term with a plain store (absorbed by the L2) instead of a memory-side atomic, which
+//      is ~5x slower per operation and bounds this pass.
 // Requires a SYMMETRIC adjacency (filter.py's always is: rank.py:33 to_symmetric) and
-// N <= 655,360 node ids (bitmap + prefix array in the 160 KiB LDS); the host falls back to the
-// tensor-op expansion above that.
+// N <= 688,128 node ids (two bitmaps + the rank tables in the 160 KiB LDS: 7.5 bytes per 32
+// ids); the host falls back to the tensor-op expansion above that.
 #include "eps_common.h"
 
 #define EX_THREADS 1024
 #define EX_WAVES (EX_THREADS / 64)
 #define EX_FIXED_SHIFT 40
-#define EX_MAX_WORDS 40448  // bitmap + prefix words: 40448 * 4 B = 158 KiB (the rest of the 160 KiB is static LDS)
+#define EX_MAX_WPT 21       // bitmap words per thread: 21 * 1024 words * 7.5 B = 157.5 KiB (the rest is static LDS)
 
 
 __device__ __forceinline__ int wave_incl_scan(int x, int lane)
@@ -99,14 +105,18 @@ __device__ __forceinline__ void for_each_path(const int64_t *__restrict__ rowptr
 template <bool FILL, bool HAS_VAL, bool HAS_W>
 __global__ __launch_bounds__(EX_THREADS) void expand_kernel(
     const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col, const float *__restrict__ val,
-    const float *__restrict__ node_w, int32_t v_lo, int32_t v_hi, int32_t wpt, unsigned int *__restrict__ next_col,
+    const float *__restrict__ node_w, int32_t v_lo, int32_t v_hi, const int32_t *__restrict__ col_order, int32_t wpt,
+    unsigned int *__restrict__ next_col,
     int64_t *__restrict__ cand_count, const int64_t *__restrict__ colptr, int32_t *__restrict__ cand_u,
-    int32_t *__restrict__ cand_v, int32_t *__restrict__ out_cn, unsigned long long *__restrict__ out_acc)
+    int32_t *__restrict__ cand_v, int32_t *__restrict__ out_cn, unsigned long long *__restrict__ out_acc,
+    float *__restrict__ out_score)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const int words = wpt * EX_THREADS;
-    uint32_t *bm = lds;
-    uint32_t *pre = lds + words;  // FILL only
+    uint32_t *bm = lds;                            // bit u: u is a 2-hop endpoint of the column
+    uint32_t *multi = lds + words;                 // FILL only.  bit u>>1: u or u^1 was marked more than once
+    uint32_t *base32 = multi + words / 2;          // rank of the first bit of every 8-word group
+    uint8_t *pre8 = (uint8_t *)(base32 + words / 8);  // rank of a word's first bit within its group (<= 224)
     __shared__ int s_wave_tot[EX_WAVES];
     __shared__ unsigned int s_col;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -114,13 +124,15 @@ __global__ __launch_bounds__(EX_THREADS) void expand_kernel(
 
     // the bitmap is all-zero between columns: every column clears exactly the words it scanned
     for (int i = tid; i < words; i += EX_THREADS) bm[i] = 0u;
+    if (FILL)
+        for (int i = tid; i < words / 2; i += EX_THREADS) multi[i] = 0u;
 
     for (;;) {
         __syncthreads();
         if (tid == 0) s_col = atomicAdd(next_col, 1u);
         __syncthreads();
-        const int64_t v = (int64_t)v_lo + s_col;
-        if (v >= v_hi) break;
+        if ((int64_t)v_lo + s_col >= v_hi) break;
+        const int64_t v = (int64_t)v_lo + (col_order ? (uint32_t)col_order[s_col] : s_col);
         const int64_t vb = rowptr[v];
         const int32_t dv = (int32_t)(rowptr[v + 1] - vb);
         const int32_t *__restrict__ vcol = col + vb;
@@ -132,8 +144,15 @@ __global__ __launch_bounds__(EX_THREADS) void expand_kernel(
         // ---- A. mark every 2-hop endpoint --------------------------------------------------
         for_each_path(rowptr, col, vcol, dv, wib, lane, [&](int, int64_t, int, v4i u4, int nvalid) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-                if (e < nvalid) atomicOr(&bm[(uint32_t)u4[e] >> 5], 1u << ((uint32_t)u4[e] & 31));
+            for (int e = 0; e < 4; ++e) {
+                if (e >= nvalid) continue;
+                const uint32_t u = (uint32_t)u4[e], bit = 1u << (u & 31);
+                if (!FILL) {
+                    atomicOr(&bm[u >> 5], bit);
+                } else if (atomicOr(&bm[u >> 5], bit) & bit) {   // seen before: more than one path ends here
+                    atomicOr(&multi[u >> 6], 1u << ((u >> 1) & 31));
+                }
+            }
         });
         __syncthreads();
         for (int k = tid; k < dv; k += EX_THREADS) {  // known edges out
@@ -168,9 +187,10 @@ __global__ __launch_bounds__(EX_THREADS) void expand_kernel(
         // ---- C. emit the candidates of this column in ascending u ---------------------------------
         const int64_t base = colptr[v - v_lo];
         const int64_t base_off = base;
+        const int run0 = run;
         for (int i = 0; i < wpt; ++i) {
             uint32_t bits = bm[w0 + i];
-            pre[w0 + i] = (uint32_t)run;
+            if (((w0 + i) & 7) == 0) base32[(w0 + i) >> 3] = (uint32_t)run;
             while (bits) {
                 const int b = __builtin_ctz(bits);
                 bits &= bits - 1;
@@ -178,6 +198,12 @@ __global__ __launch_bounds__(EX_THREADS) void expand_kernel(
                 if (cand_v) cand_v[base + run] = (int32_t)v;
                 ++run;
             }
+        }
+        __syncthreads();
+        run = run0;
+        for (int i = 0; i < wpt; ++i) {  // group bases are complete: ranks relative to them fit a byte
+            pre8[w0 + i] = (uint8_t)((uint32_t)run - base32[(w0 + i) >> 3]);
+            run += __popc(bm[w0 + i]);
         }
         __syncthreads();
 
@@ -194,13 +220,21 @@ __global__ __launch_bounds__(EX_THREADS) void expand_kernel(
                     const uint32_t u = (uint32_t)u4[e];
                     const uint32_t word = bm[u >> 5];
                     if ((word >> (u & 31)) & 1u) {
-                        const int64_t slot = base_off + pre[u >> 5] + __popc(word & ((1u << (u & 31)) - 1u));
-                        if (out_cn) atomicAdd(&out_cn[slot], 1);
+                        const int64_t slot = base_off + base32[u >> 8] + pre8[u >> 5] + __popc(word & ((1u << (u & 31)) - 1u));
+                        const bool only = !((multi[u >> 6] >> ((u >> 1) & 31)) & 1u);  // this path is the slot's only writer
+                        if (out_cn) {
+                            if (only) out_cn[slot] = 1;
+                            else atomicAdd(&out_cn[slot], 1);
+                        }
                         if (out_acc) {
                             float term = vw;              // A[u,w] * (A[v,w] * node_w[w]), float32 like the reference
                             if (HAS_VAL) term = val[wb + base + e] * vw;
-                            const long long fx = __double2ll_rn((double)term * (double)(1ll << EX_FIXED_SHIFT));
-                            atomicAdd(&out_acc[slot], (unsigned long long)fx);
+                            if (only) {
+                                out_score[slot] = term;   // the whole sum: no accumulator traffic at all
+                            } else {
+                                const long long fx = __double2ll_rn((double)term * (double)(1ll << EX_FIXED_SHIFT));
+                                atomicAdd(&out_acc[slot], (unsigned long long)fx);
+                            }
                         }
                     }
                 }
@@ -208,6 +242,7 @@ __global__ __launch_bounds__(EX_THREADS) void expand_kernel(
             __syncthreads();
         }
         for (int i = 0; i < wpt; ++i) bm[w0 + i] = 0u;
+        for (int i = tid; i < words / 2; i += EX_THREADS) multi[i] = 0u;
     }
 }
 
@@ -215,7 +250,7 @@ __global__ void fixed_to_float_kernel(const long long *__restrict__ acc, int64_t
 {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
-        out[i] = (float)((double)acc[i] * (1.0 / (double)(1ll << EX_FIXED_SHIFT)));
+        if (const long long a = acc[i]) out[i] = (float)((double)a * (1.0 / (double)(1ll << EX_FIXED_SHIFT)));
 }
 
 static int expand_words_per_thread(int64_t n_nodes)
@@ -224,16 +259,19 @@ static int expand_words_per_thread(int64_t n_nodes)
     return (int)((words + EX_THREADS - 1) / EX_THREADS);
 }
 
-extern "C" int eps_expand_max_nodes(void) { return (EX_MAX_WORDS / 2) * 32; }
+extern "C" int eps_expand_max_nodes(void) { return EX_MAX_WPT * EX_THREADS * 32; }
+
+// LDS bytes of the fill kernel: bitmap 4 B + half-resolution bitmap 2 B + group bases 0.5 B + byte ranks 1 B per word.
+static size_t expand_fill_lds(int wpt) { return (size_t)wpt * EX_THREADS * 15 / 2; }
 
 extern "C" int eps_expand_count(const int64_t *rowptr, const int32_t *col, int64_t n_nodes, int64_t v_lo, int64_t v_hi,
-                                int64_t *cand_count, void *stream)
+                                const int32_t *col_order, int64_t *cand_count, void *stream)
 {
     EPS_REQUIRE(n_nodes >= 0 && v_lo >= 0 && v_hi >= v_lo && v_hi <= n_nodes, "eps_expand_count: bad column range");
     if (v_hi == v_lo) return EPS_OK;
     EPS_REQUIRE(rowptr && col && cand_count, "eps_expand_count: null pointer");
     const int wpt = expand_words_per_thread(n_nodes);
-    EPS_REQUIRE((int64_t)wpt * EX_THREADS * 2 <= EX_MAX_WORDS, "eps_expand_count: %lld nodes exceed the LDS bitmap (max %d)",
+    EPS_REQUIRE(wpt <= EX_MAX_WPT, "eps_expand_count: %lld nodes exceed the LDS bitmap (max %d)",
                 (long long)n_nodes, eps_expand_max_nodes());
     hipStream_t s = (hipStream_t)stream;
     unsigned int *counter = nullptr;
@@ -248,28 +286,30 @@ extern "C" int eps_expand_count(const int64_t *rowptr, const int32_t *col, int64
     int64_t blocks = (int64_t)eps_num_cus() * (lds * 2 + 1024 <= 163840 ? 2 : 1);
     if (blocks > v_hi - v_lo) blocks = v_hi - v_lo;
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(EX_THREADS), lds, s, rowptr, col, (const float *)nullptr,
-                       (const float *)nullptr, (int32_t)v_lo, (int32_t)v_hi, wpt, counter, cand_count,
+                       (const float *)nullptr, (int32_t)v_lo, (int32_t)v_hi, col_order, wpt, counter, cand_count,
                        (const int64_t *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr,
-                       (unsigned long long *)nullptr);
+                       (unsigned long long *)nullptr, (float *)nullptr);
     EPS_CHECK_LAUNCH("eps_expand_count");
     return EPS_OK;
 }
 
 extern "C" int eps_expand_fill(const int64_t *rowptr, const int32_t *col, const float *val, const float *node_w,
-                               int64_t n_nodes, int64_t v_lo, int64_t v_hi, const int64_t *colptr, int32_t *cand_u,
-                               int32_t *cand_v, int32_t *cn, int64_t *acc, void *stream)
+                               int64_t n_nodes, int64_t v_lo, int64_t v_hi, const int32_t *col_order,
+                               const int64_t *colptr, int32_t *cand_u,
+                               int32_t *cand_v, int32_t *cn, int64_t *acc, float *score, void *stream)
 {
     EPS_REQUIRE(n_nodes >= 0 && v_lo >= 0 && v_hi >= v_lo && v_hi <= n_nodes, "eps_expand_fill: bad column range");
     if (v_hi == v_lo) return EPS_OK;
     EPS_REQUIRE(rowptr && col && colptr && cand_u, "eps_expand_fill: null pointer");
+    EPS_REQUIRE((acc == nullptr) == (score == nullptr), "eps_expand_fill: acc and score go together");
     const int wpt = expand_words_per_thread(n_nodes);
-    EPS_REQUIRE((int64_t)wpt * EX_THREADS * 2 <= EX_MAX_WORDS, "eps_expand_fill: %lld nodes exceed the LDS bitmap (max %d)",
+    EPS_REQUIRE(wpt <= EX_MAX_WPT, "eps_expand_fill: %lld nodes exceed the LDS bitmap (max %d)",
                 (long long)n_nodes, eps_expand_max_nodes());
     hipStream_t s = (hipStream_t)stream;
     unsigned int *counter = nullptr;
     int rc = eps_take_counter(&counter, s, "eps_expand_fill");
     if (rc) return rc;
-    const size_t lds = (size_t)wpt * EX_THREADS * 4 * 2;
+    const size_t lds = expand_fill_lds(wpt);
     int64_t blocks = eps_num_cus();
     if (blocks > v_hi - v_lo) blocks = v_hi - v_lo;
     const bool hv = val != nullptr, hw = node_w != nullptr;
@@ -282,8 +322,8 @@ extern "C" int eps_expand_fill(const int64_t *rowptr, const int32_t *col, const 
             return EPS_ELAUNCH;                                                                                        \
         }                                                                                                              \
         hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(EX_THREADS), lds, s, rowptr, col, val, node_w,           \
-                           (int32_t)v_lo, (int32_t)v_hi, wpt, counter, (int64_t *)nullptr, colptr, cand_u, cand_v, cn, \
-                           (unsigned long long *)acc);                                                                 \
+                           (int32_t)v_lo, (int32_t)v_hi, col_order, wpt, counter, (int64_t *)nullptr, colptr, cand_u,  \
+                           cand_v, cn, (unsigned long long *)acc, score);                                              \
     } while (0)
     if (hv && hw) EX_LAUNCH(true, true);
     else if (hv) EX_LAUNCH(true, false);

@@ -130,33 +130,37 @@ def expand_max_nodes() -> int:
 
 
 def expand_candidates(rowptr, col, val, node_w, n_nodes: int, v_lo: int, v_hi: int, want_cn=True, want_score=True,
-                      want_v=True):
+                      want_v=True, col_order=None):
     """Fused 2-hop expansion of columns [v_lo, v_hi) of a SYMMETRIC adjacency (filter.py:96-109 + scoring).
     -> (colptr int64[n_cols+1], cand_u int32[E], cand_v int32[E] | None, cn int32[E] | None, score float32[E] | None);
-    candidates are column-major, u ascending inside a column (the reference's order)."""
-    dev = _need_gpu(rowptr, col, val, node_w)
+    candidates are column-major, u ascending inside a column (the reference's order).  ``col_order`` (int32
+    permutation of range(v_hi - v_lo), optional) is the order the columns are handed to the workgroups; the results
+    do not depend on it."""
+    dev = _need_gpu(rowptr, col, val, node_w, col_order)
     _chk(rowptr, torch.int64, "rowptr"); _chk(col, torch.int32, "col"); _chk(val, torch.float32, "val")
-    _chk(node_w, torch.float32, "node_w")
+    _chk(node_w, torch.float32, "node_w"); _chk(col_order, torch.int32, "col_order")
     lib = _lib.load()
     n_cols = v_hi - v_lo
+    if col_order is not None and col_order.numel() != n_cols:
+        raise ValueError("col_order must have one entry per column of the range")
     colptr = torch.zeros(n_cols + 1, dtype=torch.int64, device=dev)
     with torch.cuda.device(dev):
         counts = torch.empty(n_cols, dtype=torch.int64, device=dev)
-        _lib.check(lib.eps_expand_count(_ptr(rowptr), _ptr(col), n_nodes, v_lo, v_hi, _ptr(counts), _stream(dev)),
-                   "eps_expand_count")
+        _lib.check(lib.eps_expand_count(_ptr(rowptr), _ptr(col), n_nodes, v_lo, v_hi, _ptr(col_order), _ptr(counts),
+                                        _stream(dev)), "eps_expand_count")
         torch.cumsum(counts, 0, out=colptr[1:])
         total = int(colptr[-1].item())
         cand_u = torch.empty(total, dtype=torch.int32, device=dev)
         cand_v = torch.empty(total, dtype=torch.int32, device=dev) if want_v else None
         cn = torch.zeros(total, dtype=torch.int32, device=dev) if want_cn else None
         acc = torch.zeros(total, dtype=torch.int64, device=dev) if want_score else None
+        score = torch.zeros(total, dtype=torch.float32, device=dev) if want_score else None
         if total:
             _lib.check(lib.eps_expand_fill(_ptr(rowptr), _ptr(col), _ptr(val), _ptr(node_w), n_nodes, v_lo, v_hi,
-                                           _ptr(colptr), _ptr(cand_u), _ptr(cand_v), _ptr(cn), _ptr(acc), _stream(dev)),
+                                           _ptr(col_order), _ptr(colptr), _ptr(cand_u), _ptr(cand_v), _ptr(cn), _ptr(acc), _ptr(score),
+                                           _stream(dev)),
                        "eps_expand_fill")
-        score = None
         if want_score:
-            score = torch.empty(total, dtype=torch.float32, device=dev)
             _lib.check(lib.eps_fixed_to_float(_ptr(acc), total, _ptr(score), _stream(dev)), "eps_fixed_to_float")
     return colptr, cand_u, cand_v, cn, score
 

@@ -96,20 +96,26 @@ int eps_pair_scores_grouped_f64(const int64_t *rowptr, const int32_t *col, const
  * yields every candidate of the column with its common-neighbour count and
  * sum_w A[u,w]*(A[v,w]*node_w[w]).  The adjacency must be symmetric (rank.py:33) and have at
  * most eps_expand_max_nodes() nodes (LDS bitmap).
+ *   col_order (both calls; may be NULL): a permutation of [0, v_hi - v_lo) -- the order in which the
+ *                     columns v_lo + col_order[i] are handed to the workgroups.  Results do not
+ *                     depend on it; heaviest-first shortens the tail of a launch.
  *   eps_expand_count: cand_count[v - v_lo] = number of 2-hop non-edges (u, v), v in [v_lo, v_hi).
  *   eps_expand_fill : colptr = exclusive prefix of cand_count (int64[n_cols+1], device); writes
  *                     cand_u (ascending inside a column == the reference's order), cand_v (column
  *                     id per candidate; optional), cn (int32 count; optional, ZEROED by the
- *                     caller) and acc (optional, ZEROED by the caller): the weighted sum in
- *                     2^-40 fixed point -- integer atomics make the result independent of the
- *                     accumulation order; eps_fixed_to_float converts it to float32. */
+ *                     caller) and the weighted sum (optional; acc AND score, both ZEROED by the
+ *                     caller): a candidate reached by one path gets its float32 term in score
+ *                     directly; the others accumulate in acc in 2^-40 fixed point -- integer
+ *                     atomics make the result independent of the accumulation order.
+ *   eps_fixed_to_float: score[i] = float32(acc[i] * 2^-40) wherever acc[i] != 0 (completes the
+ *                     score array of eps_expand_fill; entries with acc[i] == 0 are left alone). */
 int eps_expand_max_nodes(void);
 int eps_expand_count(const int64_t *rowptr, const int32_t *col, int64_t n_nodes, int64_t v_lo,
-                     int64_t v_hi, int64_t *cand_count, void *stream);
+                     int64_t v_hi, const int32_t *col_order, int64_t *cand_count, void *stream);
 int eps_expand_fill(const int64_t *rowptr, const int32_t *col, const float *val,
                     const float *node_w, int64_t n_nodes, int64_t v_lo, int64_t v_hi,
-                    const int64_t *colptr, int32_t *cand_u, int32_t *cand_v, int32_t *cn,
-                    int64_t *acc, void *stream);
+                    const int32_t *col_order, const int64_t *colptr, int32_t *cand_u, int32_t *cand_v, int32_t *cn,
+                    int64_t *acc, float *score, void *stream);
 int eps_fixed_to_float(const int64_t *acc, int64_t n, float *out, void *stream);
 
 /* ---- K4/K5: CSR x dense SpMM with fused epilogue -----------------------------------------

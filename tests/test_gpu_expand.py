@@ -60,6 +60,18 @@ def test_expand_rmat_and_determinism(eps, oracle, dev):
     a = eps.ops.expand_candidates(gd.rowptr, gd.col, None, wt, gd.n_rows, 0, gd.n_rows)
     b = eps.ops.expand_candidates(gd.rowptr, gd.col, None, wt, gd.n_rows, 0, gd.n_rows)
     assert torch.equal(a[4], b[4]) and torch.equal(a[1], b[1]), "fixed-point accumulation is order-independent"
+    # the hand-out order of the columns (heaviest first in the product path) must not show in any output
+    from eps_amd import candidates
+    order = candidates.heaviest_first(gd, 0, gd.n_rows)
+    assert sorted(order.tolist()) == list(range(gd.n_rows))
+    assert int(candidates.path_counts(gd)[order[0]]) == int(candidates.path_counts(gd).max())
+    c = eps.ops.expand_candidates(gd.rowptr, gd.col, None, wt, gd.n_rows, 0, gd.n_rows, col_order=order)
+    rev = order.flip(0).contiguous()
+    d = eps.ops.expand_candidates(gd.rowptr, gd.col, None, wt, gd.n_rows, 0, gd.n_rows, col_order=rev)
+    for i in range(5):
+        assert torch.equal(a[i], c[i]) and torch.equal(a[i], d[i])
+    with pytest.raises(ValueError):
+        eps.ops.expand_candidates(gd.rowptr, gd.col, None, wt, gd.n_rows, 0, gd.n_rows, col_order=order[:5])
 
 
 def test_expand_matches_pair_kernel_at_scale(eps, dev):
