@@ -65,16 +65,16 @@ def heaviest_first(g: CSRGraph, v_lo: int, v_hi: int) -> torch.Tensor:
 
 
 def expand_block(g: CSRGraph, v_lo: int, v_hi: int, node_w: Optional[torch.Tensor] = None, want_cn: bool = False,
-                 want_score: bool = False):
+                 want_score: bool = False, long_pairs: bool = True):
     """Candidates of columns [v_lo, v_hi) of a SYMMETRIC adjacency, with (optionally) the common-neighbour count
     and sum_w A[u,w]*(A[v,w]*node_w[w]) of every candidate, from ONE fused expansion.
-    -> (pairs int64 [2,E] column-major, cn int32[E] | None, score float32[E] | None)."""
+    -> (pairs int64 [2,E] column-major, cn int32[E] | None, score float32[E] | None).  ``long_pairs=False`` leaves the
+    pairs in the int32 buffer the kernel wrote (no 8-byte copy of a list that may hold 10^8 candidates)."""
     from . import ops
     if hip_expand_available(g):
-        _, cu, cv, cn, sc = ops.expand_candidates(g.rowptr, g.col, g.val, node_w, g.n_rows, v_lo, v_hi,
-                                                  want_cn=want_cn, want_score=want_score,
-                                                  col_order=heaviest_first(g, v_lo, v_hi))
-        return torch.stack([cu, cv]).long(), cn, sc
+        r = ops.expand_candidates(g.rowptr, g.col, g.val, node_w, g.n_rows, v_lo, v_hi, want_cn=want_cn,
+                                  want_score=want_score, col_order=heaviest_first(g, v_lo, v_hi))
+        return (r.pairs.long() if long_pairs else r.pairs), r[3], r[4]
     pairs = two_hop_block(g, v_lo, v_hi)
     cn = sc = None
     if (want_cn or want_score) and pairs.shape[1]:

@@ -107,7 +107,7 @@ def scored_blocks(args, model, data, ra_graph, col_lo: int = 0, col_hi: int = No
         node_w = torch.ones(g.n_rows, dtype=torch.float32, device=g.device)
     print(f'fused candidate generation + scoring ({args.model})')
     for v_lo, v_hi in blocks:
-        pairs, _, score = candidates.expand_block(g, v_lo, v_hi, node_w, want_score=True)
+        pairs, _, score = candidates.expand_block(g, v_lo, v_hi, node_w, want_score=True, long_pairs=False)
         yield v_lo, v_hi, pairs, score
 
 

@@ -129,6 +129,12 @@ def expand_max_nodes() -> int:
     return int(_lib.load().eps_expand_max_nodes())
 
 
+class ExpandResult(tuple):
+    """(colptr, cand_u, cand_v, cn, score) of ``expand_candidates``; ``.pairs`` is the int32 [2,E] buffer cand_u and
+    cand_v are rows of (None without cand_v), so the (u; v) list exists without a copy."""
+    pairs = None
+
+
 def expand_candidates(rowptr, col, val, node_w, n_nodes: int, v_lo: int, v_hi: int, want_cn=True, want_score=True,
                       want_v=True, col_order=None):
     """Fused 2-hop expansion of columns [v_lo, v_hi) of a SYMMETRIC adjacency (filter.py:96-109 + scoring).
@@ -150,8 +156,9 @@ def expand_candidates(rowptr, col, val, node_w, n_nodes: int, v_lo: int, v_hi: i
                                         _stream(dev)), "eps_expand_count")
         torch.cumsum(counts, 0, out=colptr[1:])
         total = int(colptr[-1].item())
-        cand_u = torch.empty(total, dtype=torch.int32, device=dev)
-        cand_v = torch.empty(total, dtype=torch.int32, device=dev) if want_v else None
+        pairs = torch.empty((2 if want_v else 1, total), dtype=torch.int32, device=dev)
+        cand_u = pairs[0]
+        cand_v = pairs[1] if want_v else None
         cn = torch.zeros(total, dtype=torch.int32, device=dev) if want_cn else None
         acc = torch.zeros(total, dtype=torch.int64, device=dev) if want_score else None
         score = torch.zeros(total, dtype=torch.float32, device=dev) if want_score else None
@@ -162,7 +169,9 @@ def expand_candidates(rowptr, col, val, node_w, n_nodes: int, v_lo: int, v_hi: i
                        "eps_expand_fill")
         if want_score:
             _lib.check(lib.eps_fixed_to_float(_ptr(acc), total, _ptr(score), _stream(dev)), "eps_fixed_to_float")
-    return colptr, cand_u, cand_v, cn, score
+    out = ExpandResult((colptr, cand_u, cand_v, cn, score))
+    out.pairs = pairs if want_v else None
+    return out
 
 
 def spmm_csr(rowptr, col, val, x: torch.Tensor, bias=None, relu=False, mean=False, out=None) -> torch.Tensor:

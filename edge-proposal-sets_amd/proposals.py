@@ -61,22 +61,47 @@ class StreamingTopK:
     blocks ARRIVE in candidate order: a stable descending sort keeps earlier candidates first among equal scores, so
     no candidate index has to be carried (the full ppa candidate set exceeds 2**32 entries).  Once K entries are held,
     a block is first cut to the scores strictly above the current K-th one -- an equal score from a later block can
-    never displace an earlier candidate -- which leaves next to nothing to sort for most blocks."""
+    never displace an earlier candidate -- which leaves next to nothing to sort for most blocks.  A block that is
+    still much larger than K after that (the first ones: hundreds of millions of candidates) is cut at a threshold
+    read off a strided sample and VERIFIED to keep at least K entries, so only ~1.5 K scores are ever sorted; the
+    result is the exact top-K either way.  Pairs may arrive as int32 or int64; ``result()`` returns int64."""
+
+    PRECUT_FACTOR = 4          # pre-cut blocks larger than this many times K
+    SAMPLE_STRIDE = 64
 
     def __init__(self, k: int):
         self.k = int(k)
         self.scores = None     # float32 [<=k], descending
-        self.pairs = None      # int64 [2, <=k]
+        self.pairs = None      # int [2, <=k]
+
+    def _precut(self, scores: torch.Tensor, need: int):
+        """Mask of the entries >= a threshold that provably keeps >= ``need`` of them, or None (sort everything)."""
+        n = scores.numel()
+        if need <= 0 or n <= self.PRECUT_FACTOR * max(need, 1) or n < 1 << 16:
+            return None
+        sample = scores[:: self.SAMPLE_STRIDE]
+        want = min(sample.numel() - 1, int(1.5 * need / self.SAMPLE_STRIDE) + 64)
+        t = torch.sort(sample, descending=True).values[want]
+        m = scores >= t
+        return m if int(m.sum()) >= need else None
 
     def push(self, pairs: torch.Tensor, scores: torch.Tensor) -> None:
         if scores.numel() == 0:
             return
-        if self.scores is not None and self.scores.numel() >= self.k:
-            m = scores > self.scores[-1]
-            if not bool(m.any()):
+        held = 0 if self.scores is None else self.scores.numel()
+        if held >= self.k:
+            idx = torch.nonzero(scores > self.scores[-1]).squeeze(1)      # ascending: candidate order is kept
+            if idx.numel() == 0:
                 return
-            pairs, scores = pairs[:, m], scores[m]            # boolean indexing keeps candidate order
+            pairs, scores = pairs[:, idx], scores[idx]
+        # every entry of the final top-K that comes from this block is among the block's own best K
+        m = self._precut(scores, self.k)
+        if m is not None:
+            idx = torch.nonzero(m).squeeze(1)
+            pairs, scores = pairs[:, idx], scores[idx]
         if self.scores is not None:
+            if pairs.dtype != self.pairs.dtype:
+                pairs, self.pairs = pairs.long(), self.pairs.long()
             scores = torch.cat([self.scores, scores])          # held entries come first: they are earlier candidates
             pairs = torch.cat([self.pairs, pairs], 1)
         order = torch.sort(scores, descending=True, stable=True).indices[: self.k]
@@ -86,7 +111,7 @@ class StreamingTopK:
         if self.scores is None:
             dev = "cpu"
             return torch.zeros((2, 0), dtype=torch.int64, device=dev), torch.zeros(0, dtype=torch.float32, device=dev)
-        return self.pairs, self.scores
+        return self.pairs.long(), self.scores
 
 
 def merge_ranked_lists(pair_lists, score_lists, k: int):

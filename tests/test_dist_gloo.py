@@ -132,3 +132,25 @@ def test_streaming_topk_and_ranked_merge_cpu():
             pl.append(p); sl.append(s)
         mp, ms = proposals.merge_ranked_lists(pl, sl, k)
         assert torch.equal(mp[0], want) and torch.equal(ms, scores[want])
+
+
+def test_streaming_topk_sampled_precut_cpu():
+    """Blocks far larger than K are cut at a sampled, verified threshold before sorting: same list as the full stable
+    sort, with heavy ties at the cut, int32 pairs in / int64 pairs out, and a degenerate all-equal block."""
+    sys.path.insert(0, ROOT)
+    import eps_amd  # noqa: F401
+    from eps_amd import proposals
+    g = torch.Generator().manual_seed(11)
+    n, k = 400_000, 1500
+    for scores in (torch.randint(0, 12, (n,), generator=g).float(),            # ~33k entries per tie class
+                   torch.rand(n, generator=g),
+                   torch.ones(n)):
+        pairs = torch.stack([torch.arange(n, dtype=torch.int32), (torch.arange(n) * 13 % 977).to(torch.int32)])
+        want = torch.sort(scores, descending=True, stable=True).indices[:k]
+        top = proposals.StreamingTopK(k)
+        assert top._precut(scores, k) is not None or bool((scores == scores[0]).all())
+        for b in range(0, n, 150_000):
+            top.push(pairs[:, b:b + 150_000], scores[b:b + 150_000])
+        p, s = top.result()
+        assert p.dtype == torch.int64
+        assert torch.equal(p[0], want) and torch.equal(s, scores[want])
