@@ -185,19 +185,26 @@ def main():
         dt = t.item()
     kern_ms = sum(a.elapsed_time(b) for a, b in evs) / args.steps
 
-    # Second leg, same columns: the FUSED filter path (csrc/expand_score.hip) -- candidate generation + CN + AA in one
-    # expansion of the 2-hop paths (what filter.py runs for heuristic filters).  Timed end to end on the host clock:
-    # count kernel + cumsum + zero-fill + fill kernel + fixed->float, outputs left in HBM.
+    # Second leg: the FUSED filter path (csrc/expand_score.hip) -- candidate generation + CN + AA in one expansion of
+    # the 2-hop paths (what filter.py runs for heuristic filters), on one production-sized launch: the columns from
+    # the rank's first one up to 2^29 two-hop paths, handed out heaviest first, exactly as candidates.expand_block
+    # launches them.  Timed end to end on the host clock: count kernel + cumsum + zero-fill + fill kernel +
+    # finish kernel, outputs left in HBM.
     fused = None
     if candidates.hip_expand_available(g):
-        c_lo, c_hi = col_range
+        c_lo = col_range[0]
+        pc = torch.cumsum(candidates.path_counts(g), 0)
+        base = int(pc[c_lo - 1].item()) if c_lo > 0 else 0
+        c_hi = int(torch.searchsorted(pc, torch.tensor(base + (1 << 29), device=dev), right=True).item())
+        c_hi = min(max(c_hi, c_lo + 1), g.n_rows)
+        order = candidates.heaviest_first(g, c_lo, c_hi)
         for _ in range(2):
-            r = ops.expand_candidates(g.rowptr, g.col, g.val, w, g.n_rows, c_lo, c_hi)
+            r = ops.expand_candidates(g.rowptr, g.col, g.val, w, g.n_rows, c_lo, c_hi, col_order=order)
         barrier()
         t1 = time.perf_counter()
         fsteps = max(3, args.steps // 4)
         for _ in range(fsteps):
-            r = ops.expand_candidates(g.rowptr, g.col, g.val, w, g.n_rows, c_lo, c_hi)
+            r = ops.expand_candidates(g.rowptr, g.col, g.val, w, g.n_rows, c_lo, c_hi, col_order=order)
         barrier()
         fdt = time.perf_counter() - t1
         if world > 1:
@@ -207,13 +214,14 @@ def main():
         n_cand = torch.tensor([r[1].numel()], device=dev, dtype=torch.float64)
         if world > 1:
             dist.all_reduce(n_cand)
-        deg = g.degree()
-        paths = int(deg[g.col[g.rowptr[c_lo]:g.rowptr[c_hi]].long()].sum().item())
+        paths = int(pc[c_hi - 1].item()) - base
+        del r
         fused = {"value": n_cand.item() * fsteps / fdt, "unit": "edges/s", "ms_per_step": fdt / fsteps * 1e3,
                  "candidates_per_step_all_ranks": int(n_cand.item()), "steps": fsteps,
-                 "two_hop_paths_rank0": paths,
-                 "what": "candidate generation (filter.py:96-109) + CN + AA for every candidate of the rank's column block, "
-                         "one fused expansion; host clock incl. count pass, cumsum, zero-fill, fill pass, fixed->float"}
+                 "columns_rank0": [c_lo, c_hi], "two_hop_paths_rank0": paths,
+                 "what": "candidate generation (filter.py:96-109) + CN + AA for every candidate of one production-sized "
+                         "column block (2^29 two-hop paths, heaviest column first), one fused expansion; host clock "
+                         "incl. count pass, cumsum, zero-fill, fill pass, finish kernel"}
 
     if rank == 0:
         n_cu, dev_name = ops.device_info()

@@ -108,8 +108,8 @@ __global__ __launch_bounds__(EX_THREADS) void expand_kernel(
     const float *__restrict__ node_w, int32_t v_lo, int32_t v_hi, const int32_t *__restrict__ col_order, int32_t wpt,
     unsigned int *__restrict__ next_col,
     int64_t *__restrict__ cand_count, const int64_t *__restrict__ colptr, int32_t *__restrict__ cand_u,
-    int32_t *__restrict__ cand_v, int32_t *__restrict__ out_cn, unsigned long long *__restrict__ out_acc,
-    float *__restrict__ out_score)
+    int32_t *__restrict__ cand_v, int32_t *__restrict__ out_cn, int32_t *__restrict__ out_cn_multi,
+    unsigned long long *__restrict__ out_acc, float *__restrict__ out_score)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const int words = wpt * EX_THREADS;
@@ -224,7 +224,7 @@ __global__ __launch_bounds__(EX_THREADS) void expand_kernel(
                         const bool only = !((multi[u >> 6] >> ((u >> 1) & 31)) & 1u);  // this path is the slot's only writer
                         if (out_cn) {
                             if (only) out_cn[slot] = 1;
-                            else atomicAdd(&out_cn[slot], 1);
+                            else atomicAdd(&out_cn_multi[slot], 1);
                         }
                         if (out_acc) {
                             float term = vw;              // A[u,w] * (A[v,w] * node_w[w]), float32 like the reference
@@ -246,11 +246,17 @@ __global__ __launch_bounds__(EX_THREADS) void expand_kernel(
     }
 }
 
-__global__ void fixed_to_float_kernel(const long long *__restrict__ acc, int64_t n, float *__restrict__ out)
+// Completes score[] / cn[] of a fill launch: slots reached by several paths hold their totals in the accumulator arrays.
+__global__ void expand_finish_kernel(const long long *__restrict__ acc, const int32_t *__restrict__ cn_multi, int64_t n,
+                                     float *__restrict__ score, int32_t *__restrict__ cn)
 {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
-        if (const long long a = acc[i]) out[i] = (float)((double)a * (1.0 / (double)(1ll << EX_FIXED_SHIFT)));
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        if (acc)
+            if (const long long a = acc[i]) score[i] = (float)((double)a * (1.0 / (double)(1ll << EX_FIXED_SHIFT)));
+        if (cn_multi)
+            if (const int32_t c = cn_multi[i]) cn[i] = c;
+    }
 }
 
 static int expand_words_per_thread(int64_t n_nodes)
@@ -288,7 +294,7 @@ extern "C" int eps_expand_count(const int64_t *rowptr, const int32_t *col, int64
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(EX_THREADS), lds, s, rowptr, col, (const float *)nullptr,
                        (const float *)nullptr, (int32_t)v_lo, (int32_t)v_hi, col_order, wpt, counter, cand_count,
                        (const int64_t *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr,
-                       (unsigned long long *)nullptr, (float *)nullptr);
+                       (int32_t *)nullptr, (unsigned long long *)nullptr, (float *)nullptr);
     EPS_CHECK_LAUNCH("eps_expand_count");
     return EPS_OK;
 }
@@ -296,12 +302,14 @@ extern "C" int eps_expand_count(const int64_t *rowptr, const int32_t *col, int64
 extern "C" int eps_expand_fill(const int64_t *rowptr, const int32_t *col, const float *val, const float *node_w,
                                int64_t n_nodes, int64_t v_lo, int64_t v_hi, const int32_t *col_order,
                                const int64_t *colptr, int32_t *cand_u,
-                               int32_t *cand_v, int32_t *cn, int64_t *acc, float *score, void *stream)
+                               int32_t *cand_v, int32_t *cn, int32_t *cn_multi, float *score, int64_t *score_multi,
+                               void *stream)
 {
     EPS_REQUIRE(n_nodes >= 0 && v_lo >= 0 && v_hi >= v_lo && v_hi <= n_nodes, "eps_expand_fill: bad column range");
     if (v_hi == v_lo) return EPS_OK;
     EPS_REQUIRE(rowptr && col && colptr && cand_u, "eps_expand_fill: null pointer");
-    EPS_REQUIRE((acc == nullptr) == (score == nullptr), "eps_expand_fill: acc and score go together");
+    EPS_REQUIRE((score_multi == nullptr) == (score == nullptr), "eps_expand_fill: score and score_multi go together");
+    EPS_REQUIRE((cn_multi == nullptr) == (cn == nullptr), "eps_expand_fill: cn and cn_multi go together");
     const int wpt = expand_words_per_thread(n_nodes);
     EPS_REQUIRE(wpt <= EX_MAX_WPT, "eps_expand_fill: %lld nodes exceed the LDS bitmap (max %d)",
                 (long long)n_nodes, eps_expand_max_nodes());
@@ -323,7 +331,7 @@ extern "C" int eps_expand_fill(const int64_t *rowptr, const int32_t *col, const 
         }                                                                                                              \
         hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(EX_THREADS), lds, s, rowptr, col, val, node_w,           \
                            (int32_t)v_lo, (int32_t)v_hi, col_order, wpt, counter, (int64_t *)nullptr, colptr, cand_u,  \
-                           cand_v, cn, (unsigned long long *)acc, score);                                              \
+                           cand_v, cn, cn_multi, (unsigned long long *)score_multi, score);                            \
     } while (0)
     if (hv && hw) EX_LAUNCH(true, true);
     else if (hv) EX_LAUNCH(true, false);
@@ -334,16 +342,18 @@ extern "C" int eps_expand_fill(const int64_t *rowptr, const int32_t *col, const 
     return EPS_OK;
 }
 
-extern "C" int eps_fixed_to_float(const int64_t *acc, int64_t n, float *out, void *stream)
+extern "C" int eps_expand_finish(const int64_t *score_multi, const int32_t *cn_multi, int64_t n, float *score, int32_t *cn,
+                                 void *stream)
 {
-    EPS_REQUIRE(n >= 0, "eps_fixed_to_float: negative size");
-    if (n == 0) return EPS_OK;
-    EPS_REQUIRE(acc && out, "eps_fixed_to_float: null pointer");
+    EPS_REQUIRE(n >= 0, "eps_expand_finish: negative size");
+    if (n == 0 || (!score_multi && !cn_multi)) return EPS_OK;
+    EPS_REQUIRE((score_multi == nullptr) == (score == nullptr) && (cn_multi == nullptr) == (cn == nullptr),
+                "eps_expand_finish: an accumulator array without its output (or the reverse)");
     int64_t b = (n + 255) / 256;
     const int64_t cap = (int64_t)eps_num_cus() * 8;
     if (b > cap) b = cap;
-    hipLaunchKernelGGL(fixed_to_float_kernel, dim3((unsigned)b), dim3(256), 0, (hipStream_t)stream, (const long long *)acc, n,
-                       out);
-    EPS_CHECK_LAUNCH("eps_fixed_to_float");
+    hipLaunchKernelGGL(expand_finish_kernel, dim3((unsigned)b), dim3(256), 0, (hipStream_t)stream,
+                       (const long long *)score_multi, cn_multi, n, score, cn);
+    EPS_CHECK_LAUNCH("eps_expand_finish");
     return EPS_OK;
 }

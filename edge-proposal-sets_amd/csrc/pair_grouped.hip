@@ -214,7 +214,6 @@ __global__ __launch_bounds__(PG_THREADS) void pair_scores_grouped_kernel(
             WT my_ws = 0;
             int my_qstart = 0, my_qcnt = 0;  // this lane's pair: its segment of the hit queue
             int qlen = 0;                    // wave-uniform
-            const int here = (c1 - g0) < 64 ? (int)(c1 - g0) : 64;
 
             // Resolve the queue: one parallel gather of node_w over all queued hits, then lane i adds up pair i's
             // segment in queue order.  ``open_j`` >= 0: pair open_j is still being tested (queue nearly full in the

@@ -160,15 +160,16 @@ def expand_candidates(rowptr, col, val, node_w, n_nodes: int, v_lo: int, v_hi: i
         cand_u = pairs[0]
         cand_v = pairs[1] if want_v else None
         cn = torch.zeros(total, dtype=torch.int32, device=dev) if want_cn else None
-        acc = torch.zeros(total, dtype=torch.int64, device=dev) if want_score else None
+        cn_multi = torch.zeros(total, dtype=torch.int32, device=dev) if want_cn else None
         score = torch.zeros(total, dtype=torch.float32, device=dev) if want_score else None
+        score_multi = torch.zeros(total, dtype=torch.int64, device=dev) if want_score else None
         if total:
             _lib.check(lib.eps_expand_fill(_ptr(rowptr), _ptr(col), _ptr(val), _ptr(node_w), n_nodes, v_lo, v_hi,
-                                           _ptr(col_order), _ptr(colptr), _ptr(cand_u), _ptr(cand_v), _ptr(cn), _ptr(acc), _ptr(score),
-                                           _stream(dev)),
+                                           _ptr(col_order), _ptr(colptr), _ptr(cand_u), _ptr(cand_v), _ptr(cn),
+                                           _ptr(cn_multi), _ptr(score), _ptr(score_multi), _stream(dev)),
                        "eps_expand_fill")
-        if want_score:
-            _lib.check(lib.eps_fixed_to_float(_ptr(acc), total, _ptr(score), _stream(dev)), "eps_fixed_to_float")
+            _lib.check(lib.eps_expand_finish(_ptr(score_multi), _ptr(cn_multi), total, _ptr(score), _ptr(cn),
+                                             _stream(dev)), "eps_expand_finish")
     out = ExpandResult((colptr, cand_u, cand_v, cn, score))
     out.pairs = pairs if want_v else None
     return out

@@ -102,21 +102,24 @@ int eps_pair_scores_grouped_f64(const int64_t *rowptr, const int32_t *col, const
  *   eps_expand_count: cand_count[v - v_lo] = number of 2-hop non-edges (u, v), v in [v_lo, v_hi).
  *   eps_expand_fill : colptr = exclusive prefix of cand_count (int64[n_cols+1], device); writes
  *                     cand_u (ascending inside a column == the reference's order), cand_v (column
- *                     id per candidate; optional), cn (int32 count; optional, ZEROED by the
- *                     caller) and the weighted sum (optional; acc AND score, both ZEROED by the
- *                     caller): a candidate reached by one path gets its float32 term in score
- *                     directly; the others accumulate in acc in 2^-40 fixed point -- integer
- *                     atomics make the result independent of the accumulation order.
- *   eps_fixed_to_float: score[i] = float32(acc[i] * 2^-40) wherever acc[i] != 0 (completes the
- *                     score array of eps_expand_fill; entries with acc[i] == 0 are left alone). */
+ *                     id per candidate; optional), and -- each optional, as a PAIR of arrays both
+ *                     ZEROED by the caller -- the common-neighbour count (cn, cn_multi) and the
+ *                     weighted sum (score, score_multi).  A candidate reached by exactly one path
+ *                     (most are) gets its result with a plain store into cn / score; the others
+ *                     accumulate with atomics in cn_multi / score_multi, the latter in 2^-40 fixed
+ *                     point: integer addition makes the sum independent of the arrival order.
+ *   eps_expand_finish: cn[i] = cn_multi[i] and score[i] = float32(score_multi[i] * 2^-40) wherever
+ *                     the accumulator entry is non-zero; completes the outputs of a fill launch. */
 int eps_expand_max_nodes(void);
 int eps_expand_count(const int64_t *rowptr, const int32_t *col, int64_t n_nodes, int64_t v_lo,
                      int64_t v_hi, const int32_t *col_order, int64_t *cand_count, void *stream);
 int eps_expand_fill(const int64_t *rowptr, const int32_t *col, const float *val,
                     const float *node_w, int64_t n_nodes, int64_t v_lo, int64_t v_hi,
-                    const int32_t *col_order, const int64_t *colptr, int32_t *cand_u, int32_t *cand_v, int32_t *cn,
-                    int64_t *acc, float *score, void *stream);
-int eps_fixed_to_float(const int64_t *acc, int64_t n, float *out, void *stream);
+                    const int32_t *col_order, const int64_t *colptr, int32_t *cand_u,
+                    int32_t *cand_v, int32_t *cn, int32_t *cn_multi, float *score,
+                    int64_t *score_multi, void *stream);
+int eps_expand_finish(const int64_t *score_multi, const int32_t *cn_multi, int64_t n, float *score,
+                      int32_t *cn, void *stream);
 
 /* ---- K4/K5: CSR x dense SpMM with fused epilogue -----------------------------------------
  * Replaces torch_sparse spmm_sum / spmm_mean inside GCNConv / SAGEConv (models.py:183-186,
