@@ -18,23 +18,35 @@
 //      reference's column-major order for free).
 //      Columns may be handed out in a caller-given order (heaviest first keeps the tail of a
 //      launch short: a hub column is one workgroup's work for milliseconds).
-//   D. score: walk the same paths again; a path whose u is a candidate adds its term to the
-//      candidate's slot.  Terms are accumulated in 64-bit FIXED POINT (2^-40): integer addition
-//      is associative, so the result is bit-reproducible whatever the arrival order (float
-//      atomics are not), and exact up to the final rounding to float32.  Most candidates are
-//      reached by ONE path (72% on the ppa-like graph): pass A records, in a second bitmap at
-//      half resolution, which ids were marked more than once, and a candidate outside it gets
-//      its term with a plain store (absorbed by the L2) instead of a memory-side atomic, which
-//      is ~5x slower per operation and bounds this pass.
+//   D. score: walk the same paths again; a path whose u is a candidate contributes its term to
+//      the candidate's slot.  Scattered global atomics are line read-modify-writes behind the
+//      L2 (~5x the cost of a plain store, which the L2 absorbs) and bounded this pass, so they
+//      are kept for the few paths that need them: two more LDS bitmaps over the column's
+//      candidate RANKS tell the first and the second path to reach a candidate (the value
+//      ds_or_rtn returns); the first stores its term into score[], the second into a scratch
+//      array, and only a third or later one (10 % of the paths on the ppa-like graph; 84 % of
+//      the candidates have one path, 11 % two) adds to a 64-bit accumulator.  The three kinds of
+//      slot live in separate arrays: a plain-stored dirty line and a memory-side atomic on the
+//      same line evict each other.  eps_expand_finish sums the three in 2^-40 FIXED POINT:
+//      integer addition is associative, so the result is bit-reproducible whatever the arrival
+//      order (float atomics are not), and exact up to the final rounding to float32.
 // Requires a SYMMETRIC adjacency (filter.py's always is: rank.py:33 to_symmetric) and
-// N <= 688,128 node ids (two bitmaps + the rank tables in the 160 KiB LDS: 7.5 bytes per 32
-// ids); the host falls back to the tensor-op expansion above that.
+//      The later paths of the hottest candidates (a pair of hubs has thousands of common
+//      neighbours; atomics on one address serialise) are summed in a small LDS table first.
+// N <= 786,432 node ids (bitmap + rank tables: 5.5 bytes per 32 ids of the 160 KiB LDS; what
+// is left holds the hot table and the two arrival bitmaps, at reduced resolution for columns
+// with more candidates than bits); the host falls back to the tensor-op expansion above that.
 #include "eps_common.h"
+
+#include <stdlib.h>
 
 #define EX_THREADS 1024
 #define EX_WAVES (EX_THREADS / 64)
 #define EX_FIXED_SHIFT 40
-#define EX_MAX_WPT 21       // bitmap words per thread: 21 * 1024 words * 7.5 B = 157.5 KiB (the rest is static LDS)
+#define EX_FILL_LDS 161792  // dynamic LDS of the fill kernel: 158 KiB (the rest of the 160 KiB is static LDS)
+#define EX_MAX_WPT 24       // bitmap words per thread: 24 * 1024 words * 5.5 B = 132 KiB; hot table 16 KiB; the rest: arrival bitmaps
+#define EX_HOT 1024         // entries of the per-column LDS table that absorbs the later paths of the hottest candidates
+#define EX_HOT_EMPTY 0xFFFFFFFFu
 
 
 __device__ __forceinline__ int wave_incl_scan(int x, int lane)
@@ -48,6 +60,11 @@ __device__ __forceinline__ int wave_incl_scan(int x, int lane)
 }
 
 typedef int v4i __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ long long ex_to_fixed(float x)
+{
+    return __double2ll_rn((double)x * (double)(1ll << EX_FIXED_SHIFT));
+}
 
 __device__ __forceinline__ int64_t ex_bcast64(int64_t x, int j)
 {
@@ -108,15 +125,20 @@ __global__ __launch_bounds__(EX_THREADS) void expand_kernel(
     const float *__restrict__ node_w, int32_t v_lo, int32_t v_hi, const int32_t *__restrict__ col_order, int32_t wpt,
     unsigned int *__restrict__ next_col,
     int64_t *__restrict__ cand_count, const int64_t *__restrict__ colptr, int32_t *__restrict__ cand_u,
-    int32_t *__restrict__ cand_v, int32_t *__restrict__ out_cn, int32_t *__restrict__ out_cn_multi,
-    unsigned long long *__restrict__ out_acc, float *__restrict__ out_score)
+    int32_t *__restrict__ cand_v, int32_t seen_words, int32_t *__restrict__ out_cn, int32_t *__restrict__ cn_second,
+    int32_t *__restrict__ cn_later, float *__restrict__ out_score, float *__restrict__ score_second,
+    unsigned long long *__restrict__ score_later)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const int words = wpt * EX_THREADS;
     uint32_t *bm = lds;                            // bit u: u is a 2-hop endpoint of the column
-    uint32_t *multi = lds + words;                 // FILL only.  bit u>>1: u or u^1 was marked more than once
-    uint32_t *base32 = multi + words / 2;          // rank of the first bit of every 8-word group
+    uint32_t *base32 = lds + words;                // FILL only from here.  rank of the first bit of every 8-word group
     uint8_t *pre8 = (uint8_t *)(base32 + words / 8);  // rank of a word's first bit within its group (<= 224)
+    unsigned long long *hot_acc = (unsigned long long *)(base32 + words / 8 + words / 4);  // 8-byte aligned: words % 1024 == 0
+    uint32_t *hot_key = (uint32_t *)(hot_acc + EX_HOT);  // candidate rank owning the entry
+    uint32_t *hot_cn = hot_key + EX_HOT;
+    uint32_t *seen = hot_cn + EX_HOT;                 // bit (rank >> shift): a path has reached this candidate
+    uint32_t *seen2 = seen + seen_words;              // ... and a second one
     __shared__ int s_wave_tot[EX_WAVES];
     __shared__ unsigned int s_col;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -124,8 +146,14 @@ __global__ __launch_bounds__(EX_THREADS) void expand_kernel(
 
     // the bitmap is all-zero between columns: every column clears exactly the words it scanned
     for (int i = tid; i < words; i += EX_THREADS) bm[i] = 0u;
-    if (FILL)
-        for (int i = tid; i < words / 2; i += EX_THREADS) multi[i] = 0u;
+    if (FILL) {
+        for (int i = tid; i < 2 * seen_words; i += EX_THREADS) seen[i] = 0u;
+        for (int i = tid; i < EX_HOT; i += EX_THREADS) {
+            hot_acc[i] = 0ull;
+            hot_key[i] = EX_HOT_EMPTY;
+            hot_cn[i] = 0u;
+        }
+    }
 
     for (;;) {
         __syncthreads();
@@ -146,12 +174,8 @@ __global__ __launch_bounds__(EX_THREADS) void expand_kernel(
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 if (e >= nvalid) continue;
-                const uint32_t u = (uint32_t)u4[e], bit = 1u << (u & 31);
-                if (!FILL) {
-                    atomicOr(&bm[u >> 5], bit);
-                } else if (atomicOr(&bm[u >> 5], bit) & bit) {   // seen before: more than one path ends here
-                    atomicOr(&multi[u >> 6], 1u << ((u >> 1) & 31));
-                }
+                const uint32_t u = (uint32_t)u4[e];
+                atomicOr(&bm[u >> 5], 1u << (u & 31));
             }
         });
         __syncthreads();
@@ -207,8 +231,22 @@ __global__ __launch_bounds__(EX_THREADS) void expand_kernel(
         }
         __syncthreads();
 
-        // ---- D. score: walk the paths again, add each term to its candidate's slot -------------------
-        if (out_acc || out_cn) {
+        // ---- D. score: walk the paths again, give each term to its candidate's slot -------------------
+        if (out_score || out_cn) {
+            // arrival bitmaps over the candidate ranks of this column; columns with more candidates than bits share a bit
+            // among 2^shift neighbouring ranks (an array still gets at most one plain store per bit, hence per slot)
+            const int ncand = total;
+            int shift = 0;
+            while ((ncand >> shift) >= seen_words * 32) ++shift;
+            if (shift > 0) {
+                // with shared bits a candidate's first path may be taken for a second one, and cn[] / score[] (which
+                // the caller does not zero: normally every slot is stored once) would keep a slot unwritten
+                for (int i = tid; i < ncand; i += EX_THREADS) {
+                    if (out_cn) out_cn[base_off + i] = 0;
+                    if (out_score) out_score[base_off + i] = 0.0f;
+                }
+                __syncthreads();
+            }
             for_each_path(rowptr, col, vcol, dv, wib, lane, [&](int k, int64_t wb, int base, v4i u4, int nvalid) {
                 if (nvalid == 0) return;
                 float vw = 1.0f;                          // A[v,w] * node_w[w]: the A_ entry (adamic_utils.py:17)
@@ -220,42 +258,70 @@ __global__ __launch_bounds__(EX_THREADS) void expand_kernel(
                     const uint32_t u = (uint32_t)u4[e];
                     const uint32_t word = bm[u >> 5];
                     if ((word >> (u & 31)) & 1u) {
-                        const int64_t slot = base_off + base32[u >> 8] + pre8[u >> 5] + __popc(word & ((1u << (u & 31)) - 1u));
-                        const bool only = !((multi[u >> 6] >> ((u >> 1) & 31)) & 1u);  // this path is the slot's only writer
-                        if (out_cn) {
-                            if (only) out_cn[slot] = 1;
-                            else atomicAdd(&out_cn_multi[slot], 1);
+                        const uint32_t rank = base32[u >> 8] + pre8[u >> 5] + __popc(word & ((1u << (u & 31)) - 1u));
+                        const int64_t slot = base_off + rank;
+                        const uint32_t sb = rank >> shift, sbit = 1u << (sb & 31);
+                        int arrival = 2;
+                        if (!(atomicOr(&seen[sb >> 5], sbit) & sbit)) arrival = 0;
+                        else if (!(atomicOr(&seen2[sb >> 5], sbit) & sbit)) arrival = 1;
+                        // Third and later paths: the candidates with the longest chains (a hub pair has thousands of
+                        // common neighbours, and atomics on ONE address serialise at the memory side) come back in
+                        // almost every row, so they are the first to ask for an entry of the LDS table and keep it for
+                        // the column; a candidate that finds its entry taken uses the global accumulator throughout.
+                        uint32_t h = 0;
+                        bool hot = false;
+                        if (arrival == 2) {
+                            h = (rank * 2654435761u) >> 22;
+                            const uint32_t owner = atomicCAS(&hot_key[h], EX_HOT_EMPTY, rank);
+                            hot = owner == EX_HOT_EMPTY || owner == rank;
                         }
-                        if (out_acc) {
+                        if (out_cn) {
+                            if (arrival == 0) out_cn[slot] = 1;
+                            else if (arrival == 1) cn_second[slot] = 1;
+                            else if (hot) atomicAdd(&hot_cn[h], 1u);
+                            else atomicAdd(&cn_later[slot], 1);
+                        }
+                        if (out_score) {
                             float term = vw;              // A[u,w] * (A[v,w] * node_w[w]), float32 like the reference
                             if (HAS_VAL) term = val[wb + base + e] * vw;
-                            if (only) {
-                                out_score[slot] = term;   // the whole sum: no accumulator traffic at all
-                            } else {
-                                const long long fx = __double2ll_rn((double)term * (double)(1ll << EX_FIXED_SHIFT));
-                                atomicAdd(&out_acc[slot], (unsigned long long)fx);
-                            }
+                            if (arrival == 0) out_score[slot] = term;
+                            else if (arrival == 1) score_second[slot] = term;
+                            else if (hot) atomicAdd(&hot_acc[h], (unsigned long long)ex_to_fixed(term));
+                            else atomicAdd(&score_later[slot], (unsigned long long)ex_to_fixed(term));
                         }
                     }
                 }
             });
             __syncthreads();
+            for (int i = tid; i <= (ncand >> shift) / 32; i += EX_THREADS) seen[i] = seen2[i] = 0u;
+            for (int i = tid; i < EX_HOT; i += EX_THREADS) {  // the owner of an entry is the only writer of its slot
+                const uint32_t r = hot_key[i];
+                if (r != EX_HOT_EMPTY) {
+                    if (out_score) score_later[base_off + r] = hot_acc[i];
+                    if (out_cn) cn_later[base_off + r] = (int32_t)hot_cn[i];
+                    hot_acc[i] = 0ull;
+                    hot_key[i] = EX_HOT_EMPTY;
+                    hot_cn[i] = 0u;
+                }
+            }
         }
         for (int i = 0; i < wpt; ++i) bm[w0 + i] = 0u;
-        for (int i = tid; i < words / 2; i += EX_THREADS) multi[i] = 0u;
     }
 }
 
-// Completes score[] / cn[] of a fill launch: slots reached by several paths hold their totals in the accumulator arrays.
-__global__ void expand_finish_kernel(const long long *__restrict__ acc, const int32_t *__restrict__ cn_multi, int64_t n,
-                                     float *__restrict__ score, int32_t *__restrict__ cn)
+// Completes score[] / cn[] of a fill launch: adds what the second and the later paths of a candidate left in the scratch
+// arrays.  Every term goes through the same fixed-point conversion, so the sum does not depend on which path came first.
+__global__ void expand_finish_kernel(int64_t n, int32_t *__restrict__ cn, const int32_t *__restrict__ cn_second,
+                                     const int32_t *__restrict__ cn_later, float *__restrict__ score,
+                                     const float *__restrict__ score_second, const long long *__restrict__ score_later)
 {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        if (acc)
-            if (const long long a = acc[i]) score[i] = (float)((double)a * (1.0 / (double)(1ll << EX_FIXED_SHIFT)));
-        if (cn_multi)
-            if (const int32_t c = cn_multi[i]) cn[i] = c;
+        if (score) {
+            const long long t = ex_to_fixed(score[i]) + ex_to_fixed(score_second[i]) + score_later[i];
+            score[i] = (float)((double)t * (1.0 / (double)(1ll << EX_FIXED_SHIFT)));
+        }
+        if (cn) cn[i] = cn[i] + cn_second[i] + cn_later[i];
     }
 }
 
@@ -267,8 +333,40 @@ static int expand_words_per_thread(int64_t n_nodes)
 
 extern "C" int eps_expand_max_nodes(void) { return EX_MAX_WPT * EX_THREADS * 32; }
 
-// LDS bytes of the fill kernel: bitmap 4 B + half-resolution bitmap 2 B + group bases 0.5 B + byte ranks 1 B per word.
-static size_t expand_fill_lds(int wpt) { return (size_t)wpt * EX_THREADS * 15 / 2; }
+// The fill kernel always takes EX_FILL_LDS bytes: bitmap 4 B + group bases 0.5 B + byte ranks 1 B per word, the hot
+// table (16 B per entry), and the two arrival bitmaps share what is left.
+static int expand_seen_words(int wpt) { return (int)((EX_FILL_LDS - (size_t)wpt * EX_THREADS * 11 / 2 - EX_HOT * 16) / 8); }
+
+// Scratch layout behind eps_expand_workspace_bytes: [score_later i64 x n][score_second f32 x n] then
+// [cn_second i32 x n][cn_later i32 x n], each part only when requested.
+struct ExpandScratch {
+    long long *score_later = nullptr;
+    float *score_second = nullptr;
+    int32_t *cn_second = nullptr, *cn_later = nullptr;
+};
+static ExpandScratch expand_scratch(void *workspace, int64_t n, bool want_cn, bool want_score)
+{
+    ExpandScratch w;
+    char *p = (char *)workspace;
+    if (want_score) {
+        w.score_later = (long long *)p;
+        p += n * 8;
+        w.score_second = (float *)p;
+        p += n * 4;
+    }
+    if (want_cn) {
+        w.cn_second = (int32_t *)p;
+        p += n * 4;
+        w.cn_later = (int32_t *)p;
+    }
+    return w;
+}
+
+extern "C" int64_t eps_expand_workspace_bytes(int64_t n_cand, int want_cn, int want_score)
+{
+    if (n_cand < 0) return 0;
+    return n_cand * ((want_score ? 12 : 0) + (want_cn ? 8 : 0));
+}
 
 extern "C" int eps_expand_count(const int64_t *rowptr, const int32_t *col, int64_t n_nodes, int64_t v_lo, int64_t v_hi,
                                 const int32_t *col_order, int64_t *cand_count, void *stream)
@@ -293,23 +391,23 @@ extern "C" int eps_expand_count(const int64_t *rowptr, const int32_t *col, int64
     if (blocks > v_hi - v_lo) blocks = v_hi - v_lo;
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(EX_THREADS), lds, s, rowptr, col, (const float *)nullptr,
                        (const float *)nullptr, (int32_t)v_lo, (int32_t)v_hi, col_order, wpt, counter, cand_count,
-                       (const int64_t *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr,
-                       (int32_t *)nullptr, (unsigned long long *)nullptr, (float *)nullptr);
+                       (const int64_t *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr, 0, (int32_t *)nullptr,
+                       (int32_t *)nullptr, (int32_t *)nullptr, (float *)nullptr, (float *)nullptr,
+                       (unsigned long long *)nullptr);
     EPS_CHECK_LAUNCH("eps_expand_count");
     return EPS_OK;
 }
 
 extern "C" int eps_expand_fill(const int64_t *rowptr, const int32_t *col, const float *val, const float *node_w,
                                int64_t n_nodes, int64_t v_lo, int64_t v_hi, const int32_t *col_order,
-                               const int64_t *colptr, int32_t *cand_u,
-                               int32_t *cand_v, int32_t *cn, int32_t *cn_multi, float *score, int64_t *score_multi,
-                               void *stream)
+                               const int64_t *colptr, int64_t n_cand, int32_t *cand_u, int32_t *cand_v, int32_t *cn,
+                               float *score, void *workspace, void *stream)
 {
     EPS_REQUIRE(n_nodes >= 0 && v_lo >= 0 && v_hi >= v_lo && v_hi <= n_nodes, "eps_expand_fill: bad column range");
     if (v_hi == v_lo) return EPS_OK;
-    EPS_REQUIRE(rowptr && col && colptr && cand_u, "eps_expand_fill: null pointer");
-    EPS_REQUIRE((score_multi == nullptr) == (score == nullptr), "eps_expand_fill: score and score_multi go together");
-    EPS_REQUIRE((cn_multi == nullptr) == (cn == nullptr), "eps_expand_fill: cn and cn_multi go together");
+    EPS_REQUIRE(rowptr && col && colptr && cand_u && n_cand >= 0, "eps_expand_fill: null pointer");
+    EPS_REQUIRE(workspace || !(cn || score) || n_cand == 0, "eps_expand_fill: cn / score need the zeroed workspace");
+    EPS_REQUIRE(((uintptr_t)workspace & 7) == 0, "eps_expand_fill: workspace must be 8-byte aligned");
     const int wpt = expand_words_per_thread(n_nodes);
     EPS_REQUIRE(wpt <= EX_MAX_WPT, "eps_expand_fill: %lld nodes exceed the LDS bitmap (max %d)",
                 (long long)n_nodes, eps_expand_max_nodes());
@@ -317,7 +415,13 @@ extern "C" int eps_expand_fill(const int64_t *rowptr, const int32_t *col, const 
     unsigned int *counter = nullptr;
     int rc = eps_take_counter(&counter, s, "eps_expand_fill");
     if (rc) return rc;
-    const size_t lds = expand_fill_lds(wpt);
+    const size_t lds = EX_FILL_LDS;
+    int seen_words = expand_seen_words(wpt);
+    if (const char *dbg = getenv("EPS_DEBUG_SEEN_WORDS")) {  // tests: force the shared-bit path on small graphs
+        const int v = atoi(dbg);
+        if (v >= 1 && v < seen_words) seen_words = v;
+    }
+    const ExpandScratch ws = expand_scratch(workspace, n_cand, cn != nullptr, score != nullptr);
     int64_t blocks = eps_num_cus();
     if (blocks > v_hi - v_lo) blocks = v_hi - v_lo;
     const bool hv = val != nullptr, hw = node_w != nullptr;
@@ -331,7 +435,8 @@ extern "C" int eps_expand_fill(const int64_t *rowptr, const int32_t *col, const 
         }                                                                                                              \
         hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(EX_THREADS), lds, s, rowptr, col, val, node_w,           \
                            (int32_t)v_lo, (int32_t)v_hi, col_order, wpt, counter, (int64_t *)nullptr, colptr, cand_u,  \
-                           cand_v, cn, cn_multi, (unsigned long long *)score_multi, score);                            \
+                           cand_v, seen_words, cn, ws.cn_second, ws.cn_later, score, ws.score_second,                  \
+                           (unsigned long long *)ws.score_later);                                                      \
     } while (0)
     if (hv && hw) EX_LAUNCH(true, true);
     else if (hv) EX_LAUNCH(true, false);
@@ -342,18 +447,18 @@ extern "C" int eps_expand_fill(const int64_t *rowptr, const int32_t *col, const 
     return EPS_OK;
 }
 
-extern "C" int eps_expand_finish(const int64_t *score_multi, const int32_t *cn_multi, int64_t n, float *score, int32_t *cn,
-                                 void *stream)
+extern "C" int eps_expand_finish(int64_t n_cand, int32_t *cn, float *score, const void *workspace, void *stream)
 {
-    EPS_REQUIRE(n >= 0, "eps_expand_finish: negative size");
-    if (n == 0 || (!score_multi && !cn_multi)) return EPS_OK;
-    EPS_REQUIRE((score_multi == nullptr) == (score == nullptr) && (cn_multi == nullptr) == (cn == nullptr),
-                "eps_expand_finish: an accumulator array without its output (or the reverse)");
-    int64_t b = (n + 255) / 256;
+    EPS_REQUIRE(n_cand >= 0, "eps_expand_finish: negative size");
+    if (n_cand == 0 || (!cn && !score)) return EPS_OK;
+    EPS_REQUIRE(workspace, "eps_expand_finish: null workspace");
+    const ExpandScratch ws = expand_scratch((void *)workspace, n_cand, cn != nullptr, score != nullptr);
+    int64_t b = (n_cand + 255) / 256;
     const int64_t cap = (int64_t)eps_num_cus() * 8;
     if (b > cap) b = cap;
-    hipLaunchKernelGGL(expand_finish_kernel, dim3((unsigned)b), dim3(256), 0, (hipStream_t)stream,
-                       (const long long *)score_multi, cn_multi, n, score, cn);
+    hipLaunchKernelGGL(expand_finish_kernel, dim3((unsigned)b), dim3(256), 0, (hipStream_t)stream, n_cand, cn,
+                       (const int32_t *)ws.cn_second, (const int32_t *)ws.cn_later, score, (const float *)ws.score_second,
+                       (const long long *)ws.score_later);
     EPS_CHECK_LAUNCH("eps_expand_finish");
     return EPS_OK;
 }

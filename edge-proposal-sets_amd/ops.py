@@ -129,6 +129,26 @@ def expand_max_nodes() -> int:
     return int(_lib.load().eps_expand_max_nodes())
 
 
+_EXPAND_WS = {}
+
+
+def _expand_scratch(dev, n_words: int) -> torch.Tensor:
+    """Zeroed int64[n_words] scratch of the fill / finish pair: one grow-only buffer per device, reused by every block
+    of a filter run (a fresh multi-GB allocation per block costs more than zeroing it).  Stream-ordered like any other
+    tensor on the current stream (the next block's zero-fill is queued behind the previous block's finish kernel), so
+    expansions of one device must not run concurrently on several streams."""
+    key = (dev.type, dev.index)
+    buf = _EXPAND_WS.get(key)
+    if buf is None or buf.numel() < n_words:
+        _EXPAND_WS.pop(key, None)
+        buf = None                                   # let the old buffer go before the larger one is allocated
+        buf = torch.empty(int(n_words * 1.25) + 1024, dtype=torch.int64, device=dev)
+        _EXPAND_WS[key] = buf
+    ws = buf[:n_words]
+    ws.zero_()
+    return ws
+
+
 class ExpandResult(tuple):
     """(colptr, cand_u, cand_v, cn, score) of ``expand_candidates``; ``.pairs`` is the int32 [2,E] buffer cand_u and
     cand_v are rows of (None without cand_v), so the (u; v) list exists without a copy."""
@@ -159,17 +179,18 @@ def expand_candidates(rowptr, col, val, node_w, n_nodes: int, v_lo: int, v_hi: i
         pairs = torch.empty((2 if want_v else 1, total), dtype=torch.int32, device=dev)
         cand_u = pairs[0]
         cand_v = pairs[1] if want_v else None
-        cn = torch.zeros(total, dtype=torch.int32, device=dev) if want_cn else None
-        cn_multi = torch.zeros(total, dtype=torch.int32, device=dev) if want_cn else None
-        score = torch.zeros(total, dtype=torch.float32, device=dev) if want_score else None
-        score_multi = torch.zeros(total, dtype=torch.int64, device=dev) if want_score else None
+        # cn / score are written for every candidate by the first path that reaches it: no zero-fill; the scratch
+        # of the second / later paths must start at zero
+        cn = torch.empty(total, dtype=torch.int32, device=dev) if want_cn else None
+        score = torch.empty(total, dtype=torch.float32, device=dev) if want_score else None
+        ws_bytes = int(lib.eps_expand_workspace_bytes(total, int(want_cn), int(want_score)))
+        ws = _expand_scratch(dev, (ws_bytes + 7) // 8) if ws_bytes else None
         if total:
             _lib.check(lib.eps_expand_fill(_ptr(rowptr), _ptr(col), _ptr(val), _ptr(node_w), n_nodes, v_lo, v_hi,
-                                           _ptr(col_order), _ptr(colptr), _ptr(cand_u), _ptr(cand_v), _ptr(cn),
-                                           _ptr(cn_multi), _ptr(score), _ptr(score_multi), _stream(dev)),
-                       "eps_expand_fill")
-            _lib.check(lib.eps_expand_finish(_ptr(score_multi), _ptr(cn_multi), total, _ptr(score), _ptr(cn),
-                                             _stream(dev)), "eps_expand_finish")
+                                           _ptr(col_order), _ptr(colptr), total, _ptr(cand_u), _ptr(cand_v), _ptr(cn),
+                                           _ptr(score), _ptr(ws), _stream(dev)), "eps_expand_fill")
+            _lib.check(lib.eps_expand_finish(total, _ptr(cn), _ptr(score), _ptr(ws), _stream(dev)),
+                       "eps_expand_finish")
     out = ExpandResult((colptr, cand_u, cand_v, cn, score))
     out.pairs = pairs if want_v else None
     return out

@@ -100,26 +100,29 @@ int eps_pair_scores_grouped_f64(const int64_t *rowptr, const int32_t *col, const
  *                     columns v_lo + col_order[i] are handed to the workgroups.  Results do not
  *                     depend on it; heaviest-first shortens the tail of a launch.
  *   eps_expand_count: cand_count[v - v_lo] = number of 2-hop non-edges (u, v), v in [v_lo, v_hi).
- *   eps_expand_fill : colptr = exclusive prefix of cand_count (int64[n_cols+1], device); writes
- *                     cand_u (ascending inside a column == the reference's order), cand_v (column
- *                     id per candidate; optional), and -- each optional, as a PAIR of arrays both
- *                     ZEROED by the caller -- the common-neighbour count (cn, cn_multi) and the
- *                     weighted sum (score, score_multi).  A candidate reached by exactly one path
- *                     (most are) gets its result with a plain store into cn / score; the others
- *                     accumulate with atomics in cn_multi / score_multi, the latter in 2^-40 fixed
- *                     point: integer addition makes the sum independent of the arrival order.
- *   eps_expand_finish: cn[i] = cn_multi[i] and score[i] = float32(score_multi[i] * 2^-40) wherever
- *                     the accumulator entry is non-zero; completes the outputs of a fill launch. */
+ *   eps_expand_fill : colptr = exclusive prefix of cand_count (int64[n_cols+1], device), n_cand =
+ *                     its last entry; writes cand_u (ascending inside a column == the reference's
+ *                     order), cand_v (column id per candidate; optional) and, each optional, the
+ *                     common-neighbour count cn (int32) and the weighted sum score (float32).
+ *                     cn / score need `workspace`: eps_expand_workspace_bytes(n_cand, cn != NULL,
+ *                     score != NULL) bytes, 8-byte aligned, ZEROED by the caller.  The first path
+ *                     that reaches a candidate stores into cn / score, the second into the
+ *                     workspace, later ones add to 64-bit accumulators there (few paths need the
+ *                     atomics, which are what bounds the pass).
+ *   eps_expand_finish: completes cn / score from the workspace of the fill launch (same n_cand and
+ *                     the same cn / score pointers).  Scores are summed in 2^-40 fixed point:
+ *                     integer addition makes the result independent of the arrival order. */
 int eps_expand_max_nodes(void);
 int eps_expand_count(const int64_t *rowptr, const int32_t *col, int64_t n_nodes, int64_t v_lo,
                      int64_t v_hi, const int32_t *col_order, int64_t *cand_count, void *stream);
 int eps_expand_fill(const int64_t *rowptr, const int32_t *col, const float *val,
                     const float *node_w, int64_t n_nodes, int64_t v_lo, int64_t v_hi,
-                    const int32_t *col_order, const int64_t *colptr, int32_t *cand_u,
-                    int32_t *cand_v, int32_t *cn, int32_t *cn_multi, float *score,
-                    int64_t *score_multi, void *stream);
-int eps_expand_finish(const int64_t *score_multi, const int32_t *cn_multi, int64_t n, float *score,
-                      int32_t *cn, void *stream);
+                    const int32_t *col_order, const int64_t *colptr, int64_t n_cand,
+                    int32_t *cand_u, int32_t *cand_v, int32_t *cn, float *score, void *workspace,
+                    void *stream);
+int64_t eps_expand_workspace_bytes(int64_t n_cand, int want_cn, int want_score);
+int eps_expand_finish(int64_t n_cand, int32_t *cn, float *score, const void *workspace,
+                      void *stream);
 
 /* ---- K4/K5: CSR x dense SpMM with fused epilogue -----------------------------------------
  * Replaces torch_sparse spmm_sum / spmm_mean inside GCNConv / SAGEConv (models.py:183-186,

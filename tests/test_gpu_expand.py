@@ -93,3 +93,40 @@ def test_expand_rejects_oversized_id_space(eps, dev):
     rp = torch.zeros(n + 1, dtype=torch.int64, device=dev)
     with pytest.raises(eps.EpsError):
         eps.ops.expand_candidates(rp, torch.zeros(0, dtype=torch.int32, device=dev), None, None, n, 0, 10)
+
+
+def _dense_symmetric(n, p, seed, weighted):
+    import scipy.sparse as ssp
+    rng = np.random.default_rng(seed)
+    m = np.triu(rng.random((n, n)) < p, 1)
+    vals = (rng.integers(1, 5, (n, n)).astype(np.float32) if weighted else np.ones((n, n), np.float32)) * m
+    A = ssp.csr_matrix(vals + vals.T)
+    A.sort_indices()
+    return A
+
+
+@pytest.mark.parametrize("weighted", [False, True])
+def test_expand_dense_graph_many_paths_per_candidate(eps, oracle, dev, weighted):
+    """ddi-like density: every candidate is reached by dozens of paths, so nearly all terms take the third-and-later
+    route (LDS table of the hottest candidates + global accumulators for the rest)."""
+    A = _dense_symmetric(700, 0.12, 21, weighted)
+    n_cand = _check(eps, oracle, dev, A, weighted=weighted)
+    assert n_cand > 300_000
+
+
+def test_expand_arrival_bitmaps_shared_bits(eps, oracle, dev, monkeypatch):
+    """Columns with more candidates than arrival bits share one bit among neighbouring ranks: the classification of
+    first / second / later paths turns conservative but every slot still has one plain writer per array.  Forced here
+    with a 2-word bitmap (64 bits for ~600 candidates per column) and checked against the full-resolution result."""
+    from eps_amd.heuristics import node_weight_table
+    A = _dense_symmetric(700, 0.05, 22, True)
+    g = eps.CSRGraph.from_scipy(A, device=dev)
+    wt = node_weight_table(g, eps.ops.W_AA)
+    full = eps.ops.expand_candidates(g.rowptr, g.col, g.val, wt, g.n_rows, 0, g.n_rows)
+    for words in ("1", "2", "7"):
+        monkeypatch.setenv("EPS_DEBUG_SEEN_WORDS", words)
+        got = eps.ops.expand_candidates(g.rowptr, g.col, g.val, wt, g.n_rows, 0, g.n_rows)
+        for i in range(5):
+            assert torch.equal(full[i], got[i]), (words, i)
+    monkeypatch.delenv("EPS_DEBUG_SEEN_WORDS")
+    _check(eps, oracle, dev, A, weighted=True)
