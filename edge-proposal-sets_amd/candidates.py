@@ -64,6 +64,39 @@ def heaviest_first(g: CSRGraph, v_lo: int, v_hi: int) -> torch.Tensor:
     return torch.argsort(path_counts(g)[v_lo:v_hi], descending=True, stable=True).to(torch.int32)
 
 
+class ColumnBlock:
+    """Candidates of the columns [v_lo, v_hi) in column-major order WITHOUT a materialised v array: candidate i has
+    u = cand_u[i] and v = v_lo + (the column whose colptr range holds i).  The filter stage only ever needs the pairs
+    of the few candidates that survive the top-K cut, so the expansion kernel skips one scattered 4-byte store per
+    candidate and the block is 4 bytes per candidate smaller."""
+
+    def __init__(self, v_lo: int, colptr: torch.Tensor, cand_u: torch.Tensor, cn, score):
+        self.v_lo, self.colptr, self.cand_u, self.cn, self.score = v_lo, colptr, cand_u, cn, score
+
+    def numel(self) -> int:
+        return self.cand_u.numel()
+
+    def select(self, idx: torch.Tensor) -> torch.Tensor:
+        """int64 [2, len(idx)] pairs (u; v) of the candidates ``idx`` (positions in the block)."""
+        v = torch.searchsorted(self.colptr[1:], idx, right=True) + self.v_lo
+        return torch.stack([self.cand_u[idx].long(), v])
+
+    def pairs(self) -> torch.Tensor:
+        """All pairs, int64 [2, E] (small graphs / the unsorted full-list path)."""
+        counts = self.colptr[1:] - self.colptr[:-1]
+        v = torch.repeat_interleave(torch.arange(self.v_lo, self.v_lo + counts.numel(), device=counts.device), counts)
+        return torch.stack([self.cand_u.long(), v])
+
+
+def expand_block_lazy(g: CSRGraph, v_lo: int, v_hi: int, node_w: Optional[torch.Tensor] = None, want_cn: bool = False,
+                      want_score: bool = False) -> ColumnBlock:
+    """``expand_block`` for consumers that read the pairs of a few candidates only (HIP expansion required)."""
+    from . import ops
+    r = ops.expand_candidates(g.rowptr, g.col, g.val, node_w, g.n_rows, v_lo, v_hi, want_cn=want_cn,
+                              want_score=want_score, want_v=False, col_order=heaviest_first(g, v_lo, v_hi))
+    return ColumnBlock(v_lo, r[0], r[1], r[3], r[4])
+
+
 def expand_block(g: CSRGraph, v_lo: int, v_hi: int, node_w: Optional[torch.Tensor] = None, want_cn: bool = False,
                  want_score: bool = False, long_pairs: bool = True):
     """Candidates of columns [v_lo, v_hi) of a SYMMETRIC adjacency, with (optionally) the common-neighbour count

@@ -43,7 +43,8 @@
 #define EX_THREADS 1024
 #define EX_WAVES (EX_THREADS / 64)
 #define EX_FIXED_SHIFT 40
-#define EX_FILL_LDS 161792  // dynamic LDS of the fill kernel: 158 KiB (the rest of the 160 KiB is static LDS)
+#define EX_FILL_LDS 157696  // dynamic LDS of the fill kernel: 154 KiB (the rest of the 160 KiB is static LDS)
+#define EX_LONGQ 1024       // rows longer than one unit queued per column and pass (static LDS)
 #define EX_MAX_WPT 24       // bitmap words per thread: 24 * 1024 words * 5.5 B = 132 KiB; hot table 16 KiB; the rest: arrival bitmaps
 #define EX_HOT 1024         // entries of the per-column LDS table that absorbs the later paths of the hottest candidates
 #define EX_HOT_EMPTY 0xFFFFFFFFu
@@ -73,14 +74,20 @@ __device__ __forceinline__ int64_t ex_bcast64(int64_t x, int j)
     return ((int64_t)hi << 32) | (uint32_t)lo;
 }
 
-// Walk the 2-hop paths v - w - u of one column for this wave's share of N(v) (rows k = wib, wib+16, ...).
-// The row descriptors of up to 64 of the wave's rows are fetched lane-parallel (w, rowptr[w], rowptr[w+1]: one
-// latency for the batch instead of a dependent chain per row), and the first 256 entries of the next row are in
-// flight (16-byte raw buffer loads: out-of-range lanes read 0, no bounds branch) while the current row is consumed.
+// Walk the 2-hop paths v - w - u of one column, all 16 waves of the workgroup together.
+// A "unit" is 256 consecutive entries of one row (one 16-byte load per lane) and costs about the same whatever it
+// holds, so the work is balanced in units: wave i takes the FIRST unit of rows i, i+16, ... -- the row descriptors
+// (w, rowptr[w], rowptr[w+1]) of up to 64 of its rows fetched lane-parallel (one latency for the batch instead of a
+// dependent chain per row), the next row's unit in flight while the current one is consumed (raw buffer loads:
+// out-of-range lanes read 0, no bounds branch) -- and the rows longer than one unit are queued in LDS; after a barrier
+// their remaining units are dealt round-robin over the waves.  (Row lengths are heavy-tailed: with whole rows per wave
+// the waves of a workgroup waited at the closing barrier for a third of the pass.)
 // body(k, wb, base, u4, nvalid): entries [base, base+nvalid) of row w = vcol[k] (nvalid in 0..4 per lane).
+// Ends with a workgroup barrier; the next call must be separated from this one by another barrier.
 template <typename Body>
 __device__ __forceinline__ void for_each_path(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col,
-                                              const int32_t *__restrict__ vcol, int32_t dv, int wib, int lane, Body body)
+                                              const int32_t *__restrict__ vcol, int32_t dv, int wib, int lane,
+                                              int *s_long, int *s_nlong, Body body)
 {
     for (int b0 = wib; b0 < dv; b0 += EX_WAVES * 64) {
         const int k_mine = b0 + EX_WAVES * lane;
@@ -108,16 +115,70 @@ __device__ __forceinline__ void for_each_path(const int64_t *__restrict__ rowptr
             const int k = b0 + EX_WAVES * j;
             int nv = dw - 4 * lane;
             body(k, wb, 4 * lane, cur, nv < 0 ? 0 : (nv > 4 ? 4 : nv));
-            for (int e0 = 256; e0 < dw; e0 += 512) {  // long rows: two more loads in flight per trip
-                const v4i x0 = __builtin_amdgcn_raw_buffer_load_b128(rj, lane * 16 + e0 * 4, 0, 0);
-                const v4i x1 = __builtin_amdgcn_raw_buffer_load_b128(rj, lane * 16 + e0 * 4 + 1024, 0, 0);
-                int n0 = dw - e0 - 4 * lane, n1 = n0 - 256;
-                body(k, wb, e0 + 4 * lane, x0, n0 < 0 ? 0 : (n0 > 4 ? 4 : n0));
-                if (e0 + 256 < dw) body(k, wb, e0 + 256 + 4 * lane, x1, n1 < 0 ? 0 : (n1 > 4 ? 4 : n1));
+            if (dw > 256) {
+                int q = 0;
+                if (lane == 0) q = atomicAdd(s_nlong, 1);
+                q = __builtin_amdgcn_readfirstlane(q);
+                if (q < EX_LONGQ) {
+                    if (lane == 0) s_long[q] = k;
+                } else {  // queue full (a hub column with thousands of long rows): finish this row here
+                    for (int e0 = 256; e0 < dw; e0 += 512) {
+                        const v4i x0 = __builtin_amdgcn_raw_buffer_load_b128(rj, lane * 16 + e0 * 4, 0, 0);
+                        const v4i x1 = __builtin_amdgcn_raw_buffer_load_b128(rj, lane * 16 + e0 * 4 + 1024, 0, 0);
+                        int n0 = dw - e0 - 4 * lane, n1 = n0 - 256;
+                        body(k, wb, e0 + 4 * lane, x0, n0 < 0 ? 0 : (n0 > 4 ? 4 : n0));
+                        if (e0 + 256 < dw) body(k, wb, e0 + 256 + 4 * lane, x1, n1 < 0 ? 0 : (n1 > 4 ? 4 : n1));
+                    }
+                }
             }
         }
     }
+    __syncthreads();
+    // the units past the first one of the queued rows: unit c of queue entry i belongs to wave (c + i) & 15
+    const int nl = *s_nlong < EX_LONGQ ? *s_nlong : EX_LONGQ;
+    for (int q0 = 0; q0 < nl; q0 += 64) {
+        const bool ok = q0 + lane < nl;
+        const int k_mine = ok ? s_long[q0 + lane] : 0;
+        const int32_t w_mine = vcol[k_mine];
+        const int64_t wb_mine = rowptr[w_mine];
+        const int32_t dw_mine = ok ? (int32_t)(rowptr[w_mine + 1] - wb_mine) : 0;
+        const int n = nl - q0 < 64 ? nl - q0 : 64;
+        for (int j = 0; j < n; ++j) {
+            const int32_t dw = __builtin_amdgcn_readlane(dw_mine, j);
+            const int64_t wb = ex_bcast64(wb_mine, j);
+            const int k = __builtin_amdgcn_readlane(k_mine, j);
+            int c0 = (wib - (q0 + j)) & (EX_WAVES - 1);
+            if (c0 == 0) c0 = EX_WAVES;
+            if (c0 * 256 >= dw) continue;
+            const __amdgpu_buffer_rsrc_t rj = __builtin_amdgcn_make_buffer_rsrc((void *)(col + wb), 0, dw * 4, 0x00020000);
+            for (int e0 = c0 * 256; e0 < dw; e0 += 2 * EX_WAVES * 256) {  // two of this wave's units in flight per trip
+                const int e1 = e0 + EX_WAVES * 256;
+                const v4i x0 = __builtin_amdgcn_raw_buffer_load_b128(rj, lane * 16 + e0 * 4, 0, 0);
+                const v4i x1 = __builtin_amdgcn_raw_buffer_load_b128(rj, lane * 16 + e1 * 4, 0, 0);
+                int n0 = dw - e0 - 4 * lane, n1 = dw - e1 - 4 * lane;
+                body(k, wb, e0 + 4 * lane, x0, n0 < 0 ? 0 : (n0 > 4 ? 4 : n0));
+                if (e1 < dw) body(k, wb, e1 + 4 * lane, x1, n1 < 0 ? 0 : (n1 > 4 ? 4 : n1));
+            }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) *s_nlong = 0;
 }
+
+#ifdef EX_STAMP  // diagnostic build only: per-phase s_memtime sums of wave 0 of every workgroup (never in the shipped library)
+__device__ unsigned long long g_ex_stamp[16];
+#define XSTAMP(var) unsigned long long var; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory")
+#define XSTAMP_ADD(i, a, b) xst[i] += (b) - (a)
+extern "C" int eps_debug_expand_stamps(unsigned long long *out16, int reset)
+{
+    hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_ex_stamp), sizeof(unsigned long long) * 16);
+    if (reset) { unsigned long long z[16] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(g_ex_stamp), z, sizeof(z)); }
+    return 0;
+}
+#else
+#define XSTAMP(var)
+#define XSTAMP_ADD(i, a, b)
+#endif
 
 template <bool FILL, bool HAS_VAL, bool HAS_W>
 __global__ __launch_bounds__(EX_THREADS) void expand_kernel(
@@ -141,11 +202,14 @@ __global__ __launch_bounds__(EX_THREADS) void expand_kernel(
     uint32_t *seen2 = seen + seen_words;              // ... and a second one
     __shared__ int s_wave_tot[EX_WAVES];
     __shared__ unsigned int s_col;
+    __shared__ int s_long[EX_LONGQ];
+    __shared__ int s_nlong;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wib = __builtin_amdgcn_readfirstlane(tid >> 6);
 
     // the bitmap is all-zero between columns: every column clears exactly the words it scanned
     for (int i = tid; i < words; i += EX_THREADS) bm[i] = 0u;
+    if (tid == 0) s_nlong = 0;
     if (FILL) {
         for (int i = tid; i < 2 * seen_words; i += EX_THREADS) seen[i] = 0u;
         for (int i = tid; i < EX_HOT; i += EX_THREADS) {
@@ -155,11 +219,17 @@ __global__ __launch_bounds__(EX_THREADS) void expand_kernel(
         }
     }
 
+#ifdef EX_STAMP
+    unsigned long long xst[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
     for (;;) {
+        XSTAMP(t0);
         __syncthreads();
         if (tid == 0) s_col = atomicAdd(next_col, 1u);
         __syncthreads();
         if ((int64_t)v_lo + s_col >= v_hi) break;
+        XSTAMP(t1);
+        XSTAMP_ADD(0, t0, t1);
         const int64_t v = (int64_t)v_lo + (col_order ? (uint32_t)col_order[s_col] : s_col);
         const int64_t vb = rowptr[v];
         const int32_t dv = (int32_t)(rowptr[v + 1] - vb);
@@ -170,7 +240,7 @@ __global__ __launch_bounds__(EX_THREADS) void expand_kernel(
         }
 
         // ---- A. mark every 2-hop endpoint --------------------------------------------------
-        for_each_path(rowptr, col, vcol, dv, wib, lane, [&](int, int64_t, int, v4i u4, int nvalid) {
+        for_each_path(rowptr, col, vcol, dv, wib, lane, s_long, &s_nlong, [&](int, int64_t, int, v4i u4, int nvalid) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 if (e >= nvalid) continue;
@@ -185,6 +255,8 @@ __global__ __launch_bounds__(EX_THREADS) void expand_kernel(
         }
         if (tid == 0) atomicAnd(&bm[(uint32_t)v >> 5], ~(1u << ((uint32_t)v & 31)));  // diagonal out
         __syncthreads();
+        XSTAMP(t2);
+        XSTAMP_ADD(1, t1, t2);
 
         // ---- B. rank: exclusive prefix of the per-word popcounts ---------------------------------
         const int w0 = tid * wpt;
@@ -201,6 +273,8 @@ __global__ __launch_bounds__(EX_THREADS) void expand_kernel(
             total += t;
         }
         int run = wave_base + incl - local;  // exclusive prefix of this thread's first word
+        XSTAMP(t3);
+        XSTAMP_ADD(2, t2, t3);
 
         if (!FILL) {
             if (tid == 0) cand_count[v - v_lo] = total;
@@ -219,10 +293,11 @@ __global__ __launch_bounds__(EX_THREADS) void expand_kernel(
                 const int b = __builtin_ctz(bits);
                 bits &= bits - 1;
                 cand_u[base + run] = (w0 + i) * 32 + b;
-                if (cand_v) cand_v[base + run] = (int32_t)v;
                 ++run;
             }
         }
+        if (cand_v)  // one value for the whole column: whole lines, not one scattered store per candidate
+            for (int i = tid; i < total; i += EX_THREADS) cand_v[base + i] = (int32_t)v;
         __syncthreads();
         run = run0;
         for (int i = 0; i < wpt; ++i) {  // group bases are complete: ranks relative to them fit a byte
@@ -231,6 +306,8 @@ __global__ __launch_bounds__(EX_THREADS) void expand_kernel(
         }
         __syncthreads();
 
+        XSTAMP(t4);
+        XSTAMP_ADD(3, t3, t4);
         // ---- D. score: walk the paths again, give each term to its candidate's slot -------------------
         if (out_score || out_cn) {
             // arrival bitmaps over the candidate ranks of this column; columns with more candidates than bits share a bit
@@ -247,7 +324,9 @@ __global__ __launch_bounds__(EX_THREADS) void expand_kernel(
                 }
                 __syncthreads();
             }
-            for_each_path(rowptr, col, vcol, dv, wib, lane, [&](int k, int64_t wb, int base, v4i u4, int nvalid) {
+            XSTAMP(t5);
+            XSTAMP_ADD(4, t4, t5);
+            for_each_path(rowptr, col, vcol, dv, wib, lane, s_long, &s_nlong, [&](int k, int64_t wb, int base, v4i u4, int nvalid) {
                 if (nvalid == 0) return;
                 float vw = 1.0f;                          // A[v,w] * node_w[w]: the A_ entry (adamic_utils.py:17)
                 if (HAS_VAL) vw = val[vb + k];
@@ -292,7 +371,11 @@ __global__ __launch_bounds__(EX_THREADS) void expand_kernel(
                     }
                 }
             });
+            XSTAMP(t6);
+            XSTAMP_ADD(5, t5, t6);
             __syncthreads();
+            XSTAMP(t7);
+            XSTAMP_ADD(6, t6, t7);
             for (int i = tid; i <= (ncand >> shift) / 32; i += EX_THREADS) seen[i] = seen2[i] = 0u;
             for (int i = tid; i < EX_HOT; i += EX_THREADS) {  // the owner of an entry is the only writer of its slot
                 const uint32_t r = hot_key[i];
@@ -306,7 +389,13 @@ __global__ __launch_bounds__(EX_THREADS) void expand_kernel(
             }
         }
         for (int i = 0; i < wpt; ++i) bm[w0 + i] = 0u;
+        XSTAMP(t8);
+        XSTAMP_ADD(7, t4, t8);
     }
+#ifdef EX_STAMP
+    if (FILL && tid == 0)
+        for (int i = 0; i < 8; ++i) atomicAdd(&g_ex_stamp[i], xst[i]);
+#endif
 }
 
 // Completes score[] / cn[] of a fill launch: adds what the second and the later paths of a candidate left in the scratch

@@ -107,8 +107,8 @@ def scored_blocks(args, model, data, ra_graph, col_lo: int = 0, col_hi: int = No
         node_w = torch.ones(g.n_rows, dtype=torch.float32, device=g.device)
     print(f'fused candidate generation + scoring ({args.model})')
     for v_lo, v_hi in blocks:
-        pairs, _, score = candidates.expand_block(g, v_lo, v_hi, node_w, want_score=True, long_pairs=False)
-        yield v_lo, v_hi, pairs, score
+        blk = candidates.expand_block_lazy(g, v_lo, v_hi, node_w, want_score=True)
+        yield v_lo, v_hi, blk, blk.score
 
 
 def run(args) -> str:
@@ -156,14 +156,15 @@ def run(args) -> str:
     top = proposals.StreamingTopK(keep) if keep else None
     with torch.no_grad():
         for v_lo, v_hi, pairs, score in scored_blocks(args, model, data, ra_graph, col_lo, col_hi):
-            if pairs.shape[1] == 0:
+            n_blk = pairs.numel() if (not isinstance(pairs, torch.Tensor)) else pairs.shape[1]
+            if n_blk == 0:
                 continue
             if keep:
                 top.push(pairs, score)          # blocks arrive in candidate (column-major) order
             else:
-                all_pairs.append(pairs)
+                all_pairs.append(pairs.pairs() if (not isinstance(pairs, torch.Tensor)) else pairs)
                 all_scores.append(score)
-            n_seen += pairs.shape[1]
+            n_seen += n_blk
     torch.cuda.synchronize(device)
     dt = time.perf_counter() - t0
     print(f'using {n_seen} edges; scored in {dt:.2f} s ({n_seen / max(dt, 1e-9):.3e} candidate edges/s incl. generation)')

@@ -64,7 +64,8 @@ class StreamingTopK:
     never displace an earlier candidate -- which leaves next to nothing to sort for most blocks.  A block that is
     still much larger than K after that (the first ones: hundreds of millions of candidates) is cut at a threshold
     read off a strided sample and VERIFIED to keep at least K entries, so only ~1.5 K scores are ever sorted; the
-    result is the exact top-K either way.  Pairs may arrive as int32 or int64; ``result()`` returns int64."""
+    result is the exact top-K either way.  Pairs may arrive as int32 or int64, or as an object with ``select(idx)``
+    (candidates.ColumnBlock: the pairs of the surviving positions are formed on demand); ``result()`` returns int64."""
 
     PRECUT_FACTOR = 4          # pre-cut blocks larger than this many times K
     SAMPLE_STRIDE = 64
@@ -85,20 +86,27 @@ class StreamingTopK:
         m = scores >= t
         return m if int(m.sum()) >= need else None
 
-    def push(self, pairs: torch.Tensor, scores: torch.Tensor) -> None:
+    def push(self, pairs, scores: torch.Tensor) -> None:
         if scores.numel() == 0:
             return
+        lazy = not isinstance(pairs, torch.Tensor)                       # candidates.ColumnBlock: pairs on demand
+        keep = None                                                       # surviving positions of the block, ascending
         held = 0 if self.scores is None else self.scores.numel()
         if held >= self.k:
-            idx = torch.nonzero(scores > self.scores[-1]).squeeze(1)      # ascending: candidate order is kept
-            if idx.numel() == 0:
+            keep = torch.nonzero(scores > self.scores[-1]).squeeze(1)     # ascending: candidate order is kept
+            if keep.numel() == 0:
                 return
-            pairs, scores = pairs[:, idx], scores[idx]
+            scores = scores[keep]
         # every entry of the final top-K that comes from this block is among the block's own best K
         m = self._precut(scores, self.k)
         if m is not None:
             idx = torch.nonzero(m).squeeze(1)
-            pairs, scores = pairs[:, idx], scores[idx]
+            scores = scores[idx]
+            keep = idx if keep is None else keep[idx]
+        if lazy:
+            pairs = pairs.select(keep) if keep is not None else pairs.pairs()
+        elif keep is not None:
+            pairs = pairs[:, keep]
         if self.scores is not None:
             if pairs.dtype != self.pairs.dtype:
                 pairs, self.pairs = pairs.long(), self.pairs.long()

@@ -154,3 +154,30 @@ def test_streaming_topk_sampled_precut_cpu():
         p, s = top.result()
         assert p.dtype == torch.int64
         assert torch.equal(p[0], want) and torch.equal(s, scores[want])
+
+
+def test_streaming_topk_lazy_column_block_cpu():
+    """A ColumnBlock (cand_u + colptr, no v array) pushed into StreamingTopK gives the same proposals as the
+    materialised [2,E] pairs: v is rebuilt from colptr for the surviving positions only."""
+    sys.path.insert(0, ROOT)
+    import eps_amd  # noqa: F401
+    from eps_amd import candidates, proposals
+    g = torch.Generator().manual_seed(5)
+    n_cols, v_lo, k = 3000, 17, 900
+    counts = torch.randint(0, 120, (n_cols,), generator=g)
+    counts[5] = 0; counts[-1] = 0                                            # empty columns inside and at the end
+    colptr = torch.zeros(n_cols + 1, dtype=torch.int64); colptr[1:] = torch.cumsum(counts, 0)
+    e = int(colptr[-1])
+    cand_u = torch.randint(0, 50000, (e,), generator=g, dtype=torch.int32)
+    scores = torch.randint(0, 9, (e,), generator=g).float()
+    blk = candidates.ColumnBlock(v_lo, colptr, cand_u, None, scores)
+    pairs = blk.pairs()
+    assert pairs.shape == (2, e) and int(pairs[1].min()) >= v_lo and int(pairs[1].max()) < v_lo + n_cols
+    assert torch.equal(torch.bincount(pairs[1] - v_lo, minlength=n_cols), counts)
+    idx = torch.tensor([0, 1, e // 2, e - 1])
+    assert torch.equal(blk.select(idx), pairs[:, idx])
+    a, b = proposals.StreamingTopK(k), proposals.StreamingTopK(k)
+    for rep in range(3):                                                     # later pushes run the threshold cut
+        a.push(pairs, scores + rep * (rep == 1)); b.push(blk, scores + rep * (rep == 1))
+    pa, sa = a.result(); pb, sb = b.result()
+    assert torch.equal(pa, pb) and torch.equal(sa, sb)
