@@ -326,48 +326,71 @@ __global__ __launch_bounds__(EX_THREADS) void expand_kernel(
             }
             XSTAMP(t5);
             XSTAMP_ADD(4, t4, t5);
+            // The four entries of a lane go through the LDS look-ups STAGE BY STAGE (all four bitmap words, then all four
+            // rank reads, then all four arrival tests ...): every stage is one LDS round trip for the four together,
+            // where entry-by-entry code made up to five dependent round trips per entry.  An entry that has dropped out
+            // still issues its (harmless) operation -- OR of 0, CAS that cannot match -- so no stage hides in a branch.
             for_each_path(rowptr, col, vcol, dv, wib, lane, s_long, &s_nlong, [&](int k, int64_t wb, int base, v4i u4, int nvalid) {
-                if (nvalid == 0) return;
                 float vw = 1.0f;                          // A[v,w] * node_w[w]: the A_ entry (adamic_utils.py:17)
                 if (HAS_VAL) vw = val[vb + k];
                 if (HAS_W) vw = vw * node_w[vcol[k]];
+                uint32_t u[4], word[4], rank[4], sbit[4], sw[4], old1[4], old2[4], h[4], owner[4];
+                bool cand[4], later[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) u[e] = e < nvalid ? (uint32_t)u4[e] : 0u;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) word[e] = bm[u[e] >> 5];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) rank[e] = base32[u[e] >> 8] + pre8[u[e] >> 5];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    if (e >= nvalid) continue;
-                    const uint32_t u = (uint32_t)u4[e];
-                    const uint32_t word = bm[u >> 5];
-                    if ((word >> (u & 31)) & 1u) {
-                        const uint32_t rank = base32[u >> 8] + pre8[u >> 5] + __popc(word & ((1u << (u & 31)) - 1u));
-                        const int64_t slot = base_off + rank;
-                        const uint32_t sb = rank >> shift, sbit = 1u << (sb & 31);
-                        int arrival = 2;
-                        if (!(atomicOr(&seen[sb >> 5], sbit) & sbit)) arrival = 0;
-                        else if (!(atomicOr(&seen2[sb >> 5], sbit) & sbit)) arrival = 1;
-                        // Third and later paths: the candidates with the longest chains (a hub pair has thousands of
-                        // common neighbours, and atomics on ONE address serialise at the memory side) come back in
-                        // almost every row, so they are the first to ask for an entry of the LDS table and keep it for
-                        // the column; a candidate that finds its entry taken uses the global accumulator throughout.
-                        uint32_t h = 0;
-                        bool hot = false;
-                        if (arrival == 2) {
-                            h = (rank * 2654435761u) >> 22;
-                            const uint32_t owner = atomicCAS(&hot_key[h], EX_HOT_EMPTY, rank);
-                            hot = owner == EX_HOT_EMPTY || owner == rank;
-                        }
-                        if (out_cn) {
-                            if (arrival == 0) out_cn[slot] = 1;
-                            else if (arrival == 1) cn_second[slot] = 1;
-                            else if (hot) atomicAdd(&hot_cn[h], 1u);
-                            else atomicAdd(&cn_later[slot], 1);
-                        }
-                        if (out_score) {
-                            float term = vw;              // A[u,w] * (A[v,w] * node_w[w]), float32 like the reference
-                            if (HAS_VAL) term = val[wb + base + e] * vw;
-                            if (arrival == 0) out_score[slot] = term;
-                            else if (arrival == 1) score_second[slot] = term;
-                            else if (hot) atomicAdd(&hot_acc[h], (unsigned long long)ex_to_fixed(term));
-                            else atomicAdd(&score_later[slot], (unsigned long long)ex_to_fixed(term));
-                        }
+                    cand[e] = e < nvalid && ((word[e] >> (u[e] & 31)) & 1u);
+                    rank[e] += __popc(word[e] & ((1u << (u[e] & 31)) - 1u));
+                    const uint32_t sb = rank[e] >> shift;
+                    sbit[e] = cand[e] ? 1u << (sb & 31) : 0u;
+                    sw[e] = cand[e] ? sb >> 5 : 0u;
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) old1[e] = atomicOr(&seen[sw[e]], sbit[e]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) old2[e] = atomicOr(&seen2[sw[e]], old1[e] & sbit[e]);  // only if seen before
+                // Third and later paths: the candidates with the longest chains (a hub pair has thousands of common
+                // neighbours, and atomics on ONE address serialise at the memory side) come back in almost every row, so
+                // they are the first to ask for an entry of the LDS table and keep it for the column; a candidate that
+                // finds its entry taken uses the global accumulator throughout.
+                bool any_later = false;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    later[e] = (old1[e] & old2[e] & sbit[e]) != 0u;
+                    any_later |= later[e];
+                    h[e] = later[e] ? (rank[e] * 2654435761u) >> 22 : (uint32_t)(lane + 64 * e);
+                    owner[e] = rank[e] + 1u;              // "not mine" unless the CAS below says otherwise
+                }
+                if (__any(any_later)) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)           // a lane without a later path compares with a value no key can hold
+                        owner[e] = atomicCAS(&hot_key[h[e]], later[e] ? EX_HOT_EMPTY : 0xFFFFFFFEu, rank[e]);
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (!cand[e]) continue;
+                    const int64_t slot = base_off + rank[e];
+                    const bool first = !(old1[e] & sbit[e]);
+                    const bool second = !first && !(old2[e] & sbit[e]);
+                    const bool hot = later[e] && (owner[e] == EX_HOT_EMPTY || owner[e] == rank[e]);
+                    if (out_cn) {
+                        if (first) out_cn[slot] = 1;
+                        else if (second) cn_second[slot] = 1;
+                        else if (hot) atomicAdd(&hot_cn[h[e]], 1u);
+                        else atomicAdd(&cn_later[slot], 1);
+                    }
+                    if (out_score) {
+                        float term = vw;                  // A[u,w] * (A[v,w] * node_w[w]), float32 like the reference
+                        if (HAS_VAL) term = val[wb + base + e] * vw;
+                        if (first) out_score[slot] = term;
+                        else if (second) score_second[slot] = term;
+                        else if (hot) atomicAdd(&hot_acc[h[e]], (unsigned long long)ex_to_fixed(term));
+                        else atomicAdd(&score_later[slot], (unsigned long long)ex_to_fixed(term));
                     }
                 }
             });
