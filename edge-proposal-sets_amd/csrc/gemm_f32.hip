@@ -6,11 +6,11 @@
 // Serves the dense halves of the GNN layers: `x @ W` of GCNConv (models.py:183/186, weight
 // passed transposed by the host) and lin_l / lin_r of SAGEConv (models.py:436/439).
 //
-// 128x128 block tile, BK = 32, four waves of 64x64 (2x2 MFMA 32x32 tiles, 64 accumulator
+// 128x128 block tile, BK = 16, four waves of 64x64 (2x2 MFMA 32x32 tiles, 64 accumulator
 // registers).  Both operands are k-contiguous, so a lane's ds_read_b128 at [row][8j+4h..+3]
 // feeds four consecutive MFMA k-steps of A and of B alike (the two lane halves own k-subsets
 // {8j..8j+3} and {8j+4..8j+7}; A and B use the same assignment, so the sum over k is complete).
-// LDS rows are padded to 36 floats: the 16-lane ds_read_b128 groups then hit 16 distinct 16-B
+// LDS rows are padded by 4 floats (BK + 4): the 16-lane ds_read_b128 groups then hit 16 distinct 16-B
 // bank slots.  Global->register->LDS double buffering, one barrier per K-chunk.
 #include "eps_common.h"
 
@@ -18,8 +18,13 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define G_BM 128
 #define G_BN 128
-#define G_BK 32
-#define G_LD 36
+#ifndef G_BK
+#define G_BK 16  // 40 KiB of LDS per workgroup -> three resident workgroups per CU (132 VGPRs); 32 and 64 measured slower
+#endif
+#define G_LD (G_BK + 4)
+#define G_F4 (G_BK / 4)          // float4 per tile row
+#define G_NLD (G_BM * G_F4 / 256)  // float4 per thread and operand
+#define G_NJ (G_BK / 8)
 
 typedef float v4f __attribute__((ext_vector_type(4)));
 
@@ -86,21 +91,21 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float *__restrict__
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     const int nk = (K + G_BK - 1) / G_BK;
-    v4f ra[4], rb[4];
+    v4f ra[G_NLD], rb[G_NLD];
 
 #define G_GLOAD(kc)                                                                             \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                               \
+    _Pragma("unroll") for (int i = 0; i < G_NLD; ++i)                                           \
     {                                                                                           \
         const int q = tid + 256 * i;                                                            \
-        const int row = q >> 3, c4 = q & 7;                                                     \
+        const int row = q / G_F4, c4 = q % G_F4;                                                \
         ra[i] = tile_load4(ra_rs, row, ilda, (kc)*G_BK + c4 * 4, K, fastA);                     \
         rb[i] = tile_load4(rb_rs, row, ildb, (kc)*G_BK + c4 * 4, K, fastB);                     \
     }
 #define G_LSTORE(buf)                                                                           \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                               \
+    _Pragma("unroll") for (int i = 0; i < G_NLD; ++i)                                           \
     {                                                                                           \
         const int q = tid + 256 * i;                                                            \
-        const int row = q >> 3, c4 = q & 7;                                                     \
+        const int row = q / G_F4, c4 = q % G_F4;                                                \
         *reinterpret_cast<v4f *>(&As[buf][row][c4 * 4]) = ra[i];                                \
         *reinterpret_cast<v4f *>(&Bs[buf][row][c4 * 4]) = rb[i];                                \
     }
@@ -112,10 +117,10 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float *__restrict__
     for (int kc = 0; kc < nk; ++kc) {
         const int buf = kc & 1;
         if (kc + 1 < nk) { G_GLOAD(kc + 1); }
-        // all 16 fragment reads of the chunk up front; MFMAs drain them behind counted lgkmcnt waits
-        float4 a0[4], a1[4], b0[4], b1[4];
+        // all fragment reads of the chunk up front; MFMAs drain them behind counted lgkmcnt waits
+        float4 a0[G_NJ], a1[G_NJ], b0[G_NJ], b1[G_NJ];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < G_NJ; ++j) {
             const int ko = 8 * j + 4 * h;
             a0[j] = *reinterpret_cast<const float4 *>(&As[buf][wm * 64 + r][ko]);
             a1[j] = *reinterpret_cast<const float4 *>(&As[buf][wm * 64 + 32 + r][ko]);
@@ -123,7 +128,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float *__restrict__
             b1[j] = *reinterpret_cast<const float4 *>(&Bs[buf][wn * 64 + 32 + r][ko]);
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < G_NJ; ++j) {
             const float av0[4] = {a0[j].x, a0[j].y, a0[j].z, a0[j].w}, av1[4] = {a1[j].x, a1[j].y, a1[j].z, a1[j].w};
             const float bv0[4] = {b0[j].x, b0[j].y, b0[j].z, b0[j].w}, bv1[4] = {b1[j].x, b1[j].y, b1[j].z, b1[j].w};
 #pragma unroll
@@ -133,8 +138,14 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float *__restrict__
                 acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[s], bv0[s], acc[1][0], 0, 0, 0);
                 acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[s], bv1[s], acc[1][1], 0, 0, 0);
             }
+            if (j == G_NJ / 2) {
+                // the other LDS buffer has been free since the last barrier: park the next chunk there while the
+                // matrix pipe still has a quarter of this chunk queued, so the barrier below finds the writes done
+                __builtin_amdgcn_sched_barrier(0);
+                if (kc + 1 < nk) { G_LSTORE(buf ^ 1); }
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
-        if (kc + 1 < nk) { G_LSTORE(buf ^ 1); }
         __syncthreads();
     }
 #undef G_GLOAD
