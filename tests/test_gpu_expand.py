@@ -72,6 +72,18 @@ def test_expand_rmat_and_determinism(eps, oracle, dev):
         assert torch.equal(a[i], c[i]) and torch.equal(a[i], d[i])
     with pytest.raises(ValueError):
         eps.ops.expand_candidates(gd.rowptr, gd.col, None, wt, gd.n_rows, 0, gd.n_rows, col_order=order[:5])
+    # every subset of the optional outputs (the scratch layout differs) gives the same arrays
+    only_cn = eps.ops.expand_candidates(gd.rowptr, gd.col, None, None, gd.n_rows, 0, gd.n_rows, want_score=False)
+    only_sc = eps.ops.expand_candidates(gd.rowptr, gd.col, None, wt, gd.n_rows, 0, gd.n_rows, want_cn=False, want_v=False)
+    bare = eps.ops.expand_candidates(gd.rowptr, gd.col, None, None, gd.n_rows, 0, gd.n_rows, want_cn=False, want_score=False)
+    assert torch.equal(only_cn[3], a[3]) and only_cn[4] is None and torch.equal(only_cn[1], a[1])
+    assert torch.equal(only_sc[4], a[4]) and only_sc[3] is None and only_sc[2] is None and only_sc.pairs is None
+    assert torch.equal(bare[1], a[1]) and torch.equal(bare[2], a[2]) and torch.equal(bare.pairs[0], a[1])
+    # the lazily paired block of the filter stage: same pairs as the materialised ones
+    blk = candidates.expand_block_lazy(gd, 0, gd.n_rows, wt, want_score=True)
+    assert torch.equal(blk.pairs(), torch.stack([a[1], a[2]]).long()) and torch.equal(blk.score, a[4])
+    idx = torch.tensor([0, 5, blk.numel() // 2, blk.numel() - 1], device=dev)
+    assert torch.equal(blk.select(idx), blk.pairs()[:, idx])
 
 
 def test_expand_matches_pair_kernel_at_scale(eps, dev):
