@@ -188,8 +188,7 @@ def main():
     # Second leg: the FUSED filter path (csrc/expand_score.hip) -- candidate generation + CN + AA in one expansion of
     # the 2-hop paths (what filter.py runs for heuristic filters), on one production-sized launch: the columns from
     # the rank's first one up to 2^29 two-hop paths, handed out heaviest first, exactly as candidates.expand_block
-    # launches them.  Timed end to end on the host clock: count kernel + cumsum + zero-fill + fill kernel +
-    # finish kernel, outputs left in HBM.
+    # launches them.  Timed end to end on the host clock: count kernel + cumsum + fill kernel, outputs left in HBM.
     fused = None
     if candidates.hip_expand_available(g):
         c_lo = col_range[0]
@@ -198,13 +197,14 @@ def main():
         c_hi = int(torch.searchsorted(pc, torch.tensor(base + (1 << 29), device=dev), right=True).item())
         c_hi = min(max(c_hi, c_lo + 1), g.n_rows)
         order = candidates.heaviest_first(g, c_lo, c_hi)
+        mp = candidates.max_paths_of(g)
         for _ in range(2):
-            r = ops.expand_candidates(g.rowptr, g.col, g.val, w, g.n_rows, c_lo, c_hi, col_order=order)
+            r = ops.expand_candidates(g.rowptr, g.col, g.val, w, g.n_rows, c_lo, c_hi, col_order=order, max_paths=mp)
         barrier()
         t1 = time.perf_counter()
         fsteps = max(3, args.steps // 4)
         for _ in range(fsteps):
-            r = ops.expand_candidates(g.rowptr, g.col, g.val, w, g.n_rows, c_lo, c_hi, col_order=order)
+            r = ops.expand_candidates(g.rowptr, g.col, g.val, w, g.n_rows, c_lo, c_hi, col_order=order, max_paths=mp)
         barrier()
         fdt = time.perf_counter() - t1
         if world > 1:
@@ -221,7 +221,7 @@ def main():
                  "columns_rank0": [c_lo, c_hi], "two_hop_paths_rank0": paths,
                  "what": "candidate generation (filter.py:96-109) + CN + AA for every candidate of one production-sized "
                          "column block (2^29 two-hop paths, heaviest column first), one fused expansion; host clock "
-                         "incl. count pass, cumsum, zero-fill, fill pass, finish kernel"}
+                         "incl. count pass, cumsum, fill pass (mark, bin, per-tile LDS sums)"}
 
     if rank == 0:
         n_cu, dev_name = ops.device_info()

@@ -58,6 +58,13 @@ def path_counts(g: CSRGraph) -> torch.Tensor:
     return g._cache["paths"]
 
 
+def max_paths_of(g: CSRGraph) -> int:
+    """Two-hop paths of the heaviest column of the graph (cached): sizes the bucket scratch of the fused expansion."""
+    if "max_paths" not in g._cache:
+        g._cache["max_paths"] = int(path_counts(g).max().item()) if g.n_rows else 0
+    return g._cache["max_paths"]
+
+
 def heaviest_first(g: CSRGraph, v_lo: int, v_hi: int) -> torch.Tensor:
     """Columns of [v_lo, v_hi) by descending path count (int32, relative to v_lo): the hand-out order of the
     expansion kernels -- a hub column is one workgroup's work for milliseconds and must not start last."""
@@ -93,7 +100,8 @@ def expand_block_lazy(g: CSRGraph, v_lo: int, v_hi: int, node_w: Optional[torch.
     """``expand_block`` for consumers that read the pairs of a few candidates only (HIP expansion required)."""
     from . import ops
     r = ops.expand_candidates(g.rowptr, g.col, g.val, node_w, g.n_rows, v_lo, v_hi, want_cn=want_cn,
-                              want_score=want_score, want_v=False, col_order=heaviest_first(g, v_lo, v_hi))
+                              want_score=want_score, want_v=False, col_order=heaviest_first(g, v_lo, v_hi),
+                              max_paths=max_paths_of(g))
     return ColumnBlock(v_lo, r[0], r[1], r[3], r[4])
 
 
@@ -106,7 +114,8 @@ def expand_block(g: CSRGraph, v_lo: int, v_hi: int, node_w: Optional[torch.Tenso
     from . import ops
     if hip_expand_available(g):
         r = ops.expand_candidates(g.rowptr, g.col, g.val, node_w, g.n_rows, v_lo, v_hi, want_cn=want_cn,
-                                  want_score=want_score, col_order=heaviest_first(g, v_lo, v_hi))
+                                  want_score=want_score, col_order=heaviest_first(g, v_lo, v_hi),
+                                  max_paths=max_paths_of(g))
         return (r.pairs.long() if long_pairs else r.pairs), r[3], r[4]
     pairs = two_hop_block(g, v_lo, v_hi)
     cn = sc = None

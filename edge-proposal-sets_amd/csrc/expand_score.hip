@@ -18,24 +18,22 @@
 //      reference's column-major order for free).
 //      Columns may be handed out in a caller-given order (heaviest first keeps the tail of a
 //      launch short: a hub column is one workgroup's work for milliseconds).
-//   D. score: walk the same paths again; a path whose u is a candidate contributes its term to
-//      the candidate's slot.  Scattered global atomics are line read-modify-writes behind the
-//      L2 (~5x the cost of a plain store, which the L2 absorbs) and bounded this pass, so they
-//      are kept for the few paths that need them: two more LDS bitmaps over the column's
-//      candidate RANKS tell the first and the second path to reach a candidate (the value
-//      ds_or_rtn returns); the first stores its term into score[], the second into a scratch
-//      array, and only a third or later one (10 % of the paths on the ppa-like graph; 84 % of
-//      the candidates have one path, 11 % two) adds to a 64-bit accumulator.  The three kinds of
-//      slot live in separate arrays: a plain-stored dirty line and a memory-side atomic on the
-//      same line evict each other.  eps_expand_finish sums the three in 2^-40 FIXED POINT:
-//      integer addition is associative, so the result is bit-reproducible whatever the arrival
-//      order (float atomics are not), and exact up to the final rounding to float32.
+//   D. score: walk the same paths again.  Writing each term to its candidate's slot -- plain
+//      stores or atomics -- scatters 4-byte writes over the column's whole output segment for
+//      the length of the pass: the L2 evicts the lines half-written (590 M write-backs for
+//      4.8 GB of output per launch) and every atomic is a line read-modify-write behind the
+//      L2.  So the pass is BLOCKED instead ("propagation blocking"): pass A also counts the
+//      paths per id range (512 ranges), the ranges are grouped into tiles of <= 8192 candidate
+//      ranks, and D1 appends a record (rank in tile, term) to the tile's bucket in a per-
+//      workgroup scratch buffer -- sequential streams, whole lines.  D2 then takes the tiles
+//      one by one: bucket -> 64-bit FIXED-POINT (2^-40) accumulators and counters in LDS (they
+//      reuse the bitmap's space) -> one coalesced store of the finished float32 scores / counts.
+//      Integer addition is associative: bit-reproducible whatever the arrival order (float
+//      atomics are not), exact up to the final rounding.  No global atomics, no zero-filled
+//      accumulator arrays, no second kernel.
 // Requires a SYMMETRIC adjacency (filter.py's always is: rank.py:33 to_symmetric) and
-//      The later paths of the hottest candidates (a pair of hubs has thousands of common
-//      neighbours; atomics on one address serialise) are summed in a small LDS table first.
-// N <= 786,432 node ids (bitmap + rank tables: 5.5 bytes per 32 ids of the 160 KiB LDS; what
-// is left holds the hot table and the two arrival bitmaps, at reduced resolution for columns
-// with more candidates than bits); the host falls back to the tensor-op expansion above that.
+// N <= 851,968 node ids (bitmap + rank tables: 5.5 bytes per 32 ids of the 160 KiB LDS); the
+// host falls back to the tensor-op expansion above that.
 #include "eps_common.h"
 
 #include <stdlib.h>
@@ -43,11 +41,11 @@
 #define EX_THREADS 1024
 #define EX_WAVES (EX_THREADS / 64)
 #define EX_FIXED_SHIFT 40
-#define EX_FILL_LDS 157696  // dynamic LDS of the fill kernel: 154 KiB (the rest of the 160 KiB is static LDS)
 #define EX_LONGQ 1024       // rows longer than one unit queued per column and pass (static LDS)
-#define EX_MAX_WPT 24       // bitmap words per thread: 24 * 1024 words * 5.5 B = 132 KiB; hot table 16 KiB; the rest: arrival bitmaps
-#define EX_HOT 1024         // entries of the per-column LDS table that absorbs the later paths of the hottest candidates
-#define EX_HOT_EMPTY 0xFFFFFFFFu
+#define EX_MAX_WPT 26       // bitmap words per thread: 26 * 1024 words * 5.5 B = 143 KiB + 10 KiB of tables
+#define EX_RANGES 512       // id ranges per column: path histogram and tile plan
+#define EX_TILE 8192        // candidate ranks per tile: 64 KiB of accumulators + 32 KiB of counters, aliasing the bitmap
+#define EX_TABLE_WORDS (5 * EX_RANGES + 1)
 
 
 __device__ __forceinline__ int wave_incl_scan(int x, int lane)
@@ -183,41 +181,42 @@ extern "C" int eps_debug_expand_stamps(unsigned long long *out16, int reset)
 template <bool FILL, bool HAS_VAL, bool HAS_W>
 __global__ __launch_bounds__(EX_THREADS) void expand_kernel(
     const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col, const float *__restrict__ val,
-    const float *__restrict__ node_w, int32_t v_lo, int32_t v_hi, const int32_t *__restrict__ col_order, int32_t wpt,
-    unsigned int *__restrict__ next_col,
-    int64_t *__restrict__ cand_count, const int64_t *__restrict__ colptr, int32_t *__restrict__ cand_u,
-    int32_t *__restrict__ cand_v, int32_t seen_words, int32_t *__restrict__ out_cn, int32_t *__restrict__ cn_second,
-    int32_t *__restrict__ cn_later, float *__restrict__ out_score, float *__restrict__ score_second,
-    unsigned long long *__restrict__ score_later)
+    const float *__restrict__ node_w, int32_t n_nodes, int32_t v_lo, int32_t v_hi, const int32_t *__restrict__ col_order,
+    int32_t wpt, unsigned int *__restrict__ next_col, int64_t *__restrict__ cand_count, const int64_t *__restrict__ colptr,
+    int32_t *__restrict__ cand_u, int32_t *__restrict__ cand_v, int32_t range_shift, int32_t tile_half,
+    int32_t region_words,
+    uint2 *__restrict__ scratch, int64_t scratch_per_block, int32_t *__restrict__ out_cn, float *__restrict__ out_score,
+    unsigned int *__restrict__ overflow)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const int words = wpt * EX_THREADS;
     uint32_t *bm = lds;                            // bit u: u is a 2-hop endpoint of the column
     uint32_t *base32 = lds + words;                // FILL only from here.  rank of the first bit of every 8-word group
     uint8_t *pre8 = (uint8_t *)(base32 + words / 8);  // rank of a word's first bit within its group (<= 224)
-    unsigned long long *hot_acc = (unsigned long long *)(base32 + words / 8 + words / 4);  // 8-byte aligned: words % 1024 == 0
-    uint32_t *hot_key = (uint32_t *)(hot_acc + EX_HOT);  // candidate rank owning the entry
-    uint32_t *hot_cn = hot_key + EX_HOT;
-    uint32_t *seen = hot_cn + EX_HOT;                 // bit (rank >> shift): a path has reached this candidate
-    uint32_t *seen2 = seen + seen_words;              // ... and a second one
+    // D2 reuses the space of the three arrays above (they are dead once D1 has binned the paths):
+    unsigned long long *acc = (unsigned long long *)lds;         // EX_TILE fixed-point sums
+    uint32_t *cnt = lds + 2 * EX_TILE;                           // EX_TILE path counts
+    uint32_t *hist = lds + region_words;           // paths per id range (pass A), zero between columns
+    uint32_t *rinfo = hist + EX_RANGES;            // (tile of the range << 20) | first rank of that tile
+    uint32_t *tile_r0 = rinfo + EX_RANGES;         // first candidate rank of a tile; [n_tiles] = column total
+    uint32_t *tile_base = tile_r0 + EX_RANGES + 1; // first record of the tile's bucket in this workgroup's scratch
+    uint32_t *tile_cur = tile_base + EX_RANGES;    // next free record (absolute), D1's append cursor
     __shared__ int s_wave_tot[EX_WAVES];
     __shared__ unsigned int s_col;
     __shared__ int s_long[EX_LONGQ];
     __shared__ int s_nlong;
+    __shared__ int s_ntiles;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wib = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool want_d = FILL && (out_score || out_cn);
+    const int n_ranges = ((n_nodes - 1) >> range_shift) + 1;
+    uint2 *__restrict__ my_scratch = scratch + (int64_t)blockIdx.x * scratch_per_block;
 
     // the bitmap is all-zero between columns: every column clears exactly the words it scanned
     for (int i = tid; i < words; i += EX_THREADS) bm[i] = 0u;
     if (tid == 0) s_nlong = 0;
-    if (FILL) {
-        for (int i = tid; i < 2 * seen_words; i += EX_THREADS) seen[i] = 0u;
-        for (int i = tid; i < EX_HOT; i += EX_THREADS) {
-            hot_acc[i] = 0ull;
-            hot_key[i] = EX_HOT_EMPTY;
-            hot_cn[i] = 0u;
-        }
-    }
+    if (FILL)
+        for (int i = tid; i < EX_RANGES; i += EX_THREADS) hist[i] = 0u;
 
 #ifdef EX_STAMP
     unsigned long long xst[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -239,16 +238,16 @@ __global__ __launch_bounds__(EX_THREADS) void expand_kernel(
             continue;
         }
 
-        // ---- A. mark every 2-hop endpoint --------------------------------------------------
+        // ---- A. mark every 2-hop endpoint (and count the paths per id range for the bucket sizes of D1) -------------
         for_each_path(rowptr, col, vcol, dv, wib, lane, s_long, &s_nlong, [&](int, int64_t, int, v4i u4, int nvalid) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 if (e >= nvalid) continue;
                 const uint32_t u = (uint32_t)u4[e];
                 atomicOr(&bm[u >> 5], 1u << (u & 31));
+                if (want_d) atomicAdd(&hist[u >> range_shift], 1u);
             }
         });
-        __syncthreads();
         for (int k = tid; k < dv; k += EX_THREADS) {  // known edges out
             const uint32_t u = (uint32_t)vcol[k];
             atomicAnd(&bm[u >> 5], ~(1u << (u & 31)));
@@ -284,7 +283,6 @@ __global__ __launch_bounds__(EX_THREADS) void expand_kernel(
 
         // ---- C. emit the candidates of this column in ascending u ---------------------------------
         const int64_t base = colptr[v - v_lo];
-        const int64_t base_off = base;
         const int run0 = run;
         for (int i = 0; i < wpt; ++i) {
             uint32_t bits = bm[w0 + i];
@@ -298,120 +296,126 @@ __global__ __launch_bounds__(EX_THREADS) void expand_kernel(
         }
         if (cand_v)  // one value for the whole column: whole lines, not one scattered store per candidate
             for (int i = tid; i < total; i += EX_THREADS) cand_v[base + i] = (int32_t)v;
-        __syncthreads();
+        __syncthreads();   // also orders the s_wave_tot reads above against the plan's scan below
         run = run0;
         for (int i = 0; i < wpt; ++i) {  // group bases are complete: ranks relative to them fit a byte
             pre8[w0 + i] = (uint8_t)((uint32_t)run - base32[(w0 + i) >> 3]);
             run += __popc(bm[w0 + i]);
         }
-        __syncthreads();
-
         XSTAMP(t4);
         XSTAMP_ADD(3, t3, t4);
-        // ---- D. score: walk the paths again, give each term to its candidate's slot -------------------
-        if (out_score || out_cn) {
-            // arrival bitmaps over the candidate ranks of this column; columns with more candidates than bits share a bit
-            // among 2^shift neighbouring ranks (an array still gets at most one plain store per bit, hence per slot)
-            const int ncand = total;
-            int shift = 0;
-            while ((ncand >> shift) >= seen_words * 32) ++shift;
-            if (shift > 0) {
-                // with shared bits a candidate's first path may be taken for a second one, and cn[] / score[] (which
-                // the caller does not zero: normally every slot is stored once) would keep a slot unwritten
-                for (int i = tid; i < ncand; i += EX_THREADS) {
-                    if (out_cn) out_cn[base_off + i] = 0;
-                    if (out_score) out_score[base_off + i] = 0.0f;
-                }
-                __syncthreads();
+        if (!want_d) {
+            __syncthreads();
+            for (int i = 0; i < wpt; ++i) bm[w0 + i] = 0u;
+            continue;
+        }
+
+        // ---- plan: group the id ranges into tiles of <= EX_TILE candidate ranks; bucket offsets from the histogram ------
+        // A range holds at most 2^range_shift <= tile_half (= EX_TILE/2) candidates, so tile = (rank at range start) /
+        // tile_half never skips a tile id and a tile never spans more than 2 * tile_half <= EX_TILE ranks.
+        {
+            const bool in = tid < n_ranges;
+            const uint32_t rs = in ? base32[tid << (range_shift - 8)] : 0u;       // rank at the start of the range
+            const uint32_t paths = in ? hist[tid] : 0u;
+            if (in) hist[tid] = 0u;
+            const int pin = wave_incl_scan((int)paths, lane);
+            if (lane == 63) s_wave_tot[wib] = pin;
+            __syncthreads();
+            uint32_t pbase = 0, ptotal = 0;
+#pragma unroll
+            for (int i = 0; i < EX_WAVES; ++i) {
+                const uint32_t t = (uint32_t)s_wave_tot[i];
+                if (i < wib) pbase += t;
+                ptotal += t;
             }
-            XSTAMP(t5);
-            XSTAMP_ADD(4, t4, t5);
-            // The four entries of a lane go through the LDS look-ups STAGE BY STAGE (all four bitmap words, then all four
-            // rank reads, then all four arrival tests ...): every stage is one LDS round trip for the four together,
-            // where entry-by-entry code made up to five dependent round trips per entry.  An entry that has dropped out
-            // still issues its (harmless) operation -- OR of 0, CAS that cannot match -- so no stage hides in a branch.
-            for_each_path(rowptr, col, vcol, dv, wib, lane, s_long, &s_nlong, [&](int k, int64_t wb, int base, v4i u4, int nvalid) {
+            pbase += (uint32_t)pin - paths;                                        // exclusive prefix: bucket start if first
+            const uint32_t tile = rs / (uint32_t)tile_half;
+            const uint32_t rs_prev = (in && tid > 0) ? base32[(tid - 1) << (range_shift - 8)] : 0u;
+            if (in && (tid == 0 || rs_prev / (uint32_t)tile_half != tile)) {
+                tile_r0[tile] = rs;
+                tile_base[tile] = pbase;
+                tile_cur[tile] = pbase;
+            }
+            if (tid == n_ranges - 1) {
+                s_ntiles = (int)tile + 1;
+                tile_r0[tile + 1] = (uint32_t)total;
+                if ((int64_t)ptotal > scratch_per_block) {   // the host sized the scratch from the path counts: cannot happen
+                    s_ntiles = 0;
+                    atomicOr(overflow, 1u);
+                }
+            }
+            __syncthreads();
+            if (in) rinfo[tid] = (tile << 20) | tile_r0[tile];
+            __syncthreads();
+        }
+        const int n_tiles = s_ntiles;
+        XSTAMP(t5);
+        XSTAMP_ADD(4, t4, t5);
+
+        // ---- D1. bin: walk the paths again, append (rank in tile, term) to the tile's bucket ---------------------------
+        // The four entries of a lane go through the LDS look-ups stage by stage (all four bitmap words, then all four
+        // rank reads, ...): one LDS round trip per stage for the four together.  An entry that is not a candidate still
+        // issues its look-ups (on id 0) but takes no record.
+        if (n_tiles > 0)
+            for_each_path(rowptr, col, vcol, dv, wib, lane, s_long, &s_nlong, [&](int k, int64_t wb, int base_e, v4i u4, int nvalid) {
                 float vw = 1.0f;                          // A[v,w] * node_w[w]: the A_ entry (adamic_utils.py:17)
                 if (HAS_VAL) vw = val[vb + k];
                 if (HAS_W) vw = vw * node_w[vcol[k]];
-                uint32_t u[4], word[4], rank[4], sbit[4], sw[4], old1[4], old2[4], h[4], owner[4];
-                bool cand[4], later[4];
+                uint32_t u[4], word[4], rank[4], ri[4], pos[4];
+                bool cand[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) u[e] = e < nvalid ? (uint32_t)u4[e] : 0u;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) word[e] = bm[u[e] >> 5];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) rank[e] = base32[u[e] >> 8] + pre8[u[e] >> 5];
+                for (int e = 0; e < 4; ++e) {
+                    rank[e] = base32[u[e] >> 8] + pre8[u[e] >> 5];
+                    ri[e] = rinfo[u[e] >> range_shift];
+                }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     cand[e] = e < nvalid && ((word[e] >> (u[e] & 31)) & 1u);
                     rank[e] += __popc(word[e] & ((1u << (u[e] & 31)) - 1u));
-                    const uint32_t sb = rank[e] >> shift;
-                    sbit[e] = cand[e] ? 1u << (sb & 31) : 0u;
-                    sw[e] = cand[e] ? sb >> 5 : 0u;
                 }
 #pragma unroll
-                for (int e = 0; e < 4; ++e) old1[e] = atomicOr(&seen[sw[e]], sbit[e]);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) old2[e] = atomicOr(&seen2[sw[e]], old1[e] & sbit[e]);  // only if seen before
-                // Third and later paths: the candidates with the longest chains (a hub pair has thousands of common
-                // neighbours, and atomics on ONE address serialise at the memory side) come back in almost every row, so
-                // they are the first to ask for an entry of the LDS table and keep it for the column; a candidate that
-                // finds its entry taken uses the global accumulator throughout.
-                bool any_later = false;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    later[e] = (old1[e] & old2[e] & sbit[e]) != 0u;
-                    any_later |= later[e];
-                    h[e] = later[e] ? (rank[e] * 2654435761u) >> 22 : (uint32_t)(lane + 64 * e);
-                    owner[e] = rank[e] + 1u;              // "not mine" unless the CAS below says otherwise
-                }
-                if (__any(any_later)) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)           // a lane without a later path compares with a value no key can hold
-                        owner[e] = atomicCAS(&hot_key[h[e]], later[e] ? EX_HOT_EMPTY : 0xFFFFFFFEu, rank[e]);
-                }
+                for (int e = 0; e < 4; ++e) pos[e] = cand[e] ? atomicAdd(&tile_cur[ri[e] >> 20], 1u) : 0u;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     if (!cand[e]) continue;
-                    const int64_t slot = base_off + rank[e];
-                    const bool first = !(old1[e] & sbit[e]);
-                    const bool second = !first && !(old2[e] & sbit[e]);
-                    const bool hot = later[e] && (owner[e] == EX_HOT_EMPTY || owner[e] == rank[e]);
-                    if (out_cn) {
-                        if (first) out_cn[slot] = 1;
-                        else if (second) cn_second[slot] = 1;
-                        else if (hot) atomicAdd(&hot_cn[h[e]], 1u);
-                        else atomicAdd(&cn_later[slot], 1);
-                    }
-                    if (out_score) {
-                        float term = vw;                  // A[u,w] * (A[v,w] * node_w[w]), float32 like the reference
-                        if (HAS_VAL) term = val[wb + base + e] * vw;
-                        if (first) out_score[slot] = term;
-                        else if (second) score_second[slot] = term;
-                        else if (hot) atomicAdd(&hot_acc[h[e]], (unsigned long long)ex_to_fixed(term));
-                        else atomicAdd(&score_later[slot], (unsigned long long)ex_to_fixed(term));
-                    }
+                    float term = vw;                      // A[u,w] * (A[v,w] * node_w[w]), float32 like the reference
+                    if (HAS_VAL) term = val[wb + base_e + e] * vw;
+                    my_scratch[pos[e]] = make_uint2(rank[e] - (ri[e] & 0xFFFFFu), __builtin_bit_cast(uint32_t, term));
                 }
             });
-            XSTAMP(t6);
-            XSTAMP_ADD(5, t5, t6);
-            __syncthreads();
-            XSTAMP(t7);
-            XSTAMP_ADD(6, t6, t7);
-            for (int i = tid; i <= (ncand >> shift) / 32; i += EX_THREADS) seen[i] = seen2[i] = 0u;
-            for (int i = tid; i < EX_HOT; i += EX_THREADS) {  // the owner of an entry is the only writer of its slot
-                const uint32_t r = hot_key[i];
-                if (r != EX_HOT_EMPTY) {
-                    if (out_score) score_later[base_off + r] = hot_acc[i];
-                    if (out_cn) cn_later[base_off + r] = (int32_t)hot_cn[i];
-                    hot_acc[i] = 0ull;
-                    hot_key[i] = EX_HOT_EMPTY;
-                    hot_cn[i] = 0u;
-                }
+        XSTAMP(t6);
+        XSTAMP_ADD(5, t5, t6);
+
+        // ---- D2. per tile: bucket -> fixed-point sums and counts in LDS -> coalesced float32 scores / int32 counts ----------
+        for (int t = 0; t < n_tiles; ++t) {
+            const uint32_t r0 = tile_r0[t], nslots = tile_r0[t + 1] - r0;
+            const uint32_t b0 = tile_base[t], n = tile_cur[t] - b0;
+            for (uint32_t i = tid; i < nslots; i += EX_THREADS) {
+                acc[i] = 0ull;
+                cnt[i] = 0u;
             }
+            __syncthreads();
+            for (uint32_t i = tid; i < n; i += EX_THREADS) {
+                const uint2 rec = my_scratch[b0 + i];
+                if (out_score)
+                    atomicAdd(&acc[rec.x], (unsigned long long)ex_to_fixed(__builtin_bit_cast(float, rec.y)));
+                if (out_cn) atomicAdd(&cnt[rec.x], 1u);
+            }
+            __syncthreads();
+            for (uint32_t i = tid; i < nslots; i += EX_THREADS) {
+                if (out_score)
+                    out_score[base + r0 + i] = (float)((double)(long long)acc[i] * (1.0 / (double)(1ll << EX_FIXED_SHIFT)));
+                if (out_cn) out_cn[base + r0 + i] = (int32_t)cnt[i];
+            }
+            __syncthreads();
         }
-        for (int i = 0; i < wpt; ++i) bm[w0 + i] = 0u;
+        XSTAMP(t7);
+        XSTAMP_ADD(6, t6, t7);
+        for (int i = 0; i < wpt; ++i) bm[w0 + i] = 0u;   // D2 left its accumulators in the bitmap's space
         XSTAMP(t8);
         XSTAMP_ADD(7, t4, t8);
     }
@@ -419,22 +423,6 @@ __global__ __launch_bounds__(EX_THREADS) void expand_kernel(
     if (FILL && tid == 0)
         for (int i = 0; i < 8; ++i) atomicAdd(&g_ex_stamp[i], xst[i]);
 #endif
-}
-
-// Completes score[] / cn[] of a fill launch: adds what the second and the later paths of a candidate left in the scratch
-// arrays.  Every term goes through the same fixed-point conversion, so the sum does not depend on which path came first.
-__global__ void expand_finish_kernel(int64_t n, int32_t *__restrict__ cn, const int32_t *__restrict__ cn_second,
-                                     const int32_t *__restrict__ cn_later, float *__restrict__ score,
-                                     const float *__restrict__ score_second, const long long *__restrict__ score_later)
-{
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        if (score) {
-            const long long t = ex_to_fixed(score[i]) + ex_to_fixed(score_second[i]) + score_later[i];
-            score[i] = (float)((double)t * (1.0 / (double)(1ll << EX_FIXED_SHIFT)));
-        }
-        if (cn) cn[i] = cn[i] + cn_second[i] + cn_later[i];
-    }
 }
 
 static int expand_words_per_thread(int64_t n_nodes)
@@ -445,39 +433,20 @@ static int expand_words_per_thread(int64_t n_nodes)
 
 extern "C" int eps_expand_max_nodes(void) { return EX_MAX_WPT * EX_THREADS * 32; }
 
-// The fill kernel always takes EX_FILL_LDS bytes: bitmap 4 B + group bases 0.5 B + byte ranks 1 B per word, the hot
-// table (16 B per entry), and the two arrival bitmaps share what is left.
-static int expand_seen_words(int wpt) { return (int)((EX_FILL_LDS - (size_t)wpt * EX_THREADS * 11 / 2 - EX_HOT * 16) / 8); }
-
-// Scratch layout behind eps_expand_workspace_bytes: [score_later i64 x n][score_second f32 x n] then
-// [cn_second i32 x n][cn_later i32 x n], each part only when requested.
-struct ExpandScratch {
-    long long *score_later = nullptr;
-    float *score_second = nullptr;
-    int32_t *cn_second = nullptr, *cn_later = nullptr;
-};
-static ExpandScratch expand_scratch(void *workspace, int64_t n, bool want_cn, bool want_score)
+// id ranges of the path histogram: at most EX_RANGES of them, each a whole number of 256-id groups and no wider than
+// EX_TILE / 2 ids (so a range never holds more candidates than half a tile)
+static int expand_range_shift(int64_t n_nodes)
 {
-    ExpandScratch w;
-    char *p = (char *)workspace;
-    if (want_score) {
-        w.score_later = (long long *)p;
-        p += n * 8;
-        w.score_second = (float *)p;
-        p += n * 4;
-    }
-    if (want_cn) {
-        w.cn_second = (int32_t *)p;
-        p += n * 4;
-        w.cn_later = (int32_t *)p;
-    }
-    return w;
+    int s = 8;
+    while (((n_nodes - 1) >> s) + 1 > EX_RANGES) ++s;
+    return s;
 }
 
-extern "C" int64_t eps_expand_workspace_bytes(int64_t n_cand, int want_cn, int want_score)
+// words of the LDS region shared by {bitmap, group bases, byte ranks} and {tile accumulators, tile counters}
+static int expand_region_words(int wpt)
 {
-    if (n_cand < 0) return 0;
-    return n_cand * ((want_score ? 12 : 0) + (want_cn ? 8 : 0));
+    const int a = wpt * EX_THREADS * 11 / 8, b = 3 * EX_TILE;
+    return a > b ? a : b;
 }
 
 extern "C" int eps_expand_count(const int64_t *rowptr, const int32_t *col, int64_t n_nodes, int64_t v_lo, int64_t v_hi,
@@ -499,27 +468,37 @@ extern "C" int eps_expand_count(const int64_t *rowptr, const int32_t *col, int64
         eps_set_error("eps_expand_count: cannot reserve %zu bytes of LDS", lds);
         return EPS_ELAUNCH;
     }
-    int64_t blocks = (int64_t)eps_num_cus() * (lds * 2 + 1024 <= 163840 ? 2 : 1);
+    int64_t blocks = (int64_t)eps_num_cus() * (lds * 2 + 2 * 8192 <= 163840 ? 2 : 1);
     if (blocks > v_hi - v_lo) blocks = v_hi - v_lo;
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(EX_THREADS), lds, s, rowptr, col, (const float *)nullptr,
-                       (const float *)nullptr, (int32_t)v_lo, (int32_t)v_hi, col_order, wpt, counter, cand_count,
-                       (const int64_t *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr, 0, (int32_t *)nullptr,
-                       (int32_t *)nullptr, (int32_t *)nullptr, (float *)nullptr, (float *)nullptr,
-                       (unsigned long long *)nullptr);
+                       (const float *)nullptr, (int32_t)n_nodes, (int32_t)v_lo, (int32_t)v_hi, col_order, wpt, counter,
+                       cand_count, (const int64_t *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr, 8, EX_TILE / 2, 0,
+                       (uint2 *)nullptr, (int64_t)0, (int32_t *)nullptr, (float *)nullptr, (unsigned int *)nullptr);
     EPS_CHECK_LAUNCH("eps_expand_count");
     return EPS_OK;
 }
 
+// Workspace of a fill launch: 8 bytes of status (device word 0: non-zero after the launch = a column had more two-hop
+// paths than the buckets were sized for, outputs invalid) + one bucket area per workgroup, 8 bytes per path of the
+// heaviest column.
+extern "C" int64_t eps_expand_workspace_bytes(int64_t max_col_paths)
+{
+    if (max_col_paths < 0) return 0;
+    return 8 + (int64_t)eps_num_cus() * max_col_paths * 8;
+}
+
 extern "C" int eps_expand_fill(const int64_t *rowptr, const int32_t *col, const float *val, const float *node_w,
                                int64_t n_nodes, int64_t v_lo, int64_t v_hi, const int32_t *col_order,
-                               const int64_t *colptr, int64_t n_cand, int32_t *cand_u, int32_t *cand_v, int32_t *cn,
-                               float *score, void *workspace, void *stream)
+                               const int64_t *colptr, int32_t *cand_u, int32_t *cand_v, int32_t *cn, float *score,
+                               void *workspace, int64_t workspace_bytes, void *stream)
 {
     EPS_REQUIRE(n_nodes >= 0 && v_lo >= 0 && v_hi >= v_lo && v_hi <= n_nodes, "eps_expand_fill: bad column range");
     if (v_hi == v_lo) return EPS_OK;
-    EPS_REQUIRE(rowptr && col && colptr && cand_u && n_cand >= 0, "eps_expand_fill: null pointer");
-    EPS_REQUIRE(workspace || !(cn || score) || n_cand == 0, "eps_expand_fill: cn / score need the zeroed workspace");
-    EPS_REQUIRE(((uintptr_t)workspace & 7) == 0, "eps_expand_fill: workspace must be 8-byte aligned");
+    EPS_REQUIRE(rowptr && col && colptr && cand_u, "eps_expand_fill: null pointer");
+    EPS_REQUIRE(n_nodes < (1ll << 20), "eps_expand_fill: candidate ranks are packed in 20 bits");
+    const bool scored = cn || score;
+    EPS_REQUIRE(!scored || (workspace && workspace_bytes >= 8 && ((uintptr_t)workspace & 7) == 0),
+                "eps_expand_fill: cn / score need an 8-byte aligned workspace (eps_expand_workspace_bytes)");
     const int wpt = expand_words_per_thread(n_nodes);
     EPS_REQUIRE(wpt <= EX_MAX_WPT, "eps_expand_fill: %lld nodes exceed the LDS bitmap (max %d)",
                 (long long)n_nodes, eps_expand_max_nodes());
@@ -527,15 +506,21 @@ extern "C" int eps_expand_fill(const int64_t *rowptr, const int32_t *col, const 
     unsigned int *counter = nullptr;
     int rc = eps_take_counter(&counter, s, "eps_expand_fill");
     if (rc) return rc;
-    const size_t lds = EX_FILL_LDS;
-    int seen_words = expand_seen_words(wpt);
-    if (const char *dbg = getenv("EPS_DEBUG_SEEN_WORDS")) {  // tests: force the shared-bit path on small graphs
-        const int v = atoi(dbg);
-        if (v >= 1 && v < seen_words) seen_words = v;
-    }
-    const ExpandScratch ws = expand_scratch(workspace, n_cand, cn != nullptr, score != nullptr);
+    const int region_words = expand_region_words(wpt);
+    const size_t lds = ((size_t)region_words + EX_TABLE_WORDS) * 4;
     int64_t blocks = eps_num_cus();
+    const int64_t per_block = scored ? (workspace_bytes - 8) / 8 / blocks : 0;   // records per workgroup (sized for all CUs)
     if (blocks > v_hi - v_lo) blocks = v_hi - v_lo;
+    if (scored && hipMemsetAsync(workspace, 0, 8, s) != hipSuccess) {
+        eps_set_error("eps_expand_fill: cannot reset the status word");
+        return EPS_ELAUNCH;
+    }
+    const int range_shift = expand_range_shift(n_nodes);
+    int tile_half = EX_TILE / 2;
+    if (const char *dbg = getenv("EPS_DEBUG_TILE_HALF")) {  // tests: many small tiles on small graphs
+        const int v = atoi(dbg);
+        if (v >= (1 << range_shift) && v < tile_half) tile_half = v;
+    }
     const bool hv = val != nullptr, hw = node_w != nullptr;
 #define EX_LAUNCH(HV, HW)                                                                                              \
     do {                                                                                                               \
@@ -546,9 +531,10 @@ extern "C" int eps_expand_fill(const int64_t *rowptr, const int32_t *col, const 
             return EPS_ELAUNCH;                                                                                        \
         }                                                                                                              \
         hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(EX_THREADS), lds, s, rowptr, col, val, node_w,           \
-                           (int32_t)v_lo, (int32_t)v_hi, col_order, wpt, counter, (int64_t *)nullptr, colptr, cand_u,  \
-                           cand_v, seen_words, cn, ws.cn_second, ws.cn_later, score, ws.score_second,                  \
-                           (unsigned long long *)ws.score_later);                                                      \
+                           (int32_t)n_nodes, (int32_t)v_lo, (int32_t)v_hi, col_order, wpt, counter, (int64_t *)nullptr,\
+                           colptr, cand_u, cand_v, range_shift, tile_half, region_words,                                       \
+                           scored ? (uint2 *)((char *)workspace + 8) : (uint2 *)nullptr, per_block, cn, score,         \
+                           (unsigned int *)workspace);                                                                 \
     } while (0)
     if (hv && hw) EX_LAUNCH(true, true);
     else if (hv) EX_LAUNCH(true, false);
@@ -556,21 +542,5 @@ extern "C" int eps_expand_fill(const int64_t *rowptr, const int32_t *col, const 
     else EX_LAUNCH(false, false);
 #undef EX_LAUNCH
     EPS_CHECK_LAUNCH("eps_expand_fill");
-    return EPS_OK;
-}
-
-extern "C" int eps_expand_finish(int64_t n_cand, int32_t *cn, float *score, const void *workspace, void *stream)
-{
-    EPS_REQUIRE(n_cand >= 0, "eps_expand_finish: negative size");
-    if (n_cand == 0 || (!cn && !score)) return EPS_OK;
-    EPS_REQUIRE(workspace, "eps_expand_finish: null workspace");
-    const ExpandScratch ws = expand_scratch((void *)workspace, n_cand, cn != nullptr, score != nullptr);
-    int64_t b = (n_cand + 255) / 256;
-    const int64_t cap = (int64_t)eps_num_cus() * 8;
-    if (b > cap) b = cap;
-    hipLaunchKernelGGL(expand_finish_kernel, dim3((unsigned)b), dim3(256), 0, (hipStream_t)stream, n_cand, cn,
-                       (const int32_t *)ws.cn_second, (const int32_t *)ws.cn_later, score, (const float *)ws.score_second,
-                       (const long long *)ws.score_later);
-    EPS_CHECK_LAUNCH("eps_expand_finish");
     return EPS_OK;
 }

@@ -132,21 +132,36 @@ def expand_max_nodes() -> int:
 _EXPAND_WS = {}
 
 
-def _expand_scratch(dev, n_words: int) -> torch.Tensor:
-    """Zeroed int64[n_words] scratch of the fill / finish pair: one grow-only buffer per device, reused by every block
-    of a filter run (a fresh multi-GB allocation per block costs more than zeroing it).  Stream-ordered like any other
-    tensor on the current stream (the next block's zero-fill is queued behind the previous block's finish kernel), so
-    expansions of one device must not run concurrently on several streams."""
+def _expand_scratch(dev, n_bytes: int) -> torch.Tensor:
+    """int64 scratch of the fill kernel (status word + per-workgroup path buckets): one grow-only buffer per device,
+    reused by every block of a filter run (a fresh multi-GB allocation per block costs more than the kernel saves).
+    Stream-ordered like any other tensor on the current stream, so expansions of one device must not run concurrently
+    on several streams."""
     key = (dev.type, dev.index)
+    n_words = (n_bytes + 7) // 8
     buf = _EXPAND_WS.get(key)
     if buf is None or buf.numel() < n_words:
         _EXPAND_WS.pop(key, None)
         buf = None                                   # let the old buffer go before the larger one is allocated
         buf = torch.empty(int(n_words * 1.25) + 1024, dtype=torch.int64, device=dev)
         _EXPAND_WS[key] = buf
-    ws = buf[:n_words]
-    ws.zero_()
-    return ws
+    return buf
+
+
+def max_column_paths(rowptr: torch.Tensor, col: torch.Tensor, v_lo: int, v_hi: int) -> int:
+    """max over the columns v of [v_lo, v_hi) of sum_{w in N(v)} deg(w): the two-hop paths of the heaviest column, which
+    sizes the per-workgroup buckets of the fused expansion."""
+    if v_hi <= v_lo:
+        return 0
+    deg = rowptr[1:] - rowptr[:-1]
+    lo, hi = int(rowptr[v_lo].item()), int(rowptr[v_hi].item())
+    if hi == lo:
+        return 0
+    dsum = torch.cumsum(deg[col[lo:hi].long()], 0)
+    ends = rowptr[v_lo + 1:v_hi + 1] - lo                      # exclusive end of every column's slice
+    upto = torch.where(ends > 0, dsum[(ends - 1).clamp(min=0)], torch.zeros_like(ends))
+    per_col = upto - torch.cat([upto.new_zeros(1), upto[:-1]])
+    return int(per_col.max().item())
 
 
 class ExpandResult(tuple):
@@ -155,13 +170,17 @@ class ExpandResult(tuple):
     pairs = None
 
 
+_EXPAND_WS_LIMIT = 96 << 30       # bytes of bucket scratch we are willing to hold on a 288 GB device
+
+
 def expand_candidates(rowptr, col, val, node_w, n_nodes: int, v_lo: int, v_hi: int, want_cn=True, want_score=True,
-                      want_v=True, col_order=None):
+                      want_v=True, col_order=None, max_paths=None):
     """Fused 2-hop expansion of columns [v_lo, v_hi) of a SYMMETRIC adjacency (filter.py:96-109 + scoring).
     -> (colptr int64[n_cols+1], cand_u int32[E], cand_v int32[E] | None, cn int32[E] | None, score float32[E] | None);
     candidates are column-major, u ascending inside a column (the reference's order).  ``col_order`` (int32
     permutation of range(v_hi - v_lo), optional) is the order the columns are handed to the workgroups; the results
-    do not depend on it."""
+    do not depend on it.  ``max_paths`` (optional) is an upper bound of the two-hop paths of any column of the range
+    (``max_column_paths``; callers that expand many blocks of one graph pass the cached figure)."""
     dev = _need_gpu(rowptr, col, val, node_w, col_order)
     _chk(rowptr, torch.int64, "rowptr"); _chk(col, torch.int32, "col"); _chk(val, torch.float32, "val")
     _chk(node_w, torch.float32, "node_w"); _chk(col_order, torch.int32, "col_order")
@@ -179,18 +198,23 @@ def expand_candidates(rowptr, col, val, node_w, n_nodes: int, v_lo: int, v_hi: i
         pairs = torch.empty((2 if want_v else 1, total), dtype=torch.int32, device=dev)
         cand_u = pairs[0]
         cand_v = pairs[1] if want_v else None
-        # cn / score are written for every candidate by the first path that reaches it: no zero-fill; the scratch
-        # of the second / later paths must start at zero
         cn = torch.empty(total, dtype=torch.int32, device=dev) if want_cn else None
         score = torch.empty(total, dtype=torch.float32, device=dev) if want_score else None
-        ws_bytes = int(lib.eps_expand_workspace_bytes(total, int(want_cn), int(want_score)))
-        ws = _expand_scratch(dev, (ws_bytes + 7) // 8) if ws_bytes else None
+        ws, ws_bytes = None, 0
+        if total and (want_cn or want_score):
+            if max_paths is None:
+                max_paths = max_column_paths(rowptr, col, v_lo, v_hi)
+            ws_bytes = int(lib.eps_expand_workspace_bytes(int(max_paths)))
+            if ws_bytes > _EXPAND_WS_LIMIT:
+                raise _lib.EpsError(f"expand_candidates: a column with {max_paths} two-hop paths needs {ws_bytes >> 30} GiB "
+                                    "of bucket scratch; score such graphs with the pair kernels")
+            ws = _expand_scratch(dev, ws_bytes)
         if total:
             _lib.check(lib.eps_expand_fill(_ptr(rowptr), _ptr(col), _ptr(val), _ptr(node_w), n_nodes, v_lo, v_hi,
-                                           _ptr(col_order), _ptr(colptr), total, _ptr(cand_u), _ptr(cand_v), _ptr(cn),
-                                           _ptr(score), _ptr(ws), _stream(dev)), "eps_expand_fill")
-            _lib.check(lib.eps_expand_finish(total, _ptr(cn), _ptr(score), _ptr(ws), _stream(dev)),
-                       "eps_expand_finish")
+                                           _ptr(col_order), _ptr(colptr), _ptr(cand_u), _ptr(cand_v), _ptr(cn),
+                                           _ptr(score), _ptr(ws), ws_bytes, _stream(dev)), "eps_expand_fill")
+            if ws is not None and int(ws[0].item()) != 0:
+                raise _lib.EpsError("expand_candidates: a column had more two-hop paths than max_paths allows")
     out = ExpandResult((colptr, cand_u, cand_v, cn, score))
     out.pairs = pairs if want_v else None
     return out

@@ -100,29 +100,26 @@ int eps_pair_scores_grouped_f64(const int64_t *rowptr, const int32_t *col, const
  *                     columns v_lo + col_order[i] are handed to the workgroups.  Results do not
  *                     depend on it; heaviest-first shortens the tail of a launch.
  *   eps_expand_count: cand_count[v - v_lo] = number of 2-hop non-edges (u, v), v in [v_lo, v_hi).
- *   eps_expand_fill : colptr = exclusive prefix of cand_count (int64[n_cols+1], device), n_cand =
- *                     its last entry; writes cand_u (ascending inside a column == the reference's
- *                     order), cand_v (column id per candidate; optional) and, each optional, the
- *                     common-neighbour count cn (int32) and the weighted sum score (float32).
- *                     cn / score need `workspace`: eps_expand_workspace_bytes(n_cand, cn != NULL,
- *                     score != NULL) bytes, 8-byte aligned, ZEROED by the caller.  The first path
- *                     that reaches a candidate stores into cn / score, the second into the
- *                     workspace, later ones add to 64-bit accumulators there (few paths need the
- *                     atomics, which are what bounds the pass).
- *   eps_expand_finish: completes cn / score from the workspace of the fill launch (same n_cand and
- *                     the same cn / score pointers).  Scores are summed in 2^-40 fixed point:
- *                     integer addition makes the result independent of the arrival order. */
+ *   eps_expand_fill : colptr = exclusive prefix of cand_count (int64[n_cols+1], device); writes
+ *                     cand_u (ascending inside a column == the reference's order), cand_v (column
+ *                     id per candidate; optional) and, each optional, the common-neighbour count
+ *                     cn (int32) and the weighted sum score (float32); neither needs zeroing.
+ *                     cn / score need `workspace` (device, 8-byte aligned, contents arbitrary):
+ *                     eps_expand_workspace_bytes(P) bytes, P >= the largest number of two-hop
+ *                     paths sum_{w in N(v)} deg(w) of any column in the range.  The paths of a
+ *                     column are binned there by candidate-rank tile, then summed tile by tile in
+ *                     LDS in 2^-40 fixed point: integer addition makes the sums independent of the
+ *                     arrival order.  After the launch the first 4 bytes of the workspace are 0,
+ *                     or non-zero if P was too small (outputs invalid). */
 int eps_expand_max_nodes(void);
 int eps_expand_count(const int64_t *rowptr, const int32_t *col, int64_t n_nodes, int64_t v_lo,
                      int64_t v_hi, const int32_t *col_order, int64_t *cand_count, void *stream);
 int eps_expand_fill(const int64_t *rowptr, const int32_t *col, const float *val,
                     const float *node_w, int64_t n_nodes, int64_t v_lo, int64_t v_hi,
-                    const int32_t *col_order, const int64_t *colptr, int64_t n_cand,
-                    int32_t *cand_u, int32_t *cand_v, int32_t *cn, float *score, void *workspace,
-                    void *stream);
-int64_t eps_expand_workspace_bytes(int64_t n_cand, int want_cn, int want_score);
-int eps_expand_finish(int64_t n_cand, int32_t *cn, float *score, const void *workspace,
-                      void *stream);
+                    const int32_t *col_order, const int64_t *colptr, int32_t *cand_u,
+                    int32_t *cand_v, int32_t *cn, float *score, void *workspace,
+                    int64_t workspace_bytes, void *stream);
+int64_t eps_expand_workspace_bytes(int64_t max_col_paths);
 
 /* ---- K4/K5: CSR x dense SpMM with fused epilogue -----------------------------------------
  * Replaces torch_sparse spmm_sum / spmm_mean inside GCNConv / SAGEConv (models.py:183-186,

@@ -119,26 +119,40 @@ def _dense_symmetric(n, p, seed, weighted):
 
 @pytest.mark.parametrize("weighted", [False, True])
 def test_expand_dense_graph_many_paths_per_candidate(eps, oracle, dev, weighted):
-    """ddi-like density: every candidate is reached by dozens of paths, so nearly all terms take the third-and-later
-    route (LDS table of the hottest candidates + global accumulators for the rest)."""
+    """ddi-like density: every candidate is reached by dozens of paths (long accumulation chains per slot)."""
     A = _dense_symmetric(700, 0.12, 21, weighted)
     n_cand = _check(eps, oracle, dev, A, weighted=weighted)
     assert n_cand > 300_000
 
 
-def test_expand_arrival_bitmaps_shared_bits(eps, oracle, dev, monkeypatch):
-    """Columns with more candidates than arrival bits share one bit among neighbouring ranks: the classification of
-    first / second / later paths turns conservative but every slot still has one plain writer per array.  Forced here
-    with a 2-word bitmap (64 bits for ~600 candidates per column) and checked against the full-resolution result."""
+def test_expand_many_small_tiles(eps, oracle, dev, monkeypatch):
+    """The score pass bins the paths of a column by candidate-rank tile (8192 ranks in production, so small graphs
+    are single-tile).  Forced down to 256 / 512 ranks here: every column of the 700-node graph then spans several
+    tiles, and the outputs must not change."""
     from eps_amd.heuristics import node_weight_table
     A = _dense_symmetric(700, 0.05, 22, True)
     g = eps.CSRGraph.from_scipy(A, device=dev)
     wt = node_weight_table(g, eps.ops.W_AA)
     full = eps.ops.expand_candidates(g.rowptr, g.col, g.val, wt, g.n_rows, 0, g.n_rows)
-    for words in ("1", "2", "7"):
-        monkeypatch.setenv("EPS_DEBUG_SEEN_WORDS", words)
+    assert int((full[0][1:] - full[0][:-1]).max()) > 512
+    for half in ("256", "512"):
+        monkeypatch.setenv("EPS_DEBUG_TILE_HALF", half)
         got = eps.ops.expand_candidates(g.rowptr, g.col, g.val, wt, g.n_rows, 0, g.n_rows)
         for i in range(5):
-            assert torch.equal(full[i], got[i]), (words, i)
-    monkeypatch.delenv("EPS_DEBUG_SEEN_WORDS")
+            assert torch.equal(full[i], got[i]), (half, i)
+    monkeypatch.delenv("EPS_DEBUG_TILE_HALF")
     _check(eps, oracle, dev, A, weighted=True)
+
+
+def test_expand_rejects_undersized_buckets(eps, dev):
+    """max_paths below the heaviest column's path count: the kernel flags it instead of writing past its buckets."""
+    from eps_amd import synth
+    from eps_amd.heuristics import node_weight_table
+    g = synth.rmat_graph(10, 8, 4, dev)
+    wt = node_weight_table(g, eps.ops.W_AA)
+    true_max = eps.ops.max_column_paths(g.rowptr, g.col, 0, g.n_rows)
+    ok = eps.ops.expand_candidates(g.rowptr, g.col, None, wt, g.n_rows, 0, g.n_rows, max_paths=true_max)
+    auto = eps.ops.expand_candidates(g.rowptr, g.col, None, wt, g.n_rows, 0, g.n_rows)
+    assert torch.equal(ok[4], auto[4]) and torch.equal(ok[3], auto[3])
+    with pytest.raises(eps.EpsError):
+        eps.ops.expand_candidates(g.rowptr, g.col, None, wt, g.n_rows, 0, g.n_rows, max_paths=true_max // 2)

@@ -21,8 +21,8 @@ def timed(fn):
     e0.record(); r = fn(); e1.record(); torch.cuda.synchronize(); return e0.elapsed_time(e1), r
 for lo, hi in blocks:
     order = candidates.heaviest_first(g, lo, hi) if lpt else None
-    t_list, r = timed(lambda: ops.expand_candidates(g.rowptr, g.col, None, None, g.n_rows, lo, hi, want_cn=False, want_v=True, want_score=False, col_order=order))
-    t_sc, r2 = timed(lambda: ops.expand_candidates(g.rowptr, g.col, None, w, g.n_rows, lo, hi, want_cn=False, want_v=True, want_score=True, col_order=order))
+    t_list, r = timed(lambda: ops.expand_candidates(g.rowptr, g.col, None, None, g.n_rows, lo, hi, want_cn=False, want_v=True, want_score=False, col_order=order, max_paths=candidates.max_paths_of(g)))
+    t_sc, r2 = timed(lambda: ops.expand_candidates(g.rowptr, g.col, None, w, g.n_rows, lo, hi, want_cn=False, want_v=True, want_score=True, col_order=order, max_paths=candidates.max_paths_of(g)))
     p = paths[lo:hi]
     rows.append((lo, hi, r2[1].numel(), int(p.sum()), int(p.max()), int(deg[lo:hi].max()), t_list, t_sc))
     del r, r2

@@ -12,6 +12,6 @@ w = node_weight_table(g, ops.W_AA)
 lo, hi = list(candidates.column_blocks(g))[3]
 order = candidates.heaviest_first(g, lo, hi)
 for _ in range(int(os.environ.get("REPS", "2"))):
-    r = ops.expand_candidates(g.rowptr, g.col, None, w, g.n_rows, lo, hi, want_cn=False, want_score=True, col_order=order)
+    r = ops.expand_candidates(g.rowptr, g.col, None, w, g.n_rows, lo, hi, want_cn=False, want_score=True, col_order=order, max_paths=candidates.max_paths_of(g))
 torch.cuda.synchronize()
 print("candidates", r[1].numel(), "paths", int(candidates.path_counts(g)[lo:hi].sum()))

@@ -20,7 +20,7 @@ names = ["hand-out + barrier", "A mark + known edges out", "B scan", "C emit + b
          "D end barrier", "C..end of column"]
 for want_cn, want_score in ((False, True), (True, True), (False, False)):
     for rep in range(2):
-        ops.expand_candidates(g.rowptr, g.col, None, w, g.n_rows, lo, hi, want_cn=want_cn, want_score=want_score, col_order=order)
+        ops.expand_candidates(g.rowptr, g.col, None, w, g.n_rows, lo, hi, want_cn=want_cn, want_score=want_score, col_order=order, max_paths=candidates.max_paths_of(g))
         torch.cuda.synchronize()
         lib.eps_debug_expand_stamps(buf, 1)
     tot = sum(buf[i] for i in (0, 1, 2, 7))

@@ -25,7 +25,7 @@ for name, args in {"expand+score": (False, True), "expand+score+topk": (True, Tr
 # raw kernels without the python-side stack/long conversions
 torch.cuda.synchronize(); t0 = time.perf_counter(); n = 0
 for lo, hi in blocks:
-    r = ops.expand_candidates(g.rowptr, g.col, None, w, g.n_rows, lo, hi, want_cn=False, want_v=True)
+    r = ops.expand_candidates(g.rowptr, g.col, None, w, g.n_rows, lo, hi, want_cn=False, want_v=True, max_paths=candidates.max_paths_of(g))
     n += r[1].numel()
 torch.cuda.synchronize(); dt = time.perf_counter() - t0
 print(f"{'ops.expand (u,v,score)':20s} {dt:.3f} s  {n / dt / 1e9:.2f} G cand/s")
