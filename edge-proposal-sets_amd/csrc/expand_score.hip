@@ -258,9 +258,11 @@ __global__ __launch_bounds__(EX_THREADS) void expand_kernel(
         XSTAMP_ADD(1, t1, t2);
 
         // ---- B. rank: exclusive prefix of the per-word popcounts ---------------------------------
-        const int w0 = tid * wpt;
+        // Word layout: wave i owns the words [i * 64 * wpt, (i + 1) * 64 * wpt); in trip t its 64 lanes read 64 CONSECUTIVE
+        // words, so the candidates a wave emits in one trip are consecutive in rank and their stores land in a few lines.
+        const int w0 = wib * 64 * wpt + lane;      // this thread's words: w0 + 64 * t
         int local = 0;
-        for (int i = 0; i < wpt; ++i) local += __popc(bm[w0 + i]);
+        for (int i = 0; i < wpt; ++i) local += __popc(bm[w0 + 64 * i]);
         const int incl = wave_incl_scan(local, lane);
         if (lane == 63) s_wave_tot[wib] = incl;
         __syncthreads();
@@ -271,42 +273,44 @@ __global__ __launch_bounds__(EX_THREADS) void expand_kernel(
             if (i < wib) wave_base += t;
             total += t;
         }
-        int run = wave_base + incl - local;  // exclusive prefix of this thread's first word
         XSTAMP(t3);
         XSTAMP_ADD(2, t2, t3);
 
         if (!FILL) {
             if (tid == 0) cand_count[v - v_lo] = total;
-            for (int i = 0; i < wpt; ++i) bm[w0 + i] = 0u;
+            for (int i = 0; i < wpt; ++i) bm[w0 + 64 * i] = 0u;
             continue;
         }
 
-        // ---- C. emit the candidates of this column in ascending u ---------------------------------
+        // ---- C. emit the candidates of this column in ascending u; rank tables for pass D ---------------------------
         const int64_t base = colptr[v - v_lo];
-        const int run0 = run;
-        for (int i = 0; i < wpt; ++i) {
-            uint32_t bits = bm[w0 + i];
-            if (((w0 + i) & 7) == 0) base32[(w0 + i) >> 3] = (uint32_t)run;
-            while (bits) {
-                const int b = __builtin_ctz(bits);
-                bits &= bits - 1;
-                cand_u[base + run] = (w0 + i) * 32 + b;
-                ++run;
+        {
+            int wrun = wave_base;                  // rank of the first bit of the wave's current 64 words
+            for (int i = 0; i < wpt; ++i) {
+                const int wi = w0 + 64 * i;
+                uint32_t bits = bm[wi];
+                const int c = __popc(bits);
+                const int inc = wave_incl_scan(c, lane);
+                int run = wrun + inc - c;          // rank of this word's first bit
+                const int gbase = __shfl(run, lane & ~7);   // ... of its 8-word group's first bit (the 8 lanes are neighbours)
+                if ((lane & 7) == 0) base32[wi >> 3] = (uint32_t)run;
+                pre8[wi] = (uint8_t)(run - gbase);
+                while (bits) {
+                    const int b = __builtin_ctz(bits);
+                    bits &= bits - 1;
+                    cand_u[base + run] = wi * 32 + b;
+                    ++run;
+                }
+                wrun += __builtin_amdgcn_readlane(inc, 63);
             }
         }
         if (cand_v)  // one value for the whole column: whole lines, not one scattered store per candidate
             for (int i = tid; i < total; i += EX_THREADS) cand_v[base + i] = (int32_t)v;
-        __syncthreads();   // also orders the s_wave_tot reads above against the plan's scan below
-        run = run0;
-        for (int i = 0; i < wpt; ++i) {  // group bases are complete: ranks relative to them fit a byte
-            pre8[w0 + i] = (uint8_t)((uint32_t)run - base32[(w0 + i) >> 3]);
-            run += __popc(bm[w0 + i]);
-        }
+        __syncthreads();   // rank tables complete; also orders the s_wave_tot reads above against the plan's scan below
         XSTAMP(t4);
         XSTAMP_ADD(3, t3, t4);
         if (!want_d) {
-            __syncthreads();
-            for (int i = 0; i < wpt; ++i) bm[w0 + i] = 0u;
+            for (int i = 0; i < wpt; ++i) bm[w0 + 64 * i] = 0u;
             continue;
         }
 
@@ -415,7 +419,7 @@ __global__ __launch_bounds__(EX_THREADS) void expand_kernel(
         }
         XSTAMP(t7);
         XSTAMP_ADD(6, t6, t7);
-        for (int i = 0; i < wpt; ++i) bm[w0 + i] = 0u;   // D2 left its accumulators in the bitmap's space
+        for (int i = 0; i < wpt; ++i) bm[w0 + 64 * i] = 0u;   // D2 left its accumulators in the bitmap's space
         XSTAMP(t8);
         XSTAMP_ADD(7, t4, t8);
     }

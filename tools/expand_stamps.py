@@ -16,14 +16,14 @@ order = candidates.heaviest_first(g, lo, hi)
 lib = _lib.load()
 lib.eps_debug_expand_stamps.argtypes = [ctypes.c_void_p, ctypes.c_int]
 buf = (ctypes.c_ulonglong * 16)()
-names = ["hand-out + barrier", "A mark + known edges out", "B scan", "C emit + byte ranks", "D zero/shift", "D walk + score",
-         "D end barrier", "C..end of column"]
+names = ["hand-out + barrier", "A mark (+ histogram) + known edges out", "B scan", "C emit + byte ranks", "tile plan",
+         "D1 bin", "D2 per-tile sums + output", "plan..end of column"]
 for want_cn, want_score in ((False, True), (True, True), (False, False)):
     for rep in range(2):
         ops.expand_candidates(g.rowptr, g.col, None, w, g.n_rows, lo, hi, want_cn=want_cn, want_score=want_score, col_order=order, max_paths=candidates.max_paths_of(g))
         torch.cuda.synchronize()
         lib.eps_debug_expand_stamps(buf, 1)
-    tot = sum(buf[i] for i in (0, 1, 2, 7))
+    tot = sum(buf[i] for i in (0, 1, 2, 3, 7))
     print(f"--- want_cn={want_cn} want_score={want_score}: wave-0 cycles summed over workgroups = {tot}")
     for i, n in enumerate(names):
-        print(f"{n:28s} {buf[i]:>16d}  {100.0 * buf[i] / tot:6.2f}%")
+        print(f"{n:40s} {buf[i]:>16d}  {100.0 * buf[i] / tot:6.2f}%")
