@@ -41,6 +41,9 @@
 #define EX_THREADS 1024
 #define EX_WAVES (EX_THREADS / 64)
 #define EX_FIXED_SHIFT 40
+#ifndef EX_RING
+#define EX_RING 2           // first units of a wave's next rows in flight (1: 60 % slower list pass; 4, 8: no faster)
+#endif
 #define EX_LONGQ 1024       // rows longer than one unit queued per column and pass (static LDS)
 #define EX_MAX_WPT 26       // bitmap words per thread: 26 * 1024 words * 5.5 B = 143 KiB + 10 KiB of tables
 #define EX_RANGES 512       // id ranges per column: path histogram and tile plan
@@ -76,7 +79,7 @@ __device__ __forceinline__ int64_t ex_bcast64(int64_t x, int j)
 // A "unit" is 256 consecutive entries of one row (one 16-byte load per lane) and costs about the same whatever it
 // holds, so the work is balanced in units: wave i takes the FIRST unit of rows i, i+16, ... -- the row descriptors
 // (w, rowptr[w], rowptr[w+1]) of up to 64 of its rows fetched lane-parallel (one latency for the batch instead of a
-// dependent chain per row), the next row's unit in flight while the current one is consumed (raw buffer loads:
+// dependent chain per row), the units of the next EX_RING rows in flight while the current one is consumed (raw buffer loads:
 // out-of-range lanes read 0, no bounds branch) -- and the rows longer than one unit are queued in LDS; after a barrier
 // their remaining units are dealt round-robin over the waves.  (Row lengths are heavy-tailed: with whole rows per wave
 // the waves of a workgroup waited at the closing barrier for a third of the pass.)
@@ -95,37 +98,46 @@ __device__ __forceinline__ void for_each_path(const int64_t *__restrict__ rowptr
         const int32_t dw_mine = ok ? (int32_t)(rowptr[w_mine + 1] - wb_mine) : 0;
         const int left = (dv - b0 + EX_WAVES - 1) / EX_WAVES;
         const int nrows = left < 64 ? left : 64;
-        // ring of two rows: every ring register is written by one unconditional load per trip
-        __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(col + ex_bcast64(wb_mine, 0)), 0,
-                                                                       __builtin_amdgcn_readlane(dw_mine, 0) * 4, 0x00020000);
-        v4i nxt = __builtin_amdgcn_raw_buffer_load_b128(rs, lane * 16, 0, 0);
-        for (int j = 0; j < nrows; ++j) {
-            const int32_t dw = __builtin_amdgcn_readlane(dw_mine, j);
-            const int64_t wb = ex_bcast64(wb_mine, j);
-            const __amdgpu_buffer_rsrc_t rj = rs;
-            const v4i cur = nxt;
-            {
-                const int jn = (j + 1) & 63;
-                const int32_t dn = j + 1 < nrows ? __builtin_amdgcn_readlane(dw_mine, jn) : 0;
-                rs = __builtin_amdgcn_make_buffer_rsrc((void *)(col + ex_bcast64(wb_mine, jn)), 0, dn * 4, 0x00020000);
-                nxt = __builtin_amdgcn_raw_buffer_load_b128(rs, lane * 16, 0, 0);
-            }
-            const int k = b0 + EX_WAVES * j;
-            int nv = dw - 4 * lane;
-            body(k, wb, 4 * lane, cur, nv < 0 ? 0 : (nv > 4 ? 4 : nv));
-            if (dw > 256) {
-                int q = 0;
-                if (lane == 0) q = atomicAdd(s_nlong, 1);
-                q = __builtin_amdgcn_readfirstlane(q);
-                if (q < EX_LONGQ) {
-                    if (lane == 0) s_long[q] = k;
-                } else {  // queue full (a hub column with thousands of long rows): finish this row here
-                    for (int e0 = 256; e0 < dw; e0 += 512) {
-                        const v4i x0 = __builtin_amdgcn_raw_buffer_load_b128(rj, lane * 16 + e0 * 4, 0, 0);
-                        const v4i x1 = __builtin_amdgcn_raw_buffer_load_b128(rj, lane * 16 + e0 * 4 + 1024, 0, 0);
-                        int n0 = dw - e0 - 4 * lane, n1 = n0 - 256;
-                        body(k, wb, e0 + 4 * lane, x0, n0 < 0 ? 0 : (n0 > 4 ? 4 : n0));
-                        if (e0 + 256 < dw) body(k, wb, e0 + 256 + 4 * lane, x1, n1 < 0 ? 0 : (n1 > 4 ? 4 : n1));
+        // ring of EX_RING rows in flight: every ring register is written by one unconditional load per trip (rows past
+        // the batch get a zero-length descriptor: the load returns zeros and costs nothing)
+        auto first_unit = [&](int jj) {
+            const int jl = jj & 63;
+            const int32_t dn = jj < nrows ? __builtin_amdgcn_readlane(dw_mine, jl) : 0;
+            const __amdgpu_buffer_rsrc_t rs =
+                __builtin_amdgcn_make_buffer_rsrc((void *)(col + ex_bcast64(wb_mine, jl)), 0, dn * 4, 0x00020000);
+            return __builtin_amdgcn_raw_buffer_load_b128(rs, lane * 16, 0, 0);
+        };
+        v4i ring[EX_RING];
+#pragma unroll
+        for (int r = 0; r < EX_RING; ++r) ring[r] = first_unit(r);
+        for (int j0 = 0; j0 < nrows; j0 += EX_RING) {
+#pragma unroll
+            for (int r = 0; r < EX_RING; ++r) {
+                const int j = j0 + r;
+                if (j >= nrows) break;
+                const int32_t dw = __builtin_amdgcn_readlane(dw_mine, j);
+                const int64_t wb = ex_bcast64(wb_mine, j);
+                const v4i cur = ring[r];
+                ring[r] = first_unit(j + EX_RING);
+                const int k = b0 + EX_WAVES * j;
+                int nv = dw - 4 * lane;
+                body(k, wb, 4 * lane, cur, nv < 0 ? 0 : (nv > 4 ? 4 : nv));
+                if (dw > 256) {
+                    int q = 0;
+                    if (lane == 0) q = atomicAdd(s_nlong, 1);
+                    q = __builtin_amdgcn_readfirstlane(q);
+                    if (q < EX_LONGQ) {
+                        if (lane == 0) s_long[q] = k;
+                    } else {  // queue full (a hub column with thousands of long rows): finish this row here
+                        const __amdgpu_buffer_rsrc_t rj =
+                            __builtin_amdgcn_make_buffer_rsrc((void *)(col + wb), 0, dw * 4, 0x00020000);
+                        for (int e0 = 256; e0 < dw; e0 += 512) {
+                            const v4i x0 = __builtin_amdgcn_raw_buffer_load_b128(rj, lane * 16 + e0 * 4, 0, 0);
+                            const v4i x1 = __builtin_amdgcn_raw_buffer_load_b128(rj, lane * 16 + e0 * 4 + 1024, 0, 0);
+                            int n0 = dw - e0 - 4 * lane, n1 = n0 - 256;
+                            body(k, wb, e0 + 4 * lane, x0, n0 < 0 ? 0 : (n0 > 4 ? 4 : n0));
+                            if (e0 + 256 < dw) body(k, wb, e0 + 256 + 4 * lane, x1, n1 < 0 ? 0 : (n1 > 4 ? 4 : n1));
+                        }
                     }
                 }
             }
