@@ -10,7 +10,7 @@
 // the sum of row lengths (~500 per candidate) an intersection per pair costs.
 //
 // One 1024-thread workgroup per column v (columns handed out dynamically):
-//   A. mark: for every w in N(v) (one wave each) and every u in N(w): set bit u of an LDS bitmap
+//   A. mark: for every w in N(v) and every u in N(w): set bit u of an LDS bitmap
 //      over the node ids; then clear the bits of N(v) and of v itself (known edges, diagonal).
 //   B. rank: per-word popcounts -> block-wide exclusive scan -> prefix[] in LDS; the total is the
 //      column's candidate count (kernel 1 stops here: counts -> host cumsum -> colptr).
@@ -245,8 +245,8 @@ __global__ __launch_bounds__(EX_THREADS) void expand_kernel(
         const int64_t vb = rowptr[v];
         const int32_t dv = (int32_t)(rowptr[v + 1] - vb);
         const int32_t *__restrict__ vcol = col + vb;
-        if (dv == 0) {  // no neighbours -> no candidates
-            if (!FILL && tid == 0) cand_count[v - v_lo] = 0;
+        if (dv == 0) {  // no neighbours -> no candidates (and no paths: an empty segment in either layout)
+            if (cand_count && tid == 0) cand_count[v - v_lo] = 0;
             continue;
         }
 
@@ -295,7 +295,25 @@ __global__ __launch_bounds__(EX_THREADS) void expand_kernel(
         }
 
         // ---- C. emit the candidates of this column in ascending u; rank tables for pass D ---------------------------
+        // colptr may be an UPPER-BOUND layout (segments at least as long as the column's candidate count, e.g. a prefix
+        // of the two-hop path counts, which needs no counting pass): then cand_count receives the real count and the
+        // rest of the segment is padded (score -inf, cn 0, cand_u -1) so that the arrays stay in candidate order.
         const int64_t base = colptr[v - v_lo];
+        const int64_t seg_len = colptr[v - v_lo + 1] - base;
+        if (cand_count && tid == 0) cand_count[v - v_lo] = total;
+        if (total > seg_len) {                     // the caller's bound does not hold: flag it, leave the column out
+            if (tid == 0 && overflow) atomicOr(overflow, 2u);
+            __syncthreads();
+            for (int i = 0; i < wpt; ++i) bm[w0 + 64 * i] = 0u;
+            if (tid < EX_RANGES) hist[tid] = 0u;
+            continue;
+        }
+        for (int64_t i = total + tid; i < seg_len; i += EX_THREADS) {
+            cand_u[base + i] = -1;
+            if (cand_v) cand_v[base + i] = (int32_t)v;
+            if (out_score) out_score[base + i] = -__builtin_inff();
+            if (out_cn) out_cn[base + i] = 0;
+        }
         {
             int wrun = wave_base;                  // rank of the first bit of the wave's current 64 words
             for (int i = 0; i < wpt; ++i) {
@@ -494,9 +512,9 @@ extern "C" int eps_expand_count(const int64_t *rowptr, const int32_t *col, int64
     return EPS_OK;
 }
 
-// Workspace of a fill launch: 8 bytes of status (device word 0: non-zero after the launch = a column had more two-hop
-// paths than the buckets were sized for, outputs invalid) + one bucket area per workgroup, 8 bytes per path of the
-// heaviest column.
+// Workspace of a fill launch: 8 bytes of status (device word 0, non-zero after the launch = outputs invalid: bit 0 a
+// column had more two-hop paths than the buckets were sized for, bit 1 a column had more candidates than its colptr
+// segment) + one bucket area per workgroup, 8 bytes per path of the heaviest column (none needed without cn / score).
 extern "C" int64_t eps_expand_workspace_bytes(int64_t max_col_paths)
 {
     if (max_col_paths < 0) return 0;
@@ -505,16 +523,16 @@ extern "C" int64_t eps_expand_workspace_bytes(int64_t max_col_paths)
 
 extern "C" int eps_expand_fill(const int64_t *rowptr, const int32_t *col, const float *val, const float *node_w,
                                int64_t n_nodes, int64_t v_lo, int64_t v_hi, const int32_t *col_order,
-                               const int64_t *colptr, int32_t *cand_u, int32_t *cand_v, int32_t *cn, float *score,
-                               void *workspace, int64_t workspace_bytes, void *stream)
+                               const int64_t *colptr, int64_t *cand_count, int32_t *cand_u, int32_t *cand_v, int32_t *cn,
+                               float *score, void *workspace, int64_t workspace_bytes, void *stream)
 {
     EPS_REQUIRE(n_nodes >= 0 && v_lo >= 0 && v_hi >= v_lo && v_hi <= n_nodes, "eps_expand_fill: bad column range");
     if (v_hi == v_lo) return EPS_OK;
     EPS_REQUIRE(rowptr && col && colptr && cand_u, "eps_expand_fill: null pointer");
     EPS_REQUIRE(n_nodes < (1ll << 20), "eps_expand_fill: candidate ranks are packed in 20 bits");
     const bool scored = cn || score;
-    EPS_REQUIRE(!scored || (workspace && workspace_bytes >= 8 && ((uintptr_t)workspace & 7) == 0),
-                "eps_expand_fill: cn / score need an 8-byte aligned workspace (eps_expand_workspace_bytes)");
+    EPS_REQUIRE(workspace && workspace_bytes >= 8 && ((uintptr_t)workspace & 7) == 0,
+                "eps_expand_fill: needs an 8-byte aligned workspace (eps_expand_workspace_bytes)");
     const int wpt = expand_words_per_thread(n_nodes);
     EPS_REQUIRE(wpt <= EX_MAX_WPT, "eps_expand_fill: %lld nodes exceed the LDS bitmap (max %d)",
                 (long long)n_nodes, eps_expand_max_nodes());
@@ -527,7 +545,7 @@ extern "C" int eps_expand_fill(const int64_t *rowptr, const int32_t *col, const 
     int64_t blocks = eps_num_cus();
     const int64_t per_block = scored ? (workspace_bytes - 8) / 8 / blocks : 0;   // records per workgroup (sized for all CUs)
     if (blocks > v_hi - v_lo) blocks = v_hi - v_lo;
-    if (scored && hipMemsetAsync(workspace, 0, 8, s) != hipSuccess) {
+    if (hipMemsetAsync(workspace, 0, 8, s) != hipSuccess) {
         eps_set_error("eps_expand_fill: cannot reset the status word");
         return EPS_ELAUNCH;
     }
@@ -547,7 +565,7 @@ extern "C" int eps_expand_fill(const int64_t *rowptr, const int32_t *col, const 
             return EPS_ELAUNCH;                                                                                        \
         }                                                                                                              \
         hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(EX_THREADS), lds, s, rowptr, col, val, node_w,           \
-                           (int32_t)n_nodes, (int32_t)v_lo, (int32_t)v_hi, col_order, wpt, counter, (int64_t *)nullptr,\
+                           (int32_t)n_nodes, (int32_t)v_lo, (int32_t)v_hi, col_order, wpt, counter, cand_count,        \
                            colptr, cand_u, cand_v, range_shift, tile_half, region_words,                                       \
                            scored ? (uint2 *)((char *)workspace + 8) : (uint2 *)nullptr, per_block, cn, score,         \
                            (unsigned int *)workspace);                                                                 \

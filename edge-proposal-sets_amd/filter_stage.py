@@ -161,8 +161,12 @@ def run(args) -> str:
                 continue
             if keep:
                 top.push(pairs, score)          # blocks arrive in candidate (column-major) order
+            elif not isinstance(pairs, torch.Tensor):     # candidates.ColumnBlock, possibly padded
+                idx = pairs.valid()
+                all_pairs.append(pairs.select(idx))
+                all_scores.append(score[idx])
             else:
-                all_pairs.append(pairs.pairs() if (not isinstance(pairs, torch.Tensor)) else pairs)
+                all_pairs.append(pairs)
                 all_scores.append(score)
             n_seen += n_blk
     torch.cuda.synchronize(device)

@@ -166,57 +166,71 @@ def max_column_paths(rowptr: torch.Tensor, col: torch.Tensor, v_lo: int, v_hi: i
 
 class ExpandResult(tuple):
     """(colptr, cand_u, cand_v, cn, score) of ``expand_candidates``; ``.pairs`` is the int32 [2,E] buffer cand_u and
-    cand_v are rows of (None without cand_v), so the (u; v) list exists without a copy."""
+    cand_v are rows of (None without cand_v), so the (u; v) list exists without a copy; ``.counts`` is set in the
+    upper-bound layout (see ``expand_candidates``)."""
     pairs = None
+    counts = None
 
 
 _EXPAND_WS_LIMIT = 96 << 30       # bytes of bucket scratch we are willing to hold on a 288 GB device
 
 
 def expand_candidates(rowptr, col, val, node_w, n_nodes: int, v_lo: int, v_hi: int, want_cn=True, want_score=True,
-                      want_v=True, col_order=None, max_paths=None):
+                      want_v=True, col_order=None, max_paths=None, colptr_ub=None, total_ub=None):
     """Fused 2-hop expansion of columns [v_lo, v_hi) of a SYMMETRIC adjacency (filter.py:96-109 + scoring).
     -> (colptr int64[n_cols+1], cand_u int32[E], cand_v int32[E] | None, cn int32[E] | None, score float32[E] | None);
     candidates are column-major, u ascending inside a column (the reference's order).  ``col_order`` (int32
     permutation of range(v_hi - v_lo), optional) is the order the columns are handed to the workgroups; the results
     do not depend on it.  ``max_paths`` (optional) is an upper bound of the two-hop paths of any column of the range
-    (``max_column_paths``; callers that expand many blocks of one graph pass the cached figure)."""
-    dev = _need_gpu(rowptr, col, val, node_w, col_order)
+    (``max_column_paths``; callers that expand many blocks of one graph pass the cached figure).
+
+    ``colptr_ub`` (int64[n_cols+1] on the device) + ``total_ub`` (its last entry, as a Python int) select the
+    UPPER-BOUND layout: no counting pass and no host synchronisation before the launch; column v's candidates fill
+    the front of [colptr_ub[v], colptr_ub[v+1]) and the rest of the segment is padded (cand_u -1, score -inf, cn 0).
+    The result then carries ``.counts`` (int64[n_cols], real candidates per column) and E == total_ub."""
+    dev = _need_gpu(rowptr, col, val, node_w, col_order, colptr_ub)
     _chk(rowptr, torch.int64, "rowptr"); _chk(col, torch.int32, "col"); _chk(val, torch.float32, "val")
-    _chk(node_w, torch.float32, "node_w"); _chk(col_order, torch.int32, "col_order")
+    _chk(node_w, torch.float32, "node_w"); _chk(col_order, torch.int32, "col_order"); _chk(colptr_ub, torch.int64, "colptr_ub")
     lib = _lib.load()
     n_cols = v_hi - v_lo
     if col_order is not None and col_order.numel() != n_cols:
         raise ValueError("col_order must have one entry per column of the range")
-    colptr = torch.zeros(n_cols + 1, dtype=torch.int64, device=dev)
+    if colptr_ub is not None and (colptr_ub.numel() != n_cols + 1 or total_ub is None):
+        raise ValueError("colptr_ub needs n_cols + 1 entries and total_ub")
     with torch.cuda.device(dev):
         counts = torch.empty(n_cols, dtype=torch.int64, device=dev)
-        _lib.check(lib.eps_expand_count(_ptr(rowptr), _ptr(col), n_nodes, v_lo, v_hi, _ptr(col_order), _ptr(counts),
-                                        _stream(dev)), "eps_expand_count")
-        torch.cumsum(counts, 0, out=colptr[1:])
-        total = int(colptr[-1].item())
+        if colptr_ub is None:
+            colptr = torch.zeros(n_cols + 1, dtype=torch.int64, device=dev)
+            _lib.check(lib.eps_expand_count(_ptr(rowptr), _ptr(col), n_nodes, v_lo, v_hi, _ptr(col_order), _ptr(counts),
+                                            _stream(dev)), "eps_expand_count")
+            torch.cumsum(counts, 0, out=colptr[1:])
+            total = int(colptr[-1].item())
+        else:
+            colptr, total = colptr_ub, int(total_ub)
         pairs = torch.empty((2 if want_v else 1, total), dtype=torch.int32, device=dev)
         cand_u = pairs[0]
         cand_v = pairs[1] if want_v else None
         cn = torch.empty(total, dtype=torch.int32, device=dev) if want_cn else None
         score = torch.empty(total, dtype=torch.float32, device=dev) if want_score else None
-        ws, ws_bytes = None, 0
-        if total and (want_cn or want_score):
+        if total:
             if max_paths is None:
-                max_paths = max_column_paths(rowptr, col, v_lo, v_hi)
-            ws_bytes = int(lib.eps_expand_workspace_bytes(int(max_paths)))
+                max_paths = max_column_paths(rowptr, col, v_lo, v_hi) if (want_cn or want_score) else 0
+            ws_bytes = int(lib.eps_expand_workspace_bytes(int(max_paths) if (want_cn or want_score) else 0))
             if ws_bytes > _EXPAND_WS_LIMIT:
                 raise _lib.EpsError(f"expand_candidates: a column with {max_paths} two-hop paths needs {ws_bytes >> 30} GiB "
                                     "of bucket scratch; score such graphs with the pair kernels")
             ws = _expand_scratch(dev, ws_bytes)
-        if total:
             _lib.check(lib.eps_expand_fill(_ptr(rowptr), _ptr(col), _ptr(val), _ptr(node_w), n_nodes, v_lo, v_hi,
-                                           _ptr(col_order), _ptr(colptr), _ptr(cand_u), _ptr(cand_v), _ptr(cn),
-                                           _ptr(score), _ptr(ws), ws_bytes, _stream(dev)), "eps_expand_fill")
-            if ws is not None and int(ws[0].item()) != 0:
-                raise _lib.EpsError("expand_candidates: a column had more two-hop paths than max_paths allows")
+                                           _ptr(col_order), _ptr(colptr), _ptr(counts) if colptr_ub is not None else None,
+                                           _ptr(cand_u), _ptr(cand_v), _ptr(cn), _ptr(score), _ptr(ws), ws_bytes,
+                                           _stream(dev)), "eps_expand_fill")
+            status = int(ws[0].item()) & 0xFFFFFFFF
+            if status:
+                raise _lib.EpsError("expand_candidates: " + ("a column had more two-hop paths than max_paths allows; " if status & 1 else "")
+                                    + ("a column had more candidates than its colptr_ub segment" if status & 2 else ""))
     out = ExpandResult((colptr, cand_u, cand_v, cn, score))
     out.pairs = pairs if want_v else None
+    out.counts = counts if colptr_ub is not None else None
     return out
 
 

@@ -97,6 +97,11 @@ class StreamingTopK:
             if keep.numel() == 0:
                 return
             scores = scores[keep]
+        elif lazy and getattr(pairs, "padded", False):
+            keep = torch.nonzero(scores > float("-inf")).squeeze(1)       # drop the padding between the columns
+            if keep.numel() == 0:
+                return
+            scores = scores[keep]
         # every entry of the final top-K that comes from this block is among the block's own best K
         m = self._precut(scores, self.k)
         if m is not None:

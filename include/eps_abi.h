@@ -109,15 +109,22 @@ int eps_pair_scores_grouped_f64(const int64_t *rowptr, const int32_t *col, const
  *                     paths sum_{w in N(v)} deg(w) of any column in the range.  The paths of a
  *                     column are binned there by candidate-rank tile, then summed tile by tile in
  *                     LDS in 2^-40 fixed point: integer addition makes the sums independent of the
- *                     arrival order.  After the launch the first 4 bytes of the workspace are 0,
- *                     or non-zero if P was too small (outputs invalid). */
+ *                     arrival order (P = 0 without cn / score).  colptr may also be an UPPER-BOUND
+ *                     layout -- any non-decreasing int64[n_cols+1] whose segments are at least as
+ *                     long as the columns' candidate counts, e.g. the prefix of the two-hop path
+ *                     counts, which needs no eps_expand_count pass: cand_count (optional) then
+ *                     receives the real count per column and the rest of each segment is padded
+ *                     with cand_u = -1, score = -inf, cn = 0, so the arrays stay in candidate
+ *                     order.  After the launch the first 4 bytes of the workspace are 0, or
+ *                     non-zero if P (bit 0) or a colptr segment (bit 1) was too small: outputs
+ *                     invalid. */
 int eps_expand_max_nodes(void);
 int eps_expand_count(const int64_t *rowptr, const int32_t *col, int64_t n_nodes, int64_t v_lo,
                      int64_t v_hi, const int32_t *col_order, int64_t *cand_count, void *stream);
 int eps_expand_fill(const int64_t *rowptr, const int32_t *col, const float *val,
                     const float *node_w, int64_t n_nodes, int64_t v_lo, int64_t v_hi,
-                    const int32_t *col_order, const int64_t *colptr, int32_t *cand_u,
-                    int32_t *cand_v, int32_t *cn, float *score, void *workspace,
+                    const int32_t *col_order, const int64_t *colptr, int64_t *cand_count,
+                    int32_t *cand_u, int32_t *cand_v, int32_t *cn, float *score, void *workspace,
                     int64_t workspace_bytes, void *stream);
 int64_t eps_expand_workspace_bytes(int64_t max_col_paths);
 

@@ -181,3 +181,18 @@ def test_streaming_topk_lazy_column_block_cpu():
         a.push(pairs, scores + rep * (rep == 1)); b.push(blk, scores + rep * (rep == 1))
     pa, sa = a.result(); pb, sb = b.result()
     assert torch.equal(pa, pb) and torch.equal(sa, sb)
+    # the count-free layout: every column's segment is longer than its candidates, the rest is padding
+    slack = torch.randint(0, 7, (n_cols,), generator=g)
+    colptr_ub = torch.zeros(n_cols + 1, dtype=torch.int64); colptr_ub[1:] = torch.cumsum(counts + slack, 0)
+    e_ub = int(colptr_ub[-1])
+    pos = torch.repeat_interleave(colptr_ub[:-1] - colptr[:-1], counts) + torch.arange(e)     # where candidate i lands
+    u_pad = torch.full((e_ub,), -1, dtype=torch.int32); u_pad[pos] = cand_u
+    s_pad = torch.full((e_ub,), float("-inf")); s_pad[pos] = scores
+    padded = candidates.ColumnBlock(v_lo, colptr_ub, u_pad, None, s_pad, counts=counts)
+    assert padded.padded and padded.numel() == e and torch.equal(padded.pairs(), pairs)
+    for kk in (k, e + 5):                                                    # also K larger than the whole block
+        c, d = proposals.StreamingTopK(kk), proposals.StreamingTopK(kk)
+        for rep in range(3):
+            c.push(pairs, scores + rep * (rep == 1)); d.push(padded, s_pad + rep * (rep == 1))
+        pc, sc = c.result(); pd_, sd = d.result()
+        assert torch.equal(pc, pd_) and torch.equal(sc, sd)

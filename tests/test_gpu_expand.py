@@ -80,10 +80,25 @@ def test_expand_rmat_and_determinism(eps, oracle, dev):
     assert torch.equal(only_sc[4], a[4]) and only_sc[3] is None and only_sc[2] is None and only_sc.pairs is None
     assert torch.equal(bare[1], a[1]) and torch.equal(bare[2], a[2]) and torch.equal(bare.pairs[0], a[1])
     # the lazily paired block of the filter stage: same pairs as the materialised ones
-    blk = candidates.expand_block_lazy(gd, 0, gd.n_rows, wt, want_score=True)
-    assert torch.equal(blk.pairs(), torch.stack([a[1], a[2]]).long()) and torch.equal(blk.score, a[4])
-    idx = torch.tensor([0, 5, blk.numel() // 2, blk.numel() - 1], device=dev)
-    assert torch.equal(blk.select(idx), blk.pairs()[:, idx])
+    blk = candidates.expand_block_lazy(gd, 0, gd.n_rows, wt, want_score=True, count_free=True)
+    assert torch.equal(blk.pairs(), torch.stack([a[1], a[2]]).long())
+    pick = torch.tensor([0, 5, blk.numel() // 2, blk.numel() - 1], device=dev)
+    assert torch.equal(blk.select(blk.valid()[pick]), blk.pairs()[:, pick])
+    assert blk.padded, "no counting pass: segments sized by the path counts"
+    real = blk.valid()
+    assert torch.equal(blk.cand_u[real], a[1]) and torch.equal(blk.score[real], a[4])
+    assert torch.equal(blk.counts, a[0][1:] - a[0][:-1]) and blk.numel() == a[1].numel()
+    pad = torch.ones_like(blk.cand_u, dtype=torch.bool); pad[real] = False
+    assert bool((blk.cand_u[pad] == -1).all()) and bool(torch.isinf(blk.score[pad]).all()) and bool((blk.score[pad] < 0).all())
+    both = candidates.expand_block_lazy(gd, 0, gd.n_rows, wt, want_score=True, want_cn=True, count_free=True)
+    assert torch.equal(both.cn[real], a[3]) and bool((both.cn[pad] == 0).all())
+    tight = candidates.expand_block_lazy(gd, 0, gd.n_rows, wt, want_score=True)
+    assert not tight.padded and torch.equal(tight.cand_u, a[1]) and torch.equal(tight.score, a[4])
+    # a segment layout that is too small for some column is refused, not overrun
+    short = (a[0] // 2).contiguous()
+    with pytest.raises(eps.EpsError):
+        eps.ops.expand_candidates(gd.rowptr, gd.col, None, wt, gd.n_rows, 0, gd.n_rows, colptr_ub=short,
+                                  total_ub=int(short[-1]))
 
 
 def test_expand_matches_pair_kernel_at_scale(eps, dev):
