@@ -171,3 +171,52 @@ def test_expand_rejects_undersized_buckets(eps, dev):
     assert torch.equal(ok[4], auto[4]) and torch.equal(ok[3], auto[3])
     with pytest.raises(eps.EpsError):
         eps.ops.expand_candidates(g.rowptr, g.col, None, wt, g.n_rows, 0, g.n_rows, max_paths=true_max // 2)
+
+
+def test_expand_full_size_properties(eps, dev):
+    """BASELINE scale (ppa-like, N = 576,289), one production-sized launch (2^29 two-hop paths, ~4e8 candidates), no
+    oracle run: (1) a 2 M sample of the candidates re-scored by the column-run intersection kernel -- CN equal, AA within
+    the gate; (2) sum of CN == the paths that end in candidates, counted independently; (3) symmetry: (u,v) and (v,u)
+    are both candidates and carry bit-identical scores (integer accumulation does not depend on the path order)."""
+    from eps_amd import candidates, synth
+    from eps_amd.heuristics import node_weight_table
+    g = synth.ppa_like(seed=3, device=dev)
+    wt = node_weight_table(g, eps.ops.W_AA)
+    lo, hi = next(iter(candidates.column_blocks(g)))
+    r = eps.ops.expand_candidates(g.rowptr, g.col, None, wt, g.n_rows, lo, hi,
+                                  col_order=candidates.heaviest_first(g, lo, hi), max_paths=candidates.max_paths_of(g))
+    colptr, cu, cv, cn, sc = r
+    E = cu.numel()
+    assert E > 100_000_000 and int(colptr[-1]) == E
+    assert bool((cn >= 1).all()) and bool(torch.isfinite(sc).all()) and bool((sc > 0).all())
+    gen = torch.Generator(device=dev).manual_seed(3)
+    pick = torch.randint(0, E, (2_000_000,), generator=gen, device=dev)
+    cnt, _, ws = eps.ops.pair_scores(g.rowptr, g.col, None, wt, g.n_rows, cu[pick].contiguous(), cv[pick].contiguous(),
+                                     want_cn=False, grouped=False)
+    assert torch.equal(cnt, cn[pick])
+    assert rel_err(sc[pick].cpu().numpy(), ws.cpu().numpy()) <= 1e-5
+    # (2) every two-hop path of the block ends in a candidate, a neighbour of v, or v itself
+    paths = int(candidates.path_counts(g)[lo:hi].sum())
+    deg = g.degree()
+    rows = torch.repeat_interleave(torch.arange(lo, hi, device=dev), (g.rowptr[lo + 1:hi + 1] - g.rowptr[lo:hi]))
+    nb = g.col[g.rowptr[lo]:g.rowptr[hi]].long()
+    back_to_v = int(deg[lo:hi].sum())                       # v - w - v, one per neighbour w
+    cn_nb, _, _ = eps.ops.pair_scores(g.rowptr, g.col, None, None, g.n_rows, nb.to(torch.int32), rows.to(torch.int32),
+                                      want_cn=False)       # paths v - w - u with u a neighbour of v
+    assert int(cn.sum(dtype=torch.int64)) == paths - back_to_v - int(cn_nb.sum(dtype=torch.int64))
+    # (3) symmetry inside the block's column range
+    inside = pick[(cu[pick] >= lo) & (cu[pick] < hi)][:500_000]
+    u, v = cu[inside].long(), cv[inside].long()
+    seg_lo, seg_hi = colptr[u - lo], colptr[u - lo + 1]          # column u's segment; find v in it (ascending)
+    pos = seg_lo.clone()
+    step = int((seg_hi - seg_lo).max())
+    span = 1
+    while span < step:
+        span <<= 1
+    while span:                                                  # vectorised binary search (lower bound)
+        probe = pos + span
+        ok = (probe <= seg_hi) & (cu[(probe - 1).clamp(max=E - 1)].long() < v)
+        pos = torch.where(ok, probe, pos)
+        span >>= 1
+    assert bool((pos < seg_hi).all()) and torch.equal(cu[pos].long(), v) and torch.equal(cv[pos].long(), u)
+    assert torch.equal(sc[pos], sc[inside]) and torch.equal(cn[pos], cn[inside])
