@@ -10,8 +10,8 @@
 //      1-KiB row read per endpoint, float4 per lane, all 16 reads of a wave in flight at once);
 //   2. hidden layers: X[64,H] stays in LDS (66.5 KiB); the W fragments of each 32-wide K-chunk go
 //      L2 -> registers directly (16 B per lane, one chunk ahead), so the K loop has no LDS staging
-//      and no barrier; each wave owns 32 rows x 2 MFMA 32x32 column tiles (32 accumulator
-//      registers); bias + ReLU are applied in the accumulators and written back over X --
+//      and no barrier; each wave owns one 32-wide column tile for all 64 rows (32 accumulator
+//      registers), so no two waves read the same W bytes; bias + ReLU are applied in the accumulators and written back over X --
 //      activations never leave the CU;
 //   3. last layer (H -> 1) is an 8-lanes-per-row dot product over the LDS tile + sigmoid.
 // f32 in, f32 accumulate (v_mfma_f32_32x32x2_f32 == fmaf chain): the 1e-5 parity gate rules out
@@ -53,15 +53,13 @@ __device__ __forceinline__ const float *pick(const float *const (&a)[D_MAXL], in
 // per CU gathers its rows while the first one is in its MFMA phase.
 // Raw buffer loads: rows >= H fall outside the H*H descriptor (zeros, no branch); columns >= H (H % 32 != 0) are
 // pushed out of range by a select on the offset.
-__device__ __forceinline__ void b_gload(v4f (&bf)[2][4], __amdgpu_buffer_rsrc_t wr, int H, int t0, int t1, int r, int hh,
-                                        int kc)
+__device__ __forceinline__ void b_gload(v4f (&bf)[4], __amdgpu_buffer_rsrc_t wr, int H, int t0, int r, int hh, int kc)
 {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int kcol = kc * D_BK + 8 * j + 4 * hh;
-        const int o0 = ((t0 * 32 + r) * H + kcol) * 4, o1 = ((t1 * 32 + r) * H + kcol) * 4;
-        bf[0][j] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(wr, kcol < H ? o0 : 0x7ffffff0, 0, 0));
-        bf[1][j] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(wr, kcol < H ? o1 : 0x7ffffff0, 0, 0));
+        const int o0 = ((t0 * 32 + r) * H + kcol) * 4;
+        bf[j] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(wr, kcol < H ? o0 : 0x7ffffff0, 0, 0));
     }
 }
 
@@ -77,11 +75,12 @@ __global__ __launch_bounds__(D_THREADS, 4) void mlp_decode_kernel(const float *_
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform -> scalar branches, no exec masking
     const int r = lane & 31, hh = lane >> 5;
-    const int wm = w >> 2, wn = w & 3;      // wave -> rows [32*wm, +32), column tiles wn and wn+4
+    // wave w owns column tile w for all 64 rows (two 32x32 MFMA tiles stacked): no two waves read the same W bytes,
+    // which halves the L2 -> CU weight traffic of a layer (256 KiB per tile instead of 512)
     const int Hp = (H + 31) & ~31;          // H padded to the MFMA tile width; pad columns are kept at zero
     const int n_ntiles = Hp >> 5;           // 32-column output tiles (<= 8)
-    const int t0 = wn, t1 = wn + 4;
-    const bool has0 = t0 < n_ntiles, has1 = t1 < n_ntiles;
+    const int t0 = w;
+    const bool has0 = t0 < n_ntiles;
     const int nk = Hp / D_BK;
     const int64_t n_tiles = (n_pairs + D_BM - 1) / D_BM;
     const int h4 = H >> 2;                  // float4 per row
@@ -124,37 +123,39 @@ __global__ __launch_bounds__(D_THREADS, 4) void mlp_decode_kernel(const float *_
             for (int kc = 0; kc < nk; ++kc) {
                 // this chunk's weight fragments (L2 -> registers) and activation fragments (LDS) are requested together;
                 // the three other waves of the SIMD cover the wait with their MFMAs
-                v4f bcur[2][4];
-                b_gload(bcur, wr, H, t0, t1, r, hh, kc);
-                float4 af[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) af[j] = *reinterpret_cast<const float4 *>(&Xs[wm * 32 + r][kc * D_BK + 8 * j + 4 * hh]);
+                v4f bcur[4];
+                b_gload(bcur, wr, H, t0, r, hh, kc);
+                float4 af[2][4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const float av[4] = {af[j].x, af[j].y, af[j].z, af[j].w};
-                    if (has0) {
+                    af[0][j] = *reinterpret_cast<const float4 *>(&Xs[r][kc * D_BK + 8 * j + 4 * hh]);
+                    af[1][j] = *reinterpret_cast<const float4 *>(&Xs[32 + r][kc * D_BK + 8 * j + 4 * hh]);
+                }
+                if (has0) {
 #pragma unroll
-                        for (int ss = 0; ss < 4; ++ss) acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ss], bcur[0][j][ss], acc[0], 0, 0, 0);
-                    }
-                    if (has1) {
+                    for (int j = 0; j < 4; ++j) {
+                        const float a0[4] = {af[0][j].x, af[0][j].y, af[0][j].z, af[0][j].w};
+                        const float a1[4] = {af[1][j].x, af[1][j].y, af[1][j].z, af[1][j].w};
 #pragma unroll
-                        for (int ss = 0; ss < 4; ++ss) acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ss], bcur[1][j][ss], acc[1], 0, 0, 0);
+                        for (int ss = 0; ss < 4; ++ss) {
+                            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[ss], bcur[j][ss], acc[0], 0, 0, 0);
+                            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[ss], bcur[j][ss], acc[1], 0, 0, 0);
+                        }
                     }
                 }
             }
             __syncthreads();  // every wave has finished reading X: overwrite it with relu(acc + b)
-#pragma unroll
-            for (int ni = 0; ni < 2; ++ni) {
-                const bool has = ni == 0 ? has0 : has1;
-                if (!has) continue;
-                const int cc = (ni == 0 ? t0 : t1) * 32 + r;
+            if (has0) {
+                const int cc = t0 * 32 + r;
                 const float bv = cc < H ? Bv[cc] : 0.f;
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int rr = wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
-                    const float t = acc[ni][e] + bv;
-                    Xs[rr][cc] = t > 0.f ? t : 0.f;
-                }
+                for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int rr = mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+                        const float t = acc[mi][e] + bv;
+                        Xs[rr][cc] = t > 0.f ? t : 0.f;
+                    }
             }
             __syncthreads();
         }
