@@ -120,11 +120,15 @@ __global__ __launch_bounds__(D_THREADS, 4) void mlp_decode_kernel(const float *_
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
 
+            v4f bnxt[4];
+            b_gload(bnxt, wr, H, t0, r, hh, 0);
             for (int kc = 0; kc < nk; ++kc) {
-                // this chunk's weight fragments (L2 -> registers) and activation fragments (LDS) are requested together;
-                // the three other waves of the SIMD cover the wait with their MFMAs
+                // the weight fragments of the NEXT chunk (L2 -> registers) are requested before this chunk's MFMAs;
+                // the last trip re-requests its own chunk (an L1 hit) so that the load stays unconditional
                 v4f bcur[4];
-                b_gload(bcur, wr, H, t0, r, hh, kc);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) bcur[j] = bnxt[j];
+                b_gload(bnxt, wr, H, t0, r, hh, kc + 1 < nk ? kc + 1 : kc);
                 float4 af[2][4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
