@@ -95,12 +95,16 @@ def cpu_baseline(g, u, v, ws_gpu, torch):
     # the GPU/CPU ratio is not flattered by the reference being single-threaded
     from concurrent.futures import ThreadPoolExecutor
     n_thr = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    cuts = np.linspace(0, len(pu), n_thr + 1).astype(np.int64)
+    au, av = u.cpu().numpy().astype(np.int64), v.cpu().numpy().astype(np.int64)   # the whole step: enough work per thread
+    cuts = np.linspace(0, len(au), n_thr + 1).astype(np.int64)
     with ThreadPoolExecutor(n_thr) as pool:
+        list(pool.map(lambda i: orc.pair_scores(rp, col, None, w, au[cuts[i]:cuts[i] + 64], av[cuts[i]:cuts[i] + 64]),
+                      range(n_thr)))                                               # start the threads outside the clock
         t2 = time.perf_counter()
-        list(pool.map(lambda i: orc.pair_scores(rp, col, None, w, pu[cuts[i]:cuts[i + 1]], pv[cuts[i]:cuts[i + 1]]),
+        list(pool.map(lambda i: orc.pair_scores(rp, col, None, w, au[cuts[i]:cuts[i + 1]], av[cuts[i]:cuts[i + 1]]),
                       range(n_thr)))
         dt_all = time.perf_counter() - t2
+    n_all = len(au)
     # Hits@100 parity (the second half of BASELINE's metric): positive-like pairs (stored edges) against uniform random
     # negatives, scored by the GPU engine and by the reference's CPU expression; Hits@K per ogb's rule (strict >).
     gen = torch.Generator(device=u.device).manual_seed(7)
@@ -126,8 +130,9 @@ def cpu_baseline(g, u, v, ws_gpu, torch):
                       f"adamic_utils.AA batch 2000, per-batch loop only (weight prologue excluded), "
                       f"host has {os.cpu_count()} cores, 1 used",
             "c_port_value": len(pu) / dt_c,
-            "all_cores": {"value": len(pu) / dt_all, "unit": "edges/s", "cores": n_thr,
-                          "what": "scalar C port of the same per-pair loop, the sample's pairs split over all host cores"},
+            "all_cores": {"value": n_all / dt_all, "unit": "edges/s", "cores": n_thr,
+                          "what": f"scalar C port of the same per-pair loop, all {n_all} pairs of the step split over "
+                                  "all host cores (one thread each)"},
             "gpu_vs_sample_max_rel_err": rel}
 
 
