@@ -42,10 +42,14 @@ def two_hop_block(g: CSRGraph, v_lo: int, v_hi: int) -> torch.Tensor:
 
 
 def hip_expand_available(g: CSRGraph) -> bool:
+    """The fused expansion kernels can take this graph: on the GPU, square, ids within the LDS bitmap, and no column so
+    heavy (a hub whose neighbours are hubs) that the per-workgroup path buckets would outgrow the scratch budget."""
     if g.device.type != "cuda":
         return False
     from . import ops
-    return g.n_rows == g.n_cols and g.n_rows <= ops.expand_max_nodes()
+    if not (g.n_rows == g.n_cols and g.n_rows <= ops.expand_max_nodes()):
+        return False
+    return ops.expand_workspace_fits(max_paths_of(g))
 
 
 def path_counts(g: CSRGraph) -> torch.Tensor:

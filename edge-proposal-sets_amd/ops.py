@@ -175,6 +175,11 @@ class ExpandResult(tuple):
 _EXPAND_WS_LIMIT = 96 << 30       # bytes of bucket scratch we are willing to hold on a 288 GB device
 
 
+def expand_workspace_fits(max_paths: int) -> bool:
+    """Whether the bucket scratch for columns of up to ``max_paths`` two-hop paths stays within the budget."""
+    return int(_lib.load().eps_expand_workspace_bytes(int(max_paths))) <= _EXPAND_WS_LIMIT
+
+
 def expand_candidates(rowptr, col, val, node_w, n_nodes: int, v_lo: int, v_hi: int, want_cn=True, want_score=True,
                       want_v=True, col_order=None, max_paths=None, colptr_ub=None, total_ub=None):
     """Fused 2-hop expansion of columns [v_lo, v_hi) of a SYMMETRIC adjacency (filter.py:96-109 + scoring).

@@ -220,3 +220,19 @@ def test_expand_full_size_properties(eps, dev):
         span >>= 1
     assert bool((pos < seg_hi).all()) and torch.equal(cu[pos].long(), v) and torch.equal(cv[pos].long(), u)
     assert torch.equal(sc[pos], sc[inside]) and torch.equal(cn[pos], cn[inside])
+
+
+def test_expand_falls_back_when_buckets_would_not_fit(eps, dev, monkeypatch):
+    """A graph whose heaviest column needs more bucket scratch than the budget is not offered to the fused kernels:
+    the same block then comes from the tensor-op expansion + the column-run intersection kernel, with equal results."""
+    from eps_amd import candidates, synth
+    from eps_amd.heuristics import node_weight_table
+    g = synth.rmat_graph(11, 8, 6, dev)
+    wt = node_weight_table(g, eps.ops.W_AA)
+    assert candidates.hip_expand_available(g)
+    fused = candidates.expand_block(g, 0, g.n_rows, wt, want_cn=True, want_score=True)
+    monkeypatch.setattr(eps.ops, "_EXPAND_WS_LIMIT", 1 << 16)
+    assert not candidates.hip_expand_available(g)
+    plain = candidates.expand_block(g, 0, g.n_rows, wt, want_cn=True, want_score=True)
+    assert torch.equal(fused[0], plain[0]) and torch.equal(fused[1], plain[1])
+    assert rel_err(fused[2].cpu().numpy(), plain[2].cpu().numpy()) <= 1e-5
