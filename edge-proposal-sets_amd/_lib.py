@@ -28,7 +28,7 @@ SIGNATURES = {
     "eps_pair_scores_grouped_f64": (_int, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp]),
     "eps_expand_max_nodes": (_int, []),
     "eps_expand_count": (_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp]),
-    "eps_expand_fill": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
+    "eps_expand_fill": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     "eps_expand_workspace_bytes": (_i64, [_i64]),
     "eps_spmm_csr": (_int, [_vp, _vp, _vp, _i64, _vp, _i64, _i32, _vp, _int, _int, _vp, _i64, _vp]),
     "eps_gcn_norm": (_int, [_vp, _vp, _vp, _i64, _vp, _vp, _vp]),

@@ -84,9 +84,10 @@ class ColumnBlock:
     ``counts`` is set when colptr is an UPPER-BOUND layout (segments sized by the two-hop path counts, so no counting
     pass ran): the arrays then hold padding between the columns -- cand_u -1, score -inf -- and ``padded`` is True."""
 
-    def __init__(self, v_lo: int, colptr: torch.Tensor, cand_u: torch.Tensor, cn, score, counts=None):
+    def __init__(self, v_lo: int, colptr: torch.Tensor, cand_u: torch.Tensor, cn, score, counts=None, survivors=None):
         self.v_lo, self.colptr, self.cand_u, self.cn, self.score, self.counts = v_lo, colptr, cand_u, cn, score, counts
         self.padded = counts is not None
+        self.survivors = survivors      # (positions ascending, scores) of the candidates above the kernel's cut, or None
 
     def numel(self) -> int:
         """Real candidates of the block (synchronises in the padded layout)."""
@@ -120,12 +121,14 @@ def segment_bounds(g: CSRGraph):
 
 
 def expand_block_lazy(g: CSRGraph, v_lo: int, v_hi: int, node_w: Optional[torch.Tensor] = None, want_cn: bool = False,
-                      want_score: bool = False, count_free: bool = False) -> ColumnBlock:
+                      want_score: bool = False, count_free: bool = False, cut=None) -> ColumnBlock:
     """``expand_block`` for consumers that read the pairs of a few candidates only (HIP expansion required).
     ``count_free``: lay the columns out by the upper bound ``segment_bounds`` instead of running the counting pass (one
     walk over the two-hop paths and a host synchronisation less; the arrays are then padded).  Measured on the ppa-like
     graphs: the expansion itself gets 9 % faster, but every later pass over the block (top-K cut) reads paths/candidates
-    = 1.3x to 2.8x more entries, which costs as much or more -- so the filter stage keeps the counted layout."""
+    = 1.3x to 2.8x more entries, which costs as much or more -- so the filter stage keeps the counted layout.
+    ``cut=(threshold, capacity)``: let the kernel report the candidates above the streaming top-K's bar (see
+    ``ops.expand_candidates``); with ``want_score=False`` the block then has no score array at all."""
     from . import ops
     kw = {}
     if count_free:
@@ -133,8 +136,8 @@ def expand_block_lazy(g: CSRGraph, v_lo: int, v_hi: int, node_w: Optional[torch.
         kw = dict(colptr_ub=(pre[v_lo:v_hi + 1] - pre[v_lo]).contiguous(), total_ub=int(pre_host[v_hi] - pre_host[v_lo]))
     r = ops.expand_candidates(g.rowptr, g.col, g.val, node_w, g.n_rows, v_lo, v_hi, want_cn=want_cn,
                               want_score=want_score, want_v=False, col_order=heaviest_first(g, v_lo, v_hi),
-                              max_paths=max_paths_of(g), **kw)
-    return ColumnBlock(v_lo, r[0], r[1], r[3], r[4], counts=r.counts)
+                              max_paths=max_paths_of(g), cut=cut, **kw)
+    return ColumnBlock(v_lo, r[0], r[1], r[3], r[4], counts=r.counts, survivors=r.survivors)
 
 
 def expand_block(g: CSRGraph, v_lo: int, v_hi: int, node_w: Optional[torch.Tensor] = None, want_cn: bool = False,
@@ -159,9 +162,13 @@ def expand_block(g: CSRGraph, v_lo: int, v_hi: int, node_w: Optional[torch.Tenso
     return pairs, cn, sc
 
 
-def column_blocks(g: CSRGraph, max_paths: int = 1 << 29) -> Iterator[Tuple[int, int]]:
+DEFAULT_BLOCK_PATHS = 1 << 29     # two-hop paths per launch: ~4e8 candidates, ~13 GB of outputs + scratch on a 288 GB device
+
+
+def column_blocks(g: CSRGraph, max_paths: int = None) -> Iterator[Tuple[int, int]]:
     """Column ranges whose 2-hop path count stays below ``max_paths`` (bounds a block's memory: a block never
     holds more candidates than paths)."""
+    max_paths = int(max_paths or DEFAULT_BLOCK_PATHS)
     cum = torch.cumsum(path_counts(g), 0).cpu()
     n = g.n_rows
     v = 0
@@ -173,14 +180,14 @@ def column_blocks(g: CSRGraph, max_paths: int = 1 << 29) -> Iterator[Tuple[int, 
         v = hi
 
 
-def iter_candidate_blocks(g: CSRGraph, max_paths: int = 1 << 29) -> Iterator[Tuple[int, int, torch.Tensor]]:
+def iter_candidate_blocks(g: CSRGraph, max_paths: int = None) -> Iterator[Tuple[int, int, torch.Tensor]]:
     """Yield (v_lo, v_hi, pairs[2,E_blk]) over all columns."""
     fused = hip_expand_available(g)
     for lo, hi in column_blocks(g, max_paths):
         yield lo, hi, (expand_block(g, lo, hi)[0] if fused else two_hop_block(g, lo, hi))
 
 
-def all_candidates(g: CSRGraph, max_paths: int = 1 << 29) -> torch.Tensor:
+def all_candidates(g: CSRGraph, max_paths: int = None) -> torch.Tensor:
     """The whole candidate list [2,E] (small graphs / tests)."""
     blocks = [b for _, _, b in iter_candidate_blocks(g, max_paths)]
     return torch.cat(blocks, 1) if blocks else torch.zeros((2, 0), dtype=torch.int64, device=g.device)

@@ -198,7 +198,7 @@ __global__ __launch_bounds__(EX_THREADS) void expand_kernel(
     int32_t *__restrict__ cand_u, int32_t *__restrict__ cand_v, int32_t range_shift, int32_t tile_half,
     int32_t region_words,
     uint2 *__restrict__ scratch, int64_t scratch_per_block, int32_t *__restrict__ out_cn, float *__restrict__ out_score,
-    unsigned int *__restrict__ overflow)
+    eps_score_cut *__restrict__ cut, unsigned int *__restrict__ overflow)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const int words = wpt * EX_THREADS;
@@ -220,7 +220,12 @@ __global__ __launch_bounds__(EX_THREADS) void expand_kernel(
     __shared__ int s_ntiles;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wib = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const bool want_d = FILL && (out_score || out_cn);
+    const bool want_d = FILL && (out_score || out_cn || cut);
+    const bool want_sum = out_score || cut;
+    const float cut_thr = cut ? cut->threshold : 0.f;
+    const uint32_t cut_cap = cut ? cut->capacity : 0u;
+    int64_t *__restrict__ cut_pos = cut ? cut->pos : nullptr;
+    float *__restrict__ cut_val = cut ? cut->val : nullptr;
     const int n_ranges = ((n_nodes - 1) >> range_shift) + 1;
     uint2 *__restrict__ my_scratch = scratch + (int64_t)blockIdx.x * scratch_per_block;
 
@@ -435,14 +440,23 @@ __global__ __launch_bounds__(EX_THREADS) void expand_kernel(
             __syncthreads();
             for (uint32_t i = tid; i < n; i += EX_THREADS) {
                 const uint2 rec = my_scratch[b0 + i];
-                if (out_score)
+                if (want_sum)
                     atomicAdd(&acc[rec.x], (unsigned long long)ex_to_fixed(__builtin_bit_cast(float, rec.y)));
                 if (out_cn) atomicAdd(&cnt[rec.x], 1u);
             }
             __syncthreads();
             for (uint32_t i = tid; i < nslots; i += EX_THREADS) {
-                if (out_score)
-                    out_score[base + r0 + i] = (float)((double)(long long)acc[i] * (1.0 / (double)(1ll << EX_FIXED_SHIFT)));
+                if (want_sum) {
+                    const float sc = (float)((double)(long long)acc[i] * (1.0 / (double)(1ll << EX_FIXED_SHIFT)));
+                    if (out_score) out_score[base + r0 + i] = sc;
+                    if (cut && sc > cut_thr) {      // top-K cut in the kernel: report the few candidates above the bar
+                        const uint32_t q = atomicAdd(&cut->count, 1u);
+                        if (q < cut_cap) {
+                            cut_pos[q] = base + r0 + i;
+                            cut_val[q] = sc;
+                        }
+                    }
+                }
                 if (out_cn) out_cn[base + r0 + i] = (int32_t)cnt[i];
             }
             __syncthreads();
@@ -507,7 +521,8 @@ extern "C" int eps_expand_count(const int64_t *rowptr, const int32_t *col, int64
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(EX_THREADS), lds, s, rowptr, col, (const float *)nullptr,
                        (const float *)nullptr, (int32_t)n_nodes, (int32_t)v_lo, (int32_t)v_hi, col_order, wpt, counter,
                        cand_count, (const int64_t *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr, 8, EX_TILE / 2, 0,
-                       (uint2 *)nullptr, (int64_t)0, (int32_t *)nullptr, (float *)nullptr, (unsigned int *)nullptr);
+                       (uint2 *)nullptr, (int64_t)0, (int32_t *)nullptr, (float *)nullptr, (eps_score_cut *)nullptr,
+                       (unsigned int *)nullptr);
     EPS_CHECK_LAUNCH("eps_expand_count");
     return EPS_OK;
 }
@@ -524,13 +539,13 @@ extern "C" int64_t eps_expand_workspace_bytes(int64_t max_col_paths)
 extern "C" int eps_expand_fill(const int64_t *rowptr, const int32_t *col, const float *val, const float *node_w,
                                int64_t n_nodes, int64_t v_lo, int64_t v_hi, const int32_t *col_order,
                                const int64_t *colptr, int64_t *cand_count, int32_t *cand_u, int32_t *cand_v, int32_t *cn,
-                               float *score, void *workspace, int64_t workspace_bytes, void *stream)
+                               float *score, eps_score_cut *cut, void *workspace, int64_t workspace_bytes, void *stream)
 {
     EPS_REQUIRE(n_nodes >= 0 && v_lo >= 0 && v_hi >= v_lo && v_hi <= n_nodes, "eps_expand_fill: bad column range");
     if (v_hi == v_lo) return EPS_OK;
     EPS_REQUIRE(rowptr && col && colptr && cand_u, "eps_expand_fill: null pointer");
     EPS_REQUIRE(n_nodes < (1ll << 20), "eps_expand_fill: candidate ranks are packed in 20 bits");
-    const bool scored = cn || score;
+    const bool scored = cn || score || cut;
     EPS_REQUIRE(workspace && workspace_bytes >= 8 && ((uintptr_t)workspace & 7) == 0,
                 "eps_expand_fill: needs an 8-byte aligned workspace (eps_expand_workspace_bytes)");
     const int wpt = expand_words_per_thread(n_nodes);
@@ -566,8 +581,8 @@ extern "C" int eps_expand_fill(const int64_t *rowptr, const int32_t *col, const 
         }                                                                                                              \
         hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(EX_THREADS), lds, s, rowptr, col, val, node_w,           \
                            (int32_t)n_nodes, (int32_t)v_lo, (int32_t)v_hi, col_order, wpt, counter, cand_count,        \
-                           colptr, cand_u, cand_v, range_shift, tile_half, region_words,                                       \
-                           scored ? (uint2 *)((char *)workspace + 8) : (uint2 *)nullptr, per_block, cn, score,         \
+                           colptr, cand_u, cand_v, range_shift, tile_half, region_words,                               \
+                           scored ? (uint2 *)((char *)workspace + 8) : (uint2 *)nullptr, per_block, cn, score, cut,    \
                            (unsigned int *)workspace);                                                                 \
     } while (0)
     if (hv && hw) EX_LAUNCH(true, true);

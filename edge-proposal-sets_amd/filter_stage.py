@@ -79,7 +79,10 @@ def rank_column_range(g: CSRGraph, rank: int, world: int):
     return b[rank], b[rank + 1]
 
 
-def scored_blocks(args, model, data, ra_graph, col_lo: int = 0, col_hi: int = None):
+CUT_CAPACITY = 1 << 23     # survivors per block the expansion kernel may report (96 MB); more -> the block is redone in full
+
+
+def scored_blocks(args, model, data, ra_graph, col_lo: int = 0, col_hi: int = None, bar=None):
     """(v_lo, v_hi, pairs, scores) per column block.  Heuristic filters whose scoring graph IS the candidate graph
     (AA: filter.py:122-126; CN 'simple': :116-121 with models.py:536-542) come out of the fused expansion already
     scored; RA scores on the train-only graph (filter.py:130-141) and GNN filters decode the block's pairs."""
@@ -107,7 +110,16 @@ def scored_blocks(args, model, data, ra_graph, col_lo: int = 0, col_hi: int = No
         node_w = torch.ones(g.n_rows, dtype=torch.float32, device=g.device)
     print(f'fused candidate generation + scoring ({args.model})')
     for v_lo, v_hi in blocks:
-        blk = candidates.expand_block_lazy(g, v_lo, v_hi, node_w, want_score=True)
+        # once the streaming top-K holds K proposals (``bar()`` is its K-th score) only candidates above that bar matter:
+        # the kernel reports them directly and the block's score array is neither written nor scanned
+        thr = bar() if bar is not None else None
+        blk = None
+        if thr is not None:
+            blk = candidates.expand_block_lazy(g, v_lo, v_hi, node_w, want_score=False, cut=(thr, CUT_CAPACITY))
+            if blk.survivors is None:
+                blk = None                           # more survivors than the list holds: score the block in full
+        if blk is None:
+            blk = candidates.expand_block_lazy(g, v_lo, v_hi, node_w, want_score=True)
         yield v_lo, v_hi, blk, blk.score
 
 
@@ -155,7 +167,8 @@ def run(args) -> str:
     all_pairs, all_scores = [], []
     top = proposals.StreamingTopK(keep) if keep else None
     with torch.no_grad():
-        for v_lo, v_hi, pairs, score in scored_blocks(args, model, data, ra_graph, col_lo, col_hi):
+        for v_lo, v_hi, pairs, score in scored_blocks(args, model, data, ra_graph, col_lo, col_hi,
+                                                      bar=top.bar if keep else None):
             n_blk = pairs.numel() if (not isinstance(pairs, torch.Tensor)) else pairs.shape[1]
             if n_blk == 0:
                 continue

@@ -170,6 +170,7 @@ class ExpandResult(tuple):
     upper-bound layout (see ``expand_candidates``)."""
     pairs = None
     counts = None
+    survivors = None
 
 
 _EXPAND_WS_LIMIT = 96 << 30       # bytes of bucket scratch we are willing to hold on a 288 GB device
@@ -181,7 +182,7 @@ def expand_workspace_fits(max_paths: int) -> bool:
 
 
 def expand_candidates(rowptr, col, val, node_w, n_nodes: int, v_lo: int, v_hi: int, want_cn=True, want_score=True,
-                      want_v=True, col_order=None, max_paths=None, colptr_ub=None, total_ub=None):
+                      want_v=True, col_order=None, max_paths=None, colptr_ub=None, total_ub=None, cut=None):
     """Fused 2-hop expansion of columns [v_lo, v_hi) of a SYMMETRIC adjacency (filter.py:96-109 + scoring).
     -> (colptr int64[n_cols+1], cand_u int32[E], cand_v int32[E] | None, cn int32[E] | None, score float32[E] | None);
     candidates are column-major, u ascending inside a column (the reference's order).  ``col_order`` (int32
@@ -192,7 +193,11 @@ def expand_candidates(rowptr, col, val, node_w, n_nodes: int, v_lo: int, v_hi: i
     ``colptr_ub`` (int64[n_cols+1] on the device) + ``total_ub`` (its last entry, as a Python int) select the
     UPPER-BOUND layout: no counting pass and no host synchronisation before the launch; column v's candidates fill
     the front of [colptr_ub[v], colptr_ub[v+1]) and the rest of the segment is padded (cand_u -1, score -inf, cn 0).
-    The result then carries ``.counts`` (int64[n_cols], real candidates per column) and E == total_ub."""
+    The result then carries ``.counts`` (int64[n_cols], real candidates per column) and E == total_ub.
+
+    ``cut=(threshold, capacity)``: the kernel also reports the candidates whose score exceeds ``threshold`` (the
+    streaming top-K's current K-th score) -- the result carries ``.survivors`` = (positions int64 ascending, scores) or
+    None when more than ``capacity`` qualified.  With a cut, ``want_score=False`` skips the score array altogether."""
     dev = _need_gpu(rowptr, col, val, node_w, col_order, colptr_ub)
     _chk(rowptr, torch.int64, "rowptr"); _chk(col, torch.int32, "col"); _chk(val, torch.float32, "val")
     _chk(node_w, torch.float32, "node_w"); _chk(col_order, torch.int32, "col_order"); _chk(colptr_ub, torch.int64, "colptr_ub")
@@ -217,25 +222,43 @@ def expand_candidates(rowptr, col, val, node_w, n_nodes: int, v_lo: int, v_hi: i
         cand_v = pairs[1] if want_v else None
         cn = torch.empty(total, dtype=torch.int32, device=dev) if want_cn else None
         score = torch.empty(total, dtype=torch.float32, device=dev) if want_score else None
+        cut_rec = cut_pos = cut_val = None
+        if cut is not None and total:
+            thr, cap = float(cut[0]), int(cut[1])
+            cut_pos = torch.empty(cap, dtype=torch.int64, device=dev)
+            cut_val = torch.empty(cap, dtype=torch.float32, device=dev)
+            import struct
+            head = struct.unpack("<q", struct.pack("<fI", thr, cap))[0]          # eps_score_cut: threshold, capacity
+            cut_rec = torch.tensor([head, 0, cut_pos.data_ptr(), cut_val.data_ptr()], dtype=torch.int64, device=dev)
+        scored = want_cn or want_score or cut_rec is not None
         if total:
             if max_paths is None:
-                max_paths = max_column_paths(rowptr, col, v_lo, v_hi) if (want_cn or want_score) else 0
-            ws_bytes = int(lib.eps_expand_workspace_bytes(int(max_paths) if (want_cn or want_score) else 0))
+                max_paths = max_column_paths(rowptr, col, v_lo, v_hi) if scored else 0
+            ws_bytes = int(lib.eps_expand_workspace_bytes(int(max_paths) if scored else 0))
             if ws_bytes > _EXPAND_WS_LIMIT:
                 raise _lib.EpsError(f"expand_candidates: a column with {max_paths} two-hop paths needs {ws_bytes >> 30} GiB "
                                     "of bucket scratch; score such graphs with the pair kernels")
             ws = _expand_scratch(dev, ws_bytes)
             _lib.check(lib.eps_expand_fill(_ptr(rowptr), _ptr(col), _ptr(val), _ptr(node_w), n_nodes, v_lo, v_hi,
                                            _ptr(col_order), _ptr(colptr), _ptr(counts) if colptr_ub is not None else None,
-                                           _ptr(cand_u), _ptr(cand_v), _ptr(cn), _ptr(score), _ptr(ws), ws_bytes,
-                                           _stream(dev)), "eps_expand_fill")
-            status = int(ws[0].item()) & 0xFFFFFFFF
+                                           _ptr(cand_u), _ptr(cand_v), _ptr(cn), _ptr(score), _ptr(cut_rec), _ptr(ws),
+                                           ws_bytes, _stream(dev)), "eps_expand_fill")
+            if cut_rec is not None:                      # one read-back for the status word and the survivor count
+                both = torch.stack([ws[0], cut_rec[1]]).tolist()
+                status, n_cut = both[0] & 0xFFFFFFFF, both[1] & 0xFFFFFFFF
+            else:
+                status, n_cut = int(ws[0].item()) & 0xFFFFFFFF, 0
             if status:
                 raise _lib.EpsError("expand_candidates: " + ("a column had more two-hop paths than max_paths allows; " if status & 1 else "")
                                     + ("a column had more candidates than its colptr_ub segment" if status & 2 else ""))
     out = ExpandResult((colptr, cand_u, cand_v, cn, score))
     out.pairs = pairs if want_v else None
     out.counts = counts if colptr_ub is not None else None
+    if cut_rec is not None and n_cut <= cut_pos.numel():
+        order = torch.argsort(cut_pos[:n_cut])                     # arrival order -> candidate order
+        out.survivors = (cut_pos[:n_cut][order], cut_val[:n_cut][order])
+    elif cut is not None and not total:
+        out.survivors = (torch.zeros(0, dtype=torch.int64, device=dev), torch.zeros(0, dtype=torch.float32, device=dev))
     return out
 
 

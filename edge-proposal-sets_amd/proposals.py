@@ -86,13 +86,26 @@ class StreamingTopK:
         m = scores >= t
         return m if int(m.sum()) >= need else None
 
-    def push(self, pairs, scores: torch.Tensor) -> None:
-        if scores.numel() == 0:
-            return
+    def bar(self):
+        """The score a new candidate has to EXCEED to enter the list (None while fewer than K are held)."""
+        if self.scores is None or self.scores.numel() < self.k:
+            return None
+        return float(self.scores[-1].item())
+
+    def push(self, pairs, scores: torch.Tensor = None) -> None:
         lazy = not isinstance(pairs, torch.Tensor)                       # candidates.ColumnBlock: pairs on demand
         keep = None                                                       # surviving positions of the block, ascending
         held = 0 if self.scores is None else self.scores.numel()
-        if held >= self.k:
+        if lazy and getattr(pairs, "survivors", None) is not None and held >= self.k:
+            # the expansion kernel already applied a cut at (or below) the current bar: start from its short list
+            keep, scores = pairs.survivors
+            sel = scores > self.scores[-1]
+            keep, scores = keep[sel], scores[sel]
+            if keep.numel() == 0:
+                return
+        elif scores is None or scores.numel() == 0:
+            return
+        elif held >= self.k:
             keep = torch.nonzero(scores > self.scores[-1]).squeeze(1)     # ascending: candidate order is kept
             if keep.numel() == 0:
                 return

@@ -118,14 +118,27 @@ int eps_pair_scores_grouped_f64(const int64_t *rowptr, const int32_t *col, const
  *                     order.  After the launch the first 4 bytes of the workspace are 0, or
  *                     non-zero if P (bit 0) or a colptr segment (bit 1) was too small: outputs
  *                     invalid. */
+/* Optional top-K cut of eps_expand_fill, a DEVICE-resident record: every candidate whose score exceeds `threshold`
+ * is reported as (pos, val) -- pos = its index in the launch's candidate arrays -- in arrival order (sort by pos to
+ * restore candidate order).  count (zeroed by the caller) may end above capacity: the list is then incomplete.
+ * With a cut the score array itself is optional. */
+typedef struct eps_score_cut {
+    float threshold;
+    uint32_t capacity;
+    uint32_t count;
+    uint32_t reserved;
+    int64_t *pos;
+    float *val;
+} eps_score_cut;
+
 int eps_expand_max_nodes(void);
 int eps_expand_count(const int64_t *rowptr, const int32_t *col, int64_t n_nodes, int64_t v_lo,
                      int64_t v_hi, const int32_t *col_order, int64_t *cand_count, void *stream);
 int eps_expand_fill(const int64_t *rowptr, const int32_t *col, const float *val,
                     const float *node_w, int64_t n_nodes, int64_t v_lo, int64_t v_hi,
                     const int32_t *col_order, const int64_t *colptr, int64_t *cand_count,
-                    int32_t *cand_u, int32_t *cand_v, int32_t *cn, float *score, void *workspace,
-                    int64_t workspace_bytes, void *stream);
+                    int32_t *cand_u, int32_t *cand_v, int32_t *cn, float *score,
+                    eps_score_cut *cut, void *workspace, int64_t workspace_bytes, void *stream);
 int64_t eps_expand_workspace_bytes(int64_t max_col_paths);
 
 /* ---- K4/K5: CSR x dense SpMM with fused epilogue -----------------------------------------

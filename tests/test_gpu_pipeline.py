@@ -66,6 +66,17 @@ def test_filter_cli_matches_oracle(eps, oracle, workdir, dataset, model, mode):
                                 "--synthetic", "--keep_top", "500"])
     top = torch.load(fname2)
     assert torch.equal(top, got[:500])
+    # (iv) many small launches: from the second block on the streaming top-K holds K proposals, so the expansion kernel
+    # applies the cut itself (survivor list, no score array) -- and, with a tiny list, falls back to full blocks
+    from eps_amd import candidates
+    for cap in (1 << 23, 16):
+        candidates.DEFAULT_BLOCK_PATHS, filter_stage.CUT_CAPACITY = 20_000, cap
+        try:
+            fname3 = filter_stage.main(["--dataset", dataset, "--model", model, "--checkpoint",
+                                        f"{dataset}_{model}||0|2.pt", "--synthetic", "--keep_top", "500"])
+        finally:
+            candidates.DEFAULT_BLOCK_PATHS, filter_stage.CUT_CAPACITY = 1 << 29, 1 << 23
+        assert torch.equal(torch.load(fname3), got[:500])
 
 
 @pytest.mark.parametrize("dataset", ["ddi", "collab"])
