@@ -115,7 +115,9 @@ def scored_blocks(args, model, data, ra_graph, col_lo: int = 0, col_hi: int = No
         thr = bar() if bar is not None else None
         blk = None
         if thr is not None:
-            blk = candidates.expand_block_lazy(g, v_lo, v_hi, node_w, want_score=False, cut=(thr, CUT_CAPACITY))
+            # (nothing scans the block afterwards, so the count-free segment layout costs nothing and saves the counting pass)
+            blk = candidates.expand_block_lazy(g, v_lo, v_hi, node_w, want_score=False, cut=(thr, CUT_CAPACITY),
+                                               count_free=True)
             if blk.survivors is None:
                 blk = None                           # more survivors than the list holds: score the block in full
         if blk is None:
