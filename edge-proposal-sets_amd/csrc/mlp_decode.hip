@@ -87,12 +87,26 @@ __global__ __launch_bounds__(D_THREADS, 4) void mlp_decode_kernel(const float *_
     const int hp4 = Hp >> 2;
     const int cl = lane < h4 ? lane : 0;    // this lane's float4 column of a row (clamped for H < 256)
 
+    // the endpoint ids of a tile are fetched one tile ahead: the gather then starts with its row addresses in hand
+    int32_t mu_next = 0, mv_next = 0;
+    {
+        const int64_t p = (int64_t)blockIdx.x * D_BM + lane;
+        if (p < n_pairs) {
+            mu_next = pu[p];
+            mv_next = pv[p];
+        }
+    }
     for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const int64_t e0 = tile * D_BM;
         // ---- 1. gather + Hadamard into LDS: wave w builds rows 8w..8w+7, all 16 row reads in flight at once ----
         {
-            const int64_t p = e0 + lane;
-            const int32_t mu = p < n_pairs ? pu[p] : 0, mv = p < n_pairs ? pv[p] : 0;
+            const int32_t mu = mu_next, mv = mv_next;
+            {
+                const int64_t pn = (tile + gridDim.x) * D_BM + lane;
+                const bool okn = pn < n_pairs;
+                mu_next = okn ? pu[okn ? pn : 0] : 0;
+                mv_next = okn ? pv[okn ? pn : 0] : 0;
+            }
             v4f a[8], b[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
