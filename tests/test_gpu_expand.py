@@ -236,3 +236,35 @@ def test_expand_falls_back_when_buckets_would_not_fit(eps, dev, monkeypatch):
     plain = candidates.expand_block(g, 0, g.n_rows, wt, want_cn=True, want_score=True)
     assert torch.equal(fused[0], plain[0]) and torch.equal(fused[1], plain[1])
     assert rel_err(fused[2].cpu().numpy(), plain[2].cpu().numpy()) <= 1e-5
+
+
+def test_expand_score_cut(eps, dev):
+    """eps_score_cut: the kernel's survivor list == the positions whose score exceeds the threshold (ascending after the
+    host's sort), with or without the score array, in the counted and in the count-free layout; a list that overflows
+    its capacity is reported as missing, not truncated."""
+    from eps_amd import candidates, synth
+    from eps_amd.heuristics import node_weight_table
+    g = synth.rmat_graph(12, 10, 5, dev)
+    wt = node_weight_table(g, eps.ops.W_AA)
+    full = eps.ops.expand_candidates(g.rowptr, g.col, None, wt, g.n_rows, 0, g.n_rows, want_cn=False)
+    thr = float(torch.quantile(full[4][:1_000_000].float(), 0.999))
+    want = torch.nonzero(full[4] > thr).squeeze(1)
+    assert 50 < want.numel() < 100_000
+    for want_score in (True, False):
+        r = eps.ops.expand_candidates(g.rowptr, g.col, None, wt, g.n_rows, 0, g.n_rows, want_cn=False,
+                                      want_score=want_score, cut=(thr, 1 << 20))
+        pos, val = r.survivors
+        assert torch.equal(pos, want) and torch.equal(val, full[4][want])
+        assert (r[4] is None) == (not want_score)
+        if want_score:
+            assert torch.equal(r[4], full[4])
+    blk = candidates.expand_block_lazy(g, 0, g.n_rows, wt, want_score=False, cut=(thr, 1 << 20), count_free=True)
+    pos, val = blk.survivors
+    assert blk.padded and torch.equal(blk.select(pos), torch.stack([full[1][want], full[2][want]]).long())
+    assert torch.equal(val, full[4][want])
+    small = eps.ops.expand_candidates(g.rowptr, g.col, None, wt, g.n_rows, 0, g.n_rows, want_cn=False, want_score=False,
+                                      cut=(thr, 8))
+    assert small.survivors is None
+    none = eps.ops.expand_candidates(g.rowptr, g.col, None, wt, g.n_rows, 0, g.n_rows, want_cn=False, want_score=False,
+                                     cut=(float("inf"), 8))
+    assert none.survivors[0].numel() == 0
