@@ -16,6 +16,18 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _built_library():
+    """The tests load the in-tree libeps_hip.so; a checkout that was never built gets built here (hipcc cross-compiles
+    gfx950 without a GPU).  The GPU box receives the built file with the snapshot, so this is a no-op there."""
+    lib = os.path.join(ROOT, "edge-proposal-sets_amd", "libeps_hip.so")
+    if not os.path.exists(lib):
+        import subprocess
+        subprocess.run(["make", "-C", os.path.join(ROOT, "edge-proposal-sets_amd", "csrc"), "-j8"], check=True,
+                       stdout=subprocess.DEVNULL)
+    yield
+
+
 def golden_pair_files():
     return sorted(glob.glob(os.path.join(GOLDEN, "pairs_*.npz")))
 
