@@ -29,18 +29,36 @@ def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, torch.device
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # test hook for a 1-GPU box: EPS_DIST_ONE_DEVICE=1 runs every rank on cuda:0 with gloo as the transport (RCCL needs one
+    # GPU per rank), so the multi-rank control flow of the stages runs on real kernels
+    one_device = os.environ.get("EPS_DIST_ONE_DEVICE") == "1" and torch.cuda.is_available()
     use_gpu = torch.cuda.is_available() and backend != "gloo"
-    device = torch.device("cuda", local) if use_gpu else torch.device("cpu")
-    if use_gpu:
+    device = torch.device("cuda", 0 if one_device else local) if (use_gpu or one_device) else torch.device("cpu")
+    if device.type == "cuda":
         torch.cuda.set_device(device)
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        if use_gpu:
+        if use_gpu and not one_device:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
     return rank, world, device
+
+
+def all_gather_list(t: torch.Tensor) -> List[torch.Tensor]:
+    """Every rank's copy of an equally shaped tensor, in rank order.  RCCL moves device tensors directly; gloo (CPU
+    jobs and the one-device test hook) gathers through host memory."""
+    rank, world = world_info()
+    if world == 1:
+        return [t]
+    if dist.get_backend() == "gloo" and t.device.type != "cpu":
+        parts = [torch.empty_like(t, device="cpu") for _ in range(world)]
+        dist.all_gather(parts, t.cpu())
+        return [p.to(t.device) for p in parts]
+    parts = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(parts, t.contiguous())
+    return parts
 
 
 def world_info() -> Tuple[int, int]:
@@ -86,6 +104,15 @@ def column_work(rowptr: torch.Tensor, col: torch.Tensor) -> torch.Tensor:
 
 
 # ------------------------------------------------------------------ collectives
+def _gather_into(t: torch.Tensor, world: int) -> torch.Tensor:
+    """all_gather_into_tensor along dim 0; device tensors go through host memory when the transport is gloo."""
+    via_host = dist.get_backend() == "gloo" and t.device.type != "cpu"
+    src = t.cpu() if via_host else t
+    out = torch.empty((world * src.shape[0],) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
+    dist.all_gather_into_tensor(out, src)
+    return out.to(t.device) if via_host else out
+
+
 def all_gather_rows(local: torch.Tensor, bounds: Sequence[int]) -> torch.Tensor:
     """All-gather a row-partitioned [N,F] matrix: rank r holds rows [bounds[r], bounds[r+1]).  One collective
     (ragged shards are padded to the largest)."""
@@ -99,8 +126,7 @@ def all_gather_rows(local: torch.Tensor, bounds: Sequence[int]) -> torch.Tensor:
     if local.shape[0] < mx:
         pad = torch.zeros((mx, f), dtype=local.dtype, device=local.device)
         pad[:local.shape[0]] = local
-    out = torch.empty((world * mx, f), dtype=local.dtype, device=local.device)
-    dist.all_gather_into_tensor(out, pad.contiguous())
+    out = _gather_into(pad.contiguous(), world)
     if all(s == mx for s in sizes):
         return out
     return torch.cat([out[r * mx: r * mx + sizes[r]] for r in range(world)], 0)
@@ -113,8 +139,7 @@ def all_gather_keys(keys: torch.Tensor, k: int) -> List[torch.Tensor]:
         return [keys]
     pad = torch.full((k,), torch.iinfo(torch.int64).min, dtype=torch.int64, device=keys.device)
     pad[:keys.numel()] = keys[:k]
-    out = torch.empty(world * k, dtype=torch.int64, device=keys.device)
-    dist.all_gather_into_tensor(out, pad)
+    out = _gather_into(pad, world)
     return [out[r * k:(r + 1) * k] for r in range(world)]
 
 

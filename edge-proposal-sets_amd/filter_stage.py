@@ -195,16 +195,13 @@ def run(args) -> str:
             # ranks hold contiguous column ranges in rank order: gather the (padded) per-rank lists -- K x 20 B each --
             # and stable-merge them in rank order
             n_mine = torch.tensor([best_scores.numel()], dtype=torch.int64, device=device)
-            n_all = [torch.zeros_like(n_mine) for _ in range(world)]
-            torch.distributed.all_gather(n_all, n_mine)
+            n_all = epd.all_gather_list(n_mine)
             pad_s = torch.full((keep,), float("-inf"), dtype=torch.float32, device=device)
             pad_p = torch.zeros((2, keep), dtype=torch.int64, device=device)
             pad_s[:best_scores.numel()] = best_scores
             pad_p[:, :best_pairs.shape[1]] = best_pairs
-            gs = [torch.empty_like(pad_s) for _ in range(world)]
-            gp = [torch.empty_like(pad_p) for _ in range(world)]
-            torch.distributed.all_gather(gs, pad_s)
-            torch.distributed.all_gather(gp, pad_p)
+            gs = epd.all_gather_list(pad_s)
+            gp = epd.all_gather_list(pad_p)
             cnt = [int(x.item()) for x in n_all]
             best_pairs, best_scores = proposals.merge_ranked_lists([gp[r][:, :cnt[r]] for r in range(world)],
                                                                    [gs[r][:cnt[r]] for r in range(world)], keep)
