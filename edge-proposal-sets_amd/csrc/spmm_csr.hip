@@ -7,9 +7,15 @@
 // HBM-bound gather: one wave per output row; the 64 lanes cover 256 feature columns as
 // float4, so every neighbour costs exactly one coalesced 1-KiB row read (global_load_dwordx4).
 // Column indices / values are fetched 64 at a time (coalesced) and broadcast with
-// v_readlane; four neighbour rows are kept in flight per wave.  Accumulation is sequential in
+// v_readlane; 32 neighbour rows (32 KiB) are kept in flight per wave.  Accumulation is sequential in
 // ascending neighbour order, like the reference's CPU kernel.  No MFMA: this is a gather.
 #include "eps_common.h"
+
+#include <type_traits>
+
+#ifndef SP_FLIGHT
+#define SP_FLIGHT 32   // neighbour rows in flight per wave (2: 7.3 ms, 4: 6.6, 8: 6.5, 16: 6.3, 32: 6.0 per ppa-like layer)
+#endif
 
 template <int VEC>
 struct VecT;
@@ -58,41 +64,33 @@ __global__ __launch_bounds__(256) void spmm_csr_kernel(const int64_t *__restrict
                 const int my_col = lane < nk ? col[k0 + lane] : 0;
                 float my_val = 1.0f;
                 if (HAS_VAL) my_val = lane < nk ? val[k0 + lane] : 0.0f;
+                // SP_FLIGHT neighbour rows in flight per wave.  Full groups run unguarded; the last, partial group of a row
+                // takes the guarded form (wave-uniform guards = scalar branches), so a row's tail costs one round trip too.
+                auto group = [&](int j, auto guarded) {
+                    constexpr bool G = decltype(guarded)::value;
+                    int cj[SP_FLIGHT];
+                    V xv[SP_FLIGHT];
+                    float vj[SP_FLIGHT];
+#pragma unroll
+                    for (int q = 0; q < SP_FLIGHT; ++q) cj[q] = __builtin_amdgcn_readlane(my_col, (j + q) & 63);
+#pragma unroll
+                    for (int q = 0; q < SP_FLIGHT; ++q) {
+                        xv[q] = vzero(V());
+                        if ((!G || j + q < nk) && act) xv[q] = *reinterpret_cast<const V *>(x + (int64_t)cj[q] * ldx + c);
+                    }
+#pragma unroll
+                    for (int q = 0; q < SP_FLIGHT; ++q) {
+                        vj[q] = 1.f;
+                        if (HAS_VAL)
+                            vj[q] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_val), (j + q) & 63));
+                    }
+#pragma unroll
+                    for (int q = 0; q < SP_FLIGHT; ++q)
+                        if (!G || j + q < nk) fma_vec(acc, vj[q], xv[q]);
+                };
                 int j = 0;
-                for (; j + 4 <= nk; j += 4) {
-                    const int c_0 = __builtin_amdgcn_readlane(my_col, j);
-                    const int c_1 = __builtin_amdgcn_readlane(my_col, j + 1);
-                    const int c_2 = __builtin_amdgcn_readlane(my_col, j + 2);
-                    const int c_3 = __builtin_amdgcn_readlane(my_col, j + 3);
-                    V x0 = vzero(V()), x1 = vzero(V()), x2 = vzero(V()), x3 = vzero(V());
-                    if (act) {
-                        x0 = *reinterpret_cast<const V *>(x + (int64_t)c_0 * ldx + c);
-                        x1 = *reinterpret_cast<const V *>(x + (int64_t)c_1 * ldx + c);
-                        x2 = *reinterpret_cast<const V *>(x + (int64_t)c_2 * ldx + c);
-                        x3 = *reinterpret_cast<const V *>(x + (int64_t)c_3 * ldx + c);
-                    }
-                    float v0 = 1.f, v1 = 1.f, v2 = 1.f, v3 = 1.f;
-                    if (HAS_VAL) {
-                        v0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_val), j));
-                        v1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_val), j + 1));
-                        v2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_val), j + 2));
-                        v3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_val), j + 3));
-                    }
-                    fma_vec(acc, v0, x0);
-                    fma_vec(acc, v1, x1);
-                    fma_vec(acc, v2, x2);
-                    fma_vec(acc, v3, x3);
-                }
-                for (; j < nk; ++j) {
-                    const int cj = __builtin_amdgcn_readlane(my_col, j);
-                    float vj = 1.f;
-                    if (HAS_VAL)
-                        vj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_val), j));
-                    if (act) {
-                        const V xv = *reinterpret_cast<const V *>(x + (int64_t)cj * ldx + c);
-                        fma_vec(acc, vj, xv);
-                    }
-                }
+                for (; j + SP_FLIGHT <= nk; j += SP_FLIGHT) group(j, std::false_type{});
+                if (j < nk) group(j, std::true_type{});
             }
             if (act) {
                 float a[VEC];
