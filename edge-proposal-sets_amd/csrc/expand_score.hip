@@ -438,11 +438,20 @@ __global__ __launch_bounds__(EX_THREADS) void expand_kernel(
                 cnt[i] = 0u;
             }
             __syncthreads();
-            for (uint32_t i = tid; i < n; i += EX_THREADS) {
-                const uint2 rec = my_scratch[b0 + i];
-                if (want_sum)
-                    atomicAdd(&acc[rec.x], (unsigned long long)ex_to_fixed(__builtin_bit_cast(float, rec.y)));
-                if (out_cn) atomicAdd(&cnt[rec.x], 1u);
+            for (uint32_t i0 = tid; i0 < n; i0 += 4 * EX_THREADS) {   // four records in flight per thread
+                uint2 rec[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const uint32_t i = i0 + q * EX_THREADS;
+                    rec[q] = my_scratch[b0 + (i < n ? i : i0)];
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (i0 + q * EX_THREADS >= n) break;
+                    if (want_sum)
+                        atomicAdd(&acc[rec[q].x], (unsigned long long)ex_to_fixed(__builtin_bit_cast(float, rec[q].y)));
+                    if (out_cn) atomicAdd(&cnt[rec[q].x], 1u);
+                }
             }
             __syncthreads();
             for (uint32_t i = tid; i < nslots; i += EX_THREADS) {
