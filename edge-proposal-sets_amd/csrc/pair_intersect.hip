@@ -146,6 +146,10 @@ __global__ __launch_bounds__(PI_WAVES * 64) void pair_scores_kernel(
                         x2 = __builtin_amdgcn_raw_buffer_load_b128(lrs, lane * 16 + 2048, 0, 0);
                         x3 = __builtin_amdgcn_raw_buffer_load_b128(lrs, lane * 16 + 3072, 0, 0);
                     }
+                    // ... and so is the first 64-entry slice of the short row: the pair then costs one memory round trip,
+                    // not two (most short rows ARE one slice)
+                    const int t_first = __builtin_amdgcn_raw_buffer_load_b32(srs, (s_cursor + lane) * 4, 0, 0);
+                    const int s_first = s_cursor;
                     __builtin_amdgcn_wave_barrier();
                     *reinterpret_cast<v4i *>(&L[4 * lane]) = pad_tail(x0, 4 * lane, n);
                     if (P > 256) *reinterpret_cast<v4i *>(&L[256 + 4 * lane]) = pad_tail(x1, 256 + 4 * lane, n);
@@ -163,7 +167,7 @@ __global__ __launch_bounds__(PI_WAVES * 64) void pair_scores_kernel(
                     const int last = multipass ? __builtin_amdgcn_readfirstlane(L[n - 1]) : 0x7fffffff;
                     for (int s0 = s_cursor; s0 < slen; s0 += 64) {
                         const int si = s0 + lane;
-                        const int t = __builtin_amdgcn_raw_buffer_load_b32(srs, si * 4, 0, 0);
+                        const int t = s0 == s_first ? t_first : __builtin_amdgcn_raw_buffer_load_b32(srs, si * 4, 0, 0);
                         const bool mine = si < slen && t <= last;       // a prefix of the lanes (sorted row)
                         const int n_mine = __popcll(__ballot(mine));
                         s_cursor = s0 + n_mine;
