@@ -179,3 +179,32 @@ def test_filter_rank_argument_surface(eps):
             "only_supervision", "also_supervision", "gen_dataset_only", "valid_proposal", "out_name", "save_models",
             "num_layers", "hidden_channels", "dropout", "batch_size", "lr", "epochs", "use_feature",
             "use_learnable_embedding", "device", "log_steps", "eval_steps"} <= r
+
+
+def test_path_counts_and_bucket_sizing_helpers():
+    """ops.max_column_paths (sizes the bucket scratch of the fused expansion) == max of candidates.path_counts over any
+    column range, incl. ranges that start or end with empty columns; segment_bounds caps the per-column bound at N."""
+    import eps_amd  # noqa: F401
+    from eps_amd import candidates, ops, synth
+    from eps_amd.graph import CSRGraph
+    g = synth.rmat_graph(10, 6, 3, "cpu")
+    pc = candidates.path_counts(g)
+    deg = g.rowptr[1:] - g.rowptr[:-1]
+    v = int(torch.argmax(deg))
+    want_v = int(deg[g.col[g.rowptr[v]:g.rowptr[v + 1]].long()].sum())
+    assert int(pc[v]) == want_v and candidates.max_paths_of(g) == int(pc.max())
+    for lo, hi in ((0, g.n_rows), (5, 300), (100, 101), (0, 1), (7, 7)):
+        assert ops.max_column_paths(g.rowptr, g.col, lo, hi) == (int(pc[lo:hi].max()) if hi > lo else 0)
+    rp = torch.tensor([0, 0, 2, 2, 3, 3], dtype=torch.int64)
+    col = torch.tensor([3, 1, 1], dtype=torch.int32)
+    small = CSRGraph(rp, col, None, 5, 5)
+    d = rp[1:] - rp[:-1]
+    for lo, hi in ((0, 5), (0, 1), (1, 2), (2, 5), (4, 5)):
+        want = max([int(d[col[rp[c]:rp[c + 1]].long()].sum()) for c in range(lo, hi)] + [0])
+        assert ops.max_column_paths(rp, col, lo, hi) == want
+    pre, pre_host = candidates.segment_bounds(g)
+    ub = pre[1:] - pre[:-1]
+    assert torch.equal(ub, torch.clamp(pc, max=g.n_rows)) and torch.equal(pre.cpu(), pre_host) and int(pre[0]) == 0
+    order = candidates.heaviest_first(g, 10, 200)
+    assert sorted(order.tolist()) == list(range(190)) and bool((pc[10:200][order.long()][:-1] >= pc[10:200][order.long()][1:]).all())
+    assert candidates.path_counts(small).tolist() == [0, int(d[3] + d[1]), 0, int(d[1]), 0]
