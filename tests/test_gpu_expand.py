@@ -268,3 +268,21 @@ def test_expand_score_cut(eps, dev):
     none = eps.ops.expand_candidates(g.rowptr, g.col, None, wt, g.n_rows, 0, g.n_rows, want_cn=False, want_score=False,
                                      cut=(float("inf"), 8))
     assert none.survivors[0].numel() == 0
+
+
+@pytest.mark.parametrize("n", [255, 257, 131072, 131073, 262145])
+def test_expand_id_range_boundaries(eps, dev, n):
+    """Node counts around the id-range table's limits (512 ranges of 2^k ids: k changes at 131,073 and 262,145 nodes; a
+    single range below 257): fused expansion of some columns == tensor-op candidates + column-run intersection kernel."""
+    from eps_amd import candidates, synth
+    from eps_amd.heuristics import node_weight_table
+    g = synth.rmat_graph(max(8, (n - 1).bit_length()), 6, 9, dev, n_nodes=n)
+    assert g.n_rows == n
+    wt = node_weight_table(g, eps.ops.W_AA)
+    lo, hi = (0, n) if n < 1000 else (n - 700, n)           # the last columns: ids in the last, partial range
+    colptr, cu, cv, cn, sc = eps.ops.expand_candidates(g.rowptr, g.col, None, wt, n, lo, hi)
+    pairs = candidates.two_hop_block(g, lo, hi)
+    assert torch.equal(torch.stack([cu, cv]).long(), pairs)
+    if cu.numel():
+        cnt, _, ws = eps.ops.pair_scores(g.rowptr, g.col, None, wt, n, cu, cv, want_cn=False, grouped=True)
+        assert torch.equal(cnt, cn) and rel_err(sc.cpu().numpy(), ws.cpu().numpy()) <= 1e-5
