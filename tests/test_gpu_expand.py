@@ -270,10 +270,10 @@ def test_expand_score_cut(eps, dev):
     assert none.survivors[0].numel() == 0
 
 
-@pytest.mark.parametrize("n", [255, 257, 131072, 131073, 262145])
+@pytest.mark.parametrize("n", [255, 257, 131072, 131073, 262145, 851968])
 def test_expand_id_range_boundaries(eps, dev, n):
     """Node counts around the id-range table's limits (512 ranges of 2^k ids: k changes at 131,073 and 262,145 nodes; a
-    single range below 257): fused expansion of some columns == tensor-op candidates + column-run intersection kernel."""
+    single range below 257; 851,968 = eps_expand_max_nodes(), the largest LDS footprint): fused expansion of some columns == tensor-op candidates + column-run intersection kernel."""
     from eps_amd import candidates, synth
     from eps_amd.heuristics import node_weight_table
     g = synth.rmat_graph(max(8, (n - 1).bit_length()), 6, 9, dev, n_nodes=n)
