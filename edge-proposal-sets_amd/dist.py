@@ -133,21 +133,23 @@ def all_gather_rows(local: torch.Tensor, bounds: Sequence[int]) -> torch.Tensor:
 
 
 def all_gather_keys(keys: torch.Tensor, k: int) -> List[torch.Tensor]:
-    """Gather every rank's (<= k) sorted int64 keys; short lists are padded with INT64_MIN (sorts last)."""
+    """Gather every rank's (<= k) sorted int64 keys.  The true lengths travel with the lists (every int64 bit pattern
+    is a legal key, so no value can serve as a padding sentinel)."""
     rank, world = world_info()
     if world == 1:
         return [keys]
-    pad = torch.full((k,), torch.iinfo(torch.int64).min, dtype=torch.int64, device=keys.device)
-    pad[:keys.numel()] = keys[:k]
-    out = _gather_into(pad, world)
-    return [out[r * k:(r + 1) * k] for r in range(world)]
+    n = min(int(keys.numel()), k)
+    pad = torch.zeros((k + 1,), dtype=torch.int64, device=keys.device)
+    pad[0] = n
+    pad[1:n + 1] = keys[:n]
+    out = _gather_into(pad, world).view(world, k + 1)
+    lens = out[:, 0].cpu().tolist()
+    return [out[r, 1:1 + int(lens[r])] for r in range(world)]
 
 
 def merge_topk(local_keys: torch.Tensor, k: int) -> torch.Tensor:
     """Global top-k keys (descending), identical on every rank and independent of the sharding."""
-    lists = all_gather_keys(local_keys, k)
-    allk = torch.cat(lists)
-    allk = allk[allk != torch.iinfo(torch.int64).min]
+    allk = torch.cat(all_gather_keys(local_keys, k))
     kk = min(k, allk.numel())
     return torch.topk(allk, kk, largest=True, sorted=True).values
 

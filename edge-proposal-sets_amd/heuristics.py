@@ -48,12 +48,25 @@ def _as_graph(A, device: Optional[torch.device] = None) -> CSRGraph:
     return g
 
 
-def _as_pairs(edge_index, device: torch.device) -> Tuple[torch.Tensor, torch.Tensor]:
-    """[2,E] integer tensor/array -> two contiguous int32 device vectors."""
+def check_node_ids(edge_index: torch.Tensor, n_nodes: int, what: str = "edge list") -> None:
+    """The kernels index rowptr / the embedding table with the ids they are given: an id outside [0, n_nodes) must stop
+    here (the reference raises IndexError in the same case), before it is narrowed to int32 or reaches the device."""
+    if edge_index.numel() == 0:
+        return
+    lo, hi = torch.aminmax(edge_index)
+    lo, hi = int(lo), int(hi)
+    if lo < 0 or hi >= n_nodes:
+        raise EpsError(f"{what}: node ids must lie in [0, {n_nodes}), got [{lo}, {hi}]")
+
+
+def _as_pairs(edge_index, device: torch.device, n_nodes: Optional[int] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """[2,E] integer tensor/array -> two contiguous int32 device vectors (ids range-checked against ``n_nodes``)."""
     if isinstance(edge_index, np.ndarray):
         edge_index = torch.from_numpy(edge_index)
     if edge_index.dim() != 2 or edge_index.size(0) != 2:
         raise EpsError(f"expected a [2,E] edge list, got {tuple(edge_index.shape)}")
+    if n_nodes is not None:
+        check_node_ids(edge_index, n_nodes)
     e = edge_index.to(device=device, dtype=torch.int32, non_blocking=True)
     return e[0].contiguous(), e[1].contiguous()
 
@@ -101,7 +114,7 @@ def AA(A, edge_index, batch_size: int = 2000, device_out: bool = False):
     Returns ``(torch.FloatTensor[E], edge_index)`` exactly like the reference; weighted when A
     carries non-unit values (collab): score = sum_w A[u,w] * (A[v,w] / log(colsum[w]))."""
     g = _as_graph(A)
-    u, v = _as_pairs(edge_index, g.device)
+    u, v = _as_pairs(edge_index, g.device, g.n_rows)
     w = node_weight_table(g, ops.W_AA)
     _, _, ws = pair_scores_streamed(g, u, v, w)
     return (ws if device_out else ws.cpu()), edge_index
@@ -116,7 +129,7 @@ def resource_allocation(adj_matrix, link_list, batch_size: int = 32768, device_o
     g = _as_graph(adj_matrix)
     if isinstance(link_list, np.ndarray):
         link_list = torch.from_numpy(link_list)
-    u, v = _as_pairs(link_list.t(), g.device)
+    u, v = _as_pairs(link_list.t(), g.device, g.n_rows)
     w = node_weight_table(g, ops.W_RA, f64=f64)
     _, _, ws = pair_scores_streamed(g, u, v, w)
     ws = ws.to(torch.float32)
@@ -126,6 +139,6 @@ def resource_allocation(adj_matrix, link_list, batch_size: int = 32768, device_o
 def common_neighbors(adj: CSRGraph, edges: torch.Tensor) -> torch.Tensor:
     """CN(u,v) = sum_w adj[u,w]*adj[v,w] (models.py:536-542); float32 on the adjacency's device."""
     g = _as_graph(adj)
-    u, v = _as_pairs(edges, g.device)
+    u, v = _as_pairs(edges, g.device, g.n_rows)
     _, cn, _ = pair_scores_streamed(g, u, v, None, want_cn=True)
     return cn

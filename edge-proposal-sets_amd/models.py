@@ -224,6 +224,7 @@ class LinkPredictor(torch.nn.Module):
     @torch.no_grad()
     def decode(self, h: torch.Tensor, edges: torch.Tensor, apply_sigmoid: bool = True) -> torch.Tensor:
         """Fused gather + MLP + sigmoid over edges [2,B] (eps_mlp_decode) -> float32 [B].  Inference only."""
+        heuristics.check_node_ids(edges, h.shape[0], "decode edges")   # the kernel gathers h[u], h[v] unchecked
         e = edges.to(device=h.device, dtype=torch.int32)
         ws = [lin.weight.detach().contiguous() for lin in self.lins]
         bs = [lin.bias.detach().contiguous() for lin in self.lins]
@@ -325,6 +326,7 @@ class CommonNeighborsPredictor(torch.nn.Module):
             if key not in adj._cache:
                 adj._cache[key] = (1.0 / torch.log(adj.sum(-1) + 1e-6)).contiguous()
             g = adj if adj.val is None else adj.fill_value(1.0)
+            heuristics.check_node_ids(edges, g.n_rows)
             e = edges.to(device=adj.device, dtype=torch.int32)
             _, _, ws = ops.pair_scores(g.rowptr, g.col, None, adj._cache[key], g.n_rows, e[0].contiguous(),
                                        e[1].contiguous(), want_count=False, want_cn=False)
@@ -333,6 +335,7 @@ class CommonNeighborsPredictor(torch.nn.Module):
 
 
 # ----------------------------------------------------------------------------------- factory
+DECODE_MAX_HIDDEN = 256          # csrc/mlp_decode.hip: hdim % 4 == 0 && hdim <= 256
 _MODELS = ['sage', 'sage2', 'gcn', 'dea', 'dea_512', 'mlpcos', 'simplecos', 'adamic', 'simple', 'adamic_ogb',
            "resource_allocation", 'katz', 'ensemble_gcn_sage']
 _HEURISTICS = ['mlpcos', 'simplecos', 'adamic', 'simple', 'adamic_ogb', 'katz', "resource_allocation"]
@@ -350,6 +353,11 @@ def build_model(args, data, device):
     if args.use_feature:
         input_dim += data.x.shape[1]
     if args.model in ('sage', 'gcn'):
+        hc = args.hidden_channels
+        if hc is None or hc % 4 != 0 or hc > DECODE_MAX_HIDDEN:
+            # eps_mlp_decode keeps a 64-edge tile of width H in LDS: fail here, before any training time is spent
+            raise ValueError(f"--hidden_channels {hc}: the fused decode kernel takes a multiple of 4 up to "
+                             f"{DECODE_MAX_HIDDEN} (the reference's ogbl defaults are 256)")
         gnn_cls = SAGE if args.model == 'sage' else GCN
         gnn = gnn_cls(input_dim, args.hidden_channels, args.hidden_channels, args.num_layers, args.dropout).to(device)
         linkpred = LinkPredictor(args.hidden_channels, args.hidden_channels, 1, args.num_layers,

@@ -332,6 +332,14 @@ def mlp_decode(h: torch.Tensor, u, v, weights: Sequence[torch.Tensor], biases: S
 def pack_keys(score: torch.Tensor, ids: Optional[torch.Tensor] = None, id_base: int = 0) -> torch.Tensor:
     dev = _need_gpu(score, ids)
     _chk(score, torch.float32, "score"); _chk(ids, torch.int64, "ids")
+    # the key holds the id in its low 32 bits: an id the kernel would truncate aliases another candidate's key
+    if ids is not None and ids.numel():
+        lo, hi = torch.aminmax(ids)
+        if int(lo) < 0 or int(hi) >= 1 << 32:
+            raise _lib.EpsError(f"pack_keys: ids must lie in [0, 2**32), got [{int(lo)}, {int(hi)}] "
+                                "(use shard-relative ids and merge_ranked_lists for longer candidate lists)")
+    elif ids is None and (id_base < 0 or id_base + score.numel() > 1 << 32):
+        raise _lib.EpsError("pack_keys: id_base + n exceeds the 32-bit id field of the key")
     keys = torch.empty(score.numel(), dtype=torch.int64, device=dev)  # bit pattern of the uint64 key
     with torch.cuda.device(dev):
         _lib.check(_lib.load().eps_pack_keys(_ptr(score), _ptr(ids), id_base, score.numel(), _ptr(keys),

@@ -76,6 +76,15 @@ def splice_valid_proposals(sorted_test_edges: torch.Tensor, valid_pos: torch.Ten
     return torch.cat([top, p[keep, :3]], 0)
 
 
+def append_supervision(args, split_edge, extra_edges: torch.Tensor) -> None:
+    """rank.py:303-304: with ``--only_supervision`` / ``--also_supervision`` the proposal edges become additional
+    training POSITIVES (appended to ``split_edge['train']['edge']``; like the reference, the append accumulates over the
+    sweep points of one invocation)."""
+    if args.only_supervision or args.also_supervision:
+        tr = split_edge['train']['edge']
+        split_edge['train']['edge'] = torch.cat((tr, extra_edges.t().to(tr.device, tr.dtype)))
+
+
 def sweep_schedule(args):
     """rank.py:260-272."""
     index_ends = []
@@ -149,6 +158,7 @@ def run(args):
         assert extra_edges.size(0) == 2 and extra_edges.size(1) == index_end
         if not args.only_supervision:
             data.adj_t = add_edges(args.dataset, ei_dev, ew_dev, extra_edges.to(device), data.num_nodes)
+        append_supervision(args, split_edge, extra_edges)
         if args.dataset in ["collab", "email", "reddit"]:
             val_edge_index = to_undirected(split_edge['valid']['edge'].t())
             full_extra_edges = torch.cat([extra_edges, val_edge_index], dim=-1)

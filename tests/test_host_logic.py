@@ -168,6 +168,23 @@ def test_rank_stage_helpers(eps):
     assert top == {(1, 2), (2, 1), (3, 4), (4, 3)}       # rank.py:249 assertion: the top block covers valid_pos_set
 
 
+def test_rank_supervision_flags_append_proposals_to_train_set(eps):
+    """rank.py:303-304: --only_supervision / --also_supervision append the proposal edges to split_edge['train']['edge']
+    (accumulating over sweep points); without either flag the training set is untouched."""
+    from eps_amd import rank_stage
+    ns = argparse.Namespace
+    extra = torch.tensor([[7, 8, 9], [1, 2, 3]])                      # [2,k] like sorted_test_edges[:k,:2].t().long()
+    for flags, grows in ((dict(only_supervision=True, also_supervision=False), True),
+                         (dict(only_supervision=False, also_supervision=True), True),
+                         (dict(only_supervision=False, also_supervision=False), False)):
+        split = {'train': {'edge': torch.tensor([[0, 1], [2, 3]])}}
+        rank_stage.append_supervision(ns(**flags), split, extra)
+        want = [[0, 1], [2, 3]] + ([[7, 1], [8, 2], [9, 3]] if grows else [])
+        assert split['train']['edge'].tolist() == want
+        rank_stage.append_supervision(ns(**flags), split, extra[:, :1])       # second sweep point: accumulates
+        assert split['train']['edge'].tolist() == want + ([[7, 1]] if grows else [])
+
+
 def test_filter_rank_argument_surface(eps):
     """Same flags as the reference parsers (filter.py:27-47, rank.py:130-163) + the documented extensions."""
     from eps_amd import filter_stage, rank_stage
