@@ -15,6 +15,8 @@ Fixtures
   gnn_stack_*.npz    reference GCN/SAGE/LinkGNN layer loops (models.py:181-187, :434-440,
                      :500-506) driven over the oracle's conv restatement injected as the
                      GCNConv/SAGEConv stub: pins loop structure, not conv arithmetic.
+  sageconv_ref_*.npz the reference's vendored SAGEConv2.forward (models.py:358-384) run over a stand-in
+                     SparseTensor/matmul, with and without its extra hop (:366): pins the SAGE conv arithmetic.
   model_configs.json default_model_configs output for every (dataset, model).
   state_dict_keys.json
 """
@@ -86,13 +88,53 @@ def install_stubs():
     typing_.OptPairTensor = typing_.Adj = typing_.Size = object
 
     class MessagePassing(torch.nn.Module):
-        def __init__(self, *a, **k):
+        """Minimal torch_geometric 1.7.0 MessagePassing [3p]: keeps ``aggr`` and, for a sparse adjacency, routes
+        ``propagate`` to the subclass's fused ``message_and_aggregate`` -- the only route the reference's vendored
+        SAGEConv2 (models.py:358-384) takes with a SparseTensor.  ``SKIP_ROOTLESS`` makes a propagate whose input is
+        ``(out, None)`` an identity: that is models.py:366, the extra hop that distinguishes SAGEConv2 from PyG's
+        SAGEConv, so with the switch on the reference's own forward IS the SAGEConv arithmetic."""
+        SKIP_ROOTLESS = False
+
+        def __init__(self, *a, aggr="add", **k):
             super().__init__()
+            self.aggr = aggr
+
+        def propagate(self, edge_index, size=None, **kwargs):
+            x = kwargs["x"]
+            if MessagePassing.SKIP_ROOTLESS and isinstance(x, tuple) and x[1] is None:
+                return x[0]
+            return self.message_and_aggregate(edge_index, x)
 
     conv.MessagePassing = MessagePassing
     ts = mod("torch_sparse")
-    ts.SparseTensor = object
-    ts.matmul = None
+
+    class SparseTensor:
+        """Pattern + optional values of a square sparse matrix [3p stand-in]: just what models.py:379-380 touches."""
+
+        def __init__(self, csr, has_value=True):
+            self.csr, self.has_value = csr, has_value
+
+        def set_value(self, value, layout=None):
+            assert value is None
+            return SparseTensor(self.csr, has_value=False)
+
+    def matmul(src, other, reduce="sum"):
+        """torch_sparse.matmul [3p]: rows reduced over their STORED entries; 'mean' divides the sum by the number of
+        stored entries of the row (empty rows give 0)."""
+        A = src.csr.astype(np.float64)
+        if not src.has_value:
+            A = A.copy()
+            A.data[:] = 1.0
+        out = A @ other.detach().numpy().astype(np.float64)
+        if reduce == "mean":
+            cnt = np.diff(src.csr.indptr).astype(np.float64)
+            out = out / np.maximum(cnt, 1.0)[:, None]
+        else:
+            assert reduce in ("sum", "add")
+        return torch.from_numpy(out.astype(np.float32))
+
+    ts.SparseTensor = SparseTensor
+    ts.matmul = matmul
     ts.sum = None
 
     # Conv stubs: parameters laid out like torch_geometric 1.7.0 [3p] (GCNConv.weight [in,out] +
@@ -276,6 +318,41 @@ def emit_gnn_stack(models):
             print(f"gnn_stack_{kind}_L{L}: keys={list(model.state_dict().keys())}")
 
 
+def emit_sageconv_witness(models):
+    """The reference vendors ONE conv implementation on this path: SAGEConv2 (models.py:317-384), PyG's SAGEConv plus a
+    second hop (:366).  Running its own ``forward`` over the stand-in SparseTensor / matmul pins what the restatement
+    otherwise takes from PyG's documentation: aggregate = MEAN over stored neighbours (:336), edge values dropped
+    (:379), no self loop, ``lin_l`` (with bias) on the aggregate, ``lin_r`` (no bias, :349) on the root, summed
+    (:367-371).  ``out_1hop``: line :366 skipped (== SAGEConv); ``out_2hop``: the class as written."""
+    conv_mod = sys.modules["torch_geometric.nn.conv"]
+    rng = np.random.default_rng(11)
+    graphs = {}
+    n = 60
+    M = np.triu(rng.random((n, n)) < 0.12, 1)
+    A = (M | M.T).astype(np.float32)
+    A[5, :] = 0
+    A[:, 5] = 0                                    # isolated node: mean over nothing = 0
+    graphs["plain"] = A
+    W = A * rng.integers(1, 6, size=A.shape).astype(np.float32)
+    graphs["weighted"] = np.maximum(W, W.T)        # collab-like values: must not change the mean
+    for tag, Ad in graphs.items():
+        torch.manual_seed(5)
+        fin, fout = 10, 8
+        conv = models.SAGEConv2(fin, fout)
+        x = torch.randn(Ad.shape[0], fin)
+        adj = sys.modules["torch_sparse"].SparseTensor(ssp.csr_matrix(Ad))
+        with torch.no_grad():
+            conv_mod.MessagePassing.SKIP_ROOTLESS = True
+            out1 = conv(x, adj)
+            conv_mod.MessagePassing.SKIP_ROOTLESS = False
+            out2 = conv(x, adj)
+        np.savez_compressed(os.path.join(OUT, f"sageconv_ref_{tag}.npz"), A=Ad, x=x.numpy(),
+                            lin_l_weight=conv.lin_l.weight.detach().numpy(), lin_l_bias=conv.lin_l.bias.detach().numpy(),
+                            lin_r_weight=conv.lin_r.weight.detach().numpy(), out_1hop=out1.numpy(), out_2hop=out2.numpy())
+        print(f"sageconv_ref_{tag}: |out_1hop| max {out1.abs().max():.3f}, |out_2hop - out_1hop| max "
+              f"{(out2 - out1).abs().max():.3f}")
+
+
 def emit_configs(models):
     datasets = ["ddi", "collab", "ppa", "reddit", "twitch", "fb", "email"]
     names = ['sage', 'sage2', 'gcn', 'dea', 'dea_512', 'mlpcos', 'simplecos', 'adamic', 'simple', 'adamic_ogb',
@@ -315,6 +392,7 @@ def main():
     emit_pairs(adamic_utils, train_and_eval)
     emit_linkpred(models)
     emit_gnn_stack(models)
+    emit_sageconv_witness(models)
     emit_configs(models)
 
 

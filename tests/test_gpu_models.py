@@ -44,6 +44,31 @@ def test_linkgnn_matches_reference_stack(eps, dev, kind, L):
     assert model.embeddings(x, adj) is not h
 
 
+@pytest.mark.parametrize("tag", ["plain", "weighted"])
+def test_sage_conv_matches_reference_witness(eps, dev, tag):
+    """HIP SAGEConv (mean-mode SpMM + two GEMMs) against the reference's own vendored conv code
+    (models.SAGEConv2.forward, models.py:358-384; fixture made by oracle/gen_golden.py): ``out_1hop`` is the class with
+    its extra hop (:366) skipped == SAGEConv; ``out_2hop`` is the class as written (two mean aggregations)."""
+    import scipy.sparse as ssp
+    from eps_amd import models, ops
+    d = np.load(os.path.join(GOLDEN, f"sageconv_ref_{tag}.npz"))
+    fin, fout = d["x"].shape[1], d["lin_l_weight"].shape[0]
+    conv = models.SAGEConv(fin, fout)
+    conv.load_state_dict({"lin_l.weight": torch.from_numpy(d["lin_l_weight"]), "lin_l.bias": torch.from_numpy(d["lin_l_bias"]),
+                          "lin_r.weight": torch.from_numpy(d["lin_r_weight"])})
+    conv = conv.to(dev).eval()
+    adj = eps.CSRGraph.from_scipy(ssp.csr_matrix(d["A"]), device=dev)
+    x = torch.from_numpy(d["x"]).to(dev)
+    out = conv(x, adj).cpu().numpy()
+    assert float(np.abs(out - d["out_1hop"]).max()) <= TOL * max(1.0, float(np.abs(d["out_1hop"]).max()))
+    xp = torch.zeros((x.shape[0], 12), device=dev)
+    xp[:, :fin] = x                                              # float4 rows for the bare SpMM
+    agg2 = ops.spmm_csr(adj.rowptr, adj.col, None, ops.spmm_csr(adj.rowptr, adj.col, None, xp, mean=True), mean=True)[:, :fin]
+    out2 = ops.gemm(agg2.contiguous(), conv.lin_l.weight.detach(), bias=conv.lin_l.bias.detach())
+    out2 = ops.gemm(x, conv.lin_r.weight.detach(), out=out2, accumulate=True).cpu().numpy()
+    assert float(np.abs(out2 - d["out_2hop"]).max()) <= TOL * max(1.0, float(np.abs(d["out_2hop"]).max()))
+
+
 def test_linkpredictor_reference_signature(eps, dev):
     from eps_amd import models
     d = np.load(os.path.join(GOLDEN, "linkpred_H256_L3.npz"))

@@ -93,6 +93,31 @@ def test_gnn_stack_structure(oracle, kind, L):
     assert rel_err(prob, d["prob"]) <= 1e-5
 
 
+@pytest.mark.parametrize("tag", ["plain", "weighted"])
+def test_sage_conv_matches_reference_witness(oracle, tag):
+    """The SAGE conv arithmetic against the reference's OWN conv code: models.SAGEConv2.forward (models.py:358-384) run
+    by oracle/gen_golden.py with its extra hop (:366) skipped (``out_1hop`` == PyG SAGEConv) and as written (``out_2hop``).
+    Pins mean-over-stored-neighbours, values ignored, no self loop, lin_l bias / lin_r no bias, for the dense float64
+    formula and for the CSR float32 restatement (C spmm) the GPU tests compare against."""
+    d = np.load(os.path.join(GOLDEN, f"sageconv_ref_{tag}.npz"))
+    A, x = d["A"], d["x"]
+    wl, bl, wr = [d["lin_l_weight"]], [d["lin_l_bias"]], [d["lin_r_weight"]]
+    h = oracle.sage_dense_forward(A, x, wl, bl, wr)
+    assert np.abs(h - d["out_1hop"]).max() <= 1e-5 * max(1.0, np.abs(d["out_1hop"]).max())
+    Acsr = ssp.csr_matrix(A)
+    Acsr.sort_indices()
+    h32 = oracle.sage_forward_csr(Acsr.indptr, Acsr.indices, x, wl, bl, wr)
+    assert np.abs(h32 - d["out_1hop"]).max() <= 1e-5 * max(1.0, np.abs(d["out_1hop"]).max())
+    # the class as written: the aggregate of the aggregate goes through lin_l, the root term is unchanged
+    agg1 = oracle.spmm_csr(Acsr.indptr, Acsr.indices, None, x.astype(np.float32), mean=True)
+    agg2 = oracle.spmm_csr(Acsr.indptr, Acsr.indices, None, agg1, mean=True)
+    out2 = agg2 @ wl[0].T + bl[0] + x @ wr[0].T
+    assert np.abs(out2 - d["out_2hop"]).max() <= 1e-5 * max(1.0, np.abs(d["out_2hop"]).max())
+    if tag == "weighted":      # edge values never enter the mean (models.py:379 set_value(None))
+        p = np.load(os.path.join(GOLDEN, "sageconv_ref_plain.npz"))
+        assert np.array_equal(p["out_1hop"], d["out_1hop"]) and np.array_equal((p["A"] != 0), (A != 0))
+
+
 def test_hits_at_k(oracle):
     rng = np.random.default_rng(0)
     pos = rng.random(1000).astype(np.float32)
