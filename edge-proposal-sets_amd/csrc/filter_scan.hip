@@ -1,0 +1,670 @@
+// Threshold scan of the filter stage's candidate set, gfx950: every 2-hop non-edge whose heuristic score exceeds a
+// bar, found WITHOUT materialising the candidate list.
+//
+// What it replaces.  filter.py:96-109 builds all 2-hop non-edges on the host, :113-142 score them batch by batch
+// (adamic_utils.py:13-25, train_and_eval.py:195-216, models.py:536-542), :160-161 sort all E rows -- and rank.py:294
+// then reads the first `num_sorted_edge` of them.  With `--keep_top K` only candidates above the K-th best score
+// matter, so this kernel computes the score of EVERY candidate but reports only those above `threshold` (the host
+// derives the bar from a column sample and verifies that at least K survive: edge-proposal-sets_amd/candidates.py).
+//
+// Three things make it cheaper than eps_expand_fill, which it otherwise follows (propagation blocking of the
+// 2-hop paths of a column over an LDS bitmap, order-independent 2^-40 fixed-point sums):
+//   * SYMMETRY.  For a symmetric unit-valued adjacency the score of (u,v) equals that of (v,u), term by term.
+//     Column v only expands the endpoints u < v: of row w = N(v)[k] only the first revpos[e] entries (the position
+//     of v in row w, a per-graph table) are walked -- half the two-hop paths -- and the host mirrors the survivors.
+//   * NOTHING PER CANDIDATE LEAVES THE CHIP.  No candidate list, no score array: a survivor's u is recovered from
+//     the rank tables that are still in LDS.  The only bulk traffic left is the bucket records, now 4 bytes
+//     (rank in tile | index k of w in N(v)); the fixed-point weight of (v,w) comes from an LDS table built once per
+//     column instead of one float->fixed conversion per path.  Columns whose candidates fit one tile accumulate
+//     straight into LDS and write no records at all.
+//   * PACKED UNITS.  Row heads shorter than a wave-wide unit would leave most lanes idle (mean row head: ~200
+//     entries), so the walk is over 64-entry units of a virtual concatenation of the rows, four units (possibly of
+//     four different rows) per wave instruction, dealt round-robin over the 16 waves: a unit -> row map is built
+//     per round of <= 2048 units by one block-wide max-scan.
+// Scores are bit-identical to eps_expand_fill's (same fixed-point terms, same final rounding).
+#include "eps_common.h"
+
+#define FS_THREADS 1024
+#define FS_WAVES (FS_THREADS / 64)
+#define FS_FIXED_SHIFT 40
+#define FS_RC 512            // rows (neighbours w of v) described per round
+#define FS_UR 2048           // 64-entry units per round (two list entries per thread)
+#define FS_RANGES 512        // id ranges per column: path histogram and tile plan
+#define FS_CHUNK 8192        // survivor slots reserved per global atomic
+#define FS_MAX_TILE_BITS 12  // candidate ranks per tile <= 4096 (8-byte accumulators in LDS)
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+
+// LDS carve-up, in 32-bit words from the start of the dynamic region (every section starts 8-byte aligned)
+struct fs_layout {
+    int words;      // bitmap words, a multiple of 1024
+    int tile;       // candidate ranks per tile
+    int o_base32, o_pre8, o_acc, o_hist, o_rinfo, o_tile_r0, o_tile_base, o_tile_cur, o_ustart, o_rbase, o_rlen,
+        o_ulist, o_vwfix, total_words;
+};
+
+__host__ __device__ static inline fs_layout fs_make_layout(int words, int tile_bits)
+{
+    fs_layout L;
+    L.words = words;
+    L.tile = 1 << tile_bits;
+    int o = words;
+    L.o_base32 = o;  o += words / 8;
+    L.o_pre8 = o;    o += words / 4;
+    L.o_acc = o;     o += 2 * L.tile;
+    L.o_hist = o;    o += FS_RANGES;
+    L.o_rinfo = o;   o += FS_RANGES;
+    L.o_tile_r0 = o; o += FS_RANGES + 2;
+    L.o_tile_base = o; o += FS_RANGES + 2;
+    L.o_tile_cur = o;  o += FS_RANGES;
+    L.o_ustart = o;  o += FS_RC + 2;
+    L.o_rbase = o;   o += FS_RC + 2;
+    L.o_rlen = o;    o += FS_RC + 2;
+    L.o_ulist = o;   o += FS_UR / 2;
+    L.o_vwfix = o;   o += 2 * FS_RC;
+    L.total_words = o;
+    return L;
+}
+
+struct fs_params {
+    const int64_t *rowptr;
+    const int32_t *col;
+    const int32_t *revpos;
+    const int64_t *fixw;
+    const int32_t *columns;
+    int32_t n_columns;
+    int32_t n_nodes;
+    uint32_t col_bytes;
+    int32_t words;
+    int32_t tile_bits;
+    int32_t range_shift;
+    uint32_t cap_records;     // bucket records per workgroup
+    unsigned int *next_col;
+    eps_survivors *out;
+    uint32_t *scratch;        // cap_records words per workgroup
+};
+
+__device__ __forceinline__ int fs_wave_incl_scan(int x, int lane)
+{
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int y = __shfl_up(x, o);
+        if (lane >= o) x += y;
+    }
+    return x;
+}
+
+__device__ __forceinline__ int fs_wave_incl_max(int x, int lane)
+{
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int y = __shfl_up(x, o);
+        if (lane >= o) x = x > y ? x : y;
+    }
+    return x;
+}
+
+// one quad of units in flight: the 16 bytes a lane loaded plus where they came from
+struct fs_unit {
+    v4i u4;
+    int row;      // row of the round (index into the descriptor arrays; FS_RC = the empty dummy row)
+    int nvalid;   // 0..4 entries of u4 that belong to the row head
+};
+
+__global__ __launch_bounds__(FS_THREADS) void filter_scan_kernel(fs_params p)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const fs_layout L = fs_make_layout(p.words, p.tile_bits);
+    uint32_t *bm = lds;                                   // bit u: u (< v) is a two-hop endpoint of the column
+    uint32_t *base32 = lds + L.o_base32;                  // rank of the first bit of every 8-word group
+    uint8_t *pre8 = (uint8_t *)(lds + L.o_pre8);          // rank of a word's first bit within its group
+    unsigned long long *acc = (unsigned long long *)(lds + L.o_acc);   // fixed-point sums of one tile; zero between uses
+    uint32_t *hist = lds + L.o_hist;                      // paths per id range (pass A); zero between columns
+    uint32_t *rinfo = lds + L.o_rinfo;                    // (tile of the range << 20) | first rank of that tile
+    uint32_t *tile_r0 = lds + L.o_tile_r0;                // first candidate rank of a tile; [n_tiles] = column total
+    uint32_t *tile_base = lds + L.o_tile_base;            // paths of the column before the tile; [n_tiles] = all
+    uint32_t *tile_cur = lds + L.o_tile_cur;              // next free record of the tile's bucket (window-relative)
+    int32_t *ustart = (int32_t *)(lds + L.o_ustart);      // first unit of a row in the round's unit numbering
+    uint32_t *rbase = lds + L.o_rbase;                    // first entry of the row in col[]
+    uint32_t *rlen = lds + L.o_rlen;                      // entries of the row below v
+    uint16_t *ulist = (uint16_t *)(lds + L.o_ulist);      // unit -> row of the round, + 1
+    long long *vwfix = (long long *)(lds + L.o_vwfix);    // fixed-point weight of (v, row)
+    __shared__ int s_wtot[FS_WAVES];
+    __shared__ unsigned int s_ticket;
+    __shared__ int s_done, s_next_c, s_ntiles, s_thi;
+    __shared__ unsigned int s_out_cur, s_out_end;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wib = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = lane >> 4, gl = lane & 15;
+    const int words = p.words, TILE = L.tile, tile_half = TILE >> 1, range_shift = p.range_shift;
+    const uint32_t tile_mask = (uint32_t)TILE - 1u;
+    const float thr = p.out->threshold;
+    const uint32_t out_cap = p.out->capacity;
+    int64_t *__restrict__ out_key = p.out->key;
+    float *__restrict__ out_val = p.out->val;
+    uint32_t *__restrict__ my_scratch = p.scratch + (size_t)blockIdx.x * p.cap_records;
+    const __amdgpu_buffer_rsrc_t col_rs = __builtin_amdgcn_make_buffer_rsrc((void *)p.col, 0, p.col_bytes, 0x00020000);
+
+    for (int i = tid; i < words; i += FS_THREADS) bm[i] = 0u;
+    for (int i = tid; i < TILE; i += FS_THREADS) acc[i] = 0ull;
+    if (tid < FS_RANGES) hist[tid] = 0u;
+    if (tid == 0) {
+        s_out_cur = 0u;
+        s_out_end = 0u;
+        ustart[FS_RC] = 0;       // the dummy row: units past the end of a round read nothing
+        rbase[FS_RC] = 0u;
+        rlen[FS_RC] = 0u;
+    }
+
+    for (;;) {
+        __syncthreads();
+        if (tid == 0) s_ticket = atomicAdd(p.next_col, 1u);
+        __syncthreads();
+        if (s_ticket >= (unsigned int)p.n_columns) break;
+        const int32_t v = p.columns[s_ticket];
+        const int64_t vb = p.rowptr[v];
+        const int32_t dv = (int32_t)(p.rowptr[v + 1] - vb);
+        if (dv == 0 || v == 0) continue;
+        const int32_t *__restrict__ vcol = p.col + vb;
+        const int32_t *__restrict__ vrev = p.revpos + vb;
+        const int words_v = (v + 31) >> 5;
+
+        // ---- describe a round: rows j0.. of N(v) from chunk c0 of row j0, until FS_RC rows or FS_UR units ------------
+        // Leaves the descriptors + the unit -> row list in LDS; -> units of the round; s_done / s_next_c = the cursor after it.
+        auto build_round = [&](int j0, int c0) -> int {
+            int nun = 0;
+            uint32_t rb = 0, rl = 0;
+            long long fx = 0;
+            const bool row_ok = tid < FS_RC && j0 + tid < dv;
+            if (row_ok) {
+                const int32_t w = vcol[j0 + tid];
+                rl = (uint32_t)vrev[j0 + tid];
+                rb = (uint32_t)p.rowptr[w];
+                fx = p.fixw[w];
+                nun = (int)((rl + 63u) >> 6);
+                if (tid == 0) nun -= c0;
+            }
+            int incl = fs_wave_incl_scan(nun, lane);
+            if (lane == 63) s_wtot[wib] = incl;
+            if (tid < FS_UR / 2) ((uint32_t *)ulist)[tid] = 0u;
+            if (tid == 0) {
+                s_done = 0;
+                s_next_c = 0;
+            }
+            __syncthreads();
+            int woff = 0, total = 0;
+#pragma unroll
+            for (int i = 0; i < FS_RC / 64; ++i) {
+                const int t = s_wtot[i];
+                if (i < wib) woff += t;
+                total += t;
+            }
+            incl += woff;
+            const int excl = incl - nun;
+            if (tid < FS_RC) {
+                ustart[tid] = excl - (tid == 0 ? c0 : 0);
+                rbase[tid] = rb;
+                rlen[tid] = rl;
+                vwfix[tid] = fx;
+                if (nun > 0 && excl < FS_UR) ulist[excl] = (uint16_t)(tid + 1);
+            }
+            // rows whose units all fit are done; the first row that does not fit is cut (continues in the next round)
+            const unsigned long long dm = __ballot(row_ok && incl <= FS_UR);
+            if (lane == 0 && dm) atomicAdd(&s_done, __popcll(dm));
+            if (row_ok && incl > FS_UR && excl <= FS_UR) s_next_c = (FS_UR - excl) + (tid == 0 ? c0 : 0);
+            __syncthreads();
+            // unit -> row: the last row that starts at or before the unit (block-wide inclusive max-scan, 2 units per thread)
+            {
+                const uint32_t pr = ((uint32_t *)ulist)[tid];
+                int a = (int)(pr & 0xffffu), b = (int)(pr >> 16);
+                b = b > a ? b : a;
+                const int inc = fs_wave_incl_max(b, lane);
+                if (lane == 63) s_wtot[wib] = inc;
+                int prev = __shfl_up(inc, 1);
+                if (lane == 0) prev = 0;
+                __syncthreads();
+                int carry = 0;
+#pragma unroll
+                for (int i = 0; i < FS_WAVES; ++i) {
+                    const int t = s_wtot[i];
+                    if (i < wib) carry = carry > t ? carry : t;
+                }
+                prev = prev > carry ? prev : carry;
+                a = a > prev ? a : prev;
+                b = b > a ? b : a;
+                ((uint32_t *)ulist)[tid] = (uint32_t)a | ((uint32_t)b << 16);
+            }
+            __syncthreads();
+            return total < FS_UR ? total : FS_UR;
+        };
+
+        // ---- walk the units of a round: four units per wave instruction, quads dealt round-robin over the waves ---------
+        auto fetch = [&](int q, int n_units) -> fs_unit {
+            fs_unit f;
+            const int s = q * 4 + grp;
+            f.row = s < n_units ? (int)ulist[s] - 1 : FS_RC;
+            const int off = (s - ustart[f.row]) * 64 + gl * 4;
+            const int left = (int)rlen[f.row] - off;
+            f.nvalid = left < 0 ? 0 : (left > 4 ? 4 : left);
+            f.u4 = __builtin_amdgcn_raw_buffer_load_b128(col_rs, (int)((rbase[f.row] + (uint32_t)off) * 4u), 0, 0);
+            return f;
+        };
+        auto walk = [&](int n_units, auto body) {
+            const int nq = (n_units + 3) >> 2;
+            fs_unit cur = fetch(wib, n_units), nxt = fetch(wib + FS_WAVES, n_units);
+            for (int q = wib; q < nq; q += FS_WAVES) {
+                const fs_unit nn = fetch(q + 2 * FS_WAVES, n_units);
+                body(cur);
+                cur = nxt;
+                nxt = nn;
+            }
+        };
+
+        // ---- A. mark every two-hop endpoint below v; count the paths per id range ---------------------------------------
+        int j = 0, c = 0;
+        bool single = false;
+        int n_units = 0;
+        for (;;) {
+            n_units = build_round(j, c);
+            const int nj = j + s_done, nc = s_next_c;
+            single = j == 0 && c == 0 && nj >= dv;
+            walk(n_units, [&](const fs_unit &f) {
+                const uint32_t u0 = (uint32_t)f.u4[0], u3 = (uint32_t)f.u4[3];
+                if (f.nvalid == 4 && (u0 >> range_shift) == (u3 >> range_shift)) {
+                    atomicAdd(&hist[u0 >> range_shift], 4u);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const uint32_t u = (uint32_t)f.u4[e];
+                        atomicOr(&bm[u >> 5], 1u << (u & 31));
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (e >= f.nvalid) continue;
+                        const uint32_t u = (uint32_t)f.u4[e];
+                        atomicOr(&bm[u >> 5], 1u << (u & 31));
+                        atomicAdd(&hist[u >> range_shift], 1u);
+                    }
+                }
+            });
+            j = nj;
+            c = nc;
+            if (j >= dv) break;
+            __syncthreads();       // the next round overwrites the descriptors this walk reads
+        }
+        __syncthreads();
+        for (int k = tid; k < dv; k += FS_THREADS) {   // known edges out (the diagonal is not below v)
+            const uint32_t u = (uint32_t)vcol[k];
+            if (u < (uint32_t)v) atomicAnd(&bm[u >> 5], ~(1u << (u & 31)));
+        }
+        __syncthreads();
+
+        // ---- B. rank tables: exclusive prefix of the per-word popcounts over the words below v -------------------------
+        const int per = ((words_v + FS_THREADS - 1) >> 10) << 6;   // words per wave, a multiple of 64
+        const int w0 = wib * per + lane;
+        const int trips = per >> 6;
+        int local = 0;
+        for (int i = 0; i < trips; ++i) local += __popc(bm[w0 + 64 * i]);
+        {
+            const int inc = fs_wave_incl_scan(local, lane);
+            if (lane == 63) s_wtot[wib] = inc;
+        }
+        __syncthreads();
+        int wave_base = 0, total = 0;
+#pragma unroll
+        for (int i = 0; i < FS_WAVES; ++i) {
+            const int t = s_wtot[i];
+            if (i < wib) wave_base += t;
+            total += t;
+        }
+        const int n_ranges = ((v - 1) >> range_shift) + 1;
+        if (tid == 0 && total) atomicAdd(&p.out->n_candidates, (unsigned long long)total);
+        if (total == 0) {          // every endpoint is a neighbour of v: nothing to score
+            if (tid < n_ranges) hist[tid] = 0u;
+            for (int i = tid; i < words_v; i += FS_THREADS) bm[i] = 0u;
+            continue;
+        }
+        {
+            int wrun = wave_base;
+            for (int i = 0; i < trips; ++i) {
+                const int wi = w0 + 64 * i;
+                const int cbits = __popc(bm[wi]);
+                const int inc = fs_wave_incl_scan(cbits, lane);
+                const int run = wrun + inc - cbits;               // rank of this word's first bit
+                const int gbase = __shfl(run, lane & ~7);         // ... of its 8-word group's first bit
+                if ((lane & 7) == 0) base32[wi >> 3] = (uint32_t)run;
+                pre8[wi] = (uint8_t)(run - gbase);
+                wrun += __builtin_amdgcn_readlane(inc, 63);
+            }
+        }
+        __syncthreads();
+
+        // ---- plan: id ranges -> tiles of <= TILE candidate ranks; bucket offsets from the path histogram -------------------
+        {
+            const bool in = tid < n_ranges;
+            const uint32_t rs = in ? base32[tid << (range_shift - 8)] : 0u;   // rank at the start of the range
+            const uint32_t paths = in ? hist[tid] : 0u;
+            if (in) hist[tid] = 0u;
+            const int pin = fs_wave_incl_scan((int)paths, lane);
+            if (lane == 63) s_wtot[wib] = pin;
+            __syncthreads();
+            uint32_t pbase = 0, ptotal = 0;
+#pragma unroll
+            for (int i = 0; i < FS_WAVES; ++i) {
+                const uint32_t t = (uint32_t)s_wtot[i];
+                if (i < wib) pbase += t;
+                ptotal += t;
+            }
+            pbase += (uint32_t)pin - paths;
+            const uint32_t tile = rs / (uint32_t)tile_half;
+            const uint32_t rs_prev = (in && tid > 0) ? base32[(tid - 1) << (range_shift - 8)] : 0u;
+            if (in && (tid == 0 || rs_prev / (uint32_t)tile_half != tile)) {
+                tile_r0[tile] = rs;
+                tile_base[tile] = pbase;
+            }
+            if (tid == n_ranges - 1) {
+                s_ntiles = (int)tile + 1;
+                tile_r0[tile + 1] = (uint32_t)total;
+                tile_base[tile + 1] = ptotal;
+            }
+            __syncthreads();
+            if (in) rinfo[tid] = (tile << 20) | tile_r0[tile];
+            __syncthreads();
+        }
+        const int n_tiles = s_ntiles;
+
+        // ---- D. score: tiles are taken in windows; a window of one tile accumulates in LDS directly, a wider one bins ------
+        //      4-byte records (rank in tile | k << tile_bits) per tile in this workgroup's scratch and sums tile by tile.
+        auto scan_tile = [&](int t) {     // acc -> survivors; leaves acc zero.  Caller: barrier before (sums complete).
+            const uint32_t r0 = tile_r0[t], nslots = tile_r0[t + 1] - r0;
+            for (uint32_t i = tid; i < nslots; i += FS_THREADS) {
+                const long long a = (long long)acc[i];
+                acc[i] = 0ull;
+                const float sc = (float)((double)a * (1.0 / (double)(1ll << FS_FIXED_SHIFT)));
+                if (!(sc > thr)) continue;
+                // the candidate of rank r: last 8-word group whose first rank is <= r, then the word, then the bit
+                const uint32_t r = r0 + i;
+                int glo = 0, ghi = (words_v + 7) >> 3;          // groups [glo, ghi): invariant base32[glo] <= r
+                while (ghi - glo > 1) {
+                    const int mid = (glo + ghi) >> 1;
+                    if (base32[mid] <= r) glo = mid; else ghi = mid;
+                }
+                const uint32_t rg = r - base32[glo];
+                int wi = glo * 8, wj = 7;
+                while (wj > 0 && (uint32_t)pre8[wi + wj] > rg) --wj;
+                wi += wj;
+                uint32_t bits = bm[wi];
+                for (uint32_t sidx = rg - pre8[wi]; sidx > 0; --sidx) bits &= bits - 1;
+                const uint32_t u = (uint32_t)wi * 32u + (uint32_t)__builtin_ctz(bits);
+                const uint32_t pos = atomicAdd(&s_out_cur, 1u);
+                if (pos < out_cap) {
+                    out_key[pos] = ((int64_t)v << 32) | (int64_t)u;
+                    out_val[pos] = sc;
+                }
+            }
+        };
+        auto reserve_out = [&](int t) {   // thread 0, before the barrier that precedes scan_tile(t)
+            const uint32_t nslots = tile_r0[t + 1] - tile_r0[t];
+            if (s_out_end - s_out_cur < nslots) {
+                const uint32_t b = atomicAdd(&p.out->count, (unsigned int)FS_CHUNK);
+                s_out_cur = b;
+                s_out_end = b + FS_CHUNK;
+            }
+        };
+
+        int t_lo = 0;
+        while (t_lo < n_tiles) {
+            if (tid == 0) {
+                int t_hi = t_lo + 1;
+                while (t_hi < n_tiles && tile_base[t_hi + 1] - tile_base[t_lo] <= p.cap_records) ++t_hi;
+                s_thi = t_hi;
+            }
+            __syncthreads();
+            const int t_hi = s_thi;
+            const bool direct = t_hi - t_lo == 1;
+            const uint32_t win_base = tile_base[t_lo];
+            if (!direct && tid >= t_lo && tid < t_hi) tile_cur[tid] = tile_base[tid] - win_base;
+            // walk the paths again
+            j = 0;
+            c = 0;
+            for (;;) {
+                if (!single) n_units = build_round(j, c);
+                else __syncthreads();
+                const int nj = single ? dv : j + s_done, nc = single ? 0 : s_next_c;
+                const int j_round = j;
+                walk(n_units, [&](const fs_unit &f) {
+                    uint32_t u[4], word[4], rank[4], ri[4];
+                    bool cand[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) u[e] = e < f.nvalid ? (uint32_t)f.u4[e] : 0u;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) word[e] = bm[u[e] >> 5];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        rank[e] = base32[u[e] >> 8] + pre8[u[e] >> 5];
+                        ri[e] = rinfo[u[e] >> range_shift];
+                    }
+                    int ncand = 0;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const uint32_t tl = (ri[e] >> 20) - (uint32_t)t_lo;
+                        cand[e] = e < f.nvalid && ((word[e] >> (u[e] & 31)) & 1u) && tl < (uint32_t)(t_hi - t_lo);
+                        rank[e] += __popc(word[e] & ((1u << (u[e] & 31)) - 1u));
+                        rank[e] -= ri[e] & 0xFFFFFu;                  // rank inside its tile
+                        ncand += cand[e] ? 1 : 0;
+                    }
+                    if (ncand == 0) return;
+                    if (direct) {
+                        const unsigned long long fx = (unsigned long long)vwfix[f.row];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (cand[e]) atomicAdd(&acc[rank[e]], fx);
+                        return;
+                    }
+                    const uint32_t krec = (uint32_t)(j_round + f.row) << p.tile_bits;
+                    // entries of a lane are ascending: when its first and last candidate share a tile, all of them do
+                    uint32_t tfirst = 0, tlast = 0;
+                    bool seen = false;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (cand[e]) {
+                            if (!seen) tfirst = ri[e] >> 20;
+                            seen = true;
+                            tlast = ri[e] >> 20;
+                        }
+                    if (tfirst == tlast) {
+                        uint32_t pos = atomicAdd(&tile_cur[tfirst], (uint32_t)ncand);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (cand[e]) my_scratch[pos++] = rank[e] | krec;
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (cand[e]) my_scratch[atomicAdd(&tile_cur[ri[e] >> 20], 1u)] = rank[e] | krec;
+                    }
+                });
+                j = nj;
+                c = nc;
+                if (j >= dv) break;
+                __syncthreads();
+            }
+            if (direct) {
+                if (tid == 0) reserve_out(t_lo);
+                __syncthreads();
+                scan_tile(t_lo);
+            } else {
+                for (int t = t_lo; t < t_hi; ++t) {
+                    __syncthreads();               // records visible; acc zero (previous scan done)
+                    const uint32_t b0 = tile_base[t] - win_base, n = tile_cur[t] - b0;
+                    for (uint32_t i0 = tid; i0 < n; i0 += 4 * FS_THREADS) {   // four records in flight per thread
+                        uint32_t rec[4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const uint32_t i = i0 + q * FS_THREADS;
+                            rec[q] = my_scratch[b0 + (i < n ? i : i0)];
+                        }
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            if (i0 + q * FS_THREADS >= n) break;
+                            const uint32_t k = rec[q] >> p.tile_bits;
+                            const long long fx = single ? vwfix[k] : p.fixw[vcol[k]];
+                            atomicAdd(&acc[rec[q] & tile_mask], (unsigned long long)fx);
+                        }
+                    }
+                    if (tid == 0) reserve_out(t);
+                    __syncthreads();
+                    scan_tile(t);
+                }
+            }
+            __syncthreads();           // scans done before the next window rebuilds rounds / before the bitmap is cleared
+            t_lo = t_hi;
+        }
+        for (int i = tid; i < words_v; i += FS_THREADS) bm[i] = 0u;
+    }
+}
+
+// ---- per-graph tables -----------------------------------------------------------------------------------------------
+// revpos[e], e an entry of row v with w = col[e]: the number of entries of row w that are below v.  For a symmetric
+// adjacency that is the position of v in row w.  One wave per row v; a lower-bound search per entry.
+__global__ void reverse_positions_kernel(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+                                         int64_t n_nodes, int32_t *__restrict__ revpos)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t v = wave; v < n_nodes; v += n_waves) {
+        const int64_t b = rowptr[v], e = rowptr[v + 1];
+        for (int64_t i = b + lane; i < e; i += 64) {
+            const int32_t w = col[i];
+            int64_t lo = rowptr[w], hi = rowptr[w + 1];
+            const int64_t wb = lo;
+            while (lo < hi) {
+                const int64_t mid = (lo + hi) >> 1;
+                if (col[mid] < (int32_t)v) lo = mid + 1; else hi = mid;
+            }
+            revpos[i] = (int32_t)(lo - wb);
+        }
+    }
+}
+
+__global__ void fixed_weights_kernel(const float *__restrict__ w, int64_t n, int64_t *__restrict__ fixw)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        fixw[i] = __double2ll_rn((double)w[i] * (double)(1ll << FS_FIXED_SHIFT));
+}
+
+extern "C" int eps_reverse_positions(const int64_t *rowptr, const int32_t *col, int64_t n_nodes, int32_t *revpos,
+                                     void *stream)
+{
+    EPS_REQUIRE(n_nodes >= 0, "eps_reverse_positions: negative size");
+    if (n_nodes == 0) return EPS_OK;
+    EPS_REQUIRE(rowptr && col && revpos, "eps_reverse_positions: null pointer");
+    int64_t blocks = (n_nodes + 3) / 4;
+    const int64_t cap = (int64_t)eps_num_cus() * 16;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(reverse_positions_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, rowptr, col,
+                       n_nodes, revpos);
+    EPS_CHECK_LAUNCH("eps_reverse_positions");
+    return EPS_OK;
+}
+
+extern "C" int eps_fixed_weights(const float *node_w, int64_t n, int64_t *fixw, void *stream)
+{
+    EPS_REQUIRE(n >= 0, "eps_fixed_weights: negative size");
+    if (n == 0) return EPS_OK;
+    EPS_REQUIRE(node_w && fixw, "eps_fixed_weights: null pointer");
+    int64_t blocks = (n + 255) / 256;
+    const int64_t cap = (int64_t)eps_num_cus() * 8;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(fixed_weights_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, node_w, n, fixw);
+    EPS_CHECK_LAUNCH("eps_fixed_weights");
+    return EPS_OK;
+}
+
+// ---- launch ---------------------------------------------------------------------------------------------------------
+#define FS_LDS_LIMIT (160 * 1024 - 512)     // dynamic + the few static words
+
+static int fs_words(int64_t n_nodes) { return (int)(((n_nodes + 31) / 32 + 1023) / 1024 * 1024); }
+
+// largest tile (a power of two <= 4096 ranks) whose accumulators fit beside the bitmap of an n_nodes-id space; 0 = none
+static int fs_tile_bits(int64_t n_nodes)
+{
+    const int words = fs_words(n_nodes);
+    for (int tb = FS_MAX_TILE_BITS; tb >= 9; --tb)
+        if ((size_t)fs_make_layout(words, tb).total_words * 4 <= FS_LDS_LIMIT) return tb;
+    return 0;
+}
+
+static int fs_range_shift(int64_t n_nodes, int tile_bits)
+{
+    int s = 8;
+    while (((n_nodes - 1) >> s) + 1 > FS_RANGES) ++s;
+    return s <= tile_bits - 1 ? s : -1;       // a range may hold at most half a tile
+}
+
+extern "C" int64_t eps_filter_scan_max_nodes(void)
+{
+    int64_t n = 1 << 20;                      // ranks are packed in 20 bits
+    while (n > 0 && (fs_tile_bits(n) == 0 || fs_range_shift(n, fs_tile_bits(n)) < 0)) n -= 32768;
+    return n;
+}
+
+#define FS_DEFAULT_RECORDS (1u << 20)         // bucket records per workgroup: 4 MiB each, 1 GiB on 256 CUs
+
+extern "C" int64_t eps_filter_scan_workspace_bytes(void)
+{
+    return (int64_t)eps_num_cus() * FS_DEFAULT_RECORDS * 4;
+}
+
+extern "C" int eps_filter_scan(const int64_t *rowptr, const int32_t *col, const int32_t *revpos, const int64_t *fixw,
+                               int64_t n_nodes, int64_t nnz, const int32_t *columns, int64_t n_columns,
+                               eps_survivors *out, void *workspace, int64_t workspace_bytes, void *stream)
+{
+    EPS_REQUIRE(n_nodes >= 0 && n_columns >= 0 && nnz >= 0, "eps_filter_scan: negative size");
+    if (n_columns == 0 || n_nodes == 0) return EPS_OK;
+    EPS_REQUIRE(rowptr && col && revpos && fixw && columns && out, "eps_filter_scan: null pointer");
+    EPS_REQUIRE(nnz < (1ll << 30), "eps_filter_scan: col[] is addressed with 32-bit byte offsets (nnz < 2^30)");
+    EPS_REQUIRE(n_columns < (1ll << 31), "eps_filter_scan: too many columns");
+    const int tile_bits = fs_tile_bits(n_nodes);
+    const int range_shift = tile_bits ? fs_range_shift(n_nodes, tile_bits) : -1;
+    EPS_REQUIRE(n_nodes <= (1 << 20) && tile_bits > 0 && range_shift >= 8,
+                "eps_filter_scan: %lld nodes exceed the LDS bitmap (max %lld)", (long long)n_nodes,
+                (long long)eps_filter_scan_max_nodes());
+    int64_t blocks = eps_num_cus();
+    if (blocks > n_columns) blocks = n_columns;
+    EPS_REQUIRE(workspace && ((uintptr_t)workspace & 15) == 0 && workspace_bytes >= blocks * 4096,
+                "eps_filter_scan: needs a 16-byte aligned workspace (eps_filter_scan_workspace_bytes)");
+    int64_t cap = workspace_bytes / 4 / blocks;
+    if (cap > 0xFFFFFFF0ll) cap = 0xFFFFFFF0ll;
+    hipStream_t s = (hipStream_t)stream;
+    unsigned int *counter = nullptr;
+    int rc = eps_take_counter(&counter, s, "eps_filter_scan");
+    if (rc) return rc;
+    fs_params p;
+    p.rowptr = rowptr;
+    p.col = col;
+    p.revpos = revpos;
+    p.fixw = fixw;
+    p.columns = columns;
+    p.n_columns = (int32_t)n_columns;
+    p.n_nodes = (int32_t)n_nodes;
+    p.col_bytes = (uint32_t)(nnz * 4);
+    p.words = fs_words(n_nodes);
+    p.tile_bits = tile_bits;
+    p.range_shift = range_shift;
+    p.cap_records = (uint32_t)cap;
+    p.next_col = counter;
+    p.out = out;
+    p.scratch = (uint32_t *)workspace;
+    const size_t lds = (size_t)fs_make_layout(p.words, tile_bits).total_words * 4;
+    if (hipFuncSetAttribute((const void *)filter_scan_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
+        hipSuccess) {
+        eps_set_error("eps_filter_scan: cannot reserve %zu bytes of LDS", lds);
+        return EPS_ELAUNCH;
+    }
+    hipLaunchKernelGGL(filter_scan_kernel, dim3((unsigned)blocks), dim3(FS_THREADS), lds, s, p);
+    EPS_CHECK_LAUNCH("eps_filter_scan");
+    return EPS_OK;
+}

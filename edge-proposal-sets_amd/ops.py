@@ -262,6 +262,87 @@ def expand_candidates(rowptr, col, val, node_w, n_nodes: int, v_lo: int, v_hi: i
     return out
 
 
+# ------------------------------------------------------------------ threshold scan of the whole candidate set
+def filter_scan_max_nodes() -> int:
+    return int(_lib.load().eps_filter_scan_max_nodes())
+
+
+def reverse_positions(rowptr: torch.Tensor, col: torch.Tensor) -> torch.Tensor:
+    """int32[nnz]: for entry e of row v with w = col[e], the number of entries of row w below v (per-graph table)."""
+    dev = _need_gpu(rowptr, col)
+    _chk(rowptr, torch.int64, "rowptr"); _chk(col, torch.int32, "col")
+    out = torch.empty(col.numel(), dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.load().eps_reverse_positions(_ptr(rowptr), _ptr(col), rowptr.numel() - 1, _ptr(out), _stream(dev)),
+                   "eps_reverse_positions")
+    return out
+
+
+def fixed_weights(node_w: torch.Tensor) -> torch.Tensor:
+    """int64[N]: round(node_w * 2**40), the per-node weights in the scan kernel's fixed point."""
+    dev = _need_gpu(node_w)
+    _chk(node_w, torch.float32, "node_w")
+    out = torch.empty(node_w.numel(), dtype=torch.int64, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.load().eps_fixed_weights(_ptr(node_w), node_w.numel(), _ptr(out), _stream(dev)), "eps_fixed_weights")
+    return out
+
+
+_SCAN_WS = {}
+
+
+def _scan_scratch(dev) -> torch.Tensor:
+    """Bucket scratch of eps_filter_scan (1 GiB on 256 CUs): one buffer per device, stream-ordered."""
+    key = (dev.type, dev.index)
+    if key not in _SCAN_WS:
+        _SCAN_WS[key] = torch.empty(int(_lib.load().eps_filter_scan_workspace_bytes()) // 8, dtype=torch.int64, device=dev)
+    return _SCAN_WS[key]
+
+
+class Survivors:
+    """Device-resident eps_survivors record + its key / val arrays.  ``threshold`` may be a Python float or a 0-dim /
+    1-element float32 DEVICE tensor (copied on the stream: no host round trip)."""
+
+    def __init__(self, capacity: int, threshold, device):
+        import struct
+        self.capacity = int(capacity)
+        if not 0 < self.capacity < 1 << 32:
+            raise _lib.EpsError(f"Survivors: capacity {capacity} outside (0, 2**32)")
+        self.key = torch.full((self.capacity,), -1, dtype=torch.int64, device=device)
+        self.val = torch.empty(self.capacity, dtype=torch.float32, device=device)
+        thr_host = float(threshold) if not isinstance(threshold, torch.Tensor) else 0.0
+        head = struct.unpack("<q", struct.pack("<fI", thr_host, self.capacity))[0]
+        self.rec = torch.tensor([head, 0, self.key.data_ptr(), self.val.data_ptr(), 0], dtype=torch.int64, device=device)
+        if isinstance(threshold, torch.Tensor):
+            self.rec.view(torch.float32)[0:1].copy_(threshold.reshape(1).to(torch.float32))
+
+    def counts(self):
+        """(slots handed out, unordered candidates scored) -- one device read-back."""
+        c = self.rec[[1, 4]].tolist()
+        return int(c[0]) & 0xFFFFFFFF, int(c[1])
+
+    def valid(self, slots: int):
+        """(keys, scores) of the survivors among the first ``slots`` slots (unordered)."""
+        n = min(int(slots), self.capacity)
+        k = self.key[:n]
+        m = k >= 0
+        return k[m], self.val[:n][m]
+
+
+def filter_scan(rowptr, col, revpos, fixw, n_nodes: int, columns: torch.Tensor, out: Survivors) -> None:
+    """Launch eps_filter_scan over ``columns`` (int32 ids, hand-out order); survivors accumulate in ``out``."""
+    dev = _need_gpu(rowptr, col, revpos, fixw, columns)
+    _chk(rowptr, torch.int64, "rowptr"); _chk(col, torch.int32, "col"); _chk(revpos, torch.int32, "revpos")
+    _chk(fixw, torch.int64, "fixw"); _chk(columns, torch.int32, "columns")
+    if revpos.numel() != col.numel() or fixw.numel() != n_nodes:
+        raise _lib.EpsError("filter_scan: revpos / fixw do not match the graph")
+    ws = _scan_scratch(dev)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.load().eps_filter_scan(_ptr(rowptr), _ptr(col), _ptr(revpos), _ptr(fixw), n_nodes, col.numel(),
+                                               _ptr(columns), columns.numel(), _ptr(out.rec), _ptr(ws), ws.numel() * 8,
+                                               _stream(dev)), "eps_filter_scan")
+
+
 def spmm_csr(rowptr, col, val, x: torch.Tensor, bias=None, relu=False, mean=False, out=None) -> torch.Tensor:
     dev = _need_gpu(rowptr, col, val, x, bias, out, row_strided=(x, out))
     _chk(rowptr, torch.int64, "rowptr"); _chk(col, torch.int32, "col"); _chk(val, torch.float32, "val")

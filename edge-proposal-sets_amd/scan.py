@@ -1,0 +1,185 @@
+"""Exact top-K of the filter stage's candidate set without the candidate list (``filter.py --keep_top K``).
+
+The reference generates every 2-hop non-edge (filter.py:96-109), scores all of them (:113-142), sorts all E rows
+(:160-161) -- and rank.py:294 reads the first ``num_sorted_edge``.  Here the whole candidate set is still scored, but
+by ``eps_filter_scan`` (csrc/filter_scan.hip), which reports only the candidates above a bar:
+
+1. the bar is ESTIMATED from a column sample: every ``SAMPLE_STRIDE``-th column of the heaviest-first order is scanned
+   with no bar at all, and the score that ``SAFETY x K`` candidates of the whole graph are expected to exceed is read
+   off the sample (on the device: no host round trip);
+2. ONE launch scans all columns against that bar;
+3. the result is VERIFIED: if at least K candidates survived, the K best of them under the declared rule (score
+   descending, then candidate order ascending) ARE the K best of the whole set -- exact, whatever the estimate was.
+   Too few survivors (bar too high) or more than the list holds (bar too low) -> the bar is corrected from what was
+   found and step 2 repeats.
+
+Symmetry: the kernel scores each unordered pair {u, v} once (u < v) and the list is mirrored here; candidate order is
+the reference's column-major order, i.e. ascending key (v << 32 | u).
+
+Multi-GPU (one process per GPU): rank r scans the columns ``order[r::world]`` of the same heaviest-first order
+(balanced to within one column of every weight class); the graph is replicated; the sample and therefore the bar are
+computed redundantly and identically on every rank; the survivor lists are all-gathered (a few MB) and the selection
+runs on every rank -- no collective on the data path.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+
+from . import ops
+from .graph import CSRGraph
+
+SAMPLE_STRIDE = 256        # every n-th column (heaviest-first order) estimates the bar
+SAFETY = 3.0               # aim at SAFETY x K survivors
+SMALL_SET = 1 << 25        # candidate sets with at most this many two-hop half paths are scanned without a bar
+_CHUNK_SLACK = 8192 * 320  # survivor slots are handed out in chunks of 8192 per workgroup
+
+
+def scan_available(g: CSRGraph) -> bool:
+    """eps_filter_scan can take this graph: on the GPU, square, unit values, ids within the LDS bitmap."""
+    return (g.device.type == "cuda" and g.n_rows == g.n_cols and g.val is None and 0 < g.n_rows <= ops.filter_scan_max_nodes()
+            and g.nnz() < 1 << 30)
+
+
+def reverse_positions(g: CSRGraph) -> torch.Tensor:
+    if "revpos" not in g._cache:
+        g._cache["revpos"] = ops.reverse_positions(g.rowptr, g.col)
+    return g._cache["revpos"]
+
+
+def half_paths(g: CSRGraph) -> torch.Tensor:
+    """int64[N]: two-hop paths v - w - u with u < v per column v = the work of scanning it (cached)."""
+    if "half_paths" not in g._cache:
+        out = torch.zeros(g.n_rows, dtype=torch.int64, device=g.device)
+        out.index_add_(0, g.row_index(), reverse_positions(g).to(torch.int64))
+        g._cache["half_paths"] = out
+    return g._cache["half_paths"]
+
+
+def column_order(g: CSRGraph) -> torch.Tensor:
+    """int32[N]: all columns, heaviest first (a hub column is one workgroup's work for a long time: it must not start last)."""
+    if "scan_order" not in g._cache:
+        g._cache["scan_order"] = torch.argsort(half_paths(g), descending=True, stable=True).to(torch.int32)
+    return g._cache["scan_order"]
+
+
+def fixed_weights(g: CSRGraph, node_w: torch.Tensor) -> torch.Tensor:
+    key = ("fixw", node_w.data_ptr(), node_w._version)
+    if key not in g._cache:
+        g._cache[key] = ops.fixed_weights(node_w)
+    return g._cache[key]
+
+
+def _launch(g, fixw, columns, threshold, capacity) -> ops.Survivors:
+    out = ops.Survivors(capacity, threshold, g.device)
+    if columns.numel():
+        ops.filter_scan(g.rowptr, g.col, reverse_positions(g), fixw, g.n_rows, columns, out)
+    return out
+
+
+def estimate_bar(g: CSRGraph, fixw: torch.Tensor, k: int, stride: int = SAMPLE_STRIDE, safety: float = SAFETY):
+    """Score bar (1-element float32 device tensor) that about ``safety * k`` directed candidates are expected to exceed,
+    from a scan of every ``stride``-th column of the heaviest-first order; ``None`` = no bar (keep everything)."""
+    order = column_order(g)
+    sample = order[stride // 2::stride].contiguous()         # the middle of every weight stratum, not its heaviest column
+    hp = half_paths(g)
+    bound = int(hp[sample.long()].sum().item())          # unordered candidates of the sample <= its half paths
+    if bound == 0:
+        return None
+    res = _launch(g, fixw, sample, float("-inf"), 2 * bound + _CHUNK_SLACK)
+    slots, _ = res.counts()
+    _, vals = res.valid(slots)
+    m = int(safety * k / 2 / stride) + 1                 # unordered pairs of the SAMPLE above the bar we aim at
+    if m >= vals.numel():
+        return None
+    return torch.topk(vals, m, largest=True, sorted=True).values[-1:].clone()
+
+
+def _gather_varlen(t: torch.Tensor, world: int):
+    """All ranks' 1-D tensors (different lengths) concatenated in rank order."""
+    from . import dist as epd
+    n = torch.tensor([t.numel()], dtype=torch.int64, device=t.device)
+    lens = [int(x.item()) for x in epd.all_gather_list(n)]
+    mx = max(lens + [1])
+    pad = torch.zeros(mx, dtype=t.dtype, device=t.device)
+    pad[:t.numel()] = t
+    parts = epd.all_gather_list(pad)
+    return torch.cat([parts[r][:lens[r]] for r in range(world)])
+
+
+def select_topk(keys: torch.Tensor, vals: torch.Tensor, k: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    """The k best (score descending, key ascending) of a survivor list.  -> (keys, scores), sorted."""
+    if vals.numel() > k:
+        kth = torch.topk(vals, k, largest=True, sorted=True).values[-1]
+        m = vals >= kth                                    # every tie at the k-th score stays in until the order decides
+        keys, vals = keys[m], vals[m]
+    o = torch.argsort(keys)                                # candidate order ...
+    keys, vals = keys[o], vals[o]
+    o = torch.sort(vals, descending=True, stable=True).indices[:k]     # ... kept among equal scores
+    return keys[o], vals[o]
+
+
+def scan_topk(g: CSRGraph, node_w: torch.Tensor, k: int, rank: int = 0, world: int = 1, stats: Optional[dict] = None):
+    """Exact top-``k`` candidates of the whole graph: (pairs int64 [2,<=k] as (u; v), scores float32), best first.
+    ``stats`` (optional dict) receives ``candidates`` (directed candidates scored), ``launches``, ``survivors``, ``bar``."""
+    if not scan_available(g):
+        raise ops._lib.EpsError("scan_topk: graph not supported by eps_filter_scan (see scan_available)")
+    k = int(k)
+    dev = g.device
+    fixw = fixed_weights(g, node_w)
+    order = column_order(g)
+    mine = order if world == 1 else order[rank::world].contiguous()
+    total_half = int(half_paths(g).sum().item())
+    launches = 0
+    if total_half <= SMALL_SET:
+        bar = None
+    else:
+        bar = estimate_bar(g, fixw, k)
+        launches += 1
+    expect = (2 * total_half if bar is None else int(2 * SAFETY * k)) // world
+    capacity = min(2 * expect + _CHUNK_SLACK, (1 << 32) - 1)
+    while True:
+        res = _launch(g, fixw, mine, float("-inf") if bar is None else bar, capacity)
+        launches += 1
+        slots, n_cand = res.counts()
+        keys, vals = res.valid(slots)
+        overflow = slots > res.capacity
+        n_surv = keys.numel()
+        if world > 1:
+            import torch.distributed as dist
+            from . import dist as epd
+            agg = torch.tensor([n_surv, int(overflow), n_cand], dtype=torch.int64, device=dev)
+            tot = sum(epd.all_gather_list(agg))
+            n_all, any_overflow, n_cand_all = int(tot[0]), int(tot[1]) > 0, int(tot[2])
+        else:
+            n_all, any_overflow, n_cand_all = n_surv, overflow, n_cand
+        if any_overflow:
+            # the bar was too low for the list.  What was kept is a subset of the survivors: its (k/2)-th best score
+            # is a lower bound of the final bar -- scan again just below it.
+            need = max(1, (k // 2) // world)
+            if vals.numel() >= need:
+                local = torch.topk(vals, need, largest=True, sorted=True).values[-1:]
+            else:
+                local = torch.full((1,), float("-inf"), device=dev)
+            if world > 1:
+                local = torch.stack(epd.all_gather_list(local)).min(0).values
+            bar = torch.nextafter(local, torch.full_like(local, float("-inf")))
+            capacity = min(4 * capacity, (1 << 32) - 1)
+            continue
+        if bar is not None and 2 * n_all < min(k, 2 * n_cand_all):
+            # fewer than k above the bar: lower it (a quarter of the sample rank each time, then no bar at all)
+            bar = None if launches > 3 else estimate_bar(g, fixw, k, safety=SAFETY * 8 ** (launches - 1))
+            launches += 1
+            if bar is None:
+                capacity = min(2 * (2 * total_half // world) + _CHUNK_SLACK, (1 << 32) - 1)
+            continue
+        break
+    if world > 1:
+        keys, vals = _gather_varlen(keys, world), _gather_varlen(vals, world)
+    mirrored = ((keys & 0xFFFFFFFF) << 32) | (keys >> 32)
+    keys, vals = select_topk(torch.cat([keys, mirrored]), torch.cat([vals, vals]), k)
+    if stats is not None:
+        stats.update(candidates=2 * n_cand_all, launches=launches, survivors=2 * n_all,
+                     bar=None if bar is None else float(bar.item()))
+    return torch.stack([keys & 0xFFFFFFFF, keys >> 32]), vals

@@ -141,6 +141,43 @@ int eps_expand_fill(const int64_t *rowptr, const int32_t *col, const float *val,
                     eps_score_cut *cut, void *workspace, int64_t workspace_bytes, void *stream);
 int64_t eps_expand_workspace_bytes(int64_t max_col_paths);
 
+/* ---- K7+K1+K8: threshold scan of the whole candidate set (filter.py:96-142 + :160-161 under --keep_top) ------------
+ * Computes the score of EVERY 2-hop non-edge of the given columns like eps_expand_fill does (same 2^-40 fixed-point
+ * sums, bit-identical float32 scores) but writes neither the candidate list nor the score array: only the candidates
+ * whose score exceeds out->threshold are reported.  Requires a SYMMETRIC adjacency with UNIT values (val == NULL;
+ * filter.py's is: rank.py:33-35 for every dataset but collab) and exploits the symmetry: column v expands only the
+ * endpoints u < v, so each unordered candidate pair {u, v} is scored once and reported once, as
+ * key = (v << 32) | u with u < v; the caller mirrors it (the scores of (u,v) and (v,u) are equal term by term).
+ *   eps_reverse_positions: revpos[e] for entry e of row v, w = col[e]: number of entries of row w below v (the position
+ *                     of v in row w).  Per-graph table, int32[nnz].
+ *   eps_fixed_weights: fixw[i] = round(node_w[i] * 2^40): the per-node weights (eps_node_weights; all ones for the
+ *                     common-neighbour count of models.py:536-542) in the accumulators' fixed point, int64[N].
+ *   eps_filter_scan : columns = int32[n_columns] column ids in hand-out order (any subset, any order: a heaviest-first
+ *                     order shortens the tail; a sample of columns estimates the bar; a rank's shard under
+ *                     torch.distributed).  out is DEVICE-resident: threshold and capacity set by the caller, count
+ *                     zeroed, key[] pre-filled with -1.  Slots are handed out in chunks, so after the launch the first
+ *                     min(count, capacity) slots hold the survivors interleaved with untouched (-1) slots;
+ *                     count > capacity means survivors were dropped.  workspace: eps_filter_scan_workspace_bytes()
+ *                     bytes of scratch (bucket records), 16-byte aligned. */
+typedef struct eps_survivors {
+    float threshold;
+    uint32_t capacity;
+    uint32_t count;
+    uint32_t reserved;
+    int64_t *key;
+    float *val;
+    unsigned long long n_candidates; /* out (zeroed by the caller): unordered candidate pairs scored by the launch */
+} eps_survivors;
+
+int64_t eps_filter_scan_max_nodes(void);
+int64_t eps_filter_scan_workspace_bytes(void);
+int eps_reverse_positions(const int64_t *rowptr, const int32_t *col, int64_t n_nodes, int32_t *revpos,
+                          void *stream);
+int eps_fixed_weights(const float *node_w, int64_t n, int64_t *fixw, void *stream);
+int eps_filter_scan(const int64_t *rowptr, const int32_t *col, const int32_t *revpos, const int64_t *fixw,
+                    int64_t n_nodes, int64_t nnz, const int32_t *columns, int64_t n_columns,
+                    eps_survivors *out, void *workspace, int64_t workspace_bytes, void *stream);
+
 /* ---- K4/K5: CSR x dense SpMM with fused epilogue -----------------------------------------
  * Replaces torch_sparse spmm_sum / spmm_mean inside GCNConv / SAGEConv (models.py:183-186,
  * :436-439) plus the bias add and the ReLU of the layer loop.

@@ -1,0 +1,176 @@
+"""GPU parity of the threshold scan (eps_filter_scan, csrc/filter_scan.hip) and of the exact top-K built on it
+(edge-proposal-sets_amd/scan.py) vs the restated filter.py:96-109 candidate set + the oracle pair scores, and vs
+the fused expansion kernel (bit-identical scores by construction)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden_pair_files, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle_candidates(oracle, A):
+    """(pairs [E,2] column-major, AA float64-accumulated truth, AA float32 oracle, CN counts) of every 2-hop non-edge."""
+    n = A.shape[0]
+    rp, col = A.indptr.astype(np.int64), A.indices.astype(np.int32)
+    pairs, _ = oracle.candidates_scipy(A)
+    w = oracle.node_weights(oracle.col_sums(rp, col, None, n), oracle.W_AA)
+    cnt, _, ws = oracle.pair_scores(rp, col, None, w, pairs[:, 0], pairs[:, 1])
+    _, truth = oracle.pair_scores_f64(rp, col, None, w.astype(np.float64), pairs[:, 0], pairs[:, 1])
+    return pairs, truth, ws, cnt
+
+
+def _scan_all(eps, g, node_w, thr=float("-inf"), columns=None):
+    """Every survivor of one launch as {(u, v): score} with u < v, plus the kernel's candidate count."""
+    from eps_amd import scan
+    fixw = scan.fixed_weights(g, node_w)
+    cols = scan.column_order(g) if columns is None else columns
+    cap = 2 * int(scan.half_paths(g).sum().item()) + 8192 * 300
+    res = eps.ops.Survivors(cap, thr, g.device)
+    eps.ops.filter_scan(g.rowptr, g.col, scan.reverse_positions(g), fixw, g.n_rows, cols, res)
+    slots, n_cand = res.counts()
+    assert slots <= res.capacity
+    keys, vals = res.valid(slots)
+    keys, vals = keys.cpu().numpy(), vals.cpu().numpy()
+    assert len(np.unique(keys)) == len(keys), "a candidate was reported twice"
+    return {(int(k & 0xFFFFFFFF), int(k >> 32)): float(s) for k, s in zip(keys, vals)}, n_cand
+
+
+def _unit_graph(d):
+    import scipy.sparse as ssp
+    n = len(d["rowptr"]) - 1
+    A = ssp.csr_matrix((np.ones_like(d["val"]), d["col"], d["rowptr"]), shape=(n, n))
+    A.sort_indices()
+    return A
+
+
+@pytest.mark.parametrize("path", golden_pair_files(), ids=lambda p: os.path.basename(p)[6:-4])
+def test_scan_without_bar_is_the_whole_candidate_set(eps, oracle, dev, path):
+    """No bar: every unordered 2-hop non-edge comes out exactly once, with the fused expansion's score."""
+    from eps_amd.heuristics import node_weight_table
+    A = _unit_graph(np.load(path))
+    g = eps.CSRGraph.from_scipy(A, device=dev)
+    wt = node_weight_table(g, eps.ops.W_AA)
+    pairs, truth, ws_o, _ = _oracle_candidates(oracle, A)
+    got, n_cand = _scan_all(eps, g, wt)
+    lower = pairs[:, 0] < pairs[:, 1]
+    want = {(int(u), int(v)): t for (u, v), t in zip(pairs[lower], truth[lower])}
+    assert n_cand == len(want) and set(got) == set(want)
+    if want:
+        ks = sorted(want)
+        a = np.array([got[k] for k in ks], np.float32)
+        assert rel_err(a, np.array([want[k] for k in ks], np.float32)) <= 1e-6
+        # bit-identical to the fused expansion's float32 scores, and symmetric
+        _, cu, cv, _, sc = eps.ops.expand_candidates(g.rowptr, g.col, None, wt, g.n_rows, 0, g.n_rows, want_cn=False)
+        ex = {(int(u), int(v)): float(s) for u, v, s in zip(cu.cpu().numpy(), cv.cpu().numpy(), sc.cpu().numpy())}
+        for (u, v), s in got.items():
+            assert ex[(u, v)] == s and ex[(v, u)] == s
+
+
+@pytest.mark.parametrize("seed,scale,ef", [(5, 12, 10), (9, 13, 6), (2, 11, 40)])
+def test_scan_bar_and_column_subsets(eps, oracle, dev, seed, scale, ef):
+    """Survivors == {candidates with score > bar} for several bars; column subsets partition the result; the common-
+    neighbour count (unit weights) is exact.  scale 11 / edge factor 40 makes multi-tile, multi-round hub columns."""
+    from eps_amd import scan, synth
+    from eps_amd.heuristics import node_weight_table
+    g = synth.rmat_graph(scale, ef, seed, "cpu")
+    A = g.to_scipy()
+    g = g.to(dev)
+    wt = node_weight_table(g, eps.ops.W_AA)
+    pairs, truth, _, cnt = _oracle_candidates(oracle, A)
+    lower = pairs[:, 0] < pairs[:, 1]
+    full, n_cand = _scan_all(eps, g, wt)
+    assert n_cand == int(lower.sum()) and len(full) == n_cand
+    sc = np.array(sorted(full.values()), np.float32)
+    for q in (0.5, 0.99, 0.9999):
+        bar = float(sc[int(q * (len(sc) - 1))])
+        got, n2 = _scan_all(eps, g, wt, thr=bar)
+        assert n2 == n_cand
+        assert got == {k: s for k, s in full.items() if s > bar}
+    order = scan.column_order(g)
+    parts = [_scan_all(eps, g, wt, columns=order[r::3].contiguous()) for r in range(3)]
+    merged = {}
+    for d, _ in parts:
+        assert not (set(d) & set(merged))
+        merged.update(d)
+    assert merged == full and sum(n for _, n in parts) == n_cand
+    ones = torch.ones(g.n_rows, dtype=torch.float32, device=dev)
+    cn_got, _ = _scan_all(eps, g, ones)
+    want_cn = {(int(u), int(v)): float(c) for (u, v), c in zip(pairs[lower], cnt[lower])}
+    assert cn_got == want_cn
+
+
+def test_scan_topk_is_exact(eps, oracle, dev, monkeypatch):
+    """scan_topk == the first K rows of the declared order over the full candidate list, on the direct path (small
+    set, no bar) and on the estimate -> scan -> verify path, incl. a bar that is too high and one that is too low."""
+    from eps_amd import scan, synth
+    from eps_amd.heuristics import node_weight_table
+    g = synth.rmat_graph(12, 12, 3, "cpu")
+    A = g.to_scipy()
+    g = g.to(dev)
+    wt = node_weight_table(g, eps.ops.W_AA)
+    _, cu, cv, _, sc = eps.ops.expand_candidates(g.rowptr, g.col, None, wt, g.n_rows, 0, g.n_rows, want_cn=False)
+    order = torch.sort(sc, descending=True, stable=True).indices           # candidate order is column-major already
+    for k in (1, 1000, 77777, int(sc.numel()) + 5):
+        kk = min(k, sc.numel())
+        want_pairs = torch.stack([cu[order[:kk]], cv[order[:kk]]]).long()
+        want_sc = sc[order[:kk]]
+        st = {}
+        pairs, scores = scan.scan_topk(g, wt, k, stats=st)
+        assert torch.equal(pairs, want_pairs) and torch.equal(scores, want_sc)
+        assert st["candidates"] == sc.numel()
+    # force the estimate path (sample -> bar -> verify) with strides that make the estimate poor in both directions
+    monkeypatch.setattr(scan, "SMALL_SET", 0)
+    for stride, safety in ((7, 3.0), (64, 3.0), (3, 0.02), (5, 500.0)):
+        monkeypatch.setattr(scan, "SAMPLE_STRIDE", stride)
+        monkeypatch.setattr(scan, "SAFETY", safety)
+        k = 20000
+        st = {}
+        pairs, scores = scan.scan_topk(g, wt, k, stats=st)
+        assert torch.equal(pairs, torch.stack([cu[order[:k]], cv[order[:k]]]).long()), (stride, safety, st)
+        assert torch.equal(scores, sc[order[:k]])
+    # the oracle's float32 scores agree within the gate on the selected rows
+    rp, col = A.indptr.astype(np.int64), A.indices.astype(np.int32)
+    w = oracle.node_weights(oracle.col_sums(rp, col, None, g.n_rows), oracle.W_AA)
+    _, _, ws = oracle.pair_scores(rp, col, None, w, pairs[0].cpu().numpy(), pairs[1].cpu().numpy())
+    assert rel_err(scores.cpu().numpy(), ws) <= 1e-5
+
+
+def test_scan_full_size_properties(eps, dev):
+    """ppa-sized graph (BASELINE configs[2]): the scan over all columns finds exactly the candidates above the bar that
+    the fused expansion scores above it on a block of columns, symmetric survivors mirror, and a re-run is
+    bit-identical (order-independent fixed-point sums)."""
+    from eps_amd import candidates, scan, synth
+    from eps_amd.heuristics import node_weight_table
+    g = synth.ppa_like(seed=3, device=dev)
+    wt = node_weight_table(g, eps.ops.W_AA)
+    st = {}
+    pairs, scores = scan.scan_topk(g, wt, 1_000_000, stats=st)
+    assert pairs.shape == (2, 1_000_000) and bool((scores[:-1] >= scores[1:]).all())
+    assert st["candidates"] > 1e9
+    bar = float(scores[-1])
+    # block check against the fused expansion: columns [lo, hi) -- every candidate above the bar must be in the top list
+    lo, hi = 1000, 1400
+    blk = candidates.expand_block_lazy(g, lo, hi, wt, want_score=True)
+    idx = torch.nonzero(blk.score > bar).squeeze(1)
+    want = blk.select(idx)                                                     # (u; v), column-major
+    in_blk = (pairs[1] >= lo) & (pairs[1] < hi)
+    got = pairs[:, in_blk]
+    gk = torch.sort(got[1] * g.n_rows + got[0]).values
+    wk = torch.sort(want[1] * g.n_rows + want[0]).values
+    assert torch.equal(gk, wk)
+    # mirrored rows carry equal scores
+    key = pairs[1] * g.n_rows + pairs[0]
+    mkey = pairs[0] * g.n_rows + pairs[1]
+    pos = torch.searchsorted(torch.sort(key).values, mkey)
+    skey, sidx = torch.sort(key)
+    inside = pos < key.numel()
+    hit = torch.zeros_like(inside)
+    hit[inside] = skey[pos[inside]] == mkey[inside]
+    assert bool((scores[hit] == scores[sidx[pos[hit]]]).all())
+    assert int(hit.sum()) >= pairs.shape[1] - 2                                 # at most the K-th tie loses its mirror
+    p2, s2 = scan.scan_topk(g, wt, 1_000_000)
+    assert torch.equal(p2, pairs) and torch.equal(s2, scores)
