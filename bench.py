@@ -1,24 +1,29 @@
 #!/usr/bin/env python3
-"""Headline benchmark: candidate edges scored per second on a ppa-like graph (BASELINE.json
-configs[2]: "ogbl-ppa Adamic-Adar scoring of full non-edge candidate set, 1xMI355X").
+"""Headline benchmark: candidate edges scored per second on a ppa-like graph (BASELINE.json configs[2]:
+"ogbl-ppa Adamic-Adar scoring of full non-edge candidate set, 1xMI355X").
 
     python bench.py --gpus N --steps K --warmup W
     (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
 Workload (synthetic, seeded; no dataset / network exists on either box)
-  graph : S3 "ppa-like" -- N = 576,289 nodes, ~21.2 M undirected edges (nnz ~42.5 M, avg degree
-          ~74), R-MAT skew, unit weights; replicated on every GPU (0.35 GB).
-  pairs : the reference's own candidate set for this graph -- 2-hop non-edges in column-major
-          order (filter.py:96-109) -- for a contiguous block of columns, truncated to exactly
-          2**25 = 33,554,432 pairs per GPU.  Rank r takes its own block of columns (weak scaling:
-          per-GPU work fixed; candidate pairs are independent, no data-path collective).
-  step  : one pass of the hot path over that batch: eps_pair_scores -> common-neighbour count +
-          Adamic-Adar score for every pair (adamic_utils.py:13-25 / models.py:536-542), inputs and
-          outputs resident in HBM.
-Reported: whole-job pairs/s (max-over-ranks time), the intersection kernel's achieved
-algorithmic HBM GB/s (HIP events on the launch stream) against the 8 TB/s peak, and the
-reference's CPU path (SciPy mirror of adamic_utils.AA, 1 thread) timed on a bounded sample of
-the same pairs.
+  graph : S3 "ppa-like" -- N = 576,289 nodes, ~21.2 M undirected edges (nnz ~42.5 M, avg degree ~74), R-MAT skew,
+          unit weights; replicated on every GPU (0.35 GB + 0.7 GB of per-graph tables).
+  step  : the PRODUCTION filter pass over the FULL candidate set of that graph -- what
+          `filter.py --dataset ppa --model adamic_ogb --keep_top 4000000` runs between loading the graph and writing
+          the proposal file: every 2-hop non-edge (filter.py:96-109; 12.7 G directed candidates) gets its
+          Adamic-Adar score (adamic_utils.py:13-25) and the 4,000,000 best rows under the declared order
+          (filter.py:160-161) come out, on the device.  One step = scan.scan_topk: bar estimate from a column sample,
+          ONE eps_filter_scan launch over all columns, verification, selection.
+  value : directed candidates scored per second, whole job (the kernel's own candidate count, both orientations of
+          each pair; each unordered pair is computed once -- the score is symmetric).
+  N > 1 : "weak" (default): every rank runs the full single-GPU workload on its own replica (per-GPU work fixed);
+          "strong" (--scaling strong): the columns of ONE graph are dealt round-robin over the ranks in heaviest-first
+          order, survivors are all-gathered and every rank selects the same top-K -- the north-star target
+          ("sharded candidate set").
+Reported next to it: the roofline of the dominant kernel (filter_scan_kernel; HIP events on its stream), secondary
+legs for the other hot-path kernels (pair intersection, SpMM, GEMM, decode) with their SURVEY 8(d) rooflines, and the
+reference's CPU path (SciPy mirror of adamic_utils.AA) timed on a bounded sample of the same candidates -- one
+thread like the reference, and split over all host cores.
 """
 import argparse
 import json
@@ -30,47 +35,142 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-PAIRS_PER_GPU = 1 << 25
-HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable by a float4 copy)
-CPU_SAMPLE = 6_000_000   # pairs timed through the SciPy mirror (~10-30 s on one core)
+KEEP_TOP = 4_000_000       # README.md:11-17 / submit_job.py:207-213: the published ppa recipe keeps 4 M proposals
+HBM_PEAK_GBPS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable by a float4 copy)
+MFMA_F32_PEAK_TF = 157.3   # fp32-input MFMA, dense
+CPU_SAMPLE = 4_000_000     # candidate pairs timed through the single-thread SciPy mirror (~10-20 s)
+PAIR_LEG = 1 << 25
 
 
-def build_pairs(g, rank, target, candidates, torch):
-    """2-hop non-edge candidates, column-major, from rank-specific column blocks, exactly `target` pairs."""
+def _events(torch, n):
+    return [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+
+
+def _timed_loop(torch, fn, reps, warmup=2):
+    """Mean HIP-event milliseconds of ``fn`` on the current stream."""
+    for _ in range(warmup):
+        fn()
+    evs = _events(torch, reps)
+    s = torch.cuda.current_stream()
+    for a, b in evs:
+        a.record(s)
+        fn()
+        b.record(s)
+    torch.cuda.synchronize()
+    return sum(a.elapsed_time(b) for a, b in evs) / reps
+
+
+# ------------------------------------------------------------------------------------------------ secondary legs
+def leg_pair_kernel(torch, g, w, ops, candidates):
+    """Column-run intersection kernel (eval-style explicit pair lists in candidate order): 2^25 candidate pairs."""
     n = g.n_rows
-    cols_per_rank = n // 64  # room for up to 64 disjoint rank blocks
-    v = rank * cols_per_rank
-    v_end = (rank + 1) * cols_per_rank
-    out, have = [], 0
-    while have < target and v < v_end:
-        blk = candidates.two_hop_block(g, v, min(v + 128, v_end))
+    out, have, v = [], 0, 0
+    while have < PAIR_LEG and v < n:
+        blk = candidates.expand_block(g, v, min(v + 256, n), long_pairs=False)[0]
         out.append(blk)
         have += blk.shape[1]
-        v += 128
-    pairs = torch.cat(out, 1)[:, :target]
-    if pairs.shape[1] < target:
-        raise RuntimeError(f"only {pairs.shape[1]} candidates in the rank's column block")
-    return pairs[0].to(torch.int32).contiguous(), pairs[1].to(torch.int32).contiguous(), (rank * cols_per_rank, v)
+        v += 256
+    pairs = torch.cat(out, 1)[:, :PAIR_LEG]
+    u, vv = pairs[0].contiguous(), pairs[1].contiguous()
+    res = {}
 
-
-def algorithmic_bytes(g, u, v, count, torch):
-    """bytes(u,v) = 4*(d_u+d_v) + 4*CN_uv + 32 (rowptr) + 8 (u,v) + 8 (int32 CN + f32 score)."""
+    def step():
+        res["r"] = ops.pair_scores(g.rowptr, g.col, g.val, w, n, u, vv, want_count=True, want_cn=False, grouped=True)
+    ms = _timed_loop(torch, step, 10)
+    count = res["r"][0]
     deg = g.degree()
-    du = deg[u.long()].sum().item()
-    dv = deg[v.long()].sum().item()
-    return 4 * (du + dv) + 4 * int(count.sum().item()) + 48 * u.numel(), (du + dv) / u.numel()
+    du, dv = int(deg[u.long()].sum()), int(deg[vv.long()].sum())
+    cn = int(count.sum())
+    e = u.numel()
+    runs = int((vv[1:] != vv[:-1]).sum()) + 1
+    dv_runs = int(deg[torch.unique_consecutive(vv).long()].sum())
+    alg8d = 4 * (du + dv) + 4 * cn + 48 * e                     # SURVEY 8(d): both rows charged to every pair
+    comp = 4 * du + 4 * dv_runs + 4 * cn + 16 * e + 32 * runs   # row u per pair, row v once per run, pair ids + outputs
+    return {"kernel": "pair_scores_grouped_kernel<false,true,float,true>", "pairs": e, "kernel_ms": ms,
+            "pairs_per_s": e / ms * 1e3, "bound": "hbm",
+            "compulsory": {"bytes": comp, "GBps": comp / ms / 1e6, "frac": comp / ms / 1e6 / HBM_PEAK_GBPS,
+                           "unit": "row u per pair (4 d_u) + row v once per run of equal v + 4 CN + ids/outputs"},
+            "algorithmic_8d": {"bytes": alg8d, "GBps": alg8d / ms / 1e6,
+                               "note": "SURVEY 8(d) unit 4(d_u+d_v)+4CN+48 charges row v to every pair; the kernel reads "
+                                       "it once per run, so this figure may exceed the HBM peak and is NOT a roofline fraction"},
+            "mean_du": du / e, "mean_dv": dv / e, "mean_cn": cn / e}
 
 
-def cpu_baseline(g, u, v, ws_gpu, torch):
-    """Reference CPU path on the host cores: SciPy mirror of adamic_utils.AA (bit-exact to the imported
-    reference, tests/test_oracle_golden.py), single thread like the reference (SciPy sparse ops + a
-    0-worker DataLoader), on a strided sample of this step's pairs; the GPU scores are checked on it."""
+def leg_gnn(torch, g, ops):
+    """configs[3] kernels on the ppa-like graph: GCN-normalised SpMM (F=256), the layer GEMM, the fused decode."""
+    dev = g.device
+    n, f = g.n_rows, 256
+    gen = torch.Generator(device=dev).manual_seed(11)
+    gn = g.gcn_normalized()
+    x = torch.randn(n, f, generator=gen, device=dev)
+    bias = torch.randn(f, generator=gen, device=dev)
+    y = torch.empty_like(x)
+    ms = _timed_loop(torch, lambda: ops.spmm_csr(gn.rowptr, gn.col, gn.val, x, bias=bias, relu=True, out=y), 10)
+    nnz = gn.nnz()
+    comp = nnz * 8 + (n + 1) * 8 + 2 * n * f * 4
+    gather = nnz * f * 4 + nnz * 8 + n * f * 4
+    spmm = {"kernel": "spmm_csr_kernel", "nnz": nnz, "F": f, "kernel_ms": ms, "bound": "hbm",
+            "compulsory": {"bytes": comp, "GBps": comp / ms / 1e6, "frac": comp / ms / 1e6 / HBM_PEAK_GBPS},
+            "gather_model": {"bytes": gather, "GBps": gather / ms / 1e6, "frac": gather / ms / 1e6 / HBM_PEAK_GBPS,
+                             "note": "one 1-KiB row of X per stored entry: what a permuted graph costs without reuse"}}
+    k = 316                                                               # 58 features + 256-d embedding, padded to x4
+    a = torch.randn(n, k, generator=gen, device=dev)
+    wt = torch.randn(f, k, generator=gen, device=dev)
+    ms = _timed_loop(torch, lambda: ops.gemm(a, wt, bias=bias, relu=True, out=y), 10)
+    fl = 2.0 * n * f * k
+    gemm = {"kernel": "gemm_f32_kernel", "shape": [n, f, k], "kernel_ms": ms, "bound": "mfma", "TFLOPs": fl / ms / 1e9,
+            "frac": fl / ms / 1e9 / MFMA_F32_PEAK_TF}
+    ne = 1 << 22
+    u = torch.randint(0, n, (ne,), generator=gen, device=dev, dtype=torch.int32)
+    v = torch.randint(0, n, (ne,), generator=gen, device=dev, dtype=torch.int32)
+    ws = [torch.randn(f, f, generator=gen, device=dev) * 0.06, torch.randn(f, f, generator=gen, device=dev) * 0.06,
+          torch.randn(1, f, generator=gen, device=dev) * 0.06]
+    bs = [torch.randn(f, generator=gen, device=dev) * 0.1, torch.randn(f, generator=gen, device=dev) * 0.1,
+          torch.randn(1, generator=gen, device=dev)]
+    ms = _timed_loop(torch, lambda: ops.mlp_decode(x, u, v, ws, bs), 10)
+    fl = float(ne) * (f + 2 * f * f * 2 + 2 * f)
+    dec = {"kernel": "mlp_decode_kernel", "edges": ne, "H": f, "L": 3, "kernel_ms": ms, "bound": "mfma",
+           "edges_per_s": ne / ms * 1e3, "TFLOPs": fl / ms / 1e9, "frac": fl / ms / 1e9 / MFMA_F32_PEAK_TF}
+    return {"spmm": spmm, "gemm": gemm, "decode": dec}
+
+
+# ------------------------------------------------------------------------------------------------ CPU baseline
+def _cpu_worker(args):
+    """One process of the all-cores leg: its slice of the sample through the SciPy mirror of adamic_utils.AA."""
+    path, lo, hi = args
+    import numpy as np
+    import scipy.sparse as ssp
+    d = np.load(path)
+    n = len(d["rowptr"]) - 1
+    A = ssp.csr_matrix((np.ones(len(d["col"]), np.float32), d["col"], d["rowptr"]), shape=(n, n))
+    pu, pv = d["pu"][lo:hi], d["pv"][lo:hi]
+    with np.errstate(divide="ignore"):
+        mult = 1 / np.log(A.sum(0))
+        mult[np.isinf(mult)] = 0
+        A_ = A.multiply(mult).tocsr()
+    t0 = time.perf_counter()
+    for s in range(0, len(pu), 2000):
+        np.array(np.sum(A[pu[s:s + 2000]].multiply(A_[pv[s:s + 2000]]), 1)).flatten()
+    return time.perf_counter() - t0, hi - lo
+
+
+def cpu_baseline(torch, g, w, ops, candidates, keep_pairs, keep_scores):
+    """Reference CPU path on the host cores: the SciPy mirror of adamic_utils.AA (bit-exact to the imported reference,
+    tests/test_oracle_golden.py) on a bounded sample of the step's candidate set -- the candidates of every 512-th
+    column, thinned to CPU_SAMPLE pairs -- single thread like the reference (SciPy sparse ops + a 0-worker DataLoader),
+    then the same mirror split over all host cores (one process each).  The GPU scores of the sample are checked
+    against it, and so are the scores of a slice of the step's own output rows."""
     import numpy as np
     from oracle import eps_oracle as orc
     A = g.to_scipy()
-    n = u.numel()
-    idx = torch.arange(0, n, max(1, n // CPU_SAMPLE), device=u.device)[:CPU_SAMPLE]
-    pu, pv = u[idx].cpu().numpy().astype(np.int64), v[idx].cpu().numpy().astype(np.int64)
+    n = g.n_rows
+    cols = list(range(137, n, 512))
+    blocks = [candidates.expand_block(g, c, c + 1, w, want_score=True, long_pairs=False) for c in cols]
+    pairs = torch.cat([b[0] for b in blocks], 1)
+    gpu_sc = torch.cat([b[2] for b in blocks])
+    stride = max(1, pairs.shape[1] // CPU_SAMPLE)
+    pairs, gpu_sc = pairs[:, ::stride][:, :CPU_SAMPLE], gpu_sc[::stride][:CPU_SAMPLE]
+    pu, pv = pairs[0].cpu().numpy().astype(np.int64), pairs[1].cpu().numpy().astype(np.int64)
     with np.errstate(divide="ignore"):
         mult = 1 / np.log(A.sum(0))
         mult[np.isinf(mult)] = 0
@@ -80,69 +180,99 @@ def cpu_baseline(g, u, v, ws_gpu, torch):
         for s in range(0, len(pu), 2000):  # adamic_utils.py:18-24, batch_size 2000
             scores.append(np.array(np.sum(A[pu[s:s + 2000]].multiply(A_[pv[s:s + 2000]]), 1)).flatten())
         dt = time.perf_counter() - t0
-    ref = np.concatenate(scores).astype(np.float32)
-    got = ws_gpu[idx].cpu().numpy()
-    den = np.maximum(np.abs(ref), np.abs(got))
-    den[den == 0] = 1
-    rel = float((np.abs(ref - got) / den).max())
-    # the scalar C port too, for a second CPU data point
+        ref = np.concatenate(scores).astype(np.float32)
+        # the step's own output: the first and last 20,000 of the K rows it selected
+        sel = torch.cat([torch.arange(0, 20000), torch.arange(keep_scores.numel() - 20000, keep_scores.numel())])
+        ku, kv = keep_pairs[0][sel].cpu().numpy(), keep_pairs[1][sel].cpu().numpy()
+        kref = np.array(np.sum(A[ku].multiply(A_[kv]), 1)).flatten().astype(np.float32)
+
+    def rel(a, b):
+        den = np.maximum(np.abs(a), np.abs(b))
+        den[den == 0] = 1
+        return float((np.abs(a - b) / den).max())
+    rel_sample = rel(ref, gpu_sc.cpu().numpy())
+    rel_topk = rel(kref, keep_scores[sel].cpu().numpy())
+    # the scalar C port on one core, a second CPU data point
     rp, col = g.rowptr.cpu().numpy(), g.col.cpu().numpy()
-    w = orc.node_weights(orc.col_sums(rp, col, None, g.n_rows), orc.W_AA)
+    wo = orc.node_weights(orc.col_sums(rp, col, None, n), orc.W_AA)
     t1 = time.perf_counter()
-    orc.pair_scores(rp, col, None, w, pu, pv)
+    orc.pair_scores(rp, col, None, wo, pu, pv)
     dt_c = time.perf_counter() - t1
-    # ... and the same C loop over ALL host cores (pairs split over threads; the foreign call releases the GIL), so
-    # the GPU/CPU ratio is not flattered by the reference being single-threaded
-    from concurrent.futures import ThreadPoolExecutor
-    n_thr = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    au, av = u.cpu().numpy().astype(np.int64), v.cpu().numpy().astype(np.int64)   # the whole step: enough work per thread
-    cuts = np.linspace(0, len(au), n_thr + 1).astype(np.int64)
-    with ThreadPoolExecutor(n_thr) as pool:
-        list(pool.map(lambda i: orc.pair_scores(rp, col, None, w, au[cuts[i]:cuts[i] + 64], av[cuts[i]:cuts[i] + 64]),
-                      range(n_thr)))                                               # start the threads outside the clock
-        t2 = time.perf_counter()
-        list(pool.map(lambda i: orc.pair_scores(rp, col, None, w, au[cuts[i]:cuts[i + 1]], av[cuts[i]:cuts[i + 1]]),
-                      range(n_thr)))
-        dt_all = time.perf_counter() - t2
-    n_all = len(au)
-    # Hits@100 parity (the second half of BASELINE's metric): positive-like pairs (stored edges) against uniform random
-    # negatives, scored by the GPU engine and by the reference's CPU expression; Hits@K per ogb's rule (strict >).
-    gen = torch.Generator(device=u.device).manual_seed(7)
-    row, colx, _ = g.coo()
-    sel = torch.randint(0, row.numel(), (50_000,), generator=gen, device=u.device)
-    pe = torch.stack([row[sel], colx[sel]])
-    ne = torch.randint(0, g.n_rows, (2, 50_000), generator=gen, device=u.device)
+    # all host cores: the SciPy mirror itself, the sample split over one process per core
+    import multiprocessing as mp
+    import tempfile
+    n_proc = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    n_proc = max(1, min(n_proc, 64))
+    tmp = os.path.join(tempfile.gettempdir(), f"eps_bench_cpu_{os.getpid()}.npz")
+    np.savez(tmp, rowptr=rp, col=col, pu=pu, pv=pv)
+    cuts = np.linspace(0, len(pu), n_proc + 1).astype(np.int64)
+    try:
+        with mp.get_context("spawn").Pool(n_proc) as pool:       # spawn: never fork a process that holds a HIP context
+            res = pool.map(_cpu_worker, [(tmp, int(cuts[i]), int(cuts[i + 1])) for i in range(n_proc)])
+    finally:
+        os.remove(tmp)
+    slowest = max(r[0] for r in res)
+    hits = hits_at_100_parity(torch, g, orc)
+    return {"value": len(pu) / dt, "unit": "edges/s", "cores": 1, "kind": "port",
+            "sample": f"{len(pu)} candidate pairs (the 2-hop non-edges of every 512-th column, every {stride}-th of them), "
+                      f"SciPy mirror of adamic_utils.AA batch 2000, per-batch loop only (weight prologue excluded); host has "
+                      f"{os.cpu_count()} cores, 1 used",
+            "c_port_value": len(pu) / dt_c,
+            "all_cores": {"value": len(pu) / slowest, "unit": "edges/s", "cores": n_proc,
+                          "what": "the same SciPy mirror, the sample split over one process per host core; rate = pairs / "
+                                  "slowest worker's loop time"},
+            "gpu_vs_sample_max_rel_err": rel_sample, "gpu_topk_rows_vs_mirror_max_rel_err": rel_topk,
+            "hits_at_100": hits}
+
+
+def hits_at_100_parity(torch, g, orc):
+    """Hits@100 (the second half of BASELINE's metric) on a held-out split: 2 % of the undirected edges are removed from
+    the graph (the positives), negatives are uniform random non-adjacent pairs, both scored by AA on the REMAINING
+    graph -- by the engine and by the reference's CPU expression; Hits@K per ogb's rule (strict >)."""
+    import numpy as np
     import eps_amd
     from eps_amd.evaluate import Evaluator
+    from eps_amd.graph import CSRGraph
+    dev = g.device
+    gen = torch.Generator(device=dev).manual_seed(7)
+    row, col, _ = g.coo()
+    up = row < col
+    er, ec = row[up], col[up]
+    held = torch.rand(er.numel(), generator=gen, device=dev) < 0.02
+    pos = torch.stack([er[held], ec[held]])[:, :200_000]
+    keep = torch.stack([er[~held], ec[~held]])
+    gt = CSRGraph.from_edge_index(keep, None, sparse_sizes=(g.n_rows, g.n_rows)).to_symmetric()
+    neg = torch.randint(0, g.n_rows, (2, 200_000), generator=gen, device=dev)
+    gp, _ = eps_amd.AA(gt, pos)
+    gn, _ = eps_amd.AA(gt, neg)
+    A = gt.to_scipy()
+    with np.errstate(divide="ignore"):
+        mult = 1 / np.log(A.sum(0))
+        mult[np.isinf(mult)] = 0
+        A_ = A.multiply(mult).tocsr()
+        cp = np.array(np.sum(A[pos[0].cpu().numpy()].multiply(A_[pos[1].cpu().numpy()]), 1)).flatten().astype(np.float32)
+        cn = np.array(np.sum(A[neg[0].cpu().numpy()].multiply(A_[neg[1].cpu().numpy()]), 1)).flatten().astype(np.float32)
     ev = Evaluator("ogbl-ppa")
     ev.K = 100
-    gp, _ = eps_amd.AA(g, pe)
-    gn, _ = eps_amd.AA(g, ne)
-    with np.errstate(divide="ignore"):
-        cp = np.array(np.sum(A[pe[0].cpu().numpy()].multiply(A_[pe[1].cpu().numpy()]), 1)).flatten().astype(np.float32)
-        cneg = np.array(np.sum(A[ne[0].cpu().numpy()].multiply(A_[ne[1].cpu().numpy()]), 1)).flatten().astype(np.float32)
     h_gpu = ev.eval({"y_pred_pos": gp, "y_pred_neg": gn})["hits@100"]
-    h_cpu = orc.hits_at_k(cp, cneg, 100)
-    hits = {"K": 100, "gpu": h_gpu, "cpu_reference_mirror": h_cpu, "identical": bool(h_gpu == h_cpu),
-            "pairs": "50,000 stored edges vs 50,000 uniform random pairs (seed 7)"}
-    return {"value": len(pu) / dt, "unit": "edges/s", "cores": 1, "kind": "port", "hits_at_100": hits,
-            "sample": f"{len(pu)} of the step's {n} pairs (every {max(1, n // CPU_SAMPLE)}-th), SciPy mirror of "
-                      f"adamic_utils.AA batch 2000, per-batch loop only (weight prologue excluded), "
-                      f"host has {os.cpu_count()} cores, 1 used",
-            "c_port_value": len(pu) / dt_c,
-            "all_cores": {"value": n_all / dt_all, "unit": "edges/s", "cores": n_thr,
-                          "what": f"scalar C port of the same per-pair loop, all {n_all} pairs of the step split over "
-                                  "all host cores (one thread each)"},
-            "gpu_vs_sample_max_rel_err": rel}
+    h_cpu = orc.hits_at_k(cp, cn, 100)
+    return {"K": 100, "gpu": h_gpu, "cpu_reference_mirror": h_cpu, "identical": bool(h_gpu == h_cpu),
+            "split": f"{pos.shape[1]} held-out edges (2 % of the graph's, removed before scoring) vs {neg.shape[1]} uniform "
+                     "random pairs, AA on the remaining graph (seed 7)"}
 
 
+# ------------------------------------------------------------------------------------------------ main
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=60)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--pairs", type=int, default=PAIRS_PER_GPU, help="pairs per GPU and step")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    ap.add_argument("--keep_top", type=int, default=KEEP_TOP)
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--no-legs", action="store_true", help="skip the secondary kernel legs")
+    ap.add_argument("--nodes", type=int, default=576_289, help="graph size (tests use a small one)")
+    ap.add_argument("--edges", type=int, default=21_231_931)
     args = ap.parse_args()
 
     import torch
@@ -153,7 +283,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
-    # smoke-test hooks for a 1-GPU box (never set by the driver): EPS_BENCH_ONE_DEVICE=1 maps every rank to cuda:0 and
+    # test hooks for a 1-GPU box (never set by the driver): EPS_BENCH_ONE_DEVICE=1 maps every rank to cuda:0 and
     # EPS_BENCH_BACKEND=gloo swaps RCCL for gloo, so the N > 1 control flow can be exercised without N GPUs
     if os.environ.get("EPS_BENCH_ONE_DEVICE") == "1":
         local_rank = 0
@@ -167,13 +297,16 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    import eps_amd
-    from eps_amd import candidates, ops, synth
+    import eps_amd  # noqa: F401
+    from eps_amd import candidates, ops, scan, synth
     from eps_amd.heuristics import node_weight_table
 
-    g = synth.ppa_like(seed=3, device=dev)
-    u, v, col_range = build_pairs(g, rank, args.pairs, candidates, torch)
+    g = synth.ppa_like(seed=3, device=dev, n_nodes=args.nodes, n_undirected=args.edges)
     w = node_weight_table(g, ops.W_AA)
+    scan.column_order(g)                           # per-graph tables (revpos, half paths, order): built once, like the graph
+    scan.fixed_weights(g, w)
+    half_paths_total = int(scan.half_paths(g).sum())
+    strong = args.scaling == "strong" and world > 1
     torch.cuda.synchronize(dev)
 
     def barrier():
@@ -181,100 +314,78 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    stats = {}
+    out = {}
+
     def step():
-        # candidates come column-major from the generator (filter.py:96-109 order): the column-run kernel applies
-        return ops.pair_scores(g.rowptr, g.col, g.val, w, g.n_rows, u, v, want_count=True, want_cn=False, grouped=True)
+        out["r"] = scan.scan_topk(g, w, args.keep_top, rank if strong else 0, world if strong else 1, stats=stats)
 
     for _ in range(args.warmup):
         step()
-    stream = torch.cuda.current_stream(dev)
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    ops.KERNEL_EVENTS = []                         # HIP events around every eps_filter_scan launch, on its stream
     barrier()
     t0 = time.perf_counter()
-    for a, b in evs:
-        a.record(stream)           # same stream the kernel is launched on (ops use torch's current stream)
-        count, _, ws = step()
-        b.record(stream)
+    for _ in range(args.steps):
+        step()
     barrier()
     dt = time.perf_counter() - t0
+    events, ops.KERNEL_EVENTS = ops.KERNEL_EVENTS, None
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
-    kern_ms = sum(a.elapsed_time(b) for a, b in evs) / args.steps
+    main_ms = [a.elapsed_time(b) for name, a, b, ncol in events if ncol > g.n_rows // (2 * (world if strong else 1))]
+    samp_ms = [a.elapsed_time(b) for name, a, b, ncol in events if ncol <= g.n_rows // (2 * (world if strong else 1))]
+    kern_ms = sum(main_ms) / max(1, len(main_ms))
+    n_cand = stats["candidates"]                   # directed candidates of the graph (kernel-counted)
+    job_cand = n_cand if strong else n_cand * world
 
-    # Second leg: the FUSED filter path (csrc/expand_score.hip) -- candidate generation + CN + AA in one expansion of
-    # the 2-hop paths (what filter.py runs for heuristic filters), on one production-sized launch: the columns from
-    # the rank's first one up to 2^29 two-hop paths, handed out heaviest first, exactly as candidates.expand_block
-    # launches them.  Timed end to end on the host clock: count kernel + cumsum + fill kernel, outputs left in HBM.
-    fused = None
-    if candidates.hip_expand_available(g):
-        c_lo = col_range[0]
-        pc = torch.cumsum(candidates.path_counts(g), 0)
-        base = int(pc[c_lo - 1].item()) if c_lo > 0 else 0
-        c_hi = int(torch.searchsorted(pc, torch.tensor(base + (1 << 29), device=dev), right=True).item())
-        c_hi = min(max(c_hi, c_lo + 1), g.n_rows)
-        order = candidates.heaviest_first(g, c_lo, c_hi)
-        mp = candidates.max_paths_of(g)
-        for _ in range(2):
-            r = ops.expand_candidates(g.rowptr, g.col, g.val, w, g.n_rows, c_lo, c_hi, col_order=order, max_paths=mp)
-        barrier()
-        t1 = time.perf_counter()
-        fsteps = max(3, args.steps // 4)
-        for _ in range(fsteps):
-            r = ops.expand_candidates(g.rowptr, g.col, g.val, w, g.n_rows, c_lo, c_hi, col_order=order, max_paths=mp)
-        barrier()
-        fdt = time.perf_counter() - t1
-        if world > 1:
-            t = torch.tensor([fdt], device=dev, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            fdt = t.item()
-        n_cand = torch.tensor([r[1].numel()], device=dev, dtype=torch.float64)
-        if world > 1:
-            dist.all_reduce(n_cand)
-        paths = int(pc[c_hi - 1].item()) - base
-        del r
-        fused = {"value": n_cand.item() * fsteps / fdt, "unit": "edges/s", "ms_per_step": fdt / fsteps * 1e3,
-                 "candidates_per_step_all_ranks": int(n_cand.item()), "steps": fsteps,
-                 "columns_rank0": [c_lo, c_hi], "two_hop_paths_rank0": paths,
-                 "what": "candidate generation (filter.py:96-109) + CN + AA for every candidate of one production-sized "
-                         "column block (2^29 two-hop paths, heaviest column first), one fused expansion; host clock "
-                         "incl. count pass, cumsum, fill pass (mark, bin, per-tile LDS sums)"}
-
+    line = None
     if rank == 0:
         n_cu, dev_name = ops.device_info()
-        abytes, mean_len = algorithmic_bytes(g, u, v, count, torch)
+        # dominant kernel: eps_filter_scan's main launch.  Algorithmic bytes per launch: every two-hop half
+        # path read once (4 B), the per-(v,w) descriptors (col 4 + revpos 4 + rowptr 8 + fixw 8), rowptr of the columns,
+        # and the survivors (12 B each); the per-rank share under strong scaling.
+        share = world if strong else 1
+        abytes = (4 * half_paths_total + 24 * g.nnz() + 16 * g.n_rows) // share + 12 * (stats["survivors"] // 2)
         achieved = abytes / (kern_ms * 1e-3) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
-            traffic = json.load(open(tpath)).get(f"pair_scores/ppa_like/{args.pairs}")
+            traffic = json.load(open(tpath)).get(f"filter_scan/ppa_like/{g.n_rows}")
         line = {
-            "metric": "candidate edges scored/sec on ogbl-ppa (ppa-like synthetic); CN + Adamic-Adar per pair",
-            "value": world * args.pairs * args.steps / dt,
+            "metric": "candidate edges scored/sec on ogbl-ppa (ppa-like synthetic): Adamic-Adar over the FULL 2-hop non-edge "
+                      "candidate set + top-4M selection",
+            "value": job_cand * args.steps / dt,
             "unit": "edges/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "configs[2] ppa-like S3: N=576289, nnz=%d, AA+CN over 2-hop non-edge candidates "
-                                   "(column-major, filter.py:96-109 order)" % g.nnz(),
-                       "pairs_per_gpu_per_step": args.pairs, "columns_rank0": list(col_range),
-                       "mean_du_plus_dv": mean_len, "mean_cn": float(count.float().mean().item()),
-                       "graph_replicated": True, "device": dev_name, "n_cu": n_cu},
+            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
+            "dtype": "int64 fixed-point (2^-40) sums of f32 terms -> f32", "data": "synthetic",
+            "config": {"workload": "configs[2] ppa-like S3, full candidate set: N=%d, nnz=%d, %d directed 2-hop non-edge "
+                                   "candidates per graph, filter.py --model adamic_ogb --keep_top %d (scan.scan_topk)"
+                                   % (g.n_rows, g.nnz(), n_cand, args.keep_top),
+                       "candidates_per_step_all_ranks": job_cand, "two_hop_half_paths": half_paths_total,
+                       "keep_top": args.keep_top, "bar": stats["bar"], "survivors": stats["survivors"],
+                       "launches_per_step": stats["launches"], "graph_replicated": True, "device": dev_name, "n_cu": n_cu},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "kernel": "pair_scores_grouped_kernel<false,true,float,true>", "kernel_ms": kern_ms,
+                         "kernel": "filter_scan_kernel", "kernel_ms": kern_ms, "launches_timed": len(main_ms),
+                         "sample_launch_ms": sum(samp_ms) / max(1, len(samp_ms)),
                          "algorithmic_bytes_per_launch": abytes,
-                         "note": "algorithmic bytes (SURVEY 8d) charge BOTH adjacency rows to every pair; the column-run "
-                                 "kernel keeps N(v) as an LDS bitmap and reads row v once per column segment, so frac can "
-                                 "exceed 1; `traffic` is the measured fabric-side bytes per launch (rocprofv3 PMC, "
-                                 "profiles/r01/pair_scores_grouped_pmc.json)"},
+                         "note": "compulsory bytes: 4 B per two-hop half path + 24 B per stored entry + survivors; the kernel "
+                                 "is bound by LDS atomics / instruction issue, not by HBM (DESIGN.md 4.1c), so the fraction "
+                                 "is small by nature; `traffic` = fabric bytes per launch from the rocprofv3 PMC passes in "
+                                 "profiles/r02"},
         }
-        if fused is not None:
-            line["fused_filter"] = fused
-        if world == 1 and not args.no_cpu:
-            line["cpu_baseline"] = cpu_baseline(g, u, v, ws, torch)
+    if rank == 0 and not args.no_legs:
+        line["legs"] = {"pair_intersection": leg_pair_kernel(torch, g, w, ops, candidates)}
+        line["legs"].update(leg_gnn(torch, g, ops))
+    if rank == 0 and world == 1 and not args.no_cpu:
+        line["cpu_baseline"] = cpu_baseline(torch, g, w, ops, candidates, out["r"][0], out["r"][1])
+        line["cpu_baseline"]["gpu_over_cpu_1core"] = line["value"] / line["cpu_baseline"]["value"]
+        line["cpu_baseline"]["gpu_over_cpu_all_cores"] = line["value"] / line["cpu_baseline"]["all_cores"]["value"]
+    if rank == 0:
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

@@ -29,7 +29,9 @@
 #define FS_FIXED_SHIFT 40
 #define FS_RC 512            // rows (neighbours w of v) described per round
 #define FS_UR 2048           // 64-entry units per round (two list entries per thread)
+#define FS_UPAD 384          // list entries past the last unit a prefetching wave may touch: they name the empty row
 #define FS_RANGES 512        // id ranges per column: path histogram and tile plan
+#define FS_AHEAD 4           // bucket records per thread requested one tile ahead (8 measured 6 % slower)
 #define FS_CHUNK 8192        // survivor slots reserved per global atomic
 #define FS_MAX_TILE_BITS 12  // candidate ranks per tile <= 4096 (8-byte accumulators in LDS)
 
@@ -56,11 +58,11 @@ __host__ __device__ static inline fs_layout fs_make_layout(int words, int tile_b
     L.o_rinfo = o;   o += FS_RANGES;
     L.o_tile_r0 = o; o += FS_RANGES + 2;
     L.o_tile_base = o; o += FS_RANGES + 2;
-    L.o_tile_cur = o;  o += FS_RANGES;
+    L.o_tile_cur = o;  o += FS_RANGES + 64;       // + one trash cursor per lane
     L.o_ustart = o;  o += FS_RC + 2;
     L.o_rbase = o;   o += FS_RC + 2;
     L.o_rlen = o;    o += FS_RC + 2;
-    L.o_ulist = o;   o += FS_UR / 2;
+    L.o_ulist = o;   o += (FS_UR + FS_UPAD) / 2;
     L.o_vwfix = o;   o += 2 * FS_RC;
     L.total_words = o;
     return L;
@@ -84,25 +86,36 @@ struct fs_params {
     uint32_t *scratch;        // cap_records words per workgroup
 };
 
-__device__ __forceinline__ int fs_wave_incl_scan(int x, int lane)
+// Wave-wide inclusive scans on the DPP path (row shifts inside the 16-lane rows, then the two row broadcasts): six
+// VALU instructions, no LDS traffic.  Lanes a shift does not reach add 0 (values are non-negative for the max form).
+__device__ __forceinline__ int fs_wave_incl_scan(int x, int)
 {
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const int y = __shfl_up(x, o);
-        if (lane >= o) x += y;
-    }
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, false);   // row_shr:1
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, false);   // row_shr:2
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, false);   // row_shr:4
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, false);   // row_shr:8
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xA, 0xF, false);   // row_bcast:15 -> rows 1, 3
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xC, 0xF, false);   // row_bcast:31 -> rows 2, 3
     return x;
 }
 
-__device__ __forceinline__ int fs_wave_incl_max(int x, int lane)
+__device__ __forceinline__ int fs_max(int a, int b) { return a > b ? a : b; }
+
+__device__ __forceinline__ int fs_wave_incl_max(int x, int)
 {
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const int y = __shfl_up(x, o);
-        if (lane >= o) x = x > y ? x : y;
-    }
+    x = fs_max(x, __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, false));
+    x = fs_max(x, __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, false));
+    x = fs_max(x, __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, false));
+    x = fs_max(x, __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, false));
+    x = fs_max(x, __builtin_amdgcn_update_dpp(0, x, 0x142, 0xA, 0xF, false));
+    x = fs_max(x, __builtin_amdgcn_update_dpp(0, x, 0x143, 0xC, 0xF, false));
     return x;
 }
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the vector-memory counter, which would
+// end every global load a wave keeps in flight across the barrier (record and row prefetches); all hand-offs between the
+// waves of this kernel go through LDS except one (bucket records: D1 -> D2), which keeps __syncthreads().
+__device__ __forceinline__ void fs_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // one quad of units in flight: the 16 bytes a lane loaded plus where they came from
 struct fs_unit {
@@ -116,11 +129,11 @@ __global__ __launch_bounds__(FS_THREADS) void filter_scan_kernel(fs_params p)
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const fs_layout L = fs_make_layout(p.words, p.tile_bits);
     uint32_t *bm = lds;                                   // bit u: u (< v) is a two-hop endpoint of the column
-    uint32_t *base32 = lds + L.o_base32;                  // rank of the first bit of every 8-word group
+    uint32_t *base32 = lds + L.o_base32;                  // rank of the first bit of every 8-word group; after the plan: ginfo
     uint8_t *pre8 = (uint8_t *)(lds + L.o_pre8);          // rank of a word's first bit within its group
     unsigned long long *acc = (unsigned long long *)(lds + L.o_acc);   // fixed-point sums of one tile; zero between uses
     uint32_t *hist = lds + L.o_hist;                      // paths per id range (pass A); zero between columns
-    uint32_t *rinfo = lds + L.o_rinfo;                    // (tile of the range << 20) | first rank of that tile
+    uint32_t *rinfo = lds + L.o_rinfo;                    // tile of the id range
     uint32_t *tile_r0 = lds + L.o_tile_r0;                // first candidate rank of a tile; [n_tiles] = column total
     uint32_t *tile_base = lds + L.o_tile_base;            // paths of the column before the tile; [n_tiles] = all
     uint32_t *tile_cur = lds + L.o_tile_cur;              // next free record of the tile's bucket (window-relative)
@@ -129,7 +142,7 @@ __global__ __launch_bounds__(FS_THREADS) void filter_scan_kernel(fs_params p)
     uint32_t *rlen = lds + L.o_rlen;                      // entries of the row below v
     uint16_t *ulist = (uint16_t *)(lds + L.o_ulist);      // unit -> row of the round, + 1
     long long *vwfix = (long long *)(lds + L.o_vwfix);    // fixed-point weight of (v, row)
-    __shared__ int s_wtot[FS_WAVES];
+    __shared__ int s_wtot[4 * FS_WAVES];
     __shared__ unsigned int s_ticket;
     __shared__ int s_done, s_next_c, s_ntiles, s_thi;
     __shared__ unsigned int s_out_cur, s_out_end;
@@ -140,10 +153,26 @@ __global__ __launch_bounds__(FS_THREADS) void filter_scan_kernel(fs_params p)
     const int words = p.words, TILE = L.tile, tile_half = TILE >> 1, range_shift = p.range_shift;
     const uint32_t tile_mask = (uint32_t)TILE - 1u;
     const float thr = p.out->threshold;
+    // the bar in the accumulators' domain: the smallest sum whose float32 score exceeds thr (the conversion is monotone),
+    // so the per-candidate test is one 64-bit compare and only survivors are converted
+    long long thr_fix;
+    {
+        auto above = [&](long long a) { return (float)((double)a * (1.0 / (double)(1ll << FS_FIXED_SHIFT))) > thr; };
+        if (!above(0x7fffffffffffffffll)) {
+            thr_fix = 0x7fffffffffffffffll;               // +inf / NaN bar: nothing passes (sums never reach 2^63 - 1)
+        } else {
+            unsigned long long lo = 0ull, hi = 0xffffffffffffffffull;    // biased by 2^63: order-preserving
+            while (lo < hi) {
+                const unsigned long long mid = lo + ((hi - lo) >> 1);
+                if (above((long long)(mid ^ 0x8000000000000000ull))) hi = mid; else lo = mid + 1;
+            }
+            thr_fix = (long long)(lo ^ 0x8000000000000000ull);
+        }
+    }
     const uint32_t out_cap = p.out->capacity;
     int64_t *__restrict__ out_key = p.out->key;
     float *__restrict__ out_val = p.out->val;
-    uint32_t *__restrict__ my_scratch = p.scratch + (size_t)blockIdx.x * p.cap_records;
+    uint32_t *__restrict__ my_scratch = p.scratch + (size_t)blockIdx.x * ((size_t)p.cap_records + 64);   // + a trash line
     const __amdgpu_buffer_rsrc_t col_rs = __builtin_amdgcn_make_buffer_rsrc((void *)p.col, 0, p.col_bytes, 0x00020000);
 
     for (int i = tid; i < words; i += FS_THREADS) bm[i] = 0u;
@@ -153,14 +182,14 @@ __global__ __launch_bounds__(FS_THREADS) void filter_scan_kernel(fs_params p)
         s_out_cur = 0u;
         s_out_end = 0u;
         ustart[FS_RC] = 0;       // the dummy row: units past the end of a round read nothing
-        rbase[FS_RC] = 0u;
+        rbase[FS_RC] = p.col_bytes >> 2;      // past the end of col[]: the buffer load returns zeros, no traffic
         rlen[FS_RC] = 0u;
     }
 
     for (;;) {
-        __syncthreads();
+        fs_barrier();
         if (tid == 0) s_ticket = atomicAdd(p.next_col, 1u);
-        __syncthreads();
+        fs_barrier();
         if (s_ticket >= (unsigned int)p.n_columns) break;
         const int32_t v = p.columns[s_ticket];
         const int64_t vb = p.rowptr[v];
@@ -187,12 +216,13 @@ __global__ __launch_bounds__(FS_THREADS) void filter_scan_kernel(fs_params p)
             }
             int incl = fs_wave_incl_scan(nun, lane);
             if (lane == 63) s_wtot[wib] = incl;
-            if (tid < FS_UR / 2) ((uint32_t *)ulist)[tid] = 0u;
+            ((uint32_t *)ulist)[tid] = 0u;
+            if (tid < FS_UPAD / 2) ((uint32_t *)ulist)[FS_UR / 2 + tid] = (uint32_t)(FS_RC + 1) * 0x10001u;
             if (tid == 0) {
                 s_done = 0;
                 s_next_c = 0;
             }
-            __syncthreads();
+            fs_barrier();
             int woff = 0, total = 0;
 #pragma unroll
             for (int i = 0; i < FS_RC / 64; ++i) {
@@ -213,7 +243,7 @@ __global__ __launch_bounds__(FS_THREADS) void filter_scan_kernel(fs_params p)
             const unsigned long long dm = __ballot(row_ok && incl <= FS_UR);
             if (lane == 0 && dm) atomicAdd(&s_done, __popcll(dm));
             if (row_ok && incl > FS_UR && excl <= FS_UR) s_next_c = (FS_UR - excl) + (tid == 0 ? c0 : 0);
-            __syncthreads();
+            fs_barrier();
             // unit -> row: the last row that starts at or before the unit (block-wide inclusive max-scan, 2 units per thread)
             {
                 const uint32_t pr = ((uint32_t *)ulist)[tid];
@@ -223,7 +253,7 @@ __global__ __launch_bounds__(FS_THREADS) void filter_scan_kernel(fs_params p)
                 if (lane == 63) s_wtot[wib] = inc;
                 int prev = __shfl_up(inc, 1);
                 if (lane == 0) prev = 0;
-                __syncthreads();
+                fs_barrier();
                 int carry = 0;
 #pragma unroll
                 for (int i = 0; i < FS_WAVES; ++i) {
@@ -233,32 +263,45 @@ __global__ __launch_bounds__(FS_THREADS) void filter_scan_kernel(fs_params p)
                 prev = prev > carry ? prev : carry;
                 a = a > prev ? a : prev;
                 b = b > a ? b : a;
+                const int n_units = total < FS_UR ? total : FS_UR;
+                if (2 * tid >= n_units) a = FS_RC + 1;            // past the round's last unit: the empty row
+                if (2 * tid + 1 >= n_units) b = FS_RC + 1;
                 ((uint32_t *)ulist)[tid] = (uint32_t)a | ((uint32_t)b << 16);
             }
-            __syncthreads();
+            fs_barrier();
             return total < FS_UR ? total : FS_UR;
         };
 
         // ---- walk the units of a round: four units per wave instruction, quads dealt round-robin over the waves ---------
-        auto fetch = [&](int q, int n_units) -> fs_unit {
+        auto fetch = [&](int q) -> fs_unit {
             fs_unit f;
-            const int s = q * 4 + grp;
-            f.row = s < n_units ? (int)ulist[s] - 1 : FS_RC;
+            const int s = q * 4 + grp;                 // < FS_UR + FS_UPAD: entries past the round name the empty row
+            f.row = (int)ulist[s] - 1;
             const int off = (s - ustart[f.row]) * 64 + gl * 4;
             const int left = (int)rlen[f.row] - off;
             f.nvalid = left < 0 ? 0 : (left > 4 ? 4 : left);
             f.u4 = __builtin_amdgcn_raw_buffer_load_b128(col_rs, (int)((rbase[f.row] + (uint32_t)off) * 4u), 0, 0);
             return f;
         };
+        // a ring of three quads in flight per wave; every ring slot is refilled by one unconditional load per trip
         auto walk = [&](int n_units, auto body) {
             const int nq = (n_units + 3) >> 2;
-            fs_unit cur = fetch(wib, n_units), nxt = fetch(wib + FS_WAVES, n_units);
-            for (int q = wib; q < nq; q += FS_WAVES) {
-                const fs_unit nn = fetch(q + 2 * FS_WAVES, n_units);
-                body(cur);
-                cur = nxt;
-                nxt = nn;
+            fs_unit ring[3];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                ring[r] = fetch(wib + r * FS_WAVES);
+                __builtin_amdgcn_sched_barrier(0);     // issue order == ring order, or the loop head waits for vmcnt(0)
             }
+            int q = wib;
+            for (; q + 2 * FS_WAVES < nq; q += 3 * FS_WAVES) {       // full trips only: the back edge always has 3 in flight
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    body(ring[r]);                                  // consume the slot, THEN refill it: no register copy,
+                    ring[r] = fetch(q + (r + 3) * FS_WAVES);        // so the wait before the next body is vmcnt(2), not 0
+                }
+            }
+            if (q < nq) body(ring[0]);
+            if (q + FS_WAVES < nq) body(ring[1]);
         };
 
         // ---- A. mark every two-hop endpoint below v; count the paths per id range ---------------------------------------
@@ -270,53 +313,75 @@ __global__ __launch_bounds__(FS_THREADS) void filter_scan_kernel(fs_params p)
             const int nj = j + s_done, nc = s_next_c;
             single = j == 0 && c == 0 && nj >= dv;
             walk(n_units, [&](const fs_unit &f) {
-                const uint32_t u0 = (uint32_t)f.u4[0], u3 = (uint32_t)f.u4[3];
-                if (f.nvalid == 4 && (u0 >> range_shift) == (u3 >> range_shift)) {
-                    atomicAdd(&hist[u0 >> range_shift], 4u);
+                // no branches: an entry past the row head ORs / adds 0 (into whatever word its stale id names: ids < N)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const uint32_t u = (uint32_t)f.u4[e];
-                        atomicOr(&bm[u >> 5], 1u << (u & 31));
-                    }
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        if (e >= f.nvalid) continue;
-                        const uint32_t u = (uint32_t)f.u4[e];
-                        atomicOr(&bm[u >> 5], 1u << (u & 31));
-                        atomicAdd(&hist[u >> range_shift], 1u);
-                    }
+                for (int e = 0; e < 4; ++e) {
+                    const uint32_t u = (uint32_t)f.u4[e];
+                    const uint32_t on = e < f.nvalid ? 1u : 0u;
+                    atomicOr(&bm[u >> 5], on << (u & 31));
+                    atomicAdd(&hist[u >> range_shift], on);
                 }
             });
             j = nj;
             c = nc;
             if (j >= dv) break;
-            __syncthreads();       // the next round overwrites the descriptors this walk reads
+            fs_barrier();       // the next round overwrites the descriptors this walk reads
         }
-        __syncthreads();
+        fs_barrier();
         for (int k = tid; k < dv; k += FS_THREADS) {   // known edges out (the diagonal is not below v)
             const uint32_t u = (uint32_t)vcol[k];
             if (u < (uint32_t)v) atomicAnd(&bm[u >> 5], ~(1u << (u & 31)));
         }
-        __syncthreads();
+        fs_barrier();
 
         // ---- B. rank tables: exclusive prefix of the per-word popcounts over the words below v -------------------------
-        const int per = ((words_v + FS_THREADS - 1) >> 10) << 6;   // words per wave, a multiple of 64
-        const int w0 = wib * per + lane;
-        const int trips = per >> 6;
-        int local = 0;
-        for (int i = 0; i < trips; ++i) local += __popc(bm[w0 + 64 * i]);
-        {
-            const int inc = fs_wave_incl_scan(local, lane);
-            if (lane == 63) s_wtot[wib] = inc;
-        }
-        __syncthreads();
-        int wave_base = 0, total = 0;
+        // Thread t owns the 8-word groups t, t + 1024, ... (two 16-byte reads per group, consecutive threads on consecutive
+        // groups); one wave scan per trip orders the groups, the 16 x trips wave totals are scanned once more.
+        const int n_groups = (words_v + 7) >> 3;
+        const int trips = (n_groups + FS_THREADS - 1) >> 10;          // <= 4 for ids < 2^20
+        int gcnt[4];
+        uint32_t gpre[4][2];                                          // the group's 8 byte ranks, packed
 #pragma unroll
-        for (int i = 0; i < FS_WAVES; ++i) {
-            const int t = s_wtot[i];
-            if (i < wib) wave_base += t;
-            total += t;
+        for (int i = 0; i < 4; ++i) {
+            gcnt[i] = 0;
+            gpre[i][0] = gpre[i][1] = 0u;
+            const int gi = tid + i * FS_THREADS;
+            if (i < trips && gi < n_groups) {
+                const uint4 a = *(const uint4 *)(bm + gi * 8), b = *(const uint4 *)(bm + gi * 8 + 4);
+                const int c0 = __popc(a.x), c1 = c0 + __popc(a.y), c2 = c1 + __popc(a.z), c3 = c2 + __popc(a.w);
+                const int c4 = c3 + __popc(b.x), c5 = c4 + __popc(b.y), c6 = c5 + __popc(b.z);
+                gcnt[i] = c6 + __popc(b.w);
+                gpre[i][0] = (uint32_t)c0 << 8 | (uint32_t)c1 << 16 | (uint32_t)c2 << 24;
+                gpre[i][1] = (uint32_t)c3 | (uint32_t)c4 << 8 | (uint32_t)c5 << 16 | (uint32_t)c6 << 24;
+            }
+        }
+        int ginc[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            ginc[i] = 0;
+            if (i < trips) {
+                ginc[i] = fs_wave_incl_scan(gcnt[i], lane);
+                if (lane == 63) s_wtot[i * FS_WAVES + wib] = ginc[i];
+            }
+        }
+        fs_barrier();
+        int total;
+        {
+            // exclusive prefix over the (trip, wave) totals, in every wave: lane l holds total l
+            const int tv = lane < trips * FS_WAVES ? s_wtot[lane] : 0;
+            const int tinc = fs_wave_incl_scan(tv, lane);
+            total = __builtin_amdgcn_readlane(tinc, 63);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (i >= trips) break;
+                const int idx = i * FS_WAVES + wib;
+                const int before = __builtin_amdgcn_readlane(tinc, idx) - __builtin_amdgcn_readlane(tv, idx);
+                const int gi = tid + i * FS_THREADS;
+                if (gi < n_groups) {
+                    base32[gi] = (uint32_t)(before + ginc[i] - gcnt[i]);
+                    *(uint2 *)(pre8 + gi * 8) = make_uint2(gpre[i][0], gpre[i][1]);
+                }
+            }
         }
         const int n_ranges = ((v - 1) >> range_shift) + 1;
         if (tid == 0 && total) atomicAdd(&p.out->n_candidates, (unsigned long long)total);
@@ -325,20 +390,7 @@ __global__ __launch_bounds__(FS_THREADS) void filter_scan_kernel(fs_params p)
             for (int i = tid; i < words_v; i += FS_THREADS) bm[i] = 0u;
             continue;
         }
-        {
-            int wrun = wave_base;
-            for (int i = 0; i < trips; ++i) {
-                const int wi = w0 + 64 * i;
-                const int cbits = __popc(bm[wi]);
-                const int inc = fs_wave_incl_scan(cbits, lane);
-                const int run = wrun + inc - cbits;               // rank of this word's first bit
-                const int gbase = __shfl(run, lane & ~7);         // ... of its 8-word group's first bit
-                if ((lane & 7) == 0) base32[wi >> 3] = (uint32_t)run;
-                pre8[wi] = (uint8_t)(run - gbase);
-                wrun += __builtin_amdgcn_readlane(inc, 63);
-            }
-        }
-        __syncthreads();
+        fs_barrier();
 
         // ---- plan: id ranges -> tiles of <= TILE candidate ranks; bucket offsets from the path histogram -------------------
         {
@@ -348,7 +400,7 @@ __global__ __launch_bounds__(FS_THREADS) void filter_scan_kernel(fs_params p)
             if (in) hist[tid] = 0u;
             const int pin = fs_wave_incl_scan((int)paths, lane);
             if (lane == 63) s_wtot[wib] = pin;
-            __syncthreads();
+            fs_barrier();
             uint32_t pbase = 0, ptotal = 0;
 #pragma unroll
             for (int i = 0; i < FS_WAVES; ++i) {
@@ -368,11 +420,18 @@ __global__ __launch_bounds__(FS_THREADS) void filter_scan_kernel(fs_params p)
                 tile_r0[tile + 1] = (uint32_t)total;
                 tile_base[tile + 1] = ptotal;
             }
-            __syncthreads();
-            if (in) rinfo[tid] = (tile << 20) | tile_r0[tile];
-            __syncthreads();
+            if (in) rinfo[tid] = tile;
+            fs_barrier();
+            // the group table turns from absolute ranks into (tile << 16 | rank of the group's first bit inside its tile):
+            // one look-up per path gives both (a group of 256 ids never straddles a range, hence never a tile)
+            for (int gi = tid; gi < n_groups; gi += FS_THREADS) {
+                const uint32_t tl = rinfo[gi >> (range_shift - 8)];
+                base32[gi] = (tl << 16) | (base32[gi] - tile_r0[tl]);
+            }
+            fs_barrier();
         }
         const int n_tiles = s_ntiles;
+        uint32_t *ginfo = base32;
 
         // ---- D. score: tiles are taken in windows; a window of one tile accumulates in LDS directly, a wider one bins ------
         //      4-byte records (rank in tile | k << tile_bits) per tile in this workgroup's scratch and sums tile by tile.
@@ -381,16 +440,17 @@ __global__ __launch_bounds__(FS_THREADS) void filter_scan_kernel(fs_params p)
             for (uint32_t i = tid; i < nslots; i += FS_THREADS) {
                 const long long a = (long long)acc[i];
                 acc[i] = 0ull;
+                if (a < thr_fix) continue;
                 const float sc = (float)((double)a * (1.0 / (double)(1ll << FS_FIXED_SHIFT)));
-                if (!(sc > thr)) continue;
                 // the candidate of rank r: last 8-word group whose first rank is <= r, then the word, then the bit
                 const uint32_t r = r0 + i;
-                int glo = 0, ghi = (words_v + 7) >> 3;          // groups [glo, ghi): invariant base32[glo] <= r
+                auto first_rank = [&](int gi) { const uint32_t x = ginfo[gi]; return tile_r0[x >> 16] + (x & 0xFFFFu); };
+                int glo = 0, ghi = n_groups;                     // groups [glo, ghi): invariant first_rank(glo) <= r
                 while (ghi - glo > 1) {
                     const int mid = (glo + ghi) >> 1;
-                    if (base32[mid] <= r) glo = mid; else ghi = mid;
+                    if (first_rank(mid) <= r) glo = mid; else ghi = mid;
                 }
-                const uint32_t rg = r - base32[glo];
+                const uint32_t rg = r - first_rank(glo);
                 int wi = glo * 8, wj = 7;
                 while (wj > 0 && (uint32_t)pre8[wi + wj] > rg) --wj;
                 wi += wj;
@@ -420,104 +480,129 @@ __global__ __launch_bounds__(FS_THREADS) void filter_scan_kernel(fs_params p)
                 while (t_hi < n_tiles && tile_base[t_hi + 1] - tile_base[t_lo] <= p.cap_records) ++t_hi;
                 s_thi = t_hi;
             }
-            __syncthreads();
+            fs_barrier();
             const int t_hi = s_thi;
             const bool direct = t_hi - t_lo == 1;
             const uint32_t win_base = tile_base[t_lo];
+            const uint32_t span = (uint32_t)(t_hi - t_lo);
             if (!direct && tid >= t_lo && tid < t_hi) tile_cur[tid] = tile_base[tid] - win_base;
             // walk the paths again
             j = 0;
             c = 0;
             for (;;) {
                 if (!single) n_units = build_round(j, c);
-                else __syncthreads();
+                else fs_barrier();
                 const int nj = single ? dv : j + s_done, nc = single ? 0 : s_next_c;
                 const int j_round = j;
-                walk(n_units, [&](const fs_unit &f) {
-                    uint32_t u[4], word[4], rank[4], ri[4];
-                    bool cand[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) u[e] = e < f.nvalid ? (uint32_t)f.u4[e] : 0u;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) word[e] = bm[u[e] >> 5];
+                // per entry: is it a candidate of the window, and its rank inside its tile.  No branch per entry: an entry
+                // past the row head goes through the look-ups on its stale id (< N) and is masked out of `cand`.
+                auto classify = [&](const fs_unit &f, uint32_t (&rank)[4], uint32_t (&tl)[4], uint32_t (&cand)[4]) -> uint32_t {
+                    uint32_t word[4], gi[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        rank[e] = base32[u[e] >> 8] + pre8[u[e] >> 5];
-                        ri[e] = rinfo[u[e] >> range_shift];
+                        const uint32_t u = (uint32_t)f.u4[e];
+                        word[e] = bm[u >> 5];
+                        gi[e] = ginfo[u >> 8];
+                        rank[e] = pre8[u >> 5];
                     }
-                    int ncand = 0;
+                    uint32_t ncand = 0;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const uint32_t tl = (ri[e] >> 20) - (uint32_t)t_lo;
-                        cand[e] = e < f.nvalid && ((word[e] >> (u[e] & 31)) & 1u) && tl < (uint32_t)(t_hi - t_lo);
-                        rank[e] += __popc(word[e] & ((1u << (u[e] & 31)) - 1u));
-                        rank[e] -= ri[e] & 0xFFFFFu;                  // rank inside its tile
-                        ncand += cand[e] ? 1 : 0;
+                        const uint32_t b = (uint32_t)f.u4[e] & 31u;
+                        tl[e] = (gi[e] >> 16) - (uint32_t)t_lo;                     // tile, relative to the window
+                        cand[e] = (e < f.nvalid && tl[e] < span) ? (word[e] >> b) & 1u : 0u;
+                        rank[e] += (gi[e] & 0xFFFFu) + __popc(word[e] & ((1u << b) - 1u));   // rank inside its tile
+                        ncand += cand[e];
                     }
-                    if (ncand == 0) return;
-                    if (direct) {
+                    return ncand;
+                };
+                if (direct) {
+                    walk(n_units, [&](const fs_unit &f) {
+                        uint32_t rank[4], tl[4], cand[4];
+                        classify(f, rank, tl, cand);
                         const unsigned long long fx = (unsigned long long)vwfix[f.row];
 #pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            if (cand[e]) atomicAdd(&acc[rank[e]], fx);
-                        return;
-                    }
-                    const uint32_t krec = (uint32_t)(j_round + f.row) << p.tile_bits;
-                    // entries of a lane are ascending: when its first and last candidate share a tile, all of them do
-                    uint32_t tfirst = 0, tlast = 0;
-                    bool seen = false;
+                        for (int e = 0; e < 4; ++e) atomicAdd(&acc[rank[e] & tile_mask], cand[e] ? fx : 0ull);
+                    });
+                } else {
+                    walk(n_units, [&](const fs_unit &f) {
+                        uint32_t rank[4], tl[4], cand[4];
+                        const uint32_t ncand = classify(f, rank, tl, cand);
+                        const uint32_t krec = (uint32_t)(j_round + f.row) << p.tile_bits;
+                        // entries of a lane are ascending: when its first and last candidate share a tile, all of them do --
+                        // one cursor bump for the lane (a lane without candidates bumps its own trash cursor by 0)
+                        const uint32_t tfirst = cand[0] ? tl[0] : cand[1] ? tl[1] : cand[2] ? tl[2] : tl[3];
+                        const uint32_t tlast = cand[3] ? tl[3] : cand[2] ? tl[2] : cand[1] ? tl[1] : tl[0];
+                        uint32_t pos[4];
+                        if (tfirst == tlast || ncand == 0) {
+                            pos[0] = atomicAdd(&tile_cur[ncand ? (uint32_t)t_lo + tfirst : (uint32_t)(FS_RANGES + lane)], ncand);
+                            pos[1] = pos[0] + cand[0];
+                            pos[2] = pos[1] + cand[1];
+                            pos[3] = pos[2] + cand[2];
+                        } else {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if (cand[e]) {
-                            if (!seen) tfirst = ri[e] >> 20;
-                            seen = true;
-                            tlast = ri[e] >> 20;
+                            for (int e = 0; e < 4; ++e)
+                                pos[e] = cand[e] ? atomicAdd(&tile_cur[t_lo + tl[e]], 1u) : 0u;
                         }
-                    if (tfirst == tlast) {
-                        uint32_t pos = atomicAdd(&tile_cur[tfirst], (uint32_t)ncand);
+                        // one store per entry, no branch: what is not a candidate of the window lands in the trash line
 #pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            if (cand[e]) my_scratch[pos++] = rank[e] | krec;
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            if (cand[e]) my_scratch[atomicAdd(&tile_cur[ri[e] >> 20], 1u)] = rank[e] | krec;
-                    }
-                });
+                        for (int e = 0; e < 4; ++e) my_scratch[cand[e] ? pos[e] : p.cap_records + lane] = rank[e] | krec;
+                    });
+                }
                 j = nj;
                 c = nc;
                 if (j >= dv) break;
-                __syncthreads();
+                fs_barrier();
             }
             if (direct) {
                 if (tid == 0) reserve_out(t_lo);
-                __syncthreads();
+                fs_barrier();
                 scan_tile(t_lo);
             } else {
+                // per tile: records -> sums in LDS -> scan.  The first FS_AHEAD records per thread of the NEXT tile are
+                // requested before the scan of the current one, so their latency hides behind it.
+                uint32_t rec[FS_AHEAD], b0 = 0, n = 0;
+                auto request = [&](int t) {
+                    b0 = tile_base[t] - win_base;
+                    n = tile_cur[t] - b0;
+#pragma unroll
+                    for (int q = 0; q < FS_AHEAD; ++q) {
+                        const uint32_t i = tid + q * FS_THREADS;
+                        rec[q] = my_scratch[b0 + (i < n ? i : 0u)];
+                    }
+                };
+                auto add = [&](uint32_t r, bool live) {
+                    if (!live) return;                       // (mostly whole waves: the tail of a bucket)
+                    const uint32_t k = r >> p.tile_bits;
+                    const long long fx = single ? vwfix[k] : p.fixw[vcol[k]];
+                    atomicAdd(&acc[r & tile_mask], (unsigned long long)fx);
+                };
+                __syncthreads();                   // records visible (global stores drained), cursors final
+                request(t_lo);
                 for (int t = t_lo; t < t_hi; ++t) {
-                    __syncthreads();               // records visible; acc zero (previous scan done)
-                    const uint32_t b0 = tile_base[t] - win_base, n = tile_cur[t] - b0;
-                    for (uint32_t i0 = tid; i0 < n; i0 += 4 * FS_THREADS) {   // four records in flight per thread
-                        uint32_t rec[4];
+                    const uint32_t cb0 = b0, cn = n;
+#pragma unroll
+                    for (int q = 0; q < FS_AHEAD; ++q)
+                        add(rec[q], tid + q * FS_THREADS < cn);
+                    for (uint32_t i0 = tid + FS_AHEAD * FS_THREADS; i0 < cn; i0 += 4 * FS_THREADS) {
+                        uint32_t more[4];
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
                             const uint32_t i = i0 + q * FS_THREADS;
-                            rec[q] = my_scratch[b0 + (i < n ? i : i0)];
+                            more[q] = my_scratch[cb0 + (i < cn ? i : i0)];
                         }
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            if (i0 + q * FS_THREADS >= n) break;
-                            const uint32_t k = rec[q] >> p.tile_bits;
-                            const long long fx = single ? vwfix[k] : p.fixw[vcol[k]];
-                            atomicAdd(&acc[rec[q] & tile_mask], (unsigned long long)fx);
-                        }
+                        for (int q = 0; q < 4; ++q)
+                            add(more[q], i0 + q * FS_THREADS < cn);
                     }
+                    if (t + 1 < t_hi) request(t + 1);
                     if (tid == 0) reserve_out(t);
-                    __syncthreads();
+                    fs_barrier();               // sums complete
                     scan_tile(t);
+                    fs_barrier();               // accumulators zero again
                 }
             }
-            __syncthreads();           // scans done before the next window rebuilds rounds / before the bitmap is cleared
+            fs_barrier();           // scans done before the next window rebuilds rounds / before the bitmap is cleared
             t_lo = t_hi;
         }
         for (int i = tid; i < words_v; i += FS_THREADS) bm[i] = 0u;
@@ -636,7 +721,7 @@ extern "C" int eps_filter_scan(const int64_t *rowptr, const int32_t *col, const 
     if (blocks > n_columns) blocks = n_columns;
     EPS_REQUIRE(workspace && ((uintptr_t)workspace & 15) == 0 && workspace_bytes >= blocks * 4096,
                 "eps_filter_scan: needs a 16-byte aligned workspace (eps_filter_scan_workspace_bytes)");
-    int64_t cap = workspace_bytes / 4 / blocks;
+    int64_t cap = workspace_bytes / 4 / blocks - 64;
     if (cap > 0xFFFFFFF0ll) cap = 0xFFFFFFF0ll;
     hipStream_t s = (hipStream_t)stream;
     unsigned int *counter = nullptr;

@@ -19,7 +19,7 @@ from pathlib import Path
 
 import torch
 
-from . import candidates, ops, proposals
+from . import candidates, ops, proposals, scan
 from .datasets import get_data
 from .graph import CSRGraph, add_edges
 from .heuristics import node_weight_table, pair_scores_streamed
@@ -79,6 +79,22 @@ def rank_column_range(g: CSRGraph, rank: int, world: int):
     return b[rank], b[rank + 1]
 
 
+def fused_node_weights(args, g: CSRGraph, ra_graph):
+    """Per-node weights that make the fused kernels' sum_w A[u,w]*A[v,w]*node_w[w] the filter model's score, or None
+    when the model does not score on the candidate graph itself (GNN filters; RA after proposal edges were added).
+    AA: filter.py:122-126; CN 'simple': :116-121 with models.py:536-542 (unit weights); RA: :130-141 scores on the
+    train-only graph -- when no proposal edges were added that IS the candidate graph (unit values), with 1/deg formed
+    in float64 like the reference's int64 adjacency makes it, then rounded once to float32."""
+    if args.model == "adamic_ogb":
+        return node_weight_table(g, ops.W_AA)
+    if args.model == "simple":
+        return torch.ones(g.n_rows, dtype=torch.float32, device=g.device)
+    if (args.model == "resource_allocation" and ra_graph is not None and g.val is None and ra_graph.val is None
+            and g.nnz() == ra_graph.nnz() and torch.equal(g.rowptr, ra_graph.rowptr) and torch.equal(g.col, ra_graph.col)):
+        return node_weight_table(ra_graph, ops.W_RA, f64=True).to(torch.float32)
+    return None
+
+
 CUT_CAPACITY = 1 << 23     # survivors per block the expansion kernel may report (96 MB); more -> the block is redone in full
 
 
@@ -89,25 +105,12 @@ def scored_blocks(args, model, data, ra_graph, col_lo: int = 0, col_hi: int = No
     g = data.adj_t
     col_hi = g.n_rows if col_hi is None else col_hi
     blocks = [(max(lo, col_lo), min(hi, col_hi)) for lo, hi in candidates.column_blocks(g) if lo < col_hi and hi > col_lo]
-    fused = candidates.hip_expand_available(g) and args.model in ("adamic_ogb", "simple")
-    if (args.model == "resource_allocation" and candidates.hip_expand_available(g) and ra_graph is not None
-            and g.val is None and ra_graph.val is None and g.nnz() == ra_graph.nnz()
-            and torch.equal(g.rowptr, ra_graph.rowptr) and torch.equal(g.col, ra_graph.col)):
-        # filter.py:130-141 scores RA on the train-only graph; when no proposal edges were added that IS the candidate
-        # graph (unit values), so the scores come out of the same fused expansion.  Weights 1/deg are formed in float64
-        # like the reference's int64 adjacency makes them, then rounded once to float32.
-        fused = True
-    if not fused:
+    node_w = fused_node_weights(args, g, ra_graph) if candidates.hip_expand_available(g) else None
+    if node_w is None:
         for v_lo, v_hi in blocks:
             pairs = candidates.expand_block(g, v_lo, v_hi)[0]
             yield v_lo, v_hi, pairs, (score_block(args, model, data, pairs, ra_graph) if pairs.shape[1] else None)
         return
-    if args.model == "adamic_ogb":
-        node_w = node_weight_table(g, ops.W_AA)
-    elif args.model == "resource_allocation":
-        node_w = node_weight_table(ra_graph, ops.W_RA, f64=True).to(torch.float32)
-    else:  # CN = sum_w A[u,w]*A[v,w]: the same accumulator with unit node weights
-        node_w = torch.ones(g.n_rows, dtype=torch.float32, device=g.device)
     print(f'fused candidate generation + scoring ({args.model})')
     for v_lo, v_hi in blocks:
         # once the streaming top-K holds K proposals (``bar()`` is its K-th score) only candidates above that bar matter:
@@ -164,10 +167,28 @@ def run(args) -> str:
 
     t0 = time.perf_counter()
     keep = int(args.keep_top)
+    scan_w = fused_node_weights(args, data.adj_t, ra_graph) if keep and scan.scan_available(data.adj_t) else None
+    if scan_w is not None:
+        # --keep_top on a unit-valued graph with a heuristic filter: one threshold scan of the whole candidate set
+        # (csrc/filter_scan.hip) instead of candidate blocks + streaming top-K; every rank ends with the same list
+        st = {}
+        with torch.no_grad():
+            best_pairs, best_scores = scan.scan_topk(data.adj_t, scan_w, keep, rank, world, stats=st)
+        torch.cuda.synchronize(device)
+        dt = time.perf_counter() - t0
+        print(f'threshold scan ({args.model}): bar {st["bar"]}, {st["survivors"]} survivors, {st["launches"]} launches')
+        print(f'using {st["candidates"]} edges; scored in {dt:.2f} s ({st["candidates"] / max(dt, 1e-9):.3e} candidate edges/s '
+              f'incl. generation)')
+        return _save(args, spec, sorted_edge_path, num_sorted_edge, run_id, rank, world,
+                     torch.cat([best_pairs.t().to(torch.float32), best_scores.unsqueeze(1)], 1))
     col_lo, col_hi = rank_column_range(data.adj_t, rank, world)
     n_seen = 0
     all_pairs, all_scores = [], []
     top = proposals.StreamingTopK(keep) if keep else None
+    if world > 1 and hasattr(model, "embeddings"):
+        # the row-sharded GNN forward holds a collective: every rank must reach it, whatever its column shard yields
+        with torch.no_grad():
+            model.embeddings(data.x, data.adj_t)
     with torch.no_grad():
         for v_lo, v_hi, pairs, score in scored_blocks(args, model, data, ra_graph, col_lo, col_hi,
                                                       bar=top.bar if keep else None):
@@ -210,6 +231,10 @@ def run(args) -> str:
         pairs = torch.cat(all_pairs, 1)
         scores = torch.cat(all_scores)
         sorted_edges = proposals.sorted_edges_tensor(pairs, scores)          # filter.py:160-161
+    return _save(args, spec, sorted_edge_path, num_sorted_edge, run_id, rank, world, sorted_edges)
+
+
+def _save(args, spec, sorted_edge_path, num_sorted_edge, run_id, rank, world, sorted_edges) -> str:
     filename = f'filtered_edges/{spec}_{sorted_edge_path}_{num_sorted_edge}_{run_id}_sorted_edges.pt'
     if rank == 0:
         print(sorted_edges)

@@ -289,6 +289,7 @@ def fixed_weights(node_w: torch.Tensor) -> torch.Tensor:
 
 
 _SCAN_WS = {}
+KERNEL_EVENTS = None      # a list while bench.py times kernels: (kernel name, start event, end event, work size) per launch
 
 
 def _scan_scratch(dev) -> torch.Tensor:
@@ -338,9 +339,16 @@ def filter_scan(rowptr, col, revpos, fixw, n_nodes: int, columns: torch.Tensor, 
         raise _lib.EpsError("filter_scan: revpos / fixw do not match the graph")
     ws = _scan_scratch(dev)
     with torch.cuda.device(dev):
+        ev = None
+        if KERNEL_EVENTS is not None:              # bench.py: HIP events around the launch, on the stream it runs on
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record(torch.cuda.current_stream(dev))
         _lib.check(_lib.load().eps_filter_scan(_ptr(rowptr), _ptr(col), _ptr(revpos), _ptr(fixw), n_nodes, col.numel(),
                                                _ptr(columns), columns.numel(), _ptr(out.rec), _ptr(ws), ws.numel() * 8,
                                                _stream(dev)), "eps_filter_scan")
+        if ev is not None:
+            ev[1].record(torch.cuda.current_stream(dev))
+            KERNEL_EVENTS.append(("filter_scan_kernel", ev[0], ev[1], int(columns.numel())))
 
 
 def spmm_csr(rowptr, col, val, x: torch.Tensor, bias=None, relu=False, mean=False, out=None) -> torch.Tensor:

@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""A/B of eps_filter_scan builds in ONE process (interleaved, same inputs): python tools/scan_ab.py libA.so libB.so ...
+Each library is loaded with ctypes next to the product one; only eps_filter_scan is taken from it."""
+import ctypes, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch, eps_amd
+from eps_amd import ops, scan, synth, _lib
+from eps_amd.heuristics import node_weight_table
+dev = torch.device("cuda:0")
+g = synth.ppa_like(seed=3, device=dev)
+w = node_weight_table(g, ops.W_AA)
+fixw = scan.fixed_weights(g, w)
+order = scan.column_order(g)
+revpos = scan.reverse_positions(g)
+bar = float(os.environ.get("BAR", "2.14"))
+libs = []
+for path in sys.argv[1:]:
+    lib = ctypes.CDLL(os.path.join(ROOT, path) if not os.path.isabs(path) else path)
+    lib.eps_filter_scan.restype = ctypes.c_int
+    lib.eps_filter_scan.argtypes = _lib.SIGNATURES["eps_filter_scan"][1]
+    libs.append((os.path.basename(path), lib))
+ws = ops._scan_scratch(dev)
+ref = None
+times = {n: [] for n, _ in libs}
+for rep in range(int(os.environ.get("REPS", "6"))):
+    for name, lib in libs:
+        res = ops.Survivors(32 << 20, bar, dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        rc = lib.eps_filter_scan(g.rowptr.data_ptr(), g.col.data_ptr(), revpos.data_ptr(), fixw.data_ptr(), g.n_rows, g.nnz(),
+                                 order.data_ptr(), order.numel(), res.rec.data_ptr(), ws.data_ptr(), ws.numel() * 8,
+                                 torch.cuda.current_stream().cuda_stream)
+        e1.record(); torch.cuda.synchronize()
+        assert rc == 0, name
+        times[name].append(e0.elapsed_time(e1))
+        slots, nc = res.counts()
+        k, v = res.valid(slots)
+        o = torch.argsort(k)
+        sig = (k[o], v[o])
+        if ref is None:
+            ref = sig
+        else:
+            assert torch.equal(ref[0], sig[0]) and torch.equal(ref[1], sig[1]), f"{name}: survivors differ"
+for name, t in times.items():
+    t = sorted(t[1:])
+    print(f"{name:40s} median {t[len(t)//2]:.2f} ms  min {t[0]:.2f}  (n={len(t)})")
