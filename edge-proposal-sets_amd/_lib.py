@@ -29,6 +29,7 @@ SIGNATURES = {
     "eps_expand_max_nodes": (_int, []),
     "eps_expand_count": (_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp]),
     "eps_expand_fill": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
+    "eps_expand_fill_tiled": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp]),
     "eps_expand_workspace_bytes": (_i64, [_i64]),
     "eps_filter_scan_max_nodes": (_i64, []),
     "eps_filter_scan_workspace_bytes": (_i64, []),

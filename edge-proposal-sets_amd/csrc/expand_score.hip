@@ -36,7 +36,6 @@
 // host falls back to the tensor-op expansion above that.
 #include "eps_common.h"
 
-#include <stdlib.h>
 
 #define EX_THREADS 1024
 #define EX_WAVES (EX_THREADS / 64)
@@ -175,20 +174,6 @@ __device__ __forceinline__ void for_each_path(const int64_t *__restrict__ rowptr
     if (threadIdx.x == 0) *s_nlong = 0;
 }
 
-#ifdef EX_STAMP  // diagnostic build only: per-phase s_memtime sums of wave 0 of every workgroup (never in the shipped library)
-__device__ unsigned long long g_ex_stamp[16];
-#define XSTAMP(var) unsigned long long var; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory")
-#define XSTAMP_ADD(i, a, b) xst[i] += (b) - (a)
-extern "C" int eps_debug_expand_stamps(unsigned long long *out16, int reset)
-{
-    hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_ex_stamp), sizeof(unsigned long long) * 16);
-    if (reset) { unsigned long long z[16] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(g_ex_stamp), z, sizeof(z)); }
-    return 0;
-}
-#else
-#define XSTAMP(var)
-#define XSTAMP_ADD(i, a, b)
-#endif
 
 template <bool FILL, bool HAS_VAL, bool HAS_W>
 __global__ __launch_bounds__(EX_THREADS) void expand_kernel(
@@ -235,17 +220,11 @@ __global__ __launch_bounds__(EX_THREADS) void expand_kernel(
     if (FILL)
         for (int i = tid; i < EX_RANGES; i += EX_THREADS) hist[i] = 0u;
 
-#ifdef EX_STAMP
-    unsigned long long xst[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#endif
     for (;;) {
-        XSTAMP(t0);
         __syncthreads();
         if (tid == 0) s_col = atomicAdd(next_col, 1u);
         __syncthreads();
         if ((int64_t)v_lo + s_col >= v_hi) break;
-        XSTAMP(t1);
-        XSTAMP_ADD(0, t0, t1);
         const int64_t v = (int64_t)v_lo + (col_order ? (uint32_t)col_order[s_col] : s_col);
         const int64_t vb = rowptr[v];
         const int32_t dv = (int32_t)(rowptr[v + 1] - vb);
@@ -271,8 +250,6 @@ __global__ __launch_bounds__(EX_THREADS) void expand_kernel(
         }
         if (tid == 0) atomicAnd(&bm[(uint32_t)v >> 5], ~(1u << ((uint32_t)v & 31)));  // diagonal out
         __syncthreads();
-        XSTAMP(t2);
-        XSTAMP_ADD(1, t1, t2);
 
         // ---- B. rank: exclusive prefix of the per-word popcounts ---------------------------------
         // Word layout: wave i owns the words [i * 64 * wpt, (i + 1) * 64 * wpt); in trip t its 64 lanes read 64 CONSECUTIVE
@@ -290,8 +267,6 @@ __global__ __launch_bounds__(EX_THREADS) void expand_kernel(
             if (i < wib) wave_base += t;
             total += t;
         }
-        XSTAMP(t3);
-        XSTAMP_ADD(2, t2, t3);
 
         if (!FILL) {
             if (tid == 0) cand_count[v - v_lo] = total;
@@ -342,8 +317,6 @@ __global__ __launch_bounds__(EX_THREADS) void expand_kernel(
         if (cand_v)  // one value for the whole column: whole lines, not one scattered store per candidate
             for (int i = tid; i < total; i += EX_THREADS) cand_v[base + i] = (int32_t)v;
         __syncthreads();   // rank tables complete; also orders the s_wave_tot reads above against the plan's scan below
-        XSTAMP(t4);
-        XSTAMP_ADD(3, t3, t4);
         if (!want_d) {
             for (int i = 0; i < wpt; ++i) bm[w0 + 64 * i] = 0u;
             continue;
@@ -388,8 +361,6 @@ __global__ __launch_bounds__(EX_THREADS) void expand_kernel(
             __syncthreads();
         }
         const int n_tiles = s_ntiles;
-        XSTAMP(t5);
-        XSTAMP_ADD(4, t4, t5);
 
         // ---- D1. bin: walk the paths again, append (rank in tile, term) to the tile's bucket ---------------------------
         // The four entries of a lane go through the LDS look-ups stage by stage (all four bitmap words, then all four
@@ -426,8 +397,6 @@ __global__ __launch_bounds__(EX_THREADS) void expand_kernel(
                     my_scratch[pos[e]] = make_uint2(rank[e] - (ri[e] & 0xFFFFFu), __builtin_bit_cast(uint32_t, term));
                 }
             });
-        XSTAMP(t6);
-        XSTAMP_ADD(5, t5, t6);
 
         // ---- D2. per tile: bucket -> fixed-point sums and counts in LDS -> coalesced float32 scores / int32 counts ----------
         for (int t = 0; t < n_tiles; ++t) {
@@ -470,16 +439,8 @@ __global__ __launch_bounds__(EX_THREADS) void expand_kernel(
             }
             __syncthreads();
         }
-        XSTAMP(t7);
-        XSTAMP_ADD(6, t6, t7);
         for (int i = 0; i < wpt; ++i) bm[w0 + 64 * i] = 0u;   // D2 left its accumulators in the bitmap's space
-        XSTAMP(t8);
-        XSTAMP_ADD(7, t4, t8);
     }
-#ifdef EX_STAMP
-    if (FILL && tid == 0)
-        for (int i = 0; i < 8; ++i) atomicAdd(&g_ex_stamp[i], xst[i]);
-#endif
 }
 
 static int expand_words_per_thread(int64_t n_nodes)
@@ -550,6 +511,16 @@ extern "C" int eps_expand_fill(const int64_t *rowptr, const int32_t *col, const 
                                const int64_t *colptr, int64_t *cand_count, int32_t *cand_u, int32_t *cand_v, int32_t *cn,
                                float *score, eps_score_cut *cut, void *workspace, int64_t workspace_bytes, void *stream)
 {
+    return eps_expand_fill_tiled(rowptr, col, val, node_w, n_nodes, v_lo, v_hi, col_order, colptr, cand_count, cand_u,
+                                 cand_v, cn, score, cut, workspace, workspace_bytes, 0, stream);
+}
+
+extern "C" int eps_expand_fill_tiled(const int64_t *rowptr, const int32_t *col, const float *val, const float *node_w,
+                                     int64_t n_nodes, int64_t v_lo, int64_t v_hi, const int32_t *col_order,
+                                     const int64_t *colptr, int64_t *cand_count, int32_t *cand_u, int32_t *cand_v,
+                                     int32_t *cn, float *score, eps_score_cut *cut, void *workspace,
+                                     int64_t workspace_bytes, int32_t tile_ranks, void *stream)
+{
     EPS_REQUIRE(n_nodes >= 0 && v_lo >= 0 && v_hi >= v_lo && v_hi <= n_nodes, "eps_expand_fill: bad column range");
     if (v_hi == v_lo) return EPS_OK;
     EPS_REQUIRE(rowptr && col && colptr && cand_u, "eps_expand_fill: null pointer");
@@ -575,9 +546,10 @@ extern "C" int eps_expand_fill(const int64_t *rowptr, const int32_t *col, const 
     }
     const int range_shift = expand_range_shift(n_nodes);
     int tile_half = EX_TILE / 2;
-    if (const char *dbg = getenv("EPS_DEBUG_TILE_HALF")) {  // tests: many small tiles on small graphs
-        const int v = atoi(dbg);
-        if (v >= (1 << range_shift) && v < tile_half) tile_half = v;
+    if (tile_ranks) {      // an explicit, smaller tile (a range of ids must still fit half a tile)
+        EPS_REQUIRE(tile_ranks % 2 == 0 && tile_ranks / 2 >= (1 << range_shift) && tile_ranks <= EX_TILE,
+                    "eps_expand_fill_tiled: tile_ranks must be even, in [%d, %d]", 2 << range_shift, EX_TILE);
+        tile_half = tile_ranks / 2;
     }
     const bool hv = val != nullptr, hw = node_w != nullptr;
 #define EX_LAUNCH(HV, HW)                                                                                              \

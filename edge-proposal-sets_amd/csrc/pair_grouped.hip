@@ -95,20 +95,6 @@ __device__ __forceinline__ void test_row_inline(const uint8_t *bm8, uint32_t bm_
     }
 }
 
-#ifdef PG_STAMP  // diagnostic build only: per-segment s_memtime sums (never in the shipped library)
-__device__ unsigned long long g_stamp[16];
-#define STAMP(var) unsigned long long var; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory")
-#define STAMP_ADD(i, a, b) st[i] += (b) - (a)
-extern "C" int eps_debug_stamps(unsigned long long *out16, int reset)
-{
-    hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_stamp), sizeof(unsigned long long) * 16);
-    if (reset) { unsigned long long z[16] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(g_stamp), z, sizeof(z)); }
-    return 0;
-}
-#else
-#define STAMP(var)
-#define STAMP_ADD(i, a, b)
-#endif
 
 template <bool HAS_VAL, bool HAS_W, typename WT, bool EXACT>
 __global__ __launch_bounds__(PG_THREADS) void pair_scores_grouped_kernel(
@@ -127,10 +113,6 @@ __global__ __launch_bounds__(PG_THREADS) void pair_scores_grouped_kernel(
     const int tid = threadIdx.x, lane = tid & 63, wib = tid >> 6;
     uint32_t *q = bm + bm_words + wib * PG_QCAP;  // this wave's hit queue
     const int64_t n_chunks = (n_pairs + PG_CHUNK - 1) / PG_CHUNK;
-#ifdef PG_STAMP
-    unsigned long long st[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    STAMP(t_begin);
-#endif
 
     // Chunks are handed out dynamically (one device-scope atomic per chunk): a column's cost follows the degrees
     // of its candidates, so a static split leaves the slowest workgroup running ~1.5x longer than the average one.
@@ -177,7 +159,6 @@ __global__ __launch_bounds__(PG_THREADS) void pair_scores_grouped_kernel(
         // node 0 (which, rows being sorted, can only be the FIRST element of a row) is settled on the side.
         const bool v_has0 = EXACT && dv > 0 && vcol[0] == 0;
 
-        STAMP(tb1);
         for (int i = tid * 4; i < bm_words; i += PG_THREADS * 4) *reinterpret_cast<uint4 *>(&bm[i]) = make_uint4(0, 0, 0, 0);
         __syncthreads();
         for (int k = tid; k < dv; k += PG_THREADS) {
@@ -186,15 +167,12 @@ __global__ __launch_bounds__(PG_THREADS) void pair_scores_grouped_kernel(
             if (!EXACT || w != 0) atomicOr(&bm[idx >> 5], 1u << (idx & 31));
         }
         __syncthreads();
-        STAMP(tb2);
-        STAMP_ADD(1, tb1, tb2);  // 1: bitmap rebuild
 
         for (;;) {
             unsigned int gi = 0;
             if (lane == 0) gi = atomicAdd(&s_group, 1u);
             const int64_t g0 = c0s + (int64_t)__builtin_amdgcn_readfirstlane(gi) * 64;
             if (g0 >= c1) break;
-            STAMP(tg0);
             const int64_t p = g0 + lane;
             const bool valid = p < c1;
             const int32_t nu = valid ? pu[p] : 0;
@@ -244,16 +222,10 @@ __global__ __launch_bounds__(PG_THREADS) void pair_scores_grouped_kernel(
                 ring0[r] = __builtin_amdgcn_raw_buffer_load_b128(r0, lane * 16, 0, 0);
                 ring1[r] = __builtin_amdgcn_raw_buffer_load_b128(r0, lane * 16 + 1024, 0, 0);
             }
-#ifdef PG_STAMP
-            asm volatile("" ::"v"(du), "v"(ub));
-            STAMP(tg1);
-            STAMP_ADD(2, tg0, tg1);  // 2: group metadata
-#endif
             for (int jb = 0; jb < 64; jb += PG_RING) {
 #pragma unroll
                 for (int r = 0; r < PG_RING; ++r) {
                     const int j = jb + r;
-                    STAMP(tp0);
                     const int32_t dju = __builtin_amdgcn_readlane(du, j);   // 0 for lanes past the end of the chunk
                     const int64_t bju = bcast64(ub, j);
                     const __amdgpu_buffer_rsrc_t rj = row_rsrc(col + bju, dju);
@@ -265,17 +237,6 @@ __global__ __launch_bounds__(PG_THREADS) void pair_scores_grouped_kernel(
                         ring0[r] = __builtin_amdgcn_raw_buffer_load_b128(rn, lane * 16, 0, 0);
                         ring1[r] = __builtin_amdgcn_raw_buffer_load_b128(rn, lane * 16 + 1024, 0, 0);
                     }
-#if defined(PG_ABLATE) && PG_ABLATE == 3   // timing-only: metadata + ring loads only
-                    asm volatile("" ::"v"(cur0), "v"(cur1));
-                    continue;
-#endif
-#ifdef PG_STAMP
-                    STAMP(tp05);
-                    STAMP_ADD(9, tp0, tp05);  // 9: readlanes + descriptors + refill issue
-                    asm volatile("" ::"v"(cur0), "v"(cur1));
-                    STAMP(tp1);
-                    STAMP_ADD(3, tp05, tp1);  // 3: wait for this pair's ring data
-#endif
                     if (dju == 0) continue;
                     int cnt = 0;
                     float r_cn = 0.0f;
@@ -288,13 +249,6 @@ __global__ __launch_bounds__(PG_THREADS) void pair_scores_grouped_kernel(
                             // a loop of their own: merging the two sources in one loop makes hipcc wait vmcnt(0) -- i.e.
                             // for the whole ring -- before every unit.
                             auto test_unit = [&](v4i wv) {
-#if defined(PG_ABLATE) && PG_ABLATE == 1   // timing-only: no dependence on the row loads (they become dead)
-                                wv = (v4i){lane * 4 + j, lane * 4 + 1 + 7 * j, lane * 4 + 2 + 13 * j, lane * 4 + 3 + j};
-#endif
-#if defined(PG_ABLATE) && PG_ABLATE == 2   // timing-only: row loads kept alive, no bitmap test
-                                asm volatile("" ::"v"(wv));
-                                return;
-#endif
                                 uint32_t b[4];
 #pragma unroll
                                 for (int e = 0; e < 4; ++e) {
@@ -318,16 +272,10 @@ __global__ __launch_bounds__(PG_THREADS) void pair_scores_grouped_kernel(
                                     }
                                 }
                             };
-                            STAMP(tu0);
                             test_unit(cur0);
                             if (dju > 256) test_unit(cur1);
-                            STAMP(tu1);
-                            STAMP_ADD(4, tu0, tu1);  // 4: first two units
                             // rows beyond 512 entries: four loads in flight per trip (a load-use-load chain would
                             // pay one full memory latency per 256 entries; out-of-range units read as zeros = no hit)
-#if defined(PG_ABLATE) && PG_ABLATE == 4   // timing-only: rows truncated to their first 512 entries
-                            if (false)
-#endif
                             for (int k0 = 512; k0 < dju; k0 += 1024) {
                                 const v4i x0 = __builtin_amdgcn_raw_buffer_load_b128(rj, lane * 16 + k0 * 4, 0, 0);
                                 const v4i x1 = __builtin_amdgcn_raw_buffer_load_b128(rj, lane * 16 + k0 * 4 + 1024, 0, 0);
@@ -338,8 +286,6 @@ __global__ __launch_bounds__(PG_THREADS) void pair_scores_grouped_kernel(
                                 if (k0 + 512 < dju) test_unit(x2);
                                 if (k0 + 768 < dju) test_unit(x3);
                             }
-                            STAMP(tu2);
-                            STAMP_ADD(5, tu1, tu2);  // 5: on-demand units of long rows
                             if (v_has0 && __builtin_amdgcn_readlane(cur0[0], 0) == 0) {  // node 0 is a common neighbour
                                 if (qlen >= PG_QCAP) {
                                     flush(j, q0);
@@ -350,11 +296,6 @@ __global__ __launch_bounds__(PG_THREADS) void pair_scores_grouped_kernel(
                                 cnt += 1;
                             }
                             if (cnt != 0 && lane == j) { my_count = cnt; my_cn = (float)cnt; my_qstart = q0; my_qcnt = qlen - q0; }
-#ifdef PG_STAMP
-                            asm volatile("" ::"v"(my_count), "v"(my_qstart), "v"(my_qcnt), "s"(qlen));
-                            STAMP(tu3);
-                            STAMP_ADD(8, tu2, tu3);  // 8: node-0 check + result select
-#endif
                             continue;
                         }
                         test_row_inline<HAS_VAL, HAS_W, WT, EXACT>(bm8, bm_mask, vcol, dv, vb, v_has0, rj, bju, dju, cur0, cur1,
@@ -375,10 +316,7 @@ __global__ __launch_bounds__(PG_THREADS) void pair_scores_grouped_kernel(
                     if (cnt != 0 && lane == j) { my_count = cnt; my_cn = r_cn; my_ws = r_ws; }
                 }
             }
-            STAMP(tf0);
             flush(-1, 0);
-            STAMP(tf1);
-            STAMP_ADD(6, tf0, tf1);  // 6: final flush of the group
             if (valid) {
                 if (out_count) out_count[p] = my_count;
                 if (out_cn) out_cn[p] = my_cn;
@@ -387,12 +325,6 @@ __global__ __launch_bounds__(PG_THREADS) void pair_scores_grouped_kernel(
         }
       }
     }
-#ifdef PG_STAMP
-    STAMP(t_end);
-    st[7] = t_end - t_begin;  // 7: whole wave
-    if (lane == 0)
-        for (int i = 0; i < 10; ++i) atomicAdd(&g_stamp[i], st[i]);
-#endif
 }
 
 template <typename WT>

@@ -24,25 +24,27 @@ import torch
 import torch.distributed as dist
 
 
-def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, torch.device]:
-    """Join the job described by RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* (torchrun).  -> (rank, world, device)."""
+def init_from_env(backend: Optional[str] = None, device_index: Optional[int] = None) -> Tuple[int, int, torch.device]:
+    """Join the job described by RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* (torchrun).  -> (rank, world, device).
+    ``backend``: "nccl" (RCCL over xGMI; the default on a GPU box) or "gloo" (collectives staged through host memory).
+    ``device_index``: the HIP device of this rank; default LOCAL_RANK.  RCCL needs one device per rank; with gloo several
+    ranks may share a device (``filter.py --dist_backend gloo --device 0``: how a 1-GPU box runs the multi-rank path)."""
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    # test hook for a 1-GPU box: EPS_DIST_ONE_DEVICE=1 runs every rank on cuda:0 with gloo as the transport (RCCL needs one
-    # GPU per rank), so the multi-rank control flow of the stages runs on real kernels
-    one_device = os.environ.get("EPS_DIST_ONE_DEVICE") == "1" and torch.cuda.is_available()
-    use_gpu = torch.cuda.is_available() and backend != "gloo"
-    device = torch.device("cuda", 0 if one_device else local) if (use_gpu or one_device) else torch.device("cpu")
-    if device.type == "cuda":
+    if torch.cuda.is_available():
+        device = torch.device("cuda", local if device_index is None else int(device_index))
         torch.cuda.set_device(device)
+    else:
+        device = torch.device("cpu")
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        if use_gpu and not one_device:
+        backend = backend or ("nccl" if device.type == "cuda" else "gloo")
+        if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
         else:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+            dist.init_process_group(backend, rank=rank, world_size=world)
     return rank, world, device
 
 

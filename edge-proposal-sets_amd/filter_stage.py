@@ -39,8 +39,9 @@ def make_parser():
     parser.add_argument('--epochs', type=int)
     parser.add_argument('--use_feature', type=bool)
     parser.add_argument('--use_learnable_embedding', type=bool)
-    parser.add_argument('--device', type=int, default=0)
+    parser.add_argument('--device', type=int, default=None)
     # extensions
+    parser.add_argument('--dist_backend', type=str, default=None, choices=[None, 'nccl', 'gloo'])
     parser.add_argument('--synthetic', action="store_true", default=False)
     parser.add_argument('--keep_top', type=int, default=0)
     return parser
@@ -137,8 +138,8 @@ def run(args) -> str:
     # one process per GPU under torchrun (WORLD_SIZE > 1): candidate COLUMNS are sharded, the graph is replicated, the
     # only exchange is the final top-K merge (needs --keep_top: rank.py never reads past num_sorted_edge rows anyway)
     from . import dist as epd
-    rank, world, dist_dev = epd.init_from_env()
-    device = dist_dev if world > 1 else torch.device(f'cuda:{args.device}')
+    rank, world, dist_dev = epd.init_from_env(args.dist_backend, args.device)
+    device = dist_dev if world > 1 else torch.device(f'cuda:{args.device or 0}')
     if world > 1 and not args.keep_top:
         raise ValueError("multi-GPU filter needs --keep_top K (the full [E,3] list is not gathered)")
 

@@ -182,7 +182,7 @@ def expand_workspace_fits(max_paths: int) -> bool:
 
 
 def expand_candidates(rowptr, col, val, node_w, n_nodes: int, v_lo: int, v_hi: int, want_cn=True, want_score=True,
-                      want_v=True, col_order=None, max_paths=None, colptr_ub=None, total_ub=None, cut=None):
+                      want_v=True, col_order=None, max_paths=None, colptr_ub=None, total_ub=None, cut=None, tile_ranks=0):
     """Fused 2-hop expansion of columns [v_lo, v_hi) of a SYMMETRIC adjacency (filter.py:96-109 + scoring).
     -> (colptr int64[n_cols+1], cand_u int32[E], cand_v int32[E] | None, cn int32[E] | None, score float32[E] | None);
     candidates are column-major, u ascending inside a column (the reference's order).  ``col_order`` (int32
@@ -194,6 +194,8 @@ def expand_candidates(rowptr, col, val, node_w, n_nodes: int, v_lo: int, v_hi: i
     UPPER-BOUND layout: no counting pass and no host synchronisation before the launch; column v's candidates fill
     the front of [colptr_ub[v], colptr_ub[v+1]) and the rest of the segment is padded (cand_u -1, score -inf, cn 0).
     The result then carries ``.counts`` (int64[n_cols], real candidates per column) and E == total_ub.
+
+    ``tile_ranks`` (0 = default): candidate ranks per LDS summation pass (eps_expand_fill_tiled); results do not depend on it.
 
     ``cut=(threshold, capacity)``: the kernel also reports the candidates whose score exceeds ``threshold`` (the
     streaming top-K's current K-th score) -- the result carries ``.survivors`` = (positions int64 ascending, scores) or
@@ -239,10 +241,11 @@ def expand_candidates(rowptr, col, val, node_w, n_nodes: int, v_lo: int, v_hi: i
                 raise _lib.EpsError(f"expand_candidates: a column with {max_paths} two-hop paths needs {ws_bytes >> 30} GiB "
                                     "of bucket scratch; score such graphs with the pair kernels")
             ws = _expand_scratch(dev, ws_bytes)
-            _lib.check(lib.eps_expand_fill(_ptr(rowptr), _ptr(col), _ptr(val), _ptr(node_w), n_nodes, v_lo, v_hi,
-                                           _ptr(col_order), _ptr(colptr), _ptr(counts) if colptr_ub is not None else None,
-                                           _ptr(cand_u), _ptr(cand_v), _ptr(cn), _ptr(score), _ptr(cut_rec), _ptr(ws),
-                                           ws_bytes, _stream(dev)), "eps_expand_fill")
+            _lib.check(lib.eps_expand_fill_tiled(_ptr(rowptr), _ptr(col), _ptr(val), _ptr(node_w), n_nodes, v_lo, v_hi,
+                                                 _ptr(col_order), _ptr(colptr),
+                                                 _ptr(counts) if colptr_ub is not None else None, _ptr(cand_u), _ptr(cand_v),
+                                                 _ptr(cn), _ptr(score), _ptr(cut_rec), _ptr(ws), ws_bytes, int(tile_ranks),
+                                                 _stream(dev)), "eps_expand_fill")
             if cut_rec is not None:                      # one read-back for the status word and the survivor count
                 both = torch.stack([ws[0], cut_rec[1]]).tolist()
                 status, n_cut = both[0] & 0xFFFFFFFF, both[1] & 0xFFFFFFFF

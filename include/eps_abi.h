@@ -139,6 +139,14 @@ int eps_expand_fill(const int64_t *rowptr, const int32_t *col, const float *val,
                     const int32_t *col_order, const int64_t *colptr, int64_t *cand_count,
                     int32_t *cand_u, int32_t *cand_v, int32_t *cn, float *score,
                     eps_score_cut *cut, void *workspace, int64_t workspace_bytes, void *stream);
+/* eps_expand_fill with an explicit tile size (candidate ranks summed per LDS pass; 0 = the default 8192): results do not
+ * depend on it -- small graphs are single-tile at the default, so the parity tests force several tiles per column. */
+int eps_expand_fill_tiled(const int64_t *rowptr, const int32_t *col, const float *val,
+                          const float *node_w, int64_t n_nodes, int64_t v_lo, int64_t v_hi,
+                          const int32_t *col_order, const int64_t *colptr, int64_t *cand_count,
+                          int32_t *cand_u, int32_t *cand_v, int32_t *cn, float *score,
+                          eps_score_cut *cut, void *workspace, int64_t workspace_bytes,
+                          int32_t tile_ranks, void *stream);
 int64_t eps_expand_workspace_bytes(int64_t max_col_paths);
 
 /* ---- K7+K1+K8: threshold scan of the whole candidate set (filter.py:96-142 + :160-161 under --keep_top) ------------

@@ -140,7 +140,7 @@ def test_expand_dense_graph_many_paths_per_candidate(eps, oracle, dev, weighted)
     assert n_cand > 300_000
 
 
-def test_expand_many_small_tiles(eps, oracle, dev, monkeypatch):
+def test_expand_many_small_tiles(eps, oracle, dev):
     """The score pass bins the paths of a column by candidate-rank tile (8192 ranks in production, so small graphs
     are single-tile).  Forced down to 256 / 512 ranks here: every column of the 700-node graph then spans several
     tiles, and the outputs must not change."""
@@ -150,12 +150,12 @@ def test_expand_many_small_tiles(eps, oracle, dev, monkeypatch):
     wt = node_weight_table(g, eps.ops.W_AA)
     full = eps.ops.expand_candidates(g.rowptr, g.col, g.val, wt, g.n_rows, 0, g.n_rows)
     assert int((full[0][1:] - full[0][:-1]).max()) > 512
-    for half in ("256", "512"):
-        monkeypatch.setenv("EPS_DEBUG_TILE_HALF", half)
-        got = eps.ops.expand_candidates(g.rowptr, g.col, g.val, wt, g.n_rows, 0, g.n_rows)
+    for tile in (512, 1024):
+        got = eps.ops.expand_candidates(g.rowptr, g.col, g.val, wt, g.n_rows, 0, g.n_rows, tile_ranks=tile)
         for i in range(5):
-            assert torch.equal(full[i], got[i]), (half, i)
-    monkeypatch.delenv("EPS_DEBUG_TILE_HALF")
+            assert torch.equal(full[i], got[i]), (tile, i)
+    with pytest.raises(eps.EpsError):
+        eps.ops.expand_candidates(g.rowptr, g.col, g.val, wt, g.n_rows, 0, g.n_rows, tile_ranks=100)
     _check(eps, oracle, dev, A, weighted=True)
 
 

@@ -1,6 +1,7 @@
-"""Two ranks on ONE GPU (gloo as the transport, EPS_DIST_ONE_DEVICE=1): the multi-rank control flow of the filter stage
--- column sharding by work, per-rank streaming top-K, rank-ordered merge, row-sharded last GNN layer + all-gather -- on
-the real kernels, against the single-process result."""
+"""Two ranks on ONE GPU (``--dist_backend gloo --device 0``: gloo as the transport, both ranks on cuda:0): the multi-rank
+control flow of the filter stage -- column sharding by work, the sharded threshold scan with its survivor all-gather
+(unit-valued graphs), per-rank streaming top-K + rank-ordered merge (weighted graphs), row-sharded last GNN layer +
+all-gather -- on the real kernels, against the single-process result; and bench.py's N > 1 paths as child processes."""
 import os
 import socket
 import sys
@@ -25,18 +26,23 @@ def _rank_main(rank, world, port, workdir, argv):
     sys.path.insert(0, ROOT)
     os.chdir(workdir)
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
-                      MASTER_PORT=str(port), EPS_DIST_ONE_DEVICE="1")
+                      MASTER_PORT=str(port))
     import eps_amd  # noqa: F401
     from eps_amd import candidates, filter_stage
     candidates.DEFAULT_BLOCK_PATHS = 30_000          # several blocks per rank: the in-kernel cut runs too
-    filter_stage.main(argv)
+    filter_stage.main(argv + ["--dist_backend", "gloo", "--device", "0"])
     torch.distributed.destroy_process_group()
 
 
-@pytest.mark.parametrize("model", ["adamic_ogb", "gcn"])
-def test_filter_two_ranks_one_gpu(eps, dev, tmp_path, model):
-    from eps_amd import datasets, filter_stage, models
+@pytest.mark.parametrize("model,dataset", [("adamic_ogb", "collab"), ("gcn", "collab"), ("adamic_ogb", "ddi"),
+                                           ("simple", "ddi"), ("resource_allocation", "ddi")])
+def test_filter_two_ranks_one_gpu(eps, dev, tmp_path, model, dataset, monkeypatch):
+    from eps_amd import datasets, filter_stage, models, scan
     os.chdir(tmp_path)
+    if dataset == "ddi":           # unit-valued graph: the threshold scan, sharded by columns; force the estimated-bar path
+        monkeypatch.setenv("EPS_SYNTH_SCALE", "0.5")
+        monkeypatch.setattr(scan, "SMALL_SET", 0)
+        return _scan_case(tmp_path, model)
     extra = []
     if model == "gcn":   # a seeded random-init checkpoint both runs load
         extra = ["--num_layers", "2", "--hidden_channels", "32", "--dropout", "0.0", "--batch_size", "4096",
@@ -59,3 +65,43 @@ def test_filter_two_ranks_one_gpu(eps, dev, tmp_path, model):
         assert torch.equal(single, multi)
     else:   # the row-sharded last layer sums in the same order: bit-identical embeddings, hence scores
         assert torch.equal(single, multi)
+
+
+def _scan_rank_main(rank, world, port, workdir, argv):
+    os.environ["EPS_SYNTH_SCALE"] = "0.5"
+    sys.path.insert(0, ROOT)
+    import eps_amd  # noqa: F401
+    from eps_amd import scan
+    scan.SMALL_SET = 0
+    _rank_main(rank, world, port, workdir, argv)
+
+
+def _scan_case(tmp_path, model):
+    from eps_amd import filter_stage
+    argv = lambda run: ["--dataset", "ddi", "--model", model, "--checkpoint", f"ddi_{model}||0|{run}.pt",  # noqa: E731
+                        "--synthetic", "--keep_top", "5000"]
+    single = torch.load(filter_stage.main(argv(0)))
+    mp.spawn(_scan_rank_main, args=(2, _free_port(), str(tmp_path), argv(1)), nprocs=2, join=True)
+    multi = torch.load(f"filtered_edges/ddi_{model}__0_1_sorted_edges.pt")
+    assert single.shape == (5000, 3) and torch.equal(single, multi)
+
+
+@pytest.mark.parametrize("scaling", ["weak", "strong"])
+def test_bench_two_ranks_child_process(dev, tmp_path, scaling):
+    """bench.py --gpus 2 as the driver launches it (python -m torch.distributed.run, fresh child processes), on one GPU
+    with gloo: both scaling modes print ONE JSON line with the contract's keys and a whole-job candidate count."""
+    import json
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--scaling", scaling, "--nodes", "30000", "--edges", "600000", "--keep_top", "20000", "--no-cpu", "--no-legs",
+           "--backend", "gloo", "--one-device"]
+    out = subprocess.run(cmd, cwd=tmp_path, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert key in line
+    assert line["n_gpus"] == 2 and line["scaling"] == scaling and line["value"] > 0
+    per_graph = line["config"]["candidates_per_step_all_ranks"] // (2 if scaling == "weak" else 1)
+    assert per_graph > 0 and 0 < line["roofline"]["frac"] <= 1
