@@ -19,7 +19,7 @@ SIGNATURES = {
     "eps_version": (_int, []),
     "eps_last_error": (_c.c_char_p, []),
     "eps_device_info": (_int, [_c.POINTER(_int), _c.c_char_p, _int]),
-    "eps_col_sums": (_int, [_vp, _vp, _vp, _i64, _i64, _vp, _vp]),
+    "eps_col_sums": (_int, [_vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp]),
     "eps_node_weights": (_int, [_vp, _i64, _int, _vp, _vp]),
     "eps_node_weights_f64": (_int, [_vp, _i64, _int, _vp, _vp]),
     "eps_pair_scores": (_int, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),

@@ -52,6 +52,33 @@ def hip_expand_available(g: CSRGraph) -> bool:
     return ops.expand_workspace_fits(max_paths_of(g))
 
 
+FUSED_SCORE_LIMIT = float(1 << 22)   # the 2^-40 fixed-point accumulators of the fused kernels hold |sums| < 2^23; keep half
+
+
+def fused_score_bound(g: CSRGraph, node_w: Optional[torch.Tensor]) -> float:
+    """Upper bound of every fused score sum_w A[u,w] * A[v,w] * node_w[w] of the graph:
+    max_v sum_w |A[v,w]| * |node_w[w]| * max_u |A[u,w]|  (one pass over the stored entries; cached).  Unit-valued graphs
+    stay far below the accumulators' range (AA <= 1.45 x degree); collab-like multi-edge weights of 10^3..10^4 do not."""
+    key = ("score_bound", None if node_w is None else (node_w.data_ptr(), node_w._version))
+    if key not in g._cache:
+        col = g.col.to(torch.int64)
+        term = torch.ones(g.nnz(), dtype=torch.float64, device=g.device) if node_w is None else node_w[col].abs().to(torch.float64)
+        if g.val is not None:
+            a = g.val.abs().to(torch.float64)
+            colmax = torch.zeros(g.n_cols, dtype=torch.float64, device=g.device)
+            colmax.scatter_reduce_(0, col, a, reduce="amax", include_self=True)
+            term = term * a * colmax[col]
+        rowsum = torch.zeros(g.n_rows, dtype=torch.float64, device=g.device)
+        rowsum.index_add_(0, g.row_index(), term)
+        g._cache[key] = float(rowsum.max().item()) if g.n_rows else 0.0
+    return g._cache[key]
+
+
+def fused_scores_fit(g: CSRGraph, node_w: Optional[torch.Tensor]) -> bool:
+    """Whether the fused kernels' fixed-point sums cannot overflow on this graph (else: score with the pair kernels)."""
+    return fused_score_bound(g, node_w) < FUSED_SCORE_LIMIT
+
+
 def path_counts(g: CSRGraph) -> torch.Tensor:
     """paths(v) = sum_{w in N(v)} deg(w): the 2-hop paths leaving column v = the cost of expanding it (cached)."""
     if "paths" not in g._cache:

@@ -425,6 +425,9 @@ __global__ __launch_bounds__(EX_THREADS) void expand_kernel(
             __syncthreads();
             for (uint32_t i = tid; i < nslots; i += EX_THREADS) {
                 if (want_sum) {
+                    // the heuristics' terms are non-negative: a negative sum is one that wrapped past 2^23 (backstop; the host
+                    // checks a bound of the graph's scores before it takes this path -- candidates.fused_scores_fit)
+                    if ((long long)acc[i] < 0 && overflow) atomicOr(overflow, 4u);
                     const float sc = (float)((double)(long long)acc[i] * (1.0 / (double)(1ll << EX_FIXED_SHIFT)));
                     if (out_score) out_score[base + r0 + i] = sc;
                     if (cut && sc > cut_thr) {      // top-K cut in the kernel: report the few candidates above the bar
@@ -499,7 +502,7 @@ extern "C" int eps_expand_count(const int64_t *rowptr, const int32_t *col, int64
 
 // Workspace of a fill launch: 8 bytes of status (device word 0, non-zero after the launch = outputs invalid: bit 0 a
 // column had more two-hop paths than the buckets were sized for, bit 1 a column had more candidates than its colptr
-// segment) + one bucket area per workgroup, 8 bytes per path of the heaviest column (none needed without cn / score).
+// segment, bit 2 a fixed-point sum left the accumulators' range) + one bucket area per workgroup, 8 bytes per path of the heaviest column (none needed without cn / score).
 extern "C" int64_t eps_expand_workspace_bytes(int64_t max_col_paths)
 {
     if (max_col_paths < 0) return 0;

@@ -269,21 +269,30 @@ extern "C" int eps_pair_scores_f64(const int64_t *rowptr, const int32_t *col, co
 }
 
 // ---------------------------------------------------------------- K2: node weight table
+// Column sums in FLOAT64 atomics: exact -- hence independent of the arrival order -- for integer-valued adjacencies
+// (every stored value of the reference's datasets is an integer: unit values, or collab's summed multi-edge counts)
+// up to 2^53; the float32 table is the float64 sum rounded once.  (Float32 atomics were exact only below 2^24.)
 __global__ void col_sums_kernel(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col,
-                                const float *__restrict__ val, int64_t n_rows, float *__restrict__ colsum)
+                                const float *__restrict__ val, int64_t n_rows, double *__restrict__ colsum)
 {
-    // one wave per row, lanes stride the row: coalesced col/val reads, float atomics on colsum
+    // one wave per row, lanes stride the row: coalesced col/val reads
     const int lane = threadIdx.x & 63;
     const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
     for (int64_t r = wave; r < n_rows; r += n_waves) {
         const int64_t b = rowptr[r], e = rowptr[r + 1];
-        for (int64_t k = b + lane; k < e; k += 64) atomicAdd(&colsum[col[k]], val ? val[k] : 1.0f);
+        for (int64_t k = b + lane; k < e; k += 64) atomicAdd(&colsum[col[k]], val ? (double)val[k] : 1.0);
     }
 }
 
-template <typename WT>
-__global__ void node_weights_kernel(const float *__restrict__ colsum, int64_t n, int mode, WT *__restrict__ w)
+__global__ void round_f32_kernel(const double *__restrict__ x, int64_t n, float *__restrict__ y)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] = (float)x[i];
+}
+
+template <typename ST, typename WT>
+__global__ void node_weights_kernel(const ST *__restrict__ colsum, int64_t n, int mode, WT *__restrict__ w)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -296,21 +305,25 @@ __global__ void node_weights_kernel(const float *__restrict__ colsum, int64_t n,
 }
 
 extern "C" int eps_col_sums(const int64_t *rowptr, const int32_t *col, const float *val, int64_t n_rows,
-                            int64_t n_cols, float *colsum, void *stream)
+                            int64_t n_cols, double *colsum_f64, float *colsum_f32, void *stream)
 {
     EPS_REQUIRE(n_rows >= 0 && n_cols >= 0, "eps_col_sums: negative size");
     if (n_cols == 0) return EPS_OK;
-    EPS_REQUIRE(colsum && (n_rows == 0 || (rowptr && col)), "eps_col_sums: null pointer");
+    EPS_REQUIRE(colsum_f64 && (n_rows == 0 || (rowptr && col)), "eps_col_sums: null pointer");
     hipStream_t s = (hipStream_t)stream;
-    if (hipMemsetAsync(colsum, 0, (size_t)n_cols * sizeof(float), s) != hipSuccess) {
+    if (hipMemsetAsync(colsum_f64, 0, (size_t)n_cols * sizeof(double), s) != hipSuccess) {
         eps_set_error("eps_col_sums: memset failed");
         return EPS_ELAUNCH;
     }
-    if (n_rows == 0) return EPS_OK;
-    int64_t blocks = (n_rows + 3) / 4;
-    const int64_t cap = (int64_t)eps_num_cus() * 16;
-    if (blocks > cap) blocks = cap;
-    hipLaunchKernelGGL(col_sums_kernel, dim3((unsigned)blocks), dim3(256), 0, s, rowptr, col, val, n_rows, colsum);
+    if (n_rows > 0) {
+        int64_t blocks = (n_rows + 3) / 4;
+        const int64_t cap = (int64_t)eps_num_cus() * 16;
+        if (blocks > cap) blocks = cap;
+        hipLaunchKernelGGL(col_sums_kernel, dim3((unsigned)blocks), dim3(256), 0, s, rowptr, col, val, n_rows, colsum_f64);
+    }
+    if (colsum_f32)
+        hipLaunchKernelGGL(round_f32_kernel, dim3((unsigned)((n_cols + 255) / 256)), dim3(256), 0, s, colsum_f64, n_cols,
+                           colsum_f32);
     EPS_CHECK_LAUNCH("eps_col_sums");
     return EPS_OK;
 }
@@ -320,18 +333,18 @@ extern "C" int eps_node_weights(const float *colsum, int64_t n, int mode, float 
     EPS_REQUIRE(n >= 0 && (mode == EPS_W_AA || mode == EPS_W_RA), "eps_node_weights: bad size or mode");
     if (n == 0) return EPS_OK;
     EPS_REQUIRE(colsum && w, "eps_node_weights: null pointer");
-    hipLaunchKernelGGL(node_weights_kernel<float>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+    hipLaunchKernelGGL((node_weights_kernel<float, float>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
                        (hipStream_t)stream, colsum, n, mode, w);
     EPS_CHECK_LAUNCH("eps_node_weights");
     return EPS_OK;
 }
 
-extern "C" int eps_node_weights_f64(const float *colsum, int64_t n, int mode, double *w, void *stream)
+extern "C" int eps_node_weights_f64(const double *colsum, int64_t n, int mode, double *w, void *stream)
 {
     EPS_REQUIRE(n >= 0 && (mode == EPS_W_AA || mode == EPS_W_RA), "eps_node_weights_f64: bad size or mode");
     if (n == 0) return EPS_OK;
     EPS_REQUIRE(colsum && w, "eps_node_weights_f64: null pointer");
-    hipLaunchKernelGGL(node_weights_kernel<double>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+    hipLaunchKernelGGL((node_weights_kernel<double, double>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
                        (hipStream_t)stream, colsum, n, mode, w);
     EPS_CHECK_LAUNCH("eps_node_weights_f64");
     return EPS_OK;

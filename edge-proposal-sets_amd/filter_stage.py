@@ -107,6 +107,10 @@ def scored_blocks(args, model, data, ra_graph, col_lo: int = 0, col_hi: int = No
     col_hi = g.n_rows if col_hi is None else col_hi
     blocks = [(max(lo, col_lo), min(hi, col_hi)) for lo, hi in candidates.column_blocks(g) if lo < col_hi and hi > col_lo]
     node_w = fused_node_weights(args, g, ra_graph) if candidates.hip_expand_available(g) else None
+    if node_w is not None and not candidates.fused_scores_fit(g, node_w):
+        # weights so large that a score could leave the fused kernels' fixed-point range: float32 / float64 pair kernels
+        print(f'fused scoring disabled: score bound {candidates.fused_score_bound(g, node_w):.3e} >= 2^22')
+        node_w = None
     if node_w is None:
         for v_lo, v_hi in blocks:
             pairs = candidates.expand_block(g, v_lo, v_hi)[0]

@@ -84,7 +84,7 @@ def node_weight_table(g: CSRGraph, mode: int, f64: bool = False) -> torch.Tensor
     """K2: mult[w] = 1/log(colsum[w]) (AA) or 1/colsum[w] (RA), inf -> 0; cached on the graph."""
     key = ("node_w", mode, f64)
     if key not in g._cache:
-        colsum = ops.col_sums(g.rowptr, g.col, g.val, g.n_cols)
+        colsum = ops.col_sums(g.rowptr, g.col, g.val, g.n_cols, f64=f64)
         g._cache[key] = ops.node_weights(colsum, mode, f64=f64)
     return g._cache[key]
 

@@ -58,19 +58,22 @@ def device_info() -> Tuple[int, str]:
     return n.value, buf.value.decode()
 
 
-def col_sums(rowptr, col, val, n_cols: int) -> torch.Tensor:
+def col_sums(rowptr, col, val, n_cols: int, f64: bool = False) -> torch.Tensor:
+    """Column sums, accumulated in float64 on the device; returned as float32 (rounded once) or, ``f64=True``, as is."""
     dev = _need_gpu(rowptr, col, val)
     _chk(rowptr, torch.int64, "rowptr"); _chk(col, torch.int32, "col"); _chk(val, torch.float32, "val")
-    out = torch.empty(n_cols, dtype=torch.float32, device=dev)
+    wide = torch.empty(n_cols, dtype=torch.float64, device=dev)
+    out = None if f64 else torch.empty(n_cols, dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
         _lib.check(_lib.load().eps_col_sums(_ptr(rowptr), _ptr(col), _ptr(val), rowptr.numel() - 1, n_cols,
-                                            _ptr(out), _stream(dev)), "eps_col_sums")
-    return out
+                                            _ptr(wide), _ptr(out), _stream(dev)), "eps_col_sums")
+    return wide if f64 else out
 
 
 def node_weights(colsum: torch.Tensor, mode: int, f64: bool = False) -> torch.Tensor:
+    """1/log(colsum) (AA) or 1/colsum (RA), inf -> 0: float32 from float32 sums, or float64 from float64 sums."""
     dev = _need_gpu(colsum)
-    _chk(colsum, torch.float32, "colsum")
+    _chk(colsum, torch.float64 if f64 else torch.float32, "colsum")
     out = torch.empty(colsum.numel(), dtype=torch.float64 if f64 else torch.float32, device=dev)
     fn = _lib.load().eps_node_weights_f64 if f64 else _lib.load().eps_node_weights
     with torch.cuda.device(dev):
@@ -253,7 +256,8 @@ def expand_candidates(rowptr, col, val, node_w, n_nodes: int, v_lo: int, v_hi: i
                 status, n_cut = int(ws[0].item()) & 0xFFFFFFFF, 0
             if status:
                 raise _lib.EpsError("expand_candidates: " + ("a column had more two-hop paths than max_paths allows; " if status & 1 else "")
-                                    + ("a column had more candidates than its colptr_ub segment" if status & 2 else ""))
+                                    + ("a column had more candidates than its colptr_ub segment; " if status & 2 else "")
+                                    + ("a score left the fixed-point range (|sum| >= 2**23): use the pair kernels" if status & 4 else ""))
     out = ExpandResult((colptr, cand_u, cand_v, cn, score))
     out.pairs = pairs if want_v else None
     out.counts = counts if colptr_ub is not None else None

@@ -48,14 +48,16 @@ int eps_device_info(int *n_cu, char *name, int name_len);
 /* ---- K2: per-node weight table ------------------------------------------------------
  * Replaces `A.sum(0)`, `1/np.log(.)`, inf->0 (adamic_utils.py:15-16) and `1/A.sum(axis=0)`,
  * inf->0 (train_and_eval.py:203-204).
- * eps_col_sums: colsum[c] = sum_r A[r,c]  (float32 atomics; exact for integer-valued A).
- *               colsum must be zero-filled by the caller is NOT required: it is cleared here.
- * eps_node_weights: w[i] = mode==AA ? 1/logf(colsum[i]) : 1/colsum[i]; +-inf -> 0.
- * The _f64 flavour serves filter.py:130-141, where A is int64 and the math is float64. */
+ * eps_col_sums: colsum[c] = sum_r A[r,c], accumulated in FLOAT64 (exact, hence order-independent, for integer-valued
+ *               A up to 2^53): colsum_f64 (n_cols doubles, cleared here) receives the sums, colsum_f32 (optional) the
+ *               same sums rounded once to float32 -- what SciPy's float32 `A.sum(0)` holds for such A.
+ * eps_node_weights: w[i] = mode==AA ? 1/logf(colsum[i]) : 1/colsum[i]; +-inf -> 0   (float32 sums, float32 math).
+ * eps_node_weights_f64: the same in float64 from the float64 sums: filter.py:130-141, where A is int64 and the
+ *               reference's math is float64. */
 int eps_col_sums(const int64_t *rowptr, const int32_t *col, const float *val, int64_t n_rows,
-                 int64_t n_cols, float *colsum, void *stream);
+                 int64_t n_cols, double *colsum_f64, float *colsum_f32, void *stream);
 int eps_node_weights(const float *colsum, int64_t n, int mode, float *w, void *stream);
-int eps_node_weights_f64(const float *colsum, int64_t n, int mode, double *w, void *stream);
+int eps_node_weights_f64(const double *colsum, int64_t n, int mode, double *w, void *stream);
 
 /* ---- K1/K3: pair scores by CSR neighbour-list intersection ------------------------------
  * Replaces `np.sum(A[src].multiply(A_[dst]), 1)` (adamic_utils.py:22, train_and_eval.py:212)
@@ -116,7 +118,8 @@ int eps_pair_scores_grouped_f64(const int64_t *rowptr, const int32_t *col, const
  *                     receives the real count per column and the rest of each segment is padded
  *                     with cand_u = -1, score = -inf, cn = 0, so the arrays stay in candidate
  *                     order.  After the launch the first 4 bytes of the workspace are 0, or
- *                     non-zero if P (bit 0) or a colptr segment (bit 1) was too small: outputs
+ *                     non-zero if P (bit 0) or a colptr segment (bit 1) was too small, or a sum
+ *                     left the accumulators' range |sum| < 2^23 (bit 2; terms are assumed non-negative): outputs
  *                     invalid. */
 /* Optional top-K cut of eps_expand_fill, a DEVICE-resident record: every candidate whose score exceeds `threshold`
  * is reported as (pos, val) -- pos = its index in the launch's candidate arrays -- in arrival order (sort by pos to
