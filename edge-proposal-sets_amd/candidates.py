@@ -6,8 +6,8 @@ This is SURVEY 8(f) row 1 (the step immediately before the hot path).  Column bl
 so the full candidate set never has to exist at once (the reference materialises A @ A on the host:
 the memory wall on ppa).  On the GPU a block is produced by the fused expansion kernels
 (csrc/expand_score.hip: candidates + common-neighbour counts + weighted scores in one pass over the
-2-hop paths); graphs whose id space does not fit the LDS bitmap, and CPU tensors (tests), take the
-tensor-op expansion ``two_hop_block``.
+2-hop paths; id spaces wider than the LDS bitmap in id windows); only CPU tensors (host-logic tests)
+take the tensor-op expansion ``two_hop_block``.
 """
 from __future__ import annotations
 
@@ -41,14 +41,17 @@ def two_hop_block(g: CSRGraph, v_lo: int, v_hi: int) -> torch.Tensor:
     return torch.stack([uu[keep], vv[keep]])
 
 
-def hip_expand_available(g: CSRGraph) -> bool:
-    """The fused expansion kernels can take this graph: on the GPU, square, ids within the LDS bitmap, and no column so
-    heavy (a hub whose neighbours are hubs) that the per-workgroup path buckets would outgrow the scratch budget."""
-    if g.device.type != "cuda":
+def hip_expand_available(g: CSRGraph, scored: bool = True) -> bool:
+    """The fused expansion kernels can take this graph: on the GPU and square (any number of ids: id spaces wider than
+    the LDS bitmap are expanded in id windows).  ``scored`` (common-neighbour counts / weighted sums out of the same
+    expansion) additionally needs the per-workgroup path buckets of the heaviest column to fit the scratch budget --
+    a hub whose neighbours are hubs (RMAT-24) does not: such graphs get their candidates from the expansion and their
+    scores from the pair kernels."""
+    if g.device.type != "cuda" or g.n_rows != g.n_cols or g.n_rows >= 1 << 31:
         return False
+    if not scored:
+        return True
     from . import ops
-    if not (g.n_rows == g.n_cols and g.n_rows <= ops.expand_max_nodes()):
-        return False
     return ops.expand_workspace_fits(max_paths_of(g))
 
 
@@ -174,19 +177,25 @@ def expand_block(g: CSRGraph, v_lo: int, v_hi: int, node_w: Optional[torch.Tenso
     -> (pairs int64 [2,E] column-major, cn int32[E] | None, score float32[E] | None).  ``long_pairs=False`` leaves the
     pairs in the int32 buffer the kernel wrote (no 8-byte copy of a list that may hold 10^8 candidates)."""
     from . import ops
-    if hip_expand_available(g):
+    fused = hip_expand_available(g) and (node_w is None or not want_score or fused_scores_fit(g, node_w))
+    if fused:
         r = ops.expand_candidates(g.rowptr, g.col, g.val, node_w, g.n_rows, v_lo, v_hi, want_cn=want_cn,
                                   want_score=want_score, col_order=heaviest_first(g, v_lo, v_hi),
                                   max_paths=max_paths_of(g))
         return (r.pairs.long() if long_pairs else r.pairs), r[3], r[4]
-    pairs = two_hop_block(g, v_lo, v_hi)
+    if hip_expand_available(g, scored=False):      # candidates from the expansion kernels, scores from the pair kernels
+        r = ops.expand_candidates(g.rowptr, g.col, None, None, g.n_rows, v_lo, v_hi, want_cn=False, want_score=False,
+                                  col_order=heaviest_first(g, v_lo, v_hi), max_paths=0)
+        pairs = r.pairs
+    else:                                          # CPU tensors (host-logic tests)
+        pairs = two_hop_block(g, v_lo, v_hi)
     cn = sc = None
     if (want_cn or want_score) and pairs.shape[1]:
         u, v = pairs[0].to(torch.int32).contiguous(), pairs[1].to(torch.int32).contiguous()
         cnt, _, ws = ops.pair_scores(g.rowptr, g.col, g.val, node_w if want_score else None, g.n_rows, u, v,
                                      want_count=want_cn, want_cn=False, grouped=True)
         cn, sc = cnt, ws
-    return pairs, cn, sc
+    return (pairs.long() if long_pairs else pairs), cn, sc
 
 
 DEFAULT_BLOCK_PATHS = 1 << 29     # two-hop paths per launch: ~4e8 candidates, ~13 GB of outputs + scratch on a 288 GB device
@@ -209,9 +218,8 @@ def column_blocks(g: CSRGraph, max_paths: int = None) -> Iterator[Tuple[int, int
 
 def iter_candidate_blocks(g: CSRGraph, max_paths: int = None) -> Iterator[Tuple[int, int, torch.Tensor]]:
     """Yield (v_lo, v_hi, pairs[2,E_blk]) over all columns."""
-    fused = hip_expand_available(g)
     for lo, hi in column_blocks(g, max_paths):
-        yield lo, hi, (expand_block(g, lo, hi)[0] if fused else two_hop_block(g, lo, hi))
+        yield lo, hi, expand_block(g, lo, hi)[0]
 
 
 def all_candidates(g: CSRGraph, max_paths: int = None) -> torch.Tensor:

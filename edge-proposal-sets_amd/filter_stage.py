@@ -113,7 +113,7 @@ def scored_blocks(args, model, data, ra_graph, col_lo: int = 0, col_hi: int = No
         node_w = None
     if node_w is None:
         for v_lo, v_hi in blocks:
-            pairs = candidates.expand_block(g, v_lo, v_hi)[0]
+            pairs = candidates.expand_block(g, v_lo, v_hi)[0]      # HIP expansion (list only); scores from score_block
             yield v_lo, v_hi, pairs, (score_block(args, model, data, pairs, ra_graph) if pairs.shape[1] else None)
         return
     print(f'fused candidate generation + scoring ({args.model})')

@@ -96,8 +96,9 @@ int eps_pair_scores_grouped_f64(const int64_t *rowptr, const int32_t *col, const
  * column-major order) together with the heuristic scoring that follows it (adamic_utils.py:13-25,
  * train_and_eval.py:195-216, models.py:536-542): one expansion of the 2-hop paths of a column
  * yields every candidate of the column with its common-neighbour count and
- * sum_w A[u,w]*(A[v,w]*node_w[w]).  The adjacency must be symmetric (rank.py:33) and have at
- * most eps_expand_max_nodes() nodes (LDS bitmap).
+ * sum_w A[u,w]*(A[v,w]*node_w[w]).  The adjacency must be symmetric (rank.py:33).  Id spaces of
+ * up to eps_expand_max_nodes() ids fit the LDS bitmap at once; wider ones are expanded in id windows
+ * of that size (each window walks only the row segments inside it), same outputs, same order.
  *   col_order (both calls; may be NULL): a permutation of [0, v_hi - v_lo) -- the order in which the
  *                     columns v_lo + col_order[i] are handed to the workgroups.  Results do not
  *                     depend on it; heaviest-first shortens the tail of a launch.

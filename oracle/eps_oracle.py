@@ -233,6 +233,23 @@ def candidates_scipy(A):
     return np.stack([coo.row[order], coo.col[order]], 1).astype(np.int64), coo.data[order]
 
 
+def candidates_scipy_columns(A, lo: int, hi: int):
+    """``candidates_scipy`` restricted to the columns [lo, hi): the same steps of filter.py:96-109 on the column slice
+    (A @ A)[:, lo:hi] -- for graphs whose full A @ A does not fit the test box.  -> (pairs [E,2] int64 column-major, values)."""
+    Ac = A.tocsc()
+    A2 = (A.tocsr() @ Ac[:, lo:hi]).tocoo()
+    keep = A2.row != (A2.col + lo)                               # A2.setdiag(0)
+    r, c, v = A2.row[keep], A2.col[keep], A2.data[keep]
+    known = (Ac[:, lo:hi] > 0).tocoo()                           # A2[known] = 0
+    n = A.shape[0]
+    kk = np.unique(known.col.astype(np.int64) * n + known.row.astype(np.int64))
+    key = c.astype(np.int64) * n + r.astype(np.int64)
+    m = ~np.isin(key, kk) & (v != 0)                             # eliminate_zeros
+    r, c, v = r[m], c[m], v[m]
+    order = np.lexsort((r, c))
+    return np.stack([r[order], c[order] + lo], 1).astype(np.int64), v[order]
+
+
 # ------------------------------------------------ GNN forward restatements
 def gcn_dense_forward(A_dense: np.ndarray, x: np.ndarray, weights, biases) -> np.ndarray:
     """Independent dense-formula check for tiny graphs (float64):

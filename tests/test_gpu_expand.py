@@ -270,7 +270,7 @@ def test_expand_score_cut(eps, dev):
     assert none.survivors[0].numel() == 0
 
 
-@pytest.mark.parametrize("n", [255, 257, 131072, 131073, 262145, 851968])
+@pytest.mark.parametrize("n", [255, 257, 131072, 131073, 262145, 851968, 851969, 1_100_000, 1_703_937])
 def test_expand_id_range_boundaries(eps, dev, n):
     """Node counts around the id-range table's limits (512 ranges of 2^k ids: k changes at 131,073 and 262,145 nodes; a
     single range below 257; 851,968 = eps_expand_max_nodes(), the largest LDS footprint): fused expansion of some columns == tensor-op candidates + column-run intersection kernel."""
@@ -286,3 +286,32 @@ def test_expand_id_range_boundaries(eps, dev, n):
     if cu.numel():
         cnt, _, ws = eps.ops.pair_scores(g.rowptr, g.col, None, wt, n, cu, cv, want_cn=False, grouped=True)
         assert torch.equal(cnt, cn) and rel_err(sc.cpu().numpy(), ws.cpu().numpy()) <= 1e-5
+
+
+def test_expand_wide_id_space_vs_oracle(eps, oracle, dev):
+    """filter.py:96-109 on an id space wider than the LDS bitmap (N = 2^21 + 77: three id windows): candidates of column
+    blocks at the start, across a window boundary and at the end == the restated A @ A slice, in the reference's order;
+    common-neighbour counts == the A @ A values; scores within the gate; upper-bound (count-free) layout included."""
+    from eps_amd import candidates, synth
+    from eps_amd.heuristics import node_weight_table
+    n = (1 << 21) + 77
+    g = synth.rmat_graph(21, 2, 31, "cpu", n_nodes=n)
+    A = g.to_scipy()
+    g = g.to(dev)
+    wt = node_weight_table(g, eps.ops.W_AA)
+    rp, col = A.indptr.astype(np.int64), A.indices.astype(np.int32)
+    w = oracle.node_weights(oracle.col_sums(rp, col, None, n), oracle.W_AA)
+    win = eps.ops.expand_max_nodes()
+    deg = np.diff(rp)
+    hub = int(np.argmax(deg))
+    for lo, hi in ((0, 300), (win - 150, win + 150), (n - 300, n), (hub, hub + 1)):
+        want, a2 = oracle.candidates_scipy_columns(A, lo, hi)
+        colptr, cu, cv, cn, sc = eps.ops.expand_candidates(g.rowptr, g.col, None, wt, n, lo, hi)
+        assert np.array_equal(torch.stack([cu, cv], 1).cpu().numpy(), want), (lo, hi)
+        assert np.array_equal(cn.cpu().numpy(), a2.astype(np.int32))
+        _, truth = oracle.pair_scores_f64(rp, col, None, w.astype(np.float64), want[:, 0], want[:, 1])
+        assert rel_err(sc.cpu().numpy(), truth.astype(np.float32)) <= 1e-6
+        blk = candidates.expand_block_lazy(g, lo, hi, wt, want_score=True, count_free=True)
+        idx = blk.valid()
+        assert np.array_equal(blk.select(idx).t().cpu().numpy(), want) and torch.equal(blk.score[idx], sc)
+    assert want.shape[0] > 10000 and int((want[:, 0] >= 2 * win).sum()) > 0 and int((want[:, 0] < win).sum()) > 0

@@ -171,3 +171,50 @@ def test_full_size_properties(eps, dev):
     g2 = g.fill_value(2.0)
     _, cn2, _ = eps.ops.pair_scores(g2.rowptr, g2.col, g2.val, None, n, u[:200000], v[:200000])
     assert torch.equal(cn2, 4.0 * c1[:200000].to(torch.float32))
+
+
+def test_rmat24_share_vs_oracle(eps, oracle, dev):
+    """BASELINE configs[4] on one GPU's share: R-MAT scale 24 (16.7 M nodes, ~520 M stored entries, hub degree ~4e5),
+    CN + AA over 2^24 pairs -- half uniform, half 2-hop samples -- through the generic kernel and, sorted by v, through the
+    column-run kernel (hashed bitmap: N > 2^20); a 20,000-pair sample is checked against the CPU ORACLE (counts exact,
+    AA within the gate), all pairs against each other."""
+    from eps_amd import synth
+    from eps_amd.heuristics import node_weight_table
+    g = synth.rmat_graph(scale=24, edge_factor=16, seed=5, device=dev)
+    assert g.n_rows == 1 << 24 and g.nnz() > 400_000_000
+    w = node_weight_table(g, eps.ops.W_AA)
+    gen = torch.Generator(device=dev).manual_seed(1)
+    half = 1 << 23
+    u1 = torch.randint(0, g.n_rows, (half,), generator=gen, device=dev, dtype=torch.int32)
+    v1 = torch.randint(0, g.n_rows, (half,), generator=gen, device=dev, dtype=torch.int32)
+    e = torch.randint(0, g.nnz(), (half,), generator=gen, device=dev)      # 2-hop: a stored entry (w,u), a neighbour v of w
+    deg = g.degree()
+    wnode = torch.searchsorted(g.rowptr, e, right=True) - 1
+    u2 = g.col[e]
+    off = torch.minimum((torch.rand(half, generator=gen, device=dev) * deg[wnode]).long(), deg[wnode] - 1)
+    v2 = g.col[g.rowptr[wnode] + off]
+    u, v = torch.cat([u1, u2]).contiguous(), torch.cat([v1, v2]).contiguous()
+    cnt, _, ws = eps.ops.pair_scores(g.rowptr, g.col, None, w, g.n_rows, u, v, want_cn=False, grouped=False)
+    assert float(cnt.float().mean()) > 0.5
+    order = torch.argsort(v.long() * g.n_rows + u.long())
+    cg, _, wg = eps.ops.pair_scores(g.rowptr, g.col, None, w, g.n_rows, u[order].contiguous(), v[order].contiguous(),
+                                    want_cn=False, grouped=True)
+    assert torch.equal(cg, cnt[order]) and rel_err(wg.cpu().numpy(), ws[order].cpu().numpy()) <= 1e-5
+    # the oracle on a sample (heaviest pairs included: the top of the degree-sum order + random ones)
+    heavy = torch.argsort(deg[u.long()] + deg[v.long()], descending=True)[:2000]
+    sel = torch.cat([heavy, torch.randint(0, u.numel(), (18000,), generator=gen, device=dev)])
+    rp, col = g.rowptr.cpu().numpy(), g.col.cpu().numpy()
+    wo = oracle.node_weights(oracle.col_sums(rp, col, None, g.n_rows), oracle.W_AA)
+    assert rel_err(w.cpu().numpy(), wo) <= 1e-6
+    us, vs = u[sel].cpu().numpy(), v[sel].cpu().numpy()
+    co, _, ao = oracle.pair_scores(rp, col, None, wo, us, vs)
+    assert np.array_equal(cnt[sel].cpu().numpy(), co), "common-neighbour counts bit-exact vs the oracle"
+    got = ws[sel].cpu().numpy()
+    light = co <= 1000
+    assert light.sum() > 15000 and rel_err(got[light], ao[light]) <= 1e-5
+    # hub x hub pairs sum up to ~4e5 float32 terms: there the float32 oracle itself is ~1e-4 off the float64 sum (any
+    # summation order is); both are held to the float32 accumulation bound n * 2^-24 around the float64-accumulated value
+    _, truth = oracle.pair_scores_f64(rp, col, None, wo.astype(np.float64), us, vs)
+    bound = np.maximum(1e-5, co * 2.0 ** -24) * np.abs(truth) + 1e-30
+    assert np.all(np.abs(got - truth) <= bound) and np.all(np.abs(ao - truth) <= bound)
+    assert co.max() > 100_000

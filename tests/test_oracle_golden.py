@@ -150,6 +150,19 @@ def test_candidates_order_and_cn(oracle):
     assert cnt.min() >= 1
 
 
+def test_candidates_column_slice_equals_full(oracle):
+    """The column-block form used for graphs too wide for a full A @ A agrees with the full restatement."""
+    rng = np.random.default_rng(4)
+    n = 300
+    M = np.triu(rng.random((n, n)) < 0.03, 1)
+    A = ssp.csr_matrix((M | M.T).astype(np.float32))
+    full, vals = oracle.candidates_scipy(A)
+    for lo, hi in ((0, n), (0, 1), (17, 140), (250, 300)):
+        p, v = oracle.candidates_scipy_columns(A, lo, hi)
+        m = (full[:, 1] >= lo) & (full[:, 1] < hi)
+        assert np.array_equal(p, full[m]) and np.array_equal(v, vals[m])
+
+
 def test_model_configs_fixture_shape():
     with open(os.path.join(GOLDEN, "model_configs.json")) as f:
         table = json.load(f)
