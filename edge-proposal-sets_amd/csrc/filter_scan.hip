@@ -31,7 +31,7 @@
 #define FS_UR 2048           // 64-entry units per round (two list entries per thread)
 #define FS_UPAD 384          // list entries past the last unit a prefetching wave may touch: they name the empty row
 #define FS_RANGES 512        // id ranges per column: path histogram and tile plan
-#define FS_AHEAD 4           // bucket records per thread requested one tile ahead (8 measured 6 % slower)
+#define FS_AHEAD 4           // bucket records per thread requested one tile ahead (8, always or only for long buckets: no faster)
 #define FS_CHUNK 8192        // survivor slots reserved per global atomic
 #define FS_MAX_TILE_BITS 12  // candidate ranks per tile <= 4096 (8-byte accumulators in LDS)
 
@@ -83,7 +83,9 @@ struct fs_params {
     uint32_t cap_records;     // bucket records per workgroup
     unsigned int *next_col;
     eps_survivors *out;
-    uint32_t *scratch;        // cap_records words per workgroup
+    uint32_t *scratch;        // cap_records (+ 64 trash) words per workgroup
+    long long *gfix;          // max_degree weights per workgroup: the vwfix table of columns wider than one round
+    int32_t max_degree;
 };
 
 // Wave-wide inclusive scans on the DPP path (row shifts inside the 16-lane rows, then the two row broadcasts): six
@@ -173,6 +175,7 @@ __global__ __launch_bounds__(FS_THREADS) void filter_scan_kernel(fs_params p)
     int64_t *__restrict__ out_key = p.out->key;
     float *__restrict__ out_val = p.out->val;
     uint32_t *__restrict__ my_scratch = p.scratch + (size_t)blockIdx.x * ((size_t)p.cap_records + 64);   // + a trash line
+    long long *__restrict__ my_gfix = p.gfix + (size_t)blockIdx.x * (size_t)p.max_degree;
     const __amdgpu_buffer_rsrc_t col_rs = __builtin_amdgcn_make_buffer_rsrc((void *)p.col, 0, p.col_bytes, 0x00020000);
 
     for (int i = tid; i < words; i += FS_THREADS) bm[i] = 0u;
@@ -232,6 +235,8 @@ __global__ __launch_bounds__(FS_THREADS) void filter_scan_kernel(fs_params p)
             }
             incl += woff;
             const int excl = incl - nun;
+            // a column that takes more than one round keeps its weights in a global table (the LDS one holds one round)
+            if (row_ok && (j0 > 0 || c0 > 0 || total > FS_UR || dv > FS_RC)) my_gfix[j0 + tid] = fx;
             if (tid < FS_RC) {
                 ustart[tid] = excl - (tid == 0 ? c0 : 0);
                 rbase[tid] = rb;
@@ -574,7 +579,7 @@ __global__ __launch_bounds__(FS_THREADS) void filter_scan_kernel(fs_params p)
                 auto add = [&](uint32_t r, bool live) {
                     if (!live) return;                       // (mostly whole waves: the tail of a bucket)
                     const uint32_t k = r >> p.tile_bits;
-                    const long long fx = single ? vwfix[k] : p.fixw[vcol[k]];
+                    const long long fx = single ? vwfix[k] : my_gfix[k];
                     atomicAdd(&acc[r & tile_mask], (unsigned long long)fx);
                 };
                 __syncthreads();                   // records visible (global stores drained), cursors final
@@ -698,14 +703,17 @@ extern "C" int64_t eps_filter_scan_max_nodes(void)
 
 #define FS_DEFAULT_RECORDS (1u << 20)         // bucket records per workgroup: 4 MiB each, 1 GiB on 256 CUs
 
-extern "C" int64_t eps_filter_scan_workspace_bytes(void)
+// bucket records (4 MiB + a trash line per workgroup) followed by the per-workgroup weight tables of multi-round columns
+extern "C" int64_t eps_filter_scan_workspace_bytes(int64_t max_degree)
 {
-    return (int64_t)eps_num_cus() * FS_DEFAULT_RECORDS * 4;
+    if (max_degree < 0) return 0;
+    return (int64_t)eps_num_cus() * (((int64_t)FS_DEFAULT_RECORDS + 64) * 4 + max_degree * 8);
 }
 
 extern "C" int eps_filter_scan(const int64_t *rowptr, const int32_t *col, const int32_t *revpos, const int64_t *fixw,
-                               int64_t n_nodes, int64_t nnz, const int32_t *columns, int64_t n_columns,
-                               eps_survivors *out, void *workspace, int64_t workspace_bytes, void *stream)
+                               int64_t n_nodes, int64_t nnz, int64_t max_degree, const int32_t *columns,
+                               int64_t n_columns, eps_survivors *out, void *workspace, int64_t workspace_bytes,
+                               void *stream)
 {
     EPS_REQUIRE(n_nodes >= 0 && n_columns >= 0 && nnz >= 0, "eps_filter_scan: negative size");
     if (n_columns == 0 || n_nodes == 0) return EPS_OK;
@@ -719,10 +727,11 @@ extern "C" int eps_filter_scan(const int64_t *rowptr, const int32_t *col, const 
                 (long long)eps_filter_scan_max_nodes());
     int64_t blocks = eps_num_cus();
     if (blocks > n_columns) blocks = n_columns;
-    EPS_REQUIRE(workspace && ((uintptr_t)workspace & 15) == 0 && workspace_bytes >= blocks * 4096,
-                "eps_filter_scan: needs a 16-byte aligned workspace (eps_filter_scan_workspace_bytes)");
-    int64_t cap = workspace_bytes / 4 / blocks - 64;
-    if (cap > 0xFFFFFFF0ll) cap = 0xFFFFFFF0ll;
+    EPS_REQUIRE(max_degree >= 0 && max_degree <= n_nodes, "eps_filter_scan: bad max_degree");
+    const int64_t n_wg = eps_num_cus();
+    EPS_REQUIRE(workspace && ((uintptr_t)workspace & 15) == 0 && workspace_bytes >= eps_filter_scan_workspace_bytes(max_degree),
+                "eps_filter_scan: needs a 16-byte aligned workspace of eps_filter_scan_workspace_bytes(max_degree) bytes");
+    const int64_t cap = FS_DEFAULT_RECORDS;
     hipStream_t s = (hipStream_t)stream;
     unsigned int *counter = nullptr;
     int rc = eps_take_counter(&counter, s, "eps_filter_scan");
@@ -743,6 +752,8 @@ extern "C" int eps_filter_scan(const int64_t *rowptr, const int32_t *col, const 
     p.next_col = counter;
     p.out = out;
     p.scratch = (uint32_t *)workspace;
+    p.gfix = (long long *)((char *)workspace + n_wg * ((int64_t)FS_DEFAULT_RECORDS + 64) * 4);
+    p.max_degree = (int32_t)max_degree;
     const size_t lds = (size_t)fs_make_layout(p.words, tile_bits).total_words * 4;
     if (hipFuncSetAttribute((const void *)filter_scan_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
         hipSuccess) {

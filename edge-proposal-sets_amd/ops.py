@@ -299,11 +299,14 @@ _SCAN_WS = {}
 KERNEL_EVENTS = None      # a list while bench.py times kernels: (kernel name, start event, end event, work size) per launch
 
 
-def _scan_scratch(dev) -> torch.Tensor:
-    """Bucket scratch of eps_filter_scan (1 GiB on 256 CUs): one buffer per device, stream-ordered."""
+def _scan_scratch(dev, max_degree: int) -> torch.Tensor:
+    """Scratch of eps_filter_scan (1 GiB of bucket records on 256 CUs + max_degree weights per workgroup): one grow-only
+    buffer per device, stream-ordered."""
     key = (dev.type, dev.index)
-    if key not in _SCAN_WS:
-        _SCAN_WS[key] = torch.empty(int(_lib.load().eps_filter_scan_workspace_bytes()) // 8, dtype=torch.int64, device=dev)
+    need = (int(_lib.load().eps_filter_scan_workspace_bytes(int(max_degree))) + 7) // 8
+    if key not in _SCAN_WS or _SCAN_WS[key].numel() < need:
+        _SCAN_WS.pop(key, None)
+        _SCAN_WS[key] = torch.empty(need, dtype=torch.int64, device=dev)
     return _SCAN_WS[key]
 
 
@@ -337,22 +340,23 @@ class Survivors:
         return k[m], self.val[:n][m]
 
 
-def filter_scan(rowptr, col, revpos, fixw, n_nodes: int, columns: torch.Tensor, out: Survivors) -> None:
-    """Launch eps_filter_scan over ``columns`` (int32 ids, hand-out order); survivors accumulate in ``out``."""
+def filter_scan(rowptr, col, revpos, fixw, n_nodes: int, columns: torch.Tensor, out: Survivors, max_degree: int) -> None:
+    """Launch eps_filter_scan over ``columns`` (int32 ids, hand-out order); survivors accumulate in ``out``.
+    ``max_degree``: the longest row of the graph (sizes a scratch table)."""
     dev = _need_gpu(rowptr, col, revpos, fixw, columns)
     _chk(rowptr, torch.int64, "rowptr"); _chk(col, torch.int32, "col"); _chk(revpos, torch.int32, "revpos")
     _chk(fixw, torch.int64, "fixw"); _chk(columns, torch.int32, "columns")
     if revpos.numel() != col.numel() or fixw.numel() != n_nodes:
         raise _lib.EpsError("filter_scan: revpos / fixw do not match the graph")
-    ws = _scan_scratch(dev)
+    ws = _scan_scratch(dev, max_degree)
     with torch.cuda.device(dev):
         ev = None
         if KERNEL_EVENTS is not None:              # bench.py: HIP events around the launch, on the stream it runs on
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev[0].record(torch.cuda.current_stream(dev))
         _lib.check(_lib.load().eps_filter_scan(_ptr(rowptr), _ptr(col), _ptr(revpos), _ptr(fixw), n_nodes, col.numel(),
-                                               _ptr(columns), columns.numel(), _ptr(out.rec), _ptr(ws), ws.numel() * 8,
-                                               _stream(dev)), "eps_filter_scan")
+                                               int(max_degree), _ptr(columns), columns.numel(), _ptr(out.rec), _ptr(ws),
+                                               ws.numel() * 8, _stream(dev)), "eps_filter_scan")
         if ev is not None:
             ev[1].record(torch.cuda.current_stream(dev))
             KERNEL_EVENTS.append(("filter_scan_kernel", ev[0], ev[1], int(columns.numel())))

@@ -64,6 +64,12 @@ def column_order(g: CSRGraph) -> torch.Tensor:
     return g._cache["scan_order"]
 
 
+def max_degree(g: CSRGraph) -> int:
+    if "max_degree" not in g._cache:
+        g._cache["max_degree"] = int(g.degree().max().item()) if g.n_rows else 0
+    return g._cache["max_degree"]
+
+
 def fixed_weights(g: CSRGraph, node_w: torch.Tensor) -> torch.Tensor:
     key = ("fixw", node_w.data_ptr(), node_w._version)
     if key not in g._cache:
@@ -74,7 +80,7 @@ def fixed_weights(g: CSRGraph, node_w: torch.Tensor) -> torch.Tensor:
 def _launch(g, fixw, columns, threshold, capacity) -> ops.Survivors:
     out = ops.Survivors(capacity, threshold, g.device)
     if columns.numel():
-        ops.filter_scan(g.rowptr, g.col, reverse_positions(g), fixw, g.n_rows, columns, out)
+        ops.filter_scan(g.rowptr, g.col, reverse_positions(g), fixw, g.n_rows, columns, out, max_degree(g))
     return out
 
 

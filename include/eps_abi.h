@@ -169,8 +169,9 @@ int64_t eps_expand_workspace_bytes(int64_t max_col_paths);
  *                     torch.distributed).  out is DEVICE-resident: threshold and capacity set by the caller, count
  *                     zeroed, key[] pre-filled with -1.  Slots are handed out in chunks, so after the launch the first
  *                     min(count, capacity) slots hold the survivors interleaved with untouched (-1) slots;
- *                     count > capacity means survivors were dropped.  workspace: eps_filter_scan_workspace_bytes()
- *                     bytes of scratch (bucket records), 16-byte aligned. */
+ *                     count > capacity means survivors were dropped.  max_degree: the longest row of the graph.
+ *                     workspace: eps_filter_scan_workspace_bytes(max_degree) bytes of scratch (bucket records +
+ *                     per-workgroup weight tables), 16-byte aligned. */
 typedef struct eps_survivors {
     float threshold;
     uint32_t capacity;
@@ -182,13 +183,14 @@ typedef struct eps_survivors {
 } eps_survivors;
 
 int64_t eps_filter_scan_max_nodes(void);
-int64_t eps_filter_scan_workspace_bytes(void);
+int64_t eps_filter_scan_workspace_bytes(int64_t max_degree);
 int eps_reverse_positions(const int64_t *rowptr, const int32_t *col, int64_t n_nodes, int32_t *revpos,
                           void *stream);
 int eps_fixed_weights(const float *node_w, int64_t n, int64_t *fixw, void *stream);
 int eps_filter_scan(const int64_t *rowptr, const int32_t *col, const int32_t *revpos, const int64_t *fixw,
-                    int64_t n_nodes, int64_t nnz, const int32_t *columns, int64_t n_columns,
-                    eps_survivors *out, void *workspace, int64_t workspace_bytes, void *stream);
+                    int64_t n_nodes, int64_t nnz, int64_t max_degree, const int32_t *columns,
+                    int64_t n_columns, eps_survivors *out, void *workspace, int64_t workspace_bytes,
+                    void *stream);
 
 /* ---- K4/K5: CSR x dense SpMM with fused epilogue -----------------------------------------
  * Replaces torch_sparse spmm_sum / spmm_mean inside GCNConv / SAGEConv (models.py:183-186,

@@ -30,7 +30,7 @@ def _scan_all(eps, g, node_w, thr=float("-inf"), columns=None):
     cols = scan.column_order(g) if columns is None else columns
     cap = 2 * int(scan.half_paths(g).sum().item()) + 8192 * 300
     res = eps.ops.Survivors(cap, thr, g.device)
-    eps.ops.filter_scan(g.rowptr, g.col, scan.reverse_positions(g), fixw, g.n_rows, cols, res)
+    eps.ops.filter_scan(g.rowptr, g.col, scan.reverse_positions(g), fixw, g.n_rows, cols, res, scan.max_degree(g))
     slots, n_cand = res.counts()
     assert slots <= res.capacity
     keys, vals = res.valid(slots)

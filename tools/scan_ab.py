@@ -20,7 +20,7 @@ for path in sys.argv[1:]:
     lib.eps_filter_scan.restype = ctypes.c_int
     lib.eps_filter_scan.argtypes = _lib.SIGNATURES["eps_filter_scan"][1]
     libs.append((os.path.basename(path), lib))
-ws = ops._scan_scratch(dev)
+ws = ops._scan_scratch(dev, scan.max_degree(g))
 ref = None
 times = {n: [] for n, _ in libs}
 for rep in range(int(os.environ.get("REPS", "6"))):
@@ -29,7 +29,7 @@ for rep in range(int(os.environ.get("REPS", "6"))):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         rc = lib.eps_filter_scan(g.rowptr.data_ptr(), g.col.data_ptr(), revpos.data_ptr(), fixw.data_ptr(), g.n_rows, g.nnz(),
-                                 order.data_ptr(), order.numel(), res.rec.data_ptr(), ws.data_ptr(), ws.numel() * 8,
+                                 scan.max_degree(g), order.data_ptr(), order.numel(), res.rec.data_ptr(), ws.data_ptr(), ws.numel() * 8,
                                  torch.cuda.current_stream().cuda_stream)
         e1.record(); torch.cuda.synchronize()
         assert rc == 0, name
