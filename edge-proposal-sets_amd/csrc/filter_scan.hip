@@ -24,16 +24,27 @@
 // Scores are bit-identical to eps_expand_fill's (same fixed-point terms, same final rounding).
 #include "eps_common.h"
 
+// Geometry (compile-time; the shipped values are the measured best on the ppa-sized graphs).  FS_UR must be 2 * FS_THREADS.
+#ifndef FS_THREADS
 #define FS_THREADS 1024
+#endif
+#ifndef FS_WG_PER_CU
+#define FS_WG_PER_CU 1       // workgroups resident per CU: the LDS is split between them
+#endif
 #define FS_WAVES (FS_THREADS / 64)
 #define FS_FIXED_SHIFT 40
+#ifndef FS_RC
 #define FS_RC 512            // rows (neighbours w of v) described per round
-#define FS_UR 2048           // 64-entry units per round (two list entries per thread)
+#endif
+#define FS_UR (2 * FS_THREADS)   // 64-entry units per round (two list entries per thread)
 #define FS_UPAD 384          // list entries past the last unit a prefetching wave may touch: they name the empty row
+#ifndef FS_RANGES
 #define FS_RANGES 512        // id ranges per column: path histogram and tile plan
-#define FS_AHEAD 4           // bucket records per thread requested one tile ahead (8, always or only for long buckets: no faster)
+#endif
 #define FS_CHUNK 8192        // survivor slots reserved per global atomic
+#ifndef FS_MAX_TILE_BITS
 #define FS_MAX_TILE_BITS 12  // candidate ranks per tile <= 4096 (8-byte accumulators in LDS)
+#endif
 
 typedef int v4i __attribute__((ext_vector_type(4)));
 
@@ -343,7 +354,7 @@ __global__ __launch_bounds__(FS_THREADS) void filter_scan_kernel(fs_params p)
         // Thread t owns the 8-word groups t, t + 1024, ... (two 16-byte reads per group, consecutive threads on consecutive
         // groups); one wave scan per trip orders the groups, the 16 x trips wave totals are scanned once more.
         const int n_groups = (words_v + 7) >> 3;
-        const int trips = (n_groups + FS_THREADS - 1) >> 10;          // <= 4 for ids < 2^20
+        const int trips = (n_groups + FS_THREADS - 1) / FS_THREADS;   // <= 4 for ids < 2^20 at 1024 threads
         int gcnt[4];
         uint32_t gpre[4][2];                                          // the group's 8 byte ranks, packed
 #pragma unroll
@@ -401,7 +412,7 @@ __global__ __launch_bounds__(FS_THREADS) void filter_scan_kernel(fs_params p)
         {
             const bool in = tid < n_ranges;
             const uint32_t rs = in ? base32[tid << (range_shift - 8)] : 0u;   // rank at the start of the range
-            const uint32_t paths = in ? hist[tid] : 0u;
+            const uint32_t paths = in ? (hist[tid] + 3u) & ~3u : 0u;   // buckets start on 16-byte lines (D2 reads 4 records per load)
             if (in) hist[tid] = 0u;
             const int pin = fs_wave_incl_scan((int)paths, lane);
             if (lane == 63) s_wtot[wib] = pin;
@@ -442,10 +453,7 @@ __global__ __launch_bounds__(FS_THREADS) void filter_scan_kernel(fs_params p)
         //      4-byte records (rank in tile | k << tile_bits) per tile in this workgroup's scratch and sums tile by tile.
         auto scan_tile = [&](int t) {     // acc -> survivors; leaves acc zero.  Caller: barrier before (sums complete).
             const uint32_t r0 = tile_r0[t], nslots = tile_r0[t + 1] - r0;
-            for (uint32_t i = tid; i < nslots; i += FS_THREADS) {
-                const long long a = (long long)acc[i];
-                acc[i] = 0ull;
-                if (a < thr_fix) continue;
+            auto survivor = [&](uint32_t i, long long a) {
                 const float sc = (float)((double)a * (1.0 / (double)(1ll << FS_FIXED_SHIFT)));
                 // the candidate of rank r: last 8-word group whose first rank is <= r, then the word, then the bit
                 const uint32_t r = r0 + i;
@@ -467,6 +475,15 @@ __global__ __launch_bounds__(FS_THREADS) void filter_scan_kernel(fs_params p)
                     out_key[pos] = ((int64_t)v << 32) | (int64_t)u;
                     out_val[pos] = sc;
                 }
+            };
+            // two sums per 16-byte LDS access (a slot past the tile's last is zero and is not a candidate)
+            for (uint32_t i = 2 * tid; i < nslots; i += 2 * FS_THREADS) {
+                const uint4 raw = *(const uint4 *)(acc + i);
+                *(uint4 *)(acc + i) = make_uint4(0u, 0u, 0u, 0u);
+                const long long a0 = (long long)(((unsigned long long)raw.y << 32) | raw.x);
+                const long long a1 = (long long)(((unsigned long long)raw.w << 32) | raw.z);
+                if (a0 >= thr_fix) survivor(i, a0);
+                if (a1 >= thr_fix && i + 1 < nslots) survivor(i + 1, a1);
             }
         };
         auto reserve_out = [&](int t) {   // thread 0, before the barrier that precedes scan_tile(t)
@@ -564,17 +581,14 @@ __global__ __launch_bounds__(FS_THREADS) void filter_scan_kernel(fs_params p)
                 fs_barrier();
                 scan_tile(t_lo);
             } else {
-                // per tile: records -> sums in LDS -> scan.  The first FS_AHEAD records per thread of the NEXT tile are
+                // per tile: records -> sums in LDS -> scan.  The first four records per thread of the NEXT tile are
                 // requested before the scan of the current one, so their latency hides behind it.
-                uint32_t rec[FS_AHEAD], b0 = 0, n = 0;
-                auto request = [&](int t) {
+                uint4 rec;
+                uint32_t b0 = 0, n = 0;
+                auto request = [&](int t) {    // thread t: records 4t .. 4t+3 of the tile's bucket (16-byte aligned)
                     b0 = tile_base[t] - win_base;
                     n = tile_cur[t] - b0;
-#pragma unroll
-                    for (int q = 0; q < FS_AHEAD; ++q) {
-                        const uint32_t i = tid + q * FS_THREADS;
-                        rec[q] = my_scratch[b0 + (i < n ? i : 0u)];
-                    }
+                    rec = *(const uint4 *)(my_scratch + b0 + 4 * tid);
                 };
                 auto add = [&](uint32_t r, bool live) {
                     if (!live) return;                       // (mostly whole waves: the tail of a bucket)
@@ -582,24 +596,19 @@ __global__ __launch_bounds__(FS_THREADS) void filter_scan_kernel(fs_params p)
                     const long long fx = single ? vwfix[k] : my_gfix[k];
                     atomicAdd(&acc[r & tile_mask], (unsigned long long)fx);
                 };
+                auto add4 = [&](const uint4 &r, uint32_t first, uint32_t cn) {
+                    add(r.x, first < cn);
+                    add(r.y, first + 1 < cn);
+                    add(r.z, first + 2 < cn);
+                    add(r.w, first + 3 < cn);
+                };
                 __syncthreads();                   // records visible (global stores drained), cursors final
                 request(t_lo);
                 for (int t = t_lo; t < t_hi; ++t) {
                     const uint32_t cb0 = b0, cn = n;
-#pragma unroll
-                    for (int q = 0; q < FS_AHEAD; ++q)
-                        add(rec[q], tid + q * FS_THREADS < cn);
-                    for (uint32_t i0 = tid + FS_AHEAD * FS_THREADS; i0 < cn; i0 += 4 * FS_THREADS) {
-                        uint32_t more[4];
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            const uint32_t i = i0 + q * FS_THREADS;
-                            more[q] = my_scratch[cb0 + (i < cn ? i : i0)];
-                        }
-#pragma unroll
-                        for (int q = 0; q < 4; ++q)
-                            add(more[q], i0 + q * FS_THREADS < cn);
-                    }
+                    add4(rec, 4 * tid, cn);
+                    for (uint32_t i0 = 4 * (tid + FS_THREADS); i0 < cn; i0 += 4 * FS_THREADS)
+                        add4(*(const uint4 *)(my_scratch + cb0 + i0), i0, cn);
                     if (t + 1 < t_hi) request(t + 1);
                     if (tid == 0) reserve_out(t);
                     fs_barrier();               // sums complete
@@ -674,7 +683,7 @@ extern "C" int eps_fixed_weights(const float *node_w, int64_t n, int64_t *fixw, 
 }
 
 // ---- launch ---------------------------------------------------------------------------------------------------------
-#define FS_LDS_LIMIT (160 * 1024 - 512)     // dynamic + the few static words
+#define FS_LDS_LIMIT (160 * 1024 / FS_WG_PER_CU - 512)     // dynamic + the few static words
 
 static int fs_words(int64_t n_nodes) { return (int)(((n_nodes + 31) / 32 + 1023) / 1024 * 1024); }
 
@@ -707,7 +716,7 @@ extern "C" int64_t eps_filter_scan_max_nodes(void)
 extern "C" int64_t eps_filter_scan_workspace_bytes(int64_t max_degree)
 {
     if (max_degree < 0) return 0;
-    return (int64_t)eps_num_cus() * (((int64_t)FS_DEFAULT_RECORDS + 64) * 4 + max_degree * 8);
+    return (int64_t)eps_num_cus() * FS_WG_PER_CU * (((int64_t)FS_DEFAULT_RECORDS + 64) * 4 + max_degree * 8);
 }
 
 extern "C" int eps_filter_scan(const int64_t *rowptr, const int32_t *col, const int32_t *revpos, const int64_t *fixw,
@@ -725,10 +734,10 @@ extern "C" int eps_filter_scan(const int64_t *rowptr, const int32_t *col, const 
     EPS_REQUIRE(n_nodes <= (1 << 20) && tile_bits > 0 && range_shift >= 8,
                 "eps_filter_scan: %lld nodes exceed the LDS bitmap (max %lld)", (long long)n_nodes,
                 (long long)eps_filter_scan_max_nodes());
-    int64_t blocks = eps_num_cus();
+    int64_t blocks = (int64_t)eps_num_cus() * FS_WG_PER_CU;
     if (blocks > n_columns) blocks = n_columns;
     EPS_REQUIRE(max_degree >= 0 && max_degree <= n_nodes, "eps_filter_scan: bad max_degree");
-    const int64_t n_wg = eps_num_cus();
+    const int64_t n_wg = (int64_t)eps_num_cus() * FS_WG_PER_CU;
     EPS_REQUIRE(workspace && ((uintptr_t)workspace & 15) == 0 && workspace_bytes >= eps_filter_scan_workspace_bytes(max_degree),
                 "eps_filter_scan: needs a 16-byte aligned workspace of eps_filter_scan_workspace_bytes(max_degree) bytes");
     const int64_t cap = FS_DEFAULT_RECORDS;

@@ -8,7 +8,7 @@ import torch, eps_amd
 from eps_amd import ops, scan, synth, _lib
 from eps_amd.heuristics import node_weight_table
 dev = torch.device("cuda:0")
-g = synth.ppa_like(seed=3, device=dev)
+g = synth.ppa_like(seed=3, device=dev, n_nodes=int(os.environ.get('NODES', 576289)), n_undirected=int(os.environ.get('EDGES', 21231931)))
 w = node_weight_table(g, ops.W_AA)
 fixw = scan.fixed_weights(g, w)
 order = scan.column_order(g)
@@ -20,7 +20,12 @@ for path in sys.argv[1:]:
     lib.eps_filter_scan.restype = ctypes.c_int
     lib.eps_filter_scan.argtypes = _lib.SIGNATURES["eps_filter_scan"][1]
     libs.append((os.path.basename(path), lib))
-ws = ops._scan_scratch(dev, scan.max_degree(g))
+need = 0
+for _, lib in libs:
+    lib.eps_filter_scan_workspace_bytes.restype = ctypes.c_int64
+    lib.eps_filter_scan_workspace_bytes.argtypes = [ctypes.c_int64]
+    need = max(need, lib.eps_filter_scan_workspace_bytes(scan.max_degree(g)))
+ws = torch.empty(need // 8 + 1, dtype=torch.int64, device=dev)
 ref = None
 times = {n: [] for n, _ in libs}
 for rep in range(int(os.environ.get("REPS", "6"))):
