@@ -95,8 +95,11 @@ struct fs_params {
     unsigned int *next_col;
     eps_survivors *out;
     uint32_t *scratch;        // cap_records (+ 64 trash) words per workgroup
-    long long *gfix;          // max_degree weights per workgroup: the vwfix table of columns wider than one round
+    long long *gfix;          // max_degree weights per workgroup: the weight table of columns that take several rounds
     int32_t max_degree;
+    const int32_t *splits;    // [n_win - 1][n_nodes]: entries of row w below id (k + 1) * win_ids (NULL when n_win == 1)
+    int32_t win_ids;          // ids per window (a multiple of 32768; the LDS bitmap's span)
+    int32_t n_win;
 };
 
 // Wave-wide inclusive scans on the DPP path (row shifts inside the 16-lane rows, then the two row broadcasts): six
@@ -137,6 +140,7 @@ struct fs_unit {
     int nvalid;   // 0..4 entries of u4 that belong to the row head
 };
 
+template <bool WINDOWED>
 __global__ __launch_bounds__(FS_THREADS) void filter_scan_kernel(fs_params p)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
@@ -211,7 +215,17 @@ __global__ __launch_bounds__(FS_THREADS) void filter_scan_kernel(fs_params p)
         if (dv == 0 || v == 0) continue;
         const int32_t *__restrict__ vcol = p.col + vb;
         const int32_t *__restrict__ vrev = p.revpos + vb;
-        const int words_v = (v + 31) >> 5;
+        // The endpoints below v are taken in id WINDOWS of win_ids ids (one window when the whole id space fits the LDS):
+        // window k sees of every row head only the entries inside it -- rows are ascending and splits[] holds, per node,
+        // how many of its entries lie below each window boundary -- and runs the whole pipeline on ids relative to its start.
+        // (WINDOWED == false: one window from id 0, everything below folds to constants)
+        for (int32_t wk = 0, win_base_id = 0; win_base_id < v; ++wk, win_base_id += p.win_ids) {
+        const int32_t win_lo = WINDOWED ? win_base_id : 0;
+        const int32_t vlim = (WINDOWED && v - win_lo > p.win_ids) ? p.win_ids : v - win_lo;     // ids of this window, relative
+        const uint32_t id_max = (uint32_t)vlim - 1u;
+        const int32_t *__restrict__ split_lo = (WINDOWED && wk > 0) ? p.splits + (size_t)(wk - 1) * (size_t)p.n_nodes : nullptr;
+        const int32_t *__restrict__ split_hi = (WINDOWED && wk + 1 < p.n_win) ? p.splits + (size_t)wk * (size_t)p.n_nodes : nullptr;
+        const int words_v = (vlim + 31) >> 5;
 
         // ---- describe a round: rows j0.. of N(v) from chunk c0 of row j0, until FS_RC rows or FS_UR units ------------
         // Leaves the descriptors + the unit -> row list in LDS; -> units of the round; s_done / s_next_c = the cursor after it.
@@ -222,8 +236,11 @@ __global__ __launch_bounds__(FS_THREADS) void filter_scan_kernel(fs_params p)
             const bool row_ok = tid < FS_RC && j0 + tid < dv;
             if (row_ok) {
                 const int32_t w = vcol[j0 + tid];
-                rl = (uint32_t)vrev[j0 + tid];
-                rb = (uint32_t)p.rowptr[w];
+                int32_t hi = vrev[j0 + tid], lo = 0;          // the row head below v ...
+                if (split_lo) lo = split_lo[w];                // ... cut to the window
+                if (split_hi) { const int32_t h = split_hi[w]; hi = hi < h ? hi : h; }
+                rl = hi > lo ? (uint32_t)(hi - lo) : 0u;
+                rb = (uint32_t)p.rowptr[w] + (uint32_t)lo;
                 fx = p.fixw[w];
                 nun = (int)((rl + 63u) >> 6);
                 if (tid == 0) nun -= c0;
@@ -332,7 +349,8 @@ __global__ __launch_bounds__(FS_THREADS) void filter_scan_kernel(fs_params p)
                 // no branches: an entry past the row head ORs / adds 0 (into whatever word its stale id names: ids < N)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const uint32_t u = (uint32_t)f.u4[e];
+                    uint32_t u = (uint32_t)(f.u4[e] - win_lo);
+                    if (WINDOWED) u = u < id_max ? u : id_max;         // (a stale id may lie outside the window: clamp)
                     const uint32_t on = e < f.nvalid ? 1u : 0u;
                     atomicOr(&bm[u >> 5], on << (u & 31));
                     atomicAdd(&hist[u >> range_shift], on);
@@ -345,8 +363,8 @@ __global__ __launch_bounds__(FS_THREADS) void filter_scan_kernel(fs_params p)
         }
         fs_barrier();
         for (int k = tid; k < dv; k += FS_THREADS) {   // known edges out (the diagonal is not below v)
-            const uint32_t u = (uint32_t)vcol[k];
-            if (u < (uint32_t)v) atomicAnd(&bm[u >> 5], ~(1u << (u & 31)));
+            const uint32_t u = (uint32_t)(vcol[k] - win_lo);
+            if (u < (uint32_t)vlim) atomicAnd(&bm[u >> 5], ~(1u << (u & 31)));
         }
         fs_barrier();
 
@@ -399,11 +417,13 @@ __global__ __launch_bounds__(FS_THREADS) void filter_scan_kernel(fs_params p)
                 }
             }
         }
-        const int n_ranges = ((v - 1) >> range_shift) + 1;
+        const int n_ranges = ((vlim - 1) >> range_shift) + 1;
         if (tid == 0 && total) atomicAdd(&p.out->n_candidates, (unsigned long long)total);
         if (total == 0) {          // every endpoint is a neighbour of v: nothing to score
             if (tid < n_ranges) hist[tid] = 0u;
             for (int i = tid; i < words_v; i += FS_THREADS) bm[i] = 0u;
+            if (!WINDOWED) break;
+            fs_barrier();              // (the next window marks into the words other threads just cleared)
             continue;
         }
         fs_barrier();
@@ -472,7 +492,7 @@ __global__ __launch_bounds__(FS_THREADS) void filter_scan_kernel(fs_params p)
                 const uint32_t u = (uint32_t)wi * 32u + (uint32_t)__builtin_ctz(bits);
                 const uint32_t pos = atomicAdd(&s_out_cur, 1u);
                 if (pos < out_cap) {
-                    out_key[pos] = ((int64_t)v << 32) | (int64_t)u;
+                    out_key[pos] = ((int64_t)v << 32) | (int64_t)(u + (uint32_t)win_lo);
                     out_val[pos] = sc;
                 }
             };
@@ -519,10 +539,12 @@ __global__ __launch_bounds__(FS_THREADS) void filter_scan_kernel(fs_params p)
                 // per entry: is it a candidate of the window, and its rank inside its tile.  No branch per entry: an entry
                 // past the row head goes through the look-ups on its stale id (< N) and is masked out of `cand`.
                 auto classify = [&](const fs_unit &f, uint32_t (&rank)[4], uint32_t (&tl)[4], uint32_t (&cand)[4]) -> uint32_t {
-                    uint32_t word[4], gi[4];
+                    uint32_t word[4], gi[4], f_u[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const uint32_t u = (uint32_t)f.u4[e];
+                        uint32_t u = (uint32_t)(f.u4[e] - win_lo);
+                        if (WINDOWED) u = u < id_max ? u : id_max;
+                        f_u[e] = u;
                         word[e] = bm[u >> 5];
                         gi[e] = ginfo[u >> 8];
                         rank[e] = pre8[u >> 5];
@@ -530,7 +552,7 @@ __global__ __launch_bounds__(FS_THREADS) void filter_scan_kernel(fs_params p)
                     uint32_t ncand = 0;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const uint32_t b = (uint32_t)f.u4[e] & 31u;
+                        const uint32_t b = f_u[e] & 31u;
                         tl[e] = (gi[e] >> 16) - (uint32_t)t_lo;                     // tile, relative to the window
                         cand[e] = (e < f.nvalid && tl[e] < span) ? (word[e] >> b) & 1u : 0u;
                         rank[e] += (gi[e] & 0xFFFFu) + __popc(word[e] & ((1u << b) - 1u));   // rank inside its tile
@@ -620,6 +642,9 @@ __global__ __launch_bounds__(FS_THREADS) void filter_scan_kernel(fs_params p)
             t_lo = t_hi;
         }
         for (int i = tid; i < words_v; i += FS_THREADS) bm[i] = 0u;
+        if (!WINDOWED) break;
+        fs_barrier();                  // the next window marks into the words other threads just cleared
+        }
     }
 }
 
@@ -644,6 +669,24 @@ __global__ void reverse_positions_kernel(const int64_t *__restrict__ rowptr, con
             }
             revpos[i] = (int32_t)(lo - wb);
         }
+    }
+}
+
+// splits[k][w] = number of entries of row w below id (k + 1) * win_ids, k = 0 .. n_win - 2: where the id windows cut the row
+__global__ void row_window_splits_kernel(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+                                         int64_t n_nodes, int64_t win_ids, int32_t n_cuts, int32_t *__restrict__ splits)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_nodes * n_cuts; i += stride) {
+        const int64_t w = i % n_nodes, k = i / n_nodes;
+        const int64_t bound = (k + 1) * win_ids;
+        int64_t lo = rowptr[w], hi = rowptr[w + 1];
+        const int64_t wb = lo;
+        while (lo < hi) {
+            const int64_t mid = (lo + hi) >> 1;
+            if (col[mid] < bound) lo = mid + 1; else hi = mid;
+        }
+        splits[i] = (int32_t)(lo - wb);
     }
 }
 
@@ -685,30 +728,72 @@ extern "C" int eps_fixed_weights(const float *node_w, int64_t n, int64_t *fixw, 
 // ---- launch ---------------------------------------------------------------------------------------------------------
 #define FS_LDS_LIMIT (160 * 1024 / FS_WG_PER_CU - 512)     // dynamic + the few static words
 
-static int fs_words(int64_t n_nodes) { return (int)(((n_nodes + 31) / 32 + 1023) / 1024 * 1024); }
+// Launch geometry for an id space of n_nodes: the fewest id windows (of a multiple of 32768 ids) whose bitmap, rank tables
+// and a tile of 2^FS_MAX_TILE_BITS accumulators fit the workgroup's share of the LDS; if even windows of 32768 ids do not
+// leave room for such a tile, the tile shrinks.
+struct fs_geometry {
+    int n_win, words, tile_bits, range_shift;
+    int64_t win_ids;
+};
 
-// largest tile (a power of two <= 4096 ranks) whose accumulators fit beside the bitmap of an n_nodes-id space; 0 = none
-static int fs_tile_bits(int64_t n_nodes)
-{
-    const int words = fs_words(n_nodes);
-    for (int tb = FS_MAX_TILE_BITS; tb >= 9; --tb)
-        if ((size_t)fs_make_layout(words, tb).total_words * 4 <= FS_LDS_LIMIT) return tb;
-    return 0;
-}
-
-static int fs_range_shift(int64_t n_nodes, int tile_bits)
+static int fs_range_shift(int64_t ids, int tile_bits)
 {
     int s = 8;
-    while (((n_nodes - 1) >> s) + 1 > FS_RANGES) ++s;
+    while (((ids - 1) >> s) + 1 > FS_RANGES) ++s;
     return s <= tile_bits - 1 ? s : -1;       // a range may hold at most half a tile
 }
 
-extern "C" int64_t eps_filter_scan_max_nodes(void)
+static bool fs_pick_geometry(int64_t n_nodes, fs_geometry *g)
 {
-    int64_t n = 1 << 20;                      // ranks are packed in 20 bits
-    while (n > 0 && (fs_tile_bits(n) == 0 || fs_range_shift(n, fs_tile_bits(n)) < 0)) n -= 32768;
-    return n;
+    for (int tile_bits = FS_MAX_TILE_BITS; tile_bits >= 9; --tile_bits)
+        for (int64_t n_win = 1; n_win <= 4096; ++n_win) {
+            const int64_t words = (((n_nodes + n_win - 1) / n_win + 31) / 32 + 1023) / 1024 * 1024;
+            const int64_t win_ids = words * 32;
+            if ((n_nodes + win_ids - 1) / win_ids != n_win) continue;        // rounding made a window superfluous
+            const int rs = fs_range_shift(win_ids < n_nodes ? win_ids : n_nodes, tile_bits);
+            // (four group trips per thread at most; the ranks of a window are packed in 20 bits)
+            if ((size_t)fs_make_layout((int)words, tile_bits).total_words * 4 <= FS_LDS_LIMIT && rs >= 8 &&
+                words / 8 <= 4 * FS_THREADS && win_ids <= (1 << 20)) {
+                g->n_win = (int)n_win;
+                g->words = (int)words;
+                g->tile_bits = tile_bits;
+                g->range_shift = rs;
+                g->win_ids = win_ids;
+                return true;
+            }
+            if (words == 1024) break;
+        }
+    return false;
 }
+
+// ids per window / number of windows eps_filter_scan uses for an id space of n_nodes (the caller builds the split table for
+// exactly these); returns EPS_EINVAL if no geometry fits.
+extern "C" int eps_filter_scan_windows(int64_t n_nodes, int64_t *win_ids, int64_t *n_win)
+{
+    fs_geometry g;
+    EPS_REQUIRE(n_nodes > 0 && n_nodes < (1ll << 31) && fs_pick_geometry(n_nodes, &g),
+                "eps_filter_scan_windows: no launch geometry for %lld nodes", (long long)n_nodes);
+    if (win_ids) *win_ids = g.win_ids;
+    if (n_win) *n_win = g.n_win;
+    return EPS_OK;
+}
+
+extern "C" int eps_row_window_splits(const int64_t *rowptr, const int32_t *col, int64_t n_nodes, int64_t win_ids,
+                                     int64_t n_win, int32_t *splits, void *stream)
+{
+    EPS_REQUIRE(n_nodes >= 0 && win_ids > 0 && n_win >= 1, "eps_row_window_splits: bad size");
+    if (n_nodes == 0 || n_win == 1) return EPS_OK;
+    EPS_REQUIRE(rowptr && col && splits, "eps_row_window_splits: null pointer");
+    int64_t blocks = (n_nodes * (n_win - 1) + 255) / 256;
+    const int64_t cap = (int64_t)eps_num_cus() * 16;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(row_window_splits_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, rowptr, col,
+                       n_nodes, win_ids, (int32_t)(n_win - 1), splits);
+    EPS_CHECK_LAUNCH("eps_row_window_splits");
+    return EPS_OK;
+}
+
+extern "C" int64_t eps_filter_scan_max_nodes(void) { return (1ll << 31) - 1; }
 
 #define FS_DEFAULT_RECORDS (1u << 20)         // bucket records per workgroup: 4 MiB each, 1 GiB on 256 CUs
 
@@ -720,20 +805,21 @@ extern "C" int64_t eps_filter_scan_workspace_bytes(int64_t max_degree)
 }
 
 extern "C" int eps_filter_scan(const int64_t *rowptr, const int32_t *col, const int32_t *revpos, const int64_t *fixw,
-                               int64_t n_nodes, int64_t nnz, int64_t max_degree, const int32_t *columns,
-                               int64_t n_columns, eps_survivors *out, void *workspace, int64_t workspace_bytes,
-                               void *stream)
+                               const int32_t *splits, int64_t n_nodes, int64_t nnz, int64_t max_degree,
+                               const int32_t *columns, int64_t n_columns, eps_survivors *out, void *workspace,
+                               int64_t workspace_bytes, void *stream)
 {
     EPS_REQUIRE(n_nodes >= 0 && n_columns >= 0 && nnz >= 0, "eps_filter_scan: negative size");
     if (n_columns == 0 || n_nodes == 0) return EPS_OK;
     EPS_REQUIRE(rowptr && col && revpos && fixw && columns && out, "eps_filter_scan: null pointer");
     EPS_REQUIRE(nnz < (1ll << 30), "eps_filter_scan: col[] is addressed with 32-bit byte offsets (nnz < 2^30)");
     EPS_REQUIRE(n_columns < (1ll << 31), "eps_filter_scan: too many columns");
-    const int tile_bits = fs_tile_bits(n_nodes);
-    const int range_shift = tile_bits ? fs_range_shift(n_nodes, tile_bits) : -1;
-    EPS_REQUIRE(n_nodes <= (1 << 20) && tile_bits > 0 && range_shift >= 8,
-                "eps_filter_scan: %lld nodes exceed the LDS bitmap (max %lld)", (long long)n_nodes,
-                (long long)eps_filter_scan_max_nodes());
+    fs_geometry geo;
+    EPS_REQUIRE(n_nodes < (1ll << 31) && fs_pick_geometry(n_nodes, &geo), "eps_filter_scan: no launch geometry for %lld nodes",
+                (long long)n_nodes);
+    EPS_REQUIRE(geo.n_win == 1 || splits, "eps_filter_scan: %d id windows need the row split table (eps_row_window_splits)",
+                geo.n_win);
+    const int tile_bits = geo.tile_bits, range_shift = geo.range_shift;
     int64_t blocks = (int64_t)eps_num_cus() * FS_WG_PER_CU;
     if (blocks > n_columns) blocks = n_columns;
     EPS_REQUIRE(max_degree >= 0 && max_degree <= n_nodes, "eps_filter_scan: bad max_degree");
@@ -754,7 +840,10 @@ extern "C" int eps_filter_scan(const int64_t *rowptr, const int32_t *col, const 
     p.n_columns = (int32_t)n_columns;
     p.n_nodes = (int32_t)n_nodes;
     p.col_bytes = (uint32_t)(nnz * 4);
-    p.words = fs_words(n_nodes);
+    p.words = geo.words;
+    p.splits = geo.n_win > 1 ? splits : nullptr;
+    p.win_ids = (int32_t)(geo.win_ids < (1ll << 30) ? geo.win_ids : (1ll << 30));
+    p.n_win = geo.n_win;
     p.tile_bits = tile_bits;
     p.range_shift = range_shift;
     p.cap_records = (uint32_t)cap;
@@ -764,12 +853,12 @@ extern "C" int eps_filter_scan(const int64_t *rowptr, const int32_t *col, const 
     p.gfix = (long long *)((char *)workspace + n_wg * ((int64_t)FS_DEFAULT_RECORDS + 64) * 4);
     p.max_degree = (int32_t)max_degree;
     const size_t lds = (size_t)fs_make_layout(p.words, tile_bits).total_words * 4;
-    if (hipFuncSetAttribute((const void *)filter_scan_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
-        hipSuccess) {
+    auto kern = geo.n_win > 1 ? filter_scan_kernel<true> : filter_scan_kernel<false>;
+    if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
         eps_set_error("eps_filter_scan: cannot reserve %zu bytes of LDS", lds);
         return EPS_ELAUNCH;
     }
-    hipLaunchKernelGGL(filter_scan_kernel, dim3((unsigned)blocks), dim3(FS_THREADS), lds, s, p);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(FS_THREADS), lds, s, p);
     EPS_CHECK_LAUNCH("eps_filter_scan");
     return EPS_OK;
 }

@@ -285,6 +285,26 @@ def reverse_positions(rowptr: torch.Tensor, col: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def filter_scan_windows(n_nodes: int):
+    """(ids per window, number of windows) eps_filter_scan uses for an id space of ``n_nodes``."""
+    w, k = ctypes.c_int64(0), ctypes.c_int64(0)
+    _lib.check(_lib.load().eps_filter_scan_windows(int(n_nodes), ctypes.byref(w), ctypes.byref(k)), "eps_filter_scan_windows")
+    return int(w.value), int(k.value)
+
+
+def row_window_splits(rowptr: torch.Tensor, col: torch.Tensor, win_ids: int, n_win: int) -> Optional[torch.Tensor]:
+    """int32[(n_win - 1) * N]: entries of every row below each window boundary (None for a single window)."""
+    if n_win <= 1:
+        return None
+    dev = _need_gpu(rowptr, col)
+    n = rowptr.numel() - 1
+    out = torch.empty((n_win - 1) * n, dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.load().eps_row_window_splits(_ptr(rowptr), _ptr(col), n, int(win_ids), int(n_win), _ptr(out),
+                                                     _stream(dev)), "eps_row_window_splits")
+    return out
+
+
 def fixed_weights(node_w: torch.Tensor) -> torch.Tensor:
     """int64[N]: round(node_w * 2**40), the per-node weights in the scan kernel's fixed point."""
     dev = _need_gpu(node_w)
@@ -340,12 +360,14 @@ class Survivors:
         return k[m], self.val[:n][m]
 
 
-def filter_scan(rowptr, col, revpos, fixw, n_nodes: int, columns: torch.Tensor, out: Survivors, max_degree: int) -> None:
+def filter_scan(rowptr, col, revpos, fixw, n_nodes: int, columns: torch.Tensor, out: Survivors, max_degree: int,
+                splits: Optional[torch.Tensor] = None) -> None:
     """Launch eps_filter_scan over ``columns`` (int32 ids, hand-out order); survivors accumulate in ``out``.
-    ``max_degree``: the longest row of the graph (sizes a scratch table)."""
-    dev = _need_gpu(rowptr, col, revpos, fixw, columns)
+    ``max_degree``: the longest row of the graph (sizes a scratch table); ``splits``: ``row_window_splits`` of the graph
+    when ``filter_scan_windows`` reports more than one id window."""
+    dev = _need_gpu(rowptr, col, revpos, fixw, columns, splits)
     _chk(rowptr, torch.int64, "rowptr"); _chk(col, torch.int32, "col"); _chk(revpos, torch.int32, "revpos")
-    _chk(fixw, torch.int64, "fixw"); _chk(columns, torch.int32, "columns")
+    _chk(fixw, torch.int64, "fixw"); _chk(columns, torch.int32, "columns"); _chk(splits, torch.int32, "splits")
     if revpos.numel() != col.numel() or fixw.numel() != n_nodes:
         raise _lib.EpsError("filter_scan: revpos / fixw do not match the graph")
     ws = _scan_scratch(dev, max_degree)
@@ -354,8 +376,8 @@ def filter_scan(rowptr, col, revpos, fixw, n_nodes: int, columns: torch.Tensor, 
         if KERNEL_EVENTS is not None:              # bench.py: HIP events around the launch, on the stream it runs on
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev[0].record(torch.cuda.current_stream(dev))
-        _lib.check(_lib.load().eps_filter_scan(_ptr(rowptr), _ptr(col), _ptr(revpos), _ptr(fixw), n_nodes, col.numel(),
-                                               int(max_degree), _ptr(columns), columns.numel(), _ptr(out.rec), _ptr(ws),
+        _lib.check(_lib.load().eps_filter_scan(_ptr(rowptr), _ptr(col), _ptr(revpos), _ptr(fixw), _ptr(splits), n_nodes,
+                                               col.numel(), int(max_degree), _ptr(columns), columns.numel(), _ptr(out.rec), _ptr(ws),
                                                ws.numel() * 8, _stream(dev)), "eps_filter_scan")
         if ev is not None:
             ev[1].record(torch.cuda.current_stream(dev))

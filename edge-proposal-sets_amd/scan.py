@@ -39,7 +39,7 @@ _CHUNK_SLACK = 8192 * 320  # survivor slots are handed out in chunks of 8192 per
 def scan_available(g: CSRGraph) -> bool:
     """eps_filter_scan can take this graph: on the GPU, square, unit values, ids within the LDS bitmap."""
     return (g.device.type == "cuda" and g.n_rows == g.n_cols and g.val is None and 0 < g.n_rows <= ops.filter_scan_max_nodes()
-            and g.nnz() < 1 << 30)
+            and g.nnz() < 1 << 30)       # (any id space: wider ones are scanned in id windows)
 
 
 def reverse_positions(g: CSRGraph) -> torch.Tensor:
@@ -64,6 +64,14 @@ def column_order(g: CSRGraph) -> torch.Tensor:
     return g._cache["scan_order"]
 
 
+def window_splits(g: CSRGraph):
+    """Row split table for the id windows eps_filter_scan uses on this graph (None: one window); cached."""
+    if "scan_splits" not in g._cache:
+        win_ids, n_win = ops.filter_scan_windows(g.n_rows)
+        g._cache["scan_splits"] = ops.row_window_splits(g.rowptr, g.col, win_ids, n_win)
+    return g._cache["scan_splits"]
+
+
 def max_degree(g: CSRGraph) -> int:
     if "max_degree" not in g._cache:
         g._cache["max_degree"] = int(g.degree().max().item()) if g.n_rows else 0
@@ -80,7 +88,7 @@ def fixed_weights(g: CSRGraph, node_w: torch.Tensor) -> torch.Tensor:
 def _launch(g, fixw, columns, threshold, capacity) -> ops.Survivors:
     out = ops.Survivors(capacity, threshold, g.device)
     if columns.numel():
-        ops.filter_scan(g.rowptr, g.col, reverse_positions(g), fixw, g.n_rows, columns, out, max_degree(g))
+        ops.filter_scan(g.rowptr, g.col, reverse_positions(g), fixw, g.n_rows, columns, out, max_degree(g), window_splits(g))
     return out
 
 

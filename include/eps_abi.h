@@ -184,13 +184,19 @@ typedef struct eps_survivors {
 
 int64_t eps_filter_scan_max_nodes(void);
 int64_t eps_filter_scan_workspace_bytes(int64_t max_degree);
+/* Id spaces wider than the LDS bitmap are scanned in id windows: eps_filter_scan_windows reports the window size / count
+ * the launch will use for n_nodes ids, eps_row_window_splits fills the per-graph table it then needs:
+ * splits[k * n_nodes + w] = number of entries of row w below id (k + 1) * win_ids, k = 0 .. n_win - 2 (int32). */
+int eps_filter_scan_windows(int64_t n_nodes, int64_t *win_ids, int64_t *n_win);
+int eps_row_window_splits(const int64_t *rowptr, const int32_t *col, int64_t n_nodes, int64_t win_ids,
+                          int64_t n_win, int32_t *splits, void *stream);
 int eps_reverse_positions(const int64_t *rowptr, const int32_t *col, int64_t n_nodes, int32_t *revpos,
                           void *stream);
 int eps_fixed_weights(const float *node_w, int64_t n, int64_t *fixw, void *stream);
 int eps_filter_scan(const int64_t *rowptr, const int32_t *col, const int32_t *revpos, const int64_t *fixw,
-                    int64_t n_nodes, int64_t nnz, int64_t max_degree, const int32_t *columns,
-                    int64_t n_columns, eps_survivors *out, void *workspace, int64_t workspace_bytes,
-                    void *stream);
+                    const int32_t *splits_or_null, int64_t n_nodes, int64_t nnz, int64_t max_degree,
+                    const int32_t *columns, int64_t n_columns, eps_survivors *out, void *workspace,
+                    int64_t workspace_bytes, void *stream);
 
 /* ---- K4/K5: CSR x dense SpMM with fused epilogue -----------------------------------------
  * Replaces torch_sparse spmm_sum / spmm_mean inside GCNConv / SAGEConv (models.py:183-186,

@@ -28,9 +28,9 @@ def _scan_all(eps, g, node_w, thr=float("-inf"), columns=None):
     from eps_amd import scan
     fixw = scan.fixed_weights(g, node_w)
     cols = scan.column_order(g) if columns is None else columns
-    cap = 2 * int(scan.half_paths(g).sum().item()) + 8192 * 300
+    cap = 2 * int(scan.half_paths(g)[cols.long()].sum().item()) + 8192 * 300
     res = eps.ops.Survivors(cap, thr, g.device)
-    eps.ops.filter_scan(g.rowptr, g.col, scan.reverse_positions(g), fixw, g.n_rows, cols, res, scan.max_degree(g))
+    eps.ops.filter_scan(g.rowptr, g.col, scan.reverse_positions(g), fixw, g.n_rows, cols, res, scan.max_degree(g), scan.window_splits(g))
     slots, n_cand = res.counts()
     assert slots <= res.capacity
     keys, vals = res.valid(slots)
@@ -174,3 +174,48 @@ def test_scan_full_size_properties(eps, dev):
     assert int(hit.sum()) >= pairs.shape[1] - 2                                 # at most the K-th tie loses its mirror
     p2, s2 = scan.scan_topk(g, wt, 1_000_000)
     assert torch.equal(p2, pairs) and torch.equal(s2, scores)
+
+
+def test_scan_wide_id_space_in_windows(eps, oracle, dev):
+    """An id space wider than the LDS bitmap (N = 1.3 M: three id windows): the windowed scan finds, for sampled columns,
+    exactly the fused expansion's candidates (u < v) with bit-identical scores; its candidate count equals the oracle's
+    for those columns; scan_topk over the whole graph equals the top of an explicit full scoring of those columns' rows."""
+    from eps_amd import scan, synth
+    from eps_amd.heuristics import node_weight_table
+    n = 1_300_000
+    g = synth.rmat_graph(21, 1, 13, "cpu", n_nodes=n)
+    A = g.to_scipy()
+    g = g.to(dev)
+    win_ids, n_win = eps.ops.filter_scan_windows(n)
+    assert n_win >= 2 and win_ids * n_win >= n
+    wt = node_weight_table(g, eps.ops.W_AA)
+    deg = g.degree()
+    hub = int(torch.argmax(deg))
+    cols = sorted({5, hub, win_ids - 1, win_ids, win_ids + 7, 2 * win_ids + 3 if 2 * win_ids + 3 < n else n - 2, n - 1,
+                   int(torch.argsort(deg, descending=True)[3])})
+    colt = torch.tensor(cols, dtype=torch.int32, device=dev)
+    got, n_cand = _scan_all(eps, g, wt, columns=colt)
+    want = {}
+    for c in cols:
+        _, cu, cv, _, sc = eps.ops.expand_candidates(g.rowptr, g.col, None, wt, n, c, c + 1, want_cn=False)
+        m = cu < c
+        for u, s in zip(cu[m].cpu().numpy(), sc[m].cpu().numpy()):
+            want[(int(u), c)] = float(s)
+        ref, _ = oracle.candidates_scipy_columns(A, c, c + 1)
+        assert int((ref[:, 0] < c).sum()) == int(m.sum())
+    assert n_cand == len(want) and got == want
+    assert any(u >= win_ids for u, _ in want) and any(u < win_ids for u, _ in want)
+    # whole graph: the exact top-K through the estimate path == the K best of a no-bar scan (compared on the device)
+    fixw = scan.fixed_weights(g, wt)
+    res = eps.ops.Survivors(2 * int(scan.half_paths(g).sum().item()) + 8192 * 300, float("-inf"), dev)
+    eps.ops.filter_scan(g.rowptr, g.col, scan.reverse_positions(g), fixw, n, scan.column_order(g), res, scan.max_degree(g),
+                        scan.window_splits(g))
+    keys, vals = res.valid(res.counts()[0])
+    keys = torch.cat([keys, ((keys & 0xFFFFFFFF) << 32) | (keys >> 32)])
+    vals = torch.cat([vals, vals])
+    o = torch.argsort(keys)
+    keys, vals = keys[o], vals[o]
+    k = 5000
+    o = torch.sort(vals, descending=True, stable=True).indices[:k]
+    pairs, scores = scan.scan_topk(g, wt, k)
+    assert torch.equal((pairs[1] << 32) | pairs[0], keys[o]) and torch.equal(scores, vals[o])

@@ -26,6 +26,17 @@ for _, lib in libs:
     lib.eps_filter_scan_workspace_bytes.argtypes = [ctypes.c_int64]
     need = max(need, lib.eps_filter_scan_workspace_bytes(scan.max_degree(g)))
 ws = torch.empty(need // 8 + 1, dtype=torch.int64, device=dev)
+_splits = {}
+def splits_ptr(lib):
+    """each build has its own window geometry: its own split table"""
+    lib.eps_filter_scan_windows.argtypes = [ctypes.c_int64, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]
+    w, k = ctypes.c_int64(0), ctypes.c_int64(0)
+    assert lib.eps_filter_scan_windows(g.n_rows, ctypes.byref(w), ctypes.byref(k)) == 0
+    key = (w.value, k.value)
+    if key not in _splits:
+        _splits[key] = ops.row_window_splits(g.rowptr, g.col, w.value, k.value)
+        print("geometry", key)
+    return None if _splits[key] is None else _splits[key].data_ptr()
 ref = None
 times = {n: [] for n, _ in libs}
 for rep in range(int(os.environ.get("REPS", "6"))):
@@ -33,7 +44,7 @@ for rep in range(int(os.environ.get("REPS", "6"))):
         res = ops.Survivors(32 << 20, bar, dev)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        rc = lib.eps_filter_scan(g.rowptr.data_ptr(), g.col.data_ptr(), revpos.data_ptr(), fixw.data_ptr(), g.n_rows, g.nnz(),
+        rc = lib.eps_filter_scan(g.rowptr.data_ptr(), g.col.data_ptr(), revpos.data_ptr(), fixw.data_ptr(), splits_ptr(lib), g.n_rows, g.nnz(),
                                  scan.max_degree(g), order.data_ptr(), order.numel(), res.rec.data_ptr(), ws.data_ptr(), ws.numel() * 8,
                                  torch.cuda.current_stream().cuda_stream)
         e1.record(); torch.cuda.synchronize()

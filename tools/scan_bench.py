@@ -31,7 +31,7 @@ order = scan.column_order(g)
 for rep in range(3):
     res = ops.Survivors(64 << 20, bar, dev)
     e0, e1 = ev(), ev()
-    e0.record(); ops.filter_scan(g.rowptr, g.col, scan.reverse_positions(g), fixw, g.n_rows, order, res, scan.max_degree(g)); e1.record()
+    e0.record(); ops.filter_scan(g.rowptr, g.col, scan.reverse_positions(g), fixw, g.n_rows, order, res, scan.max_degree(g), scan.window_splits(g)); e1.record()
     torch.cuda.synchronize()
     print(f"main launch at bar {bar:.4f}: {e0.elapsed_time(e1):.2f} ms, slots/cands {res.counts()}")
 e0, e1 = ev(), ev(); e0.record(); b = scan.estimate_bar(g, fixw, a.k); e1.record(); torch.cuda.synchronize()

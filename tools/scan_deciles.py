@@ -25,7 +25,7 @@ for d in range(10):
     for rep in range(3):
         res = ops.Survivors(32 << 20, bar, dev)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(); ops.filter_scan(g.rowptr, g.col, scan.reverse_positions(g), fixw, g.n_rows, cols, res, scan.max_degree(g)); e1.record()
+        e0.record(); ops.filter_scan(g.rowptr, g.col, scan.reverse_positions(g), fixw, g.n_rows, cols, res, scan.max_degree(g), scan.window_splits(g)); e1.record()
         torch.cuda.synchronize(); ts.append(e0.elapsed_time(e1))
     t = min(ts); tot_t += t
     print(f"{d:3d} {cols.numel():8d} {p/1e6:12.1f} {p/int(hp.sum()):6.3f} {float(deg[cols.long()].float().mean()):8.1f} {t:7.2f} "

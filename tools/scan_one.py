@@ -14,6 +14,6 @@ order = scan.column_order(g)
 bar = float(os.environ.get("BAR", "3.25"))
 for _ in range(int(os.environ.get("REPS", "1"))):
     res = ops.Survivors(64 << 20, bar, dev)
-    ops.filter_scan(g.rowptr, g.col, scan.reverse_positions(g), fixw, g.n_rows, order, res, scan.max_degree(g))
+    ops.filter_scan(g.rowptr, g.col, scan.reverse_positions(g), fixw, g.n_rows, order, res, scan.max_degree(g), scan.window_splits(g))
 torch.cuda.synchronize()
 print("slots, unordered candidates:", res.counts(), "half paths:", int(scan.half_paths(g).sum()))

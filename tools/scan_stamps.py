@@ -21,7 +21,7 @@ names = ["hand-out + column setup", "A rounds: describe + mark + histogram", "kn
 bar = float(os.environ.get("BAR", "3.25"))
 for rep in range(2):
     res = ops.Survivors(64 << 20, bar, dev)
-    ops.filter_scan(g.rowptr, g.col, scan.reverse_positions(g), fixw, g.n_rows, scan.column_order(g), res, scan.max_degree(g))
+    ops.filter_scan(g.rowptr, g.col, scan.reverse_positions(g), fixw, g.n_rows, scan.column_order(g), res, scan.max_degree(g), scan.window_splits(g))
     torch.cuda.synchronize()
     lib.eps_debug_scan_stamps(buf, 1)
 tot = sum(buf[i] for i in (0, 1, 2, 3, 4))
