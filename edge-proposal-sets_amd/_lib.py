@@ -42,6 +42,8 @@ SIGNATURES = {
     "eps_gcn_norm": (_int, [_vp, _vp, _vp, _i64, _vp, _vp, _vp]),
     "eps_gemm_f32": (_int, [_vp, _i64, _vp, _i64, _vp, _int, _int, _vp, _i64, _i64, _i32, _i32, _vp]),
     "eps_mlp_decode": (_int, [_vp, _i64, _i32, _vp, _vp, _i64, _c.POINTER(_vp), _c.POINTER(_vp), _i32, _int, _vp, _vp]),
+    "eps_kth_largest_workspace_bytes": (_i64, []),
+    "eps_kth_largest_f32": (_int, [_vp, _i64, _i64, _vp, _vp, _vp]),
     "eps_pack_keys": (_int, [_vp, _vp, _i64, _i64, _vp, _vp]),
     "eps_unpack_keys": (_int, [_vp, _i64, _vp, _vp, _vp]),
 }

@@ -71,3 +71,75 @@ extern "C" int eps_unpack_keys(const int64_t *keys, int64_t n, float *score, int
     EPS_CHECK_LAUNCH("eps_unpack_keys");
     return EPS_OK;
 }
+
+// ---- k-th largest of a float32 array by radix select --------------------------------------------------------------------
+// The bar of the threshold scan and the final top-K cut (filter.py:160-161 keeps the K best rows) need one VALUE, not a
+// sorted array: four rounds over the order-preserving bit pattern of the floats, 8 bits per round -- a 256-bin histogram of
+// the values that still match the prefix found so far, then the bin that holds the k-th largest.  4 reads of the array
+// instead of a sort; everything stays on the device (state: prefix, remaining k).
+struct kth_state {
+    uint32_t prefix, mask;     // bits decided so far (in ordered_bits space) and which bits those are
+    uint64_t k;                // rank (1-based, from the top) still to find inside the matching values
+    uint32_t hist[256];
+};
+
+__global__ void kth_init_kernel(kth_state *__restrict__ st, uint64_t k) { st->k = k; }
+
+__global__ void kth_hist_kernel(const float *__restrict__ x, int64_t n, kth_state *__restrict__ st, int shift)
+{
+    __shared__ uint32_t h[256];
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) h[i] = 0u;
+    __syncthreads();
+    const uint32_t prefix = st->prefix, mask = st->mask;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const uint32_t o = ordered_bits(x[i]);
+        if ((o & mask) == prefix) atomicAdd(&h[(o >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 256; i += blockDim.x)
+        if (h[i]) atomicAdd(&st->hist[i], h[i]);
+}
+
+__global__ void kth_pick_kernel(kth_state *__restrict__ st, int shift, float *__restrict__ out)
+{
+    // one wave: walk the bins from the top until the k-th largest falls inside one
+    if (threadIdx.x == 0) {
+        uint64_t k = st->k;
+        int b = 255;
+        for (; b > 0; --b) {
+            const uint32_t c = st->hist[b];
+            if (k <= c) break;
+            k -= c;
+        }
+        st->k = k;
+        st->prefix |= (uint32_t)b << shift;
+        st->mask |= 255u << shift;
+        for (int i = 0; i < 256; ++i) st->hist[i] = 0u;
+        if (shift == 0 && out) *out = unordered_bits(st->prefix);
+    }
+}
+
+extern "C" int64_t eps_kth_largest_workspace_bytes(void) { return (int64_t)sizeof(kth_state); }
+
+extern "C" int eps_kth_largest_f32(const float *x, int64_t n, int64_t k, float *kth, void *workspace, void *stream)
+{
+    EPS_REQUIRE(n > 0 && k >= 1 && k <= n, "eps_kth_largest_f32: need 1 <= k <= n (k=%lld, n=%lld)", (long long)k, (long long)n);
+    EPS_REQUIRE(x && kth && workspace && ((uintptr_t)workspace & 7) == 0, "eps_kth_largest_f32: null or misaligned pointer");
+    EPS_REQUIRE(n < (1ll << 32), "eps_kth_largest_f32: histogram counters are 32-bit");
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(workspace, 0, sizeof(kth_state), s) != hipSuccess) {
+        eps_set_error("eps_kth_largest_f32: cannot initialise the state");
+        return EPS_ELAUNCH;
+    }
+    hipLaunchKernelGGL(kth_init_kernel, dim3(1), dim3(1), 0, s, (kth_state *)workspace, (uint64_t)k);
+    int64_t blocks = (n + 256 * 16 - 1) / (256 * 16);
+    const int64_t cap = (int64_t)eps_num_cus() * 8;
+    if (blocks > cap) blocks = cap;
+    for (int shift = 24; shift >= 0; shift -= 8) {
+        hipLaunchKernelGGL(kth_hist_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, n, (kth_state *)workspace, shift);
+        hipLaunchKernelGGL(kth_pick_kernel, dim3(1), dim3(64), 0, s, (kth_state *)workspace, shift, kth);
+    }
+    EPS_CHECK_LAUNCH("eps_kth_largest_f32");
+    return EPS_OK;
+}

@@ -200,6 +200,22 @@ class CSRGraph:
             self._cache[key] = CSRGraph(rowptr, c, v, self.n_rows, self.n_cols)
         return self._cache[key]
 
+    def degree_ordered(self):
+        """(graph relabelled hubs-first, perm, inv): new id i is old id perm[i], inv[perm] = arange.  The SpMM gathers one
+        row of X per stored entry; with the most-referenced rows (the hubs: 5 % of the nodes hold ~37 % of the entries of
+        the ppa-like graph) packed at the front of X they stay cache-resident: 6.25 -> 5.60 ms per layer (tools/
+        spmm_reorder.py).  Square graphs only; cached."""
+        if "deg_order" not in self._cache:
+            assert self.n_rows == self.n_cols
+            perm = torch.argsort(self.degree(), descending=True, stable=True)
+            inv = torch.empty_like(perm)
+            inv[perm] = torch.arange(self.n_rows, device=self.device)
+            row, col, val = self.coo()
+            rowptr, c, v = _coalesce(inv[row], inv[col], self.values_or_ones() if val is not None else None,
+                                     self.n_rows, self.n_cols)
+            self._cache["deg_order"] = (CSRGraph(rowptr, c, v, self.n_rows, self.n_cols), perm, inv)
+        return self._cache["deg_order"]
+
     def gcn_normalized(self) -> "CSRGraph":
         """gcn_norm of torch_geometric 1.7.0 GCNConv [third-party, restated]: A^ = A with diag := 1,
         val' = (val * deg^-1/2[row]) * deg^-1/2[col].  Computed once per adjacency on the GPU

@@ -204,6 +204,9 @@ class SAGE(_ConvStack):
     conv_cls = SAGEConv
 
 
+REORDER_MIN_NODES = 100_000      # graphs from this size on run their GNN layers on the hubs-first relabelling
+
+
 # ----------------------------------------------------------------------------------- decode
 class LinkPredictor(torch.nn.Module):
     """models.py:461-485: Hadamard -> (L-1) x [Linear, ReLU, dropout] -> Linear(hidden, out) -> sigmoid."""
@@ -277,10 +280,19 @@ class LinkGNN(torch.nn.Module):
                 xin = x
             from . import dist as epd
             rank, world = epd.world_info()
-            if world > 1 and hasattr(self.gnn, "forward_sharded"):
-                self._h = self.gnn.forward_sharded(xin, adj, rank, world, epd.all_gather_rows)
+            # large graphs run the layers on the hubs-first relabelling (graph.degree_ordered: the SpMM's gathers hit the
+            # cache more often); the embeddings come back in the caller's node order
+            relabel = adj.n_rows >= REORDER_MIN_NODES and adj.n_rows == adj.n_cols
+            if relabel:
+                adj_run, perm, inv = adj.degree_ordered()
+                xin = xin[perm].contiguous()
             else:
-                self._h = self.gnn(xin, adj)
+                adj_run = adj
+            if world > 1 and hasattr(self.gnn, "forward_sharded"):
+                h = self.gnn.forward_sharded(xin, adj_run, rank, world, epd.all_gather_rows)
+            else:
+                h = self.gnn(xin, adj_run)
+            self._h = h[inv].contiguous() if relabel else h
             self._h_key = key
         return self._h
 

@@ -451,6 +451,18 @@ def mlp_decode(h: torch.Tensor, u, v, weights: Sequence[torch.Tensor], biases: S
     return out
 
 
+def kth_largest(x: torch.Tensor, k: int) -> torch.Tensor:
+    """The k-th largest value of a float32 device vector (1-element device tensor; no host round trip): radix select."""
+    dev = _need_gpu(x)
+    _chk(x, torch.float32, "x")
+    lib = _lib.load()
+    out = torch.empty(1, dtype=torch.float32, device=dev)
+    ws = torch.empty((int(lib.eps_kth_largest_workspace_bytes()) + 7) // 8, dtype=torch.int64, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(lib.eps_kth_largest_f32(_ptr(x), x.numel(), int(k), _ptr(out), _ptr(ws), _stream(dev)), "eps_kth_largest_f32")
+    return out
+
+
 def pack_keys(score: torch.Tensor, ids: Optional[torch.Tensor] = None, id_base: int = 0) -> torch.Tensor:
     dev = _need_gpu(score, ids)
     _chk(score, torch.float32, "score"); _chk(ids, torch.int64, "ids")

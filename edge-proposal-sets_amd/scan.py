@@ -107,7 +107,7 @@ def estimate_bar(g: CSRGraph, fixw: torch.Tensor, k: int, stride: int = SAMPLE_S
     m = int(safety * k / 2 / stride) + 1                 # unordered pairs of the SAMPLE above the bar we aim at
     if m >= vals.numel():
         return None
-    return torch.topk(vals, m, largest=True, sorted=True).values[-1:].clone()
+    return ops.kth_largest(vals, m)                      # radix select on the device (csrc/topk_keys.hip)
 
 
 def _gather_varlen(t: torch.Tensor, world: int):
@@ -123,11 +123,17 @@ def _gather_varlen(t: torch.Tensor, world: int):
 
 
 def select_topk(keys: torch.Tensor, vals: torch.Tensor, k: int) -> Tuple[torch.Tensor, torch.Tensor]:
-    """The k best (score descending, key ascending) of a survivor list.  -> (keys, scores), sorted."""
-    if vals.numel() > k:
-        kth = torch.topk(vals, k, largest=True, sorted=True).values[-1]
-        m = vals >= kth                                    # every tie at the k-th score stays in until the order decides
+    """The k best DIRECTED candidates (score descending, key ascending) of a list of unordered survivors (key = v << 32 | u,
+    u < v; both orientations carry the pair's score).  -> (keys, scores), sorted.  The k-th best directed score is the
+    ceil(k/2)-th best unordered one (radix select on the device); every pair at or above it is mirrored, ties included,
+    and the declared order decides among them."""
+    k2 = (k + 1) // 2
+    if vals.numel() > k2:
+        kth = ops.kth_largest(vals, k2)
+        m = vals >= kth
         keys, vals = keys[m], vals[m]
+    keys = torch.cat([keys, ((keys & 0xFFFFFFFF) << 32) | (keys >> 32)])
+    vals = torch.cat([vals, vals])
     o = torch.argsort(keys)                                # candidate order ...
     keys, vals = keys[o], vals[o]
     o = torch.sort(vals, descending=True, stable=True).indices[:k]     # ... kept among equal scores
@@ -173,7 +179,7 @@ def scan_topk(g: CSRGraph, node_w: torch.Tensor, k: int, rank: int = 0, world: i
             # is a lower bound of the final bar -- scan again just below it.
             need = max(1, (k // 2) // world)
             if vals.numel() >= need:
-                local = torch.topk(vals, need, largest=True, sorted=True).values[-1:]
+                local = ops.kth_largest(vals, need)
             else:
                 local = torch.full((1,), float("-inf"), device=dev)
             if world > 1:
@@ -191,8 +197,7 @@ def scan_topk(g: CSRGraph, node_w: torch.Tensor, k: int, rank: int = 0, world: i
         break
     if world > 1:
         keys, vals = _gather_varlen(keys, world), _gather_varlen(vals, world)
-    mirrored = ((keys & 0xFFFFFFFF) << 32) | (keys >> 32)
-    keys, vals = select_topk(torch.cat([keys, mirrored]), torch.cat([vals, vals]), k)
+    keys, vals = select_topk(keys, vals, k)
     if stats is not None:
         stats.update(candidates=2 * n_cand_all, launches=launches, survivors=2 * n_all,
                      bar=None if bar is None else float(bar.item()))

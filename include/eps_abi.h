@@ -244,6 +244,12 @@ int eps_mlp_decode(const float *h, int64_t n_nodes, int32_t hdim, const int32_t 
  *   key = (ordered_bits(score) ^ 0x80000000) << 32 | (0xFFFFFFFF - id),   id < 2^32,
  * so a plain descending sort / top-K / k-way merge of keys -- on one GPU or across shards --
  * gives the same result.  id = ids[i] if ids != NULL else id_base + i. */
+/* k-th largest value of a float32 array (1 <= k <= n < 2^32) by radix select over the same order-preserving bit pattern:
+ * the bar of the threshold scan and the cut of the final top-K need this one value, not a sorted array.  *kth (device)
+ * receives it; torch.sort semantics for the order (-0 == +0; NaNs sort above +inf).  workspace:
+ * eps_kth_largest_workspace_bytes() bytes, 8-byte aligned, contents arbitrary. */
+int64_t eps_kth_largest_workspace_bytes(void);
+int eps_kth_largest_f32(const float *x, int64_t n, int64_t k, float *kth, void *workspace, void *stream);
 int eps_pack_keys(const float *score, const int64_t *ids_or_null, int64_t id_base, int64_t n,
                   int64_t *keys, void *stream);
 int eps_unpack_keys(const int64_t *keys, int64_t n, float *score_or_null, int64_t *id_or_null,

@@ -177,3 +177,21 @@ def test_full_size_properties_spmm_decode(eps, dev):
     # permuting the edge list permutes the outputs (tiles / workgroups are independent)
     perm = torch.randperm(E, generator=gen, device=dev)
     assert torch.equal(eps.ops.mlp_decode(h, u[perm].contiguous(), v[perm].contiguous(), ws, bs), p1[perm])
+
+
+def test_kth_largest_radix_select(eps, dev):
+    """eps_kth_largest_f32 == the k-th entry of a descending sort, incl. ties, negatives, +-0, infinities and tiny arrays."""
+    gen = torch.Generator(device=dev).manual_seed(3)
+    for n in (1, 2, 257, 100_003, 3_000_000):
+        x = torch.randn(n, generator=gen, device=dev)
+        if n > 1000:
+            x[::7] = x[3]                                  # many ties
+            x[5], x[6], x[8], x[9] = 0.0, -0.0, float("inf"), float("-inf")
+        ref = torch.sort(x, descending=True).values
+        for k in sorted({1, 2, n // 3 + 1, n // 2 + 1, n}):
+            if k > n:
+                continue
+            got = eps.ops.kth_largest(x, k)
+            assert got.shape == (1,) and float(got) == float(ref[k - 1]), (n, k)
+    with pytest.raises(eps.EpsError):
+        eps.ops.kth_largest(torch.zeros(4, device=dev), 5)

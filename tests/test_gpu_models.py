@@ -216,3 +216,24 @@ def test_row_sharded_last_layer_equals_full_forward(eps, dev, kind):
     for rank in range(world):
         parts.append(net.forward_sharded(x, g, rank, world, lambda local, bounds: local))
     assert torch.equal(torch.cat(parts, 0), full)
+
+
+@pytest.mark.parametrize("kind", ["gcn", "sage"])
+def test_hubs_first_relabelling_is_transparent(eps, dev, kind, monkeypatch):
+    """LinkGNN.embeddings on the degree-ordered relabelling of the graph (large graphs: the SpMM's gathers stay cache-
+    resident) returns the embeddings in the caller's node order, equal to the plain run up to the summation order."""
+    from eps_amd import models, synth
+    g = synth.rmat_graph(12, 12, 4, dev)
+    n = g.n_rows
+    gen = torch.Generator(device=dev).manual_seed(1)
+    x = torch.randn(n, 20, generator=gen, device=dev)
+    cls = models.GCN if kind == "gcn" else models.SAGE
+    torch.manual_seed(3)
+    model = models.LinkGNN(torch.nn.Embedding(n, 12), cls(32, 32, 32, 3, 0.0), models.LinkPredictor(32, 32, 1, 3, 0.0)).to(dev).eval()
+    plain = model.embeddings(x, g).clone()
+    monkeypatch.setattr(models, "REORDER_MIN_NODES", 1)
+    model._h_key = None
+    gp, perm, inv = g.degree_ordered()
+    assert torch.equal(perm[inv], torch.arange(n, device=dev)) and bool((gp.degree()[:-1] >= gp.degree()[1:]).all())
+    relab = model.embeddings(x, g)
+    assert float((relab - plain).abs().max()) <= 2e-5 * max(1.0, float(plain.abs().max()))
