@@ -65,10 +65,13 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float *__restrict__
                                                        const float *__restrict__ B, int64_t ldb,
                                                        const float *__restrict__ bias, int relu, int accumulate,
                                                        float *__restrict__ C, int64_t ldc, int64_t M, int32_t N,
-                                                       int32_t K, int fastA, int fastB)
+                                                       int32_t K, int fastA, int fastB, int fastC)
 {
-    __shared__ __attribute__((aligned(16))) float As[2][G_BM][G_LD];
-    __shared__ __attribute__((aligned(16))) float Bs[2][G_BN][G_LD];
+    // one LDS block: the two operand double buffers, and -- after the last K-chunk -- the staging tile of the epilogue
+    __shared__ __attribute__((aligned(16))) float smem[2 * (G_BM + G_BN) * G_LD];
+    float(*As)[G_BM][G_LD] = reinterpret_cast<float(*)[G_BM][G_LD]>(smem);
+    float(*Bs)[G_BN][G_LD] = reinterpret_cast<float(*)[G_BN][G_LD]>(smem + 2 * G_BM * G_LD);
+    static_assert(64 * (G_BN + 4) <= 2 * (G_BM + G_BN) * G_LD, "the epilogue's staging tile must fit the operand buffers");
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -151,7 +154,50 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float *__restrict__
 #undef G_GLOAD
 #undef G_LSTORE
 
-    // epilogue: C/D map of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+    // epilogue: C/D map of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
+    // Written straight from the accumulators that is 64 dword stores per lane: the store ISSUE, not the bandwidth, sets the
+    // tail of every tile.  With 16-byte aligned C rows the tile goes through LDS instead (the operand buffers are free
+    // after the last barrier): two passes of 64 rows, accumulators -> Cs[64][128+4] (conflict-free dword writes), then every
+    // thread stores 8 float4 -- lanes 0-31 one 512-byte row, lanes 32-63 the next -- bias / accumulate / ReLU applied there.
+    if (fastC) {
+        float(*Cs)[G_BN + 4] = reinterpret_cast<float(*)[G_BN + 4]>(smem);   // 64 x 132 floats = 33 KiB of the 40
+        const int c4 = (tid & 31) * 4;
+        const int cc = n0 + c4;
+        v4f bv = {0.f, 0.f, 0.f, 0.f};
+        if (bias && cc < N) bv = *reinterpret_cast<const v4f *>(bias + cc);   // N % 4 == 0 on this path
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+            if (wm == pass) {
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e)
+                            Cs[mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * h][wn * 64 + ni * 32 + r] = acc[mi][ni][e];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int rl = (tid >> 5) + 8 * i;
+                const int64_t rr = m0 + pass * 64 + rl;
+                if (rr < M && cc < N) {
+                    v4f t = *reinterpret_cast<const v4f *>(&Cs[rl][c4]) + bv;
+                    v4f *cp = reinterpret_cast<v4f *>(C + rr * ldc + cc);
+                    if (accumulate) t += *cp;
+                    if (relu) {
+                        t.x = t.x > 0.f ? t.x : 0.f;
+                        t.y = t.y > 0.f ? t.y : 0.f;
+                        t.z = t.z > 0.f ? t.z : 0.f;
+                        t.w = t.w > 0.f ? t.w : 0.f;
+                    }
+                    *cp = t;
+                }
+            }
+            if (pass == 0) __syncthreads();
+        }
+        return;
+    }
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
@@ -183,12 +229,13 @@ extern "C" int eps_gemm_f32(const float *a, int64_t lda, const float *b, int64_t
     EPS_REQUIRE(a && b && c, "eps_gemm_f32: null pointer");
     const int fastA = (lda % 4 == 0) && ((uintptr_t)a % 16 == 0);
     const int fastB = (ldb % 4 == 0) && ((uintptr_t)b % 16 == 0);
+    const int fastC = (ldc % 4 == 0) && ((uintptr_t)c % 16 == 0) && (n % 4 == 0) && (!bias || (uintptr_t)bias % 16 == 0);
     const int64_t mblk = (m + G_BM - 1) / G_BM;
     const int64_t nblk = (n + G_BN - 1) / G_BN;
     EPS_REQUIRE(mblk * nblk < (1ll << 31), "eps_gemm_f32: grid too large");
     EPS_REQUIRE(lda < (1 << 22) && ldb < (1 << 22), "eps_gemm_f32: leading dimension too large for 32-bit tile offsets");
     hipLaunchKernelGGL(gemm_f32_kernel, dim3((unsigned)(mblk * nblk)), dim3(256), 0, (hipStream_t)stream, a, lda, b,
-                       ldb, bias, relu, accumulate, c, ldc, m, n, k, fastA, fastB);
+                       ldb, bias, relu, accumulate, c, ldc, m, n, k, fastA, fastB, fastC);
     EPS_CHECK_LAUNCH("eps_gemm_f32");
     return EPS_OK;
 }
