@@ -42,6 +42,7 @@
 #define FS_RANGES 512        // id ranges per column: path histogram and tile plan
 #endif
 #define FS_CHUNK 8192        // survivor slots reserved per global atomic
+#define FS_SVCAP 384         // survivors of a column parked in LDS until its tiles are done (more: resolved on the spot)
 #ifndef FS_MAX_TILE_BITS
 #define FS_MAX_TILE_BITS 12  // candidate ranks per tile <= 4096 (8-byte accumulators in LDS)
 #endif
@@ -53,7 +54,7 @@ struct fs_layout {
     int words;      // bitmap words, a multiple of 1024
     int tile;       // candidate ranks per tile
     int o_base32, o_pre8, o_acc, o_hist, o_rinfo, o_tile_r0, o_tile_base, o_tile_cur, o_ustart, o_rbase, o_rlen,
-        o_ulist, o_vwfix, total_words;
+        o_ulist, o_vwfix, o_sv, total_words;
 };
 
 __host__ __device__ static inline fs_layout fs_make_layout(int words, int tile_bits)
@@ -75,6 +76,7 @@ __host__ __device__ static inline fs_layout fs_make_layout(int words, int tile_b
     L.o_rlen = o;    o += FS_RC + 2;
     L.o_ulist = o;   o += (FS_UR + FS_UPAD) / 2;
     L.o_vwfix = o;   o += 2 * FS_RC;
+    L.o_sv = o;      o += 2 * FS_SVCAP;
     L.total_words = o;
     return L;
 }
@@ -159,9 +161,12 @@ __global__ __launch_bounds__(FS_THREADS) void filter_scan_kernel(fs_params p)
     uint32_t *rlen = lds + L.o_rlen;                      // entries of the row below v
     uint16_t *ulist = (uint16_t *)(lds + L.o_ulist);      // unit -> row of the round, + 1
     long long *vwfix = (long long *)(lds + L.o_vwfix);    // fixed-point weight of (v, row)
+    uint32_t *sv_rank = lds + L.o_sv;                     // parked survivors: candidate rank in the window ...
+    float *sv_val = (float *)(lds + L.o_sv + FS_SVCAP);   // ... and score
     __shared__ int s_wtot[4 * FS_WAVES];
     __shared__ unsigned int s_ticket;
     __shared__ int s_done, s_next_c, s_ntiles, s_thi;
+    __shared__ unsigned int s_nsv;
     __shared__ unsigned int s_out_cur, s_out_end;
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -199,6 +204,7 @@ __global__ __launch_bounds__(FS_THREADS) void filter_scan_kernel(fs_params p)
     if (tid == 0) {
         s_out_cur = 0u;
         s_out_end = 0u;
+        s_nsv = 0u;
         ustart[FS_RC] = 0;       // the dummy row: units past the end of a round read nothing
         rbase[FS_RC] = p.col_bytes >> 2;      // past the end of col[]: the buffer load returns zeros, no traffic
         rlen[FS_RC] = 0u;
@@ -471,29 +477,39 @@ __global__ __launch_bounds__(FS_THREADS) void filter_scan_kernel(fs_params p)
 
         // ---- D. score: tiles are taken in windows; a window of one tile accumulates in LDS directly, a wider one bins ------
         //      4-byte records (rank in tile | k << tile_bits) per tile in this workgroup's scratch and sums tile by tile.
+        // A survivor's u comes from its rank: last 8-word group whose first rank is <= r, then the word, then the bit -- a
+        // chain of ~25 dependent LDS reads.  Done on the spot it sits on the critical path of its tile (one lane works, fifteen
+        // waves wait at the barrier), so survivors are parked in LDS and resolved together when the column's tiles are done.
+        auto resolve = [&](uint32_t r, float sc) {
+            auto first_rank = [&](int gi) { const uint32_t x = ginfo[gi]; return tile_r0[x >> 16] + (x & 0xFFFFu); };
+            int glo = 0, ghi = n_groups;                     // groups [glo, ghi): invariant first_rank(glo) <= r
+            while (ghi - glo > 1) {
+                const int mid = (glo + ghi) >> 1;
+                if (first_rank(mid) <= r) glo = mid; else ghi = mid;
+            }
+            const uint32_t rg = r - first_rank(glo);
+            int wi = glo * 8, wj = 7;
+            while (wj > 0 && (uint32_t)pre8[wi + wj] > rg) --wj;
+            wi += wj;
+            uint32_t bits = bm[wi];
+            for (uint32_t sidx = rg - pre8[wi]; sidx > 0; --sidx) bits &= bits - 1;
+            const uint32_t u = (uint32_t)wi * 32u + (uint32_t)__builtin_ctz(bits);
+            const uint32_t pos = atomicAdd(&s_out_cur, 1u);
+            if (pos < out_cap) {
+                out_key[pos] = ((int64_t)v << 32) | (int64_t)(u + (uint32_t)win_lo);
+                out_val[pos] = sc;
+            }
+        };
         auto scan_tile = [&](int t) {     // acc -> survivors; leaves acc zero.  Caller: barrier before (sums complete).
             const uint32_t r0 = tile_r0[t], nslots = tile_r0[t + 1] - r0;
             auto survivor = [&](uint32_t i, long long a) {
                 const float sc = (float)((double)a * (1.0 / (double)(1ll << FS_FIXED_SHIFT)));
-                // the candidate of rank r: last 8-word group whose first rank is <= r, then the word, then the bit
-                const uint32_t r = r0 + i;
-                auto first_rank = [&](int gi) { const uint32_t x = ginfo[gi]; return tile_r0[x >> 16] + (x & 0xFFFFu); };
-                int glo = 0, ghi = n_groups;                     // groups [glo, ghi): invariant first_rank(glo) <= r
-                while (ghi - glo > 1) {
-                    const int mid = (glo + ghi) >> 1;
-                    if (first_rank(mid) <= r) glo = mid; else ghi = mid;
-                }
-                const uint32_t rg = r - first_rank(glo);
-                int wi = glo * 8, wj = 7;
-                while (wj > 0 && (uint32_t)pre8[wi + wj] > rg) --wj;
-                wi += wj;
-                uint32_t bits = bm[wi];
-                for (uint32_t sidx = rg - pre8[wi]; sidx > 0; --sidx) bits &= bits - 1;
-                const uint32_t u = (uint32_t)wi * 32u + (uint32_t)__builtin_ctz(bits);
-                const uint32_t pos = atomicAdd(&s_out_cur, 1u);
-                if (pos < out_cap) {
-                    out_key[pos] = ((int64_t)v << 32) | (int64_t)(u + (uint32_t)win_lo);
-                    out_val[pos] = sc;
+                const uint32_t q = atomicAdd(&s_nsv, 1u);
+                if (q < FS_SVCAP) {
+                    sv_rank[q] = r0 + i;
+                    sv_val[q] = sc;
+                } else {
+                    resolve(r0 + i, sc);                          // the parking lot is full (a low bar): on the spot
                 }
             };
             // two sums per 16-byte LDS access (a slot past the tile's last is zero and is not a candidate)
@@ -507,7 +523,7 @@ __global__ __launch_bounds__(FS_THREADS) void filter_scan_kernel(fs_params p)
             }
         };
         auto reserve_out = [&](int t) {   // thread 0, before the barrier that precedes scan_tile(t)
-            const uint32_t nslots = tile_r0[t + 1] - tile_r0[t];
+            const uint32_t nslots = tile_r0[t + 1] - tile_r0[t] + FS_SVCAP;      // this tile's + everything parked
             if (s_out_end - s_out_cur < nslots) {
                 const uint32_t b = atomicAdd(&p.out->count, (unsigned int)FS_CHUNK);
                 s_out_cur = b;
@@ -638,7 +654,16 @@ __global__ __launch_bounds__(FS_THREADS) void filter_scan_kernel(fs_params p)
                     fs_barrier();               // accumulators zero again
                 }
             }
-            fs_barrier();           // scans done before the next window rebuilds rounds / before the bitmap is cleared
+            fs_barrier();           // scans done: the parked survivors are all in
+            {
+                const uint32_t nsv = s_nsv < FS_SVCAP ? s_nsv : FS_SVCAP;
+                if (nsv) {             // (uniform) resolve them, one per thread; room was reserved with the tiles
+                    if ((uint32_t)tid < nsv) resolve(sv_rank[tid], sv_val[tid]);
+                    fs_barrier();
+                    if (tid == 0) s_nsv = 0u;
+                    fs_barrier();
+                }
+            }
             t_lo = t_hi;
         }
         for (int i = tid; i < words_v; i += FS_THREADS) bm[i] = 0u;

@@ -14,7 +14,6 @@ fixw = scan.fixed_weights(g, w)
 order = scan.column_order(g)
 revpos = scan.reverse_positions(g)
 bar = float(os.environ.get("BAR", "2.14"))
-PRE = int(os.environ.get('PREFILTER', '1'))
 libs = []
 for path in sys.argv[1:]:
     lib = ctypes.CDLL(os.path.join(ROOT, path) if not os.path.isabs(path) else path)
@@ -30,9 +29,9 @@ ws = torch.empty(need // 8 + 1, dtype=torch.int64, device=dev)
 _splits = {}
 def splits_ptr(lib):
     """each build has its own window geometry: its own split table"""
-    lib.eps_filter_scan_windows.argtypes = [ctypes.c_int64, ctypes.c_int, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]
+    lib.eps_filter_scan_windows.argtypes = [ctypes.c_int64, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]
     w, k = ctypes.c_int64(0), ctypes.c_int64(0)
-    assert lib.eps_filter_scan_windows(g.n_rows, PRE, ctypes.byref(w), ctypes.byref(k)) == 0
+    assert lib.eps_filter_scan_windows(g.n_rows, ctypes.byref(w), ctypes.byref(k)) == 0
     key = (w.value, k.value)
     if key not in _splits:
         _splits[key] = ops.row_window_splits(g.rowptr, g.col, w.value, k.value)
@@ -46,7 +45,7 @@ for rep in range(int(os.environ.get("REPS", "6"))):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         rc = lib.eps_filter_scan(g.rowptr.data_ptr(), g.col.data_ptr(), revpos.data_ptr(), fixw.data_ptr(), splits_ptr(lib), g.n_rows, g.nnz(),
-                                 scan.max_degree(g), order.data_ptr(), order.numel(), PRE, res.rec.data_ptr(), ws.data_ptr(), ws.numel() * 8,
+                                 scan.max_degree(g), order.data_ptr(), order.numel(), res.rec.data_ptr(), ws.data_ptr(), ws.numel() * 8,
                                  torch.cuda.current_stream().cuda_stream)
         e1.record(); torch.cuda.synchronize()
         assert rc == 0, name
