@@ -31,7 +31,7 @@ from . import ops
 from .graph import CSRGraph
 
 SAMPLE_STRIDE = 256        # every n-th column (heaviest-first order) estimates the bar
-SAFETY = 3.0               # aim at SAFETY x K survivors
+SAFETY = 2.0               # aim at SAFETY x K survivors (the estimate has been within 10 % on the ppa-sized graphs; too few -> one more scan)
 SMALL_SET = 1 << 25        # candidate sets with at most this many two-hop half paths are scanned without a bar
 _CHUNK_SLACK = 8192 * 320  # survivor slots are handed out in chunks of 8192 per workgroup
 
