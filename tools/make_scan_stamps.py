@@ -51,13 +51,17 @@ rep('''            t_lo = t_hi;
             t_lo = t_hi;
         }
         XS(t7); XA(4, t4, t7);''')
-rep('''        for (int i = tid; i < words_v; i += FS_THREADS) bm[i] = 0u;
+rep('''        }
     }
-}''', '''        for (int i = tid; i < words_v; i += FS_THREADS) bm[i] = 0u;
+}
+
+// ---- per-graph tables''', '''        }
     }
     if (tid == 0)
         for (int i = 0; i < 16; ++i) atomicAdd(&g_fs_stamp[i], xst[i]);
-}''')
+}
+
+// ---- per-graph tables''')
 # inside record-mode D2, per tile: accumulate / wait at the barrier / scan / wait at the barrier; and the D1 walk
 rep('''                for (int t = t_lo; t < t_hi; ++t) {
                     const uint32_t cb0 = b0, cn = n;''', '''                XS(d0); XA(8, t5, d0);
