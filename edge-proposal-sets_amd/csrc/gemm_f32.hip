@@ -19,7 +19,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define G_BM 128
 #define G_BN 128
 #ifndef G_BK
-#define G_BK 16  // 40 KiB of LDS per workgroup -> three resident workgroups per CU (132 VGPRs); 32 and 64 measured slower
+#define G_BK 16  // 40 KiB of LDS per workgroup -> four resident workgroups per CU on the aligned path (128 VGPRs); 32 and 64 measured slower
 #endif
 #define G_LD (G_BK + 4)
 #define G_F4 (G_BK / 4)          // float4 per tile row
@@ -31,9 +31,11 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 // One float4 of an operand tile through a raw buffer descriptor that covers rows [row0, nrows) of the matrix:
 // rows past the end fall outside the descriptor and read as zeros (no exec-mask branch), the K tail is pushed out
 // of range by a select on the offset.  `fast` == rows 16-byte aligned (ld % 4 == 0); otherwise four dword loads.
+template <bool ALIGNED>
 __device__ __forceinline__ v4f tile_load4(__amdgpu_buffer_rsrc_t rs, int row, int ld, int k, int kmax, bool fast)
 {
     const int off = (row * ld + k) * 4;
+    if (ALIGNED) return __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rs, k + 3 < kmax ? off : 0x7ffffff0, 0, 0));
     if (fast) {
         v4f t = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rs, k + 3 < kmax ? off : 0x7ffffff0, 0, 0));
         if (k < kmax && k + 3 >= kmax) {  // straddling float4 of the K tail (K % 4 != 0): element-wise
@@ -61,12 +63,18 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t tile_rsrc(const float *base, i
     return __builtin_amdgcn_make_buffer_rsrc((void *)(base + row0 * ld), 0, (int)bytes, 0x00020000);
 }
 
-__global__ __launch_bounds__(256) void gemm_f32_kernel(const float *__restrict__ A, int64_t lda,
+// ALIGNED: every operand row and the C rows are 16-byte aligned and K % 4 == 0 (every layer of the recipes): no
+// element-wise tail paths, which keeps the kernel at 128 VGPRs = four workgroups (16 waves) per CU instead of three
+// (r02 lab, tools/gemm_lab.hip: 104 -> 110 TF), and the MFMA groups run at raised wave priority so that a wave with
+// matrix work is issued ahead of the waves that are staging operands (-> 118 TF).
+template <bool ALIGNED>
+__global__ __launch_bounds__(256, ALIGNED ? 4 : 2) void gemm_f32_kernel(const float *__restrict__ A, int64_t lda,
                                                        const float *__restrict__ B, int64_t ldb,
                                                        const float *__restrict__ bias, int relu, int accumulate,
                                                        float *__restrict__ C, int64_t ldc, int64_t M, int32_t N,
-                                                       int32_t K, int fastA, int fastB, int fastC)
+                                                       int32_t K, int fastA_, int fastB_, int fastC_)
 {
+    const bool fastA = ALIGNED || fastA_, fastB = ALIGNED || fastB_, fastC = ALIGNED || fastC_;
     // one LDS block: the two operand double buffers, and -- after the last K-chunk -- the staging tile of the epilogue
     __shared__ __attribute__((aligned(16))) float smem[2 * (G_BM + G_BN) * G_LD];
     float(*As)[G_BM][G_LD] = reinterpret_cast<float(*)[G_BM][G_LD]>(smem);
@@ -101,8 +109,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float *__restrict__
     {                                                                                           \
         const int q = tid + 256 * i;                                                            \
         const int row = q / G_F4, c4 = q % G_F4;                                                \
-        ra[i] = tile_load4(ra_rs, row, ilda, (kc)*G_BK + c4 * 4, K, fastA);                     \
-        rb[i] = tile_load4(rb_rs, row, ildb, (kc)*G_BK + c4 * 4, K, fastB);                     \
+        ra[i] = tile_load4<ALIGNED>(ra_rs, row, ilda, (kc)*G_BK + c4 * 4, K, fastA);                     \
+        rb[i] = tile_load4<ALIGNED>(rb_rs, row, ildb, (kc)*G_BK + c4 * 4, K, fastB);                     \
     }
 #define G_LSTORE(buf)                                                                           \
     _Pragma("unroll") for (int i = 0; i < G_NLD; ++i)                                           \
@@ -134,6 +142,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float *__restrict__
         for (int j = 0; j < G_NJ; ++j) {
             const float av0[4] = {a0[j].x, a0[j].y, a0[j].z, a0[j].w}, av1[4] = {a1[j].x, a1[j].y, a1[j].z, a1[j].w};
             const float bv0[4] = {b0[j].x, b0[j].y, b0[j].z, b0[j].w}, bv1[4] = {b1[j].x, b1[j].y, b1[j].z, b1[j].w};
+            __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[s], bv0[s], acc[0][0], 0, 0, 0);
@@ -141,6 +150,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float *__restrict__
                 acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[s], bv0[s], acc[1][0], 0, 0, 0);
                 acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[s], bv1[s], acc[1][1], 0, 0, 0);
             }
+            __builtin_amdgcn_s_setprio(0);
             if (j == G_NJ / 2) {
                 // the other LDS buffer has been free since the last barrier: park the next chunk there while the
                 // matrix pipe still has a quarter of this chunk queued, so the barrier below finds the writes done
@@ -234,8 +244,12 @@ extern "C" int eps_gemm_f32(const float *a, int64_t lda, const float *b, int64_t
     const int64_t nblk = (n + G_BN - 1) / G_BN;
     EPS_REQUIRE(mblk * nblk < (1ll << 31), "eps_gemm_f32: grid too large");
     EPS_REQUIRE(lda < (1 << 22) && ldb < (1 << 22), "eps_gemm_f32: leading dimension too large for 32-bit tile offsets");
-    hipLaunchKernelGGL(gemm_f32_kernel, dim3((unsigned)(mblk * nblk)), dim3(256), 0, (hipStream_t)stream, a, lda, b,
-                       ldb, bias, relu, accumulate, c, ldc, m, n, k, fastA, fastB, fastC);
+    if (fastA && fastB && fastC && k % 4 == 0)
+        hipLaunchKernelGGL(gemm_f32_kernel<true>, dim3((unsigned)(mblk * nblk)), dim3(256), 0, (hipStream_t)stream, a, lda, b,
+                           ldb, bias, relu, accumulate, c, ldc, m, n, k, 1, 1, 1);
+    else
+        hipLaunchKernelGGL(gemm_f32_kernel<false>, dim3((unsigned)(mblk * nblk)), dim3(256), 0, (hipStream_t)stream, a, lda, b,
+                           ldb, bias, relu, accumulate, c, ldc, m, n, k, fastA, fastB, fastC);
     EPS_CHECK_LAUNCH("eps_gemm_f32");
     return EPS_OK;
 }

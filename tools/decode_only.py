@@ -21,5 +21,12 @@ for nl in (2, 3):
 w = torch.randn(H, H, generator=gen, device=dev)
 for _ in range(3):
     ops.gemm(x, w)
+# the layer shape of the ppa recipe with its fused epilogue: [N x 316] x [316 x 256] + bias, ReLU
+x316 = torch.randn(N, 316, generator=gen, device=dev)
+w316 = torch.randn(H, 316, generator=gen, device=dev)
+b316 = torch.randn(H, generator=gen, device=dev)
+y = torch.empty(N, H, device=dev)
+for _ in range(6):
+    ops.gemm(x316, w316, bias=b316, relu=True, out=y)
 torch.cuda.synchronize()
 print("ok")
