@@ -135,6 +135,14 @@ __device__ __forceinline__ int fs_wave_incl_max(int x, int)
 // waves of this kernel go through LDS except one (bucket records: D1 -> D2), which keeps __syncthreads().
 __device__ __forceinline__ void fs_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// 16-byte store to a dword-aligned address (global memory takes unaligned vector stores)
+typedef uint32_t fs_u4a4 __attribute__((ext_vector_type(4), aligned(4)));
+__device__ __forceinline__ void fs_store4(uint32_t *dst, uint32_t a, uint32_t b, uint32_t c, uint32_t d)
+{
+    fs_u4a4 v = {a, b, c, d};
+    *(fs_u4a4 *)dst = v;
+}
+
 // one quad of units in flight: the 16 bytes a lane loaded plus where they came from
 struct fs_unit {
     v4i u4;
@@ -353,13 +361,23 @@ __global__ __launch_bounds__(FS_THREADS) void filter_scan_kernel(fs_params p)
             single = j == 0 && c == 0 && nj >= dv;
             walk(n_units, [&](const fs_unit &f) {
                 // no branches: an entry past the row head ORs / adds 0 (into whatever word its stale id names: ids < N)
+                uint32_t rg[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     uint32_t u = (uint32_t)(f.u4[e] - win_lo);
                     if (WINDOWED) u = u < id_max ? u : id_max;         // (a stale id may lie outside the window: clamp)
                     const uint32_t on = e < f.nvalid ? 1u : 0u;
                     atomicOr(&bm[u >> 5], on << (u & 31));
-                    atomicAdd(&hist[u >> range_shift], on);
+                    rg[e] = u >> range_shift;
+                }
+                // a lane's entries ascend: when the first and the last valid one share an id range all of them do -- one add
+                const uint32_t rlast = rg[f.nvalid > 0 ? f.nvalid - 1 : 0];
+                if (rg[0] == rlast) {
+                    atomicAdd(&hist[rg[0]], (uint32_t)f.nvalid);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (e < f.nvalid) atomicAdd(&hist[rg[e]], 1u);
                 }
             });
             j = nj;
@@ -594,6 +612,12 @@ __global__ __launch_bounds__(FS_THREADS) void filter_scan_kernel(fs_params p)
                         const uint32_t tfirst = cand[0] ? tl[0] : cand[1] ? tl[1] : cand[2] ? tl[2] : tl[3];
                         const uint32_t tlast = cand[3] ? tl[3] : cand[2] ? tl[2] : cand[1] ? tl[1] : tl[0];
                         uint32_t pos[4];
+                        if (ncand == 4u && tfirst == tlast) {
+                            // the common lane: four candidates of one tile -> four consecutive records, ONE 16-byte store
+                            // (dword-aligned; four scattered 4-byte stores cost four write requests per 64-byte chunk)
+                            const uint32_t p0 = atomicAdd(&tile_cur[(uint32_t)t_lo + tfirst], 4u);
+                            fs_store4(my_scratch + p0, rank[0] | krec, rank[1] | krec, rank[2] | krec, rank[3] | krec);
+                        } else {
                         if (tfirst == tlast || ncand == 0) {
                             pos[0] = atomicAdd(&tile_cur[ncand ? (uint32_t)t_lo + tfirst : (uint32_t)(FS_RANGES + lane)], ncand);
                             pos[1] = pos[0] + cand[0];
@@ -607,6 +631,7 @@ __global__ __launch_bounds__(FS_THREADS) void filter_scan_kernel(fs_params p)
                         // one store per entry, no branch: what is not a candidate of the window lands in the trash line
 #pragma unroll
                         for (int e = 0; e < 4; ++e) my_scratch[cand[e] ? pos[e] : p.cap_records + lane] = rank[e] | krec;
+                        }
                     });
                 }
                 j = nj;
