@@ -309,9 +309,9 @@ def main():
 
     g = synth.ppa_like(seed=3, device=dev, n_nodes=args.nodes, n_undirected=args.edges)
     w = node_weight_table(g, ops.W_AA)
-    scan.column_order(g)                           # per-graph tables (revpos, half paths, order): built once, like the graph
-    scan.fixed_weights(g, w)
-    half_paths_total = int(scan.half_paths(g).sum())
+    gs, _ = scan.scan_graph(g, build=True)         # per-graph tables, built once like the graph: the hubs-first relabelled
+    scan.column_order(gs)                          # copy the scan runs on, its revpos / half paths / column order
+    half_paths_total = int(scan.half_paths(gs).sum())
     strong = args.scaling == "strong" and world > 1
     torch.cuda.synchronize(dev)
 

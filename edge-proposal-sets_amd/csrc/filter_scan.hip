@@ -172,7 +172,7 @@ __global__ __launch_bounds__(FS_THREADS) void filter_scan_kernel(fs_params p)
     uint32_t *sv_rank = lds + L.o_sv;                     // parked survivors: candidate rank in the window ...
     float *sv_val = (float *)(lds + L.o_sv + FS_SVCAP);   // ... and score
     __shared__ int s_wtot[4 * FS_WAVES];
-    __shared__ unsigned int s_ticket;
+    __shared__ unsigned int s_tq;
     __shared__ int s_done, s_next_c, s_ntiles, s_thi;
     __shared__ unsigned int s_nsv;
     __shared__ unsigned int s_out_cur, s_out_end;
@@ -218,17 +218,57 @@ __global__ __launch_bounds__(FS_THREADS) void filter_scan_kernel(fs_params p)
         rlen[FS_RC] = 0u;
     }
 
-    for (;;) {
-        fs_barrier();
-        if (tid == 0) s_ticket = atomicAdd(p.next_col, 1u);
-        fs_barrier();
-        if (s_ticket >= (unsigned int)p.n_columns) break;
-        const int32_t v = p.columns[s_ticket];
-        const int64_t vb = p.rowptr[v];
-        const int32_t dv = (int32_t)(p.rowptr[v + 1] - vb);
-        if (dv == 0 || v == 0) continue;
+    // Columns are handed out by a device counter.  A column starts with a chain of dependent round trips -- ticket -> column
+    // id -> row bounds -> neighbour list -> row descriptors -> first entries -- during which the CU's only workgroup has
+    // nothing else to do, so the first links are fetched AHEAD, in stages that each ride on a wait the current column has
+    // anyway: while column n marks its endpoints the ticket of column n + 3, the id of column n + 2 and the row bounds of
+    // column n + 1 are in flight (stage 1); they are picked up after the marking walk (stage 2).
+    const uint32_t *__restrict__ rowptr_lo = (const uint32_t *)p.rowptr;     // nnz < 2^30: the low words suffice
+    const unsigned int ncol = (unsigned int)p.n_columns;
+    // (the first three tickets of a workgroup are static -- one column of each of the three heaviest grid-wide rounds --, the
+    // counter hands out the rest)
+    const unsigned int t_static = 3u * gridDim.x;
+    int32_t v_cur = -1, v_nx = -1;
+    uint32_t vb_cur = 0, t_nx2 = blockIdx.x + 2u * gridDim.x;
+    int32_t dv_cur = 0;
+    {
+        const unsigned int t0 = blockIdx.x;
+        if (t0 < ncol) {
+            v_cur = p.columns[t0];
+            vb_cur = rowptr_lo[2 * (size_t)v_cur];
+            dv_cur = (int32_t)(rowptr_lo[2 * (size_t)v_cur + 2] - vb_cur);
+        }
+        if (t0 + gridDim.x < ncol) v_nx = p.columns[t0 + gridDim.x];
+    }
+    while (v_cur >= 0) {
+        const int32_t v = v_cur;
+        const uint32_t vb = vb_cur;
+        const int32_t dv = dv_cur;
         const int32_t *__restrict__ vcol = p.col + vb;
         const int32_t *__restrict__ vrev = p.revpos + vb;
+        int staged = 0;
+        unsigned int pf_t = 0;
+        int32_t pf_v = -1;
+        uint32_t pf_b = 0, pf_e = 0;
+        auto stage1 = [&]() {
+            staged = 1;
+            if (tid == 0) pf_t = t_static + atomicAdd(p.next_col, 1u);
+            if (t_nx2 < ncol) pf_v = p.columns[t_nx2];
+            if (v_nx >= 0) {
+                pf_b = rowptr_lo[2 * (size_t)v_nx];
+                pf_e = rowptr_lo[2 * (size_t)v_nx + 2];
+            }
+        };
+        int32_t v_nx2 = -1, dv_nx = 0;
+        uint32_t vb_nx = 0;
+        auto stage2 = [&]() {
+            staged = 2;
+            if (tid == 0) s_tq = pf_t;
+            v_nx2 = __builtin_amdgcn_readfirstlane(pf_v);
+            vb_nx = __builtin_amdgcn_readfirstlane(pf_b);
+            dv_nx = (int32_t)(__builtin_amdgcn_readfirstlane(pf_e) - vb_nx);
+        };
+        if (dv != 0 && v != 0) {
         // The endpoints below v are taken in id WINDOWS of win_ids ids (one window when the whole id space fits the LDS):
         // window k sees of every row head only the entries inside it -- rows are ascending and splits[] holds, per node,
         // how many of its entries lie below each window boundary -- and runs the whole pipeline on ids relative to its start.
@@ -359,6 +399,7 @@ __global__ __launch_bounds__(FS_THREADS) void filter_scan_kernel(fs_params p)
             n_units = build_round(j, c);
             const int nj = j + s_done, nc = s_next_c;
             single = j == 0 && c == 0 && nj >= dv;
+            if (staged < 1) stage1();
             walk(n_units, [&](const fs_unit &f) {
                 // no branches: an entry past the row head ORs / adds 0 (into whatever word its stale id names: ids < N)
                 uint32_t rg[4];
@@ -385,6 +426,7 @@ __global__ __launch_bounds__(FS_THREADS) void filter_scan_kernel(fs_params p)
             if (j >= dv) break;
             fs_barrier();       // the next round overwrites the descriptors this walk reads
         }
+        if (staged < 2) stage2();
         fs_barrier();
         for (int k = tid; k < dv; k += FS_THREADS) {   // known edges out (the diagonal is not below v)
             const uint32_t u = (uint32_t)(vcol[k] - win_lo);
@@ -695,6 +737,18 @@ __global__ __launch_bounds__(FS_THREADS) void filter_scan_kernel(fs_params p)
         if (!WINDOWED) break;
         fs_barrier();                  // the next window marks into the words other threads just cleared
         }
+        }
+        if (staged == 0) {             // (a column without work: the stages still have to run)
+            stage1();
+            fs_barrier();              // every thread has read the previous ticket
+            stage2();
+        }
+        fs_barrier();                  // thread 0's ticket is in LDS; the column's LDS state is clean
+        t_nx2 = __builtin_amdgcn_readfirstlane(s_tq);
+        v_cur = v_nx;
+        vb_cur = vb_nx;
+        dv_cur = dv_nx;
+        v_nx = v_nx2;
     }
 }
 

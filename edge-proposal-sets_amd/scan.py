@@ -34,6 +34,7 @@ SAMPLE_STRIDE = 256        # every n-th column (heaviest-first order) estimates 
 SAFETY = 2.0               # aim at SAFETY x K survivors (the estimate has been within 10 % on the ppa-sized graphs; too few -> one more scan)
 SMALL_SET = 1 << 25        # candidate sets with at most this many two-hop half paths are scanned without a bar
 _CHUNK_SLACK = 8192 * 320  # survivor slots are handed out in chunks of 8192 per workgroup
+RELABEL_MIN_NODES = 100_000  # graphs at least this large are scanned under hubs-first labels (see scan_graph)
 
 
 def scan_available(g: CSRGraph) -> bool:
@@ -83,6 +84,40 @@ def fixed_weights(g: CSRGraph, node_w: torch.Tensor) -> torch.Tensor:
     if key not in g._cache:
         g._cache[key] = ops.fixed_weights(node_w)
     return g._cache[key]
+
+
+def scan_graph(g: CSRGraph, build: bool = False):
+    """(graph to scan, perm): large graphs are scanned under hubs-first labels (``CSRGraph.degree_ordered``: new id i is
+    old id perm[i]); perm is None when the graph is scanned as it is.  The symmetric scheme gives column v the endpoints
+    u < v, so the labelling decides how the half paths spread over the columns: as generated the ppa-like graph has columns
+    of up to 3.7 M half paths (several rounds of row descriptors, several windows of tiles, buckets far beyond the L2);
+    hubs first no column has more than 64 k -- the same 8.35 G paths in uniform columns: 47.8 -> 44.8 ms per scan
+    (tools/scan_ab.py RELABEL=1).  Scores do not depend on the labels (order-independent fixed-point sums).
+    Relabelling sorts the stored entries once (~35 ms for 42.5 M): worth it for a graph that is scanned repeatedly, not
+    for one scan -- so the relabelled copy is used when it exists (``build=True`` makes it; the GNN path builds the same
+    copy for its SpMM) and a one-shot caller (filter.py) scans the graph as it is."""
+    if g.n_rows < RELABEL_MIN_NODES or not (build or "deg_order" in g._cache):
+        return g, None
+    gs, perm, _ = g.degree_ordered()
+    return gs, perm
+
+
+def _scan_weights(g: CSRGraph, gs: CSRGraph, perm, node_w: torch.Tensor) -> torch.Tensor:
+    """Fixed-point weight table in the labels of the scanned graph (cached on the original graph per weight tensor)."""
+    if perm is None:
+        return fixed_weights(g, node_w)
+    key = ("fixw_relabelled", node_w.data_ptr(), node_w._version)
+    if key not in g._cache:
+        g._cache[key] = ops.fixed_weights(node_w[perm].contiguous())
+    return g._cache[key]
+
+
+def _original_keys(keys: torch.Tensor, perm) -> torch.Tensor:
+    """Survivor keys (v << 32 | u, u < v in the scanned graph's labels) -> the same unordered pairs in the original labels."""
+    if perm is None:
+        return keys
+    a, b = perm[keys & 0xFFFFFFFF], perm[keys >> 32]
+    return (torch.maximum(a, b) << 32) | torch.minimum(a, b)
 
 
 def _launch(g, fixw, columns, threshold, capacity) -> ops.Survivors:
@@ -140,14 +175,18 @@ def select_topk(keys: torch.Tensor, vals: torch.Tensor, k: int) -> Tuple[torch.T
     return keys[o], vals[o]
 
 
-def scan_topk(g: CSRGraph, node_w: torch.Tensor, k: int, rank: int = 0, world: int = 1, stats: Optional[dict] = None):
+def scan_topk(g: CSRGraph, node_w: torch.Tensor, k: int, rank: int = 0, world: int = 1, stats: Optional[dict] = None,
+              relabel: bool = False):
     """Exact top-``k`` candidates of the whole graph: (pairs int64 [2,<=k] as (u; v), scores float32), best first.
-    ``stats`` (optional dict) receives ``candidates`` (directed candidates scored), ``launches``, ``survivors``, ``bar``."""
+    ``stats`` (optional dict) receives ``candidates`` (directed candidates scored), ``launches``, ``survivors``, ``bar``.
+    ``relabel``: build the hubs-first copy of a large graph if it does not exist yet (see ``scan_graph``)."""
     if not scan_available(g):
         raise ops._lib.EpsError("scan_topk: graph not supported by eps_filter_scan (see scan_available)")
     k = int(k)
     dev = g.device
-    fixw = fixed_weights(g, node_w)
+    g0 = g
+    g, perm = scan_graph(g0, relabel)    # from here on g is the graph as scanned; ids go back through perm at the end
+    fixw = _scan_weights(g0, g, perm, node_w)
     order = column_order(g)
     mine = order if world == 1 else order[rank::world].contiguous()
     total_half = int(half_paths(g).sum().item())
@@ -195,6 +234,7 @@ def scan_topk(g: CSRGraph, node_w: torch.Tensor, k: int, rank: int = 0, world: i
                 capacity = min(2 * (2 * total_half // world) + _CHUNK_SLACK, (1 << 32) - 1)
             continue
         break
+    keys = _original_keys(keys, perm)
     if world > 1:
         keys, vals = _gather_varlen(keys, world), _gather_varlen(vals, world)
     keys, vals = select_topk(keys, vals, k)

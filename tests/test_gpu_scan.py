@@ -114,24 +114,32 @@ def test_scan_topk_is_exact(eps, oracle, dev, monkeypatch):
     wt = node_weight_table(g, eps.ops.W_AA)
     _, cu, cv, _, sc = eps.ops.expand_candidates(g.rowptr, g.col, None, wt, g.n_rows, 0, g.n_rows, want_cn=False)
     order = torch.sort(sc, descending=True, stable=True).indices           # candidate order is column-major already
-    for k in (1, 1000, 77777, int(sc.numel()) + 5):
-        kk = min(k, sc.numel())
-        want_pairs = torch.stack([cu[order[:kk]], cv[order[:kk]]]).long()
-        want_sc = sc[order[:kk]]
-        st = {}
-        pairs, scores = scan.scan_topk(g, wt, k, stats=st)
-        assert torch.equal(pairs, want_pairs) and torch.equal(scores, want_sc)
-        assert st["candidates"] == sc.numel()
-    # force the estimate path (sample -> bar -> verify) with strides that make the estimate poor in both directions
-    monkeypatch.setattr(scan, "SMALL_SET", 0)
-    for stride, safety in ((7, 3.0), (64, 3.0), (3, 0.02), (5, 500.0)):
-        monkeypatch.setattr(scan, "SAMPLE_STRIDE", stride)
-        monkeypatch.setattr(scan, "SAFETY", safety)
-        k = 20000
-        st = {}
-        pairs, scores = scan.scan_topk(g, wt, k, stats=st)
-        assert torch.equal(pairs, torch.stack([cu[order[:k]], cv[order[:k]]]).long()), (stride, safety, st)
-        assert torch.equal(scores, sc[order[:k]])
+    small_set = scan.SMALL_SET
+    # as labelled, then under the hubs-first relabelling large graphs are scanned with (ids mapped back, same tie rule)
+    for relabel_min in (scan.RELABEL_MIN_NODES, 0):
+        monkeypatch.setattr(scan, "RELABEL_MIN_NODES", relabel_min)
+        monkeypatch.setattr(scan, "SMALL_SET", small_set)
+        monkeypatch.setattr(scan, "SAMPLE_STRIDE", 256)
+        monkeypatch.setattr(scan, "SAFETY", 2.0)
+        assert (scan.scan_graph(g, build=relabel_min == 0)[1] is None) == (relabel_min > 0)
+        for k in (1, 1000, 77777, int(sc.numel()) + 5):
+            kk = min(k, sc.numel())
+            want_pairs = torch.stack([cu[order[:kk]], cv[order[:kk]]]).long()
+            want_sc = sc[order[:kk]]
+            st = {}
+            pairs, scores = scan.scan_topk(g, wt, k, stats=st)
+            assert torch.equal(pairs, want_pairs) and torch.equal(scores, want_sc)
+            assert st["candidates"] == sc.numel()
+        # force the estimate path (sample -> bar -> verify) with strides that make the estimate poor in both directions
+        monkeypatch.setattr(scan, "SMALL_SET", 0)
+        for stride, safety in ((7, 3.0), (64, 3.0), (3, 0.02), (5, 500.0)):
+            monkeypatch.setattr(scan, "SAMPLE_STRIDE", stride)
+            monkeypatch.setattr(scan, "SAFETY", safety)
+            k = 20000
+            st = {}
+            pairs, scores = scan.scan_topk(g, wt, k, stats=st)
+            assert torch.equal(pairs, torch.stack([cu[order[:k]], cv[order[:k]]]).long()), (stride, safety, st)
+            assert torch.equal(scores, sc[order[:k]])
     # the oracle's float32 scores agree within the gate on the selected rows
     rp, col = A.indptr.astype(np.int64), A.indices.astype(np.int32)
     w = oracle.node_weights(oracle.col_sums(rp, col, None, g.n_rows), oracle.W_AA)
@@ -174,6 +182,10 @@ def test_scan_full_size_properties(eps, dev):
     assert int(hit.sum()) >= pairs.shape[1] - 2                                 # at most the K-th tie loses its mirror
     p2, s2 = scan.scan_topk(g, wt, 1_000_000)
     assert torch.equal(p2, pairs) and torch.equal(s2, scores)
+    # the same scan under hubs-first labels (what a repeatedly scanned graph runs on): ids mapped back, bit-identical list
+    p3, s3 = scan.scan_topk(g, wt, 1_000_000, relabel=True)
+    assert scan.scan_graph(g)[1] is not None
+    assert torch.equal(p3, pairs) and torch.equal(s3, scores)
 
 
 def test_scan_wide_id_space_in_windows(eps, oracle, dev):

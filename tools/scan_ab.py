@@ -9,9 +9,15 @@ from eps_amd import ops, scan, synth, _lib
 from eps_amd.heuristics import node_weight_table
 dev = torch.device("cuda:0")
 g = synth.ppa_like(seed=3, device=dev, n_nodes=int(os.environ.get('NODES', 576289)), n_undirected=int(os.environ.get('EDGES', 21231931)))
+if os.environ.get("RELABEL") == "1":       # hubs first: column v (endpoints u < v) then needs a bitmap of the HEAVIER nodes only
+    g = g.degree_ordered()[0]
 w = node_weight_table(g, ops.W_AA)
 fixw = scan.fixed_weights(g, w)
 order = scan.column_order(g)
+if os.environ.get("COLMAX"):               # only the columns with id < COLMAX (>= -COLMAX when negative)
+    cm = int(os.environ["COLMAX"])
+    order = order[order < cm].contiguous() if cm > 0 else order[order >= -cm].contiguous()
+    print("columns", order.numel(), "half paths", int(scan.half_paths(g)[order.long()].sum()))
 revpos = scan.reverse_positions(g)
 bar = float(os.environ.get("BAR", "2.14"))
 libs = []
