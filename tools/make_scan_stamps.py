@@ -20,13 +20,11 @@ extern "C" int eps_debug_scan_stamps(unsigned long long *out16, int reset)
     return 0;
 }
 struct fs_params {''')
-rep('''    for (;;) {
-        fs_barrier();
-        if (tid == 0) s_ticket = atomicAdd(p.next_col, 1u);''', '''    unsigned long long xst[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    for (;;) {
+rep('''    while (v_cur >= 0) {
+        const int32_t v = v_cur;''', '''    unsigned long long xst[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    while (v_cur >= 0) {
         XS(t0);
-        fs_barrier();
-        if (tid == 0) s_ticket = atomicAdd(p.next_col, 1u);''')
+        const int32_t v = v_cur;''')
 rep('''        int j = 0, c = 0;
         bool single = false;''', '''        XS(t1); XA(0, t0, t1);
         int j = 0, c = 0;
@@ -51,17 +49,15 @@ rep('''            t_lo = t_hi;
             t_lo = t_hi;
         }
         XS(t7); XA(4, t4, t7);''')
-rep('''        }
+rep('''        v_nx = v_nx2;
     }
 }
-
-// ---- per-graph tables''', '''        }
+''', '''        v_nx = v_nx2;
     }
     if (tid == 0)
         for (int i = 0; i < 16; ++i) atomicAdd(&g_fs_stamp[i], xst[i]);
 }
-
-// ---- per-graph tables''')
+''')
 # inside record-mode D2, per tile: accumulate / wait at the barrier / scan / wait at the barrier; and the D1 walk
 rep('''                for (int t = t_lo; t < t_hi; ++t) {
                     const uint32_t cb0 = b0, cn = n;''', '''                XS(d0); XA(8, t5, d0);
