@@ -140,12 +140,10 @@ def run(args) -> str:
     if not torch.cuda.is_available():
         raise RuntimeError("filter stage needs a HIP device: the scoring path has no CPU fallback")
     # one process per GPU under torchrun (WORLD_SIZE > 1): candidate COLUMNS are sharded, the graph is replicated, the
-    # only exchange is the final top-K merge (needs --keep_top: rank.py never reads past num_sorted_edge rows anyway)
+    # only exchange is the final merge (top-K lists under --keep_top, else the shards of the full list)
     from . import dist as epd
     rank, world, dist_dev = epd.init_from_env(args.dist_backend, args.device)
     device = dist_dev if world > 1 else torch.device(f'cuda:{args.device or 0}')
-    if world > 1 and not args.keep_top:
-        raise ValueError("multi-GPU filter needs --keep_top K (the full [E,3] list is not gathered)")
 
     edge_index, edge_weight, split_edge, data = get_data(args)
     data = data.to(device)
@@ -233,8 +231,15 @@ def run(args) -> str:
                                                                    [gs[r][:cnt[r]] for r in range(world)], keep)
         sorted_edges = torch.cat([best_pairs.t().to(torch.float32), best_scores.unsqueeze(1)], 1)
     else:
-        pairs = torch.cat(all_pairs, 1)
-        scores = torch.cat(all_scores)
+        pairs = torch.cat(all_pairs, 1) if all_pairs else torch.zeros((2, 0), dtype=torch.int64, device=device)
+        scores = torch.cat(all_scores) if all_scores else torch.zeros(0, dtype=torch.float32, device=device)
+        if world > 1:
+            # the full list: ranks hold contiguous column ranges in rank order, so the shards concatenated in rank order ARE
+            # the single-process candidate order -- one variable-length all-gather (20 B per candidate; sized for lists that
+            # fit one GPU, which is what a file of all [E,3] rows presupposes), then the same sort on every rank
+            pairs = torch.stack([scan._gather_varlen(pairs[0].contiguous(), world),
+                                 scan._gather_varlen(pairs[1].contiguous(), world)])
+            scores = scan._gather_varlen(scores, world)
         sorted_edges = proposals.sorted_edges_tensor(pairs, scores)          # filter.py:160-161
     return _save(args, spec, sorted_edge_path, num_sorted_edge, run_id, rank, world, sorted_edges)
 

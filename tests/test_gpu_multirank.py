@@ -86,6 +86,26 @@ def _scan_case(tmp_path, model):
     assert single.shape == (5000, 3) and torch.equal(single, multi)
 
 
+@pytest.mark.parametrize("model,dataset", [("adamic_ogb", "collab"), ("simple", "ddi")])
+def test_filter_two_ranks_full_list(eps, dev, tmp_path, model, dataset, monkeypatch):
+    """Without --keep_top the reference writes ALL [E,3] rows: two ranks score their column shards, the shards are gathered in
+    rank order (= candidate order) and sorted -- the file equals the single-process one bit for bit."""
+    from eps_amd import filter_stage
+    os.chdir(tmp_path)
+    monkeypatch.setenv("EPS_SYNTH_SCALE", "0.25")
+    argv = lambda run: ["--dataset", dataset, "--model", model, "--checkpoint", f"{dataset}_{model}||0|{run}.pt",  # noqa: E731
+                        "--synthetic"]
+    single = torch.load(filter_stage.main(argv(0)))
+    mp.spawn(_scaled_rank_main, args=(2, _free_port(), str(tmp_path), argv(1)), nprocs=2, join=True)
+    multi = torch.load(f"filtered_edges/{dataset}_{model}__0_1_sorted_edges.pt")
+    assert single.shape[0] > 10_000 and torch.equal(single, multi)
+
+
+def _scaled_rank_main(rank, world, port, workdir, argv):
+    os.environ["EPS_SYNTH_SCALE"] = "0.25"
+    _rank_main(rank, world, port, workdir, argv)
+
+
 @pytest.mark.parametrize("scaling", ["weak", "strong"])
 def test_bench_two_ranks_child_process(dev, tmp_path, scaling):
     """bench.py --gpus 2 as the driver launches it (python -m torch.distributed.run, fresh child processes), on one GPU
