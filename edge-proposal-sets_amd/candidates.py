@@ -150,6 +150,19 @@ def segment_bounds(g: CSRGraph):
     return g._cache["seg_ub"]
 
 
+def _unit_expand(g: CSRGraph, v_lo: int, v_hi: int, node_w, want_score: bool, want_v: bool):
+    """The block through the scan-structured list kernels (``ops.expand_unit``: graphs without stored values, or the list
+    only) -- same bits as ``ops.expand_candidates``, about half the time; None when the graph does not qualify."""
+    from . import ops, scan
+    if not (g.device.type == "cuda" and g.n_rows == g.n_cols and 0 < g.n_rows and g.nnz() < 1 << 30):
+        return None
+    if want_score and g.val is not None:
+        return None
+    return ops.expand_unit(g.rowptr, g.col, node_w if want_score else None, g.n_rows, v_lo, v_hi, scan.max_degree(g),
+                           scan.window_splits(g), want_score=want_score, want_v=want_v,
+                           col_order=heaviest_first(g, v_lo, v_hi))
+
+
 def expand_block_lazy(g: CSRGraph, v_lo: int, v_hi: int, node_w: Optional[torch.Tensor] = None, want_cn: bool = False,
                       want_score: bool = False, count_free: bool = False, cut=None) -> ColumnBlock:
     """``expand_block`` for consumers that read the pairs of a few candidates only (HIP expansion required).
@@ -160,6 +173,10 @@ def expand_block_lazy(g: CSRGraph, v_lo: int, v_hi: int, node_w: Optional[torch.
     ``cut=(threshold, capacity)``: let the kernel report the candidates above the streaming top-K's bar (see
     ``ops.expand_candidates``); with ``want_score=False`` the block then has no score array at all."""
     from . import ops
+    if not want_cn and not count_free and cut is None:
+        r = _unit_expand(g, v_lo, v_hi, node_w, want_score, want_v=False)
+        if r is not None:
+            return ColumnBlock(v_lo, r[0], r[1], None, r[4])
     kw = {}
     if count_free:
         pre, pre_host = segment_bounds(g)
@@ -178,14 +195,20 @@ def expand_block(g: CSRGraph, v_lo: int, v_hi: int, node_w: Optional[torch.Tenso
     pairs in the int32 buffer the kernel wrote (no 8-byte copy of a list that may hold 10^8 candidates)."""
     from . import ops
     fused = hip_expand_available(g) and (node_w is None or not want_score or fused_scores_fit(g, node_w))
+    if fused and not want_cn and (g.val is None or not want_score):
+        r = _unit_expand(g, v_lo, v_hi, node_w, want_score, want_v=True)
+        if r is not None:
+            return (r.pairs.long() if long_pairs else r.pairs), None, r[4]
     if fused:
         r = ops.expand_candidates(g.rowptr, g.col, g.val, node_w, g.n_rows, v_lo, v_hi, want_cn=want_cn,
                                   want_score=want_score, col_order=heaviest_first(g, v_lo, v_hi),
                                   max_paths=max_paths_of(g))
         return (r.pairs.long() if long_pairs else r.pairs), r[3], r[4]
     if hip_expand_available(g, scored=False):      # candidates from the expansion kernels, scores from the pair kernels
-        r = ops.expand_candidates(g.rowptr, g.col, None, None, g.n_rows, v_lo, v_hi, want_cn=False, want_score=False,
-                                  col_order=heaviest_first(g, v_lo, v_hi), max_paths=0)
+        r = _unit_expand(g, v_lo, v_hi, None, False, want_v=True)
+        if r is None:
+            r = ops.expand_candidates(g.rowptr, g.col, None, None, g.n_rows, v_lo, v_hi, want_cn=False, want_score=False,
+                                      col_order=heaviest_first(g, v_lo, v_hi), max_paths=0)
         pairs = r.pairs
     else:                                          # CPU tensors (host-logic tests)
         pairs = two_hop_block(g, v_lo, v_hi)

@@ -23,6 +23,7 @@
 //     per round of <= 2048 units by one block-wide max-scan.
 // Scores are bit-identical to eps_expand_fill's (same fixed-point terms, same final rounding).
 #include "eps_common.h"
+#include <string.h>
 
 // Geometry (compile-time; the shipped values are the measured best on the ppa-sized graphs).  FS_UR must be 2 * FS_THREADS.
 #ifndef FS_THREADS
@@ -102,7 +103,19 @@ struct fs_params {
     const int32_t *splits;    // [n_win - 1][n_nodes]: entries of row w below id (k + 1) * win_ids (NULL when n_win == 1)
     int32_t win_ids;          // ids per window (a multiple of 32768; the LDS bitmap's span)
     int32_t n_win;
+    // FS_EMIT / FS_COUNT (the candidate LIST of a block of columns, eps_expand_unit_*): columns are col_base + columns[t]
+    // (columns == NULL: col_base + t), every endpoint counts (not only u < v), outputs go to colptr-addressed segments
+    int32_t col_base;
+    const int64_t *colptr;    // [n_columns + 1], by column - col_base: first output slot (an upper bound layout is allowed)
+    int64_t *cand_count;      // [n_columns] or NULL: candidates found per column
+    int32_t *cand_u, *cand_v; // ascending u inside a column; cand_v may be NULL
+    float *out_score;         // NULL: the list only
+    unsigned int *status;     // bit 1: a column outgrew its segment, bit 2: a sum left the fixed-point range
 };
+
+#define FS_SCAN 0             // report the candidates above a bar (symmetric half scheme)
+#define FS_EMIT 1             // write every candidate (and its score)
+#define FS_COUNT 2            // count the candidates per column
 
 // Wave-wide inclusive scans on the DPP path (row shifts inside the 16-lane rows, then the two row broadcasts): six
 // VALU instructions, no LDS traffic.  Lanes a shift does not reach add 0 (values are non-negative for the max form).
@@ -150,9 +163,10 @@ struct fs_unit {
     int nvalid;   // 0..4 entries of u4 that belong to the row head
 };
 
-template <bool WINDOWED>
+template <bool WINDOWED, int MODE>
 __global__ __launch_bounds__(FS_THREADS) void filter_scan_kernel(fs_params p)
 {
+    constexpr bool FULL = MODE != FS_SCAN;      // all endpoints of a column, not only those below it
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const fs_layout L = fs_make_layout(p.words, p.tile_bits);
     uint32_t *bm = lds;                                   // bit u: u (< v) is a two-hop endpoint of the column
@@ -182,11 +196,11 @@ __global__ __launch_bounds__(FS_THREADS) void filter_scan_kernel(fs_params p)
     const int grp = lane >> 4, gl = lane & 15;
     const int words = p.words, TILE = L.tile, tile_half = TILE >> 1, range_shift = p.range_shift;
     const uint32_t tile_mask = (uint32_t)TILE - 1u;
-    const float thr = p.out->threshold;
+    const float thr = MODE == FS_SCAN ? p.out->threshold : 0.f;
     // the bar in the accumulators' domain: the smallest sum whose float32 score exceeds thr (the conversion is monotone),
     // so the per-candidate test is one 64-bit compare and only survivors are converted
-    long long thr_fix;
-    {
+    long long thr_fix = 0;
+    if (MODE == FS_SCAN) {
         auto above = [&](long long a) { return (float)((double)a * (1.0 / (double)(1ll << FS_FIXED_SHIFT))) > thr; };
         if (!above(0x7fffffffffffffffll)) {
             thr_fix = 0x7fffffffffffffffll;               // +inf / NaN bar: nothing passes (sums never reach 2^63 - 1)
@@ -199,9 +213,9 @@ __global__ __launch_bounds__(FS_THREADS) void filter_scan_kernel(fs_params p)
             thr_fix = (long long)(lo ^ 0x8000000000000000ull);
         }
     }
-    const uint32_t out_cap = p.out->capacity;
-    int64_t *__restrict__ out_key = p.out->key;
-    float *__restrict__ out_val = p.out->val;
+    const uint32_t out_cap = MODE == FS_SCAN ? p.out->capacity : 0u;
+    int64_t *__restrict__ out_key = MODE == FS_SCAN ? p.out->key : nullptr;
+    float *__restrict__ out_val = MODE == FS_SCAN ? p.out->val : nullptr;
     uint32_t *__restrict__ my_scratch = p.scratch + (size_t)blockIdx.x * ((size_t)p.cap_records + 64);   // + a trash line
     long long *__restrict__ my_gfix = p.gfix + (size_t)blockIdx.x * (size_t)p.max_degree;
     const __amdgpu_buffer_rsrc_t col_rs = __builtin_amdgcn_make_buffer_rsrc((void *)p.col, 0, p.col_bytes, 0x00020000);
@@ -228,24 +242,33 @@ __global__ __launch_bounds__(FS_THREADS) void filter_scan_kernel(fs_params p)
     // (the first three tickets of a workgroup are static -- one column of each of the three heaviest grid-wide rounds --, the
     // counter hands out the rest)
     const unsigned int t_static = 3u * gridDim.x;
+    auto col_of = [&](unsigned int t) -> int32_t {
+        if (MODE == FS_SCAN) return p.columns[t];
+        return p.col_base + (p.columns ? p.columns[t] : (int32_t)t);
+    };
     int32_t v_cur = -1, v_nx = -1;
     uint32_t vb_cur = 0, t_nx2 = blockIdx.x + 2u * gridDim.x;
     int32_t dv_cur = 0;
     {
         const unsigned int t0 = blockIdx.x;
         if (t0 < ncol) {
-            v_cur = p.columns[t0];
+            v_cur = col_of(t0);
             vb_cur = rowptr_lo[2 * (size_t)v_cur];
             dv_cur = (int32_t)(rowptr_lo[2 * (size_t)v_cur + 2] - vb_cur);
         }
-        if (t0 + gridDim.x < ncol) v_nx = p.columns[t0 + gridDim.x];
+        if (t0 + gridDim.x < ncol) v_nx = col_of(t0 + gridDim.x);
     }
     while (v_cur >= 0) {
         const int32_t v = v_cur;
         const uint32_t vb = vb_cur;
         const int32_t dv = dv_cur;
         const int32_t *__restrict__ vcol = p.col + vb;
-        const int32_t *__restrict__ vrev = p.revpos + vb;
+        const int32_t *__restrict__ vrev = FULL ? nullptr : p.revpos + vb;
+        // FULL: this column's output segment; candidates of the id windows before the current one
+        const int64_t seg_base = MODE == FS_EMIT ? p.colptr[v - p.col_base] : 0;
+        const int64_t seg_len = MODE == FS_EMIT ? p.colptr[v - p.col_base + 1] - seg_base : 0;
+        int64_t col_off = 0;
+        bool seg_overflow = false;
         int staged = 0;
         unsigned int pf_t = 0;
         int32_t pf_v = -1;
@@ -253,7 +276,7 @@ __global__ __launch_bounds__(FS_THREADS) void filter_scan_kernel(fs_params p)
         auto stage1 = [&]() {
             staged = 1;
             if (tid == 0) pf_t = t_static + atomicAdd(p.next_col, 1u);
-            if (t_nx2 < ncol) pf_v = p.columns[t_nx2];
+            if (t_nx2 < ncol) pf_v = col_of(t_nx2);
             if (v_nx >= 0) {
                 pf_b = rowptr_lo[2 * (size_t)v_nx];
                 pf_e = rowptr_lo[2 * (size_t)v_nx + 2];
@@ -268,14 +291,15 @@ __global__ __launch_bounds__(FS_THREADS) void filter_scan_kernel(fs_params p)
             vb_nx = __builtin_amdgcn_readfirstlane(pf_b);
             dv_nx = (int32_t)(__builtin_amdgcn_readfirstlane(pf_e) - vb_nx);
         };
-        if (dv != 0 && v != 0) {
+        if (dv != 0 && (FULL || v != 0)) {
         // The endpoints below v are taken in id WINDOWS of win_ids ids (one window when the whole id space fits the LDS):
         // window k sees of every row head only the entries inside it -- rows are ascending and splits[] holds, per node,
         // how many of its entries lie below each window boundary -- and runs the whole pipeline on ids relative to its start.
         // (WINDOWED == false: one window from id 0, everything below folds to constants)
-        for (int32_t wk = 0, win_base_id = 0; win_base_id < v; ++wk, win_base_id += p.win_ids) {
+        const int32_t id_end = FULL ? p.n_nodes : v;           // endpoints taken: ids [0, id_end)
+        for (int32_t wk = 0, win_base_id = 0; win_base_id < id_end; ++wk, win_base_id += p.win_ids) {
         const int32_t win_lo = WINDOWED ? win_base_id : 0;
-        const int32_t vlim = (WINDOWED && v - win_lo > p.win_ids) ? p.win_ids : v - win_lo;     // ids of this window, relative
+        const int32_t vlim = (WINDOWED && id_end - win_lo > p.win_ids) ? p.win_ids : id_end - win_lo;     // ids of this window, relative
         const uint32_t id_max = (uint32_t)vlim - 1u;
         const int32_t *__restrict__ split_lo = (WINDOWED && wk > 0) ? p.splits + (size_t)(wk - 1) * (size_t)p.n_nodes : nullptr;
         const int32_t *__restrict__ split_hi = (WINDOWED && wk + 1 < p.n_win) ? p.splits + (size_t)wk * (size_t)p.n_nodes : nullptr;
@@ -290,12 +314,21 @@ __global__ __launch_bounds__(FS_THREADS) void filter_scan_kernel(fs_params p)
             const bool row_ok = tid < FS_RC && j0 + tid < dv;
             if (row_ok) {
                 const int32_t w = vcol[j0 + tid];
-                int32_t hi = vrev[j0 + tid], lo = 0;          // the row head below v ...
+                uint32_t r0;
+                int32_t hi, lo = 0;                            // the row head below v (FULL: the whole row) ...
+                if (FULL) {
+                    r0 = rowptr_lo[2 * (size_t)w];
+                    hi = (int32_t)(rowptr_lo[2 * (size_t)w + 2] - r0);
+                    if (p.fixw) fx = p.fixw[w];                // (NULL: the list / the counts only)
+                } else {
+                    hi = vrev[j0 + tid];
+                    r0 = (uint32_t)p.rowptr[w];
+                    fx = p.fixw[w];
+                }
                 if (split_lo) lo = split_lo[w];                // ... cut to the window
                 if (split_hi) { const int32_t h = split_hi[w]; hi = hi < h ? hi : h; }
                 rl = hi > lo ? (uint32_t)(hi - lo) : 0u;
-                rb = (uint32_t)p.rowptr[w] + (uint32_t)lo;
-                fx = p.fixw[w];
+                rb = r0 + (uint32_t)lo;
                 nun = (int)((rl + 63u) >> 6);
                 if (tid == 0) nun -= c0;
             }
@@ -432,6 +465,10 @@ __global__ __launch_bounds__(FS_THREADS) void filter_scan_kernel(fs_params p)
             const uint32_t u = (uint32_t)(vcol[k] - win_lo);
             if (u < (uint32_t)vlim) atomicAnd(&bm[u >> 5], ~(1u << (u & 31)));
         }
+        if (FULL && tid == 0) {                          // the diagonal out (SCAN: it is not below v)
+            const uint32_t u = (uint32_t)(v - win_lo);
+            if (u < (uint32_t)vlim) atomicAnd(&bm[u >> 5], ~(1u << (u & 31)));
+        }
         fs_barrier();
 
         // ---- B. rank tables: exclusive prefix of the per-word popcounts over the words below v -------------------------
@@ -484,11 +521,38 @@ __global__ __launch_bounds__(FS_THREADS) void filter_scan_kernel(fs_params p)
             }
         }
         const int n_ranges = ((vlim - 1) >> range_shift) + 1;
-        if (tid == 0 && total) atomicAdd(&p.out->n_candidates, (unsigned long long)total);
-        if (total == 0) {          // every endpoint is a neighbour of v: nothing to score
+        if (MODE == FS_SCAN && tid == 0 && total) atomicAdd(&p.out->n_candidates, (unsigned long long)total);
+        bool listed = MODE == FS_COUNT;                   // FULL: nothing (more) to do for this window after the list
+        const int64_t obase = seg_base + col_off;         // EMIT: first output slot of this window's candidates
+        if (MODE == FS_EMIT && total) {
+            if (col_off + total > seg_len) {             // the caller's segment does not hold the column: flag it, stop
+                if (tid == 0) atomicOr(p.status, 2u);
+                seg_overflow = true;
+                listed = true;
+            } else {
+                // the list: thread per bitmap word (neighbouring lanes -> neighbouring ranks), ascending u
+                fs_barrier();                             // rank tables complete
+                for (int wi = tid; wi < words_v; wi += FS_THREADS) {
+                    uint32_t bits = bm[wi];
+                    if (bits) {
+                        uint32_t run = base32[wi >> 3] + pre8[wi];
+                        do {
+                            p.cand_u[obase + run++] = win_lo + wi * 32 + __builtin_ctz(bits);
+                            bits &= bits - 1;
+                        } while (bits);
+                    }
+                }
+                if (p.cand_v)
+                    for (int i = tid; i < total; i += FS_THREADS) p.cand_v[obase + i] = v;
+                listed = p.out_score == nullptr;
+            }
+        }
+        col_off += total;
+        if (total == 0 || listed) {          // nothing to score (SCAN: every endpoint is a neighbour of v)
+            if (MODE == FS_EMIT && total) fs_barrier();      // (the list pass read the bitmap)
             if (tid < n_ranges) hist[tid] = 0u;
             for (int i = tid; i < words_v; i += FS_THREADS) bm[i] = 0u;
-            if (!WINDOWED) break;
+            if (!WINDOWED || seg_overflow) break;
             fs_barrier();              // (the next window marks into the words other threads just cleared)
             continue;
         }
@@ -578,11 +642,21 @@ __global__ __launch_bounds__(FS_THREADS) void filter_scan_kernel(fs_params p)
                 *(uint4 *)(acc + i) = make_uint4(0u, 0u, 0u, 0u);
                 const long long a0 = (long long)(((unsigned long long)raw.y << 32) | raw.x);
                 const long long a1 = (long long)(((unsigned long long)raw.w << 32) | raw.z);
-                if (a0 >= thr_fix) survivor(i, a0);
-                if (a1 >= thr_fix && i + 1 < nslots) survivor(i + 1, a1);
+                if (MODE == FS_EMIT) {               // every candidate's score, in candidate order (the ranks ARE the order)
+                    // the heuristics' terms are non-negative: a negative sum is one that wrapped past 2^23 (backstop; the host
+                    // bounds the graph's scores before it takes this path -- candidates.fused_scores_fit)
+                    if ((a0 | a1) < 0) atomicOr(p.status, 4u);
+                    float *o = p.out_score + obase + r0 + i;
+                    o[0] = (float)((double)a0 * (1.0 / (double)(1ll << FS_FIXED_SHIFT)));
+                    if (i + 1 < nslots) o[1] = (float)((double)a1 * (1.0 / (double)(1ll << FS_FIXED_SHIFT)));
+                } else {
+                    if (a0 >= thr_fix) survivor(i, a0);
+                    if (a1 >= thr_fix && i + 1 < nslots) survivor(i + 1, a1);
+                }
             }
         };
         auto reserve_out = [&](int t) {   // thread 0, before the barrier that precedes scan_tile(t)
+            if (MODE != FS_SCAN) return;
             const uint32_t nslots = tile_r0[t + 1] - tile_r0[t] + FS_SVCAP;      // this tile's + everything parked
             if (s_out_end - s_out_cur < nslots) {
                 const uint32_t b = atomicAdd(&p.out->count, (unsigned int)FS_CHUNK);
@@ -737,6 +811,15 @@ __global__ __launch_bounds__(FS_THREADS) void filter_scan_kernel(fs_params p)
         if (!WINDOWED) break;
         fs_barrier();                  // the next window marks into the words other threads just cleared
         }
+        }
+        if (FULL) {
+            if (p.cand_count && tid == 0 && !seg_overflow) p.cand_count[v - p.col_base] = col_off;
+            if (MODE == FS_EMIT && !seg_overflow)
+                for (int64_t i = col_off + tid; i < seg_len; i += FS_THREADS) {   // padding of an upper-bound segment
+                    p.cand_u[seg_base + i] = -1;
+                    if (p.cand_v) p.cand_v[seg_base + i] = v;
+                    if (p.out_score) p.out_score[seg_base + i] = -__builtin_inff();
+                }
         }
         if (staged == 0) {             // (a column without work: the stages still have to run)
             stage1();
@@ -908,6 +991,62 @@ extern "C" int64_t eps_filter_scan_workspace_bytes(int64_t max_degree)
     return (int64_t)eps_num_cus() * FS_WG_PER_CU * (((int64_t)FS_DEFAULT_RECORDS + 64) * 4 + max_degree * 8);
 }
 
+// one launch of filter_scan_kernel<WINDOWED, MODE>: geometry, counter, LDS size (the caller filled the mode's own fields of p)
+static int fs_launch(const char *who, fs_params p, int mode, const int32_t *splits, int64_t n_nodes, int64_t nnz,
+                     int64_t max_degree, int64_t n_columns, void *workspace, int64_t workspace_bytes, void *stream)
+{
+    EPS_REQUIRE(nnz < (1ll << 30), "%s: col[] is addressed with 32-bit byte offsets (nnz < 2^30)", who);
+    EPS_REQUIRE(n_columns < (1ll << 31), "%s: too many columns", who);
+    fs_geometry geo;
+    EPS_REQUIRE(n_nodes < (1ll << 31) && fs_pick_geometry(n_nodes, &geo), "%s: no launch geometry for %lld nodes", who,
+                (long long)n_nodes);
+    EPS_REQUIRE(geo.n_win == 1 || splits, "%s: %d id windows need the row split table (eps_row_window_splits)", who, geo.n_win);
+    int64_t blocks = (int64_t)eps_num_cus() * FS_WG_PER_CU;
+    if (blocks > n_columns) blocks = n_columns;
+    EPS_REQUIRE(max_degree >= 0 && max_degree <= n_nodes, "%s: bad max_degree", who);
+    const int64_t n_wg = (int64_t)eps_num_cus() * FS_WG_PER_CU;
+    EPS_REQUIRE(workspace && ((uintptr_t)workspace & 15) == 0 && workspace_bytes >= eps_filter_scan_workspace_bytes(max_degree),
+                "%s: needs a 16-byte aligned workspace of eps_filter_scan_workspace_bytes(max_degree) bytes", who);
+    hipStream_t s = (hipStream_t)stream;
+    unsigned int *counter = nullptr;
+    int rc = eps_take_counter(&counter, s, who);
+    if (rc) return rc;
+    p.n_columns = (int32_t)n_columns;
+    p.n_nodes = (int32_t)n_nodes;
+    p.col_bytes = (uint32_t)(nnz * 4);
+    p.words = geo.words;
+    p.splits = geo.n_win > 1 ? splits : nullptr;
+    p.win_ids = (int32_t)(geo.win_ids < (1ll << 30) ? geo.win_ids : (1ll << 30));
+    p.n_win = geo.n_win;
+    p.tile_bits = geo.tile_bits;
+    p.range_shift = geo.range_shift;
+    p.cap_records = (uint32_t)FS_DEFAULT_RECORDS;
+    p.next_col = counter;
+    p.scratch = (uint32_t *)workspace;
+    p.gfix = (long long *)((char *)workspace + n_wg * ((int64_t)FS_DEFAULT_RECORDS + 64) * 4);
+    p.max_degree = (int32_t)max_degree;
+    const size_t lds = (size_t)fs_make_layout(p.words, geo.tile_bits).total_words * 4;
+    const bool win = geo.n_win > 1;
+    void (*kern)(fs_params) =
+        mode == FS_SCAN ? (win ? filter_scan_kernel<true, FS_SCAN> : filter_scan_kernel<false, FS_SCAN>)
+        : mode == FS_EMIT ? (win ? filter_scan_kernel<true, FS_EMIT> : filter_scan_kernel<false, FS_EMIT>)
+                          : (win ? filter_scan_kernel<true, FS_COUNT> : filter_scan_kernel<false, FS_COUNT>);
+    if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+        eps_set_error("%s: cannot reserve %zu bytes of LDS", who, lds);
+        return EPS_ELAUNCH;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(FS_THREADS), lds, s, p);
+    EPS_CHECK_LAUNCH(who);
+    return EPS_OK;
+}
+
+static fs_params fs_blank_params()
+{
+    fs_params p;
+    memset(&p, 0, sizeof p);
+    return p;
+}
+
 extern "C" int eps_filter_scan(const int64_t *rowptr, const int32_t *col, const int32_t *revpos, const int64_t *fixw,
                                const int32_t *splits, int64_t n_nodes, int64_t nnz, int64_t max_degree,
                                const int32_t *columns, int64_t n_columns, eps_survivors *out, void *workspace,
@@ -916,53 +1055,64 @@ extern "C" int eps_filter_scan(const int64_t *rowptr, const int32_t *col, const 
     EPS_REQUIRE(n_nodes >= 0 && n_columns >= 0 && nnz >= 0, "eps_filter_scan: negative size");
     if (n_columns == 0 || n_nodes == 0) return EPS_OK;
     EPS_REQUIRE(rowptr && col && revpos && fixw && columns && out, "eps_filter_scan: null pointer");
-    EPS_REQUIRE(nnz < (1ll << 30), "eps_filter_scan: col[] is addressed with 32-bit byte offsets (nnz < 2^30)");
-    EPS_REQUIRE(n_columns < (1ll << 31), "eps_filter_scan: too many columns");
-    fs_geometry geo;
-    EPS_REQUIRE(n_nodes < (1ll << 31) && fs_pick_geometry(n_nodes, &geo), "eps_filter_scan: no launch geometry for %lld nodes",
-                (long long)n_nodes);
-    EPS_REQUIRE(geo.n_win == 1 || splits, "eps_filter_scan: %d id windows need the row split table (eps_row_window_splits)",
-                geo.n_win);
-    const int tile_bits = geo.tile_bits, range_shift = geo.range_shift;
-    int64_t blocks = (int64_t)eps_num_cus() * FS_WG_PER_CU;
-    if (blocks > n_columns) blocks = n_columns;
-    EPS_REQUIRE(max_degree >= 0 && max_degree <= n_nodes, "eps_filter_scan: bad max_degree");
-    const int64_t n_wg = (int64_t)eps_num_cus() * FS_WG_PER_CU;
-    EPS_REQUIRE(workspace && ((uintptr_t)workspace & 15) == 0 && workspace_bytes >= eps_filter_scan_workspace_bytes(max_degree),
-                "eps_filter_scan: needs a 16-byte aligned workspace of eps_filter_scan_workspace_bytes(max_degree) bytes");
-    const int64_t cap = FS_DEFAULT_RECORDS;
-    hipStream_t s = (hipStream_t)stream;
-    unsigned int *counter = nullptr;
-    int rc = eps_take_counter(&counter, s, "eps_filter_scan");
-    if (rc) return rc;
-    fs_params p;
+    fs_params p = fs_blank_params();
     p.rowptr = rowptr;
     p.col = col;
     p.revpos = revpos;
     p.fixw = fixw;
     p.columns = columns;
-    p.n_columns = (int32_t)n_columns;
-    p.n_nodes = (int32_t)n_nodes;
-    p.col_bytes = (uint32_t)(nnz * 4);
-    p.words = geo.words;
-    p.splits = geo.n_win > 1 ? splits : nullptr;
-    p.win_ids = (int32_t)(geo.win_ids < (1ll << 30) ? geo.win_ids : (1ll << 30));
-    p.n_win = geo.n_win;
-    p.tile_bits = tile_bits;
-    p.range_shift = range_shift;
-    p.cap_records = (uint32_t)cap;
-    p.next_col = counter;
     p.out = out;
-    p.scratch = (uint32_t *)workspace;
-    p.gfix = (long long *)((char *)workspace + n_wg * ((int64_t)FS_DEFAULT_RECORDS + 64) * 4);
-    p.max_degree = (int32_t)max_degree;
-    const size_t lds = (size_t)fs_make_layout(p.words, tile_bits).total_words * 4;
-    auto kern = geo.n_win > 1 ? filter_scan_kernel<true> : filter_scan_kernel<false>;
-    if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
-        eps_set_error("eps_filter_scan: cannot reserve %zu bytes of LDS", lds);
+    return fs_launch("eps_filter_scan", p, FS_SCAN, splits, n_nodes, nnz, max_degree, n_columns, workspace, workspace_bytes, stream);
+}
+
+// ---- the candidate LIST of a block of columns of a unit-valued graph, on the scan kernel's structure ---------------------
+// eps_expand_unit_count / eps_expand_unit_fill do what eps_expand_count / eps_expand_fill (expand_score.hip) do -- every 2-hop
+// non-edge of columns [v_lo, v_hi) in the reference's order (filter.py:96-109), optionally with its score
+// sum_w A[u,w] A[v,w] node_w[w] -- for adjacencies WITHOUT stored values, with the threshold scan's machinery: packed 64-entry
+// units, 4-byte bucket records, one fixed-point weight per (v, w) from a table, 16-byte record stores.  Both orientations of
+// a pair are produced (column-major order cannot be mirrored cheaply), so whole rows are walked, not row heads.
+extern "C" int eps_expand_unit_count(const int64_t *rowptr, const int32_t *col, const int32_t *splits, int64_t n_nodes,
+                                     int64_t nnz, int64_t max_degree, int64_t v_lo, int64_t v_hi, const int32_t *col_order,
+                                     int64_t *cand_count, void *workspace, int64_t workspace_bytes, void *stream)
+{
+    EPS_REQUIRE(n_nodes >= 0 && nnz >= 0 && v_lo >= 0 && v_lo <= v_hi && v_hi <= n_nodes, "eps_expand_unit_count: bad range");
+    if (v_hi == v_lo) return EPS_OK;
+    EPS_REQUIRE(rowptr && col && cand_count, "eps_expand_unit_count: null pointer");
+    fs_params p = fs_blank_params();
+    p.rowptr = rowptr;
+    p.col = col;
+    p.columns = col_order;
+    p.col_base = (int32_t)v_lo;
+    p.cand_count = cand_count;
+    return fs_launch("eps_expand_unit_count", p, FS_COUNT, splits, n_nodes, nnz, max_degree, v_hi - v_lo, workspace,
+                     workspace_bytes, stream);
+}
+
+extern "C" int eps_expand_unit_fill(const int64_t *rowptr, const int32_t *col, const int64_t *fixw, const int32_t *splits,
+                                    int64_t n_nodes, int64_t nnz, int64_t max_degree, int64_t v_lo, int64_t v_hi,
+                                    const int32_t *col_order, const int64_t *colptr, int64_t *cand_count, int32_t *cand_u,
+                                    int32_t *cand_v, float *score, uint32_t *status, void *workspace,
+                                    int64_t workspace_bytes, void *stream)
+{
+    EPS_REQUIRE(n_nodes >= 0 && nnz >= 0 && v_lo >= 0 && v_lo <= v_hi && v_hi <= n_nodes, "eps_expand_unit_fill: bad range");
+    if (v_hi == v_lo) return EPS_OK;
+    EPS_REQUIRE(rowptr && col && colptr && cand_u && status && (fixw || !score), "eps_expand_unit_fill: null pointer");
+    if (hipMemsetAsync(status, 0, sizeof(uint32_t), (hipStream_t)stream) != hipSuccess) {
+        eps_set_error("eps_expand_unit_fill: cannot clear the status word");
         return EPS_ELAUNCH;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(FS_THREADS), lds, s, p);
-    EPS_CHECK_LAUNCH("eps_filter_scan");
-    return EPS_OK;
+    fs_params p = fs_blank_params();
+    p.rowptr = rowptr;
+    p.col = col;
+    p.fixw = fixw;
+    p.columns = col_order;
+    p.col_base = (int32_t)v_lo;
+    p.colptr = colptr;
+    p.cand_count = cand_count;
+    p.cand_u = cand_u;
+    p.cand_v = cand_v;
+    p.out_score = score;
+    p.status = status;
+    return fs_launch("eps_expand_unit_fill", p, FS_EMIT, splits, n_nodes, nnz, max_degree, v_hi - v_lo, workspace,
+                     workspace_bytes, stream);
 }

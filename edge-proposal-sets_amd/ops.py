@@ -184,6 +184,51 @@ def expand_workspace_fits(max_paths: int) -> bool:
     return int(_lib.load().eps_expand_workspace_bytes(int(max_paths))) <= _EXPAND_WS_LIMIT
 
 
+def expand_unit(rowptr, col, node_w, n_nodes: int, v_lo: int, v_hi: int, max_degree: int, splits=None, want_score=True,
+                want_v=True, col_order=None):
+    """The candidate list of columns [v_lo, v_hi) of a graph WITHOUT stored values, on the threshold scan's structure
+    (eps_expand_unit_count / eps_expand_unit_fill, csrc/filter_scan.hip): same tuple and same bits as
+    ``expand_candidates(rowptr, col, None, node_w, ...)`` with ``want_cn=False`` -- (colptr, cand_u, cand_v | None, None,
+    score | None) -- at about half the time.  ``node_w`` None with ``want_score``: all-ones weights (the score is the
+    common-neighbour count).  ``max_degree`` / ``splits``: the per-graph figures ``filter_scan`` takes."""
+    dev = _need_gpu(rowptr, col, node_w, col_order, splits)
+    _chk(rowptr, torch.int64, "rowptr"); _chk(col, torch.int32, "col"); _chk(node_w, torch.float32, "node_w")
+    _chk(col_order, torch.int32, "col_order"); _chk(splits, torch.int32, "splits")
+    lib = _lib.load()
+    n_cols = v_hi - v_lo
+    if col_order is not None and col_order.numel() != n_cols:
+        raise ValueError("col_order must have one entry per column of the range")
+    with torch.cuda.device(dev):
+        ws = _scan_scratch(dev, int(max_degree))
+        counts = torch.zeros(n_cols, dtype=torch.int64, device=dev)
+        colptr = torch.zeros(n_cols + 1, dtype=torch.int64, device=dev)
+        if n_cols:
+            _lib.check(lib.eps_expand_unit_count(_ptr(rowptr), _ptr(col), _ptr(splits), n_nodes, col.numel(), int(max_degree),
+                                                 v_lo, v_hi, _ptr(col_order), _ptr(counts), _ptr(ws), ws.numel() * 8,
+                                                 _stream(dev)), "eps_expand_unit_count")
+        torch.cumsum(counts, 0, out=colptr[1:])
+        total = int(colptr[-1].item())
+        pairs = torch.empty((2 if want_v else 1, total), dtype=torch.int32, device=dev)
+        score = torch.empty(total, dtype=torch.float32, device=dev) if want_score else None
+        if total:
+            fixw = None
+            if want_score:
+                fixw = fixed_weights(node_w if node_w is not None else torch.ones(n_nodes, dtype=torch.float32, device=dev))
+            status = torch.zeros(1, dtype=torch.int32, device=dev)
+            _lib.check(lib.eps_expand_unit_fill(_ptr(rowptr), _ptr(col), _ptr(fixw), _ptr(splits), n_nodes, col.numel(),
+                                                int(max_degree), v_lo, v_hi, _ptr(col_order), _ptr(colptr), None,
+                                                _ptr(pairs[0]), _ptr(pairs[1]) if want_v else None, _ptr(score), _ptr(status),
+                                                _ptr(ws), ws.numel() * 8, _stream(dev)), "eps_expand_unit_fill")
+            st = int(status.item())
+            if st:
+                raise _lib.EpsError("expand_unit: " + ("a column outgrew its segment; " if st & 2 else "")
+                                    + ("a score left the fixed-point range (|sum| >= 2**23): use the pair kernels" if st & 4 else ""))
+    out = ExpandResult((colptr, pairs[0], pairs[1] if want_v else None, None, score))
+    out.pairs = pairs if want_v else None
+    out.counts = None
+    return out
+
+
 def expand_candidates(rowptr, col, val, node_w, n_nodes: int, v_lo: int, v_hi: int, want_cn=True, want_score=True,
                       want_v=True, col_order=None, max_paths=None, colptr_ub=None, total_ub=None, cut=None, tile_ranks=0):
     """Fused 2-hop expansion of columns [v_lo, v_hi) of a SYMMETRIC adjacency (filter.py:96-109 + scoring).

@@ -198,6 +198,25 @@ int eps_filter_scan(const int64_t *rowptr, const int32_t *col, const int32_t *re
                     const int32_t *columns, int64_t n_columns, eps_survivors *out, void *workspace,
                     int64_t workspace_bytes, void *stream);
 
+/* ---- the candidate list of a block of columns of a graph WITHOUT stored values, on the scan kernel's structure ----------
+ * Same results as eps_expand_count / eps_expand_fill above (filter.py:96-109: every 2-hop non-edge of columns
+ * [v_lo, v_hi), column-major, u ascending; score = sum_w A[u,w] A[v,w] node_w[w] in 2^-40 fixed point, rounded once --
+ * bit-identical), for unit-valued adjacencies: packed 64-entry units, 4-byte bucket records, one fixed-point weight per
+ * (v, w) from a table (fixw = eps_fixed_weights(node_w); NULL with score == NULL: the list only).  col_order (optional)
+ * = hand-out order, a permutation of range(v_hi - v_lo).  colptr[v_hi - v_lo + 1] = exclusive prefix of the counts
+ * (or any upper-bound layout: the rest of a segment is padded with cand_u -1 / score -inf and cand_count, if given,
+ * receives the real counts).  status: one device word, cleared by the call; after the stream has drained bit 1 = a
+ * column outgrew its segment, bit 2 = a sum left the fixed-point range -- the outputs are then invalid.  splits /
+ * max_degree / workspace as for eps_filter_scan (eps_filter_scan_workspace_bytes(max_degree) bytes). */
+int eps_expand_unit_count(const int64_t *rowptr, const int32_t *col, const int32_t *splits_or_null, int64_t n_nodes,
+                          int64_t nnz, int64_t max_degree, int64_t v_lo, int64_t v_hi, const int32_t *col_order,
+                          int64_t *cand_count, void *workspace, int64_t workspace_bytes, void *stream);
+int eps_expand_unit_fill(const int64_t *rowptr, const int32_t *col, const int64_t *fixw, const int32_t *splits_or_null,
+                         int64_t n_nodes, int64_t nnz, int64_t max_degree, int64_t v_lo, int64_t v_hi,
+                         const int32_t *col_order, const int64_t *colptr, int64_t *cand_count, int32_t *cand_u,
+                         int32_t *cand_v, float *score, uint32_t *status, void *workspace, int64_t workspace_bytes,
+                         void *stream);
+
 /* ---- K4/K5: CSR x dense SpMM with fused epilogue -----------------------------------------
  * Replaces torch_sparse spmm_sum / spmm_mean inside GCNConv / SAGEConv (models.py:183-186,
  * :436-439) plus the bias add and the ReLU of the layer loop.

@@ -315,3 +315,57 @@ def test_expand_wide_id_space_vs_oracle(eps, oracle, dev):
         idx = blk.valid()
         assert np.array_equal(blk.select(idx).t().cpu().numpy(), want) and torch.equal(blk.score[idx], sc)
     assert want.shape[0] > 10000 and int((want[:, 0] >= 2 * win).sum()) > 0 and int((want[:, 0] < win).sum()) > 0
+
+
+def _unit_vs_expand(eps, g, wt, lo, hi, col_order=None):
+    """eps_expand_unit_* (scan-structured list kernels) against eps_expand_* on the same block: same bits."""
+    from eps_amd import scan
+    md, sp = scan.max_degree(g), scan.window_splits(g)
+    want = eps.ops.expand_candidates(g.rowptr, g.col, None, wt, g.n_rows, lo, hi, want_cn=False, col_order=col_order)
+    got = eps.ops.expand_unit(g.rowptr, g.col, wt, g.n_rows, lo, hi, md, sp, col_order=col_order)
+    assert torch.equal(got[0], want[0]), "colptr"
+    assert torch.equal(got[1], want[1]) and torch.equal(got[2], want[2]), "candidate list"
+    assert got[3] is None and torch.equal(got[4], want[4]), "scores bit-identical"
+    lst = eps.ops.expand_unit(g.rowptr, g.col, None, g.n_rows, lo, hi, md, sp, want_score=False, want_v=False)
+    assert torch.equal(lst[0], want[0]) and torch.equal(lst[1], want[1]) and lst[2] is None and lst[4] is None
+    cn = eps.ops.expand_unit(g.rowptr, g.col, None, g.n_rows, lo, hi, md, sp)         # all-ones weights: the CN count
+    ref_cn = eps.ops.expand_candidates(g.rowptr, g.col, None, None, g.n_rows, lo, hi, want_cn=True, want_score=False)[3]
+    assert torch.equal(cn[4], ref_cn.to(torch.float32))
+    return int(want[0][-1])
+
+
+@pytest.mark.parametrize("path", golden_pair_files(), ids=lambda p: os.path.basename(p)[6:-4])
+def test_expand_unit_on_golden_graphs(eps, dev, path):
+    from eps_amd.heuristics import node_weight_table
+    d = np.load(path)
+    n = len(d["rowptr"]) - 1
+    g = eps.CSRGraph(torch.from_numpy(d["rowptr"].astype(np.int64)).to(dev), torch.from_numpy(d["col"].astype(np.int32)).to(dev),
+                     None, n, n)                                           # the structure only: unit values
+    wt = node_weight_table(g, eps.ops.W_AA)
+    step = max(1, n // 3)
+    for lo in range(0, n, step):
+        _unit_vs_expand(eps, g, wt, lo, min(n, lo + step))
+
+
+def test_expand_unit_rmat_hubs_and_order(eps, dev):
+    """R-MAT graph with hub columns (several rounds of row descriptors, several tiles), a hand-out order, partial blocks."""
+    from eps_amd import candidates, synth
+    from eps_amd.heuristics import node_weight_table
+    g = synth.rmat_graph(15, 16, 5, dev)
+    wt = node_weight_table(g, eps.ops.W_AA)
+    n = g.n_rows
+    assert _unit_vs_expand(eps, g, wt, 0, n // 2, col_order=candidates.heaviest_first(g, 0, n // 2)) > 1_000_000
+    _unit_vs_expand(eps, g, wt, n // 2, n)
+    _unit_vs_expand(eps, g, wt, 17, 18)
+    _unit_vs_expand(eps, g, wt, 5, 5)
+
+
+def test_expand_unit_wide_id_space(eps, dev):
+    """An id space wider than the LDS bitmap (N = 1.3 M: id windows): candidates still come out in ascending u."""
+    from eps_amd import synth
+    from eps_amd.heuristics import node_weight_table
+    g = synth.rmat_graph(21, 3, 11, dev, n_nodes=1_300_000)
+    assert eps.ops.filter_scan_windows(g.n_rows)[1] > 1
+    wt = node_weight_table(g, eps.ops.W_AA)
+    assert _unit_vs_expand(eps, g, wt, 400_000, 440_000) > 100_000
+    _unit_vs_expand(eps, g, wt, 1_299_000, 1_300_000)
