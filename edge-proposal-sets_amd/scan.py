@@ -38,15 +38,32 @@ RELABEL_MIN_NODES = 100_000  # graphs at least this large are scanned under hubs
 
 
 def scan_available(g: CSRGraph) -> bool:
-    """eps_filter_scan can take this graph: on the GPU, square, unit values, ids within the LDS bitmap."""
+    """eps_filter_scan can take this graph: on the GPU, square, unit values, SYMMETRIC (the half scheme scores a pair once,
+    in the column of its larger endpoint -- on an asymmetric pattern that would silently be a different sum)."""
     return (g.device.type == "cuda" and g.n_rows == g.n_cols and g.val is None and 0 < g.n_rows <= ops.filter_scan_max_nodes()
-            and g.nnz() < 1 << 30)       # (any id space: wider ones are scanned in id windows)
+            and g.nnz() < 1 << 30 and is_symmetric(g))       # (any id space: wider ones are scanned in id windows)
 
 
 def reverse_positions(g: CSRGraph) -> torch.Tensor:
     if "revpos" not in g._cache:
         g._cache["revpos"] = ops.reverse_positions(g.rowptr, g.col)
     return g._cache["revpos"]
+
+
+def is_symmetric(g: CSRGraph) -> bool:
+    """Whether the stored pattern is symmetric (cached).  One gather over the entries: for entry (v, w), revpos counts the
+    entries of row w below v -- in a symmetric pattern that position holds v itself."""
+    if "symmetric" not in g._cache:
+        if g.nnz() == 0:
+            g._cache["symmetric"] = True
+        else:
+            rev = reverse_positions(g).to(torch.int64)
+            w = g.col.to(torch.int64)
+            pos = g.rowptr[w] + rev
+            inside = pos < g.rowptr[w + 1]
+            hit = g.col[torch.where(inside, pos, torch.zeros_like(pos))].to(torch.int64) == g.row_index()
+            g._cache["symmetric"] = bool((inside & hit).all().item())
+    return g._cache["symmetric"]
 
 
 def half_paths(g: CSRGraph) -> torch.Tensor:

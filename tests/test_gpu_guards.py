@@ -84,3 +84,19 @@ def test_fused_score_bound_sends_heavy_weights_to_the_pair_kernels(eps, oracle, 
     got_p, got_s = torch.cat(got_p, 1).cpu().numpy(), torch.cat(got_s).cpu().numpy()
     assert np.array_equal(got_p.T, pairs)
     assert rel_err(got_s, truth.astype(np.float32)) <= 1e-5
+
+
+def test_scan_refuses_asymmetric_pattern(eps, dev):
+    """The threshold scan's half scheme needs a symmetric pattern: an asymmetric one is refused (scan_available False,
+    scan_topk raises) instead of being scored as something else."""
+    from eps_amd import scan, synth
+    from eps_amd.graph import CSRGraph
+    g = synth.rmat_graph(10, 8, 3, dev)
+    assert scan.is_symmetric(g) and scan.scan_available(g)
+    row, col, _ = g.coo()
+    keep = ~((row == row[5]) & (col == col[5]))                  # drop ONE direction of one edge
+    h = CSRGraph.from_edge_index(torch.stack([row[keep], col[keep].long()]), None, sparse_sizes=(g.n_rows, g.n_cols))
+    assert h.nnz() == g.nnz() - 1
+    assert not scan.is_symmetric(h) and not scan.scan_available(h)
+    with pytest.raises(eps.EpsError):
+        scan.scan_topk(h, torch.ones(h.n_rows, device=dev), 10)
