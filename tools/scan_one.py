@@ -8,6 +8,8 @@ from eps_amd import ops, scan, synth
 from eps_amd.heuristics import node_weight_table
 dev = torch.device("cuda:0")
 g = synth.ppa_like(seed=3, device=dev)
+if os.environ.get("RELABEL", "1") == "1":
+    g = g.degree_ordered()[0]               # hubs first: the labels bench.py's repeatedly scanned graph runs under
 w = node_weight_table(g, ops.W_AA)
 fixw = scan.fixed_weights(g, w)
 order = scan.column_order(g)
