@@ -16,7 +16,7 @@ for relabel in (True, False):
     fixw = scan._scan_weights(g0, g, perm, w)
     order = scan.column_order(g)
     # all unordered scores above a low bar once: counts above any estimate come from this list
-    res = scan._launch(g, fixw, order, 3.0, 80 << 20)
+    res = scan._launch(g, fixw, order, 1.7, 400 << 20)
     slots, _ = res.counts()
     _, vals = res.valid(slots)
     vals = torch.sort(vals).values
