@@ -369,3 +369,51 @@ def test_expand_unit_wide_id_space(eps, dev):
     wt = node_weight_table(g, eps.ops.W_AA)
     assert _unit_vs_expand(eps, g, wt, 400_000, 440_000) > 100_000
     _unit_vs_expand(eps, g, wt, 1_299_000, 1_300_000)
+
+
+def test_expand_unit_upper_bound_layout_and_status(eps, dev):
+    """eps_expand_unit_fill through the C ABI with an UPPER-BOUND colptr (segments of min(paths, N) slots: no counting pass):
+    the front of every segment holds the column's candidates, the rest is padded (cand_u -1, score -inf), cand_count receives
+    the real counts; segments that are too small raise status bit 1 (value 2)."""
+    import ctypes
+    from eps_amd import _lib, candidates, scan, synth
+    from eps_amd.heuristics import node_weight_table
+    g = synth.rmat_graph(13, 10, 9, dev)
+    n = g.n_rows
+    wt = node_weight_table(g, eps.ops.W_AA)
+    lo, hi = 100, 5000
+    want = eps.ops.expand_unit(g.rowptr, g.col, wt, n, lo, hi, scan.max_degree(g), scan.window_splits(g))
+    counts_want = want[0][1:] - want[0][:-1]
+    ub = torch.clamp(candidates.path_counts(g)[lo:hi], max=n)
+    colptr = torch.zeros(hi - lo + 1, dtype=torch.int64, device=dev)
+    torch.cumsum(ub, 0, out=colptr[1:])
+    total = int(colptr[-1])
+    cu = torch.full((total,), -7, dtype=torch.int32, device=dev)
+    cv = torch.full((total,), -7, dtype=torch.int32, device=dev)
+    sc = torch.full((total,), 123.0, dtype=torch.float32, device=dev)
+    cnt = torch.full((hi - lo,), -1, dtype=torch.int64, device=dev)
+    status = torch.ones(1, dtype=torch.int32, device=dev)
+    fixw = eps.ops.fixed_weights(wt)
+    ws = eps.ops._scan_scratch(dev, scan.max_degree(g))
+    P = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())       # noqa: E731
+    lib = _lib.load()
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def fill(colptr_t, cnt_t):
+        return lib.eps_expand_unit_fill(P(g.rowptr), P(g.col), P(fixw), None, n, g.nnz(), scan.max_degree(g), lo, hi, None,
+                                        P(colptr_t), P(cnt_t), P(cu), P(cv), P(sc), P(status), P(ws), ws.numel() * 8, stream)
+    assert fill(colptr, cnt) == 0
+    torch.cuda.synchronize()
+    assert int(status) == 0 and torch.equal(cnt, counts_want)
+    real = cu >= 0
+    assert torch.equal(cu[real], want[1]) and torch.equal(sc[real], want[4]) and torch.equal(cv[real], want[2])
+    assert bool((sc[~real] == float("-inf")).all()) and bool((cu[~real] == -1).all())
+    seg = torch.repeat_interleave(torch.arange(hi - lo, device=dev), ub)          # padding sits at the END of each segment
+    first_pad = colptr[:-1] + counts_want
+    assert bool((real == (torch.arange(total, device=dev) < first_pad[seg])).all())
+    # segments one slot too small for the columns that have candidates: flagged, nothing is written past a segment
+    small = torch.zeros_like(colptr)
+    torch.cumsum(torch.clamp(counts_want - 1, min=0), 0, out=small[1:])
+    assert fill(small, None) == 0
+    torch.cuda.synchronize()
+    assert int(status) & 2
