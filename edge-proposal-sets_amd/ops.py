@@ -13,8 +13,20 @@ from . import _lib
 W_AA, W_RA = 0, 1
 
 
+_EMPTY = {}
+
+
 def _ptr(t: Optional[torch.Tensor]):
-    return None if t is None else ctypes.c_void_p(t.data_ptr())
+    """Device pointer for the C ABI.  An EMPTY tensor has no storage (data_ptr() == 0), which the ABI would take for a
+    missing argument: it gets the address of a small per-device dummy instead (nothing is read through it: the sizes say 0)."""
+    if t is None:
+        return None
+    if t.numel() == 0 and t.is_cuda:
+        key = (t.device.type, t.device.index)
+        if key not in _EMPTY:
+            _EMPTY[key] = torch.zeros(8, dtype=torch.int64, device=t.device)
+        return ctypes.c_void_p(_EMPTY[key].data_ptr())
+    return ctypes.c_void_p(t.data_ptr())
 
 
 def _stream(dev: torch.device):
@@ -62,6 +74,8 @@ def col_sums(rowptr, col, val, n_cols: int, f64: bool = False) -> torch.Tensor:
     """Column sums, accumulated in float64 on the device; returned as float32 (rounded once) or, ``f64=True``, as is."""
     dev = _need_gpu(rowptr, col, val)
     _chk(rowptr, torch.int64, "rowptr"); _chk(col, torch.int32, "col"); _chk(val, torch.float32, "val")
+    if col.numel() == 0:                        # a graph without entries (its col[] has no storage to point at)
+        return torch.zeros(n_cols, dtype=torch.float64 if f64 else torch.float32, device=dev)
     wide = torch.empty(n_cols, dtype=torch.float64, device=dev)
     out = None if f64 else torch.empty(n_cols, dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):

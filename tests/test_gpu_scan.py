@@ -231,3 +231,57 @@ def test_scan_wide_id_space_in_windows(eps, oracle, dev):
     o = torch.sort(vals, descending=True, stable=True).indices[:k]
     pairs, scores = scan.scan_topk(g, wt, k)
     assert torch.equal((pairs[1] << 32) | pairs[0], keys[o]) and torch.equal(scores, vals[o])
+
+
+def _structured_graphs():
+    import scipy.sparse as ssp
+    rng = np.random.default_rng(17)
+
+    def sym(n, r, c):
+        A = ssp.coo_matrix((np.ones(len(r), dtype=np.float32), (r, c)), shape=(n, n)).tocsr()
+        A = ((A + A.T) > 0).astype(np.float32).tocsr()
+        A.setdiag(0)
+        A.eliminate_zeros()
+        A.sort_indices()
+        return A
+    out = {}
+    n = 3001                                          # star: a hub of degree n - 1 (several descriptor rounds), leaf columns
+    out["star"] = sym(n, np.zeros(n - 1, dtype=np.int64), np.arange(1, n))
+    n = 200                                           # complete graph: no candidate at all
+    r, c = np.nonzero(np.ones((n, n)) - np.eye(n))
+    out["complete"] = sym(n, r, c)
+    n = 1000
+    out["path"] = sym(n, np.arange(n - 1), np.arange(1, n))
+    n = 130                                           # two cliques joined by one edge, plus isolated nodes
+    r, c = np.nonzero(np.ones((60, 60)) - np.eye(60))
+    out["two_cliques"] = sym(n, np.concatenate([r, r + 60, [0]]), np.concatenate([c, c + 60, [60]]))
+    out["empty"] = sym(50, np.zeros(0, dtype=np.int64), np.zeros(0, dtype=np.int64))
+    out["single_edge"] = sym(2, np.array([0]), np.array([1]))
+    for n, p in ((31, 0.3), (33, 0.2), (1000, 0.01), (4097, 0.002), (1500, 0.5)):      # the last: > 2^20 records per column
+        m = int(n * n * p / 2)
+        out[f"er_{n}_{p}"] = sym(n, rng.integers(0, n, m), rng.integers(0, n, m))
+    return out
+
+
+@pytest.mark.parametrize("name", list(_structured_graphs()))
+def test_scan_and_unit_lists_on_structured_graphs(eps, dev, name):
+    """Edge-case shapes: the threshold scan (no bar, all columns) reports exactly the u < v half of the list the unit list
+    kernels write, with the same score bits; the unit list equals eps_expand_fill's (whose parity with the oracle is
+    established in test_gpu_expand.py)."""
+    from eps_amd import scan
+    from eps_amd.heuristics import node_weight_table
+    A = _structured_graphs()[name]
+    g = eps.CSRGraph.from_scipy(A, device=dev, keep_values=False)
+    n = g.n_rows
+    wt = node_weight_table(g, eps.ops.W_AA)
+    want = eps.ops.expand_candidates(g.rowptr, g.col, None, wt, n, 0, n, want_cn=False)
+    got = eps.ops.expand_unit(g.rowptr, g.col, wt, n, 0, n, scan.max_degree(g), scan.window_splits(g))
+    assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1]) and torch.equal(got[2], want[2])
+    assert torch.equal(got[4], want[4])
+    half = want[1] < want[2]
+    full = {(int(u), int(v)): float(s) for u, v, s in zip(want[1][half].cpu(), want[2][half].cpu(), want[4][half].cpu())}
+    if not scan.scan_available(g):
+        assert g.nnz() == 0 or n < 1
+        return
+    found, n_cand = _scan_all(eps, g, wt)
+    assert n_cand == len(full) and found == full
