@@ -125,3 +125,36 @@ def test_bench_two_ranks_child_process(dev, tmp_path, scaling):
     assert line["n_gpus"] == 2 and line["scaling"] == scaling and line["value"] > 0
     per_graph = line["config"]["candidates_per_step_all_ranks"] // (2 if scaling == "weak" else 1)
     assert per_graph > 0 and 0 < line["roofline"]["frac"] <= 1
+
+
+def _relabelled_scan_rank_main(rank, world, port, workdir):
+    sys.path.insert(0, ROOT)
+    os.chdir(workdir)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    import eps_amd  # noqa: F401
+    from eps_amd import dist as epd, ops, scan, synth
+    from eps_amd.heuristics import node_weight_table
+    epd.init_from_env("gloo", 0)
+    scan.RELABEL_MIN_NODES = 0
+    scan.SMALL_SET = 0                               # the estimated-bar path
+    dev = torch.device("cuda:0")
+    g = synth.rmat_graph(13, 10, 21, dev)
+    pairs, scores = scan.scan_topk(g, node_weight_table(g, ops.W_AA), 30000, rank, world, relabel=True)
+    assert scan.scan_graph(g)[1] is not None
+    torch.save((pairs.cpu(), scores.cpu()), f"scan_rank{rank}.pt")
+    torch.distributed.destroy_process_group()
+
+
+def test_scan_two_ranks_hubs_first_labels(eps, dev, tmp_path):
+    """The sharded threshold scan on the hubs-first relabelled copy (what bench.py --scaling strong runs): both ranks end
+    with the single-process list as scanned under the original labels, bit for bit."""
+    from eps_amd import scan, synth
+    from eps_amd.heuristics import node_weight_table
+    g = synth.rmat_graph(13, 10, 21, dev)
+    want_p, want_s = scan.scan_topk(g, node_weight_table(g, eps.ops.W_AA), 30000)
+    assert scan.scan_graph(g)[1] is None
+    mp.spawn(_relabelled_scan_rank_main, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    for r in (0, 1):
+        p, s = torch.load(os.path.join(tmp_path, f"scan_rank{r}.pt"))
+        assert torch.equal(p, want_p.cpu()) and torch.equal(s, want_s.cpu())
