@@ -1,0 +1,200 @@
+// The K best DIRECTED proposals out of a list of unordered survivors of the threshold scan, in the declared order, gfx950.
+//
+// Replaces `all_scores[:,2].sort(descending=True)` + row gather (filter.py:160-161) for the K rows rank.py reads (rank.py:294),
+// on top of eps_filter_scan's survivor list: key = v << 32 | u with u < v, one entry per unordered pair, both orientations
+// carry the pair's score.  Declared order: score descending, then key ascending (== the reference's column-major candidate
+// order; its own torch.sort is unstable on ties).
+//   1. the k-th best directed score is the ceil(k/2)-th best unordered one (radix select, topk_keys.hip);
+//   2. the pairs at or above it are compacted (eps_select_topk_cut); the caller reads their number m back -- the one host
+//      round trip of the selection, as short as a device word;
+//   3. each becomes two rows (key, mirrored key); stable LSD radix sorts by the id bits of u, of v, then descending by score
+//      (rocPRIM through hipCUB: library sorts -- the selection logic, the row layout and the C ABI are what this file adds);
+//   4. the first min(k, 2 m) rows are the answer (eps_select_topk_rows).
+#include "eps_common.h"
+
+#include <hipcub/hipcub.hpp>
+
+extern "C" int64_t eps_kth_largest_workspace_bytes(void);
+extern "C" int eps_kth_largest_f32(const float *x, int64_t n, int64_t k, float *kth, void *workspace, void *stream);
+
+struct sel_state {
+    unsigned long long n_sel;    // unordered pairs at or above the cut
+    float kth;
+    float pad;
+};
+
+// pairs at or above the cut, appended in arbitrary order (the sorts that follow order them).  A wave takes 1024 consecutive
+// entries at a time (16 coalesced loads per lane) and reserves room for all its hits with ONE atomic: a returning atomic per
+// 64 entries on a single counter costs more than the whole selection (0.9 ms for 4.8 M entries).
+__global__ void sel_cut_kernel(const int64_t *__restrict__ keys, const float *__restrict__ vals, int64_t n, int use_cut,
+                               sel_state *__restrict__ st, int64_t *__restrict__ sel_keys, float *__restrict__ sel_vals)
+{
+    const float cut = use_cut ? st->kth : -__builtin_inff();
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t c0 = wave * 1024; c0 < n; c0 += n_waves * 1024) {
+        int64_t k[16];
+        float s[16];
+        unsigned int bits = 0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int64_t i = c0 + j * 64 + lane;
+            const bool in = i < n;
+            s[j] = in ? vals[i] : 0.f;
+            k[j] = in ? keys[i] : -1;
+            if (in && s[j] >= cut && k[j] >= 0) bits |= 1u << j;
+        }
+        const int cnt = __popc(bits);
+        int incl = cnt;                                         // inclusive prefix over the lanes
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int t = __shfl_up(incl, d);
+            if (lane >= d) incl += t;
+        }
+        const int total = __shfl(incl, 63);
+        if (total == 0) continue;
+        unsigned long long base = 0;
+        if (lane == 0) base = atomicAdd(&st->n_sel, (unsigned long long)total);
+        const unsigned int blo = __shfl((unsigned int)base, 0), bhi = __shfl((unsigned int)(base >> 32), 0);
+        unsigned long long pos = (((unsigned long long)bhi << 32) | blo) + (unsigned long long)(incl - cnt);
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+            if (bits & (1u << j)) {
+                sel_keys[pos] = k[j];
+                sel_vals[pos] = s[j];
+                ++pos;
+            }
+    }
+}
+
+__global__ void sel_count_kernel(const sel_state *__restrict__ st, int64_t *__restrict__ n_sel) { *n_sel = (int64_t)st->n_sel; }
+
+__global__ void sel_mirror_kernel(const int64_t *__restrict__ keys, const float *__restrict__ vals, int64_t m,
+                                  int64_t *__restrict__ dkeys, float *__restrict__ dvals)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += stride) {
+        const int64_t k = keys[i];
+        const float s = vals[i];
+        dkeys[i] = k;
+        dkeys[m + i] = (int64_t)((((uint64_t)k & 0xFFFFFFFFull) << 32) | ((uint64_t)k >> 32));
+        dvals[i] = s;
+        dvals[m + i] = s;
+    }
+}
+
+static size_t sel_align(size_t x) { return (x + 255) & ~(size_t)255; }
+
+static size_t sel_sort_temp_bytes(int64_t rows)
+{
+    size_t a = 0, b = 0;
+    (void)hipcub::DeviceRadixSort::SortPairs((void *)nullptr, a, (const int64_t *)nullptr, (int64_t *)nullptr, (const float *)nullptr,
+                                             (float *)nullptr, rows, 0, 64, (hipStream_t)0);
+    (void)hipcub::DeviceRadixSort::SortPairsDescending((void *)nullptr, b, (const float *)nullptr, (float *)nullptr,
+                                                       (const int64_t *)nullptr, (int64_t *)nullptr, rows, 0, 32, (hipStream_t)0);
+    return a > b ? a : b;
+}
+
+static unsigned sel_blocks(int64_t n)
+{
+    int64_t blocks = (n + 255) / 256;
+    const int64_t cap = (int64_t)eps_num_cus() * 8;
+    if (blocks > cap) blocks = cap;
+    return (unsigned)(blocks < 1 ? 1 : blocks);
+}
+
+extern "C" int64_t eps_select_topk_cut_workspace_bytes(void)
+{
+    return (int64_t)(sel_align(sizeof(sel_state)) + sel_align((size_t)eps_kth_largest_workspace_bytes()));
+}
+
+// Step 1: the pairs whose score reaches the ceil(k/2)-th best one (all of them when the list is shorter), compacted, in
+// arbitrary order; *n_sel (device) = how many.  sel_keys / sel_vals hold n entries.
+extern "C" int eps_select_topk_cut(const int64_t *keys, const float *vals, int64_t n, int64_t k, int64_t *sel_keys,
+                                   float *sel_vals, int64_t *n_sel, void *workspace, int64_t workspace_bytes, void *stream)
+{
+    EPS_REQUIRE(n >= 0 && k >= 0, "eps_select_topk_cut: negative size");
+    EPS_REQUIRE(n_sel, "eps_select_topk_cut: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    if (n == 0 || k == 0) {
+        if (hipMemsetAsync(n_sel, 0, sizeof(int64_t), s) != hipSuccess) {
+            eps_set_error("eps_select_topk_cut: cannot clear the count");
+            return EPS_ELAUNCH;
+        }
+        return EPS_OK;
+    }
+    EPS_REQUIRE(keys && vals && sel_keys && sel_vals, "eps_select_topk_cut: null pointer");
+    EPS_REQUIRE(n < (1ll << 31), "eps_select_topk_cut: list too long");
+    EPS_REQUIRE(workspace && ((uintptr_t)workspace & 255) == 0 && workspace_bytes >= eps_select_topk_cut_workspace_bytes(),
+                "eps_select_topk_cut: needs a 256-byte aligned workspace of eps_select_topk_cut_workspace_bytes() bytes");
+    sel_state *st = (sel_state *)workspace;
+    void *kws = (char *)workspace + sel_align(sizeof(sel_state));
+    if (hipMemsetAsync(st, 0, sizeof(sel_state), s) != hipSuccess) {
+        eps_set_error("eps_select_topk_cut: cannot initialise the state");
+        return EPS_ELAUNCH;
+    }
+    const int64_t k2 = (k + 1) / 2;                    // the k-th best directed row belongs to the ceil(k/2)-th best pair
+    const int use_cut = n > k2;
+    if (use_cut) {
+        const int rc = eps_kth_largest_f32(vals, n, k2, &st->kth, kws, stream);
+        if (rc) return rc;
+    }
+    hipLaunchKernelGGL(sel_cut_kernel, dim3(sel_blocks((n + 3) / 4)), dim3(256), 0, s, keys, vals, n, use_cut, st, sel_keys, sel_vals);
+    hipLaunchKernelGGL(sel_count_kernel, dim3(1), dim3(1), 0, s, st, n_sel);
+    EPS_CHECK_LAUNCH("eps_select_topk_cut");
+    return EPS_OK;
+}
+
+extern "C" int64_t eps_select_topk_rows_workspace_bytes(int64_t m)
+{
+    if (m <= 0) return 256;
+    const size_t rows = 2 * (size_t)m;
+    return (int64_t)(2 * sel_align(rows * 8) + 2 * sel_align(rows * 4) + sel_align(sel_sort_temp_bytes((int64_t)rows)));
+}
+
+// Step 2: the m selected pairs (m read back by the caller) -> both orientations, sorted by the declared rule; the first
+// min(k, 2 m) rows go to out_keys / out_vals.  id_bits: every id is below 2^id_bits (1..32): the key sort skips the other bits.
+extern "C" int eps_select_topk_rows(const int64_t *sel_keys, const float *sel_vals, int64_t m, int64_t k, int32_t id_bits,
+                                    int64_t *out_keys, float *out_vals, void *workspace, int64_t workspace_bytes, void *stream)
+{
+    EPS_REQUIRE(m >= 0 && k >= 0 && id_bits >= 1 && id_bits <= 32, "eps_select_topk_rows: bad argument");
+    if (m == 0 || k == 0) return EPS_OK;
+    EPS_REQUIRE(sel_keys && sel_vals && out_keys && out_vals, "eps_select_topk_rows: null pointer");
+    EPS_REQUIRE(m < (1ll << 30), "eps_select_topk_rows: list too long");
+    EPS_REQUIRE(workspace && ((uintptr_t)workspace & 255) == 0 && workspace_bytes >= eps_select_topk_rows_workspace_bytes(m),
+                "eps_select_topk_rows: needs a 256-byte aligned workspace of eps_select_topk_rows_workspace_bytes(m) bytes");
+    hipStream_t s = (hipStream_t)stream;
+    const size_t rows = 2 * (size_t)m;
+    char *w = (char *)workspace;
+    int64_t *k0 = (int64_t *)w;                        w += sel_align(rows * 8);
+    int64_t *k1 = (int64_t *)w;                        w += sel_align(rows * 8);
+    float *v0 = (float *)w;                            w += sel_align(rows * 4);
+    float *v1 = (float *)w;                            w += sel_align(rows * 4);
+    void *temp = w;
+    size_t temp_bytes = sel_sort_temp_bytes((int64_t)rows);
+    hipLaunchKernelGGL(sel_mirror_kernel, dim3(sel_blocks(m)), dim3(256), 0, s, sel_keys, sel_vals, m, k0, v0);
+    // stable LSD sorts, least significant criterion first: u (low id bits), v (high id bits), then the score, descending
+    hipError_t e;
+    if (id_bits >= 24) {         // (nearly) all bits count: one sort over the whole key (non-negative: the sign bit is idle)
+        e = hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, k0, k1, v0, v1, (int64_t)rows, 0, 63, s);
+        if (e == hipSuccess) e = hipMemcpyAsync(k0, k1, rows * 8, hipMemcpyDeviceToDevice, s);
+        if (e == hipSuccess) e = hipMemcpyAsync(v0, v1, rows * 4, hipMemcpyDeviceToDevice, s);
+    } else {
+        e = hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, k0, k1, v0, v1, (int64_t)rows, 0, id_bits, s);
+        if (e == hipSuccess) e = hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, k1, k0, v1, v0, (int64_t)rows, 32, 32 + id_bits, s);
+    }
+    if (e != hipSuccess ||
+        hipcub::DeviceRadixSort::SortPairsDescending(temp, temp_bytes, v0, v1, k0, k1, (int64_t)rows, 0, 32, s) != hipSuccess) {
+        eps_set_error("eps_select_topk_rows: radix sort failed");
+        return EPS_ELAUNCH;
+    }
+    const size_t take = (size_t)k < rows ? (size_t)k : rows;
+    if (hipMemcpyAsync(out_keys, k1, take * 8, hipMemcpyDeviceToDevice, s) != hipSuccess ||
+        hipMemcpyAsync(out_vals, v1, take * 4, hipMemcpyDeviceToDevice, s) != hipSuccess) {
+        eps_set_error("eps_select_topk_rows: cannot copy the rows out");
+        return EPS_ELAUNCH;
+    }
+    EPS_CHECK_LAUNCH("eps_select_topk_rows");
+    return EPS_OK;
+}

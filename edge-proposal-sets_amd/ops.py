@@ -522,6 +522,50 @@ def kth_largest(x: torch.Tensor, k: int) -> torch.Tensor:
     return out
 
 
+_SELECT_WS = {}
+
+
+def _aligned_ws(dev, n_bytes: int):
+    """(tensor, 256-byte aligned pointer, bytes from there) of a grow-only per-device scratch."""
+    need = (int(n_bytes) + 7) // 8 + 32
+    key = (dev.type, dev.index)
+    if key not in _SELECT_WS or _SELECT_WS[key].numel() < need:
+        _SELECT_WS.pop(key, None)
+        _SELECT_WS[key] = torch.empty(int(need * 1.25), dtype=torch.int64, device=dev)
+    ws = _SELECT_WS[key]
+    off = (-ws.data_ptr()) % 256
+    return ws, ctypes.c_void_p(ws.data_ptr() + off), ws.numel() * 8 - off
+
+
+def select_topk(keys: torch.Tensor, vals: torch.Tensor, k: int, id_bits: int = 32) -> Tuple[torch.Tensor, torch.Tensor]:
+    """The k best DIRECTED rows (score descending, key ascending) of a list of unordered survivors of ``filter_scan``
+    (key = v << 32 | u, u < v; no -1 slots): (keys int64, scores float32), sorted.  eps_select_topk_cut (radix select of the
+    cut + compaction) -> one host read of the count -> eps_select_topk_rows (mirror + stable radix sorts).  ``id_bits``:
+    every node id is below 2**id_bits (fewer sort passes)."""
+    dev = _need_gpu(keys, vals)
+    _chk(keys, torch.int64, "keys"); _chk(vals, torch.float32, "vals")
+    n, k = keys.numel(), int(k)
+    if vals.numel() != n:
+        raise _lib.EpsError("select_topk: keys and vals differ in length")
+    lib = _lib.load()
+    sel_k = torch.empty(n, dtype=torch.int64, device=dev)
+    sel_v = torch.empty(n, dtype=torch.float32, device=dev)
+    n_sel = torch.zeros(1, dtype=torch.int64, device=dev)
+    with torch.cuda.device(dev):
+        _, wsp, wsb = _aligned_ws(dev, lib.eps_select_topk_cut_workspace_bytes())
+        _lib.check(lib.eps_select_topk_cut(_ptr(keys), _ptr(vals), n, k, _ptr(sel_k), _ptr(sel_v), _ptr(n_sel), wsp, wsb,
+                                           _stream(dev)), "eps_select_topk_cut")
+        m = int(n_sel.item())
+        take = min(k, 2 * m)
+        out_k = torch.empty(take, dtype=torch.int64, device=dev)
+        out_v = torch.empty(take, dtype=torch.float32, device=dev)
+        if take:
+            _, wsp, wsb = _aligned_ws(dev, lib.eps_select_topk_rows_workspace_bytes(m))
+            _lib.check(lib.eps_select_topk_rows(_ptr(sel_k), _ptr(sel_v), m, k, int(id_bits), _ptr(out_k), _ptr(out_v), wsp, wsb,
+                                                _stream(dev)), "eps_select_topk_rows")
+    return out_k, out_v
+
+
 def pack_keys(score: torch.Tensor, ids: Optional[torch.Tensor] = None, id_base: int = 0) -> torch.Tensor:
     dev = _need_gpu(score, ids)
     _chk(score, torch.float32, "score"); _chk(ids, torch.int64, "ids")

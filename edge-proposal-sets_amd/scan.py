@@ -174,14 +174,23 @@ def _gather_varlen(t: torch.Tensor, world: int):
     return torch.cat([parts[r][:lens[r]] for r in range(world)])
 
 
-def select_topk(keys: torch.Tensor, vals: torch.Tensor, k: int) -> Tuple[torch.Tensor, torch.Tensor]:
+def select_topk(keys: torch.Tensor, vals: torch.Tensor, k: int, n_nodes: Optional[int] = None) -> Tuple[torch.Tensor, torch.Tensor]:
     """The k best DIRECTED candidates (score descending, key ascending) of a list of unordered survivors (key = v << 32 | u,
-    u < v; both orientations carry the pair's score).  -> (keys, scores), sorted.  The k-th best directed score is the
-    ceil(k/2)-th best unordered one (radix select on the device); every pair at or above it is mirrored, ties included,
-    and the declared order decides among them."""
+    u < v; both orientations carry the pair's score).  -> (keys, scores), sorted.  On the device: eps_select_topk_cut / _rows
+    (``n_nodes`` bounds the ids: fewer radix passes)."""
+    if keys.is_cuda:
+        bits = 32 if not n_nodes else max(1, min(32, int(n_nodes - 1).bit_length()))
+        return ops.select_topk(keys.contiguous(), vals.contiguous(), k, bits)
+    return select_topk_torch(keys, vals, k)
+
+
+def select_topk_torch(keys: torch.Tensor, vals: torch.Tensor, k: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    """The same selection in tensor ops (host tensors; the device path is checked against it).  The k-th best directed score
+    is the ceil(k/2)-th best unordered one; every pair at or above it is mirrored, ties included, and the declared order
+    decides among them."""
     k2 = (k + 1) // 2
     if vals.numel() > k2:
-        kth = ops.kth_largest(vals, k2)
+        kth = torch.sort(vals, descending=True).values[k2 - 1] if k2 >= 1 else float("inf")
         m = vals >= kth
         keys, vals = keys[m], vals[m]
     keys = torch.cat([keys, ((keys & 0xFFFFFFFF) << 32) | (keys >> 32)])
@@ -254,7 +263,7 @@ def scan_topk(g: CSRGraph, node_w: torch.Tensor, k: int, rank: int = 0, world: i
     keys = _original_keys(keys, perm)
     if world > 1:
         keys, vals = _gather_varlen(keys, world), _gather_varlen(vals, world)
-    keys, vals = select_topk(keys, vals, k)
+    keys, vals = select_topk(keys, vals, k, g.n_rows)
     if stats is not None:
         stats.update(candidates=2 * n_cand_all, launches=launches, survivors=2 * n_all,
                      bar=None if bar is None else float(bar.item()))

@@ -269,6 +269,20 @@ int eps_mlp_decode(const float *h, int64_t n_nodes, int32_t hdim, const int32_t 
  * eps_kth_largest_workspace_bytes() bytes, 8-byte aligned, contents arbitrary. */
 int64_t eps_kth_largest_workspace_bytes(void);
 int eps_kth_largest_f32(const float *x, int64_t n, int64_t k, float *kth, void *workspace, void *stream);
+/* The k best DIRECTED proposals of a list of n unordered survivors of eps_filter_scan (keys v << 32 | u with u < v, one
+ * entry per pair, no -1 slots; both orientations carry the pair's score), sorted by the declared rule -- score descending,
+ * then key ascending (the reference's column-major candidate order): filter.py:160-161 for the rows rank.py:294 reads.
+ *   eps_select_topk_cut : the pairs whose score reaches the ceil(k/2)-th best one, compacted into sel_keys / sel_vals
+ *                         (n entries each, arbitrary order); *n_sel (DEVICE word) = their number m, which the caller reads.
+ *   eps_select_topk_rows: those m pairs -> 2 m rows (v << 32 | u of proposal (u, v), score), sorted; the first
+ *                         min(k, 2 m) go to out_keys / out_vals.  id_bits: every node id is below 2^id_bits.
+ * workspaces: eps_select_topk_cut_workspace_bytes() / eps_select_topk_rows_workspace_bytes(m) bytes, 256-byte aligned. */
+int64_t eps_select_topk_cut_workspace_bytes(void);
+int eps_select_topk_cut(const int64_t *keys, const float *vals, int64_t n, int64_t k, int64_t *sel_keys, float *sel_vals,
+                        int64_t *n_sel, void *workspace, int64_t workspace_bytes, void *stream);
+int64_t eps_select_topk_rows_workspace_bytes(int64_t m);
+int eps_select_topk_rows(const int64_t *sel_keys, const float *sel_vals, int64_t m, int64_t k, int32_t id_bits,
+                         int64_t *out_keys, float *out_vals, void *workspace, int64_t workspace_bytes, void *stream);
 int eps_pack_keys(const float *score, const int64_t *ids_or_null, int64_t id_base, int64_t n,
                   int64_t *keys, void *stream);
 int eps_unpack_keys(const int64_t *keys, int64_t n, float *score_or_null, int64_t *id_or_null,

@@ -195,3 +195,40 @@ def test_kth_largest_radix_select(eps, dev):
             assert got.shape == (1,) and float(got) == float(ref[k - 1]), (n, k)
     with pytest.raises(eps.EpsError):
         eps.ops.kth_largest(torch.zeros(4, device=dev), 5)
+
+
+@pytest.mark.parametrize("n,k", [(1, 1), (5, 3), (1000, 7), (1000, 2000), (1000, 5000), (200_000, 40_001), (3_000_000, 1_000_000)])
+def test_select_topk_matches_tensor_ops(eps, dev, n, k):
+    """eps_select_topk (cut by radix select, mirror, two stable radix sorts) against the same selection in tensor ops: heavy
+    ties (scores from a small set), k odd / above the list / below it."""
+    from eps_amd import scan
+    g = torch.Generator().manual_seed(n + k)
+    u = torch.randint(0, 1 << 19, (n,), generator=g)
+    v = u + 1 + torch.randint(0, 1 << 19, (n,), generator=g)
+    keys = torch.unique((v << 32) | u)                                   # distinct unordered pairs, u < v
+    vals = (torch.randint(0, 50, (keys.numel(),), generator=g).float() / 7).contiguous()
+    want_k, want_v = scan.select_topk_torch(keys, vals, k)
+    for bits in (32, 21):                                                 # ids <= 2^20: the key sort may skip the other bits
+        got_k, got_v = eps.ops.select_topk(keys.to(dev), vals.to(dev), k, bits)
+        assert torch.equal(got_k.cpu(), want_k) and torch.equal(got_v.cpu(), want_v)
+
+
+def test_select_topk_random_sizes_and_id_widths(eps, dev):
+    from eps_amd import scan
+    g = torch.Generator().manual_seed(99)
+    for trial in range(40):
+        bits = int(torch.randint(3, 31, (1,), generator=g))
+        n = int(torch.randint(1, 30000, (1,), generator=g))
+        k = int(torch.randint(1, 3 * n + 2, (1,), generator=g))
+        u = torch.randint(0, (1 << bits) - 1, (n,), generator=g)
+        v = u + 1 + (torch.rand(n, generator=g) * ((1 << bits) - 1 - u).double()).long()
+        v = torch.clamp(v, max=(1 << bits) - 1)
+        ok = v > u
+        keys = torch.unique((v[ok] << 32) | u[ok])
+        if keys.numel() == 0:
+            continue
+        vals = (torch.randint(0, 9, (keys.numel(),), generator=g).float() - 3.5).contiguous()      # ties, negative scores too
+        want_k, want_v = scan.select_topk_torch(keys, vals, k)
+        for b in (bits, 32):
+            got_k, got_v = eps.ops.select_topk(keys.to(dev), vals.to(dev), k, b)
+            assert torch.equal(got_k.cpu(), want_k) and torch.equal(got_v.cpu(), want_v), (trial, bits, b, n, k)
