@@ -393,13 +393,20 @@ class Survivors:
     """Device-resident eps_survivors record + its key / val arrays.  ``threshold`` may be a Python float or a 0-dim /
     1-element float32 DEVICE tensor (copied on the stream: no host round trip)."""
 
-    def __init__(self, capacity: int, threshold, device):
+    def __init__(self, capacity: int, threshold, device, scores_only: bool = False):
+        """``scores_only``: the caller will read the scores alone (the bar estimate): untouched slots are then recognisable
+        in ``val`` (-inf) instead of in ``key`` (-1), so no compaction pass is needed before a k-th-largest query."""
         import struct
         self.capacity = int(capacity)
         if not 0 < self.capacity < 1 << 32:
             raise _lib.EpsError(f"Survivors: capacity {capacity} outside (0, 2**32)")
-        self.key = torch.full((self.capacity,), -1, dtype=torch.int64, device=device)
-        self.val = torch.empty(self.capacity, dtype=torch.float32, device=device)
+        self.scores_only = bool(scores_only)
+        if scores_only:
+            self.key = torch.empty(self.capacity, dtype=torch.int64, device=device)
+            self.val = torch.full((self.capacity,), float("-inf"), dtype=torch.float32, device=device)
+        else:
+            self.key = torch.full((self.capacity,), -1, dtype=torch.int64, device=device)
+            self.val = torch.empty(self.capacity, dtype=torch.float32, device=device)
         thr_host = float(threshold) if not isinstance(threshold, torch.Tensor) else 0.0
         head = struct.unpack("<q", struct.pack("<fI", thr_host, self.capacity))[0]
         self.rec = torch.tensor([head, 0, self.key.data_ptr(), self.val.data_ptr(), 0], dtype=torch.int64, device=device)
@@ -411,8 +418,14 @@ class Survivors:
         c = self.rec[[1, 4]].tolist()
         return int(c[0]) & 0xFFFFFFFF, int(c[1])
 
+    def scores(self, slots: int) -> torch.Tensor:
+        """The first ``slots`` score slots as they are: survivors' scores, -inf in untouched slots (``scores_only``)."""
+        assert self.scores_only
+        return self.val[:min(int(slots), self.capacity)]
+
     def valid(self, slots: int):
         """(keys, scores) of the survivors among the first ``slots`` slots (unordered)."""
+        assert not self.scores_only
         n = min(int(slots), self.capacity)
         k = self.key[:n]
         m = k >= 0

@@ -137,8 +137,8 @@ def _original_keys(keys: torch.Tensor, perm) -> torch.Tensor:
     return (torch.maximum(a, b) << 32) | torch.minimum(a, b)
 
 
-def _launch(g, fixw, columns, threshold, capacity) -> ops.Survivors:
-    out = ops.Survivors(capacity, threshold, g.device)
+def _launch(g, fixw, columns, threshold, capacity, scores_only: bool = False) -> ops.Survivors:
+    out = ops.Survivors(capacity, threshold, g.device, scores_only)
     if columns.numel():
         ops.filter_scan(g.rowptr, g.col, reverse_positions(g), fixw, g.n_rows, columns, out, max_degree(g), window_splits(g))
     return out
@@ -153,13 +153,12 @@ def estimate_bar(g: CSRGraph, fixw: torch.Tensor, k: int, stride: int = SAMPLE_S
     bound = int(hp[sample.long()].sum().item())          # unordered candidates of the sample <= its half paths
     if bound == 0:
         return None
-    res = _launch(g, fixw, sample, float("-inf"), 2 * bound + _CHUNK_SLACK)
-    slots, _ = res.counts()
-    _, vals = res.valid(slots)
+    res = _launch(g, fixw, sample, float("-inf"), 2 * bound + _CHUNK_SLACK, scores_only=True)
+    slots, n_cand = res.counts()                         # no bar: every candidate of the sample holds a slot
     m = int(safety * k / 2 / stride) + 1                 # unordered pairs of the SAMPLE above the bar we aim at
-    if m >= vals.numel():
+    if m >= n_cand or slots > res.capacity:
         return None
-    return ops.kth_largest(vals, m)                      # radix select on the device (csrc/topk_keys.hip)
+    return ops.kth_largest(res.scores(slots), m)         # radix select over the slots as they are (untouched ones: -inf)
 
 
 def _gather_varlen(t: torch.Tensor, world: int):
