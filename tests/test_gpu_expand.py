@@ -116,10 +116,21 @@ def test_expand_matches_pair_kernel_at_scale(eps, dev):
 
 
 def test_expand_rejects_oversized_id_space(eps, dev):
+    """Node ids are int32: an id space of 2^31 is refused before anything is launched (wider-than-LDS id spaces below that
+    are expanded in id windows: test_expand_id_range_boundaries)."""
+    import ctypes
+    from eps_amd import _lib
+    rp = torch.zeros(16, dtype=torch.int64, device=dev)
+    col = torch.zeros(16, dtype=torch.int32, device=dev)
+    cnt = torch.zeros(16, dtype=torch.int64, device=dev)
+    P = lambda t: ctypes.c_void_p(t.data_ptr())       # noqa: E731
+    rc = _lib.load().eps_expand_count(P(rp), P(col), 1 << 31, 0, 10, None, P(cnt), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc != 0 and b"int32" in _lib.load().eps_last_error()
+    # an EMPTY graph over an id space wider than the LDS bitmap is fine (and has no candidates)
     n = eps.ops.expand_max_nodes() + 1
-    rp = torch.zeros(n + 1, dtype=torch.int64, device=dev)
-    with pytest.raises(eps.EpsError):
-        eps.ops.expand_candidates(rp, torch.zeros(0, dtype=torch.int32, device=dev), None, None, n, 0, 10)
+    r = eps.ops.expand_candidates(torch.zeros(n + 1, dtype=torch.int64, device=dev), torch.zeros(0, dtype=torch.int32, device=dev),
+                                  None, None, n, 0, 10)
+    assert r[1].numel() == 0 and int(r[0][-1]) == 0
 
 
 def _dense_symmetric(n, p, seed, weighted):
