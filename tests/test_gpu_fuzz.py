@@ -124,3 +124,52 @@ def test_dense_kernels_ragged_shapes(eps, oracle, dev, seed):
                                apply_sigmoid=False).cpu().numpy()
     assert rel_err(prob, prob_o) <= 1e-5, (H, L, E)
     assert float(np.abs(logit - logit_o).max()) <= 2e-5 * max(1.0, float(np.abs(logit_o).max())), (H, L, E)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_scan_topk_fuzz(eps, oracle, dev, seed, monkeypatch):
+    """The production filter path on random graphs: scan_topk (estimated bar or none, labels as given or hubs first) equals
+    the first K rows of the declared order over the oracle's full candidate scoring -- pairs exactly wherever the K-th score is
+    not tied within float rounding of a neighbour, scores within the gate."""
+    import scipy.sparse as ssp
+    from eps_amd import scan
+    from eps_amd.heuristics import node_weight_table
+    rng = np.random.default_rng(500 + seed)
+    n = int(rng.integers(40, 4000))
+    m = int(n * rng.uniform(1.5, 12))
+    r, c = rng.integers(0, n, m), rng.integers(0, n, m)
+    if seed % 2:                                                       # skew: a few hubs
+        hubs = rng.integers(0, n, max(1, n // 200))
+        r = np.concatenate([r, np.repeat(hubs, n // 4)]); c = np.concatenate([c, rng.integers(0, n, len(hubs) * (n // 4))])
+    A = ssp.coo_matrix((np.ones(len(r), dtype=np.float32), (r, c)), shape=(n, n)).tocsr()
+    A = ((A + A.T) > 0).astype(np.float32).tocsr()
+    A.setdiag(0); A.eliminate_zeros(); A.sort_indices()
+    g = eps.CSRGraph.from_scipy(A, device=dev, keep_values=False)
+    rp, col = A.indptr.astype(np.int64), A.indices.astype(np.int32)
+    cand, _ = oracle.candidates_scipy(A)
+    if len(cand) == 0:
+        return
+    w = oracle.node_weights(oracle.col_sums(rp, col, None, n), oracle.W_AA)
+    _, truth = oracle.pair_scores_f64(rp, col, None, w.astype(np.float64), cand[:, 0], cand[:, 1])
+    wt = node_weight_table(g, eps.ops.W_AA)
+    monkeypatch.setattr(scan, "SMALL_SET", 0 if seed % 3 else scan.SMALL_SET)      # mostly the estimated-bar path
+    monkeypatch.setattr(scan, "SAMPLE_STRIDE", int(rng.integers(2, 40)))
+    monkeypatch.setattr(scan, "RELABEL_MIN_NODES", 0)
+    k = int(rng.integers(1, max(2, len(cand))))
+    got = {}
+    for relabel in (False, True):
+        pairs, scores = scan.scan_topk(g, wt, k, relabel=relabel)
+        got[relabel] = (pairs.cpu().numpy(), scores.cpu().numpy())
+        assert (scan.scan_graph(g)[1] is not None) == relabel
+    assert np.array_equal(got[False][0], got[True][0]) and np.array_equal(got[False][1], got[True][1]), "labels must not matter"
+    p, s = got[False]
+    assert p.shape[1] == min(k, len(cand)) and bool((s[:-1] >= s[1:]).all())
+    key = cand[:, 1].astype(np.int64) * n + cand[:, 0]                 # candidates_scipy: column-major, keys ascend
+    pos = np.searchsorted(key, p[1] * n + p[0])
+    assert np.array_equal(key[pos], p[1] * n + p[0]), "a proposal is not a 2-hop non-edge"
+    assert rel_err(s, truth[pos].astype(np.float32)) <= 1e-6
+    kth = np.sort(truth)[-p.shape[1]]
+    assert s.min() >= np.float32(kth) * (1 - 1e-6), "a better candidate was left out"
+    # equal scores come out in candidate order (key ascending)
+    same = s[:-1] == s[1:]
+    assert bool((pos[:-1][same] < pos[1:][same]).all())
