@@ -225,3 +225,33 @@ def test_path_counts_and_bucket_sizing_helpers():
     order = candidates.heaviest_first(g, 10, 200)
     assert sorted(order.tolist()) == list(range(190)) and bool((pc[10:200][order.long()][:-1] >= pc[10:200][order.long()][1:]).all())
     assert candidates.path_counts(small).tolist() == [0, int(d[3] + d[1]), 0, int(d[1]), 0]
+
+
+def test_select_topk_tensor_ops_vs_brute_force():
+    """scan.select_topk_torch (the host mirror the device selection is checked against): the K best DIRECTED rows of a list of
+    unordered pairs, score descending then key ascending -- against a brute-force sort of both orientations."""
+    import torch
+    from eps_amd import scan
+    g = torch.Generator().manual_seed(4)
+    for n, k in ((1, 1), (1, 5), (50, 7), (50, 99), (50, 100), (50, 1000), (2000, 1501)):
+        u = torch.randint(0, 500, (n,), generator=g)
+        v = u + 1 + torch.randint(0, 500, (n,), generator=g)
+        keys = torch.unique((v << 32) | u)
+        vals = torch.randint(0, 6, (keys.numel(),), generator=g).float() / 3          # many ties
+        got_k, got_v = scan.select_topk_torch(keys, vals, k)
+        rows = [(-float(s), int(kk)) for kk, s in zip(keys.tolist(), vals.tolist())]
+        rows += [(-float(s), ((kk & 0xFFFFFFFF) << 32) | (kk >> 32)) for kk, s in zip(keys.tolist(), vals.tolist())]
+        rows.sort()
+        want = rows[:k]
+        assert got_k.tolist() == [r[1] for r in want] and got_v.tolist() == [-r[0] for r in want]
+
+
+def test_original_keys_after_relabelling():
+    """Survivor keys in the scanned graph's labels -> the same unordered pairs in the original labels (larger id in the high word)."""
+    import torch
+    from eps_amd import scan
+    perm = torch.tensor([4, 0, 3, 1, 2])                   # new id i is old id perm[i]
+    keys = torch.tensor([(3 << 32) | 1, (4 << 32) | 0, (2 << 32) | 1])      # (u', v') = (1,3), (0,4), (1,2)
+    out = scan._original_keys(keys, perm)
+    assert out.tolist() == [(1 << 32) | 0, (4 << 32) | 2, (3 << 32) | 0]
+    assert scan._original_keys(keys, None) is keys
