@@ -221,7 +221,12 @@ def expand_block(g: CSRGraph, v_lo: int, v_hi: int, node_w: Optional[torch.Tenso
     return (pairs.long() if long_pairs else pairs), cn, sc
 
 
-DEFAULT_BLOCK_PATHS = 1 << 29     # two-hop paths per launch: ~4e8 candidates, ~13 GB of outputs + scratch on a 288 GB device
+# Two-hop paths per launch.  A block never holds more candidates than paths, so every per-block count stays below 2^31; at
+# ~0.76 candidates per path a full block is ~1.6e9 candidates = 13 GB of ids + scores on a 288 GB device.  Large blocks matter:
+# one column is one workgroup's work from start to end, so a launch is never shorter than its heaviest column (7 M paths =
+# ~10 ms on the ppa-like graph) -- at 2^29 paths per launch (r01) the 256 workgroups' average share was a quarter of that
+# column and the list kernels spent a quarter of their time waiting for it (scored list of the whole graph: 194 -> 141 ms).
+DEFAULT_BLOCK_PATHS = (1 << 31) - 1
 
 
 def column_blocks(g: CSRGraph, max_paths: int = None) -> Iterator[Tuple[int, int]]:

@@ -75,7 +75,7 @@ def test_filter_cli_matches_oracle(eps, oracle, workdir, dataset, model, mode):
             fname3 = filter_stage.main(["--dataset", dataset, "--model", model, "--checkpoint",
                                         f"{dataset}_{model}||0|2.pt", "--synthetic", "--keep_top", "500"])
         finally:
-            candidates.DEFAULT_BLOCK_PATHS, filter_stage.CUT_CAPACITY = 1 << 29, 1 << 23
+            candidates.DEFAULT_BLOCK_PATHS, filter_stage.CUT_CAPACITY = (1 << 31) - 1, 1 << 23
         assert torch.equal(torch.load(fname3), got[:500])
 
 

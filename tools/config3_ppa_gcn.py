@@ -5,7 +5,9 @@ import argparse, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch, eps_amd
-from eps_amd import datasets, filter_stage, models
+from eps_amd import candidates, datasets, filter_stage, models
+if os.environ.get("MAX_PATHS"):
+    candidates.DEFAULT_BLOCK_PATHS = int(os.environ["MAX_PATHS"])      # two-hop paths per column block (A/B of the block size)
 os.makedirs("/tmp/cfg3", exist_ok=True); os.chdir("/tmp/cfg3")
 cli = ["--num_layers", "3", "--hidden_channels", "256", "--dropout", "0.0", "--batch_size", "65536", "--use_feature", "1",
        "--use_learnable_embedding", "1"]   # the reference has no ppa defaults: flags come from the CLI

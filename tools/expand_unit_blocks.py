@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Whole ppa-like graph, block by block (2^29 two-hop paths per launch, as the filter stage cuts it): the candidate list
+"""Whole ppa-like graph, block by block (as the filter stage cuts it: candidates.DEFAULT_BLOCK_PATHS two-hop paths per launch; MAX_PATHS overrides): the candidate list
 with Adamic-Adar scores / the list only, through eps_expand_count + eps_expand_fill (expand_score.hip) and through
 eps_expand_unit_count + eps_expand_unit_fill (the scan kernel's structure) -- wall time per call incl. the counting pass,
 the prefix sum and the one host read of the total; outputs compared bit for bit on every block."""
@@ -12,7 +12,7 @@ from eps_amd.heuristics import node_weight_table
 dev = torch.device("cuda:0")
 g = synth.ppa_like(seed=3, device=dev)
 w = node_weight_table(g, ops.W_AA)
-blocks = list(candidates.column_blocks(g, int(os.environ.get("MAX_PATHS", 1 << 29))))
+blocks = list(candidates.column_blocks(g, int(os.environ.get("MAX_PATHS", candidates.DEFAULT_BLOCK_PATHS))))
 md, sp, mp = scan.max_degree(g), scan.window_splits(g), candidates.max_paths_of(g)
 def timed(fn):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
