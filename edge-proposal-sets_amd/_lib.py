@@ -48,6 +48,7 @@ SIGNATURES = {
     "eps_kth_largest_workspace_bytes": (_i64, []),
     "eps_kth_largest_f32": (_int, [_vp, _i64, _i64, _vp, _vp, _vp]),
     "eps_select_topk_cut_workspace_bytes": (_i64, []),
+    "eps_compact_survivors": (_int, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp]),
     "eps_select_topk_cut": (_int, [_vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _i64, _vp]),
     "eps_select_topk_rows_workspace_bytes": (_i64, [_i64]),
     "eps_select_topk_rows": (_int, [_vp, _vp, _i64, _i64, _i32, _vp, _vp, _vp, _i64, _vp]),

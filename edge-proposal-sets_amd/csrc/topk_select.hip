@@ -146,6 +146,36 @@ extern "C" int eps_select_topk_cut(const int64_t *keys, const float *vals, int64
     return EPS_OK;
 }
 
+// The survivors among the first n slots of an eps_survivors list (slots are handed out in chunks: untouched ones keep key -1),
+// compacted in arbitrary order; *n_out (device) = how many.  out arrays hold n entries; workspace as for eps_select_topk_cut.
+extern "C" int eps_compact_survivors(const int64_t *keys, const float *vals, int64_t n, int64_t *out_keys, float *out_vals,
+                                     int64_t *n_out, void *workspace, int64_t workspace_bytes, void *stream)
+{
+    EPS_REQUIRE(n >= 0, "eps_compact_survivors: negative size");
+    EPS_REQUIRE(n_out, "eps_compact_survivors: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    if (n == 0) {
+        if (hipMemsetAsync(n_out, 0, sizeof(int64_t), s) != hipSuccess) {
+            eps_set_error("eps_compact_survivors: cannot clear the count");
+            return EPS_ELAUNCH;
+        }
+        return EPS_OK;
+    }
+    EPS_REQUIRE(keys && vals && out_keys && out_vals, "eps_compact_survivors: null pointer");
+    EPS_REQUIRE(n < (1ll << 32), "eps_compact_survivors: list too long");
+    EPS_REQUIRE(workspace && ((uintptr_t)workspace & 255) == 0 && workspace_bytes >= eps_select_topk_cut_workspace_bytes(),
+                "eps_compact_survivors: needs a 256-byte aligned workspace of eps_select_topk_cut_workspace_bytes() bytes");
+    sel_state *st = (sel_state *)workspace;
+    if (hipMemsetAsync(st, 0, sizeof(sel_state), s) != hipSuccess) {
+        eps_set_error("eps_compact_survivors: cannot initialise the state");
+        return EPS_ELAUNCH;
+    }
+    hipLaunchKernelGGL(sel_cut_kernel, dim3(sel_blocks((n + 3) / 4)), dim3(256), 0, s, keys, vals, n, 0, st, out_keys, out_vals);
+    hipLaunchKernelGGL(sel_count_kernel, dim3(1), dim3(1), 0, s, st, n_out);
+    EPS_CHECK_LAUNCH("eps_compact_survivors");
+    return EPS_OK;
+}
+
 extern "C" int64_t eps_select_topk_rows_workspace_bytes(int64_t m)
 {
     if (m <= 0) return 256;

@@ -424,12 +424,21 @@ class Survivors:
         return self.val[:min(int(slots), self.capacity)]
 
     def valid(self, slots: int):
-        """(keys, scores) of the survivors among the first ``slots`` slots (unordered)."""
+        """(keys, scores) of the survivors among the first ``slots`` slots (unordered): eps_compact_survivors + one host
+        read of the count."""
         assert not self.scores_only
         n = min(int(slots), self.capacity)
-        k = self.key[:n]
-        m = k >= 0
-        return k[m], self.val[:n][m]
+        dev = self.key.device
+        out_k = torch.empty(n, dtype=torch.int64, device=dev)
+        out_v = torch.empty(n, dtype=torch.float32, device=dev)
+        n_out = torch.zeros(1, dtype=torch.int64, device=dev)
+        lib = _lib.load()
+        with torch.cuda.device(dev):
+            _, wsp, wsb = _aligned_ws(dev, lib.eps_select_topk_cut_workspace_bytes())
+            _lib.check(lib.eps_compact_survivors(_ptr(self.key), _ptr(self.val), n, _ptr(out_k), _ptr(out_v), _ptr(n_out), wsp, wsb,
+                                                 _stream(dev)), "eps_compact_survivors")
+        m = int(n_out.item())
+        return out_k[:m], out_v[:m]
 
 
 def filter_scan(rowptr, col, revpos, fixw, n_nodes: int, columns: torch.Tensor, out: Survivors, max_degree: int,

@@ -8,7 +8,7 @@
 //            then candidate order (column-major) ascending -- the order tests/test_gpu_examples.py compares with scan.scan_topk.
 //
 // Small graphs only: every column is scanned with no bar (the Python host estimates a bar from a column sample first:
-// edge-proposal-sets_amd/scan.py); the survivor list is compacted on the host to keep the example short.
+// edge-proposal-sets_amd/scan.py).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -129,20 +129,17 @@ int main(int argc, char **argv)
         fprintf(stderr, "survivor list overflow\n");
         return 4;
     }
-    // compact (host side here; the Python host does it on the device)
-    std::vector<int64_t> key(rec.count);
-    std::vector<float> val(rec.count);
-    HIP_OK(hipMemcpy(key.data(), d_key, (size_t)rec.count * 8, hipMemcpyDeviceToHost));
-    HIP_OK(hipMemcpy(val.data(), d_val, (size_t)rec.count * 4, hipMemcpyDeviceToHost));
-    size_t m = 0;
-    for (size_t i = 0; i < key.size(); ++i)
-        if (key[i] >= 0) {
-            key[m] = key[i];
-            val[m] = val[i];
-            ++m;
-        }
+    // the survivors, compacted on the device (slots are handed out in chunks: untouched ones kept their -1)
+    const int64_t slots = rec.count;
+    int64_t *d_ck = dev_alloc<int64_t>(slots), *d_m = dev_alloc<int64_t>(1);
+    float *d_cv = dev_alloc<float>(slots);
+    void *d_cws = dev_alloc<char>(eps_select_topk_cut_workspace_bytes());
+    EPS_OK_(eps_compact_survivors(d_key, d_val, slots, d_ck, d_cv, d_m, d_cws, eps_select_topk_cut_workspace_bytes(), stream));
+    int64_t m = 0;
+    HIP_OK(hipMemcpyAsync(&m, d_m, 8, hipMemcpyDeviceToHost, stream));
+    HIP_OK(hipStreamSynchronize(stream));
     if ((unsigned long long)m != rec.n_candidates) {
-        fprintf(stderr, "survivors %zu != candidates %llu\n", m, rec.n_candidates);
+        fprintf(stderr, "survivors %lld != candidates %llu\n", (long long)m, rec.n_candidates);
         return 5;
     }
 
@@ -151,11 +148,8 @@ int main(int argc, char **argv)
     std::vector<int64_t> out_key;
     std::vector<float> out_val;
     if (m && K > 0) {
-        int64_t *d_ck = dev_alloc<int64_t>(m), *d_sk = dev_alloc<int64_t>(m), *d_nsel = dev_alloc<int64_t>(1);
-        float *d_cv = dev_alloc<float>(m), *d_sv = dev_alloc<float>(m);
-        HIP_OK(hipMemcpyAsync(d_ck, key.data(), m * 8, hipMemcpyHostToDevice, stream));
-        HIP_OK(hipMemcpyAsync(d_cv, val.data(), m * 4, hipMemcpyHostToDevice, stream));
-        void *d_cws = dev_alloc<char>(eps_select_topk_cut_workspace_bytes());
+        int64_t *d_sk = dev_alloc<int64_t>(m), *d_nsel = dev_alloc<int64_t>(1);
+        float *d_sv = dev_alloc<float>(m);
         EPS_OK_(eps_select_topk_cut(d_ck, d_cv, (int64_t)m, K, d_sk, d_sv, d_nsel, d_cws, eps_select_topk_cut_workspace_bytes(), stream));
         int64_t n_sel = 0;
         HIP_OK(hipMemcpyAsync(&n_sel, d_nsel, 8, hipMemcpyDeviceToHost, stream));

@@ -277,7 +277,12 @@ int eps_kth_largest_f32(const float *x, int64_t n, int64_t k, float *kth, void *
  *   eps_select_topk_rows: those m pairs -> 2 m rows (v << 32 | u of proposal (u, v), score), sorted; the first
  *                         min(k, 2 m) go to out_keys / out_vals.  id_bits: every node id is below 2^id_bits.
  * workspaces: eps_select_topk_cut_workspace_bytes() / eps_select_topk_rows_workspace_bytes(m) bytes, 256-byte aligned. */
+/* eps_compact_survivors: the survivors among the first n slots of an eps_survivors list (untouched slots keep key -1),
+ * compacted in arbitrary order into out_keys / out_vals (n entries each); *n_out (DEVICE word) = how many.  workspace as for
+ * eps_select_topk_cut. */
 int64_t eps_select_topk_cut_workspace_bytes(void);
+int eps_compact_survivors(const int64_t *keys, const float *vals, int64_t n, int64_t *out_keys, float *out_vals,
+                          int64_t *n_out, void *workspace, int64_t workspace_bytes, void *stream);
 int eps_select_topk_cut(const int64_t *keys, const float *vals, int64_t n, int64_t k, int64_t *sel_keys, float *sel_vals,
                         int64_t *n_sel, void *workspace, int64_t workspace_bytes, void *stream);
 int64_t eps_select_topk_rows_workspace_bytes(int64_t m);
