@@ -170,7 +170,7 @@ def run(args) -> str:
 
     t0 = time.perf_counter()
     keep = int(args.keep_top)
-    scan_w = fused_node_weights(args, data.adj_t, ra_graph) if keep and scan.scan_available(data.adj_t) else None
+    scan_w = fused_node_weights(args, data.adj_t, ra_graph) if 0 < keep <= scan.MAX_K and scan.scan_available(data.adj_t) else None
     if scan_w is not None:
         # --keep_top on a unit-valued graph with a heuristic filter: one threshold scan of the whole candidate set
         # (csrc/filter_scan.hip) instead of candidate blocks + streaming top-K; every rank ends with the same list

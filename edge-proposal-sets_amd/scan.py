@@ -33,6 +33,8 @@ from .graph import CSRGraph
 SAMPLE_STRIDE = 256        # every n-th column (heaviest-first order) estimates the bar
 SAFETY = 2.0               # aim at SAFETY x K survivors (the estimate has been within 10 % on the ppa-sized graphs; too few -> one more scan)
 SMALL_SET = 1 << 25        # candidate sets with at most this many two-hop half paths are scanned without a bar
+MAX_K = 1 << 30            # rows a survivor list (< 2^32 slots, handed out in chunks) can be asked for; beyond: block streaming
+MAX_LAUNCHES = 8           # estimate -> scan -> correct rounds before giving up (two are the rule)
 _CHUNK_SLACK = 8192 * 320  # survivor slots are handed out in chunks of 8192 per workgroup
 RELABEL_MIN_NODES = 100_000  # graphs at least this large are scanned under hubs-first labels (see scan_graph)
 
@@ -208,6 +210,8 @@ def scan_topk(g: CSRGraph, node_w: torch.Tensor, k: int, rank: int = 0, world: i
     if not scan_available(g):
         raise ops._lib.EpsError("scan_topk: graph not supported by eps_filter_scan (see scan_available)")
     k = int(k)
+    if not 0 < k <= MAX_K:
+        raise ops._lib.EpsError(f"scan_topk: k = {k} outside (0, {MAX_K}] (longer lists: the block-streaming filter path)")
     dev = g.device
     g0 = g
     g, perm = scan_graph(g0, relabel)    # from here on g is the graph as scanned; ids go back through perm at the end
@@ -224,6 +228,8 @@ def scan_topk(g: CSRGraph, node_w: torch.Tensor, k: int, rank: int = 0, world: i
     expect = (2 * total_half if bar is None else int(2 * SAFETY * k)) // world
     capacity = min(2 * expect + _CHUNK_SLACK, (1 << 32) - 1)
     while True:
+        if launches >= MAX_LAUNCHES:
+            raise ops._lib.EpsError(f"scan_topk: no usable bar after {launches} launches (k = {k}, capacity {capacity})")
         res = _launch(g, fixw, mine, float("-inf") if bar is None else bar, capacity)
         launches += 1
         slots, n_cand = res.counts()

@@ -100,3 +100,14 @@ def test_scan_refuses_asymmetric_pattern(eps, dev):
     assert not scan.is_symmetric(h) and not scan.scan_available(h)
     with pytest.raises(eps.EpsError):
         scan.scan_topk(h, torch.ones(h.n_rows, device=dev), 10)
+
+
+def test_scan_topk_refuses_unusable_k(eps, dev):
+    from eps_amd import scan, synth
+    g = synth.rmat_graph(9, 6, 3, dev)
+    w = torch.ones(g.n_rows, device=dev)
+    for k in (0, -3, scan.MAX_K + 1):
+        with pytest.raises(eps.EpsError):
+            scan.scan_topk(g, w, k)
+    pairs, scores = scan.scan_topk(g, w, scan.MAX_K)            # more rows than candidates: all of them, sorted
+    assert pairs.shape[1] == scores.numel() > 0 and bool((scores[:-1] >= scores[1:]).all())
