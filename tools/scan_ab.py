@@ -18,6 +18,11 @@ if os.environ.get("COLMAX"):               # only the columns with id < COLMAX (
     cm = int(os.environ["COLMAX"])
     order = order[order < cm].contiguous() if cm > 0 else order[order >= -cm].contiguous()
     print("columns", order.numel(), "half paths", int(scan.half_paths(g)[order.long()].sum()))
+if os.environ.get("HPMAX"):                # only the columns with at most HPMAX half paths (more than -HPMAX when negative)
+    hm = int(os.environ["HPMAX"])
+    hpv = scan.half_paths(g)[order.long()]
+    order = order[hpv <= hm].contiguous() if hm > 0 else order[hpv > -hm].contiguous()
+    print("columns", order.numel(), "half paths", int(scan.half_paths(g)[order.long()].sum()))
 revpos = scan.reverse_positions(g)
 bar = float(os.environ.get("BAR", "2.14"))
 libs = []
