@@ -38,8 +38,8 @@ SIGNATURES = {
     "eps_filter_scan_windows": (_int, [_i64, _c.POINTER(_i64), _c.POINTER(_i64)]),
     "eps_row_window_splits": (_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp]),
     "eps_filter_scan": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _i64, _vp, _vp, _i64, _vp]),
-    "eps_expand_unit_count": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _i64, _vp]),
-    "eps_expand_unit_fill": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+    "eps_expand_unit_count": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _i64, _vp]),
+    "eps_expand_unit_fill": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                     _i64, _vp]),
     "eps_spmm_csr": (_int, [_vp, _vp, _vp, _i64, _vp, _i64, _i32, _vp, _int, _int, _vp, _i64, _vp]),
     "eps_gcn_norm": (_int, [_vp, _vp, _vp, _i64, _vp, _vp, _vp]),

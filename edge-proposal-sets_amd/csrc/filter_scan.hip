@@ -163,10 +163,13 @@ struct fs_unit {
     int nvalid;   // 0..4 entries of u4 that belong to the row head
 };
 
-template <bool WINDOWED, int MODE>
+// HALF (FS_EMIT / FS_COUNT): the list holds the endpoints BELOW the column only, like the scan -- for symmetric patterns
+// whose consumer is symmetric in (u, v) too (the GNN filters: the decoder scores h_u * h_v), so that each unordered pair is
+// listed -- and decoded -- once.
+template <bool WINDOWED, int MODE, bool HALF = false>
 __global__ __launch_bounds__(FS_THREADS) void filter_scan_kernel(fs_params p)
 {
-    constexpr bool FULL = MODE != FS_SCAN;      // all endpoints of a column, not only those below it
+    constexpr bool FULL = MODE != FS_SCAN && !HALF;      // all endpoints of a column, not only those below it
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const fs_layout L = fs_make_layout(p.words, p.tile_bits);
     uint32_t *bm = lds;                                   // bit u: u (< v) is a two-hop endpoint of the column
@@ -320,6 +323,10 @@ __global__ __launch_bounds__(FS_THREADS) void filter_scan_kernel(fs_params p)
                     r0 = rowptr_lo[2 * (size_t)w];
                     hi = (int32_t)(rowptr_lo[2 * (size_t)w + 2] - r0);
                     if (p.fixw) fx = p.fixw[w];                // (NULL: the list / the counts only)
+                } else if (MODE != FS_SCAN) {                  // HALF list
+                    hi = vrev[j0 + tid];
+                    r0 = rowptr_lo[2 * (size_t)w];
+                    if (p.fixw) fx = p.fixw[w];
                 } else {
                     hi = vrev[j0 + tid];
                     r0 = (uint32_t)p.rowptr[w];
@@ -812,7 +819,7 @@ __global__ __launch_bounds__(FS_THREADS) void filter_scan_kernel(fs_params p)
         fs_barrier();                  // the next window marks into the words other threads just cleared
         }
         }
-        if (FULL) {
+        if (MODE != FS_SCAN) {
             if (p.cand_count && tid == 0 && !seg_overflow) p.cand_count[v - p.col_base] = col_off;
             if (MODE == FS_EMIT && !seg_overflow)
                 for (int64_t i = col_off + tid; i < seg_len; i += FS_THREADS) {   // padding of an upper-bound segment
@@ -993,7 +1000,8 @@ extern "C" int64_t eps_filter_scan_workspace_bytes(int64_t max_degree)
 
 // one launch of filter_scan_kernel<WINDOWED, MODE>: geometry, counter, LDS size (the caller filled the mode's own fields of p)
 static int fs_launch(const char *who, fs_params p, int mode, const int32_t *splits, int64_t n_nodes, int64_t nnz,
-                     int64_t max_degree, int64_t n_columns, void *workspace, int64_t workspace_bytes, void *stream)
+                     int64_t max_degree, int64_t n_columns, void *workspace, int64_t workspace_bytes, void *stream,
+                     bool half = false)
 {
     EPS_REQUIRE(nnz < (1ll << 30), "%s: col[] is addressed with 32-bit byte offsets (nnz < 2^30)", who);
     EPS_REQUIRE(n_columns < (1ll << 31), "%s: too many columns", who);
@@ -1029,8 +1037,11 @@ static int fs_launch(const char *who, fs_params p, int mode, const int32_t *spli
     const bool win = geo.n_win > 1;
     void (*kern)(fs_params) =
         mode == FS_SCAN ? (win ? filter_scan_kernel<true, FS_SCAN> : filter_scan_kernel<false, FS_SCAN>)
-        : mode == FS_EMIT ? (win ? filter_scan_kernel<true, FS_EMIT> : filter_scan_kernel<false, FS_EMIT>)
-                          : (win ? filter_scan_kernel<true, FS_COUNT> : filter_scan_kernel<false, FS_COUNT>);
+        : mode == FS_EMIT
+            ? (half ? (win ? filter_scan_kernel<true, FS_EMIT, true> : filter_scan_kernel<false, FS_EMIT, true>)
+                    : (win ? filter_scan_kernel<true, FS_EMIT> : filter_scan_kernel<false, FS_EMIT>))
+            : (half ? (win ? filter_scan_kernel<true, FS_COUNT, true> : filter_scan_kernel<false, FS_COUNT, true>)
+                    : (win ? filter_scan_kernel<true, FS_COUNT> : filter_scan_kernel<false, FS_COUNT>));
     if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
         eps_set_error("%s: cannot reserve %zu bytes of LDS", who, lds);
         return EPS_ELAUNCH;
@@ -1070,10 +1081,13 @@ extern "C" int eps_filter_scan(const int64_t *rowptr, const int32_t *col, const 
 // non-edge of columns [v_lo, v_hi) in the reference's order (filter.py:96-109), optionally with its score
 // sum_w A[u,w] A[v,w] node_w[w] -- for adjacencies WITHOUT stored values, with the threshold scan's machinery: packed 64-entry
 // units, 4-byte bucket records, one fixed-point weight per (v, w) from a table, 16-byte record stores.  Both orientations of
-// a pair are produced (column-major order cannot be mirrored cheaply), so whole rows are walked, not row heads.
-extern "C" int eps_expand_unit_count(const int64_t *rowptr, const int32_t *col, const int32_t *splits, int64_t n_nodes,
-                                     int64_t nnz, int64_t max_degree, int64_t v_lo, int64_t v_hi, const int32_t *col_order,
-                                     int64_t *cand_count, void *workspace, int64_t workspace_bytes, void *stream)
+// a pair are produced (column-major order cannot be mirrored cheaply), so whole rows are walked, not row heads -- unless the
+// caller passes revpos (eps_reverse_positions; symmetric pattern): then column v lists only its candidates u < v, every
+// unordered pair once, for consumers that are symmetric in (u, v) themselves (the GNN filters' decoder).
+extern "C" int eps_expand_unit_count(const int64_t *rowptr, const int32_t *col, const int32_t *revpos_or_null,
+                                     const int32_t *splits, int64_t n_nodes, int64_t nnz, int64_t max_degree, int64_t v_lo,
+                                     int64_t v_hi, const int32_t *col_order, int64_t *cand_count, void *workspace,
+                                     int64_t workspace_bytes, void *stream)
 {
     EPS_REQUIRE(n_nodes >= 0 && nnz >= 0 && v_lo >= 0 && v_lo <= v_hi && v_hi <= n_nodes, "eps_expand_unit_count: bad range");
     if (v_hi == v_lo) return EPS_OK;
@@ -1084,11 +1098,13 @@ extern "C" int eps_expand_unit_count(const int64_t *rowptr, const int32_t *col, 
     p.columns = col_order;
     p.col_base = (int32_t)v_lo;
     p.cand_count = cand_count;
+    p.revpos = revpos_or_null;
     return fs_launch("eps_expand_unit_count", p, FS_COUNT, splits, n_nodes, nnz, max_degree, v_hi - v_lo, workspace,
-                     workspace_bytes, stream);
+                     workspace_bytes, stream, revpos_or_null != nullptr);
 }
 
-extern "C" int eps_expand_unit_fill(const int64_t *rowptr, const int32_t *col, const int64_t *fixw, const int32_t *splits,
+extern "C" int eps_expand_unit_fill(const int64_t *rowptr, const int32_t *col, const int32_t *revpos_or_null,
+                                    const int64_t *fixw, const int32_t *splits,
                                     int64_t n_nodes, int64_t nnz, int64_t max_degree, int64_t v_lo, int64_t v_hi,
                                     const int32_t *col_order, const int64_t *colptr, int64_t *cand_count, int32_t *cand_u,
                                     int32_t *cand_v, float *score, uint32_t *status, void *workspace,
@@ -1113,6 +1129,7 @@ extern "C" int eps_expand_unit_fill(const int64_t *rowptr, const int32_t *col, c
     p.cand_v = cand_v;
     p.out_score = score;
     p.status = status;
+    p.revpos = revpos_or_null;
     return fs_launch("eps_expand_unit_fill", p, FS_EMIT, splits, n_nodes, nnz, max_degree, v_hi - v_lo, workspace,
-                     workspace_bytes, stream);
+                     workspace_bytes, stream, revpos_or_null != nullptr);
 }

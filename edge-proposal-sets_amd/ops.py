@@ -199,13 +199,15 @@ def expand_workspace_fits(max_paths: int) -> bool:
 
 
 def expand_unit(rowptr, col, node_w, n_nodes: int, v_lo: int, v_hi: int, max_degree: int, splits=None, want_score=True,
-                want_v=True, col_order=None):
+                want_v=True, col_order=None, revpos=None):
     """The candidate list of columns [v_lo, v_hi) of a graph WITHOUT stored values, on the threshold scan's structure
     (eps_expand_unit_count / eps_expand_unit_fill, csrc/filter_scan.hip): same tuple and same bits as
     ``expand_candidates(rowptr, col, None, node_w, ...)`` with ``want_cn=False`` -- (colptr, cand_u, cand_v | None, None,
     score | None) -- at about half the time.  ``node_w`` None with ``want_score``: all-ones weights (the score is the
-    common-neighbour count).  ``max_degree`` / ``splits``: the per-graph figures ``filter_scan`` takes."""
-    dev = _need_gpu(rowptr, col, node_w, col_order, splits)
+    common-neighbour count).  ``max_degree`` / ``splits``: the per-graph figures ``filter_scan`` takes.  ``revpos``
+    (``reverse_positions``; symmetric pattern) selects the HALF list: column v holds its candidates u < v only."""
+    dev = _need_gpu(rowptr, col, node_w, col_order, splits, revpos)
+    _chk(revpos, torch.int32, "revpos")
     _chk(rowptr, torch.int64, "rowptr"); _chk(col, torch.int32, "col"); _chk(node_w, torch.float32, "node_w")
     _chk(col_order, torch.int32, "col_order"); _chk(splits, torch.int32, "splits")
     lib = _lib.load()
@@ -217,7 +219,7 @@ def expand_unit(rowptr, col, node_w, n_nodes: int, v_lo: int, v_hi: int, max_deg
         counts = torch.zeros(n_cols, dtype=torch.int64, device=dev)
         colptr = torch.zeros(n_cols + 1, dtype=torch.int64, device=dev)
         if n_cols:
-            _lib.check(lib.eps_expand_unit_count(_ptr(rowptr), _ptr(col), _ptr(splits), n_nodes, col.numel(), int(max_degree),
+            _lib.check(lib.eps_expand_unit_count(_ptr(rowptr), _ptr(col), _ptr(revpos), _ptr(splits), n_nodes, col.numel(), int(max_degree),
                                                  v_lo, v_hi, _ptr(col_order), _ptr(counts), _ptr(ws), ws.numel() * 8,
                                                  _stream(dev)), "eps_expand_unit_count")
         torch.cumsum(counts, 0, out=colptr[1:])
@@ -229,7 +231,7 @@ def expand_unit(rowptr, col, node_w, n_nodes: int, v_lo: int, v_hi: int, max_deg
             if want_score:
                 fixw = fixed_weights(node_w if node_w is not None else torch.ones(n_nodes, dtype=torch.float32, device=dev))
             status = torch.zeros(1, dtype=torch.int32, device=dev)
-            _lib.check(lib.eps_expand_unit_fill(_ptr(rowptr), _ptr(col), _ptr(fixw), _ptr(splits), n_nodes, col.numel(),
+            _lib.check(lib.eps_expand_unit_fill(_ptr(rowptr), _ptr(col), _ptr(revpos), _ptr(fixw), _ptr(splits), n_nodes, col.numel(),
                                                 int(max_degree), v_lo, v_hi, _ptr(col_order), _ptr(colptr), None,
                                                 _ptr(pairs[0]), _ptr(pairs[1]) if want_v else None, _ptr(score), _ptr(status),
                                                 _ptr(ws), ws.numel() * 8, _stream(dev)), "eps_expand_unit_fill")

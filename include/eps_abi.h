@@ -207,11 +207,16 @@ int eps_filter_scan(const int64_t *rowptr, const int32_t *col, const int32_t *re
  * (or any upper-bound layout: the rest of a segment is padded with cand_u -1 / score -inf and cand_count, if given,
  * receives the real counts).  status: one device word, cleared by the call; after the stream has drained bit 1 = a
  * column outgrew its segment, bit 2 = a sum left the fixed-point range -- the outputs are then invalid.  splits /
- * max_degree / workspace as for eps_filter_scan (eps_filter_scan_workspace_bytes(max_degree) bytes). */
-int eps_expand_unit_count(const int64_t *rowptr, const int32_t *col, const int32_t *splits_or_null, int64_t n_nodes,
-                          int64_t nnz, int64_t max_degree, int64_t v_lo, int64_t v_hi, const int32_t *col_order,
-                          int64_t *cand_count, void *workspace, int64_t workspace_bytes, void *stream);
-int eps_expand_unit_fill(const int64_t *rowptr, const int32_t *col, const int64_t *fixw, const int32_t *splits_or_null,
+ * max_degree / workspace as for eps_filter_scan (eps_filter_scan_workspace_bytes(max_degree) bytes).
+ * revpos_or_null (eps_reverse_positions; symmetric pattern only): non-NULL selects the HALF list -- column v lists its
+ * candidates u < v only, every unordered pair once -- for consumers that are symmetric in (u, v) themselves, like the
+ * LinkPredictor decode of h_u * h_v (models.py:478-485): half the list, half the decode, the same scores. */
+int eps_expand_unit_count(const int64_t *rowptr, const int32_t *col, const int32_t *revpos_or_null,
+                          const int32_t *splits_or_null, int64_t n_nodes, int64_t nnz, int64_t max_degree, int64_t v_lo,
+                          int64_t v_hi, const int32_t *col_order, int64_t *cand_count, void *workspace,
+                          int64_t workspace_bytes, void *stream);
+int eps_expand_unit_fill(const int64_t *rowptr, const int32_t *col, const int32_t *revpos_or_null, const int64_t *fixw,
+                         const int32_t *splits_or_null,
                          int64_t n_nodes, int64_t nnz, int64_t max_degree, int64_t v_lo, int64_t v_hi,
                          const int32_t *col_order, const int64_t *colptr, int64_t *cand_count, int32_t *cand_u,
                          int32_t *cand_v, float *score, uint32_t *status, void *workspace, int64_t workspace_bytes,

@@ -339,6 +339,15 @@ def _unit_vs_expand(eps, g, wt, lo, hi, col_order=None):
     assert got[3] is None and torch.equal(got[4], want[4]), "scores bit-identical"
     lst = eps.ops.expand_unit(g.rowptr, g.col, None, g.n_rows, lo, hi, md, sp, want_score=False, want_v=False)
     assert torch.equal(lst[0], want[0]) and torch.equal(lst[1], want[1]) and lst[2] is None and lst[4] is None
+    # the HALF list (revpos given; symmetric patterns): exactly the u < v part of every column, same score bits
+    from eps_amd import scan as _scan
+    if _scan.is_symmetric(g):
+        half = eps.ops.expand_unit(g.rowptr, g.col, wt, g.n_rows, lo, hi, md, sp, col_order=col_order, revpos=_scan.reverse_positions(g))
+        keep = want[1] < want[2]
+        assert torch.equal(half[1], want[1][keep]) and torch.equal(half[2], want[2][keep]) and torch.equal(half[4], want[4][keep])
+        per_col = torch.zeros(hi - lo, dtype=torch.int64, device=want[1].device)
+        per_col.index_add_(0, (want[2][keep] - lo).long(), torch.ones(int(keep.sum()), dtype=torch.int64, device=want[1].device))
+        assert torch.equal(half[0][1:] - half[0][:-1], per_col)
     cn = eps.ops.expand_unit(g.rowptr, g.col, None, g.n_rows, lo, hi, md, sp)         # all-ones weights: the CN count
     ref_cn = eps.ops.expand_candidates(g.rowptr, g.col, None, None, g.n_rows, lo, hi, want_cn=True, want_score=False)[3]
     assert torch.equal(cn[4], ref_cn.to(torch.float32))
@@ -411,7 +420,7 @@ def test_expand_unit_upper_bound_layout_and_status(eps, dev):
     stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
     def fill(colptr_t, cnt_t):
-        return lib.eps_expand_unit_fill(P(g.rowptr), P(g.col), P(fixw), None, n, g.nnz(), scan.max_degree(g), lo, hi, None,
+        return lib.eps_expand_unit_fill(P(g.rowptr), P(g.col), None, P(fixw), None, n, g.nnz(), scan.max_degree(g), lo, hi, None,
                                         P(colptr_t), P(cnt_t), P(cu), P(cv), P(sc), P(status), P(ws), ws.numel() * 8, stream)
     assert fill(colptr, cnt) == 0
     torch.cuda.synchronize()
