@@ -96,6 +96,72 @@ def fused_node_weights(args, g: CSRGraph, ra_graph):
     return None
 
 
+GNN_HALF = True            # GNN filters under --keep_top on symmetric graphs: decode every unordered pair once (gnn_half_topk)
+
+
+def gnn_half_topk(args, model, data, keep: int, rank: int, world: int):
+    """The ``keep`` best proposals of a GNN filter, decoding each unordered candidate pair ONCE.
+
+    The reference scores both orientations of a pair (filter.py:96-121), but LinkPredictor decodes h_u * h_v
+    (models.py:478-485): the product commutes bit for bit, so score(u, v) == score(v, u).  On a symmetric pattern column v
+    therefore lists only its candidates u < v (eps_expand_unit_* with revpos: half the list), the decoder runs on those
+    (half the MFMA work -- the decode is all of this filter's time: 39.5 -> 20 s on the ppa stand-in), the pairs whose score
+    reaches the running ceil(keep/2)-th best are kept, and the final selection mirrors them and orders the rows by the
+    declared rule (score descending, then candidate order), exactly as the threshold scan's does (scan.select_topk).
+    -> (pairs int64 [2,<=keep], scores float32), candidates seen (both orientations counted)."""
+    g = data.adj_t
+    dev = g.device
+    revpos, md, sp = scan.reverse_positions(g), scan.max_degree(g), scan.window_splits(g)
+    col_lo, col_hi = rank_column_range(g, rank, world)
+    blocks = [(max(lo, col_lo), min(hi, col_hi)) for lo, hi in candidates.column_blocks(g) if lo < col_hi and hi > col_lo]
+    k2 = (keep + 1) // 2
+    keys_l, vals_l, held, bar, n_seen = [], [], 0, None, 0
+    if world > 1 and hasattr(model, "embeddings"):
+        model.embeddings(data.x, data.adj_t)         # the row-sharded forward holds a collective: every rank reaches it
+
+    def prune():
+        nonlocal keys_l, vals_l, held, bar
+        keys, vals = torch.cat(keys_l), torch.cat(vals_l)
+        if vals.numel() > k2:
+            bar = ops.kth_largest(vals, k2)
+            m = vals >= bar
+            keys, vals = keys[m], vals[m]
+        keys_l, vals_l, held = [keys], [vals], keys.numel()
+
+    for v_lo, v_hi in blocks:
+        r = ops.expand_unit(g.rowptr, g.col, None, g.n_rows, v_lo, v_hi, md, sp, want_score=False, want_v=True,
+                            col_order=candidates.heaviest_first(g, v_lo, v_hi), revpos=revpos)
+        pairs = r.pairs                                          # int32 [2, E]: (u; v), u < v
+        if pairs.shape[1] == 0:
+            continue
+        n_seen += 2 * pairs.shape[1]
+        sc = model(data.x, pairs, data.adj_t).reshape(-1)
+        if bar is not None:
+            m = sc >= bar
+            pairs, sc = pairs[:, m], sc[m]
+        keys_l.append((pairs[1].to(torch.int64) << 32) | pairs[0].to(torch.int64))
+        vals_l.append(sc)
+        held += sc.numel()
+        if held > 4 * k2 + (1 << 20):
+            prune()
+    if keys_l:
+        prune()
+        keys, vals = keys_l[0], vals_l[0]
+    else:
+        keys, vals = torch.zeros(0, dtype=torch.int64, device=dev), torch.zeros(0, dtype=torch.float32, device=dev)
+    if world > 1:
+        keys, vals = scan._gather_varlen(keys, world), scan._gather_varlen(vals, world)
+        n_seen = int(sum(epd_gather_int(n_seen)))
+    keys, vals = scan.select_topk(keys, vals, keep, g.n_rows)
+    return torch.stack([keys & 0xFFFFFFFF, keys >> 32]), vals, n_seen
+
+
+def epd_gather_int(x: int):
+    from . import dist as epd
+    t = torch.tensor([x], dtype=torch.int64, device=torch.device("cuda", torch.cuda.current_device()))
+    return [int(v.item()) for v in epd.all_gather_list(t)]
+
+
 CUT_CAPACITY = 1 << 23     # survivors per block the expansion kernel may report (96 MB); more -> the block is redone in full
 
 
@@ -182,6 +248,17 @@ def run(args) -> str:
         print(f'threshold scan ({args.model}): bar {st["bar"]}, {st["survivors"]} survivors, {st["launches"]} launches')
         print(f'using {st["candidates"]} edges; scored in {dt:.2f} s ({st["candidates"] / max(dt, 1e-9):.3e} candidate edges/s '
               f'incl. generation)')
+        return _save(args, spec, sorted_edge_path, num_sorted_edge, run_id, rank, world,
+                     torch.cat([best_pairs.t().to(torch.float32), best_scores.unsqueeze(1)], 1))
+    from .models import LinkGNN
+    if (GNN_HALF and 0 < keep <= scan.MAX_K and isinstance(model, LinkGNN) and data.adj_t.device.type == "cuda"
+            and data.adj_t.n_rows == data.adj_t.n_cols and data.adj_t.nnz() < 1 << 30 and scan.is_symmetric(data.adj_t)):
+        with torch.no_grad():
+            best_pairs, best_scores, n_seen = gnn_half_topk(args, model, data, keep, rank, world)
+        torch.cuda.synchronize(device)
+        dt = time.perf_counter() - t0
+        print(f'GNN filter, each unordered pair decoded once ({args.model})')
+        print(f'using {n_seen} edges; scored in {dt:.2f} s ({n_seen / max(dt, 1e-9):.3e} candidate edges/s incl. generation)')
         return _save(args, spec, sorted_edge_path, num_sorted_edge, run_id, rank, world,
                      torch.cat([best_pairs.t().to(torch.float32), best_scores.unsqueeze(1)], 1))
     col_lo, col_hi = rank_column_range(data.adj_t, rank, world)

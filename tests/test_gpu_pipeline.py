@@ -155,6 +155,19 @@ def test_gnn_filter_cli(eps, oracle, workdir):
     assert float(np.abs(got[sel, 2].numpy() - prob).max()) <= 2e-5
     pairs, _ = oracle.candidates_scipy(A)
     assert len(got) == len(pairs)
+    # --keep_top K: each unordered pair decoded ONCE (filter_stage.gnn_half_topk) == the first K rows of the full file, and ==
+    # the block-streaming path that decodes both orientations
+    for k in (1, 777, 20_000):
+        argv = ["--dataset", "collab", "--model", "gcn", "--checkpoint", "collab_gcn||0|0.pt", "--synthetic",
+                "--hidden_channels", "32", "--keep_top", str(k)]
+        half = torch.load(filter_stage.main(argv))
+        assert torch.equal(half, got[:k])
+        filter_stage.GNN_HALF = False
+        try:
+            both = torch.load(filter_stage.main(argv))
+        finally:
+            filter_stage.GNN_HALF = True
+        assert torch.equal(both, half)
 
 
 def test_collab_recipe_with_valid_proposal(eps, oracle, workdir):
