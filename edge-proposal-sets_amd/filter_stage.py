@@ -250,6 +250,35 @@ def run(args) -> str:
               f'incl. generation)')
         return _save(args, spec, sorted_edge_path, num_sorted_edge, run_id, rank, world,
                      torch.cat([best_pairs.t().to(torch.float32), best_scores.unsqueeze(1)], 1))
+    full_w = fused_node_weights(args, data.adj_t, ra_graph) if keep == 0 and scan.scan_available(data.adj_t) else None
+    if full_w is not None and candidates.fused_scores_fit(data.adj_t, full_w):
+        # the whole [E,3] file of a heuristic filter on a unit-valued symmetric graph: scores are symmetric too, so the list
+        # kernels write each unordered pair once (column v: its candidates u < v), and the rows -- both orientations -- come
+        # out of the same mirror + declared-order sort the threshold scan's selection uses
+        g = data.adj_t
+        col_lo, col_hi = rank_column_range(g, rank, world)
+        keys_l, vals_l = [], []
+        with torch.no_grad():
+            for lo, hi in candidates.column_blocks(g):
+                lo, hi = max(lo, col_lo), min(hi, col_hi)
+                if lo >= hi:
+                    continue
+                r = ops.expand_unit(g.rowptr, g.col, full_w, g.n_rows, lo, hi, scan.max_degree(g), scan.window_splits(g),
+                                    col_order=candidates.heaviest_first(g, lo, hi), revpos=scan.reverse_positions(g))
+                keys_l.append((r.pairs[1].to(torch.int64) << 32) | r.pairs[0].to(torch.int64))
+                vals_l.append(r[4])
+        keys = torch.cat(keys_l) if keys_l else torch.zeros(0, dtype=torch.int64, device=device)
+        vals = torch.cat(vals_l) if vals_l else torch.zeros(0, dtype=torch.float32, device=device)
+        if world > 1:
+            keys, vals = scan._gather_varlen(keys, world), scan._gather_varlen(vals, world)
+        if 0 < keys.numel() < 1 << 29:
+            rows_k, rows_v = scan.select_topk(keys, vals, 2 * keys.numel(), g.n_rows)
+            torch.cuda.synchronize(device)
+            dt = time.perf_counter() - t0
+            n_seen = rows_k.numel()
+            print(f'using {n_seen} edges; scored in {dt:.2f} s ({n_seen / max(dt, 1e-9):.3e} candidate edges/s incl. generation)')
+            rows = torch.stack([(rows_k & 0xFFFFFFFF).to(torch.float32), (rows_k >> 32).to(torch.float32), rows_v], 1)
+            return _save(args, spec, sorted_edge_path, num_sorted_edge, run_id, rank, world, rows)
     from .models import LinkGNN
     if (GNN_HALF and 0 < keep <= scan.MAX_K and isinstance(model, LinkGNN) and data.adj_t.device.type == "cuda"
             and data.adj_t.n_rows == data.adj_t.n_cols and data.adj_t.nnz() < 1 << 30 and scan.is_symmetric(data.adj_t)):
