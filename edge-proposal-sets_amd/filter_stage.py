@@ -280,10 +280,11 @@ def run(args) -> str:
             rows = torch.stack([(rows_k & 0xFFFFFFFF).to(torch.float32), (rows_k >> 32).to(torch.float32), rows_v], 1)
             return _save(args, spec, sorted_edge_path, num_sorted_edge, run_id, rank, world, rows)
     from .models import LinkGNN
-    if (GNN_HALF and 0 < keep <= scan.MAX_K and isinstance(model, LinkGNN) and data.adj_t.device.type == "cuda"
-            and data.adj_t.n_rows == data.adj_t.n_cols and data.adj_t.nnz() < 1 << 30 and scan.is_symmetric(data.adj_t)):
+    if (GNN_HALF and 0 <= keep <= scan.MAX_K and isinstance(model, LinkGNN) and data.adj_t.device.type == "cuda"
+            and data.adj_t.n_rows == data.adj_t.n_cols and data.adj_t.nnz() < 1 << 30 and scan.is_symmetric(data.adj_t)
+            and (keep > 0 or int(scan.half_paths(data.adj_t).sum().item()) < 1 << 29)):     # (the whole file: lists that fit)
         with torch.no_grad():
-            best_pairs, best_scores, n_seen = gnn_half_topk(args, model, data, keep, rank, world)
+            best_pairs, best_scores, n_seen = gnn_half_topk(args, model, data, keep if keep else scan.MAX_K, rank, world)
         torch.cuda.synchronize(device)
         dt = time.perf_counter() - t0
         print(f'GNN filter, each unordered pair decoded once ({args.model})')
