@@ -5,7 +5,7 @@
 // (adamic_utils.py:13-25, train_and_eval.py:195-216, models.py:536-542), :160-161 sort all E rows -- and rank.py:294
 // then reads the first `num_sorted_edge` of them.  With `--keep_top K` only candidates above the K-th best score
 // matter, so this kernel computes the score of EVERY candidate but reports only those above `threshold` (the host
-// derives the bar from a column sample and verifies that at least K survive: edge-proposal-sets_amd/candidates.py).
+// derives the bar from a column sample and verifies that at least K survive: edge-proposal-sets_amd/scan.py).
 //
 // Three things make it cheaper than eps_expand_fill, which it otherwise follows (propagation blocking of the
 // 2-hop paths of a column over an LDS bitmap, order-independent 2^-40 fixed-point sums):
@@ -22,6 +22,10 @@
 //     four different rows) per wave instruction, dealt round-robin over the 16 waves: a unit -> row map is built
 //     per round of <= 2048 units by one block-wide max-scan.
 // Scores are bit-identical to eps_expand_fill's (same fixed-point terms, same final rounding).
+//
+// The same template also writes candidate LISTS (MODE = FS_COUNT / FS_EMIT, entry points eps_expand_unit_count / _fill at the
+// end of this file): every endpoint of a column (whole rows) or, HALF, the endpoints below it, with the score of every
+// candidate instead of the survivors above a bar.
 #include "eps_common.h"
 #include <string.h>
 
