@@ -97,6 +97,7 @@ def fused_node_weights(args, g: CSRGraph, ra_graph):
 
 
 GNN_HALF = True            # GNN filters under --keep_top on symmetric graphs: decode every unordered pair once (gnn_half_topk)
+GNN_PRUNE_SLACK = 1 << 20  # gnn_half_topk re-cuts its kept pairs to the running bar when it holds more than 4 x ceil(K/2) + this
 
 
 def gnn_half_topk(args, model, data, keep: int, rank: int, world: int):
@@ -142,7 +143,7 @@ def gnn_half_topk(args, model, data, keep: int, rank: int, world: int):
         keys_l.append((pairs[1].to(torch.int64) << 32) | pairs[0].to(torch.int64))
         vals_l.append(sc)
         held += sc.numel()
-        if held > 4 * k2 + (1 << 20):
+        if held > 4 * k2 + GNN_PRUNE_SLACK:
             prune()
     if keys_l:
         prune()

@@ -168,6 +168,14 @@ def test_gnn_filter_cli(eps, oracle, workdir):
         finally:
             filter_stage.GNN_HALF = True
         assert torch.equal(both, half)
+        # many small column blocks + no slack: the kept pairs are re-cut to the running bar after nearly every block
+        from eps_amd import candidates
+        candidates.DEFAULT_BLOCK_PATHS, filter_stage.GNN_PRUNE_SLACK = 50_000, 0
+        try:
+            pruned = torch.load(filter_stage.main(argv))
+        finally:
+            candidates.DEFAULT_BLOCK_PATHS, filter_stage.GNN_PRUNE_SLACK = (1 << 31) - 1, 1 << 20
+        assert torch.equal(pruned, half)
 
 
 def test_collab_recipe_with_valid_proposal(eps, oracle, workdir):
