@@ -152,15 +152,15 @@ def gnn_half_topk(args, model, data, keep: int, rank: int, world: int):
         keys, vals = torch.zeros(0, dtype=torch.int64, device=dev), torch.zeros(0, dtype=torch.float32, device=dev)
     if world > 1:
         keys, vals = scan._gather_varlen(keys, world), scan._gather_varlen(vals, world)
-        n_seen = int(sum(epd_gather_int(n_seen)))
+        n_seen = _sum_over_ranks(n_seen)
     keys, vals = scan.select_topk(keys, vals, keep, g.n_rows)
     return torch.stack([keys & 0xFFFFFFFF, keys >> 32]), vals, n_seen
 
 
-def epd_gather_int(x: int):
+def _sum_over_ranks(x: int) -> int:
     from . import dist as epd
     t = torch.tensor([x], dtype=torch.int64, device=torch.device("cuda", torch.cuda.current_device()))
-    return [int(v.item()) for v in epd.all_gather_list(t)]
+    return int(sum(int(v.item()) for v in epd.all_gather_list(t)))
 
 
 CUT_CAPACITY = 1 << 23     # survivors per block the expansion kernel may report (96 MB); more -> the block is redone in full
