@@ -252,7 +252,8 @@ def run(args) -> str:
         return _save(args, spec, sorted_edge_path, num_sorted_edge, run_id, rank, world,
                      torch.cat([best_pairs.t().to(torch.float32), best_scores.unsqueeze(1)], 1))
     full_w = fused_node_weights(args, data.adj_t, ra_graph) if keep == 0 and scan.scan_available(data.adj_t) else None
-    if full_w is not None and candidates.fused_scores_fit(data.adj_t, full_w):
+    if (full_w is not None and candidates.fused_scores_fit(data.adj_t, full_w)
+            and int(scan.half_paths(data.adj_t).sum().item()) < 1 << 29):      # (unordered pairs <= half paths: lists that fit)
         # the whole [E,3] file of a heuristic filter on a unit-valued symmetric graph: scores are symmetric too, so the list
         # kernels write each unordered pair once (column v: its candidates u < v), and the rows -- both orientations -- come
         # out of the same mirror + declared-order sort the threshold scan's selection uses
@@ -272,7 +273,7 @@ def run(args) -> str:
         vals = torch.cat(vals_l) if vals_l else torch.zeros(0, dtype=torch.float32, device=device)
         if world > 1:
             keys, vals = scan._gather_varlen(keys, world), scan._gather_varlen(vals, world)
-        if 0 < keys.numel() < 1 << 29:
+        if keys.numel():
             rows_k, rows_v = scan.select_topk(keys, vals, 2 * keys.numel(), g.n_rows)
             torch.cuda.synchronize(device)
             dt = time.perf_counter() - t0
