@@ -33,7 +33,7 @@ SIGNATURES = {
     "eps_expand_workspace_bytes": (_i64, [_i64]),
     "eps_filter_scan_max_nodes": (_i64, []),
     "eps_filter_scan_workspace_bytes": (_i64, [_i64]),
-    "eps_reverse_positions": (_int, [_vp, _vp, _i64, _vp, _vp]),
+    "eps_reverse_positions": (_int, [_vp, _vp, _i64, _vp, _vp, _vp, _vp]),
     "eps_fixed_weights": (_int, [_vp, _i64, _vp, _vp]),
     "eps_filter_scan_windows": (_int, [_i64, _c.POINTER(_i64), _c.POINTER(_i64)]),
     "eps_row_window_splits": (_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp]),

@@ -850,23 +850,34 @@ __global__ __launch_bounds__(FS_THREADS) void filter_scan_kernel(fs_params p)
 // revpos[e], e an entry of row v with w = col[e]: the number of entries of row w that are below v.  For a symmetric
 // adjacency that is the position of v in row w.  One wave per row v; a lower-bound search per entry.
 __global__ void reverse_positions_kernel(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col,
-                                         int64_t n_nodes, int32_t *__restrict__ revpos)
+                                         int64_t n_nodes, int32_t *__restrict__ revpos, int64_t *__restrict__ half_paths,
+                                         unsigned int *__restrict__ asymmetric)
 {
     const int lane = threadIdx.x & 63;
     const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
     for (int64_t v = wave; v < n_nodes; v += n_waves) {
         const int64_t b = rowptr[v], e = rowptr[v + 1];
+        long long below = 0;                 // the column's two-hop half paths: sum of its entries' row heads
+        bool odd = false;                    // an entry (v, w) without its mirror (w, v)
         for (int64_t i = b + lane; i < e; i += 64) {
             const int32_t w = col[i];
             int64_t lo = rowptr[w], hi = rowptr[w + 1];
-            const int64_t wb = lo;
+            const int64_t wb = lo, we = hi;
             while (lo < hi) {
                 const int64_t mid = (lo + hi) >> 1;
                 if (col[mid] < (int32_t)v) lo = mid + 1; else hi = mid;
             }
             revpos[i] = (int32_t)(lo - wb);
+            below += lo - wb;
+            odd |= lo >= we || col[lo] != (int32_t)v;
         }
+        if (half_paths) {
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) below += __shfl_xor(below, d);
+            if (lane == 0) half_paths[v] = below;
+        }
+        if (asymmetric && __ballot(odd) && lane == 0) atomicOr(asymmetric, 1u);
     }
 }
 
@@ -896,16 +907,21 @@ __global__ void fixed_weights_kernel(const float *__restrict__ w, int64_t n, int
 }
 
 extern "C" int eps_reverse_positions(const int64_t *rowptr, const int32_t *col, int64_t n_nodes, int32_t *revpos,
-                                     void *stream)
+                                     int64_t *half_paths_or_null, uint32_t *asymmetric_or_null, void *stream)
 {
     EPS_REQUIRE(n_nodes >= 0, "eps_reverse_positions: negative size");
+    hipStream_t s = (hipStream_t)stream;
+    if (asymmetric_or_null && hipMemsetAsync(asymmetric_or_null, 0, sizeof(uint32_t), s) != hipSuccess) {
+        eps_set_error("eps_reverse_positions: cannot clear the flag");
+        return EPS_ELAUNCH;
+    }
     if (n_nodes == 0) return EPS_OK;
     EPS_REQUIRE(rowptr && col && revpos, "eps_reverse_positions: null pointer");
     int64_t blocks = (n_nodes + 3) / 4;
     const int64_t cap = (int64_t)eps_num_cus() * 16;
     if (blocks > cap) blocks = cap;
-    hipLaunchKernelGGL(reverse_positions_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, rowptr, col,
-                       n_nodes, revpos);
+    hipLaunchKernelGGL(reverse_positions_kernel, dim3((unsigned)blocks), dim3(256), 0, s, rowptr, col, n_nodes, revpos,
+                       half_paths_or_null, asymmetric_or_null);
     EPS_CHECK_LAUNCH("eps_reverse_positions");
     return EPS_OK;
 }

@@ -335,15 +335,19 @@ def filter_scan_max_nodes() -> int:
     return int(_lib.load().eps_filter_scan_max_nodes())
 
 
-def reverse_positions(rowptr: torch.Tensor, col: torch.Tensor) -> torch.Tensor:
-    """int32[nnz]: for entry e of row v with w = col[e], the number of entries of row w below v (per-graph table)."""
+def reverse_positions(rowptr: torch.Tensor, col: torch.Tensor, with_stats: bool = False):
+    """int32[nnz]: for entry e of row v with w = col[e], the number of entries of row w below v (per-graph table).
+    ``with_stats``: -> (revpos, half_paths int64[N] = its row sums, asymmetric int32[1] device flag) from the same pass."""
     dev = _need_gpu(rowptr, col)
     _chk(rowptr, torch.int64, "rowptr"); _chk(col, torch.int32, "col")
+    n = rowptr.numel() - 1
     out = torch.empty(col.numel(), dtype=torch.int32, device=dev)
+    hp = torch.zeros(n, dtype=torch.int64, device=dev) if with_stats else None
+    flag = torch.zeros(1, dtype=torch.int32, device=dev) if with_stats else None
     with torch.cuda.device(dev):
-        _lib.check(_lib.load().eps_reverse_positions(_ptr(rowptr), _ptr(col), rowptr.numel() - 1, _ptr(out), _stream(dev)),
+        _lib.check(_lib.load().eps_reverse_positions(_ptr(rowptr), _ptr(col), n, _ptr(out), _ptr(hp), _ptr(flag), _stream(dev)),
                    "eps_reverse_positions")
-    return out
+    return (out, hp, flag) if with_stats else out
 
 
 def filter_scan_windows(n_nodes: int):

@@ -47,33 +47,26 @@ def scan_available(g: CSRGraph) -> bool:
 
 
 def reverse_positions(g: CSRGraph) -> torch.Tensor:
+    """revpos of the graph (cached); the same kernel pass leaves the half-path counts and the symmetry flag in the cache."""
     if "revpos" not in g._cache:
-        g._cache["revpos"] = ops.reverse_positions(g.rowptr, g.col)
+        rev, hp, flag = ops.reverse_positions(g.rowptr, g.col, with_stats=True)
+        g._cache["revpos"], g._cache["half_paths"], g._cache["asymmetric_flag"] = rev, hp, flag
     return g._cache["revpos"]
 
 
 def is_symmetric(g: CSRGraph) -> bool:
-    """Whether the stored pattern is symmetric (cached).  One gather over the entries: for entry (v, w), revpos counts the
-    entries of row w below v -- in a symmetric pattern that position holds v itself."""
+    """Whether the stored pattern is symmetric (cached): every entry (v, w) finds v at its position in row w (checked by the
+    reverse-positions pass itself)."""
     if "symmetric" not in g._cache:
-        if g.nnz() == 0:
-            g._cache["symmetric"] = True
-        else:
-            rev = reverse_positions(g).to(torch.int64)
-            w = g.col.to(torch.int64)
-            pos = g.rowptr[w] + rev
-            inside = pos < g.rowptr[w + 1]
-            hit = g.col[torch.where(inside, pos, torch.zeros_like(pos))].to(torch.int64) == g.row_index()
-            g._cache["symmetric"] = bool((inside & hit).all().item())
+        reverse_positions(g)
+        g._cache["symmetric"] = int(g._cache["asymmetric_flag"].item()) == 0
     return g._cache["symmetric"]
 
 
 def half_paths(g: CSRGraph) -> torch.Tensor:
-    """int64[N]: two-hop paths v - w - u with u < v per column v = the work of scanning it (cached)."""
+    """int64[N]: two-hop paths v - w - u with u < v per column v = the work of scanning it (cached; from the revpos pass)."""
     if "half_paths" not in g._cache:
-        out = torch.zeros(g.n_rows, dtype=torch.int64, device=g.device)
-        out.index_add_(0, g.row_index(), reverse_positions(g).to(torch.int64))
-        g._cache["half_paths"] = out
+        reverse_positions(g)
     return g._cache["half_paths"]
 
 

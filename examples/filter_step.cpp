@@ -77,7 +77,7 @@ int main(int argc, char **argv)
     // per-graph tables of the threshold scan
     int32_t *d_revpos = dev_alloc<int32_t>(nnz);
     int64_t *d_fixw = dev_alloc<int64_t>(n);
-    EPS_OK_(eps_reverse_positions(d_rowptr, d_col, n, d_revpos, stream));
+    EPS_OK_(eps_reverse_positions(d_rowptr, d_col, n, d_revpos, nullptr, nullptr, stream));
     EPS_OK_(eps_fixed_weights(d_w, n, d_fixw, stream));
     int64_t win_ids = 0, n_win = 0;
     EPS_OK_(eps_filter_scan_windows(n, &win_ids, &n_win));

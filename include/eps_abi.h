@@ -161,7 +161,10 @@ int64_t eps_expand_workspace_bytes(int64_t max_col_paths);
  * endpoints u < v, so each unordered candidate pair {u, v} is scored once and reported once, as
  * key = (v << 32) | u with u < v; the caller mirrors it (the scores of (u,v) and (v,u) are equal term by term).
  *   eps_reverse_positions: revpos[e] for entry e of row v, w = col[e]: number of entries of row w below v (the position
- *                     of v in row w).  Per-graph table, int32[nnz].
+ *                     of v in row w).  Per-graph table, int32[nnz].  The same pass can give half_paths[v] = sum of revpos
+ *                     over row v (int64[N]: the two-hop half paths of column v = its work in the scan and the bound of
+ *                     its survivors) and *asymmetric (device word, cleared by the call) = 1 if some entry (v, w) has no
+ *                     mirror (w, v) -- the half scheme needs a symmetric pattern.
  *   eps_fixed_weights: fixw[i] = round(node_w[i] * 2^40): the per-node weights (eps_node_weights; all ones for the
  *                     common-neighbour count of models.py:536-542) in the accumulators' fixed point, int64[N].
  *   eps_filter_scan : columns = int32[n_columns] column ids in hand-out order (any subset, any order: a heaviest-first
@@ -191,7 +194,7 @@ int eps_filter_scan_windows(int64_t n_nodes, int64_t *win_ids, int64_t *n_win);
 int eps_row_window_splits(const int64_t *rowptr, const int32_t *col, int64_t n_nodes, int64_t win_ids,
                           int64_t n_win, int32_t *splits, void *stream);
 int eps_reverse_positions(const int64_t *rowptr, const int32_t *col, int64_t n_nodes, int32_t *revpos,
-                          void *stream);
+                          int64_t *half_paths_or_null, uint32_t *asymmetric_or_null, void *stream);
 int eps_fixed_weights(const float *node_w, int64_t n, int64_t *fixw, void *stream);
 int eps_filter_scan(const int64_t *rowptr, const int32_t *col, const int32_t *revpos, const int64_t *fixw,
                     const int32_t *splits_or_null, int64_t n_nodes, int64_t nnz, int64_t max_degree,
