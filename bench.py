@@ -275,12 +275,14 @@ def hits_at_100_parity(torch, g, orc):
 
 
 # ------------------------------------------------------------------------------------------------ main
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default=None,
+                    help="N > 1: 'strong' (default) shards the columns of ONE graph over the ranks; 'weak' = one replica of the "
+                         "whole job per rank")
     ap.add_argument("--keep_top", type=int, default=KEEP_TOP)
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-legs", action="store_true", help="skip the secondary kernel legs")
@@ -288,7 +290,30 @@ def main():
     ap.add_argument("--one-device", action="store_true", help="every rank on cuda:0 (tests on a 1-GPU box, with --backend gloo)")
     ap.add_argument("--nodes", type=int, default=576_289, help="graph size (tests use a small one)")
     ap.add_argument("--edges", type=int, default=21_231_931)
-    args = ap.parse_args()
+    return ap.parse_args(argv)
+
+
+def launch_ranks(args) -> int:
+    """`python bench.py --gpus N` from a plain shell: start N fresh rank processes through torch.distributed.run and pass their
+    output through.  Decided BEFORE anything touches a GPU: this parent never initialises HIP (it does not even import
+    torch), it only waits for the child and exits with its code -- no exec of a process that holds a device."""
+    import socket
+    import subprocess
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC: what RCCL needs on this host driver
+    return subprocess.call(cmd, env=env)
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args))
 
     import torch
     import torch.distributed as dist
@@ -297,7 +322,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if args.one_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -311,26 +336,55 @@ def main():
 
     import eps_amd  # noqa: F401
     from eps_amd import candidates, ops, scan, synth
+    from eps_amd.graph import CSRGraph
     from eps_amd.heuristics import node_weight_table
+
+    def sync():
+        torch.cuda.synchronize(dev)
 
     g = synth.ppa_like(seed=3, device=dev, n_nodes=args.nodes, n_undirected=args.edges)
     w = node_weight_table(g, ops.W_AA)
-    gs, _ = scan.scan_graph(g, build=True)         # per-graph tables, built once like the graph: the hubs-first relabelled
-    scan.column_order(gs)                          # copy the scan runs on, its revpos / half paths / column order
-    half_paths_total = int(scan.half_paths(gs).sum())
-    strong = args.scaling == "strong" and world > 1
-    torch.cuda.synchronize(dev)
+    strong = world > 1 and args.scaling != "weak"
+    srank, sworld = (rank, world) if strong else (0, 1)
+    sync()
+
+    # what a one-shot `filter.py --keep_top K` pays: the first scan of a FRESH graph object, per-graph tables included (no
+    # hubs-first copy: one scan does not repay its sort)
+    cold_ms = None
+    if world == 1:
+        g_cold = CSRGraph(g.rowptr, g.col, None, g.n_rows, g.n_cols)
+        w_cold = w.clone()
+        candidates.fused_scores_fit(g_cold, w_cold)
+        sync()
+        t0 = time.perf_counter()
+        scan.scan_topk(g_cold, w_cold, args.keep_top)
+        sync()
+        cold_ms = (time.perf_counter() - t0) * 1e3
+        del g_cold, w_cold
+
+    # per-graph tables of a graph that is scanned repeatedly, built once like the graph itself: the hubs-first relabelled copy
+    # the scan runs on, its revpos / half paths / column order / fixed-point weights / sample -- timed, reported as prep_ms
+    t0 = time.perf_counter()
+    gs, perm = scan.scan_graph(g, build=True)
+    scan.column_order(gs)
+    scan._scan_weights(g, gs, perm, w)
+    scan.shard_columns(gs, srank, sworld)
+    scan.sample_columns(gs, scan.SAMPLE_STRIDE, srank, sworld)
+    half_paths_total = scan.total_half_paths(gs)
+    candidates.fused_scores_fit(g, w)
+    sync()
+    prep_ms = (time.perf_counter() - t0) * 1e3
 
     def barrier():
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize(dev)
+        sync()
 
     stats = {}
     out = {}
 
     def step():
-        out["r"] = scan.scan_topk(g, w, args.keep_top, rank if strong else 0, world if strong else 1, stats=stats)
+        out["r"] = scan.scan_topk(g, w, args.keep_top, srank, sworld, stats=stats)
 
     for _ in range(args.warmup):
         step()
@@ -346,11 +400,34 @@ def main():
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
-    main_ms = [a.elapsed_time(b) for name, a, b, ncol in events if ncol > g.n_rows // (2 * (world if strong else 1))]
-    samp_ms = [a.elapsed_time(b) for name, a, b, ncol in events if ncol <= g.n_rows // (2 * (world if strong else 1))]
+    half = g.n_rows // (2 * sworld)
+    main_ms = [a.elapsed_time(b) for name, a, b, ncol in events if ncol > half]
+    samp_ms = [a.elapsed_time(b) for name, a, b, ncol in events if ncol <= half]
     kern_ms = sum(main_ms) / max(1, len(main_ms))
+    samp = sum(samp_ms) / max(1, len(samp_ms))
+    per_rank = [[kern_ms, samp]]
+    if world > 1:
+        from eps_amd import dist as epd
+        per_rank = torch.stack(epd.all_gather_list(torch.tensor([kern_ms, samp], device=dev, dtype=torch.float64))).tolist()
     n_cand = stats["candidates"]                   # directed candidates of the graph (kernel-counted)
-    job_cand = n_cand if strong else n_cand * world
+    job_cand = n_cand if strong or world == 1 else n_cand * world
+    bar = None if stats["bar"] is None else float(stats["bar"])
+
+    # N > 1, strong: the weak figure (every rank the whole job on its own replica) as a secondary key, from a short loop
+    weak_value = None
+    if strong:
+        def wstep():
+            scan.scan_topk(g, w, args.keep_top, 0, 1)
+        wsteps = max(1, min(args.steps, 5))
+        wstep()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(wsteps):
+            wstep()
+        barrier()
+        tw = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+        dist.all_reduce(tw, op=dist.ReduceOp.MAX)
+        weak_value = n_cand * world * wsteps / tw.item()
 
     line = None
     if rank == 0:
@@ -358,40 +435,56 @@ def main():
         # dominant kernel: eps_filter_scan's main launch.  Algorithmic bytes per launch: every two-hop half
         # path read once (4 B), the per-(v,w) descriptors (col 4 + revpos 4 + rowptr 8 + fixw 8), rowptr of the columns,
         # and the survivors (12 B each); the per-rank share under strong scaling.
-        share = world if strong else 1
-        abytes = (4 * half_paths_total + 24 * g.nnz() + 16 * g.n_rows) // share + 12 * (stats["survivors"] // 2)
-        achieved = abytes / (kern_ms * 1e-3) / 1e9
-        traffic = None
+        abytes = (4 * half_paths_total + 24 * g.nnz() + 16 * g.n_rows) // sworld + 12 * (stats["survivors"] // 2 // sworld)
+        kmax = max(r[0] for r in per_rank)
+        achieved = abytes / (kmax * 1e-3) / 1e9
+        pmc = {}
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
-            traffic = json.load(open(tpath)).get(f"filter_scan/ppa_like/{g.n_rows}")
+            pmc = json.load(open(tpath)).get(f"filter_scan/ppa_like/{g.n_rows}") or {}
+            if not isinstance(pmc, dict):
+                pmc = {"traffic": pmc}
+        ms_step = dt / args.steps * 1e3
         line = {
             "metric": "candidate edges scored/sec on ogbl-ppa (ppa-like synthetic): Adamic-Adar over the FULL 2-hop non-edge "
                       "candidate set + top-4M selection",
             "value": job_cand * args.steps / dt,
             "unit": "edges/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3,
+            "ms_per_step": ms_step,
             "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": "int64", "data": "synthetic",
+            "value_unordered_pairs_per_s": job_cand / 2 * args.steps / dt,
+            "weak_value": weak_value,
+            "prep_ms": prep_ms, "cold_ms_per_step": cold_ms,
+            "kernel_ms_per_rank": [r[0] for r in per_rank], "sample_ms_per_rank": [r[1] for r in per_rank],
+            "serial_ms": ms_step - kmax - max(r[1] for r in per_rank),
             "config": {"workload": "configs[2] ppa-like S3, full candidate set: N=%d, nnz=%d, %d directed 2-hop non-edge "
                                    "candidates per graph, filter.py --model adamic_ogb --keep_top %d (scan.scan_topk)"
                                    % (g.n_rows, g.nnz(), n_cand, args.keep_top),
                        "candidates_per_step_all_ranks": job_cand, "two_hop_half_paths": half_paths_total,
-                       "arithmetic": "f32 terms summed in 2^-40 fixed point (int64, order-independent), rounded once to f32",
-                       "keep_top": args.keep_top, "bar": stats["bar"], "survivors": stats["survivors"],
-                       "launches_per_step": stats["launches"], "graph_replicated": True, "device": dev_name, "n_cu": n_cu},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "kernel": "filter_scan_kernel", "kernel_ms": kern_ms, "launches_timed": len(main_ms),
-                         "sample_launch_ms": sum(samp_ms) / max(1, len(samp_ms)),
+                       "arithmetic": "f32 terms summed in 2^-40 fixed point (int64, order-independent), rounded to f32",
+                       "keep_top": args.keep_top, "bar": bar, "survivors": stats["survivors"],
+                       "launches_per_step": stats["launches"], "graph_replicated": True, "device": dev_name, "n_cu": n_cu,
+                       "notes": {"value": "DIRECTED candidates (both rows of the proposal file carry the score); each unordered "
+                                          "pair is computed once: value_unordered_pairs_per_s",
+                                 "prep_ms": "hubs-first relabelled copy + revpos / half paths / column order / fixed-point "
+                                            "weights / sample, built once per graph, OUTSIDE the timed region",
+                                 "cold_ms_per_step": "first scan of a fresh graph object incl. its tables, no relabelling: what "
+                                                     "a one-shot filter.py --keep_top run pays",
+                                 "serial_ms": "ms_per_step - slowest rank's main kernel - its sample launch: bar, selection, "
+                                              "collectives, host"}},
+            "roofline": {"bound": pmc.get("bound", "hbm"), "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "hbm_frac": achieved / HBM_PEAK_GBPS, "traffic": pmc.get("traffic"),
+                         "kernel": "filter_scan_kernel", "kernel_ms": kmax, "launches_timed": len(main_ms),
+                         "sample_launch_ms": samp,
                          "algorithmic_bytes_per_launch": abytes,
-                         "note": "compulsory bytes: 4 B per two-hop half path + 24 B per stored entry + survivors; the kernel "
-                                 "is bound by LDS atomics / instruction issue, not by HBM (DESIGN.md 4.1c), so the fraction "
-                                 "is small by nature; `traffic` = fabric bytes per launch from the rocprofv3 PMC passes in "
-                                 "profiles/r02"},
+                         "issue": pmc.get("issue"),
+                         "note": "compulsory bytes: 4 B per two-hop half path + 24 B per stored entry + survivors; `traffic` = "
+                                 "fabric bytes per launch and `issue` = LDS / VALU occupancy of the same launch, both from the "
+                                 "rocprofv3 PMC passes committed under profiles/ (profiles/traffic.json)"},
         }
-    if rank == 0 and not args.no_legs:
+    if rank == 0 and world == 1 and not args.no_legs:
         line["legs"] = {"pair_intersection": leg_pair_kernel(torch, g, w, ops, candidates)}
         line["legs"].update(leg_gnn(torch, g, ops))
     if rank == 0 and world == 1 and not args.no_cpu:

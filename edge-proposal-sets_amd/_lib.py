@@ -47,6 +47,10 @@ SIGNATURES = {
     "eps_mlp_decode": (_int, [_vp, _i64, _i32, _vp, _vp, _i64, _c.POINTER(_vp), _c.POINTER(_vp), _i32, _int, _vp, _vp]),
     "eps_kth_largest_workspace_bytes": (_i64, []),
     "eps_kth_largest_f32": (_int, [_vp, _i64, _i64, _vp, _vp, _vp]),
+    "eps_kth_begin": (_int, [_vp, _i64, _vp]),
+    "eps_kth_hist_f32": (_int, [_vp, _i64, _vp, _i32, _vp]),
+    "eps_kth_pick": (_int, [_vp, _i32, _vp, _vp]),
+    "eps_compact_at_least": (_int, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
     "eps_select_topk_cut_workspace_bytes": (_i64, []),
     "eps_compact_survivors": (_int, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp]),
     "eps_select_topk_cut": (_int, [_vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _i64, _vp]),
@@ -56,6 +60,7 @@ SIGNATURES = {
     "eps_unpack_keys": (_int, [_vp, _i64, _vp, _vp, _vp]),
 }
 
+ABI_VERSION = 3        # include/eps_abi.h EPS_ABI_VERSION
 _lib = None
 
 
@@ -89,8 +94,8 @@ def load() -> ctypes.CDLL:
         fn = getattr(lib, name)  # AttributeError here == ABI drift, fail loudly
         fn.restype = res
         fn.argtypes = args
-    if lib.eps_version() != 1:
-        raise EpsError(f"libeps_hip.so ABI version {lib.eps_version()} != 1")
+    if lib.eps_version() != ABI_VERSION:
+        raise EpsError(f"libeps_hip.so ABI version {lib.eps_version()} != {ABI_VERSION}: rebuild (make -C {CSRC})")
     _lib = lib
     return lib
 

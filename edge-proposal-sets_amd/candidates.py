@@ -62,8 +62,7 @@ def fused_score_bound(g: CSRGraph, node_w: Optional[torch.Tensor]) -> float:
     """Upper bound of every fused score sum_w A[u,w] * A[v,w] * node_w[w] of the graph:
     max_v sum_w |A[v,w]| * |node_w[w]| * max_u |A[u,w]|  (one pass over the stored entries; cached).  Unit-valued graphs
     stay far below the accumulators' range (AA <= 1.45 x degree); collab-like multi-edge weights of 10^3..10^4 do not."""
-    key = ("score_bound", None if node_w is None else (node_w.data_ptr(), node_w._version))
-    if key not in g._cache:
+    def build() -> float:
         col = g.col.to(torch.int64)
         term = torch.ones(g.nnz(), dtype=torch.float64, device=g.device) if node_w is None else node_w[col].abs().to(torch.float64)
         if g.val is not None:
@@ -73,8 +72,8 @@ def fused_score_bound(g: CSRGraph, node_w: Optional[torch.Tensor]) -> float:
             term = term * a * colmax[col]
         rowsum = torch.zeros(g.n_rows, dtype=torch.float64, device=g.device)
         rowsum.index_add_(0, g.row_index(), term)
-        g._cache[key] = float(rowsum.max().item()) if g.n_rows else 0.0
-    return g._cache[key]
+        return float(rowsum.max().item()) if g.n_rows else 0.0
+    return g.weight_cached("score_bound", node_w, build)    # (keyed on the tensor itself, not on its recyclable address)
 
 
 def fused_scores_fit(g: CSRGraph, node_w: Optional[torch.Tensor]) -> bool:

@@ -670,7 +670,9 @@ __global__ __launch_bounds__(FS_THREADS) void filter_scan_kernel(fs_params p)
             if (MODE != FS_SCAN) return;
             const uint32_t nslots = tile_r0[t + 1] - tile_r0[t] + FS_SVCAP;      // this tile's + everything parked
             if (s_out_end - s_out_cur < nslots) {
-                const uint32_t b = atomicAdd(&p.out->count, (unsigned int)FS_CHUNK);
+                // (64-bit counter: a list that overflows can never wrap back under the capacity; chunks past it are dropped)
+                const unsigned long long b64 = atomicAdd(&p.out->count, (unsigned long long)FS_CHUNK);
+                const uint32_t b = b64 < (unsigned long long)out_cap ? (uint32_t)b64 : out_cap;
                 s_out_cur = b;
                 s_out_end = b + FS_CHUNK;
             }

@@ -1,0 +1,576 @@
+// Threshold scan of the filter stage's candidate set in ONE pass over the two-hop paths, gfx950 (r03).
+//
+// What it replaces: the same as filter_scan.hip -- filter.py:96-109 (every 2-hop non-edge), :113-142 (its heuristic score:
+// adamic_utils.py:13-25, train_and_eval.py:195-216, models.py:536-542) and :160-161 under `--keep_top K` -- and it reports the
+// same thing: the unordered candidates {u < v} whose score can exceed a bar.  What differs is how a column is scored.
+//
+// filter_scan.hip walks a column's paths twice (mark the endpoints in an id bitmap, rank them; bin the paths by rank tile)
+// and sums 4-byte bucket records per tile: ~95 VALU + 18 LDS wave-instructions per path, 4x the compulsory memory traffic.
+// Here a column is cut into PIECES -- runs of id windows of the endpoint space -- small enough that every endpoint of a
+// piece owns a slot of an LDS table, and each path is read once and costs one table update:
+//   * the id space is cut per graph into SP_M windows of equal stored-entry mass (`bounds`); `cuts[w][k]` = entries of row w
+//     below bounds[k+1] (uint16) turns (row, window run) into a segment of col[] without searching;
+//   * a column's paths per window are summed from those cuts (exact), and windows are merged greedily into pieces:
+//     DIRECT when the run spans at most 2 x slots ids (hub ids: the accumulator of u is slot u - lo, no key, one LDS add
+//     per path -- under hubs-first labels half of all paths end there), HASH when it holds at most slots / 2 paths (open
+//     addressing, double hashing, a CAS on the key word + an add on the value word), hash-PARTITIONED passes for a single
+//     window that is both wide and heavy;
+//   * segments are packed: a lane takes 4 consecutive entries of one row segment (16-byte load), lanes are dealt over the
+//     virtual concatenation of the piece's segments (row found by a binary search over the unit prefix in LDS);
+//   * the table holds 32-bit SCREENING sums: weights rounded UP to 2^-shift fixed point, so a sum is an upper bound of
+//     the exact 2^-40 fixed-point score of filter_scan.hip / expand_score.hip and `sum >= floor(bar)` loses no survivor.  The
+//     few candidates that pass (K of 10^10) are re-scored exactly by the caller (float64 pair kernel over weights that are
+//     multiples of 2^-40: order-independent, bit-identical to the fixed-point sum) -- the final list is bit-identical.
+// Symmetry, the survivor record and the dynamic column hand-out are as in filter_scan.hip.
+#include "eps_common.h"
+#include <string.h>
+
+#define SP_M 32                 // id windows per graph (one 64-byte row of cuts per node)
+#define SP_EMPTY 0xFFFFFFFFu
+#define SP_MAXP (SP_M + 1)
+
+typedef int sp_v4i __attribute__((ext_vector_type(4)));
+
+struct sp_params {
+    const int64_t *rowptr;
+    const int32_t *col;
+    const int32_t *revpos;
+    const uint32_t *fx32;       // screening weight per node (>= 1)
+    const uint16_t *cuts;       // [n_nodes][SP_M]
+    const int32_t *bounds;      // [SP_M + 1]
+    const int32_t *columns;
+    int32_t n_columns;
+    int32_t n_nodes;
+    uint32_t col_bytes;
+    int32_t table_bits;         // slots = 1 << table_bits (keys) + as many values
+    uint32_t piece_paths;       // a hash piece holds at most this many paths (<= slots / 2)
+    uint32_t thr32;             // a candidate survives when its screening sum >= thr32 (>= 1)
+    float scale;                // 2^-shift: screening sum -> approximate score
+    unsigned int *next_col;
+    eps_survivors *out;
+    unsigned int *status;       // bit 1: a hash table filled up (cannot happen within the piece limits; backstop)
+};
+
+__device__ __forceinline__ void sp_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+__device__ __forceinline__ int sp_wave_incl_scan(int x)
+{
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, false);   // row_shr:1
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, false);   // row_shr:2
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, false);   // row_shr:4
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, false);   // row_shr:8
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xA, 0xF, false);   // row_bcast:15 -> rows 1, 3
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xC, 0xF, false);   // row_bcast:31 -> rows 2, 3
+    return x;
+}
+
+__device__ __forceinline__ uint32_t sp_wave_sum(uint32_t x)
+{
+    return (uint32_t)__builtin_amdgcn_readlane(sp_wave_incl_scan((int)x), 63);
+}
+
+struct sp_unit {
+    sp_v4i u4;
+    uint32_t fx;
+    int nvalid;
+};
+
+template <int T>
+__global__ __launch_bounds__(T) void scan_piece_kernel(sp_params p)
+{
+    constexpr int W = T / 64;
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const int slots = 1 << p.table_bits;
+    uint32_t *tkey = lds;                    // [slots]  hash mode: key (node id) or SP_EMPTY
+    uint32_t *tval = lds + slots;            // [slots]  hash mode: screening sum.  Direct mode: lds[0 .. 2 slots) are the sums
+    uint32_t *r_seg = lds + 2 * slots;       // [T + 1] first entry of the row's segment, as an index into col[]
+    uint32_t *r_len = r_seg + T + 1;         // [T + 1] entries of the segment
+    uint32_t *r_fx = r_len + T + 1;          // [T + 1] screening weight of the row's node
+    uint32_t *ustart = r_fx + T + 1;         // [T]     first 4-entry unit of the row in the piece's unit numbering; padded
+    __shared__ uint32_t s_pw[SP_M];          // paths of the column per id window
+    __shared__ int s_wtot[W];
+    __shared__ int32_t s_pk0[SP_MAXP], s_pk1[SP_MAXP];   // pieces: window run [k0, k1)
+    __shared__ int32_t s_plo[SP_MAXP], s_phi[SP_MAXP];   // ... = ids [lo, hi) (hi cut at v)
+    __shared__ uint32_t s_pinfo[SP_MAXP];    // paths of the piece | direct flag << 31
+    __shared__ int s_np;
+    __shared__ unsigned int s_ticket;
+    __shared__ unsigned int s_out_cur, s_out_end;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wib = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t out_cap = p.out->capacity;
+    int64_t *__restrict__ out_key = p.out->key;
+    float *__restrict__ out_val = p.out->val;
+    const uint32_t *__restrict__ rowptr_lo = (const uint32_t *)p.rowptr;     // nnz < 2^30: the low words suffice
+    const __amdgpu_buffer_rsrc_t col_rs = __builtin_amdgcn_make_buffer_rsrc((void *)p.col, 0, p.col_bytes, 0x00020000);
+    const uint32_t thr32 = p.thr32;
+    const uint32_t direct_ids = 2u * (uint32_t)slots;
+    const uint32_t chunk = direct_ids > 8192u ? direct_ids : 8192u;     // survivor slots per reservation: >= a piece's yield
+    const int32_t my_bound = p.bounds[lane <= SP_M ? lane : SP_M];      // lane k holds window boundary k (the plan runs in wave 0)
+
+    for (int i = tid; i < slots; i += T) {
+        tkey[i] = SP_EMPTY;
+        tval[i] = 0u;
+    }
+    if (tid == 0) {
+        s_out_cur = 0u;
+        s_out_end = 0u;
+    }
+    unsigned long long n_cand = 0;           // candidates seen by this thread
+    const unsigned int ncol = (unsigned int)p.n_columns;
+    unsigned int t = blockIdx.x;
+    sp_barrier();
+
+    while (t < ncol) {
+        unsigned int t_next = 0;
+        if (tid == 0) t_next = gridDim.x + atomicAdd(p.next_col, 1u);     // in flight while this column is scored
+        const int32_t v = p.columns[t];
+        const uint32_t vb = rowptr_lo[2 * (size_t)v];
+        const int32_t dv = (int32_t)(rowptr_lo[2 * (size_t)v + 2] - vb);
+        const int32_t *__restrict__ vcol = p.col + vb;
+        const int32_t *__restrict__ vrev = p.revpos + vb;
+        const int rounds = (dv + T - 1) / T;
+        const bool single = rounds == 1;
+        if (dv > 0 && v > 0) {
+            // ---- paths of the column per id window: sum over its rows of the row head's entries inside the window --------
+            if (tid < SP_M) s_pw[tid] = 0u;
+            uint32_t my_w = 0, my_rev = 0, my_base = 0, my_fx = 0;      // this thread's row (of the last round)
+            {
+                uint32_t cnt[SP_M];
+#pragma unroll
+                for (int k = 0; k < SP_M; ++k) cnt[k] = 0u;
+                bool any = false;
+                for (int r = 0; r < rounds; ++r) {
+                    const int j = r * T + tid;
+                    if (j < dv) {
+                        any = true;
+                        my_w = (uint32_t)vcol[j];
+                        my_rev = (uint32_t)vrev[j];
+                        const uint4 *row = (const uint4 *)(p.cuts + (size_t)my_w * SP_M);
+                        uint32_t prev = 0u;
+#pragma unroll
+                        for (int q = 0; q < SP_M / 8; ++q) {
+                            const uint4 c = row[q];
+                            const uint32_t wds[4] = {c.x, c.y, c.z, c.w};
+#pragma unroll
+                            for (int h = 0; h < 4; ++h) {
+                                uint32_t a = wds[h] & 0xFFFFu, b = wds[h] >> 16;
+                                a = a < my_rev ? a : my_rev;
+                                b = b < my_rev ? b : my_rev;
+                                cnt[q * 8 + h * 2] += a - prev;
+                                cnt[q * 8 + h * 2 + 1] += b - a;
+                                prev = b;
+                            }
+                        }
+                    }
+                }
+                sp_barrier();                                            // s_pw cleared
+                if (__ballot(any)) {
+#pragma unroll
+                    for (int k = 0; k < SP_M; ++k) {
+                        const uint32_t s = sp_wave_sum(cnt[k]);
+                        if (lane == 0 && s) atomicAdd(&s_pw[k], s);
+                    }
+                }
+                if (single && tid < dv) {
+                    my_base = rowptr_lo[2 * (size_t)my_w];
+                    my_fx = p.fx32[my_w];
+                }
+            }
+            sp_barrier();
+            // ---- plan: merge windows into pieces.  Wave 0, lane k = window k: the extents are ballots over monotone predicates -
+            if (wib == 0) {
+                const uint32_t pwk = lane < SP_M ? s_pw[lane] : 0u;
+                const uint32_t ek = (uint32_t)sp_wave_incl_scan((int)pwk) - pwk;      // paths in the windows before k (lane 32: all)
+                // windows 0 .. kv hold ids below v
+                const int kv = __popcll(__ballot(lane >= 1 && lane < SP_M && my_bound <= v - 1));
+                const int32_t hi_k = my_bound < v ? my_bound : v;                    // end of the run [.., k) in id space
+                int np = 0, k0 = 0;
+                while (k0 <= kv) {
+                    const int32_t lo = __builtin_amdgcn_readlane(my_bound, k0);
+                    const uint32_t e0 = (uint32_t)__builtin_amdgcn_readlane((int)ek, k0);
+                    const bool in = lane > k0 && lane <= kv + 1;
+                    const int kd = k0 + __popcll(__ballot(in && (uint32_t)(hi_k - lo) <= direct_ids));
+                    const int kh = k0 + __popcll(__ballot(in && ek - e0 <= p.piece_paths));
+                    int k1;
+                    uint32_t flag = 0u;
+                    if (kd >= kh && kd > k0) {
+                        k1 = kd;
+                        flag = 0x80000000u;
+                    } else if (kh > k0) {
+                        k1 = kh;
+                    } else {
+                        k1 = k0 + 1;                                     // one window, wide and heavy: hash-partitioned passes
+                    }
+                    const uint32_t sum = (uint32_t)__builtin_amdgcn_readlane((int)ek, k1) - e0;
+                    if (sum) {
+                        if (lane == 0) {
+                            s_pk0[np] = k0;
+                            s_pk1[np] = k1;
+                            s_plo[np] = lo;
+                            s_phi[np] = __builtin_amdgcn_readlane(hi_k, k1);
+                            s_pinfo[np] = sum | flag;
+                        }
+                        ++np;
+                    }
+                    k0 = k1;
+                }
+                if (lane == 0) s_np = np;
+            }
+            sp_barrier();
+            const int np = s_np;
+
+            for (int pi = 0; pi < np; ++pi) {
+                const int k0 = s_pk0[pi], k1 = s_pk1[pi];
+                const uint32_t info = s_pinfo[pi];
+                const bool direct = (info >> 31) != 0u;
+                const uint32_t ppaths = info & 0x7FFFFFFFu;
+                const int32_t lo_id = s_plo[pi], hi_id = s_phi[pi];
+                // hash geometry: the smallest power-of-two table with load <= 1/2; a heavier single window goes in `parts` passes
+                uint32_t parts = 1u;
+                if (!direct)
+                    while (ppaths > p.piece_paths * parts) parts <<= 1;
+                if (parts > 1u) parts <<= 1;                             // (random split: aim at a quarter load)
+                int bits = 10;
+                {
+                    const uint32_t per = (ppaths + parts - 1) / parts;
+                    while (bits < p.table_bits && (1u << bits) < 2u * per) ++bits;
+                }
+                const uint32_t mask = (1u << bits) - 1u;
+                const uint32_t scan_slots = direct ? (uint32_t)(hi_id - lo_id) : (1u << bits);
+                if (tid == 0) {
+                    const uint32_t need = ppaths < chunk ? ppaths : chunk;        // survivors <= distinct endpoints <= paths, slots
+                    if (s_out_end - s_out_cur < need) {
+                        const unsigned long long b64 = atomicAdd(&p.out->count, (unsigned long long)chunk);
+                        const uint32_t b = b64 < (unsigned long long)out_cap ? (uint32_t)b64 : out_cap;
+                        s_out_cur = b;
+                        s_out_end = b + chunk;
+                    }
+                }
+                for (uint32_t part = 0; part < parts; ++part) {
+                    for (int r = 0; r < rounds; ++r) {
+                        // ---- describe the round's row segments inside the piece ------------------------------------------
+                        const int j = r * T + tid;
+                        const int nrows = dv - r * T < T ? dv - r * T : T;
+                        uint32_t w = my_w, rev = my_rev, base = my_base, fx = my_fx;
+                        uint32_t len = 0u, a = 0u;
+                        if (j < dv) {
+                            if (!single) {
+                                w = (uint32_t)vcol[j];
+                                rev = (uint32_t)vrev[j];
+                                base = rowptr_lo[2 * (size_t)w];
+                                fx = p.fx32[w];
+                            }
+                            const uint16_t *crow = p.cuts + (size_t)w * SP_M;
+                            uint32_t b = crow[k1 - 1];
+                            if (k0 > 0) a = crow[k0 - 1];
+                            a = a < rev ? a : rev;
+                            b = b < rev ? b : rev;
+                            len = b - a;
+                        }
+                        const int units = (int)((len + 3u) >> 2);
+                        int incl = sp_wave_incl_scan(units);
+                        if (lane == 63) s_wtot[wib] = incl;
+                        r_seg[tid] = base + a;
+                        r_len[tid] = len;
+                        r_fx[tid] = fx;
+                        sp_barrier();
+                        int woff = 0, total = 0;
+#pragma unroll
+                        for (int i = 0; i < W; ++i) {
+                            const int x = s_wtot[i];
+                            if (i < wib) woff += x;
+                            total += x;
+                        }
+                        ustart[tid] = tid < nrows ? (uint32_t)(incl - units + woff) : 0xFFFFFFFFu;
+                        sp_barrier();
+                        // ---- walk: lane = one 4-entry unit; row by binary search over the unit prefix ---------------------
+                        int pow2 = 1;
+                        while (pow2 < nrows) pow2 <<= 1;
+                        auto fetch = [&](int s) -> sp_unit {
+                            sp_unit f;
+                            int lo = 0;
+                            for (int step = pow2 >> 1; step >= 1; step >>= 1)
+                                if (ustart[lo + step] <= (uint32_t)s) lo += step;
+                            const int off = (s - (int)ustart[lo]) * 4;
+                            const int left = s < total ? (int)r_len[lo] - off : 0;
+                            f.nvalid = left < 0 ? 0 : (left > 4 ? 4 : left);
+                            f.fx = r_fx[lo];
+                            const uint32_t at = s < total ? r_seg[lo] + (uint32_t)off : (p.col_bytes >> 2);
+                            f.u4 = __builtin_amdgcn_raw_buffer_load_b128(col_rs, (int)(at * 4u), 0, 0);
+                            return f;
+                        };
+                        auto consume = [&](const sp_unit &f) {
+                            if (direct) {
+#pragma unroll
+                                for (int e = 0; e < 4; ++e)
+                                    if (e < f.nvalid) atomicAdd(&lds[(uint32_t)(f.u4[e] - lo_id)], f.fx);
+                            } else {
+                                uint32_t key[4], h[4], st[4];
+                                uint32_t pend = 0u;
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) {
+                                    key[e] = (uint32_t)f.u4[e];
+                                    const uint32_t mix = key[e] * 0x9E3779B1u;
+                                    h[e] = (mix >> (32 - bits)) & mask;
+                                    st[e] = ((mix >> 7) | 1u) & mask;
+                                    if (e < f.nvalid && (mix & (parts - 1u)) == part) pend |= 1u << e;
+                                }
+                                uint32_t tries = 0;
+                                while (__ballot(pend != 0u)) {
+                                    uint32_t old[4];
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e)
+                                        if (pend & (1u << e)) old[e] = atomicCAS(&tkey[h[e]], SP_EMPTY, key[e]);
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e)
+                                        if (pend & (1u << e)) {
+                                            if (old[e] == SP_EMPTY || old[e] == key[e]) {
+                                                atomicAdd(&tval[h[e]], f.fx);
+                                                pend &= ~(1u << e);
+                                            } else {
+                                                h[e] = (h[e] + st[e]) & mask;
+                                            }
+                                        }
+                                    if (++tries > mask + 1u) {           // the table is full (backstop; never within the piece limits)
+                                        if (pend) atomicOr(p.status, 2u);
+                                        pend = 0u;
+                                    }
+                                }
+                            }
+                        };
+                        {
+                            const int n_iter = (total + T - 1) / T;      // uniform over the workgroup
+                            sp_unit f0 = fetch(tid);
+                            for (int it = 0; it < n_iter; ++it) {
+                                const sp_unit f1 = fetch((it + 1) * T + tid);      // (past the end: an empty unit)
+                                consume(f0);
+                                f0 = f1;
+                            }
+                        }
+                        sp_barrier();        // the next round / the scan follows: descriptors and table updates are complete
+                    }
+                    // ---- known edges out: a neighbour of v is no candidate ------------------------------------------------
+                    for (int j = tid; j < dv; j += T) {
+                        const uint32_t u = (uint32_t)vcol[j];
+                        if ((int32_t)u >= lo_id && (int32_t)u < hi_id) {
+                            if (direct) {
+                                lds[u - (uint32_t)lo_id] = 0u;
+                            } else {
+                                const uint32_t mix = u * 0x9E3779B1u;
+                                if ((mix & (parts - 1u)) == part) {
+                                    uint32_t h = (mix >> (32 - bits)) & mask;
+                                    const uint32_t st = ((mix >> 7) | 1u) & mask;
+                                    for (uint32_t tries = 0; tries <= mask; ++tries) {
+                                        const uint32_t k = tkey[h];
+                                        if (k == u) {
+                                            tval[h] = 0u;
+                                            break;
+                                        }
+                                        if (k == SP_EMPTY) break;
+                                        h = (h + st) & mask;
+                                    }
+                                }
+                            }
+                        }
+                    }
+                    sp_barrier();
+                    // ---- scan the table: count the candidates, report the survivors, leave it clean --------------------------
+                    auto emit = [&](uint32_t u, uint32_t sum) {
+                        const uint32_t pos = atomicAdd(&s_out_cur, 1u);
+                        if (pos < out_cap) {
+                            out_key[pos] = ((int64_t)v << 32) | (int64_t)u;
+                            out_val[pos] = (float)sum * p.scale;
+                        }
+                    };
+                    uint32_t cnt_here = 0u;
+                    if (direct) {
+                        const uint32_t n4 = (scan_slots + 3u) & ~3u;
+                        for (uint32_t i = 4u * tid; i < n4; i += 4u * T) {
+                            const uint4 s4 = *(const uint4 *)(lds + i);
+                            *(uint4 *)(lds + i) = make_uint4(0u, 0u, 0u, 0u);
+                            const uint32_t sv[4] = {s4.x, s4.y, s4.z, s4.w};
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                if (sv[e]) {
+                                    ++cnt_here;
+                                    if (sv[e] >= thr32) emit((uint32_t)lo_id + i + e, sv[e]);
+                                }
+                        }
+                        // the scan may have cleared up to three words past the ids (whole uint4s): they belong to the key words
+                        // of hash mode only when the piece spans more than `slots` ids -- restore the empty pattern below
+                    } else {
+                        for (uint32_t i = 4u * tid; i < scan_slots; i += 4u * T) {
+                            const uint4 k4 = *(const uint4 *)(tkey + i);
+                            const uint4 s4 = *(const uint4 *)(tval + i);
+                            *(uint4 *)(tkey + i) = make_uint4(SP_EMPTY, SP_EMPTY, SP_EMPTY, SP_EMPTY);
+                            *(uint4 *)(tval + i) = make_uint4(0u, 0u, 0u, 0u);
+                            const uint32_t kk[4] = {k4.x, k4.y, k4.z, k4.w};
+                            const uint32_t sv[4] = {s4.x, s4.y, s4.z, s4.w};
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                if (kk[e] != SP_EMPTY && sv[e]) {
+                                    ++cnt_here;
+                                    if (sv[e] >= thr32) emit(kk[e], sv[e]);
+                                }
+                        }
+                    }
+                    n_cand += cnt_here;
+                    sp_barrier();
+                    if (direct) {
+                        // the direct sums used the key words as plain sums: back to the empty pattern (only what was touched)
+                        const uint32_t used = ((scan_slots + 3u) & ~3u) < (uint32_t)slots ? ((scan_slots + 3u) & ~3u) : (uint32_t)slots;
+                        for (uint32_t i = 4u * tid; i < used; i += 4u * T)
+                            *(uint4 *)(tkey + i) = make_uint4(SP_EMPTY, SP_EMPTY, SP_EMPTY, SP_EMPTY);
+                        sp_barrier();
+                    }
+                }
+            }
+        }
+        if (tid == 0) s_ticket = t_next;
+        sp_barrier();
+        t = s_ticket;
+        sp_barrier();
+    }
+    // candidates scored by this workgroup: one atomic per wave
+    {
+        unsigned long long x = n_cand;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) x += __shfl_xor(x, d);
+        if (lane == 0 && x) atomicAdd(&p.out->n_candidates, x);
+    }
+}
+
+// ---- per-graph tables --------------------------------------------------------------------------------------------------
+// cuts[w][k] = number of entries of row w with id < bounds[k + 1], k = 0 .. SP_M - 1 (uint16: needs max degree < 65536)
+__global__ void sp_cuts_kernel(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col, int64_t n_nodes,
+                               const int32_t *__restrict__ bounds, uint16_t *__restrict__ cuts)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_nodes * SP_M; i += stride) {
+        const int64_t w = i / SP_M;
+        const int k = (int)(i % SP_M);
+        const int32_t bound = bounds[k + 1];
+        int64_t lo = rowptr[w], hi = rowptr[w + 1];
+        const int64_t wb = lo;
+        while (lo < hi) {
+            const int64_t mid = (lo + hi) >> 1;
+            if (col[mid] < bound) lo = mid + 1; else hi = mid;
+        }
+        cuts[i] = (uint16_t)(lo - wb);
+    }
+}
+
+// fx32[i] = max(1, ceil(fixw[i] / 2^(40 - shift))): the node weights of the scan in the screening fixed point, rounded UP
+__global__ void sp_screen_weights_kernel(const int64_t *__restrict__ fixw, int64_t n, int shift, uint32_t *__restrict__ fx32,
+                                         unsigned int *__restrict__ bad)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int down = 40 - shift;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const long long f = fixw[i];
+        if (f < 0) {
+            atomicOr(bad, 1u);                        // negative weights: the sums are no upper bounds any more
+            fx32[i] = 1u;
+            continue;
+        }
+        const unsigned long long q = ((unsigned long long)f + ((1ull << down) - 1ull)) >> down;
+        if (q > 0xFFFFFFFFull) atomicOr(bad, 2u);
+        fx32[i] = q ? (uint32_t)q : 1u;
+    }
+}
+
+extern "C" int32_t eps_scan_windows(void) { return SP_M; }
+
+extern "C" int eps_scan_cuts(const int64_t *rowptr, const int32_t *col, int64_t n_nodes, const int32_t *bounds, uint16_t *cuts,
+                             void *stream)
+{
+    EPS_REQUIRE(n_nodes >= 0, "eps_scan_cuts: negative size");
+    if (n_nodes == 0) return EPS_OK;
+    EPS_REQUIRE(rowptr && col && bounds && cuts, "eps_scan_cuts: null pointer");
+    EPS_REQUIRE(((uintptr_t)cuts & 15) == 0, "eps_scan_cuts: cuts must be 16-byte aligned");
+    int64_t blocks = (n_nodes * SP_M + 255) / 256;
+    const int64_t cap = (int64_t)eps_num_cus() * 16;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(sp_cuts_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, rowptr, col, n_nodes, bounds, cuts);
+    EPS_CHECK_LAUNCH("eps_scan_cuts");
+    return EPS_OK;
+}
+
+extern "C" int eps_scan_screen_weights(const int64_t *fixw, int64_t n, int32_t shift, uint32_t *fx32, uint32_t *bad,
+                                       void *stream)
+{
+    EPS_REQUIRE(n >= 0 && shift >= 0 && shift <= 40, "eps_scan_screen_weights: bad argument");
+    EPS_REQUIRE(bad, "eps_scan_screen_weights: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(bad, 0, sizeof(uint32_t), s) != hipSuccess) {
+        eps_set_error("eps_scan_screen_weights: cannot clear the flag");
+        return EPS_ELAUNCH;
+    }
+    if (n == 0) return EPS_OK;
+    EPS_REQUIRE(fixw && fx32, "eps_scan_screen_weights: null pointer");
+    int64_t blocks = (n + 255) / 256;
+    const int64_t cap = (int64_t)eps_num_cus() * 8;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(sp_screen_weights_kernel, dim3((unsigned)blocks), dim3(256), 0, s, fixw, n, (int)shift, fx32, bad);
+    EPS_CHECK_LAUNCH("eps_scan_screen_weights");
+    return EPS_OK;
+}
+
+// ---- launch -------------------------------------------------------------------------------------------------------------
+// variant: 0 = 512 threads, 8192-slot table (two workgroups per CU); 1 = 1024 threads, 16384 slots (one per CU);
+//          2 = 256 threads, 4096 slots (four per CU)
+extern "C" int eps_scan_screen(const int64_t *rowptr, const int32_t *col, const int32_t *revpos, const uint32_t *fx32,
+                               const uint16_t *cuts, const int32_t *bounds, int64_t n_nodes, int64_t nnz,
+                               const int32_t *columns, int64_t n_columns, uint32_t thr32, int32_t shift, int32_t variant,
+                               eps_survivors *out, uint32_t *status, void *stream)
+{
+    EPS_REQUIRE(n_nodes >= 0 && n_columns >= 0 && nnz >= 0, "eps_scan_screen: negative size");
+    EPS_REQUIRE(status, "eps_scan_screen: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(status, 0, sizeof(uint32_t), s) != hipSuccess) {
+        eps_set_error("eps_scan_screen: cannot clear the status word");
+        return EPS_ELAUNCH;
+    }
+    if (n_columns == 0 || n_nodes == 0) return EPS_OK;
+    EPS_REQUIRE(rowptr && col && revpos && fx32 && cuts && bounds && columns && out, "eps_scan_screen: null pointer");
+    EPS_REQUIRE(nnz < (1ll << 30), "eps_scan_screen: col[] is addressed with 32-bit byte offsets (nnz < 2^30)");
+    EPS_REQUIRE(n_nodes < (1ll << 31) && n_columns < (1ll << 31), "eps_scan_screen: too many nodes / columns");
+    EPS_REQUIRE(shift >= 0 && shift <= 40 && variant >= 0 && variant <= 2, "eps_scan_screen: bad shift / variant");
+    EPS_REQUIRE(((uintptr_t)cuts & 15) == 0, "eps_scan_screen: cuts must be 16-byte aligned");
+    static const int threads_of[3] = {512, 1024, 256}, bits_of[3] = {13, 14, 12}, per_cu[3] = {2, 1, 4};
+    const int T = threads_of[variant], bits = bits_of[variant];
+    unsigned int *counter = nullptr;
+    const int rc = eps_take_counter(&counter, s, "eps_scan_screen");
+    if (rc) return rc;
+    sp_params p;
+    memset(&p, 0, sizeof p);
+    p.rowptr = rowptr;
+    p.col = col;
+    p.revpos = revpos;
+    p.fx32 = fx32;
+    p.cuts = cuts;
+    p.bounds = bounds;
+    p.columns = columns;
+    p.n_columns = (int32_t)n_columns;
+    p.n_nodes = (int32_t)n_nodes;
+    p.col_bytes = (uint32_t)(nnz * 4);
+    p.table_bits = bits;
+    p.piece_paths = (1u << bits) / 2u;
+    p.thr32 = thr32 ? thr32 : 1u;
+    p.scale = ldexpf(1.0f, -shift);
+    p.next_col = counter;
+    p.out = out;
+    p.status = status;
+    int64_t blocks = (int64_t)eps_num_cus() * per_cu[variant];
+    if (blocks > n_columns) blocks = n_columns;
+    const size_t lds = ((size_t)(2 << bits) + 3 * (size_t)(T + 1) + (size_t)T + 1) * 4;
+    void (*kern)(sp_params) = variant == 0 ? scan_piece_kernel<512> : variant == 1 ? scan_piece_kernel<1024> : scan_piece_kernel<256>;
+    if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+        eps_set_error("eps_scan_screen: cannot reserve %zu bytes of LDS", lds);
+        return EPS_ELAUNCH;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(T), lds, s, p);
+    EPS_CHECK_LAUNCH("eps_scan_screen");
+    return EPS_OK;
+}

@@ -103,24 +103,41 @@ __global__ void kth_hist_kernel(const float *__restrict__ x, int64_t n, kth_stat
 
 __global__ void kth_pick_kernel(kth_state *__restrict__ st, int shift, float *__restrict__ out)
 {
-    // one wave: walk the bins from the top until the k-th largest falls inside one
+    // one thread: walk the bins from the top until the k-th largest falls inside one.  Fewer than k values in all (seen in the
+    // first round, whose histogram counts everything): the answer is -inf, and the later rounds leave it alone.
     if (threadIdx.x == 0) {
-        uint64_t k = st->k;
-        int b = 255;
-        for (; b > 0; --b) {
-            const uint32_t c = st->hist[b];
-            if (k <= c) break;
-            k -= c;
+        if (st->mask != 0xFFFFFFFFu) {
+            uint64_t k = st->k, total = 0;
+            for (int i = 0; i < 256; ++i) total += st->hist[i];
+            if (shift == 24 && (k == 0 || k > total)) {
+                st->prefix = ordered_bits(-__builtin_inff());
+                st->mask = 0xFFFFFFFFu;
+            } else {
+                int b = 255;
+                for (; b > 0; --b) {
+                    const uint32_t c = st->hist[b];
+                    if (k <= c) break;
+                    k -= c;
+                }
+                st->k = k;
+                st->prefix |= (uint32_t)b << shift;
+                st->mask |= 255u << shift;
+            }
         }
-        st->k = k;
-        st->prefix |= (uint32_t)b << shift;
-        st->mask |= 255u << shift;
         for (int i = 0; i < 256; ++i) st->hist[i] = 0u;
         if (shift == 0 && out) *out = unordered_bits(st->prefix);
     }
 }
 
 extern "C" int64_t eps_kth_largest_workspace_bytes(void) { return (int64_t)sizeof(kth_state); }
+
+static unsigned kth_blocks(int64_t n)
+{
+    int64_t blocks = (n + 256 * 16 - 1) / (256 * 16);
+    const int64_t cap = (int64_t)eps_num_cus() * 8;
+    if (blocks > cap) blocks = cap;
+    return (unsigned)(blocks < 1 ? 1 : blocks);
+}
 
 extern "C" int eps_kth_largest_f32(const float *x, int64_t n, int64_t k, float *kth, void *workspace, void *stream)
 {
@@ -133,13 +150,48 @@ extern "C" int eps_kth_largest_f32(const float *x, int64_t n, int64_t k, float *
         return EPS_ELAUNCH;
     }
     hipLaunchKernelGGL(kth_init_kernel, dim3(1), dim3(1), 0, s, (kth_state *)workspace, (uint64_t)k);
-    int64_t blocks = (n + 256 * 16 - 1) / (256 * 16);
-    const int64_t cap = (int64_t)eps_num_cus() * 8;
-    if (blocks > cap) blocks = cap;
     for (int shift = 24; shift >= 0; shift -= 8) {
-        hipLaunchKernelGGL(kth_hist_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, n, (kth_state *)workspace, shift);
+        hipLaunchKernelGGL(kth_hist_kernel, dim3(kth_blocks(n)), dim3(256), 0, s, x, n, (kth_state *)workspace, shift);
         hipLaunchKernelGGL(kth_pick_kernel, dim3(1), dim3(64), 0, s, (kth_state *)workspace, shift, kth);
     }
     EPS_CHECK_LAUNCH("eps_kth_largest_f32");
+    return EPS_OK;
+}
+
+// ---- the same radix select in steps, for a vector that is spread over the ranks of a job ----------------------------------
+// state (device, eps_kth_largest_workspace_bytes() bytes, 8-byte aligned) = { uint32 prefix, mask; uint64 k; uint32 hist[256] }.
+// Per round (shift = 24, 16, 8, 0): every rank adds the histogram of ITS values to state.hist (eps_kth_hist_f32), the caller
+// sums the 256 counters over the ranks (one all-reduce of 1 KiB: hist starts at byte 16), every rank picks the same bin
+// (eps_kth_pick; clears hist).  After the round with shift 0, *out is the k-th largest of the union, or -inf when the union
+// holds fewer than k values.
+extern "C" int eps_kth_begin(void *state, int64_t k, void *stream)
+{
+    EPS_REQUIRE(state && ((uintptr_t)state & 7) == 0 && k >= 0, "eps_kth_begin: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(state, 0, sizeof(kth_state), s) != hipSuccess) {
+        eps_set_error("eps_kth_begin: cannot initialise the state");
+        return EPS_ELAUNCH;
+    }
+    hipLaunchKernelGGL(kth_init_kernel, dim3(1), dim3(1), 0, s, (kth_state *)state, (uint64_t)k);
+    EPS_CHECK_LAUNCH("eps_kth_begin");
+    return EPS_OK;
+}
+
+extern "C" int eps_kth_hist_f32(const float *x, int64_t n, void *state, int32_t shift, void *stream)
+{
+    EPS_REQUIRE(n >= 0 && n < (1ll << 31) && state && (shift == 24 || shift == 16 || shift == 8 || shift == 0),
+                "eps_kth_hist_f32: bad argument");
+    if (n == 0) return EPS_OK;
+    EPS_REQUIRE(x, "eps_kth_hist_f32: null pointer");
+    hipLaunchKernelGGL(kth_hist_kernel, dim3(kth_blocks(n)), dim3(256), 0, (hipStream_t)stream, x, n, (kth_state *)state, (int)shift);
+    EPS_CHECK_LAUNCH("eps_kth_hist_f32");
+    return EPS_OK;
+}
+
+extern "C" int eps_kth_pick(void *state, int32_t shift, float *out_or_null, void *stream)
+{
+    EPS_REQUIRE(state && (shift == 24 || shift == 16 || shift == 8 || shift == 0), "eps_kth_pick: bad argument");
+    hipLaunchKernelGGL(kth_pick_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (kth_state *)state, (int)shift, out_or_null);
+    EPS_CHECK_LAUNCH("eps_kth_pick");
     return EPS_OK;
 }

@@ -26,10 +26,11 @@ struct sel_state {
 // pairs at or above the cut, appended in arbitrary order (the sorts that follow order them).  A wave takes 1024 consecutive
 // entries at a time (16 coalesced loads per lane) and reserves room for all its hits with ONE atomic: a returning atomic per
 // 64 entries on a single counter costs more than the whole selection (0.9 ms for 4.8 M entries).
-__global__ void sel_cut_kernel(const int64_t *__restrict__ keys, const float *__restrict__ vals, int64_t n, int use_cut,
-                               sel_state *__restrict__ st, int64_t *__restrict__ sel_keys, float *__restrict__ sel_vals)
+__global__ void sel_cut_kernel(const int64_t *__restrict__ keys, const float *__restrict__ vals, int64_t n,
+                               const float *__restrict__ cut_or_null, unsigned long long *__restrict__ n_sel,
+                               int64_t *__restrict__ sel_keys, float *__restrict__ sel_vals)
 {
-    const float cut = use_cut ? st->kth : -__builtin_inff();
+    const float cut = cut_or_null ? *cut_or_null : -__builtin_inff();
     const int lane = threadIdx.x & 63;
     const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
@@ -55,7 +56,7 @@ __global__ void sel_cut_kernel(const int64_t *__restrict__ keys, const float *__
         const int total = __shfl(incl, 63);
         if (total == 0) continue;
         unsigned long long base = 0;
-        if (lane == 0) base = atomicAdd(&st->n_sel, (unsigned long long)total);
+        if (lane == 0) base = atomicAdd(n_sel, (unsigned long long)total);
         const unsigned int blo = __shfl((unsigned int)base, 0), bhi = __shfl((unsigned int)(base >> 32), 0);
         unsigned long long pos = (((unsigned long long)bhi << 32) | blo) + (unsigned long long)(incl - cnt);
 #pragma unroll
@@ -140,7 +141,8 @@ extern "C" int eps_select_topk_cut(const int64_t *keys, const float *vals, int64
         const int rc = eps_kth_largest_f32(vals, n, k2, &st->kth, kws, stream);
         if (rc) return rc;
     }
-    hipLaunchKernelGGL(sel_cut_kernel, dim3(sel_blocks((n + 3) / 4)), dim3(256), 0, s, keys, vals, n, use_cut, st, sel_keys, sel_vals);
+    hipLaunchKernelGGL(sel_cut_kernel, dim3(sel_blocks((n + 3) / 4)), dim3(256), 0, s, keys, vals, n, use_cut ? &st->kth : (const float *)nullptr,
+                       &st->n_sel, sel_keys, sel_vals);
     hipLaunchKernelGGL(sel_count_kernel, dim3(1), dim3(1), 0, s, st, n_sel);
     EPS_CHECK_LAUNCH("eps_select_topk_cut");
     return EPS_OK;
@@ -170,9 +172,31 @@ extern "C" int eps_compact_survivors(const int64_t *keys, const float *vals, int
         eps_set_error("eps_compact_survivors: cannot initialise the state");
         return EPS_ELAUNCH;
     }
-    hipLaunchKernelGGL(sel_cut_kernel, dim3(sel_blocks((n + 3) / 4)), dim3(256), 0, s, keys, vals, n, 0, st, out_keys, out_vals);
+    hipLaunchKernelGGL(sel_cut_kernel, dim3(sel_blocks((n + 3) / 4)), dim3(256), 0, s, keys, vals, n, (const float *)nullptr, &st->n_sel,
+                       out_keys, out_vals);
     hipLaunchKernelGGL(sel_count_kernel, dim3(1), dim3(1), 0, s, st, n_out);
     EPS_CHECK_LAUNCH("eps_compact_survivors");
+    return EPS_OK;
+}
+
+// The entries of an eps_survivors list (untouched slots: key -1) whose score is at least *cut (a DEVICE float, e.g. the
+// job-wide k-th best from eps_kth_hist_f32 / eps_kth_pick), compacted in arbitrary order; *n_out (DEVICE int64, zeroed by the
+// call) = how many.  cut_or_null == NULL keeps every survivor.  No workspace, no host round trip.
+extern "C" int eps_compact_at_least(const int64_t *keys, const float *vals, int64_t n, const float *cut_or_null,
+                                    int64_t *out_keys, float *out_vals, int64_t *n_out, void *stream)
+{
+    EPS_REQUIRE(n >= 0 && n < (1ll << 32), "eps_compact_at_least: bad size");
+    EPS_REQUIRE(n_out, "eps_compact_at_least: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(n_out, 0, sizeof(int64_t), s) != hipSuccess) {
+        eps_set_error("eps_compact_at_least: cannot clear the count");
+        return EPS_ELAUNCH;
+    }
+    if (n == 0) return EPS_OK;
+    EPS_REQUIRE(keys && vals && out_keys && out_vals, "eps_compact_at_least: null pointer");
+    hipLaunchKernelGGL(sel_cut_kernel, dim3(sel_blocks((n + 3) / 4)), dim3(256), 0, s, keys, vals, n, cut_or_null,
+                       (unsigned long long *)n_out, out_keys, out_vals);
+    EPS_CHECK_LAUNCH("eps_compact_at_least");
     return EPS_OK;
 }
 

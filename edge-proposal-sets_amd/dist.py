@@ -32,7 +32,8 @@ def init_from_env(backend: Optional[str] = None, device_index: Optional[int] = N
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if torch.cuda.is_available():
+    # backend "gloo" without an explicit device keeps its old meaning: a host job (CPU tensors), also on a box with GPUs
+    if torch.cuda.is_available() and not (backend == "gloo" and device_index is None):
         device = torch.device("cuda", local if device_index is None else int(device_index))
         torch.cuda.set_device(device)
     else:
@@ -61,6 +62,34 @@ def all_gather_list(t: torch.Tensor) -> List[torch.Tensor]:
     parts = [torch.empty_like(t) for _ in range(world)]
     dist.all_gather(parts, t.contiguous())
     return parts
+
+
+def all_reduce_sum_(t: torch.Tensor) -> torch.Tensor:
+    """In-place sum over the ranks of a small device tensor (histograms, counters).  RCCL reduces device memory directly and
+    stays on the stream; gloo (the one-device test hook) goes through host memory."""
+    rank, world = world_info()
+    if world == 1:
+        return t
+    if dist.get_backend() == "gloo" and t.device.type != "cpu":
+        h = t.cpu()
+        dist.all_reduce(h)
+        t.copy_(h)
+        return t
+    dist.all_reduce(t)
+    return t
+
+
+def gather_ragged(t: torch.Tensor, lens: Sequence[int]) -> torch.Tensor:
+    """All ranks' 1-D tensors concatenated in rank order when every rank already KNOWS all lengths (they travelled with an
+    earlier exchange): one padded all-gather, no length round trip, no host synchronisation."""
+    rank, world = world_info()
+    if world == 1:
+        return t[:lens[0]]
+    mx = max(max(lens), 1)
+    pad = torch.zeros(mx, dtype=t.dtype, device=t.device)
+    pad[:lens[rank]] = t[:lens[rank]]
+    out = _gather_into(pad, world).view(world, mx)
+    return torch.cat([out[r, :lens[r]] for r in range(world)])
 
 
 def world_info() -> Tuple[int, int]:

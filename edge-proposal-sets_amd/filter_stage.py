@@ -238,6 +238,8 @@ def run(args) -> str:
     t0 = time.perf_counter()
     keep = int(args.keep_top)
     scan_w = fused_node_weights(args, data.adj_t, ra_graph) if 0 < keep <= scan.MAX_K and scan.scan_available(data.adj_t) else None
+    if scan_w is not None and not candidates.fused_scores_fit(data.adj_t, scan_w):
+        scan_w = None                    # sums could leave the scan's fixed-point range: the pair kernels score this graph
     if scan_w is not None:
         # --keep_top on a unit-valued graph with a heuristic filter: one threshold scan of the whole candidate set
         # (csrc/filter_scan.hip) instead of candidate blocks + streaming top-K; every rank ends with the same list
@@ -246,7 +248,8 @@ def run(args) -> str:
             best_pairs, best_scores = scan.scan_topk(data.adj_t, scan_w, keep, rank, world, stats=st)
         torch.cuda.synchronize(device)
         dt = time.perf_counter() - t0
-        print(f'threshold scan ({args.model}): bar {st["bar"]}, {st["survivors"]} survivors, {st["launches"]} launches')
+        bar = None if st["bar"] is None else float(st["bar"])
+        print(f'threshold scan ({args.model}): bar {bar}, {st["survivors"]} survivors, {st["launches"]} launches')
         print(f'using {st["candidates"]} edges; scored in {dt:.2f} s ({st["candidates"] / max(dt, 1e-9):.3e} candidate edges/s '
               f'incl. generation)')
         return _save(args, spec, sorted_edge_path, num_sorted_edge, run_id, rank, world,

@@ -65,6 +65,23 @@ class CSRGraph:
         self._cache = {}
         self.uid = next(_UID)   # identity for caches keyed on the adjacency (id() can be recycled after a free)
 
+    def weight_cached(self, name: str, node_w: Optional[torch.Tensor], build):
+        """Cache of a table derived from this graph AND a weight tensor.  An entry holds the weight tensor ITSELF (a strong
+        reference, compared with ``is``) and its version counter -- never its address: a freed temporary's address is handed
+        to the next tensor of the same size, again at version 0, and a table built for other weights would be served.  At
+        most four weight tensors are remembered per graph and table."""
+        entries = self._cache.setdefault(("by_weight", name), [])
+        ver = None if node_w is None else node_w._version
+        for i, (t, v, val) in enumerate(entries):
+            if t is node_w and v == ver:
+                if i:
+                    entries.insert(0, entries.pop(i))
+                return val
+        val = build()
+        entries.insert(0, (node_w, ver, val))
+        del entries[4:]
+        return val
+
     # ------------------------------------------------------------------ construction
     @classmethod
     def from_edge_index(cls, edge_index: torch.Tensor, edge_attr: Optional[torch.Tensor] = None,

@@ -395,19 +395,27 @@ def _scan_scratch(dev, max_degree: int) -> torch.Tensor:
     return _SCAN_WS[key]
 
 
+SURVIVOR_SLOTS_MAX = (1 << 32) - (1 << 20)   # slots are 32-bit positions handed out in chunks: keep a chunk's worth of head-room
+
+
 class Survivors:
     """Device-resident eps_survivors record + its key / val arrays.  ``threshold`` may be a Python float or a 0-dim /
     1-element float32 DEVICE tensor (copied on the stream: no host round trip)."""
 
-    def __init__(self, capacity: int, threshold, device, scores_only: bool = False):
+    def __init__(self, capacity: int, threshold, device, scores_only: bool = False, both: bool = False):
         """``scores_only``: the caller will read the scores alone (the bar estimate): untouched slots are then recognisable
-        in ``val`` (-inf) instead of in ``key`` (-1), so no compaction pass is needed before a k-th-largest query."""
+        in ``val`` (-inf) instead of in ``key`` (-1), so no compaction pass is needed before a k-th-largest query.
+        ``both``: both fills (key -1 AND val -inf): the list can go through a k-th-largest query as it is and be compacted
+        afterwards (scan_topk's selection)."""
         import struct
         self.capacity = int(capacity)
-        if not 0 < self.capacity < 1 << 32:
-            raise _lib.EpsError(f"Survivors: capacity {capacity} outside (0, 2**32)")
-        self.scores_only = bool(scores_only)
-        if scores_only:
+        if not 0 < self.capacity <= SURVIVOR_SLOTS_MAX:
+            raise _lib.EpsError(f"Survivors: capacity {capacity} outside (0, {SURVIVOR_SLOTS_MAX}]")
+        self.scores_only = bool(scores_only) and not both
+        if both:
+            self.key = torch.full((self.capacity,), -1, dtype=torch.int64, device=device)
+            self.val = torch.full((self.capacity,), float("-inf"), dtype=torch.float32, device=device)
+        elif scores_only:
             self.key = torch.empty(self.capacity, dtype=torch.int64, device=device)
             self.val = torch.full((self.capacity,), float("-inf"), dtype=torch.float32, device=device)
         else:
@@ -422,7 +430,7 @@ class Survivors:
     def counts(self):
         """(slots handed out, unordered candidates scored) -- one device read-back."""
         c = self.rec[[1, 4]].tolist()
-        return int(c[0]) & 0xFFFFFFFF, int(c[1])
+        return int(c[0]), int(c[1])                          # (the slot counter is 64-bit: it cannot wrap under the capacity)
 
     def scores(self, slots: int) -> torch.Tensor:
         """The first ``slots`` score slots as they are: survivors' scores, -inf in untouched slots (``scores_only``)."""
@@ -548,6 +556,60 @@ def kth_largest(x: torch.Tensor, k: int) -> torch.Tensor:
     with torch.cuda.device(dev):
         _lib.check(lib.eps_kth_largest_f32(_ptr(x), x.numel(), int(k), _ptr(out), _ptr(ws), _stream(dev)), "eps_kth_largest_f32")
     return out
+
+
+def kth_largest_dist(x: torch.Tensor, k: int, world: int = 1) -> torch.Tensor:
+    """The k-th largest value of the UNION of every rank's float32 device vector ``x`` (lengths may differ, 0 allowed) as a
+    1-element device tensor, identical on all ranks; -inf when the union holds fewer than k values.  Radix select in four
+    rounds; per round one all-reduce of the 256-bin histogram (1 KiB) -- no host round trip.  ``world`` == 1: no collective."""
+    dev = _need_gpu(x)
+    _chk(x, torch.float32, "x")
+    lib = _lib.load()
+    state = torch.empty(int(lib.eps_kth_largest_workspace_bytes()) // 4, dtype=torch.int32, device=dev)
+    out = torch.empty(1, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        st = _stream(dev)
+        _lib.check(lib.eps_kth_begin(_ptr(state), int(k), st), "eps_kth_begin")
+        for shift in (24, 16, 8, 0):
+            _lib.check(lib.eps_kth_hist_f32(_ptr(x), x.numel(), _ptr(state), shift, st), "eps_kth_hist_f32")
+            if world > 1:
+                from . import dist as epd
+                epd.all_reduce_sum_(state[4:260])
+            _lib.check(lib.eps_kth_pick(_ptr(state), shift, _ptr(out), st), "eps_kth_pick")
+    return out
+
+
+def compact_at_least(keys: torch.Tensor, vals: torch.Tensor, cut: Optional[torch.Tensor]):
+    """(keys, vals, n) -- the survivors (key >= 0) with score >= ``cut`` (1-element float32 DEVICE tensor; None: all of them)
+    compacted to the front of fresh arrays, ``n`` a 1-element int64 device tensor (no host read)."""
+    dev = _need_gpu(keys, vals, cut)
+    _chk(keys, torch.int64, "keys"); _chk(vals, torch.float32, "vals"); _chk(cut, torch.float32, "cut")
+    n = keys.numel()
+    out_k = torch.empty(n, dtype=torch.int64, device=dev)
+    out_v = torch.empty(n, dtype=torch.float32, device=dev)
+    n_out = torch.empty(1, dtype=torch.int64, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.load().eps_compact_at_least(_ptr(keys), _ptr(vals), n, _ptr(cut), _ptr(out_k), _ptr(out_v), _ptr(n_out),
+                                                    _stream(dev)), "eps_compact_at_least")
+    return out_k, out_v, n_out
+
+
+def select_rows(sel_keys: torch.Tensor, sel_vals: torch.Tensor, k: int, id_bits: int = 32) -> Tuple[torch.Tensor, torch.Tensor]:
+    """The first min(k, 2 m) DIRECTED rows, in the declared order, of m selected unordered pairs (every pair at or above the
+    job-wide cut): mirror + stable radix sorts (eps_select_topk_rows).  No host read: m is the arrays' length."""
+    dev = _need_gpu(sel_keys, sel_vals)
+    _chk(sel_keys, torch.int64, "sel_keys"); _chk(sel_vals, torch.float32, "sel_vals")
+    m, k = sel_keys.numel(), int(k)
+    take = min(k, 2 * m)
+    out_k = torch.empty(take, dtype=torch.int64, device=dev)
+    out_v = torch.empty(take, dtype=torch.float32, device=dev)
+    if take:
+        lib = _lib.load()
+        with torch.cuda.device(dev):
+            _, wsp, wsb = _aligned_ws(dev, lib.eps_select_topk_rows_workspace_bytes(m))
+            _lib.check(lib.eps_select_topk_rows(_ptr(sel_keys), _ptr(sel_vals), m, k, int(id_bits), _ptr(out_k), _ptr(out_v), wsp, wsb,
+                                                _stream(dev)), "eps_select_topk_rows")
+    return out_k, out_v
 
 
 _SELECT_WS = {}

@@ -23,7 +23,7 @@ runs on every rank -- no collective on the data path.
 """
 from __future__ import annotations
 
-from typing import Optional, Tuple
+from typing import List, Optional, Tuple
 
 import torch
 
@@ -91,11 +91,13 @@ def max_degree(g: CSRGraph) -> int:
     return g._cache["max_degree"]
 
 
+def weight_cache(g: CSRGraph, name: str, node_w: Optional[torch.Tensor], build):
+    """Per-graph cache of a table derived from a weight tensor (see ``CSRGraph.weight_cached``)."""
+    return g.weight_cached(name, node_w, build)
+
+
 def fixed_weights(g: CSRGraph, node_w: torch.Tensor) -> torch.Tensor:
-    key = ("fixw", node_w.data_ptr(), node_w._version)
-    if key not in g._cache:
-        g._cache[key] = ops.fixed_weights(node_w)
-    return g._cache[key]
+    return weight_cache(g, "fixw", node_w, lambda: ops.fixed_weights(node_w))
 
 
 def scan_graph(g: CSRGraph, build: bool = False):
@@ -118,10 +120,7 @@ def _scan_weights(g: CSRGraph, gs: CSRGraph, perm, node_w: torch.Tensor) -> torc
     """Fixed-point weight table in the labels of the scanned graph (cached on the original graph per weight tensor)."""
     if perm is None:
         return fixed_weights(g, node_w)
-    key = ("fixw_relabelled", node_w.data_ptr(), node_w._version)
-    if key not in g._cache:
-        g._cache[key] = ops.fixed_weights(node_w[perm].contiguous())
-    return g._cache[key]
+    return weight_cache(g, "fixw_relabelled", node_w, lambda: ops.fixed_weights(node_w[perm].contiguous()))
 
 
 def _original_keys(keys: torch.Tensor, perm) -> torch.Tensor:
@@ -132,40 +131,72 @@ def _original_keys(keys: torch.Tensor, perm) -> torch.Tensor:
     return (torch.maximum(a, b) << 32) | torch.minimum(a, b)
 
 
-def _launch(g, fixw, columns, threshold, capacity, scores_only: bool = False) -> ops.Survivors:
-    out = ops.Survivors(capacity, threshold, g.device, scores_only)
+def _launch(g, fixw, columns, threshold, capacity, scores_only: bool = False, both: bool = False) -> ops.Survivors:
+    out = ops.Survivors(capacity, threshold, g.device, scores_only, both)
     if columns.numel():
         ops.filter_scan(g.rowptr, g.col, reverse_positions(g), fixw, g.n_rows, columns, out, max_degree(g), window_splits(g))
     return out
 
 
-def estimate_bar(g: CSRGraph, fixw: torch.Tensor, k: int, stride: int = SAMPLE_STRIDE, safety: float = SAFETY):
-    """Score bar (1-element float32 device tensor) that about ``safety * k`` directed candidates are expected to exceed,
-    from a scan of every ``stride``-th column of the heaviest-first order; ``None`` = no bar (keep everything)."""
-    order = column_order(g)
-    sample = order[stride // 2::stride].contiguous()         # the middle of every weight stratum, not its heaviest column
-    hp = half_paths(g)
-    bound = int(hp[sample.long()].sum().item())          # unordered candidates of the sample <= its half paths
-    if bound == 0:
+def total_half_paths(g: CSRGraph) -> int:
+    """Two-hop half paths of the whole graph (cached host number: an upper bound of its unordered candidates)."""
+    if "total_half" not in g._cache:
+        g._cache["total_half"] = int(half_paths(g).sum().item())
+    return g._cache["total_half"]
+
+
+def shard_columns(g: CSRGraph, rank: int, world: int) -> torch.Tensor:
+    """This rank's columns of the heaviest-first order: order[rank::world] (cached)."""
+    if world == 1:
+        return column_order(g)
+    key = ("scan_shard", rank, world)
+    if key not in g._cache:
+        g._cache[key] = column_order(g)[rank::world].contiguous()
+    return g._cache[key]
+
+
+def sample_columns(g: CSRGraph, stride: int, rank: int = 0, world: int = 1):
+    """(this rank's share of the bar sample, its half paths, the whole sample's half paths) -- cached.  The sample is every
+    ``stride``-th column of the heaviest-first order, taken from the middle of each stratum; rank r scans sample[r::world]."""
+    key = ("scan_sample", stride, rank, world)
+    if key not in g._cache:
+        sample = column_order(g)[stride // 2::stride]
+        mine = sample[rank::world].contiguous()
+        hp = half_paths(g)
+        both = torch.stack([hp[mine.long()].sum(), hp[sample.long()].sum()]).tolist()     # one read, once per graph
+        g._cache[key] = (mine, int(both[0]), int(both[1]))
+    return g._cache[key]
+
+
+def estimate_bar(g: CSRGraph, fixw: torch.Tensor, k: int, stride: Optional[int] = None, safety: Optional[float] = None,
+                 rank: int = 0, world: int = 1):
+    """Score bar (1-element float32 device tensor) that about ``safety * k`` directed candidates are expected to reach,
+    from a scan of every ``stride``-th column of the heaviest-first order; ``None`` = no bar (keep everything).  The bar is
+    INCLUSIVE of the sample's m-th best score (one float below it: the kernel keeps scores strictly above its threshold), so
+    a run of tied scores at the estimate passes as a whole.  ``world`` > 1: rank r scans its share of the sample and the m-th
+    best of the union comes from all-reduced radix-select histograms (ops.kth_largest_dist) -- same bar on every rank, no
+    host round trip after the first call on a graph."""
+    stride = SAMPLE_STRIDE if stride is None else int(stride)          # module globals read at CALL time (tests patch them)
+    safety = SAFETY if safety is None else float(safety)
+    mine, bound_mine, bound_all = sample_columns(g, stride, rank, world)
+    if bound_all == 0:
         return None
-    res = _launch(g, fixw, sample, float("-inf"), 2 * bound + _CHUNK_SLACK, scores_only=True)
-    slots, n_cand = res.counts()                         # no bar: every candidate of the sample holds a slot
     m = int(safety * k / 2 / stride) + 1                 # unordered pairs of the SAMPLE above the bar we aim at
-    if m >= n_cand or slots > res.capacity:
+    if m >= bound_all:                                   # (candidates <= half paths: the sample cannot hold that many)
         return None
-    return ops.kth_largest(res.scores(slots), m)         # radix select over the slots as they are (untouched ones: -inf)
+    res = _launch(g, fixw, mine, float("-inf"), min(2 * bound_mine + _CHUNK_SLACK, ops.SURVIVOR_SLOTS_MAX), scores_only=True)
+    # no bar: every candidate of the sample holds a slot, untouched slots are -inf (fewer than m candidates -> bar -inf)
+    kth = ops.kth_largest_dist(res.val, m, world)
+    return torch.nextafter(kth, torch.full_like(kth, float("-inf")))
 
 
 def _gather_varlen(t: torch.Tensor, world: int):
-    """All ranks' 1-D tensors (different lengths) concatenated in rank order."""
+    """All ranks' 1-D tensors (different lengths) concatenated in rank order: one all-gather of the lengths (one host read),
+    one padded all-gather of the data."""
     from . import dist as epd
     n = torch.tensor([t.numel()], dtype=torch.int64, device=t.device)
-    lens = [int(x.item()) for x in epd.all_gather_list(n)]
-    mx = max(lens + [1])
-    pad = torch.zeros(mx, dtype=t.dtype, device=t.device)
-    pad[:t.numel()] = t
-    parts = epd.all_gather_list(pad)
-    return torch.cat([parts[r][:lens[r]] for r in range(world)])
+    lens = torch.cat(epd.all_gather_list(n)).tolist()
+    return epd.gather_ragged(t, lens)
 
 
 def select_topk(keys: torch.Tensor, vals: torch.Tensor, k: int, n_nodes: Optional[int] = None) -> Tuple[torch.Tensor, torch.Tensor]:
@@ -195,74 +226,88 @@ def select_topk_torch(keys: torch.Tensor, vals: torch.Tensor, k: int) -> Tuple[t
     return keys[o], vals[o]
 
 
+def _capacity(slots_wanted: int) -> int:
+    cap = int(slots_wanted) + _CHUNK_SLACK
+    if cap > ops.SURVIVOR_SLOTS_MAX:
+        raise ops._lib.EpsError(f"scan_topk: a survivor list of {cap} slots exceeds the {ops.SURVIVOR_SLOTS_MAX} a launch can "
+                                "address (slots are 32-bit positions); use the block-streaming filter path for this set")
+    return cap
+
+
 def scan_topk(g: CSRGraph, node_w: torch.Tensor, k: int, rank: int = 0, world: int = 1, stats: Optional[dict] = None,
               relabel: bool = False):
     """Exact top-``k`` candidates of the whole graph: (pairs int64 [2,<=k] as (u; v), scores float32), best first.
     ``stats`` (optional dict) receives ``candidates`` (directed candidates scored), ``launches``, ``survivors``, ``bar``.
-    ``relabel``: build the hubs-first copy of a large graph if it does not exist yet (see ``scan_graph``)."""
+    ``relabel``: build the hubs-first copy of a large graph if it does not exist yet (see ``scan_graph``).
+
+    Per call, in the steady state (tables cached on the graph): sample launch -> bar (device) -> main launch -> job-wide
+    ceil(k/2)-th best survivor score (device, ops.kth_largest_dist) -> compaction of the survivors at or above it -> ONE host
+    read (slot counter, candidate count, selected count, cut; all-gathered when world > 1) -> the selected pairs of all ranks
+    (about k / 2 / world each) gathered -> mirrored + ordered (ops.select_rows)."""
     if not scan_available(g):
         raise ops._lib.EpsError("scan_topk: graph not supported by eps_filter_scan (see scan_available)")
     k = int(k)
     if not 0 < k <= MAX_K:
         raise ops._lib.EpsError(f"scan_topk: k = {k} outside (0, {MAX_K}] (longer lists: the block-streaming filter path)")
+    from . import candidates
+    if not candidates.fused_scores_fit(g, node_w):
+        raise ops._lib.EpsError(f"scan_topk: score bound {candidates.fused_score_bound(g, node_w):.3e} of this graph / weight "
+                                "table leaves the 2^-40 fixed-point range of the scan (use the pair kernels)")
     dev = g.device
     g0 = g
     g, perm = scan_graph(g0, relabel)    # from here on g is the graph as scanned; ids go back through perm at the end
     fixw = _scan_weights(g0, g, perm, node_w)
-    order = column_order(g)
-    mine = order if world == 1 else order[rank::world].contiguous()
-    total_half = int(half_paths(g).sum().item())
+    mine = shard_columns(g, rank, world)
+    total_half = total_half_paths(g)
+    k2 = (k + 1) // 2                    # the k-th best directed row belongs to the ceil(k/2)-th best unordered pair
     launches = 0
-    if total_half <= SMALL_SET:
-        bar = None
-    else:
-        bar = estimate_bar(g, fixw, k)
+    bar = None
+    if total_half > SMALL_SET and SAFETY * k < total_half:
+        bar = estimate_bar(g, fixw, k, rank=rank, world=world)
         launches += 1
-    expect = (2 * total_half if bar is None else int(2 * SAFETY * k)) // world
-    capacity = min(2 * expect + _CHUNK_SLACK, (1 << 32) - 1)
+    capacity = _capacity(2 * ((2 * total_half if bar is None else int(2 * SAFETY * k)) // world))
+    neg_inf = torch.full((1,), float("-inf"), device=dev)
     while True:
         if launches >= MAX_LAUNCHES:
             raise ops._lib.EpsError(f"scan_topk: no usable bar after {launches} launches (k = {k}, capacity {capacity})")
-        res = _launch(g, fixw, mine, float("-inf") if bar is None else bar, capacity)
+        res = _launch(g, fixw, mine, float("-inf") if bar is None else bar, capacity, both=True)
         launches += 1
-        slots, n_cand = res.counts()
-        keys, vals = res.valid(slots)
-        overflow = slots > res.capacity
-        n_surv = keys.numel()
+        # the job-wide cut: the k2-th best survivor score over all ranks (-inf when fewer survived); untouched slots are -inf
+        cut = ops.kth_largest_dist(res.val, k2, world)
+        sel_k, sel_v, n_sel = ops.compact_at_least(res.key, res.val, cut)
+        st = torch.cat([res.rec[[1, 4]], n_sel, cut.view(torch.int32).to(torch.int64)])      # slots, candidates, selected, cut bits
         if world > 1:
-            import torch.distributed as dist
             from . import dist as epd
-            agg = torch.tensor([n_surv, int(overflow), n_cand], dtype=torch.int64, device=dev)
-            tot = sum(epd.all_gather_list(agg))
-            n_all, any_overflow, n_cand_all = int(tot[0]), int(tot[1]) > 0, int(tot[2])
+            table = torch.stack(epd.all_gather_list(st)).tolist()                          # the ONE host read of the step
         else:
-            n_all, any_overflow, n_cand_all = n_surv, overflow, n_cand
-        if any_overflow:
-            # the bar was too low for the list.  What was kept is a subset of the survivors: its (k/2)-th best score
-            # is a lower bound of the final bar -- scan again just below it.
-            need = max(1, (k // 2) // world)
-            if vals.numel() >= need:
-                local = ops.kth_largest(vals, need)
-            else:
-                local = torch.full((1,), float("-inf"), device=dev)
-            if world > 1:
-                local = torch.stack(epd.all_gather_list(local)).min(0).values
-            bar = torch.nextafter(local, torch.full_like(local, float("-inf")))
-            capacity = min(4 * capacity, (1 << 32) - 1)
+            table = [st.tolist()]
+        slots_r, ncand_r, nsel_r = [t[0] for t in table], [t[1] for t in table], [t[2] for t in table]
+        n_cand_all, n_sel_all = sum(ncand_r), sum(nsel_r)
+        cut_is_inf = (table[0][3] & 0xFFFFFFFF) == 0xFF800000
+        if any(sl > capacity for sl in slots_r):
+            # the bar was too low for the list.  What was kept is a subset of the survivors, so the k2-th best score among
+            # it (the cut just computed, job-wide) is a lower bound of the final cut: scan again just below it, with more
+            # room (a level of tied scores -- common-neighbour counts -- may hold far more pairs than K).
+            if not cut_is_inf:
+                bar = torch.nextafter(cut, neg_inf)
+            capacity = _capacity(4 * (capacity - _CHUNK_SLACK))
             continue
-        if bar is not None and 2 * n_all < min(k, 2 * n_cand_all):
+        if bar is not None and n_sel_all < min(k2, n_cand_all):
             # fewer than k above the bar: lower it (a quarter of the sample rank each time, then no bar at all)
-            bar = None if launches > 3 else estimate_bar(g, fixw, k, safety=SAFETY * 8 ** (launches - 1))
+            bar = None if launches > 3 else estimate_bar(g, fixw, k, safety=SAFETY * 8 ** (launches - 1), rank=rank, world=world)
             launches += 1
             if bar is None:
-                capacity = min(2 * (2 * total_half // world) + _CHUNK_SLACK, (1 << 32) - 1)
+                capacity = _capacity(2 * (2 * total_half // world))
             continue
         break
-    keys = _original_keys(keys, perm)
+    keys, vals = _original_keys(sel_k[:nsel_r[rank]], perm), sel_v[:nsel_r[rank]]
     if world > 1:
-        keys, vals = _gather_varlen(keys, world), _gather_varlen(vals, world)
-    keys, vals = select_topk(keys, vals, k, g.n_rows)
+        keys, vals = epd.gather_ragged(keys, nsel_r), epd.gather_ragged(vals, nsel_r)
+    bits = max(1, min(32, int(g.n_rows - 1).bit_length()))
+    keys, vals = ops.select_rows(keys.contiguous(), vals.contiguous(), k, bits)
     if stats is not None:
-        stats.update(candidates=2 * n_cand_all, launches=launches, survivors=2 * n_all,
-                     bar=None if bar is None else float(bar.item()))
+        # survivors: DIRECTED rows at or above the job-wide cut (what the selection orders); survivor_slots: list slots the
+        # launches handed out (chunks: holes included); bar: None or a 1-element device tensor (float(bar) reads it)
+        stats.update(candidates=2 * n_cand_all, launches=launches, survivors=2 * n_sel_all,
+                     survivor_slots=sum(min(s_, capacity) for s_ in slots_r), bar=bar)
     return torch.stack([keys & 0xFFFFFFFF, keys >> 32]), vals

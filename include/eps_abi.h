@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define EPS_ABI_VERSION 1
+#define EPS_ABI_VERSION 3   /* 2: eps_col_sums / eps_node_weights_f64 signatures (r02); 3: 64-bit survivor count, eps_scan_* (r03) */
 
 #define EPS_OK 0
 #define EPS_EINVAL (-1)   /* bad argument (null pointer, negative size, unsupported shape) */
@@ -178,8 +178,7 @@ int64_t eps_expand_workspace_bytes(int64_t max_col_paths);
 typedef struct eps_survivors {
     float threshold;
     uint32_t capacity;
-    uint32_t count;
-    uint32_t reserved;
+    unsigned long long count;        /* slots handed out (64-bit: a list that overflows cannot wrap back under capacity) */
     int64_t *key;
     float *val;
     unsigned long long n_candidates; /* out (zeroed by the caller): unordered candidate pairs scored by the launch */
@@ -277,6 +276,15 @@ int eps_mlp_decode(const float *h, int64_t n_nodes, int32_t hdim, const int32_t 
  * eps_kth_largest_workspace_bytes() bytes, 8-byte aligned, contents arbitrary. */
 int64_t eps_kth_largest_workspace_bytes(void);
 int eps_kth_largest_f32(const float *x, int64_t n, int64_t k, float *kth, void *workspace, void *stream);
+/* The same radix select in steps, for a vector that is spread over the ranks of a torch.distributed job (the bar of the
+ * sharded scan, the final cut of filter.py:160-161 over all ranks' survivors).  state = eps_kth_largest_workspace_bytes()
+ * bytes on the device, 8-byte aligned: { uint32 prefix, mask; uint64 k; uint32 hist[256] } (hist at byte 16).  Per round
+ * (shift = 24, 16, 8, 0): eps_kth_hist_f32 adds the histogram of this rank's values (n may be 0), the caller sums hist over
+ * the ranks (one all-reduce of 1 KiB), eps_kth_pick narrows the prefix and clears hist.  After the round with shift 0,
+ * *out = the k-th largest of the union, -inf when the union holds fewer than k values. */
+int eps_kth_begin(void *state, int64_t k, void *stream);
+int eps_kth_hist_f32(const float *x, int64_t n, void *state, int32_t shift, void *stream);
+int eps_kth_pick(void *state, int32_t shift, float *out_or_null, void *stream);
 /* The k best DIRECTED proposals of a list of n unordered survivors of eps_filter_scan (keys v << 32 | u with u < v, one
  * entry per pair, no -1 slots; both orientations carry the pair's score), sorted by the declared rule -- score descending,
  * then key ascending (the reference's column-major candidate order): filter.py:160-161 for the rows rank.py:294 reads.
@@ -291,6 +299,11 @@ int eps_kth_largest_f32(const float *x, int64_t n, int64_t k, float *kth, void *
 int64_t eps_select_topk_cut_workspace_bytes(void);
 int eps_compact_survivors(const int64_t *keys, const float *vals, int64_t n, int64_t *out_keys, float *out_vals,
                           int64_t *n_out, void *workspace, int64_t workspace_bytes, void *stream);
+/* eps_compact_at_least: the survivors (key >= 0) among n slots whose score is at least *cut_or_null (a DEVICE float: the
+ * job-wide cut from eps_kth_pick; NULL keeps every survivor), compacted in arbitrary order; *n_out (DEVICE int64, zeroed by
+ * the call) = how many.  No workspace, no host round trip. */
+int eps_compact_at_least(const int64_t *keys, const float *vals, int64_t n, const float *cut_or_null, int64_t *out_keys,
+                         float *out_vals, int64_t *n_out, void *stream);
 int eps_select_topk_cut(const int64_t *keys, const float *vals, int64_t n, int64_t k, int64_t *sel_keys, float *sel_vals,
                         int64_t *n_sel, void *workspace, int64_t workspace_bytes, void *stream);
 int64_t eps_select_topk_rows_workspace_bytes(int64_t m);

@@ -125,6 +125,24 @@ def test_bench_two_ranks_child_process(dev, tmp_path, scaling):
     assert line["n_gpus"] == 2 and line["scaling"] == scaling and line["value"] > 0
     per_graph = line["config"]["candidates_per_step_all_ranks"] // (2 if scaling == "weak" else 1)
     assert per_graph > 0 and 0 < line["roofline"]["frac"] <= 1
+    assert (line["weak_value"] is not None) == (scaling == "strong")
+
+
+def test_bench_self_launch_from_plain_shell(dev, tmp_path):
+    """`python bench.py --gpus 2` with NO torchrun around it (how a person -- or a driver that does not wrap it -- starts
+    it): the parent starts the two ranks itself, never touches a GPU, and passes the one JSON line through.  Strong scaling is
+    the default for N > 1; the line carries per-rank kernel times, serial_ms and the weak figure as a secondary key."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--nodes", "30000",
+           "--edges", "600000", "--keep_top", "20000", "--no-cpu", "--no-legs", "--backend", "gloo", "--one-device"]
+    out = subprocess.run(cmd, cwd=tmp_path, capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["value"] > 0 and line["weak_value"] > 0
+    assert len(line["kernel_ms_per_rank"]) == 2 and "serial_ms" in line and "prep_ms" in line
+    assert 0 < line["roofline"]["frac"] <= 1 and line["value_unordered_pairs_per_s"] * 2 == pytest.approx(line["value"])
 
 
 def _relabelled_scan_rank_main(rank, world, port, workdir):

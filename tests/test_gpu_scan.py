@@ -147,7 +147,53 @@ def test_scan_topk_is_exact(eps, oracle, dev, monkeypatch):
     assert rel_err(scores.cpu().numpy(), ws) <= 1e-5
 
 
-def test_scan_full_size_properties(eps, dev):
+def test_scan_topk_overflow_and_ties(eps, dev, monkeypatch):
+    """The correction branches of scan_topk, forced: a survivor list that is far too small for the bar (slots > capacity ->
+    the bar is raised to just below the k2-th best of what was kept and the list grows) and heavily TIED scores (common-
+    neighbour counts: one integer level holds far more pairs than k) -- the result is still the first k rows of the declared
+    order; and two weight tables on ONE graph never share a cached fixed-point table (the cache is keyed on the tensor)."""
+    from eps_amd import scan, synth
+    g = synth.rmat_graph(12, 12, 3, dev)
+    ones = torch.ones(g.n_rows, dtype=torch.float32, device=dev)
+    from eps_amd.heuristics import node_weight_table
+    aa = node_weight_table(g, eps.ops.W_AA)
+
+    def want(wt, k):
+        _, cu, cv, _, sc = eps.ops.expand_candidates(g.rowptr, g.col, None, wt, g.n_rows, 0, g.n_rows, want_cn=False)
+        o = torch.sort(sc, descending=True, stable=True).indices[:k]
+        return torch.stack([cu[o], cv[o]]).long(), sc[o]
+
+    monkeypatch.setattr(scan, "SMALL_SET", 0)
+    monkeypatch.setattr(scan, "_CHUNK_SLACK", 0)
+    real = scan.estimate_bar
+    calls = []
+
+    def low_bar(*a, **kw):                       # an estimate that is far too low: (nearly) everything survives
+        calls.append(1)
+        return torch.full((1,), 1e-30, device=dev)
+    for wt in (ones, aa):
+        for k in (3000, 20001):
+            monkeypatch.setattr(scan, "estimate_bar", low_bar)
+            monkeypatch.setattr(scan, "SAFETY", 0.05)                      # ... and a list sized for a twentieth of k
+            st = {}
+            pairs, scores = scan.scan_topk(g, wt, k, stats=st)
+            assert st["launches"] >= 3, "the overflow branch did not run"
+            wp, ws = want(wt, k)
+            assert torch.equal(pairs, wp) and torch.equal(scores, ws)
+            monkeypatch.setattr(scan, "estimate_bar", real)
+            monkeypatch.setattr(scan, "SAFETY", 2.0)
+            pairs, scores = scan.scan_topk(g, wt, k)                     # tied levels through the regular path
+            assert torch.equal(pairs, wp) and torch.equal(scores, ws)
+    # alternating weight tables (fresh temporaries of the same size: the allocator recycles their addresses)
+    for i in range(4):
+        wt = (ones * 1.0) if i % 2 == 0 else (aa * 1.0)
+        pairs, scores = scan.scan_topk(g, wt, 5000)
+        wp, ws = want(ones if i % 2 == 0 else aa, 5000)
+        assert torch.equal(pairs, wp) and torch.equal(scores, ws)
+        del wt
+
+
+def test_scan_full_size_properties(eps, dev, oracle):
     """ppa-sized graph (BASELINE configs[2]): the scan over all columns finds exactly the candidates above the bar that
     the fused expansion scores above it on a block of columns, symmetric survivors mirror, and a re-run is
     bit-identical (order-independent fixed-point sums)."""
@@ -182,10 +228,39 @@ def test_scan_full_size_properties(eps, dev):
     assert int(hit.sum()) >= pairs.shape[1] - 2                                 # at most the K-th tie loses its mirror
     p2, s2 = scan.scan_topk(g, wt, 1_000_000)
     assert torch.equal(p2, pairs) and torch.equal(s2, scores)
+    _full_size_oracle_columns(eps, g, wt, pairs, scores, bar)
     # the same scan under hubs-first labels (what a repeatedly scanned graph runs on): ids mapped back, bit-identical list
     p3, s3 = scan.scan_topk(g, wt, 1_000_000, relabel=True)
     assert scan.scan_graph(g)[1] is not None
     assert torch.equal(p3, pairs) and torch.equal(s3, scores)
+
+
+def _full_size_oracle_columns(eps, g, wt, pairs, scores, bar):
+    """The full-size scan against the ORACLE directly (not against the build's own expansion kernel): for a dozen columns --
+    hubs, median-degree, tail -- the restated filter.py:96-109 candidate set (oracle.candidates_scipy_columns) scored by the
+    oracle's pair_scores; the scan's rows of those columns must be exactly the oracle's candidates above the bar (ids exact,
+    scores <= 1e-5 relative).  Rows whose oracle score is within 1e-5 of the bar may fall on either side."""
+    from oracle import eps_oracle as orc
+    deg = g.degree()
+    by_deg = torch.argsort(deg, descending=True)
+    n = g.n_rows
+    cols = sorted({int(by_deg[i]) for i in (0, 3, 50, 1000, n // 4, n // 2, n // 2 + 1, 3 * n // 4, n - 1000, n - 2)} | {7, n - 1})
+    A = g.to_scipy()
+    rp, col = A.indptr.astype(np.int64), A.indices.astype(np.int32)
+    w = orc.node_weights(orc.col_sums(rp, col, None, n), orc.W_AA)
+    pu, pv, ps = pairs[0].cpu().numpy(), pairs[1].cpu().numpy(), scores.cpu().numpy()
+    for c in cols:
+        cand, _ = orc.candidates_scipy_columns(A, c, c + 1)
+        _, _, sc = orc.pair_scores(rp, col, None, w, cand[:, 0], cand[:, 1])
+        sure = sc > bar * (1 + 2e-5)
+        maybe = sc > bar * (1 - 2e-5)
+        m = pv == c
+        got = dict(zip(pu[m].tolist(), ps[m].tolist()))
+        want_sure = dict(zip(cand[sure, 0].tolist(), sc[sure].tolist()))
+        want_maybe = set(cand[maybe, 0].tolist())
+        assert set(want_sure) <= set(got) <= want_maybe, f"column {c}: rows differ from the oracle's"
+        for u, s_ in want_sure.items():
+            assert abs(got[u] - s_) <= 1e-5 * max(abs(s_), abs(got[u])), (c, u, got[u], s_)
 
 
 def test_scan_wide_id_space_in_windows(eps, oracle, dev):
