@@ -38,6 +38,11 @@ SIGNATURES = {
     "eps_filter_scan_windows": (_int, [_i64, _c.POINTER(_i64), _c.POINTER(_i64)]),
     "eps_row_window_splits": (_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp]),
     "eps_filter_scan": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _i64, _vp, _vp, _i64, _vp]),
+    "eps_scan_windows": (_i32, []),
+    "eps_rescore_runs": (_int, [_vp, _vp, _vp, _i64, _vp, _i64, _vp, _vp]),
+    "eps_scan_cuts": (_int, [_vp, _vp, _i64, _vp, _vp, _vp]),
+    "eps_scan_screen_weights": (_int, [_vp, _i64, _i32, _vp, _vp, _vp]),
+    "eps_scan_screen": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _i64, _i32, _i32, _vp, _vp, _vp]),
     "eps_expand_unit_count": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _i64, _vp]),
     "eps_expand_unit_fill": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                     _i64, _vp]),

@@ -26,8 +26,12 @@
 #include <string.h>
 
 #define SP_M 32                 // id windows per graph (one 64-byte row of cuts per node)
-#define SP_EMPTY 0xFFFFFFFFu
+#define SP_EMPTY 0u             // an empty key word; a key is stored as id + 1, so a clean table is all zeros in BOTH modes
 #define SP_MAXP (SP_M + 1)
+#define SP_UBITS 8192           // units per range of the unit -> row bitmap (64 lanes x 128 bits: one uint4 per lane)
+#ifndef SP_G
+#define SP_G 2                  // units (of 4 entries) a lane looks up, loads and inserts together
+#endif
 
 typedef int sp_v4i __attribute__((ext_vector_type(4)));
 
@@ -44,7 +48,7 @@ struct sp_params {
     uint32_t col_bytes;
     int32_t table_bits;         // slots = 1 << table_bits (keys) + as many values
     uint32_t piece_paths;       // a hash piece holds at most this many paths (<= slots / 2)
-    uint32_t thr32;             // a candidate survives when its screening sum >= thr32 (>= 1)
+    int32_t shift;              // screening fixed point: 2^-shift
     float scale;                // 2^-shift: screening sum -> approximate score
     unsigned int *next_col;
     eps_survivors *out;
@@ -86,9 +90,13 @@ __global__ __launch_bounds__(T) void scan_piece_kernel(sp_params p)
     uint32_t *r_seg = lds + 2 * slots;       // [T + 1] first entry of the row's segment, as an index into col[]
     uint32_t *r_len = r_seg + T + 1;         // [T + 1] entries of the segment
     uint32_t *r_fx = r_len + T + 1;          // [T + 1] screening weight of the row's node
-    uint32_t *ustart = r_fx + T + 1;         // [T]     first 4-entry unit of the row in the piece's unit numbering; padded
+    uint32_t *ustart = r_fx + T + 1;         // [T + 1] first 4-entry unit of the row in the round's unit numbering
+    uint32_t *ubits = ustart + T + 1 + ((T + 1) & 1 ? 1 : 0) + 2;      // [SP_UBITS / 32] bit s: a row starts at unit s (of the range)
+    ubits = (uint32_t *)(((uintptr_t)ubits + 15) & ~(uintptr_t)15);
+    uint16_t *wrank = (uint16_t *)(ubits + SP_UBITS / 32);               // [SP_UBITS / 32] rows that start before the word
     __shared__ uint32_t s_pw[SP_M];          // paths of the column per id window
-    __shared__ int s_wtot[W];
+    __shared__ int s_wtot[W], s_wtot2[W];
+    __shared__ int s_rbase;
     __shared__ int32_t s_pk0[SP_MAXP], s_pk1[SP_MAXP];   // pieces: window run [k0, k1)
     __shared__ int32_t s_plo[SP_MAXP], s_phi[SP_MAXP];   // ... = ids [lo, hi) (hi cut at v)
     __shared__ uint32_t s_pinfo[SP_MAXP];    // paths of the piece | direct flag << 31
@@ -103,15 +111,34 @@ __global__ __launch_bounds__(T) void scan_piece_kernel(sp_params p)
     float *__restrict__ out_val = p.out->val;
     const uint32_t *__restrict__ rowptr_lo = (const uint32_t *)p.rowptr;     // nnz < 2^30: the low words suffice
     const __amdgpu_buffer_rsrc_t col_rs = __builtin_amdgcn_make_buffer_rsrc((void *)p.col, 0, p.col_bytes, 0x00020000);
-    const uint32_t thr32 = p.thr32;
+    // the bar in the table's domain.  filter_scan.hip keeps a candidate when its 2^-40 fixed-point sum a satisfies
+    // float(a * 2^-40) > threshold, i.e. a >= thr_fix (monotone: found by bisection); a screening sum s >= a / 2^(40 - shift),
+    // so s >= floor(thr_fix / 2^(40 - shift)) holds for every such candidate.  Any bar <= 0 (or -inf): every candidate.
+    uint32_t thr32 = 1u;
+    {
+        const float thr = p.out->threshold;
+        auto above = [&](long long a) { return (float)((double)a * (1.0 / (double)(1ll << 40))) > thr; };
+        if (!above(0x7fffffffffffffffll)) {
+            thr32 = 0xFFFFFFFFu;                      // +inf / NaN bar: nothing passes (sums stay below 2^32 - 1)
+        } else if (!above(0ll)) {
+            long long lo = 1ll, hi = 0x7fffffffffffffffll;      // smallest positive a with above(a)
+            while (lo < hi) {
+                const long long mid = lo + ((hi - lo) >> 1);
+                if (above(mid)) hi = mid; else lo = mid + 1;
+            }
+            const unsigned long long q = (unsigned long long)lo >> (40 - p.shift);
+            thr32 = q > 0xFFFFFFFEull ? 0xFFFFFFFFu : (q ? (uint32_t)q : 1u);
+        }
+    }
     const uint32_t direct_ids = 2u * (uint32_t)slots;
-    const uint32_t chunk = direct_ids > 8192u ? direct_ids : 8192u;     // survivor slots per reservation: >= a piece's yield
+    // Survivor slots are reserved in chunks (one global atomic each).  Without a bar every candidate of a piece survives: the
+    // chunk holds a whole piece's yield.  With one, survivors are rare: a piece asks for room for 1024, and a survivor that
+    // does not fit its workgroup's reservation takes a slot of its own (one more global atomic: rare).
+    const bool no_bar = thr32 <= 1u;
+    const uint32_t chunk = no_bar && direct_ids > 8192u ? direct_ids : 8192u;
     const int32_t my_bound = p.bounds[lane <= SP_M ? lane : SP_M];      // lane k holds window boundary k (the plan runs in wave 0)
 
-    for (int i = tid; i < slots; i += T) {
-        tkey[i] = SP_EMPTY;
-        tval[i] = 0u;
-    }
+    for (int i = tid; i < 2 * slots; i += T) lds[i] = 0u;
     if (tid == 0) {
         s_out_cur = 0u;
         s_out_end = 0u;
@@ -239,8 +266,10 @@ __global__ __launch_bounds__(T) void scan_piece_kernel(sp_params p)
                 const uint32_t mask = (1u << bits) - 1u;
                 const uint32_t scan_slots = direct ? (uint32_t)(hi_id - lo_id) : (1u << bits);
                 if (tid == 0) {
-                    const uint32_t need = ppaths < chunk ? ppaths : chunk;        // survivors <= distinct endpoints <= paths, slots
-                    if (s_out_end - s_out_cur < need) {
+                    uint32_t need = ppaths < scan_slots ? ppaths : scan_slots;    // survivors <= distinct endpoints <= paths, slots
+                    if (!no_bar && need > 1024u) need = 1024u;
+                    const uint32_t left = s_out_cur < s_out_end ? s_out_end - s_out_cur : 0u;
+                    if (left < need) {
                         const unsigned long long b64 = atomicAdd(&p.out->count, (unsigned long long)chunk);
                         const uint32_t b = b64 < (unsigned long long)out_cap ? (uint32_t)b64 : out_cap;
                         s_out_cur = b;
@@ -251,7 +280,6 @@ __global__ __launch_bounds__(T) void scan_piece_kernel(sp_params p)
                     for (int r = 0; r < rounds; ++r) {
                         // ---- describe the round's row segments inside the piece ------------------------------------------
                         const int j = r * T + tid;
-                        const int nrows = dv - r * T < T ? dv - r * T : T;
                         uint32_t w = my_w, rev = my_rev, base = my_base, fx = my_fx;
                         uint32_t len = 0u, a = 0u;
                         if (j < dv) {
@@ -268,68 +296,122 @@ __global__ __launch_bounds__(T) void scan_piece_kernel(sp_params p)
                             b = b < rev ? b : rev;
                             len = b - a;
                         }
+                        // Rows with entries in the piece get DENSE indices (block scans of the unit counts and of the non-empty
+                        // flags), and the unit -> row map is a bitmap of row starts over the unit numbering plus the rank of every
+                        // 32-unit word: a lane finds the row of its unit with two independent LDS reads and a popcount (a binary
+                        // search over the unit prefix -- ten dependent reads -- was 12 of the launch's 32 ms).
                         const int units = (int)((len + 3u) >> 2);
-                        int incl = sp_wave_incl_scan(units);
-                        if (lane == 63) s_wtot[wib] = incl;
-                        r_seg[tid] = base + a;
-                        r_len[tid] = len;
-                        r_fx[tid] = fx;
+                        const int flag = units > 0 ? 1 : 0;
+                        const int incl = sp_wave_incl_scan(units), incl_f = sp_wave_incl_scan(flag);
+                        if (lane == 63) {
+                            s_wtot[wib] = incl;
+                            s_wtot2[wib] = incl_f;
+                        }
+                        for (int i = tid; i < SP_UBITS / 32; i += T) ubits[i] = 0u;
                         sp_barrier();
-                        int woff = 0, total = 0;
+                        int woff = 0, total = 0, woff_f = 0;
 #pragma unroll
                         for (int i = 0; i < W; ++i) {
-                            const int x = s_wtot[i];
-                            if (i < wib) woff += x;
+                            const int x = s_wtot[i], y = s_wtot2[i];
+                            if (i < wib) {
+                                woff += x;
+                                woff_f += y;
+                            }
                             total += x;
                         }
-                        ustart[tid] = tid < nrows ? (uint32_t)(incl - units + woff) : 0xFFFFFFFFu;
-                        sp_barrier();
-                        // ---- walk: lane = one 4-entry unit; row by binary search over the unit prefix ---------------------
-                        int pow2 = 1;
-                        while (pow2 < nrows) pow2 <<= 1;
-                        auto fetch = [&](int s) -> sp_unit {
-                            sp_unit f;
-                            int lo = 0;
-                            for (int step = pow2 >> 1; step >= 1; step >>= 1)
-                                if (ustart[lo + step] <= (uint32_t)s) lo += step;
-                            const int off = (s - (int)ustart[lo]) * 4;
-                            const int left = s < total ? (int)r_len[lo] - off : 0;
-                            f.nvalid = left < 0 ? 0 : (left > 4 ? 4 : left);
-                            f.fx = r_fx[lo];
-                            const uint32_t at = s < total ? r_seg[lo] + (uint32_t)off : (p.col_bytes >> 2);
-                            f.u4 = __builtin_amdgcn_raw_buffer_load_b128(col_rs, (int)(at * 4u), 0, 0);
-                            return f;
+                        const uint32_t a_u = (uint32_t)(incl - units + woff);          // first unit of this thread's row
+                        if (flag) {
+                            const int d = incl_f - 1 + woff_f;
+                            r_seg[d] = base + a;
+                            r_len[d] = len;
+                            r_fx[d] = fx;
+                            ustart[d] = a_u;
+                        }
+                        for (uint32_t ulo = 0; ulo < (uint32_t)total; ulo += SP_UBITS) {       // (one range unless > 32 k paths)
+                            const uint32_t uhi = ulo + SP_UBITS < (uint32_t)total ? ulo + SP_UBITS : (uint32_t)total;
+                            if (ulo > 0u) {
+                                for (int i = tid; i < SP_UBITS / 32; i += T) ubits[i] = 0u;
+                                if (tid == 0) s_rbase = 0;
+                                sp_barrier();
+                                const unsigned long long before = __ballot(flag && a_u + (uint32_t)units <= ulo);
+                                if (lane == 0 && before) atomicAdd(&s_rbase, __popcll(before));
+                            }
+                            if (flag && a_u + (uint32_t)units > ulo && a_u < uhi) {
+                                const uint32_t pos = (a_u > ulo ? a_u : ulo) - ulo;
+                                atomicOr(&ubits[pos >> 5], 1u << (pos & 31));
+                            }
+                            sp_barrier();
+                            const int rbase = ulo > 0u ? s_rbase : 0;
+                            {   // rank of every word's first bit: every wave computes all of them (identical values: no barrier)
+                                const uint4 b4 = *(const uint4 *)(ubits + 4 * lane);
+                                const int c0 = __popc(b4.x), c1 = c0 + __popc(b4.y), c2 = c1 + __popc(b4.z), c3 = c2 + __popc(b4.w);
+                                const int ex = sp_wave_incl_scan(c3) - c3;
+                                uint2 pk;
+                                pk.x = (uint32_t)ex | ((uint32_t)(ex + c0) << 16);
+                                pk.y = (uint32_t)(ex + c1) | ((uint32_t)(ex + c2) << 16);
+                                *(uint2 *)(wrank + 4 * lane) = pk;
+                                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                            }
+                        // A GROUP of SP_G units per lane is looked up, loaded and inserted together: the binary searches of a
+                        // group run side by side (one LDS latency per step, not SP_G), its loads are in flight together, and its
+                        // 4 x SP_G table updates share the probing loop (a trip costs one LDS round trip however many of them are
+                        // still pending).  The next group is requested before the current one is consumed.
+                        auto fetch_group = [&](int it0, sp_unit (&f)[SP_G]) {
+                            int lo[SP_G];
+#pragma unroll
+                            for (int q = 0; q < SP_G; ++q) {
+                                const uint32_t sr = (uint32_t)((it0 + q) * T + tid);       // unit, relative to the range
+                                const uint32_t wd = sr < SP_UBITS ? sr >> 5 : 0u;
+                                const uint32_t bits = ubits[wd];
+                                const int rk = (int)wrank[wd];
+                                lo[q] = rbase + rk + __popc(bits & ((2u << (sr & 31u)) - 1u)) - 1;
+                                lo[q] = lo[q] < 0 ? 0 : lo[q];
+                            }
+#pragma unroll
+                            for (int q = 0; q < SP_G; ++q) {
+                                const int s = (int)ulo + (it0 + q) * T + tid;
+                                const int off = (s - (int)ustart[lo[q]]) * 4;
+                                const int left = s < (int)uhi ? (int)r_len[lo[q]] - off : 0;
+                                f[q].nvalid = left < 0 ? 0 : (left > 4 ? 4 : left);
+                                f[q].fx = r_fx[lo[q]];
+                                const uint32_t at = s < (int)uhi ? r_seg[lo[q]] + (uint32_t)off : (p.col_bytes >> 2);
+                                f[q].u4 = __builtin_amdgcn_raw_buffer_load_b128(col_rs, (int)(at * 4u), 0, 0);
+                            }
                         };
-                        auto consume = [&](const sp_unit &f) {
+                        auto consume_group = [&](const sp_unit (&f)[SP_G]) {
                             if (direct) {
 #pragma unroll
-                                for (int e = 0; e < 4; ++e)
-                                    if (e < f.nvalid) atomicAdd(&lds[(uint32_t)(f.u4[e] - lo_id)], f.fx);
+                                for (int q = 0; q < SP_G; ++q)
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e)
+                                        if (e < f[q].nvalid) atomicAdd(&lds[(uint32_t)(f[q].u4[e] - lo_id)], f[q].fx);
                             } else {
-                                uint32_t key[4], h[4], st[4];
+                                constexpr int E = 4 * SP_G;
+                                uint32_t key[E], h[E], st[E];
                                 uint32_t pend = 0u;
 #pragma unroll
-                                for (int e = 0; e < 4; ++e) {
-                                    key[e] = (uint32_t)f.u4[e];
-                                    const uint32_t mix = key[e] * 0x9E3779B1u;
-                                    h[e] = (mix >> (32 - bits)) & mask;
-                                    st[e] = ((mix >> 7) | 1u) & mask;
-                                    if (e < f.nvalid && (mix & (parts - 1u)) == part) pend |= 1u << e;
+                                for (int i = 0; i < E; ++i) {
+                                    const uint32_t id = (uint32_t)f[i >> 2].u4[i & 3];
+                                    const uint32_t mix = id * 0x9E3779B1u;
+                                    key[i] = id + 1u;
+                                    h[i] = (mix >> (32 - bits)) & mask;
+                                    st[i] = ((mix >> 7) | 1u) & mask;
+                                    if ((i & 3) < f[i >> 2].nvalid && (mix & (parts - 1u)) == part) pend |= 1u << i;
                                 }
                                 uint32_t tries = 0;
                                 while (__ballot(pend != 0u)) {
-                                    uint32_t old[4];
+                                    uint32_t old[E];
 #pragma unroll
-                                    for (int e = 0; e < 4; ++e)
-                                        if (pend & (1u << e)) old[e] = atomicCAS(&tkey[h[e]], SP_EMPTY, key[e]);
+                                    for (int i = 0; i < E; ++i)
+                                        if (pend & (1u << i)) old[i] = atomicCAS(&tkey[h[i]], SP_EMPTY, key[i]);
 #pragma unroll
-                                    for (int e = 0; e < 4; ++e)
-                                        if (pend & (1u << e)) {
-                                            if (old[e] == SP_EMPTY || old[e] == key[e]) {
-                                                atomicAdd(&tval[h[e]], f.fx);
-                                                pend &= ~(1u << e);
+                                    for (int i = 0; i < E; ++i)
+                                        if (pend & (1u << i)) {
+                                            if (old[i] == SP_EMPTY || old[i] == key[i]) {
+                                                atomicAdd(&tval[h[i]], f[i >> 2].fx);
+                                                pend &= ~(1u << i);
                                             } else {
-                                                h[e] = (h[e] + st[e]) & mask;
+                                                h[i] = (h[i] + st[i]) & mask;
                                             }
                                         }
                                     if (++tries > mask + 1u) {           // the table is full (backstop; never within the piece limits)
@@ -340,13 +422,19 @@ __global__ __launch_bounds__(T) void scan_piece_kernel(sp_params p)
                             }
                         };
                         {
-                            const int n_iter = (total + T - 1) / T;      // uniform over the workgroup
-                            sp_unit f0 = fetch(tid);
-                            for (int it = 0; it < n_iter; ++it) {
-                                const sp_unit f1 = fetch((it + 1) * T + tid);      // (past the end: an empty unit)
-                                consume(f0);
-                                f0 = f1;
+                            const int n_iter = (int)(uhi - ulo + T - 1) / T;      // uniform over the workgroup
+                            sp_unit fa[SP_G], fb[SP_G];
+                            fetch_group(0, fa);
+                            for (int it0 = 0; it0 < n_iter; it0 += 2 * SP_G) {
+                                if (it0 + SP_G < n_iter) fetch_group(it0 + SP_G, fb);
+                                consume_group(fa);
+                                if (it0 + SP_G < n_iter) {
+                                    if (it0 + 2 * SP_G < n_iter) fetch_group(it0 + 2 * SP_G, fa);
+                                    consume_group(fb);
+                                }
                             }
+                        }
+                            if (uhi < (uint32_t)total) sp_barrier();       // (the next range rewrites the start bits)
                         }
                         sp_barrier();        // the next round / the scan follows: descriptors and table updates are complete
                     }
@@ -363,7 +451,7 @@ __global__ __launch_bounds__(T) void scan_piece_kernel(sp_params p)
                                     const uint32_t st = ((mix >> 7) | 1u) & mask;
                                     for (uint32_t tries = 0; tries <= mask; ++tries) {
                                         const uint32_t k = tkey[h];
-                                        if (k == u) {
+                                        if (k == u + 1u) {
                                             tval[h] = 0u;
                                             break;
                                         }
@@ -377,7 +465,11 @@ __global__ __launch_bounds__(T) void scan_piece_kernel(sp_params p)
                     sp_barrier();
                     // ---- scan the table: count the candidates, report the survivors, leave it clean --------------------------
                     auto emit = [&](uint32_t u, uint32_t sum) {
-                        const uint32_t pos = atomicAdd(&s_out_cur, 1u);
+                        uint32_t pos = atomicAdd(&s_out_cur, 1u);
+                        if (pos >= s_out_end) {                          // past the reservation: a slot of its own
+                            const unsigned long long q = atomicAdd(&p.out->count, 1ull);
+                            pos = q < (unsigned long long)out_cap ? (uint32_t)q : out_cap;
+                        }
                         if (pos < out_cap) {
                             out_key[pos] = ((int64_t)v << 32) | (int64_t)u;
                             out_val[pos] = (float)sum * p.scale;
@@ -397,13 +489,11 @@ __global__ __launch_bounds__(T) void scan_piece_kernel(sp_params p)
                                     if (sv[e] >= thr32) emit((uint32_t)lo_id + i + e, sv[e]);
                                 }
                         }
-                        // the scan may have cleared up to three words past the ids (whole uint4s): they belong to the key words
-                        // of hash mode only when the piece spans more than `slots` ids -- restore the empty pattern below
                     } else {
                         for (uint32_t i = 4u * tid; i < scan_slots; i += 4u * T) {
                             const uint4 k4 = *(const uint4 *)(tkey + i);
                             const uint4 s4 = *(const uint4 *)(tval + i);
-                            *(uint4 *)(tkey + i) = make_uint4(SP_EMPTY, SP_EMPTY, SP_EMPTY, SP_EMPTY);
+                            *(uint4 *)(tkey + i) = make_uint4(0u, 0u, 0u, 0u);
                             *(uint4 *)(tval + i) = make_uint4(0u, 0u, 0u, 0u);
                             const uint32_t kk[4] = {k4.x, k4.y, k4.z, k4.w};
                             const uint32_t sv[4] = {s4.x, s4.y, s4.z, s4.w};
@@ -411,19 +501,12 @@ __global__ __launch_bounds__(T) void scan_piece_kernel(sp_params p)
                             for (int e = 0; e < 4; ++e)
                                 if (kk[e] != SP_EMPTY && sv[e]) {
                                     ++cnt_here;
-                                    if (sv[e] >= thr32) emit(kk[e], sv[e]);
+                                    if (sv[e] >= thr32) emit(kk[e] - 1u, sv[e]);
                                 }
                         }
                     }
                     n_cand += cnt_here;
                     sp_barrier();
-                    if (direct) {
-                        // the direct sums used the key words as plain sums: back to the empty pattern (only what was touched)
-                        const uint32_t used = ((scan_slots + 3u) & ~3u) < (uint32_t)slots ? ((scan_slots + 3u) & ~3u) : (uint32_t)slots;
-                        for (uint32_t i = 4u * tid; i < used; i += 4u * T)
-                            *(uint4 *)(tkey + i) = make_uint4(SP_EMPTY, SP_EMPTY, SP_EMPTY, SP_EMPTY);
-                        sp_barrier();
-                    }
                 }
             }
         }
@@ -480,6 +563,134 @@ __global__ void sp_screen_weights_kernel(const int64_t *__restrict__ fixw, int64
     }
 }
 
+// ---- exact re-scoring of the screened survivors -----------------------------------------------------------------------------
+// The survivors of a scan are pairs of hubs: a few thousand nodes u recur in hundreds of pairs each.  The list comes sorted by
+// (u, v) as keys (u << 32) | v; a workgroup takes 256 consecutive pairs, and for every run of equal u inside them turns N(u)
+// into an LDS bitmap over the id space (windows of RS_BITS ids when the space is wider), streams the short rows N(v) of the
+// run against it -- one wave per pair, coalesced -- and sums the exact weights of the hits in float64.  The weights are
+// multiples of 2^-40 below 2^12, so the float64 sum is exact whatever the order: (float)sum is eps_filter_scan's score, bit
+// for bit (adamic_utils.py:13-25 / train_and_eval.py:195-216 / models.py:536-542 with the engine's fixed-point definition).
+#define RS_THREADS 512
+#define RS_CHUNK 256
+#define RS_BITS (1 << 20)       // ids per bitmap window: 128 KiB of LDS
+
+__global__ __launch_bounds__(RS_THREADS) void rescore_runs_kernel(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+                                                                 const double *__restrict__ w64, int32_t n_nodes,
+                                                                 const int64_t *__restrict__ keys, int64_t n,
+                                                                 float *__restrict__ out, unsigned int *__restrict__ next_chunk)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t bm[];          // RS_BITS / 32 words
+    __shared__ unsigned long long s_starts[RS_CHUNK / 64];
+    __shared__ double s_sum[RS_CHUNK];
+    __shared__ unsigned int s_c;
+    const int tid = threadIdx.x, lane = tid & 63, wib = tid >> 6;
+    constexpr int W = RS_THREADS / 64;
+    const int words = (n_nodes < RS_BITS ? (n_nodes + 31) >> 5 : RS_BITS >> 5);
+    for (int i = tid; i < words; i += RS_THREADS) bm[i] = 0u;
+    const int64_t n_chunks = (n + RS_CHUNK - 1) / RS_CHUNK;
+    for (;;) {
+        if (tid == 0) s_c = atomicAdd(next_chunk, 1u);
+        __syncthreads();
+        const int64_t c = s_c;
+        if (c >= n_chunks) break;
+        const int64_t c0 = c * RS_CHUNK;
+        const int cn = (int)(n - c0 < RS_CHUNK ? n - c0 : RS_CHUNK);
+        // run starts inside the chunk
+        if (tid < RS_CHUNK) {
+            s_sum[tid] = 0.0;
+            bool start = false;
+            if (tid < cn) start = tid == 0 || (keys[c0 + tid] >> 32) != (keys[c0 + tid - 1] >> 32);
+            const unsigned long long m = __ballot(start);
+            if (lane == 0) s_starts[wib] = m;
+        }
+        __syncthreads();
+        int s = 0;
+        while (s < cn) {
+            // end of the run that starts at s: the next start bit after s
+            int e = cn;
+            for (int q = s >> 6; q < RS_CHUNK / 64; ++q) {
+                unsigned long long m = s_starts[q];
+                if (q == (s >> 6)) m &= (s & 63) == 63 ? 0ull : ~0ull << ((s & 63) + 1);
+                if (m) {
+                    e = q * 64 + __builtin_ctzll(m);
+                    break;
+                }
+            }
+            if (e > cn) e = cn;
+            const int32_t u = (int32_t)(keys[c0 + s] >> 32);
+            const int64_t ub = rowptr[u], ue = rowptr[u + 1];
+            for (int32_t wlo = 0; wlo < n_nodes; wlo += RS_BITS) {
+                // N(u) inside the id window -> bits (rows ascend; a plain scan of the row is cheap next to the pairs)
+                for (int64_t i = ub + tid; i < ue; i += RS_THREADS) {
+                    const uint32_t x = (uint32_t)(col[i] - wlo);
+                    if (x < (uint32_t)RS_BITS) atomicOr(&bm[x >> 5], 1u << (x & 31));
+                }
+                __syncthreads();
+                for (int pi = s + wib; pi < e; pi += W) {
+                    const int32_t v = (int32_t)(keys[c0 + pi] & 0xFFFFFFFFll);
+                    const int64_t vb = rowptr[v], ve = rowptr[v + 1];
+                    double acc = 0.0;
+                    for (int64_t i0 = vb; i0 < ve; i0 += 256) {          // four independent row loads in flight per lane
+                        int32_t wv[4];
+#pragma unroll
+                        for (int b = 0; b < 4; ++b) {
+                            const int64_t i = i0 + b * 64 + lane;
+                            wv[b] = i < ve ? col[i] : -1;
+                        }
+                        double add[4];
+#pragma unroll
+                        for (int b = 0; b < 4; ++b) {
+                            const uint32_t x = (uint32_t)(wv[b] - wlo);
+                            const bool hit = wv[b] >= 0 && x < (uint32_t)RS_BITS && ((bm[x >> 5] >> (x & 31)) & 1u);
+                            add[b] = hit ? w64[wv[b]] : 0.0;
+                        }
+                        acc += (add[0] + add[1]) + (add[2] + add[3]);
+                    }
+#pragma unroll
+                    for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d);
+                    if (lane == 0) s_sum[pi] += acc;
+                }
+                __syncthreads();
+                for (int64_t i = ub + tid; i < ue; i += RS_THREADS) {
+                    const uint32_t x = (uint32_t)(col[i] - wlo);
+                    if (x < (uint32_t)RS_BITS) bm[x >> 5] = 0u;
+                }
+                __syncthreads();
+            }
+            s = e;
+        }
+        if (tid < cn) out[c0 + tid] = (float)s_sum[tid];
+        __syncthreads();
+    }
+}
+
+// keys: (u << 32) | v sorted ascending (runs of equal u); w64[i] = exact weight of node i (multiples of 2^-40); out[i] = score of
+// pair i as float32 of the exact sum.  Unit-valued adjacency.
+extern "C" int eps_rescore_runs(const int64_t *rowptr, const int32_t *col, const double *w64, int64_t n_nodes,
+                                const int64_t *keys, int64_t n, float *out, void *stream)
+{
+    EPS_REQUIRE(n >= 0 && n_nodes >= 0 && n_nodes < (1ll << 31), "eps_rescore_runs: bad size");
+    if (n == 0) return EPS_OK;
+    EPS_REQUIRE(rowptr && col && w64 && keys && out, "eps_rescore_runs: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    unsigned int *counter = nullptr;
+    const int rc = eps_take_counter(&counter, s, "eps_rescore_runs");
+    if (rc) return rc;
+    const size_t lds = (size_t)(n_nodes < RS_BITS ? ((n_nodes + 31) >> 5) : (RS_BITS >> 5)) * 4 + 16;
+    if (hipFuncSetAttribute((const void *)rescore_runs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+        eps_set_error("eps_rescore_runs: cannot reserve %zu bytes of LDS", lds);
+        return EPS_ELAUNCH;
+    }
+    int64_t blocks = (n + RS_CHUNK - 1) / RS_CHUNK;
+    const int64_t per_cu = (160 * 1024 - 2048) / (int64_t)(lds + 2560);            // workgroups the LDS lets a CU hold
+    const int64_t cap = (int64_t)eps_num_cus() * (per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu));
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(rescore_runs_kernel, dim3((unsigned)blocks), dim3(RS_THREADS), lds, s, rowptr, col, w64, (int32_t)n_nodes, keys,
+                       n, out, counter);
+    EPS_CHECK_LAUNCH("eps_rescore_runs");
+    return EPS_OK;
+}
+
 extern "C" int32_t eps_scan_windows(void) { return SP_M; }
 
 extern "C" int eps_scan_cuts(const int64_t *rowptr, const int32_t *col, int64_t n_nodes, const int32_t *bounds, uint16_t *cuts,
@@ -522,7 +733,7 @@ extern "C" int eps_scan_screen_weights(const int64_t *fixw, int64_t n, int32_t s
 //          2 = 256 threads, 4096 slots (four per CU)
 extern "C" int eps_scan_screen(const int64_t *rowptr, const int32_t *col, const int32_t *revpos, const uint32_t *fx32,
                                const uint16_t *cuts, const int32_t *bounds, int64_t n_nodes, int64_t nnz,
-                               const int32_t *columns, int64_t n_columns, uint32_t thr32, int32_t shift, int32_t variant,
+                               const int32_t *columns, int64_t n_columns, int32_t shift, int32_t variant,
                                eps_survivors *out, uint32_t *status, void *stream)
 {
     EPS_REQUIRE(n_nodes >= 0 && n_columns >= 0 && nnz >= 0, "eps_scan_screen: negative size");
@@ -557,14 +768,14 @@ extern "C" int eps_scan_screen(const int64_t *rowptr, const int32_t *col, const 
     p.col_bytes = (uint32_t)(nnz * 4);
     p.table_bits = bits;
     p.piece_paths = (1u << bits) / 2u;
-    p.thr32 = thr32 ? thr32 : 1u;
+    p.shift = shift;
     p.scale = ldexpf(1.0f, -shift);
     p.next_col = counter;
     p.out = out;
     p.status = status;
     int64_t blocks = (int64_t)eps_num_cus() * per_cu[variant];
     if (blocks > n_columns) blocks = n_columns;
-    const size_t lds = ((size_t)(2 << bits) + 3 * (size_t)(T + 1) + (size_t)T + 1) * 4;
+    const size_t lds = ((size_t)(2 << bits) + 4 * (size_t)(T + 1) + 8) * 4 + (SP_UBITS / 32) * 6 + 32;
     void (*kern)(sp_params) = variant == 0 ? scan_piece_kernel<512> : variant == 1 ? scan_piece_kernel<1024> : scan_piece_kernel<256>;
     if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
         eps_set_error("eps_scan_screen: cannot reserve %zu bytes of LDS", lds);

@@ -479,6 +479,74 @@ def filter_scan(rowptr, col, revpos, fixw, n_nodes: int, columns: torch.Tensor, 
             KERNEL_EVENTS.append(("filter_scan_kernel", ev[0], ev[1], int(columns.numel())))
 
 
+# ------------------------------------------------------------------ one-pass threshold scan (csrc/scan_pieces.hip)
+def scan_windows() -> int:
+    return int(_lib.load().eps_scan_windows())
+
+
+def scan_cuts(rowptr: torch.Tensor, col: torch.Tensor, bounds: torch.Tensor) -> torch.Tensor:
+    """uint16 table [N, M] (stored as int16 bits): entries of every row below each id-window boundary (per-graph table)."""
+    dev = _need_gpu(rowptr, col, bounds)
+    _chk(rowptr, torch.int64, "rowptr"); _chk(col, torch.int32, "col"); _chk(bounds, torch.int32, "bounds")
+    m = scan_windows()
+    if bounds.numel() != m + 1:
+        raise _lib.EpsError(f"scan_cuts: bounds must hold {m + 1} boundaries")
+    n = rowptr.numel() - 1
+    out = torch.empty((n, m), dtype=torch.int16, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.load().eps_scan_cuts(_ptr(rowptr), _ptr(col), n, _ptr(bounds), _ptr(out), _stream(dev)), "eps_scan_cuts")
+    return out
+
+
+def scan_screen_weights(fixw: torch.Tensor, shift: int):
+    """(fx32 int32-bits[N], bad int32[1]): the scan's fixed-point weights rounded UP to 2^-shift (at least 1)."""
+    dev = _need_gpu(fixw)
+    _chk(fixw, torch.int64, "fixw")
+    out = torch.empty(fixw.numel(), dtype=torch.int32, device=dev)
+    bad = torch.empty(1, dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.load().eps_scan_screen_weights(_ptr(fixw), fixw.numel(), int(shift), _ptr(out), _ptr(bad), _stream(dev)),
+                   "eps_scan_screen_weights")
+    return out, bad
+
+
+def rescore_runs(rowptr, col, w64: torch.Tensor, n_nodes: int, keys_by_u: torch.Tensor) -> torch.Tensor:
+    """float32 exact scores of the pairs ``keys_by_u`` = (u << 32) | v, sorted ascending (eps_rescore_runs)."""
+    dev = _need_gpu(rowptr, col, w64, keys_by_u)
+    _chk(rowptr, torch.int64, "rowptr"); _chk(col, torch.int32, "col"); _chk(w64, torch.float64, "w64"); _chk(keys_by_u, torch.int64, "keys")
+    out = torch.empty(keys_by_u.numel(), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.load().eps_rescore_runs(_ptr(rowptr), _ptr(col), _ptr(w64), n_nodes, _ptr(keys_by_u), keys_by_u.numel(),
+                                                _ptr(out), _stream(dev)), "eps_rescore_runs")
+    return out
+
+
+SCAN_VARIANT = 2          # workgroup / table geometry of eps_scan_screen (see include/eps_abi.h); tools/ set it for A/B runs
+
+
+def scan_screen(rowptr, col, revpos, fx32, cuts, bounds, n_nodes: int, columns: torch.Tensor, shift: int, out: "Survivors",
+                status: torch.Tensor, variant: Optional[int] = None) -> None:
+    """Launch eps_scan_screen over ``columns``; survivors (screening scores) accumulate in ``out``."""
+    dev = _need_gpu(rowptr, col, revpos, fx32, cuts, bounds, columns, status)
+    _chk(rowptr, torch.int64, "rowptr"); _chk(col, torch.int32, "col"); _chk(revpos, torch.int32, "revpos")
+    _chk(fx32, torch.int32, "fx32"); _chk(cuts, torch.int16, "cuts"); _chk(bounds, torch.int32, "bounds")
+    _chk(columns, torch.int32, "columns"); _chk(status, torch.int32, "status")
+    if revpos.numel() != col.numel() or fx32.numel() != n_nodes or cuts.shape[0] != n_nodes:
+        raise _lib.EpsError("scan_screen: revpos / fx32 / cuts do not match the graph")
+    with torch.cuda.device(dev):
+        ev = None
+        if KERNEL_EVENTS is not None:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record(torch.cuda.current_stream(dev))
+        _lib.check(_lib.load().eps_scan_screen(_ptr(rowptr), _ptr(col), _ptr(revpos), _ptr(fx32), _ptr(cuts), _ptr(bounds), n_nodes,
+                                               col.numel(), _ptr(columns), columns.numel(), int(shift),
+                                               SCAN_VARIANT if variant is None else int(variant), _ptr(out.rec), _ptr(status),
+                                               _stream(dev)), "eps_scan_screen")
+        if ev is not None:
+            ev[1].record(torch.cuda.current_stream(dev))
+            KERNEL_EVENTS.append(("scan_piece_kernel", ev[0], ev[1], int(columns.numel())))
+
+
 def spmm_csr(rowptr, col, val, x: torch.Tensor, bias=None, relu=False, mean=False, out=None) -> torch.Tensor:
     dev = _need_gpu(rowptr, col, val, x, bias, out, row_strided=(x, out))
     _chk(rowptr, torch.int64, "rowptr"); _chk(col, torch.int32, "col"); _chk(val, torch.float32, "val")

@@ -37,6 +37,9 @@ MAX_K = 1 << 30            # rows a survivor list (< 2^32 slots, handed out in c
 MAX_LAUNCHES = 8           # estimate -> scan -> correct rounds before giving up (two are the rule)
 _CHUNK_SLACK = 8192 * 320  # survivor slots are handed out in chunks of 8192 per workgroup
 RELABEL_MIN_NODES = 100_000  # graphs at least this large are scanned under hubs-first labels (see scan_graph)
+ONE_PASS = True            # score with the one-pass piece kernel (csrc/scan_pieces.hip) where the graph qualifies, else eps_filter_scan
+_PIECE_SLACK = 8192 * 1024 + 65536   # eps_scan_screen hands slots out in chunks of <= 32768 per workgroup (<= 1024 workgroups)
+MAX_SCREEN_SHIFT = 30
 
 
 def scan_available(g: CSRGraph) -> bool:
@@ -131,11 +134,86 @@ def _original_keys(keys: torch.Tensor, perm) -> torch.Tensor:
     return (torch.maximum(a, b) << 32) | torch.minimum(a, b)
 
 
-def _launch(g, fixw, columns, threshold, capacity, scores_only: bool = False, both: bool = False) -> ops.Survivors:
+def screen_tables(g: CSRGraph):
+    """(bounds int32[M + 1], cuts int16-bits [N, M]) of the one-pass scan, cached on the graph: the id space cut into M windows
+    of equal stored-entry mass (so a column's paths spread evenly over them), and per row the number of entries below each
+    boundary."""
+    if "screen_tables" not in g._cache:
+        m = ops.scan_windows()
+        n = g.n_rows
+        cdeg = torch.cumsum(g.degree(), 0).to(torch.float64)
+        targets = torch.arange(1, m, device=g.device, dtype=torch.float64) * (cdeg[-1] / m)
+        inner = torch.clamp(torch.searchsorted(cdeg, targets) + 1, max=n)
+        bounds = torch.cat([torch.zeros(1, dtype=torch.int64, device=g.device), inner,
+                            torch.full((1,), n, dtype=torch.int64, device=g.device)]).to(torch.int32)
+        bounds = torch.cummax(bounds, 0).values.contiguous()
+        g._cache["screen_tables"] = (bounds, ops.scan_cuts(g.rowptr, g.col, bounds))
+    return g._cache["screen_tables"]
+
+
+def screen_shift(bound: float, max_deg: int) -> int:
+    """Fixed point 2^-shift of the screening sums: the finest one that keeps every sum of the graph below 2^32 (score bound
+    plus one rounding unit per term), at most MAX_SCREEN_SHIFT."""
+    shift = MAX_SCREEN_SHIFT
+    while shift > 0 and bound * (1 << shift) + max_deg >= (1 << 32) - 2:
+        shift -= 1
+    return shift
+
+
+def screen_weights(g0: CSRGraph, g: CSRGraph, perm, node_w: torch.Tensor):
+    """(fx32, shift, float64 weights, usable) for the one-pass scan of ``g`` (the scanned copy of ``g0``), cached per weight
+    tensor: screening weights rounded up to 2^-shift, and the exact weights fixw * 2^-40 as doubles for the re-scoring (sums
+    of multiples of 2^-40 below 2^12 are exact in float64, whatever the order).  ``usable`` is False for negative weights or a
+    score bound beyond 32 bits: such tables stay on eps_filter_scan."""
+    def build():
+        from . import candidates
+        fixw = _scan_weights(g0, g, perm, node_w)
+        bound = candidates.fused_score_bound(g0, node_w)
+        shift = screen_shift(bound, max_degree(g))
+        fx32, bad = ops.scan_screen_weights(fixw, shift)
+        usable = int(bad.item()) == 0 and bound * (1 << shift) + max_degree(g) < (1 << 32) - 2
+        return fx32, shift, fixw.to(torch.float64) * (2.0 ** -40), usable
+    # (one entry per labelling: the tables are indexed by the SCANNED graph's node ids)
+    return g0.weight_cached("screen_weights" if perm is None else "screen_weights_relabelled", node_w, build)
+
+
+def one_pass_available(g: CSRGraph) -> bool:
+    """The piece kernel takes what eps_filter_scan takes, with rows shorter than 2^16 (its cut table is uint16)."""
+    return ONE_PASS and 0 < max_degree(g) < 1 << 16
+
+
+def _launch(g, fixw, columns, threshold, capacity, scores_only: bool = False, both: bool = False, screen=None) -> ops.Survivors:
+    """``screen`` = (fx32, shift) -> the one-pass kernel (screening scores in ``val``), else eps_filter_scan (exact scores)."""
     out = ops.Survivors(capacity, threshold, g.device, scores_only, both)
     if columns.numel():
-        ops.filter_scan(g.rowptr, g.col, reverse_positions(g), fixw, g.n_rows, columns, out, max_degree(g), window_splits(g))
+        if screen is not None:
+            bounds, cuts = screen_tables(g)
+            out.status = torch.empty(1, dtype=torch.int32, device=g.device)
+            ops.scan_screen(g.rowptr, g.col, reverse_positions(g), screen[0], cuts, bounds, g.n_rows, columns, screen[1], out,
+                            out.status)
+        else:
+            ops.filter_scan(g.rowptr, g.col, reverse_positions(g), fixw, g.n_rows, columns, out, max_degree(g), window_splits(g))
     return out
+
+
+def rescore_exact(g: CSRGraph, w64: torch.Tensor, keys: torch.Tensor, bar):
+    """Exact scores of the screened survivors ``keys`` (v << 32 | u, u < v): float32 of the float64 sum of the exact weights
+    over the common neighbours -- bit-identical to eps_filter_scan's 2^-40 fixed-point sums.  -> (keys, scores) in another
+    order; candidates that do not exceed ``bar`` (a 1-element device tensor or None) get key -1 / score -inf, like an
+    untouched slot.
+    The survivors are pairs of hubs (under hubs-first labels u is the heavier one and recurs in hundreds of pairs), so they
+    are sorted by u and go through eps_rescore_runs: one LDS bitmap of N(u) per run of equal u, the short rows N(v) streamed
+    against it, the exact weights of the hits summed in float64 (exact, order-independent)."""
+    if keys.numel() == 0:
+        return keys, torch.zeros(0, dtype=torch.float32, device=keys.device)
+    by_u = torch.sort(((keys & 0xFFFFFFFF) << 32) | (keys >> 32)).values          # (u << 32 | v): runs of equal u
+    vals = ops.rescore_runs(g.rowptr, g.col, w64, g.n_rows, by_u)
+    keys = ((by_u & 0xFFFFFFFF) << 32) | (by_u >> 32)
+    if bar is not None:
+        keep = vals > bar
+        keys = torch.where(keep, keys, torch.full_like(keys, -1))
+        vals = torch.where(keep, vals, torch.full_like(vals, float("-inf")))
+    return keys, vals
 
 
 def total_half_paths(g: CSRGraph) -> int:
@@ -169,7 +247,7 @@ def sample_columns(g: CSRGraph, stride: int, rank: int = 0, world: int = 1):
 
 
 def estimate_bar(g: CSRGraph, fixw: torch.Tensor, k: int, stride: Optional[int] = None, safety: Optional[float] = None,
-                 rank: int = 0, world: int = 1):
+                 rank: int = 0, world: int = 1, screen=None):
     """Score bar (1-element float32 device tensor) that about ``safety * k`` directed candidates are expected to reach,
     from a scan of every ``stride``-th column of the heaviest-first order; ``None`` = no bar (keep everything).  The bar is
     INCLUSIVE of the sample's m-th best score (one float below it: the kernel keeps scores strictly above its threshold), so
@@ -184,8 +262,10 @@ def estimate_bar(g: CSRGraph, fixw: torch.Tensor, k: int, stride: Optional[int] 
     m = int(safety * k / 2 / stride) + 1                 # unordered pairs of the SAMPLE above the bar we aim at
     if m >= bound_all:                                   # (candidates <= half paths: the sample cannot hold that many)
         return None
-    res = _launch(g, fixw, mine, float("-inf"), min(2 * bound_mine + _CHUNK_SLACK, ops.SURVIVOR_SLOTS_MAX), scores_only=True)
-    # no bar: every candidate of the sample holds a slot, untouched slots are -inf (fewer than m candidates -> bar -inf)
+    slack = _CHUNK_SLACK if screen is None else _PIECE_SLACK
+    res = _launch(g, fixw, mine, float("-inf"), min(2 * bound_mine + slack, ops.SURVIVOR_SLOTS_MAX), scores_only=True, screen=screen)
+    # no bar: every candidate of the sample holds a slot, untouched slots are -inf (fewer than m candidates -> bar -inf).
+    # (one-pass kernel: screening scores, at most a few 2^-shift above the exact ones -- an estimate either way)
     kth = ops.kth_largest_dist(res.val, m, world)
     return torch.nextafter(kth, torch.full_like(kth, float("-inf")))
 
@@ -226,8 +306,8 @@ def select_topk_torch(keys: torch.Tensor, vals: torch.Tensor, k: int) -> Tuple[t
     return keys[o], vals[o]
 
 
-def _capacity(slots_wanted: int) -> int:
-    cap = int(slots_wanted) + _CHUNK_SLACK
+def _capacity(slots_wanted: int, slack: Optional[int] = None) -> int:
+    cap = int(slots_wanted) + (_CHUNK_SLACK if slack is None else slack)
     if cap > ops.SURVIVOR_SLOTS_MAX:
         raise ops._lib.EpsError(f"scan_topk: a survivor list of {cap} slots exceeds the {ops.SURVIVOR_SLOTS_MAX} a launch can "
                                 "address (slots are 32-bit positions); use the block-streaming filter path for this set")
@@ -260,28 +340,47 @@ def scan_topk(g: CSRGraph, node_w: torch.Tensor, k: int, rank: int = 0, world: i
     mine = shard_columns(g, rank, world)
     total_half = total_half_paths(g)
     k2 = (k + 1) // 2                    # the k-th best directed row belongs to the ceil(k/2)-th best unordered pair
+    screen, w64 = None, None
+    if one_pass_available(g):
+        fx32, shift, w64, usable = screen_weights(g0, g, perm, node_w)
+        if usable:
+            screen = (fx32, shift)
+    slack = _CHUNK_SLACK if screen is None else _PIECE_SLACK
     launches = 0
     bar = None
     if total_half > SMALL_SET and SAFETY * k < total_half:
-        bar = estimate_bar(g, fixw, k, rank=rank, world=world)
+        bar = estimate_bar(g, fixw, k, rank=rank, world=world, screen=screen)
         launches += 1
-    capacity = _capacity(2 * ((2 * total_half if bar is None else int(2 * SAFETY * k)) // world))
+    wanted = 2 * ((2 * total_half if bar is None else int(2 * SAFETY * k)) // world)
+    capacity = _capacity(wanted, slack)
     neg_inf = torch.full((1,), float("-inf"), device=dev)
     while True:
         if launches >= MAX_LAUNCHES:
             raise ops._lib.EpsError(f"scan_topk: no usable bar after {launches} launches (k = {k}, capacity {capacity})")
-        res = _launch(g, fixw, mine, float("-inf") if bar is None else bar, capacity, both=True)
+        res = _launch(g, fixw, mine, float("-inf") if bar is None else bar, capacity, both=True, screen=screen)
         launches += 1
+        l_keys, l_vals = res.key, res.val
+        status = None
+        if screen is not None:
+            # the one-pass kernel screens with upper bounds: its survivors are re-scored exactly (those that do not exceed the
+            # bar after all drop out), so from here on the list holds eps_filter_scan's scores bit for bit
+            c_keys, _, n_valid = ops.compact_at_least(l_keys, l_vals, None)
+            nv = int(n_valid.item())                                                      # (one word: sizes the re-scoring)
+            l_keys, l_vals = rescore_exact(g, w64, c_keys[:nv], bar)
+            status = res.status
         # the job-wide cut: the k2-th best survivor score over all ranks (-inf when fewer survived); untouched slots are -inf
-        cut = ops.kth_largest_dist(res.val, k2, world)
-        sel_k, sel_v, n_sel = ops.compact_at_least(res.key, res.val, cut)
-        st = torch.cat([res.rec[[1, 4]], n_sel, cut.view(torch.int32).to(torch.int64)])      # slots, candidates, selected, cut bits
+        cut = ops.kth_largest_dist(l_vals, k2, world)
+        sel_k, sel_v, n_sel = ops.compact_at_least(l_keys, l_vals, cut)
+        st = torch.cat([res.rec[[1, 4]], n_sel, cut.view(torch.int32).to(torch.int64),      # slots, candidates, selected, cut bits,
+                        (status if status is not None else torch.zeros(1, dtype=torch.int32, device=dev)).to(torch.int64)])
         if world > 1:
             from . import dist as epd
-            table = torch.stack(epd.all_gather_list(st)).tolist()                          # the ONE host read of the step
+            table = torch.stack(epd.all_gather_list(st)).tolist()                          # the host read of the step
         else:
             table = [st.tolist()]
         slots_r, ncand_r, nsel_r = [t[0] for t in table], [t[1] for t in table], [t[2] for t in table]
+        if any(t[4] for t in table):
+            raise ops._lib.EpsError("scan_topk: eps_scan_screen reported a full hash table (status %s)" % [t[4] for t in table])
         n_cand_all, n_sel_all = sum(ncand_r), sum(nsel_r)
         cut_is_inf = (table[0][3] & 0xFFFFFFFF) == 0xFF800000
         if any(sl > capacity for sl in slots_r):
@@ -290,14 +389,17 @@ def scan_topk(g: CSRGraph, node_w: torch.Tensor, k: int, rank: int = 0, world: i
             # room (a level of tied scores -- common-neighbour counts -- may hold far more pairs than K).
             if not cut_is_inf:
                 bar = torch.nextafter(cut, neg_inf)
-            capacity = _capacity(4 * (capacity - _CHUNK_SLACK))
+            wanted *= 4
+            capacity = _capacity(wanted, slack)
             continue
         if bar is not None and n_sel_all < min(k2, n_cand_all):
             # fewer than k above the bar: lower it (a quarter of the sample rank each time, then no bar at all)
-            bar = None if launches > 3 else estimate_bar(g, fixw, k, safety=SAFETY * 8 ** (launches - 1), rank=rank, world=world)
+            bar = None if launches > 3 else estimate_bar(g, fixw, k, safety=SAFETY * 8 ** (launches - 1), rank=rank, world=world,
+                                                         screen=screen)
             launches += 1
             if bar is None:
-                capacity = _capacity(2 * (2 * total_half // world))
+                wanted = 2 * (2 * total_half // world)
+                capacity = _capacity(wanted, slack)
             continue
         break
     keys, vals = _original_keys(sel_k[:nsel_r[rank]], perm), sel_v[:nsel_r[rank]]

@@ -200,6 +200,38 @@ int eps_filter_scan(const int64_t *rowptr, const int32_t *col, const int32_t *re
                     const int32_t *columns, int64_t n_columns, eps_survivors *out, void *workspace,
                     int64_t workspace_bytes, void *stream);
 
+/* ---- the same threshold scan in ONE pass over the two-hop paths (r03; csrc/scan_pieces.hip) --------------------------------
+ * Reports what eps_filter_scan reports -- key = (v << 32) | u, u < v, of every 2-hop non-edge of the given columns whose
+ * score can exceed out->threshold (filter.py:96-142 + :160-161 under --keep_top) -- but a column is scored in PIECES (runs of
+ * id windows of its endpoints) whose candidates each own a slot of an LDS table, so every path is read once and costs one
+ * table update.  The table holds 32-bit SCREENING sums of weights rounded UP to 2^-shift fixed point: an upper bound of the
+ * exact 2^-40 fixed-point score, so no candidate above the bar is lost and a few just below it pass as well; out->val holds
+ * the screening score (sum * 2^-shift).  The caller re-scores the survivors exactly (eps_pair_scores_f64 over the weights
+ * fixw * 2^-40 as doubles: exact and order-independent, bit-identical to eps_filter_scan's sums) and drops those <= the bar.
+ * Needs what eps_filter_scan needs (symmetric unit-valued adjacency, revpos) plus max degree < 65536 and weights >= 0.
+ *   eps_scan_windows      : M, the number of id windows per graph (32).
+ *   eps_scan_cuts         : cuts[w * M + k] = entries of row w with id < bounds[k + 1] (uint16; 16-byte aligned), for the
+ *                           caller's window boundaries bounds[0 .. M] (bounds[0] = 0, bounds[M] = n_nodes, non-decreasing;
+ *                           windows of equal stored-entry mass balance the pieces).  Per-graph table.
+ *   eps_scan_screen_weights: fx32[i] = max(1, ceil(fixw[i] / 2^(40 - shift))); *bad (device word, cleared by the call):
+ *                           bit 1 a negative weight, bit 2 a weight that does not fit 32 bits.  shift must keep every
+ *                           screening sum of the graph below 2^32 (the caller's score bound: eps_amd.scan.screen_shift).
+ *   eps_scan_screen       : out as for eps_filter_scan (slots are handed out in chunks of max(8192, 2 * table slots));
+ *                           variant 0: 512 threads / 8192-slot table (2 workgroups per CU), 1: 1024 / 16384 (1), 2: 256 / 4096 (4);
+ *                           *status (device word, cleared by the call): bit 2 = a table filled up (results invalid). */
+int32_t eps_scan_windows(void);
+/* eps_rescore_runs: exact scores of screened survivors.  keys = (u << 32) | v, sorted ascending (runs of equal u: the hubs
+ * recur); w64[i] = the exact weight of node i as a double (fixw[i] * 2^-40); out[i] = float32 of the exact float64 sum over the
+ * common neighbours of pair i -- bit-identical to eps_filter_scan's score.  Unit-valued adjacency. */
+int eps_rescore_runs(const int64_t *rowptr, const int32_t *col, const double *w64, int64_t n_nodes, const int64_t *keys,
+                     int64_t n, float *out, void *stream);
+int eps_scan_cuts(const int64_t *rowptr, const int32_t *col, int64_t n_nodes, const int32_t *bounds, uint16_t *cuts,
+                  void *stream);
+int eps_scan_screen_weights(const int64_t *fixw, int64_t n, int32_t shift, uint32_t *fx32, uint32_t *bad, void *stream);
+int eps_scan_screen(const int64_t *rowptr, const int32_t *col, const int32_t *revpos, const uint32_t *fx32,
+                    const uint16_t *cuts, const int32_t *bounds, int64_t n_nodes, int64_t nnz, const int32_t *columns,
+                    int64_t n_columns, int32_t shift, int32_t variant, eps_survivors *out, uint32_t *status, void *stream);
+
 /* ---- the candidate list of a block of columns of a graph WITHOUT stored values, on the scan kernel's structure ----------
  * Same results as eps_expand_count / eps_expand_fill above (filter.py:96-109: every 2-hop non-edge of columns
  * [v_lo, v_hi), column-major, u ascending; score = sum_w A[u,w] A[v,w] node_w[w] in 2^-40 fixed point, rounded once --

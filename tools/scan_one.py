@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""One main launch of eps_filter_scan over the whole ppa-like graph at a fixed bar -- the subject of rocprofv3 PMC passes."""
+"""One main launch of the production scan kernel over the whole ppa-like graph at a fixed bar -- the subject of rocprofv3 PMC
+passes.  KERNEL=pieces (eps_scan_screen, default) | twopass (eps_filter_scan, the r02 kernel); VARIANT, BAR, REPS, RELABEL."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -7,15 +8,23 @@ import torch, eps_amd
 from eps_amd import ops, scan, synth
 from eps_amd.heuristics import node_weight_table
 dev = torch.device("cuda:0")
-g = synth.ppa_like(seed=3, device=dev)
-if os.environ.get("RELABEL", "1") == "1":
-    g = g.degree_ordered()[0]               # hubs first: the labels bench.py's repeatedly scanned graph runs under
-w = node_weight_table(g, ops.W_AA)
-fixw = scan.fixed_weights(g, w)
+g0 = synth.ppa_like(seed=3, device=dev)
+w = node_weight_table(g0, ops.W_AA)
+g, perm = (g0.degree_ordered()[:2]) if os.environ.get("RELABEL", "1") == "1" else (g0, None)   # hubs first: bench.py's labels
+fixw = scan._scan_weights(g0, g, perm, w)
 order = scan.column_order(g)
-bar = float(os.environ.get("BAR", "3.25"))
+bar = float(os.environ.get("BAR", "2.378"))
+kernel = os.environ.get("KERNEL", "pieces")
+if kernel == "pieces":
+    fx32, shift, w64, usable = scan.screen_weights(g0, g, perm, w)
+    bounds, cuts = scan.screen_tables(g)
+    variant = int(os.environ.get("VARIANT", str(ops.SCAN_VARIANT)))
 for _ in range(int(os.environ.get("REPS", "1"))):
     res = ops.Survivors(64 << 20, bar, dev)
-    ops.filter_scan(g.rowptr, g.col, scan.reverse_positions(g), fixw, g.n_rows, order, res, scan.max_degree(g), scan.window_splits(g))
+    if kernel == "pieces":
+        status = torch.zeros(1, dtype=torch.int32, device=dev)
+        ops.scan_screen(g.rowptr, g.col, scan.reverse_positions(g), fx32, cuts, bounds, g.n_rows, order, shift, res, status, variant)
+    else:
+        ops.filter_scan(g.rowptr, g.col, scan.reverse_positions(g), fixw, g.n_rows, order, res, scan.max_degree(g), scan.window_splits(g))
 torch.cuda.synchronize()
-print("slots, unordered candidates:", res.counts(), "half paths:", int(scan.half_paths(g).sum()))
+print(kernel, "slots, unordered candidates:", res.counts(), "half paths:", scan.total_half_paths(g))
