@@ -91,8 +91,9 @@ __global__ __launch_bounds__(T) void scan_piece_kernel(sp_params p)
     uint32_t *r_len = r_seg + T + 1;         // [T + 1] entries of the segment
     uint32_t *r_fx = r_len + T + 1;          // [T + 1] screening weight of the row's node
     uint32_t *ustart = r_fx + T + 1;         // [T + 1] first 4-entry unit of the row in the round's unit numbering
-    uint32_t *ubits = ustart + T + 1 + ((T + 1) & 1 ? 1 : 0) + 2;      // [SP_UBITS / 32] bit s: a row starts at unit s (of the range)
-    ubits = (uint32_t *)(((uintptr_t)ubits + 15) & ~(uintptr_t)15);
+    // (offsets in words off `lds`, never through an integer cast: a pointer that loses the LDS address space turns its reads
+    //  into FLAT loads, which count on vmcnt and make every look-up drain the row loads in flight)
+    uint32_t *ubits = lds + ((2 * slots + 4 * (T + 1) + 3) & ~3);      // [SP_UBITS / 32] bit s: a row starts at unit s (of the range)
     uint16_t *wrank = (uint16_t *)(ubits + SP_UBITS / 32);               // [SP_UBITS / 32] rows that start before the word
     __shared__ uint32_t s_pw[SP_M];          // paths of the column per id window
     __shared__ int s_wtot[W], s_wtot2[W];
@@ -369,12 +370,17 @@ __global__ __launch_bounds__(T) void scan_piece_kernel(sp_params p)
                             }
 #pragma unroll
                             for (int q = 0; q < SP_G; ++q) {
+                                // (every LDS read unconditional, the range test a select: a read inside a branch makes hipcc
+                                //  drain the loads in flight at the branch)
                                 const int s = (int)ulo + (it0 + q) * T + tid;
-                                const int off = (s - (int)ustart[lo[q]]) * 4;
-                                const int left = s < (int)uhi ? (int)r_len[lo[q]] - off : 0;
-                                f[q].nvalid = left < 0 ? 0 : (left > 4 ? 4 : left);
+                                const uint32_t us = ustart[lo[q]], rl = r_len[lo[q]], rs = r_seg[lo[q]];
                                 f[q].fx = r_fx[lo[q]];
-                                const uint32_t at = s < (int)uhi ? r_seg[lo[q]] + (uint32_t)off : (p.col_bytes >> 2);
+                                const bool in = s < (int)uhi;
+                                const int off = (s - (int)us) * 4;
+                                int left = (int)rl - off;
+                                left = in ? left : 0;
+                                f[q].nvalid = left < 0 ? 0 : (left > 4 ? 4 : left);
+                                const uint32_t at = in ? rs + (uint32_t)off : (p.col_bytes >> 2);
                                 f[q].u4 = __builtin_amdgcn_raw_buffer_load_b128(col_rs, (int)(at * 4u), 0, 0);
                             }
                         };
@@ -425,13 +431,13 @@ __global__ __launch_bounds__(T) void scan_piece_kernel(sp_params p)
                             const int n_iter = (int)(uhi - ulo + T - 1) / T;      // uniform over the workgroup
                             sp_unit fa[SP_G], fb[SP_G];
                             fetch_group(0, fa);
+                            // (refills are unconditional -- a group past the end is empty units at an out-of-range address: no
+                            //  traffic -- because a conditional refill becomes a phi copy and hipcc then drains vmcnt before it)
                             for (int it0 = 0; it0 < n_iter; it0 += 2 * SP_G) {
-                                if (it0 + SP_G < n_iter) fetch_group(it0 + SP_G, fb);
+                                fetch_group(it0 + SP_G, fb);
                                 consume_group(fa);
-                                if (it0 + SP_G < n_iter) {
-                                    if (it0 + 2 * SP_G < n_iter) fetch_group(it0 + 2 * SP_G, fa);
-                                    consume_group(fb);
-                                }
+                                fetch_group(it0 + 2 * SP_G, fa);
+                                consume_group(fb);
                             }
                         }
                             if (uhi < (uint32_t)total) sp_barrier();       // (the next range rewrites the start bits)
@@ -570,9 +576,10 @@ __global__ void sp_screen_weights_kernel(const int64_t *__restrict__ fixw, int64
 // run against it -- one wave per pair, coalesced -- and sums the exact weights of the hits in float64.  The weights are
 // multiples of 2^-40 below 2^12, so the float64 sum is exact whatever the order: (float)sum is eps_filter_scan's score, bit
 // for bit (adamic_utils.py:13-25 / train_and_eval.py:195-216 / models.py:536-542 with the engine's fixed-point definition).
-#define RS_THREADS 512
+#define RS_THREADS 1024
 #define RS_CHUNK 256
 #define RS_BITS (1 << 20)       // ids per bitmap window: 128 KiB of LDS
+#define RS_SHORT 512            // rows up to this long go through rescore_short_kernel
 
 __global__ __launch_bounds__(RS_THREADS) void rescore_runs_kernel(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col,
                                                                  const double *__restrict__ w64, int32_t n_nodes,
@@ -619,6 +626,10 @@ __global__ __launch_bounds__(RS_THREADS) void rescore_runs_kernel(const int64_t 
             if (e > cn) e = cn;
             const int32_t u = (int32_t)(keys[c0 + s] >> 32);
             const int64_t ub = rowptr[u], ue = rowptr[u + 1];
+            if (ue - ub <= RS_SHORT) {        // a short row: its pairs are rescore_short_kernel's (no bitmap, no barriers)
+                s = e;
+                continue;
+            }
             for (int32_t wlo = 0; wlo < n_nodes; wlo += RS_BITS) {
                 // N(u) inside the id window -> bits (rows ascend; a plain scan of the row is cheap next to the pairs)
                 for (int64_t i = ub + tid; i < ue; i += RS_THREADS) {
@@ -626,15 +637,25 @@ __global__ __launch_bounds__(RS_THREADS) void rescore_runs_kernel(const int64_t 
                     if (x < (uint32_t)RS_BITS) atomicOr(&bm[x >> 5], 1u << (x & 31));
                 }
                 __syncthreads();
-                for (int pi = s + wib; pi < e; pi += W) {
-                    const int32_t v = (int32_t)(keys[c0 + pi] & 0xFFFFFFFFll);
-                    const int64_t vb = rowptr[v], ve = rowptr[v + 1];
+                // two pairs per wave, one per half: the rows N(v) are short (a few hundred entries), so half a wave with four
+                // loads in flight per lane covers a row in two or three trips, and twice as many pairs are in flight per CU
+                for (int p0 = s + 2 * wib; p0 < e; p0 += 2 * W) {
+                    const int pi = p0 + (lane >> 5);
+                    const bool live = pi < e;
+                    const int32_t v = live ? (int32_t)(keys[c0 + pi] & 0xFFFFFFFFll) : 0;
+                    const int64_t vb = live ? rowptr[v] : 0, ve = live ? rowptr[v + 1] : 0;
+                    const int hl = lane & 31;
                     double acc = 0.0;
-                    for (int64_t i0 = vb; i0 < ve; i0 += 256) {          // four independent row loads in flight per lane
+                    int64_t longest = ve - vb;
+                    {
+                        const int64_t o = __shfl_xor(longest, 32);
+                        longest = o > longest ? o : longest;
+                    }
+                    for (int64_t off = 0; off < longest; off += 128) {     // (uniform trip count over the wave)
                         int32_t wv[4];
 #pragma unroll
                         for (int b = 0; b < 4; ++b) {
-                            const int64_t i = i0 + b * 64 + lane;
+                            const int64_t i = vb + off + b * 32 + hl;
                             wv[b] = i < ve ? col[i] : -1;
                         }
                         double add[4];
@@ -647,8 +668,8 @@ __global__ __launch_bounds__(RS_THREADS) void rescore_runs_kernel(const int64_t 
                         acc += (add[0] + add[1]) + (add[2] + add[3]);
                     }
 #pragma unroll
-                    for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d);
-                    if (lane == 0) s_sum[pi] += acc;
+                    for (int d = 16; d >= 1; d >>= 1) acc += __shfl_xor(acc, d);
+                    if (hl == 0 && live) s_sum[pi] += acc;
                 }
                 __syncthreads();
                 for (int64_t i = ub + tid; i < ue; i += RS_THREADS) {
@@ -659,8 +680,55 @@ __global__ __launch_bounds__(RS_THREADS) void rescore_runs_kernel(const int64_t 
             }
             s = e;
         }
-        if (tid < cn) out[c0 + tid] = (float)s_sum[tid];
+        if (tid < cn) {
+            const int32_t u = (int32_t)(keys[c0 + tid] >> 32);
+            if (rowptr[u + 1] - rowptr[u] > RS_SHORT) out[c0 + tid] = (float)s_sum[tid];
+        }
         __syncthreads();
+    }
+}
+
+// The pairs whose u has at most RS_SHORT entries (most distinct u have few survivors each: a bitmap per run would cost three
+// workgroup barriers for a handful of pairs).  Under hubs-first labels v is the lighter endpoint, so both rows are short: a
+// wave stages the shorter row in its own 2 KiB of LDS (no barrier: wave-private), spreads the other row over its lanes and
+// looks every entry up by a binary search in LDS.  Same exact float64 sums.
+#define RSS_THREADS 256
+__global__ __launch_bounds__(RSS_THREADS) void rescore_short_kernel(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+                                                                  const double *__restrict__ w64, const int64_t *__restrict__ keys,
+                                                                  int64_t n, float *__restrict__ out)
+{
+    __shared__ int32_t s_stage[RSS_THREADS / 64][RS_SHORT];
+    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+    int32_t *stage = s_stage[wib];
+    const int64_t wave = (int64_t)blockIdx.x * (RSS_THREADS / 64) + wib;
+    const int64_t n_waves = (int64_t)gridDim.x * (RSS_THREADS / 64);
+    for (int64_t pi = wave; pi < n; pi += n_waves) {
+        const int64_t key = keys[pi];
+        const int32_t u = (int32_t)(key >> 32), v = (int32_t)(key & 0xFFFFFFFFll);
+        const int64_t ub = rowptr[u], ue = rowptr[u + 1];
+        if (ue - ub > RS_SHORT) continue;                      // rescore_runs_kernel's
+        const int64_t vb = rowptr[v], ve = rowptr[v + 1];
+        const bool u_short = ue - ub <= ve - vb;
+        const int64_t sb = u_short ? ub : vb, se = u_short ? ue : ve;       // staged (the shorter: <= RS_SHORT entries)
+        const int64_t lb = u_short ? vb : ub, le = u_short ? ve : ue;       // spread over the lanes
+        const int ns = (int)(se - sb);
+        int pow2 = 1;
+        while (pow2 < ns) pow2 <<= 1;
+        for (int i = lane; i < pow2; i += 64) stage[i] = i < ns ? col[sb + i] : 0x7fffffff;
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        double acc = 0.0;
+        for (int64_t i0 = lb; i0 < le; i0 += 64) {
+            const int64_t i = i0 + lane;
+            const int32_t w = i < le ? col[i] : -1;
+            int lo = 0;                                           // last position with stage[pos] <= w
+            for (int step = pow2 >> 1; step >= 1; step >>= 1)
+                if (stage[lo + step] <= w) lo += step;
+            if (w >= 0 && ns > 0 && stage[lo] == w) acc += w64[w];
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d);
+        if (lane == 0) out[pi] = (float)acc;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (the next pair overwrites the staged row)
     }
 }
 
@@ -687,6 +755,12 @@ extern "C" int eps_rescore_runs(const int64_t *rowptr, const int32_t *col, const
     if (blocks > cap) blocks = cap;
     hipLaunchKernelGGL(rescore_runs_kernel, dim3((unsigned)blocks), dim3(RS_THREADS), lds, s, rowptr, col, w64, (int32_t)n_nodes, keys,
                        n, out, counter);
+    {
+        int64_t sb = (n + RSS_THREADS / 64 - 1) / (RSS_THREADS / 64);
+        const int64_t scap = (int64_t)eps_num_cus() * 8;
+        if (sb > scap) sb = scap;
+        hipLaunchKernelGGL(rescore_short_kernel, dim3((unsigned)sb), dim3(RSS_THREADS), 0, s, rowptr, col, w64, keys, n, out);
+    }
     EPS_CHECK_LAUNCH("eps_rescore_runs");
     return EPS_OK;
 }

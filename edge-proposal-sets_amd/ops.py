@@ -521,7 +521,7 @@ def rescore_runs(rowptr, col, w64: torch.Tensor, n_nodes: int, keys_by_u: torch.
     return out
 
 
-SCAN_VARIANT = 2          # workgroup / table geometry of eps_scan_screen (see include/eps_abi.h); tools/ set it for A/B runs
+SCAN_VARIANT = 2          # default workgroup / table geometry of eps_scan_screen (include/eps_abi.h); scan.screen_variant picks per graph
 
 
 def scan_screen(rowptr, col, revpos, fx32, cuts, bounds, n_nodes: int, columns: torch.Tensor, shift: int, out: "Survivors",

@@ -177,9 +177,28 @@ def screen_weights(g0: CSRGraph, g: CSRGraph, perm, node_w: torch.Tensor):
     return g0.weight_cached("screen_weights" if perm is None else "screen_weights_relabelled", node_w, build)
 
 
+def screen_variant(g: CSRGraph):
+    """Geometry of eps_scan_screen for this graph, or None when the piece kernel does not suit it (-> eps_filter_scan).
+    A column's paths spread evenly over the M id windows (they have equal stored-entry mass), and a window that holds more
+    paths than a hash piece takes is re-walked in hash-partitioned passes -- so the heaviest column decides: its paths / M
+    must fit a piece.  Smaller tables mean more workgroups per CU (31 ms vs 35 / 46 ms on the ppa-like graph under
+    hubs-first labels, whose heaviest column has 63 k half paths); a graph scanned as labelled (columns of millions of
+    paths) stays on the two-pass kernel.  Rows must be shorter than 2^16 (the cut table is uint16)."""
+    if "screen_variant" not in g._cache:
+        v = None
+        if ONE_PASS and 0 < max_degree(g) < 1 << 16:
+            hp_max = int(half_paths(g).max().item()) if g.n_rows else 0
+            m = ops.scan_windows()
+            for variant, piece_paths in ((2, 2048), (0, 4096), (1, 8192)):
+                if hp_max <= piece_paths * m:
+                    v = variant
+                    break
+        g._cache["screen_variant"] = v
+    return g._cache["screen_variant"]
+
+
 def one_pass_available(g: CSRGraph) -> bool:
-    """The piece kernel takes what eps_filter_scan takes, with rows shorter than 2^16 (its cut table is uint16)."""
-    return ONE_PASS and 0 < max_degree(g) < 1 << 16
+    return screen_variant(g) is not None
 
 
 def _launch(g, fixw, columns, threshold, capacity, scores_only: bool = False, both: bool = False, screen=None) -> ops.Survivors:
@@ -190,7 +209,7 @@ def _launch(g, fixw, columns, threshold, capacity, scores_only: bool = False, bo
             bounds, cuts = screen_tables(g)
             out.status = torch.empty(1, dtype=torch.int32, device=g.device)
             ops.scan_screen(g.rowptr, g.col, reverse_positions(g), screen[0], cuts, bounds, g.n_rows, columns, screen[1], out,
-                            out.status)
+                            out.status, screen_variant(g))
         else:
             ops.filter_scan(g.rowptr, g.col, reverse_positions(g), fixw, g.n_rows, columns, out, max_degree(g), window_splits(g))
     return out
@@ -364,7 +383,12 @@ def scan_topk(g: CSRGraph, node_w: torch.Tensor, k: int, rank: int = 0, world: i
         if screen is not None:
             # the one-pass kernel screens with upper bounds: its survivors are re-scored exactly (those that do not exceed the
             # bar after all drop out), so from here on the list holds eps_filter_scan's scores bit for bit
-            c_keys, _, n_valid = ops.compact_at_least(l_keys, l_vals, None)
+            # Not all of them need it: a screening score is at most eps above the exact one (one rounding unit per term), so
+            # the k2 best exact scores all have screening scores >= (k2-th best screening score, job-wide) - eps -- only
+            # those are re-scored (about k2 of the SAFETY x k2 survivors).
+            cut_a = ops.kth_largest_dist(l_vals, k2, world)
+            eps = max_degree(g) * 2.0 ** -screen[1]
+            c_keys, _, n_valid = ops.compact_at_least(l_keys, l_vals, cut_a - (eps + cut_a.abs() * 4e-6))
             nv = int(n_valid.item())                                                      # (one word: sizes the re-scoring)
             l_keys, l_vals = rescore_exact(g, w64, c_keys[:nv], bar)
             status = res.status
