@@ -286,6 +286,7 @@ def parse_args(argv=None):
     ap.add_argument("--keep_top", type=int, default=KEEP_TOP)
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-legs", action="store_true", help="skip the secondary kernel legs")
+    ap.add_argument("--no-config-legs", action="store_true", help="skip the per-config end-to-end legs (bench_configs.py)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (tests on a 1-GPU box: gloo)")
     ap.add_argument("--one-device", action="store_true", help="every rank on cuda:0 (tests on a 1-GPU box, with --backend gloo)")
     ap.add_argument("--nodes", type=int, default=576_289, help="graph size (tests use a small one)")
@@ -497,6 +498,10 @@ def main():
     if rank == 0 and world == 1 and not args.no_legs:
         line["legs"] = {"pair_intersection": leg_pair_kernel(torch, g, w, ops, candidates)}
         line["legs"].update(leg_gnn(torch, g, ops))
+        if not args.no_config_legs:
+            import bench_configs
+            torch.cuda.empty_cache()
+            line["legs"].update(bench_configs.run_all(torch, args.keep_top))
     if rank == 0 and world == 1 and not args.no_cpu:
         line["cpu_baseline"] = cpu_baseline(torch, g, w, ops, candidates, out["r"][0], out["r"][1])
         line["cpu_baseline"]["gpu_over_cpu_1core"] = line["value"] / line["cpu_baseline"]["value"]

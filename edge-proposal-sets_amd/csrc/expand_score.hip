@@ -404,9 +404,13 @@ __global__ __launch_bounds__(EX_THREADS) void expand_kernel(
             if (n_tiles > 0)
                 for_each_path<WINDOWED>(rowptr, col, vcol, dv, wib, lane, s_long, &s_nlong, win_lo, win_hi,
                                         [&](int k, int64_t wb, int base_e, v4i u4, int nvalid) {
-                    float vw = 1.0f;                          // A[v,w] * node_w[w]: the A_ entry (adamic_utils.py:17)
+                    // A path's term is (A[u,w] * A[v,w]) * node_w[w] in float32.  adamic_utils.py:17-23 associates it as
+                    // A[u,w] * (A[v,w] * mult[w]) (one ulp apart at most, far inside the 1e-5 gate); this association is
+                    // symmetric in (u, v), so a pair's two orientations carry the same bits and the symmetric-half scan
+                    // (scan_pieces.hip) reproduces them.  Unit-valued graphs: the term is node_w[w] either way.
+                    float vw = 1.0f, nw = 1.0f;
                     if (HAS_VAL) vw = val[vb + k];
-                    if (HAS_W) vw = vw * node_w[vcol[k]];
+                    if (HAS_W) nw = node_w[vcol[k]];
                     uint32_t u[4], word[4], rank[4], ri[4], pos[4];
                     bool cand[4];
 #pragma unroll
@@ -428,8 +432,8 @@ __global__ __launch_bounds__(EX_THREADS) void expand_kernel(
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         if (!cand[e]) continue;
-                        float term = vw;                      // A[u,w] * (A[v,w] * node_w[w]), float32 like the reference
-                        if (HAS_VAL) term = val[wb + base_e + e] * vw;
+                        float term = nw;
+                        if (HAS_VAL) term = (val[wb + base_e + e] * vw) * nw;
                         my_scratch[pos[e]] = make_uint2(rank[e] - (ri[e] & 0xFFFFFu), __builtin_bit_cast(uint32_t, term));
                     }
                 });

@@ -39,7 +39,10 @@ struct sp_params {
     const int64_t *rowptr;
     const int32_t *col;
     const int32_t *revpos;
-    const uint32_t *fx32;       // screening weight per node (>= 1)
+    const uint32_t *fx32;       // screening weight per node (>= 1); weighted graphs: unused
+    const float *val;           // stored values A[.,.] (weighted graphs: HV) or NULL
+    const float *node_w;        // float node weights (weighted graphs): a path's term is (A[u,w] * A[v,w]) * node_w[w]
+    float up;                   // weighted graphs: 2^shift * (1 + 2^-20), the scale of the per-row factor
     const uint16_t *cuts;       // [n_nodes][SP_M]
     const int32_t *bounds;      // [SP_M + 1]
     const int32_t *columns;
@@ -73,13 +76,20 @@ __device__ __forceinline__ uint32_t sp_wave_sum(uint32_t x)
     return (uint32_t)__builtin_amdgcn_readlane(sp_wave_incl_scan((int)x), 63);
 }
 
+typedef float sp_v4f __attribute__((ext_vector_type(4)));
+
 struct sp_unit {
     sp_v4i u4;
+    sp_v4f a4;                  // weighted graphs: the entries' stored values
     uint32_t fx;
     int nvalid;
 };
 
-template <int T>
+// HV: the adjacency has stored values (collab: rank.py:32-35 keeps the summed multi-edge weights).  A path's term is then
+// (A[u,w] * A[v,w]) * node_w[w] -- symmetric in (u, v) like the unit-valued one, so the half scheme holds -- and its
+// screening weight is formed per path: ceil(A[u,w] * rowf) + 1 with rowf = A[v,w] * node_w[w] * 2^shift * (1 + 2^-20) per
+// row (float32 products are within 2^-22 of the exact one: still an upper bound of the term's exact fixed-point value).
+template <int T, bool HV>
 __global__ __launch_bounds__(T) void scan_piece_kernel(sp_params p)
 {
     constexpr int W = T / 64;
@@ -112,6 +122,8 @@ __global__ __launch_bounds__(T) void scan_piece_kernel(sp_params p)
     float *__restrict__ out_val = p.out->val;
     const uint32_t *__restrict__ rowptr_lo = (const uint32_t *)p.rowptr;     // nnz < 2^30: the low words suffice
     const __amdgpu_buffer_rsrc_t col_rs = __builtin_amdgcn_make_buffer_rsrc((void *)p.col, 0, p.col_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t val_rs = __builtin_amdgcn_make_buffer_rsrc((void *)(HV ? (const void *)p.val : (const void *)p.col), 0,
+                                                                            p.col_bytes, 0x00020000);
     // the bar in the table's domain.  filter_scan.hip keeps a candidate when its 2^-40 fixed-point sum a satisfies
     // float(a * 2^-40) > threshold, i.e. a >= thr_fix (monotone: found by bisection); a screening sum s >= a / 2^(40 - shift),
     // so s >= floor(thr_fix / 2^(40 - shift)) holds for every such candidate.  Any bar <= 0 (or -inf): every candidate.
@@ -202,7 +214,7 @@ __global__ __launch_bounds__(T) void scan_piece_kernel(sp_params p)
                 }
                 if (single && tid < dv) {
                     my_base = rowptr_lo[2 * (size_t)my_w];
-                    my_fx = p.fx32[my_w];
+                    my_fx = HV ? __builtin_bit_cast(uint32_t, (p.val[vb + tid] * p.node_w[my_w]) * p.up) : p.fx32[my_w];
                 }
             }
             sp_barrier();
@@ -288,7 +300,7 @@ __global__ __launch_bounds__(T) void scan_piece_kernel(sp_params p)
                                 w = (uint32_t)vcol[j];
                                 rev = (uint32_t)vrev[j];
                                 base = rowptr_lo[2 * (size_t)w];
-                                fx = p.fx32[w];
+                                fx = HV ? __builtin_bit_cast(uint32_t, (p.val[vb + j] * p.node_w[w]) * p.up) : p.fx32[w];
                             }
                             const uint16_t *crow = p.cuts + (size_t)w * SP_M;
                             uint32_t b = crow[k1 - 1];
@@ -382,7 +394,12 @@ __global__ __launch_bounds__(T) void scan_piece_kernel(sp_params p)
                                 f[q].nvalid = left < 0 ? 0 : (left > 4 ? 4 : left);
                                 const uint32_t at = in ? rs + (uint32_t)off : (p.col_bytes >> 2);
                                 f[q].u4 = __builtin_amdgcn_raw_buffer_load_b128(col_rs, (int)(at * 4u), 0, 0);
+                                if (HV) f[q].a4 = __builtin_bit_cast(sp_v4f, __builtin_amdgcn_raw_buffer_load_b128(val_rs, (int)(at * 4u), 0, 0));
                             }
+                        };
+                        auto path_fx = [&](const sp_unit &f, int e) -> uint32_t {
+                            if (!HV) return f.fx;
+                            return (uint32_t)__builtin_ceilf(f.a4[e] * __builtin_bit_cast(float, f.fx)) + 1u;
                         };
                         auto consume_group = [&](const sp_unit (&f)[SP_G]) {
                             if (direct) {
@@ -390,7 +407,7 @@ __global__ __launch_bounds__(T) void scan_piece_kernel(sp_params p)
                                 for (int q = 0; q < SP_G; ++q)
 #pragma unroll
                                     for (int e = 0; e < 4; ++e)
-                                        if (e < f[q].nvalid) atomicAdd(&lds[(uint32_t)(f[q].u4[e] - lo_id)], f[q].fx);
+                                        if (e < f[q].nvalid) atomicAdd(&lds[(uint32_t)(f[q].u4[e] - lo_id)], path_fx(f[q], e));
                             } else {
                                 constexpr int E = 4 * SP_G;
                                 uint32_t key[E], h[E], st[E];
@@ -414,7 +431,7 @@ __global__ __launch_bounds__(T) void scan_piece_kernel(sp_params p)
                                     for (int i = 0; i < E; ++i)
                                         if (pend & (1u << i)) {
                                             if (old[i] == SP_EMPTY || old[i] == key[i]) {
-                                                atomicAdd(&tval[h[i]], f[i >> 2].fx);
+                                                atomicAdd(&tval[h[i]], path_fx(f[i >> 2], i & 3));
                                                 pend &= ~(1u << i);
                                             } else {
                                                 h[i] = (h[i] + st[i]) & mask;
@@ -582,13 +599,13 @@ __global__ void sp_screen_weights_kernel(const int64_t *__restrict__ fixw, int64
 #define RS_SHORT 512            // rows up to this long go through rescore_short_kernel
 
 __global__ __launch_bounds__(RS_THREADS) void rescore_runs_kernel(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col,
-                                                                 const double *__restrict__ w64, int32_t n_nodes,
+                                                                 const int64_t *__restrict__ fixw, int32_t n_nodes,
                                                                  const int64_t *__restrict__ keys, int64_t n,
                                                                  float *__restrict__ out, unsigned int *__restrict__ next_chunk)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t bm[];          // RS_BITS / 32 words
     __shared__ unsigned long long s_starts[RS_CHUNK / 64];
-    __shared__ double s_sum[RS_CHUNK];
+    __shared__ long long s_sum[RS_CHUNK];
     __shared__ unsigned int s_c;
     const int tid = threadIdx.x, lane = tid & 63, wib = tid >> 6;
     constexpr int W = RS_THREADS / 64;
@@ -604,7 +621,7 @@ __global__ __launch_bounds__(RS_THREADS) void rescore_runs_kernel(const int64_t 
         const int cn = (int)(n - c0 < RS_CHUNK ? n - c0 : RS_CHUNK);
         // run starts inside the chunk
         if (tid < RS_CHUNK) {
-            s_sum[tid] = 0.0;
+            s_sum[tid] = 0ll;
             bool start = false;
             if (tid < cn) start = tid == 0 || (keys[c0 + tid] >> 32) != (keys[c0 + tid - 1] >> 32);
             const unsigned long long m = __ballot(start);
@@ -645,7 +662,7 @@ __global__ __launch_bounds__(RS_THREADS) void rescore_runs_kernel(const int64_t 
                     const int32_t v = live ? (int32_t)(keys[c0 + pi] & 0xFFFFFFFFll) : 0;
                     const int64_t vb = live ? rowptr[v] : 0, ve = live ? rowptr[v + 1] : 0;
                     const int hl = lane & 31;
-                    double acc = 0.0;
+                    long long acc = 0ll;
                     int64_t longest = ve - vb;
                     {
                         const int64_t o = __shfl_xor(longest, 32);
@@ -658,12 +675,12 @@ __global__ __launch_bounds__(RS_THREADS) void rescore_runs_kernel(const int64_t 
                             const int64_t i = vb + off + b * 32 + hl;
                             wv[b] = i < ve ? col[i] : -1;
                         }
-                        double add[4];
+                        long long add[4];
 #pragma unroll
                         for (int b = 0; b < 4; ++b) {
                             const uint32_t x = (uint32_t)(wv[b] - wlo);
                             const bool hit = wv[b] >= 0 && x < (uint32_t)RS_BITS && ((bm[x >> 5] >> (x & 31)) & 1u);
-                            add[b] = hit ? w64[wv[b]] : 0.0;
+                            add[b] = hit ? (long long)fixw[wv[b]] : 0ll;
                         }
                         acc += (add[0] + add[1]) + (add[2] + add[3]);
                     }
@@ -682,7 +699,7 @@ __global__ __launch_bounds__(RS_THREADS) void rescore_runs_kernel(const int64_t 
         }
         if (tid < cn) {
             const int32_t u = (int32_t)(keys[c0 + tid] >> 32);
-            if (rowptr[u + 1] - rowptr[u] > RS_SHORT) out[c0 + tid] = (float)s_sum[tid];
+            if (rowptr[u + 1] - rowptr[u] > RS_SHORT) out[c0 + tid] = (float)((double)s_sum[tid] * (1.0 / (double)(1ll << 40)));
         }
         __syncthreads();
     }
@@ -694,7 +711,7 @@ __global__ __launch_bounds__(RS_THREADS) void rescore_runs_kernel(const int64_t 
 // looks every entry up by a binary search in LDS.  Same exact float64 sums.
 #define RSS_THREADS 256
 __global__ __launch_bounds__(RSS_THREADS) void rescore_short_kernel(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col,
-                                                                  const double *__restrict__ w64, const int64_t *__restrict__ keys,
+                                                                  const int64_t *__restrict__ fixw, const int64_t *__restrict__ keys,
                                                                   int64_t n, float *__restrict__ out)
 {
     __shared__ int32_t s_stage[RSS_THREADS / 64][RS_SHORT];
@@ -716,30 +733,65 @@ __global__ __launch_bounds__(RSS_THREADS) void rescore_short_kernel(const int64_
         while (pow2 < ns) pow2 <<= 1;
         for (int i = lane; i < pow2; i += 64) stage[i] = i < ns ? col[sb + i] : 0x7fffffff;
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        double acc = 0.0;
+        long long acc = 0ll;
         for (int64_t i0 = lb; i0 < le; i0 += 64) {
             const int64_t i = i0 + lane;
             const int32_t w = i < le ? col[i] : -1;
             int lo = 0;                                           // last position with stage[pos] <= w
             for (int step = pow2 >> 1; step >= 1; step >>= 1)
                 if (stage[lo + step] <= w) lo += step;
-            if (w >= 0 && ns > 0 && stage[lo] == w) acc += w64[w];
+            if (w >= 0 && ns > 0 && stage[lo] == w) acc += (long long)fixw[w];
         }
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d);
-        if (lane == 0) out[pi] = (float)acc;
+        if (lane == 0) out[pi] = (float)((double)acc * (1.0 / (double)(1ll << 40)));
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (the next pair overwrites the staged row)
     }
 }
 
-// keys: (u << 32) | v sorted ascending (runs of equal u); w64[i] = exact weight of node i (multiples of 2^-40); out[i] = score of
-// pair i as float32 of the exact sum.  Unit-valued adjacency.
-extern "C" int eps_rescore_runs(const int64_t *rowptr, const int32_t *col, const double *w64, int64_t n_nodes,
+// A weighted pair: term = (A[u,w] * A[v,w]) * node_w[w] in float32 (the association eps_expand_fill uses: symmetric in u, v),
+// converted to 2^-40 fixed point and summed in int64.  One wave per pair: the shorter row spread over the lanes, each entry
+// looked up in the longer row by a binary search in global memory (the lists of weighted graphs -- collab -- are short).
+__global__ __launch_bounds__(256) void rescore_weighted_kernel(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+                                                              const float *__restrict__ val, const float *__restrict__ node_w,
+                                                              const int64_t *__restrict__ keys, int64_t n, float *__restrict__ out)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t pi = wave; pi < n; pi += n_waves) {
+        const int64_t key = keys[pi];
+        const int32_t u = (int32_t)(key >> 32), v = (int32_t)(key & 0xFFFFFFFFll);
+        const int64_t ub = rowptr[u], ue = rowptr[u + 1], vb = rowptr[v], ve = rowptr[v + 1];
+        const bool u_short = ue - ub <= ve - vb;
+        const int64_t sb = u_short ? ub : vb, se = u_short ? ue : ve, lb = u_short ? vb : ub, le = u_short ? ve : ue;
+        long long acc = 0ll;
+        for (int64_t i = sb + lane; i < se; i += 64) {
+            const int32_t w = col[i];
+            int64_t lo = lb, hi = le;
+            while (lo < hi) {
+                const int64_t mid = (lo + hi) >> 1;
+                if (col[mid] < w) lo = mid + 1; else hi = mid;
+            }
+            if (lo < le && col[lo] == w) {
+                const float term = (val[i] * val[lo]) * node_w[w];
+                acc += __double2ll_rn((double)term * (double)(1ll << 40));
+            }
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d);
+        if (lane == 0) out[pi] = (float)((double)acc * (1.0 / (double)(1ll << 40)));
+    }
+}
+
+// keys: (u << 32) | v sorted ascending (runs of equal u); fixw[i] = the 2^-40 fixed-point weight of node i (eps_fixed_weights);
+// out[i] = score of pair i as float32 of the exact sum.  Unit-valued adjacency.
+extern "C" int eps_rescore_runs(const int64_t *rowptr, const int32_t *col, const int64_t *fixw, int64_t n_nodes,
                                 const int64_t *keys, int64_t n, float *out, void *stream)
 {
     EPS_REQUIRE(n >= 0 && n_nodes >= 0 && n_nodes < (1ll << 31), "eps_rescore_runs: bad size");
     if (n == 0) return EPS_OK;
-    EPS_REQUIRE(rowptr && col && w64 && keys && out, "eps_rescore_runs: null pointer");
+    EPS_REQUIRE(rowptr && col && fixw && keys && out, "eps_rescore_runs: null pointer");
     hipStream_t s = (hipStream_t)stream;
     unsigned int *counter = nullptr;
     const int rc = eps_take_counter(&counter, s, "eps_rescore_runs");
@@ -753,15 +805,31 @@ extern "C" int eps_rescore_runs(const int64_t *rowptr, const int32_t *col, const
     const int64_t per_cu = (160 * 1024 - 2048) / (int64_t)(lds + 2560);            // workgroups the LDS lets a CU hold
     const int64_t cap = (int64_t)eps_num_cus() * (per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu));
     if (blocks > cap) blocks = cap;
-    hipLaunchKernelGGL(rescore_runs_kernel, dim3((unsigned)blocks), dim3(RS_THREADS), lds, s, rowptr, col, w64, (int32_t)n_nodes, keys,
+    hipLaunchKernelGGL(rescore_runs_kernel, dim3((unsigned)blocks), dim3(RS_THREADS), lds, s, rowptr, col, fixw, (int32_t)n_nodes, keys,
                        n, out, counter);
     {
         int64_t sb = (n + RSS_THREADS / 64 - 1) / (RSS_THREADS / 64);
         const int64_t scap = (int64_t)eps_num_cus() * 8;
         if (sb > scap) sb = scap;
-        hipLaunchKernelGGL(rescore_short_kernel, dim3((unsigned)sb), dim3(RSS_THREADS), 0, s, rowptr, col, w64, keys, n, out);
+        hipLaunchKernelGGL(rescore_short_kernel, dim3((unsigned)sb), dim3(RSS_THREADS), 0, s, rowptr, col, fixw, keys, n, out);
     }
     EPS_CHECK_LAUNCH("eps_rescore_runs");
+    return EPS_OK;
+}
+
+// The same for an adjacency with stored values (any order of the keys).
+extern "C" int eps_rescore_weighted(const int64_t *rowptr, const int32_t *col, const float *val, const float *node_w,
+                                    int64_t n_nodes, const int64_t *keys, int64_t n, float *out, void *stream)
+{
+    EPS_REQUIRE(n >= 0 && n_nodes >= 0, "eps_rescore_weighted: bad size");
+    if (n == 0) return EPS_OK;
+    EPS_REQUIRE(rowptr && col && val && node_w && keys && out, "eps_rescore_weighted: null pointer");
+    int64_t blocks = (n + 3) / 4;
+    const int64_t cap = (int64_t)eps_num_cus() * 8;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(rescore_weighted_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, rowptr, col, val, node_w, keys,
+                       n, out);
+    EPS_CHECK_LAUNCH("eps_rescore_weighted");
     return EPS_OK;
 }
 
@@ -805,10 +873,36 @@ extern "C" int eps_scan_screen_weights(const int64_t *fixw, int64_t n, int32_t s
 // ---- launch -------------------------------------------------------------------------------------------------------------
 // variant: 0 = 512 threads, 8192-slot table (two workgroups per CU); 1 = 1024 threads, 16384 slots (one per CU);
 //          2 = 256 threads, 4096 slots (four per CU)
+static int sp_launch(const int64_t *rowptr, const int32_t *col, const float *val, const int32_t *revpos, const uint32_t *fx32,
+                     const float *node_w, const uint16_t *cuts, const int32_t *bounds, int64_t n_nodes, int64_t nnz,
+                     const int32_t *columns, int64_t n_columns, int32_t shift, int32_t variant, eps_survivors *out,
+                     uint32_t *status, void *stream);
+
 extern "C" int eps_scan_screen(const int64_t *rowptr, const int32_t *col, const int32_t *revpos, const uint32_t *fx32,
                                const uint16_t *cuts, const int32_t *bounds, int64_t n_nodes, int64_t nnz,
                                const int32_t *columns, int64_t n_columns, int32_t shift, int32_t variant,
                                eps_survivors *out, uint32_t *status, void *stream)
+{
+    EPS_REQUIRE(n_columns == 0 || n_nodes == 0 || fx32, "eps_scan_screen: null pointer");
+    return sp_launch(rowptr, col, nullptr, revpos, fx32, nullptr, cuts, bounds, n_nodes, nnz, columns, n_columns, shift, variant, out,
+                     status, stream);
+}
+
+// The same scan on a SYMMETRIC adjacency with stored values (val[e] == val[mirror of e]); node_w = the float node weights.
+extern "C" int eps_scan_screen_weighted(const int64_t *rowptr, const int32_t *col, const float *val, const int32_t *revpos,
+                                        const float *node_w, const uint16_t *cuts, const int32_t *bounds, int64_t n_nodes,
+                                        int64_t nnz, const int32_t *columns, int64_t n_columns, int32_t shift, int32_t variant,
+                                        eps_survivors *out, uint32_t *status, void *stream)
+{
+    EPS_REQUIRE(n_columns == 0 || n_nodes == 0 || (val && node_w), "eps_scan_screen_weighted: null pointer");
+    return sp_launch(rowptr, col, val, revpos, nullptr, node_w, cuts, bounds, n_nodes, nnz, columns, n_columns, shift, variant, out,
+                     status, stream);
+}
+
+static int sp_launch(const int64_t *rowptr, const int32_t *col, const float *val, const int32_t *revpos, const uint32_t *fx32,
+                     const float *node_w, const uint16_t *cuts, const int32_t *bounds, int64_t n_nodes, int64_t nnz,
+                     const int32_t *columns, int64_t n_columns, int32_t shift, int32_t variant, eps_survivors *out,
+                     uint32_t *status, void *stream)
 {
     EPS_REQUIRE(n_nodes >= 0 && n_columns >= 0 && nnz >= 0, "eps_scan_screen: negative size");
     EPS_REQUIRE(status, "eps_scan_screen: null pointer");
@@ -818,7 +912,7 @@ extern "C" int eps_scan_screen(const int64_t *rowptr, const int32_t *col, const 
         return EPS_ELAUNCH;
     }
     if (n_columns == 0 || n_nodes == 0) return EPS_OK;
-    EPS_REQUIRE(rowptr && col && revpos && fx32 && cuts && bounds && columns && out, "eps_scan_screen: null pointer");
+    EPS_REQUIRE(rowptr && col && revpos && cuts && bounds && columns && out, "eps_scan_screen: null pointer");
     EPS_REQUIRE(nnz < (1ll << 30), "eps_scan_screen: col[] is addressed with 32-bit byte offsets (nnz < 2^30)");
     EPS_REQUIRE(n_nodes < (1ll << 31) && n_columns < (1ll << 31), "eps_scan_screen: too many nodes / columns");
     EPS_REQUIRE(shift >= 0 && shift <= 40 && variant >= 0 && variant <= 2, "eps_scan_screen: bad shift / variant");
@@ -834,6 +928,9 @@ extern "C" int eps_scan_screen(const int64_t *rowptr, const int32_t *col, const 
     p.col = col;
     p.revpos = revpos;
     p.fx32 = fx32;
+    p.val = val;
+    p.node_w = node_w;
+    p.up = ldexpf(1.0f, shift) * (1.0f + ldexpf(1.0f, -20));
     p.cuts = cuts;
     p.bounds = bounds;
     p.columns = columns;
@@ -850,7 +947,9 @@ extern "C" int eps_scan_screen(const int64_t *rowptr, const int32_t *col, const 
     int64_t blocks = (int64_t)eps_num_cus() * per_cu[variant];
     if (blocks > n_columns) blocks = n_columns;
     const size_t lds = ((size_t)(2 << bits) + 4 * (size_t)(T + 1) + 8) * 4 + (SP_UBITS / 32) * 6 + 32;
-    void (*kern)(sp_params) = variant == 0 ? scan_piece_kernel<512> : variant == 1 ? scan_piece_kernel<1024> : scan_piece_kernel<256>;
+    void (*kern)(sp_params) =
+        val ? (variant == 0 ? scan_piece_kernel<512, true> : variant == 1 ? scan_piece_kernel<1024, true> : scan_piece_kernel<256, true>)
+            : (variant == 0 ? scan_piece_kernel<512, false> : variant == 1 ? scan_piece_kernel<1024, false> : scan_piece_kernel<256, false>);
     if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
         eps_set_error("eps_scan_screen: cannot reserve %zu bytes of LDS", lds);
         return EPS_ELAUNCH;

@@ -8,11 +8,13 @@
 //   2. the pairs at or above it are compacted (eps_select_topk_cut); the caller reads their number m back -- the one host
 //      round trip of the selection, as short as a device word;
 //   3. each becomes two rows (key, mirrored key); stable LSD radix sorts by the id bits of u, of v, then descending by score
-//      (rocPRIM through hipCUB: library sorts -- the selection logic, the row layout and the C ABI are what this file adds);
+//      (rocPRIM's device radix sort, called directly: library sorts -- the selection logic, the row layout and the C ABI are
+//      what this file adds);
 //   4. the first min(k, 2 m) rows are the answer (eps_select_topk_rows).
 #include "eps_common.h"
 
-#include <hipcub/hipcub.hpp>
+#include <string.h>
+#include <rocprim/device/device_radix_sort.hpp>
 
 extern "C" int64_t eps_kth_largest_workspace_bytes(void);
 extern "C" int eps_kth_largest_f32(const float *x, int64_t n, int64_t k, float *kth, void *workspace, void *stream);
@@ -90,10 +92,10 @@ static size_t sel_align(size_t x) { return (x + 255) & ~(size_t)255; }
 static size_t sel_sort_temp_bytes(int64_t rows)
 {
     size_t a = 0, b = 0;
-    (void)hipcub::DeviceRadixSort::SortPairs((void *)nullptr, a, (const int64_t *)nullptr, (int64_t *)nullptr, (const float *)nullptr,
-                                             (float *)nullptr, rows, 0, 64, (hipStream_t)0);
-    (void)hipcub::DeviceRadixSort::SortPairsDescending((void *)nullptr, b, (const float *)nullptr, (float *)nullptr,
-                                                       (const int64_t *)nullptr, (int64_t *)nullptr, rows, 0, 32, (hipStream_t)0);
+    (void)rocprim::radix_sort_pairs((void *)nullptr, a, (const int64_t *)nullptr, (int64_t *)nullptr, (const float *)nullptr,
+                                    (float *)nullptr, (size_t)rows, 0u, 64u, (hipStream_t)0);
+    (void)rocprim::radix_sort_pairs_desc((void *)nullptr, b, (const float *)nullptr, (float *)nullptr, (const int64_t *)nullptr,
+                                         (int64_t *)nullptr, (size_t)rows, 0u, 32u, (hipStream_t)0);
     return a > b ? a : b;
 }
 
@@ -231,15 +233,15 @@ extern "C" int eps_select_topk_rows(const int64_t *sel_keys, const float *sel_va
     // stable LSD sorts, least significant criterion first: u (low id bits), v (high id bits), then the score, descending
     hipError_t e;
     if (id_bits >= 24) {         // (nearly) all bits count: one sort over the whole key (non-negative: the sign bit is idle)
-        e = hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, k0, k1, v0, v1, (int64_t)rows, 0, 63, s);
+        e = rocprim::radix_sort_pairs(temp, temp_bytes, k0, k1, v0, v1, rows, 0u, 63u, s);
         if (e == hipSuccess) e = hipMemcpyAsync(k0, k1, rows * 8, hipMemcpyDeviceToDevice, s);
         if (e == hipSuccess) e = hipMemcpyAsync(v0, v1, rows * 4, hipMemcpyDeviceToDevice, s);
     } else {
-        e = hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, k0, k1, v0, v1, (int64_t)rows, 0, id_bits, s);
-        if (e == hipSuccess) e = hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, k1, k0, v1, v0, (int64_t)rows, 32, 32 + id_bits, s);
+        e = rocprim::radix_sort_pairs(temp, temp_bytes, k0, k1, v0, v1, rows, 0u, (unsigned)id_bits, s);
+        if (e == hipSuccess) e = rocprim::radix_sort_pairs(temp, temp_bytes, k1, k0, v1, v0, rows, 32u, 32u + (unsigned)id_bits, s);
     }
     if (e != hipSuccess ||
-        hipcub::DeviceRadixSort::SortPairsDescending(temp, temp_bytes, v0, v1, k0, k1, (int64_t)rows, 0, 32, s) != hipSuccess) {
+        rocprim::radix_sort_pairs_desc(temp, temp_bytes, v0, v1, k0, k1, rows, 0u, 32u, s) != hipSuccess) {
         eps_set_error("eps_select_topk_rows: radix sort failed");
         return EPS_ELAUNCH;
     }

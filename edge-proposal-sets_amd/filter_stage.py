@@ -238,11 +238,12 @@ def run(args) -> str:
     t0 = time.perf_counter()
     keep = int(args.keep_top)
     scan_w = fused_node_weights(args, data.adj_t, ra_graph) if 0 < keep <= scan.MAX_K and scan.scan_available(data.adj_t) else None
-    if scan_w is not None and not candidates.fused_scores_fit(data.adj_t, scan_w):
+    if scan_w is not None and not scan.scan_usable(data.adj_t, scan_w):
         scan_w = None                    # sums could leave the scan's fixed-point range: the pair kernels score this graph
     if scan_w is not None:
-        # --keep_top on a unit-valued graph with a heuristic filter: one threshold scan of the whole candidate set
-        # (csrc/filter_scan.hip) instead of candidate blocks + streaming top-K; every rank ends with the same list
+        # --keep_top with a heuristic filter on a symmetric graph (unit-valued, or collab's summed multi-edge weights): one
+        # threshold scan of the whole candidate set (csrc/scan_pieces.hip / filter_scan.hip) instead of candidate blocks +
+        # streaming top-K; every rank ends with the same list
         st = {}
         with torch.no_grad():
             best_pairs, best_scores = scan.scan_topk(data.adj_t, scan_w, keep, rank, world, stats=st)
@@ -254,7 +255,8 @@ def run(args) -> str:
               f'incl. generation)')
         return _save(args, spec, sorted_edge_path, num_sorted_edge, run_id, rank, world,
                      torch.cat([best_pairs.t().to(torch.float32), best_scores.unsqueeze(1)], 1))
-    full_w = fused_node_weights(args, data.adj_t, ra_graph) if keep == 0 and scan.scan_available(data.adj_t) else None
+    full_w = (fused_node_weights(args, data.adj_t, ra_graph)
+              if keep == 0 and data.adj_t.val is None and scan.scan_available(data.adj_t) else None)
     if (full_w is not None and candidates.fused_scores_fit(data.adj_t, full_w)
             and int(scan.half_paths(data.adj_t).sum().item()) < 1 << 29):      # (unordered pairs <= half paths: lists that fit)
         # the whole [E,3] file of a heuristic filter on a unit-valued symmetric graph: scores are symmetric too, so the list

@@ -137,13 +137,22 @@ class SAGEConv(torch.nn.Module):
         with torch.no_grad():
             return self._forward_hip(x, adj_t, relu)
 
+    TRANSFORM_FIRST = True     # aggregate lin_l(x) instead of x when the layer narrows (see _forward_hip)
+
     def _forward_hip(self, x, adj_t, relu, rows=None):
         k = x.shape[1]
         x, x_full = _pad4_full(x)                      # pad columns are zero: aggregate the padded width (float4 path)
         rowptr = adj_t.rowptr if rows is None else adj_t.rowptr[rows[0]:rows[1] + 1]
-        agg = ops.spmm_csr(rowptr, adj_t.col, None, x_full, mean=True)[:, :k]
-        out = ops.gemm(agg, self.lin_l.weight.detach(), bias=self.lin_l.bias.detach())
         x_rows = x if rows is None else x[rows[0]:rows[1]]
+        if self.TRANSFORM_FIRST and self.in_channels > self.out_channels and self.out_channels % 4 == 0:
+            # the mean commutes with lin_l: mean_j(x_j) W^T == mean_j(x_j W^T).  A layer that narrows (ppa: 58 features +
+            # 256-d embedding = 314 -> 256; collab: 384 -> 256) then gathers ONE 1-KiB row of z = x W_l^T per neighbour
+            # instead of a 256-column pass plus a partial-row pass over x; lin_l's bias rides in the SpMM's epilogue.
+            z = ops.gemm(x, self.lin_l.weight.detach())
+            out = ops.spmm_csr(rowptr, adj_t.col, None, z, bias=self.lin_l.bias.detach(), mean=True)
+        else:
+            agg = ops.spmm_csr(rowptr, adj_t.col, None, x_full, mean=True)[:, :k]
+            out = ops.gemm(agg, self.lin_l.weight.detach(), bias=self.lin_l.bias.detach())
         return ops.gemm(x_rows, self.lin_r.weight.detach(), out=out, accumulate=True, relu=relu)
 
     @torch.no_grad()

@@ -510,14 +510,26 @@ def scan_screen_weights(fixw: torch.Tensor, shift: int):
     return out, bad
 
 
-def rescore_runs(rowptr, col, w64: torch.Tensor, n_nodes: int, keys_by_u: torch.Tensor) -> torch.Tensor:
-    """float32 exact scores of the pairs ``keys_by_u`` = (u << 32) | v, sorted ascending (eps_rescore_runs)."""
-    dev = _need_gpu(rowptr, col, w64, keys_by_u)
-    _chk(rowptr, torch.int64, "rowptr"); _chk(col, torch.int32, "col"); _chk(w64, torch.float64, "w64"); _chk(keys_by_u, torch.int64, "keys")
+def rescore_runs(rowptr, col, fixw: torch.Tensor, n_nodes: int, keys_by_u: torch.Tensor) -> torch.Tensor:
+    """float32 exact scores of the pairs ``keys_by_u`` = (u << 32) | v, sorted ascending (eps_rescore_runs; unit values)."""
+    dev = _need_gpu(rowptr, col, fixw, keys_by_u)
+    _chk(rowptr, torch.int64, "rowptr"); _chk(col, torch.int32, "col"); _chk(fixw, torch.int64, "fixw"); _chk(keys_by_u, torch.int64, "keys")
     out = torch.empty(keys_by_u.numel(), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
-        _lib.check(_lib.load().eps_rescore_runs(_ptr(rowptr), _ptr(col), _ptr(w64), n_nodes, _ptr(keys_by_u), keys_by_u.numel(),
+        _lib.check(_lib.load().eps_rescore_runs(_ptr(rowptr), _ptr(col), _ptr(fixw), n_nodes, _ptr(keys_by_u), keys_by_u.numel(),
                                                 _ptr(out), _stream(dev)), "eps_rescore_runs")
+    return out
+
+
+def rescore_weighted(rowptr, col, val, node_w: torch.Tensor, n_nodes: int, keys: torch.Tensor) -> torch.Tensor:
+    """float32 exact scores of the pairs ``keys`` = (a << 32) | b on an adjacency with stored values (eps_rescore_weighted)."""
+    dev = _need_gpu(rowptr, col, val, node_w, keys)
+    _chk(rowptr, torch.int64, "rowptr"); _chk(col, torch.int32, "col"); _chk(val, torch.float32, "val")
+    _chk(node_w, torch.float32, "node_w"); _chk(keys, torch.int64, "keys")
+    out = torch.empty(keys.numel(), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.load().eps_rescore_weighted(_ptr(rowptr), _ptr(col), _ptr(val), _ptr(node_w), n_nodes, _ptr(keys), keys.numel(),
+                                                    _ptr(out), _stream(dev)), "eps_rescore_weighted")
     return out
 
 
@@ -525,23 +537,34 @@ SCAN_VARIANT = 2          # default workgroup / table geometry of eps_scan_scree
 
 
 def scan_screen(rowptr, col, revpos, fx32, cuts, bounds, n_nodes: int, columns: torch.Tensor, shift: int, out: "Survivors",
-                status: torch.Tensor, variant: Optional[int] = None) -> None:
-    """Launch eps_scan_screen over ``columns``; survivors (screening scores) accumulate in ``out``."""
-    dev = _need_gpu(rowptr, col, revpos, fx32, cuts, bounds, columns, status)
+                status: torch.Tensor, variant: Optional[int] = None, val: Optional[torch.Tensor] = None,
+                node_w: Optional[torch.Tensor] = None) -> None:
+    """Launch eps_scan_screen over ``columns``; survivors (screening scores) accumulate in ``out``.  ``val`` / ``node_w``
+    (float32 stored values / node weights): the weighted flavour (eps_scan_screen_weighted; ``fx32`` unused)."""
+    dev = _need_gpu(rowptr, col, revpos, fx32, cuts, bounds, columns, status, val, node_w)
     _chk(rowptr, torch.int64, "rowptr"); _chk(col, torch.int32, "col"); _chk(revpos, torch.int32, "revpos")
     _chk(fx32, torch.int32, "fx32"); _chk(cuts, torch.int16, "cuts"); _chk(bounds, torch.int32, "bounds")
-    _chk(columns, torch.int32, "columns"); _chk(status, torch.int32, "status")
-    if revpos.numel() != col.numel() or fx32.numel() != n_nodes or cuts.shape[0] != n_nodes:
+    _chk(columns, torch.int32, "columns"); _chk(status, torch.int32, "status"); _chk(val, torch.float32, "val")
+    _chk(node_w, torch.float32, "node_w")
+    if revpos.numel() != col.numel() or cuts.shape[0] != n_nodes or (val is None and fx32.numel() != n_nodes):
         raise _lib.EpsError("scan_screen: revpos / fx32 / cuts do not match the graph")
+    if val is not None and (val.numel() != col.numel() or node_w is None or node_w.numel() != n_nodes):
+        raise _lib.EpsError("scan_screen: val / node_w do not match the graph")
+    variant = SCAN_VARIANT if variant is None else int(variant)
+    lib = _lib.load()
     with torch.cuda.device(dev):
         ev = None
         if KERNEL_EVENTS is not None:
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev[0].record(torch.cuda.current_stream(dev))
-        _lib.check(_lib.load().eps_scan_screen(_ptr(rowptr), _ptr(col), _ptr(revpos), _ptr(fx32), _ptr(cuts), _ptr(bounds), n_nodes,
-                                               col.numel(), _ptr(columns), columns.numel(), int(shift),
-                                               SCAN_VARIANT if variant is None else int(variant), _ptr(out.rec), _ptr(status),
-                                               _stream(dev)), "eps_scan_screen")
+        if val is None:
+            _lib.check(lib.eps_scan_screen(_ptr(rowptr), _ptr(col), _ptr(revpos), _ptr(fx32), _ptr(cuts), _ptr(bounds), n_nodes,
+                                           col.numel(), _ptr(columns), columns.numel(), int(shift), variant, _ptr(out.rec), _ptr(status),
+                                           _stream(dev)), "eps_scan_screen")
+        else:
+            _lib.check(lib.eps_scan_screen_weighted(_ptr(rowptr), _ptr(col), _ptr(val), _ptr(revpos), _ptr(node_w), _ptr(cuts),
+                                                    _ptr(bounds), n_nodes, col.numel(), _ptr(columns), columns.numel(), int(shift),
+                                                    variant, _ptr(out.rec), _ptr(status), _stream(dev)), "eps_scan_screen_weighted")
         if ev is not None:
             ev[1].record(torch.cuda.current_stream(dev))
             KERNEL_EVENTS.append(("scan_piece_kernel", ev[0], ev[1], int(columns.numel())))

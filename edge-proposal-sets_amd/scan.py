@@ -43,10 +43,38 @@ MAX_SCREEN_SHIFT = 30
 
 
 def scan_available(g: CSRGraph) -> bool:
-    """eps_filter_scan can take this graph: on the GPU, square, unit values, SYMMETRIC (the half scheme scores a pair once,
-    in the column of its larger endpoint -- on an asymmetric pattern that would silently be a different sum)."""
-    return (g.device.type == "cuda" and g.n_rows == g.n_cols and g.val is None and 0 < g.n_rows <= ops.filter_scan_max_nodes()
-            and g.nnz() < 1 << 30 and is_symmetric(g))       # (any id space: wider ones are scanned in id windows)
+    """The threshold scan can take this graph: on the GPU, square, SYMMETRIC (the half scheme scores a pair once, in the
+    column of its larger endpoint -- on an asymmetric pattern that would silently be a different sum).  Unit values: either
+    kernel.  Stored values (collab, rank.py:32-35): positive, symmetric like the pattern, and a graph the piece kernel suits
+    (``screen_variant``) -- eps_filter_scan has no weighted flavour."""
+    if not (g.device.type == "cuda" and g.n_rows == g.n_cols and 0 < g.n_rows <= ops.filter_scan_max_nodes()
+            and g.nnz() < 1 << 30 and is_symmetric(g)):       # (any id space: wider ones are scanned in id windows)
+        return False
+    return g.val is None or (values_symmetric(g) and screen_variant(scan_graph(g)[0]) is not None)
+
+
+def scan_usable(g: CSRGraph, node_w: torch.Tensor) -> bool:
+    """scan_topk will take this (graph, weight table): ``scan_available``, the scores fit the fixed-point range, and -- for a
+    graph with stored values -- the one-pass kernel's tables are usable (non-negative weights, 32-bit screening sums)."""
+    from . import candidates
+    if not (scan_available(g) and candidates.fused_scores_fit(g, node_w)):
+        return False
+    if g.val is None:
+        return True
+    gs, perm = scan_graph(g)
+    return screen_variant(gs) is not None and screen_weights(g, gs, perm, node_w).usable
+
+
+def values_symmetric(g: CSRGraph) -> bool:
+    """Stored values positive and equal on mirrored entries (cached): entry e = (v, w) has its mirror (w, v) at
+    rowptr[w] + revpos[e]."""
+    if "values_symmetric" not in g._cache:
+        ok = True
+        if g.val is not None and g.nnz():
+            mirror = g.rowptr[g.col.long()] + reverse_positions(g).long()
+            ok = bool(((g.val[mirror] == g.val) & (g.val > 0)).all().item())
+        g._cache["values_symmetric"] = ok
+    return g._cache["values_symmetric"]
 
 
 def reverse_positions(g: CSRGraph) -> torch.Tensor:
@@ -113,6 +141,9 @@ def scan_graph(g: CSRGraph, build: bool = False):
     Relabelling sorts the stored entries once (~35 ms for 42.5 M): worth it for a graph that is scanned repeatedly, not
     for one scan -- so the relabelled copy is used when it exists (``build=True`` makes it; the GNN path builds the same
     copy for its SpMM) and a one-shot caller (filter.py) scans the graph as it is."""
+    if g.val is not None:                 # stored values: only the piece kernel scans them, and it wants even columns
+        gs, perm, _ = g.degree_ordered()
+        return gs, perm
     if g.n_rows < RELABEL_MIN_NODES or not (build or "deg_order" in g._cache):
         return g, None
     gs, perm, _ = g.degree_ordered()
@@ -160,19 +191,30 @@ def screen_shift(bound: float, max_deg: int) -> int:
     return shift
 
 
-def screen_weights(g0: CSRGraph, g: CSRGraph, perm, node_w: torch.Tensor):
-    """(fx32, shift, float64 weights, usable) for the one-pass scan of ``g`` (the scanned copy of ``g0``), cached per weight
-    tensor: screening weights rounded up to 2^-shift, and the exact weights fixw * 2^-40 as doubles for the re-scoring (sums
-    of multiples of 2^-40 below 2^12 are exact in float64, whatever the order).  ``usable`` is False for negative weights or a
-    score bound beyond 32 bits: such tables stay on eps_filter_scan."""
+class Screen:
+    """What a launch of the piece kernel and the exact re-scoring of its survivors need, for one (graph, weight table)."""
+    __slots__ = ("fx32", "shift", "fixw", "val", "node_w", "usable")
+
+    def __init__(self, fx32, shift, fixw, val, node_w, usable):
+        self.fx32, self.shift, self.fixw, self.val, self.node_w, self.usable = fx32, shift, fixw, val, node_w, usable
+
+
+def screen_weights(g0: CSRGraph, g: CSRGraph, perm, node_w: torch.Tensor) -> Screen:
+    """Tables of the one-pass scan of ``g`` (the scanned copy of ``g0``), cached per weight tensor and labelling: unit-valued
+    graphs get screening weights rounded up to 2^-shift (fx32) and re-score with the 2^-40 fixed-point weights (fixw); graphs
+    with stored values form the screening weight per path from (val, float node weights) and re-score with those.
+    ``usable`` is False for negative weights or a score bound beyond 32 bits: such tables stay on eps_filter_scan."""
     def build():
         from . import candidates
-        fixw = _scan_weights(g0, g, perm, node_w)
         bound = candidates.fused_score_bound(g0, node_w)
-        shift = screen_shift(bound, max_degree(g))
+        shift = screen_shift(bound, 2 * max_degree(g))
+        fits = bound * (1 << shift) + 2 * max_degree(g) < (1 << 32) - 2
+        if g.val is not None:
+            nw = (node_w if perm is None else node_w[perm]).contiguous()
+            return Screen(None, shift, None, g.val, nw, fits and bool((nw >= 0).all().item()))
+        fixw = _scan_weights(g0, g, perm, node_w)
         fx32, bad = ops.scan_screen_weights(fixw, shift)
-        usable = int(bad.item()) == 0 and bound * (1 << shift) + max_degree(g) < (1 << 32) - 2
-        return fx32, shift, fixw.to(torch.float64) * (2.0 ** -40), usable
+        return Screen(fx32, shift, fixw, None, None, fits and int(bad.item()) == 0)
     # (one entry per labelling: the tables are indexed by the SCANNED graph's node ids)
     return g0.weight_cached("screen_weights" if perm is None else "screen_weights_relabelled", node_w, build)
 
@@ -202,32 +244,35 @@ def one_pass_available(g: CSRGraph) -> bool:
 
 
 def _launch(g, fixw, columns, threshold, capacity, scores_only: bool = False, both: bool = False, screen=None) -> ops.Survivors:
-    """``screen`` = (fx32, shift) -> the one-pass kernel (screening scores in ``val``), else eps_filter_scan (exact scores)."""
+    """``screen`` (a Screen) -> the one-pass kernel (screening scores in ``val``), else eps_filter_scan (exact scores)."""
     out = ops.Survivors(capacity, threshold, g.device, scores_only, both)
     if columns.numel():
         if screen is not None:
             bounds, cuts = screen_tables(g)
             out.status = torch.empty(1, dtype=torch.int32, device=g.device)
-            ops.scan_screen(g.rowptr, g.col, reverse_positions(g), screen[0], cuts, bounds, g.n_rows, columns, screen[1], out,
-                            out.status, screen_variant(g))
+            ops.scan_screen(g.rowptr, g.col, reverse_positions(g), screen.fx32, cuts, bounds, g.n_rows, columns, screen.shift, out,
+                            out.status, screen_variant(g), screen.val, screen.node_w)
         else:
             ops.filter_scan(g.rowptr, g.col, reverse_positions(g), fixw, g.n_rows, columns, out, max_degree(g), window_splits(g))
     return out
 
 
-def rescore_exact(g: CSRGraph, w64: torch.Tensor, keys: torch.Tensor, bar):
-    """Exact scores of the screened survivors ``keys`` (v << 32 | u, u < v): float32 of the float64 sum of the exact weights
-    over the common neighbours -- bit-identical to eps_filter_scan's 2^-40 fixed-point sums.  -> (keys, scores) in another
-    order; candidates that do not exceed ``bar`` (a 1-element device tensor or None) get key -1 / score -inf, like an
-    untouched slot.
-    The survivors are pairs of hubs (under hubs-first labels u is the heavier one and recurs in hundreds of pairs), so they
-    are sorted by u and go through eps_rescore_runs: one LDS bitmap of N(u) per run of equal u, the short rows N(v) streamed
-    against it, the exact weights of the hits summed in float64 (exact, order-independent)."""
+def rescore_exact(g: CSRGraph, screen: Screen, keys: torch.Tensor, bar):
+    """Exact scores of the screened survivors ``keys`` (v << 32 | u, u < v): float32 of the int64 sum of the 2^-40 fixed-point
+    terms over the common neighbours -- bit-identical to eps_filter_scan's / eps_expand_fill's sums.  -> (keys, scores) in
+    another order; candidates that do not exceed ``bar`` (a 1-element device tensor or None) get key -1 / score -inf, like
+    an untouched slot.
+    Unit values: the survivors are pairs of hubs (under hubs-first labels u is the heavier one and recurs in hundreds of
+    pairs), so they are sorted by u and go through eps_rescore_runs (one LDS bitmap of N(u) per run of a long row, staged
+    short rows otherwise).  Stored values: eps_rescore_weighted (both values of every common neighbour)."""
     if keys.numel() == 0:
         return keys, torch.zeros(0, dtype=torch.float32, device=keys.device)
-    by_u = torch.sort(((keys & 0xFFFFFFFF) << 32) | (keys >> 32)).values          # (u << 32 | v): runs of equal u
-    vals = ops.rescore_runs(g.rowptr, g.col, w64, g.n_rows, by_u)
-    keys = ((by_u & 0xFFFFFFFF) << 32) | (by_u >> 32)
+    if screen.val is not None:
+        vals = ops.rescore_weighted(g.rowptr, g.col, screen.val, screen.node_w, g.n_rows, keys)
+    else:
+        by_u = torch.sort(((keys & 0xFFFFFFFF) << 32) | (keys >> 32)).values          # (u << 32 | v): runs of equal u
+        vals = ops.rescore_runs(g.rowptr, g.col, screen.fixw, g.n_rows, by_u)
+        keys = ((by_u & 0xFFFFFFFF) << 32) | (by_u >> 32)
     if bar is not None:
         keep = vals > bar
         keys = torch.where(keep, keys, torch.full_like(keys, -1))
@@ -355,15 +400,17 @@ def scan_topk(g: CSRGraph, node_w: torch.Tensor, k: int, rank: int = 0, world: i
     dev = g.device
     g0 = g
     g, perm = scan_graph(g0, relabel)    # from here on g is the graph as scanned; ids go back through perm at the end
-    fixw = _scan_weights(g0, g, perm, node_w)
+    fixw = _scan_weights(g0, g, perm, node_w) if g.val is None else None
     mine = shard_columns(g, rank, world)
     total_half = total_half_paths(g)
     k2 = (k + 1) // 2                    # the k-th best directed row belongs to the ceil(k/2)-th best unordered pair
-    screen, w64 = None, None
+    screen = None
     if one_pass_available(g):
-        fx32, shift, w64, usable = screen_weights(g0, g, perm, node_w)
-        if usable:
-            screen = (fx32, shift)
+        sc = screen_weights(g0, g, perm, node_w)
+        if sc.usable:
+            screen = sc
+    if screen is None and g.val is not None:
+        raise ops._lib.EpsError("scan_topk: this weighted graph / weight table does not fit the one-pass scan (see scan_available)")
     slack = _CHUNK_SLACK if screen is None else _PIECE_SLACK
     launches = 0
     bar = None
@@ -387,10 +434,10 @@ def scan_topk(g: CSRGraph, node_w: torch.Tensor, k: int, rank: int = 0, world: i
             # the k2 best exact scores all have screening scores >= (k2-th best screening score, job-wide) - eps -- only
             # those are re-scored (about k2 of the SAFETY x k2 survivors).
             cut_a = ops.kth_largest_dist(l_vals, k2, world)
-            eps = max_degree(g) * 2.0 ** -screen[1]
+            eps = (2 if screen.val is not None else 1) * max_degree(g) * 2.0 ** -screen.shift
             c_keys, _, n_valid = ops.compact_at_least(l_keys, l_vals, cut_a - (eps + cut_a.abs() * 4e-6))
             nv = int(n_valid.item())                                                      # (one word: sizes the re-scoring)
-            l_keys, l_vals = rescore_exact(g, w64, c_keys[:nv], bar)
+            l_keys, l_vals = rescore_exact(g, screen, c_keys[:nv], bar)
             status = res.status
         # the job-wide cut: the k2-th best survivor score over all ranks (-inf when fewer survived); untouched slots are -inf
         cut = ops.kth_largest_dist(l_vals, k2, world)

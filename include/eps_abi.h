@@ -221,16 +221,29 @@ int eps_filter_scan(const int64_t *rowptr, const int32_t *col, const int32_t *re
  *                           *status (device word, cleared by the call): bit 2 = a table filled up (results invalid). */
 int32_t eps_scan_windows(void);
 /* eps_rescore_runs: exact scores of screened survivors.  keys = (u << 32) | v, sorted ascending (runs of equal u: the hubs
- * recur); w64[i] = the exact weight of node i as a double (fixw[i] * 2^-40); out[i] = float32 of the exact float64 sum over the
- * common neighbours of pair i -- bit-identical to eps_filter_scan's score.  Unit-valued adjacency. */
-int eps_rescore_runs(const int64_t *rowptr, const int32_t *col, const double *w64, int64_t n_nodes, const int64_t *keys,
+ * recur); fixw = eps_fixed_weights(node_w); out[i] = float32 of the exact int64 sum of the 2^-40 fixed-point weights over the
+ * common neighbours of pair i -- bit-identical to eps_filter_scan's / eps_expand_fill's score.  Unit-valued adjacency.
+ * eps_rescore_weighted: the same for an adjacency with stored values: term = (A[u,w] * A[v,w]) * node_w[w] in float32, each
+ * converted to 2^-40 fixed point (eps_expand_fill's weighted score); keys in any order. */
+int eps_rescore_runs(const int64_t *rowptr, const int32_t *col, const int64_t *fixw, int64_t n_nodes, const int64_t *keys,
                      int64_t n, float *out, void *stream);
+int eps_rescore_weighted(const int64_t *rowptr, const int32_t *col, const float *val, const float *node_w, int64_t n_nodes,
+                         const int64_t *keys, int64_t n, float *out, void *stream);
 int eps_scan_cuts(const int64_t *rowptr, const int32_t *col, int64_t n_nodes, const int32_t *bounds, uint16_t *cuts,
                   void *stream);
 int eps_scan_screen_weights(const int64_t *fixw, int64_t n, int32_t shift, uint32_t *fx32, uint32_t *bad, void *stream);
 int eps_scan_screen(const int64_t *rowptr, const int32_t *col, const int32_t *revpos, const uint32_t *fx32,
                     const uint16_t *cuts, const int32_t *bounds, int64_t n_nodes, int64_t nnz, const int32_t *columns,
                     int64_t n_columns, int32_t shift, int32_t variant, eps_survivors *out, uint32_t *status, void *stream);
+/* eps_scan_screen_weighted: the scan on a SYMMETRIC adjacency WITH stored values (collab: rank.py:32-35 keeps the summed
+ * multi-edge weights; val[e] must equal the value of e's mirror entry and be positive).  A path's term is
+ * (A[u,w] * A[v,w]) * node_w[w] -- symmetric in (u, v), so the half scheme holds -- and its screening weight is formed per
+ * path from the float values, rounded up.  node_w = the float32 node weights (no fx32 table); re-score with
+ * eps_rescore_weighted. */
+int eps_scan_screen_weighted(const int64_t *rowptr, const int32_t *col, const float *val, const int32_t *revpos,
+                             const float *node_w, const uint16_t *cuts, const int32_t *bounds, int64_t n_nodes, int64_t nnz,
+                             const int32_t *columns, int64_t n_columns, int32_t shift, int32_t variant, eps_survivors *out,
+                             uint32_t *status, void *stream);
 
 /* ---- the candidate list of a block of columns of a graph WITHOUT stored values, on the scan kernel's structure ----------
  * Same results as eps_expand_count / eps_expand_fill above (filter.py:96-109: every 2-hop non-edge of columns

@@ -179,6 +179,72 @@ def test_full_size_properties_spmm_decode(eps, dev):
     assert torch.equal(eps.ops.mlp_decode(h, u[perm].contiguous(), v[perm].contiguous(), ws, bs), p1[perm])
 
 
+def test_full_size_properties_collab_shape(eps, dev, monkeypatch):
+    """BASELINE configs[1] at FULL size (collab stand-in: N = 235,868, summed integer multi-edge weights, 128 features +
+    256-d embedding = 384 -> H = 256, L = 3), size-independent checks, no oracle run: the SpMM WITH stored values of an
+    all-ones matrix = the weighted row sums (exact: small integers); the GCN-normalised weighted adjacency fixes
+    sqrt(weighted degree + 1); the K = 384 layer GEMM against float64 on sampled rows; a full GCN forward (finite, right shape);
+    the fused decode is symmetric in (u, v) bit for bit; and the weighted threshold scan's top
+    proposals equal the fused expansion's on a block of columns."""
+    import argparse
+    from eps_amd import candidates, datasets, models, scan
+    from eps_amd.heuristics import node_weight_table
+    monkeypatch.delenv("EPS_SYNTH_SCALE", raising=False)
+    args = models.default_model_configs(argparse.Namespace(dataset="collab", model="gcn", synthetic=True, num_layers=None,
+                                                           hidden_channels=None, dropout=None, batch_size=None, lr=None, epochs=None,
+                                                           use_feature=None, use_learnable_embedding=None))
+    _, _, _, data = datasets.get_data(args)
+    data = data.to(dev)
+    g = data.adj_t
+    n = g.n_rows
+    assert n == 235_868 and g.val is not None and data.x.shape[1] == 128
+    wdeg = torch.zeros(n, device=dev).index_add_(0, g.row_index(), g.val)
+    y = eps.ops.spmm_csr(g.rowptr, g.col, g.val, torch.ones(n, 256, device=dev))
+    assert torch.equal(y[:, 0], wdeg) and torch.equal(y[:, 255], wdeg)
+    gn = g.gcn_normalized()
+    s = torch.sqrt(wdeg + 1.0)
+    z = eps.ops.spmm_csr(gn.rowptr, gn.col, gn.val, s[:, None].repeat(1, 4).contiguous())
+    assert bool(((z[:, 0] - s).abs() <= 2.0 ** -22 * (g.degree().float() + 2.0) * s).all())
+    gen = torch.Generator(device=dev).manual_seed(4)
+    a = torch.randn(n, 384, generator=gen, device=dev)
+    wt = torch.randn(256, 384, generator=gen, device=dev) / 20
+    bias = torch.randn(256, generator=gen, device=dev)
+    c = eps.ops.gemm(a, wt, bias=bias, relu=True)
+    rows = torch.randint(0, n, (512,), generator=gen, device=dev)
+    want = torch.relu(a[rows].double() @ wt.double().t() + bias.double())
+    assert float((c[rows].double() - want).abs().max()) <= 1e-4 * max(1.0, float(want.abs().max()))
+    torch.manual_seed(0)
+    model = models.build_model(args, data, dev).eval()
+    with torch.no_grad():
+        h = model.embeddings(data.x, g)
+        assert h.shape == (n, 256) and bool(h.isfinite().all())
+        lp = model.linkpred
+        ws = [l.weight.detach() for l in lp.lins]
+        bs = [l.bias.detach() for l in lp.lins]
+        E = 2_000_003
+        u = torch.randint(0, n, (E,), generator=gen, device=dev, dtype=torch.int32)
+        v = torch.randint(0, n, (E,), generator=gen, device=dev, dtype=torch.int32)
+        p1 = eps.ops.mlp_decode(h, u, v, ws, bs)
+        assert torch.equal(p1, eps.ops.mlp_decode(h, v, u, ws, bs)) and float(p1.min()) >= 0.0 and float(p1.max()) <= 1.0
+    # the weighted threshold scan (AA, the published collab filter: submit_job.py:199-205) against the fused expansion
+    w = node_weight_table(g, eps.ops.W_AA)
+    assert scan.scan_usable(g, w)
+    k = 150_000
+    pairs, scores = scan.scan_topk(g, w, k)
+    assert pairs.shape == (2, k) and bool((scores[:-1] >= scores[1:]).all())
+    bar = float(scores[-1])
+    lo, hi = 5000, 9000
+    blk = candidates.expand_block_lazy(g, lo, hi, w, want_score=True)
+    idx = torch.nonzero(blk.score > bar).squeeze(1)
+    want_p = blk.select(idx)
+    in_blk = (pairs[1] >= lo) & (pairs[1] < hi) & (scores > bar)
+    got = pairs[:, in_blk]
+    assert torch.equal(torch.sort(got[1] * n + got[0]).values, torch.sort(want_p[1] * n + want_p[0]).values)
+    got_s = dict(zip((got[1] * n + got[0]).tolist(), scores[in_blk].tolist()))
+    want_s = dict(zip((want_p[1] * n + want_p[0]).tolist(), blk.score[idx].tolist()))
+    assert got_s == want_s                                     # the same fixed-point terms: bit-identical scores
+
+
 def test_kth_largest_radix_select(eps, dev):
     """eps_kth_largest_f32 == the k-th entry of a descending sort, incl. ties, negatives, +-0, infinities and tiny arrays."""
     gen = torch.Generator(device=dev).manual_seed(3)

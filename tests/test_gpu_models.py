@@ -69,6 +69,35 @@ def test_sage_conv_matches_reference_witness(eps, dev, tag):
     assert float(np.abs(out2 - d["out_2hop"]).max()) <= TOL * max(1.0, float(np.abs(d["out_2hop"]).max()))
 
 
+def test_sage_conv_transform_first(eps, oracle, dev):
+    """A SAGE layer that narrows (ppa: 58 features + 256-d embedding -> 256) aggregates lin_l(x) instead of x -- the mean
+    commutes with the linear map (models.py:358-384: lin_l(mean_j x_j) + lin_r(x_i)).  Same result as the aggregate-first
+    order and as the oracle's dense float64 conv, within the float32 gate; also as rows [lo, hi) of a row shard."""
+    from eps_amd import models, synth
+    g = synth.rmat_graph(12, 10, 4, dev)
+    n, fin, fout = g.n_rows, 314, 256
+    gen = torch.Generator(device=dev).manual_seed(5)
+    x = torch.randn(n, fin, generator=gen, device=dev)
+    torch.manual_seed(3)
+    conv = models.SAGEConv(fin, fout).to(dev).eval()
+    assert conv.TRANSFORM_FIRST and fin > fout
+    a = conv(x, g, relu=True)
+    conv.TRANSFORM_FIRST = False
+    b = conv(x, g, relu=True)
+    conv.TRANSFORM_FIRST = True
+    scale = max(1.0, float(b.abs().max()))
+    assert float((a - b).abs().max()) <= TOL * scale
+    A = g.to_scipy().astype(np.float64)
+    deg = np.maximum(np.asarray(A.sum(1)).ravel(), 1.0)
+    xs = x.cpu().numpy().astype(np.float64)
+    want = (A @ xs) / deg[:, None] @ conv.lin_l.weight.detach().cpu().numpy().astype(np.float64).T \
+        + conv.lin_l.bias.detach().cpu().numpy().astype(np.float64) + xs @ conv.lin_r.weight.detach().cpu().numpy().astype(np.float64).T
+    want = np.maximum(want, 0.0)
+    assert float(np.abs(a.cpu().numpy() - want).max()) <= TOL * max(1.0, float(np.abs(want).max()))
+    rows = conv.forward_rows(x, g, 1000, 3000, relu=True)
+    assert torch.equal(rows, a[1000:3000])
+
+
 def test_linkpredictor_reference_signature(eps, dev):
     from eps_amd import models
     d = np.load(os.path.join(GOLDEN, "linkpred_H256_L3.npz"))

@@ -311,6 +311,52 @@ def test_scan_wide_id_space_in_windows(eps, oracle, dev):
     assert torch.equal((pairs[1] << 32) | pairs[0], keys[o]) and torch.equal(scores, vals[o])
 
 
+def _weighted_graphs(eps, dev):
+    """(name, graph) with stored values: the collab-like golden graph (integer multi-edge weights) and a weighted R-MAT."""
+    import scipy.sparse as ssp
+    from eps_amd import synth
+    d = np.load([p for p in golden_pair_files() if "collab_like" in p][0])
+    n = len(d["rowptr"]) - 1
+    A = ssp.csr_matrix((d["val"], d["col"], d["rowptr"]), shape=(n, n))
+    yield "collab_like", eps.CSRGraph.from_scipy(A, device=dev)
+    ei = synth.rmat_edges(12, 14 << 12, 8, dev)
+    ei = ei[:, ei[0] != ei[1]]
+    w = torch.randint(1, 6, (ei.shape[1],), generator=torch.Generator(device=dev).manual_seed(2), device=dev).to(torch.float32)
+    yield "rmat_weighted", eps.CSRGraph.from_edge_index(ei, w, sparse_sizes=(1 << 12, 1 << 12)).to_symmetric()
+
+
+def test_scan_weighted_symmetric_graphs(eps, oracle, dev, monkeypatch):
+    """The threshold scan on adjacencies WITH stored values (collab keeps its summed multi-edge weights: rank.py:32-35; the
+    published collab recipe is an AA filter: submit_job.py:199-205): scan_topk == the first K rows of the declared order over
+    the fused expansion's full weighted list (same fixed-point terms: bit-identical), on the no-bar path and through the
+    estimated bar; scores within 1e-5 of the oracle's float32 AA; common-neighbour weights (models.py:536-542) exact."""
+    from eps_amd import scan
+    from eps_amd.heuristics import node_weight_table
+    for name, g in _weighted_graphs(eps, dev):
+        assert g.val is not None and scan.scan_available(g), name
+        A = g.to_scipy()
+        rp, col, val = A.indptr.astype(np.int64), A.indices.astype(np.int32), A.data.astype(np.float32)
+        for mode in ("aa", "cn"):
+            wt = node_weight_table(g, eps.ops.W_AA) if mode == "aa" else torch.ones(g.n_rows, dtype=torch.float32, device=dev)
+            assert scan.scan_usable(g, wt)
+            _, cu, cv, _, sc = eps.ops.expand_candidates(g.rowptr, g.col, g.val, wt, g.n_rows, 0, g.n_rows, want_cn=False)
+            order = torch.sort(sc, descending=True, stable=True).indices
+            for small_set in (scan.SMALL_SET, 0):
+                monkeypatch.setattr(scan, "SMALL_SET", small_set)
+                for k in (1, 777, 20000):
+                    kk = min(k, sc.numel())
+                    st = {}
+                    pairs, scores = scan.scan_topk(g, wt, k, stats=st)
+                    assert torch.equal(pairs, torch.stack([cu[order[:kk]], cv[order[:kk]]]).long()), (name, mode, small_set, k)
+                    assert torch.equal(scores, sc[order[:kk]]) and st["candidates"] == sc.numel()
+            pu, pv = pairs[0].cpu().numpy(), pairs[1].cpu().numpy()
+            w_o = oracle.node_weights(oracle.col_sums(rp, col, val, g.n_rows), oracle.W_AA) if mode == "aa" else np.ones(g.n_rows, np.float32)
+            _, cn_o, ws_o = oracle.pair_scores(rp, col, val, w_o, pu, pv)
+            assert rel_err(scores.cpu().numpy(), ws_o) <= 1e-5
+            if mode == "cn":
+                assert np.array_equal(scores.cpu().numpy(), cn_o)
+
+
 def _structured_graphs():
     import scipy.sparse as ssp
     rng = np.random.default_rng(17)

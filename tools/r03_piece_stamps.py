@@ -66,7 +66,7 @@ def run():
     g0 = synth.ppa_like(seed=3, device=dev)
     w = node_weight_table(g0, ops.W_AA)
     g, perm = g0.degree_ordered()[:2]
-    fx32, shift, w64, usable = scan.screen_weights(g0, g, perm, w)
+    sc = scan.screen_weights(g0, g, perm, w); fx32, shift, usable = sc.fx32, sc.shift, sc.usable
     bounds, cuts = scan.screen_tables(g)
     order = scan.column_order(g)
     lib = ctypes.CDLL(OUT)

@@ -39,7 +39,7 @@ rk, rv = sorted_list(*res.valid(slots))
 print(f"eps_filter_scan: {min(ts):.2f} ms (min of {reps}), candidates {ncand}, survivors {rk.numel()}, slots {slots}")
 
 t_tab, _ = timed(lambda: scan.screen_tables(g))
-fx32, shift, w64, usable = scan.screen_weights(g0, g, perm, w)
+sc = scan.screen_weights(g0, g, perm, w); fx32, shift, usable = sc.fx32, sc.shift, sc.usable
 bounds, cuts = scan.screen_tables(g)
 print(f"screen tables built in {t_tab:.2f} ms; shift {shift}, usable {usable}, bounds {bounds.tolist()}")
 for variant in [int(x) for x in os.environ.get("VARIANTS", "0,1,2").split(",")]:
@@ -51,7 +51,7 @@ for variant in [int(x) for x in os.environ.get("VARIANTS", "0,1,2").split(",")]:
         ts.append(t)
     slots, nc2 = res.counts()
     keys, vals = res.valid(slots)
-    t_re, (k2, v2) = timed(lambda: scan.rescore_exact(g, w64, keys, torch.tensor([bar], device=dev)))
+    t_re, (k2, v2) = timed(lambda: scan.rescore_exact(g, sc, keys, torch.tensor([bar], device=dev)))
     m = k2 >= 0
     nk, nv = sorted_list(k2[m], v2[m])
     same = nk.numel() == rk.numel() and torch.equal(nk, rk) and torch.equal(nv, rv)

@@ -16,7 +16,7 @@ order = scan.column_order(g)
 bar = float(os.environ.get("BAR", "2.378"))
 kernel = os.environ.get("KERNEL", "pieces")
 if kernel == "pieces":
-    fx32, shift, w64, usable = scan.screen_weights(g0, g, perm, w)
+    sc = scan.screen_weights(g0, g, perm, w); fx32, shift, usable = sc.fx32, sc.shift, sc.usable
     bounds, cuts = scan.screen_tables(g)
     variant = int(os.environ.get("VARIANT", str(ops.SCAN_VARIANT)))
 for _ in range(int(os.environ.get("REPS", "1"))):

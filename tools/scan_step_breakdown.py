@@ -15,8 +15,8 @@ for _ in range(3):
     scan.scan_topk(g0, w, K, relabel=True)
 g, perm = scan.scan_graph(g0)
 fixw = scan._scan_weights(g0, g, perm, w)
-fx32, shift, w64, usable = scan.screen_weights(g0, g, perm, w)
-screen = (fx32, shift) if usable and scan.one_pass_available(g) else None
+sc = scan.screen_weights(g0, g, perm, w); fx32, shift, usable = sc.fx32, sc.shift, sc.usable
+screen = sc if usable and scan.one_pass_available(g) else None
 order = scan.column_order(g)
 def T(fn, n=20):
     torch.cuda.synchronize(); t = time.perf_counter()
@@ -30,8 +30,8 @@ t_main, res = T(lambda: scan._launch(g, fixw, order, bar, cap, both=True, screen
 t_comp, (ck, cv, nv) = T(lambda: ops.compact_at_least(res.key, res.val, None))
 nv = int(nv.item())
 t_sort, by_u = T(lambda: torch.sort(((ck[:nv] & 0xFFFFFFFF) << 32) | (ck[:nv] >> 32)).values)
-t_resc, vals = T(lambda: ops.rescore_runs(g.rowptr, g.col, w64, g.n_rows, by_u))
-t_re_all, (lk, lv) = T(lambda: scan.rescore_exact(g, w64, ck[:nv], bar))
+t_resc, vals = T(lambda: ops.rescore_runs(g.rowptr, g.col, sc.fixw, g.n_rows, by_u))
+t_re_all, (lk, lv) = T(lambda: scan.rescore_exact(g, sc, ck[:nv], bar))
 k2 = (K + 1) // 2
 t_kth, cut = T(lambda: ops.kth_largest_dist(lv, k2, 1))
 t_cut, (sk, sv, ns) = T(lambda: ops.compact_at_least(lk, lv, cut))
