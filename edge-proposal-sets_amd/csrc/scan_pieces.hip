@@ -97,10 +97,9 @@ __global__ __launch_bounds__(T) void scan_piece_kernel(sp_params p)
     const int slots = 1 << p.table_bits;
     uint32_t *tkey = lds;                    // [slots]  hash mode: key (node id) or SP_EMPTY
     uint32_t *tval = lds + slots;            // [slots]  hash mode: screening sum.  Direct mode: lds[0 .. 2 slots) are the sums
-    uint32_t *r_seg = lds + 2 * slots;       // [T + 1] first entry of the row's segment, as an index into col[]
-    uint32_t *r_len = r_seg + T + 1;         // [T + 1] entries of the segment
-    uint32_t *r_fx = r_len + T + 1;          // [T + 1] screening weight of the row's node
-    uint32_t *ustart = r_fx + T + 1;         // [T + 1] first 4-entry unit of the row in the round's unit numbering
+    // row descriptors of the round, one uint4 per (dense) row: x = first entry of the row's segment (index into col[]),
+    // y = entries of the segment, z = screening weight of the row's node, w = first 4-entry unit of the row
+    uint4 *r_desc = (uint4 *)(lds + 2 * slots);          // [T + 1]
     // (offsets in words off `lds`, never through an integer cast: a pointer that loses the LDS address space turns its reads
     //  into FLAT loads, which count on vmcnt and make every look-up drain the row loads in flight)
     uint32_t *ubits = lds + ((2 * slots + 4 * (T + 1) + 3) & ~3);      // [SP_UBITS / 32] bit s: a row starts at unit s (of the range)
@@ -335,10 +334,7 @@ __global__ __launch_bounds__(T) void scan_piece_kernel(sp_params p)
                         const uint32_t a_u = (uint32_t)(incl - units + woff);          // first unit of this thread's row
                         if (flag) {
                             const int d = incl_f - 1 + woff_f;
-                            r_seg[d] = base + a;
-                            r_len[d] = len;
-                            r_fx[d] = fx;
-                            ustart[d] = a_u;
+                            r_desc[d] = make_uint4(base + a, len, fx, a_u);
                         }
                         for (uint32_t ulo = 0; ulo < (uint32_t)total; ulo += SP_UBITS) {       // (one range unless > 32 k paths)
                             const uint32_t uhi = ulo + SP_UBITS < (uint32_t)total ? ulo + SP_UBITS : (uint32_t)total;
@@ -385,8 +381,9 @@ __global__ __launch_bounds__(T) void scan_piece_kernel(sp_params p)
                                 // (every LDS read unconditional, the range test a select: a read inside a branch makes hipcc
                                 //  drain the loads in flight at the branch)
                                 const int s = (int)ulo + (it0 + q) * T + tid;
-                                const uint32_t us = ustart[lo[q]], rl = r_len[lo[q]], rs = r_seg[lo[q]];
-                                f[q].fx = r_fx[lo[q]];
+                                const uint4 rd = r_desc[lo[q]];
+                                const uint32_t us = rd.w, rl = rd.y, rs = rd.x;
+                                f[q].fx = rd.z;
                                 const bool in = s < (int)uhi;
                                 const int off = (s - (int)us) * 4;
                                 int left = (int)rl - off;
@@ -448,13 +445,17 @@ __global__ __launch_bounds__(T) void scan_piece_kernel(sp_params p)
                             const int n_iter = (int)(uhi - ulo + T - 1) / T;      // uniform over the workgroup
                             sp_unit fa[SP_G], fb[SP_G];
                             fetch_group(0, fa);
-                            // (refills are unconditional -- a group past the end is empty units at an out-of-range address: no
-                            //  traffic -- because a conditional refill becomes a phi copy and hipcc then drains vmcnt before it)
-                            for (int it0 = 0; it0 < n_iter; it0 += 2 * SP_G) {
-                                fetch_group(it0 + SP_G, fb);
+                            if (n_iter <= SP_G) {          // one group (every hash piece: <= piece_paths / 4 units): nothing to overlap
                                 consume_group(fa);
-                                fetch_group(it0 + 2 * SP_G, fa);
-                                consume_group(fb);
+                            } else {
+                                // (refills are unconditional -- a group past the end is empty units at an out-of-range address:
+                                //  no traffic -- because a conditional refill becomes a phi copy and hipcc then drains vmcnt)
+                                for (int it0 = 0; it0 < n_iter; it0 += 2 * SP_G) {
+                                    fetch_group(it0 + SP_G, fb);
+                                    consume_group(fa);
+                                    fetch_group(it0 + 2 * SP_G, fa);
+                                    consume_group(fb);
+                                }
                             }
                         }
                             if (uhi < (uint32_t)total) sp_barrier();       // (the next range rewrites the start bits)

@@ -6,16 +6,13 @@ import ctypes, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "edge-proposal-sets_amd", "csrc")
 ABL = {
-    "noinsert": [("                        auto consume_group = [&](const sp_unit (&f)[SP_G]) {\n",
-                  "                        auto consume_group = [&](const sp_unit (&f)[SP_G]) {\n                            if (f[0].nvalid >= 0) { asm volatile(\"\" :: \"v\"(f[0].u4[0]), \"v\"(f[SP_G - 1].u4[3])); return; }\n")],
-    "nosearch": [("                                    if (ustart[lo[q] + step] <= (uint32_t)((it0 + q) * T + tid)) lo[q] += step;\n",
-                  "                                    if (step == 0 && ustart[lo[q] + step] <= (uint32_t)((it0 + q) * T + tid)) lo[q] += step;\n")],
-    "noscan": [("                    uint32_t cnt_here = 0u;\n                    if (direct) {\n", "                    uint32_t cnt_here = 0u;\n                    if (scan_slots == 0xFFFFFFFFu) {\n"),
-               ("                    } else {\n                        for (uint32_t i = 4u * tid; i < scan_slots; i += 4u * T) {\n                            const uint4 k4",
-                "                    } else if (scan_slots == 0xFFFFFFFEu) {\n                        for (uint32_t i = 4u * tid; i < scan_slots; i += 4u * T) {\n                            const uint4 k4")],
-    "hashonly_direct": [("                            if (direct) {\n#pragma unroll\n                                for (int q = 0; q < SP_G; ++q)",
-                         "                            if (true) {\n#pragma unroll\n                                for (int q = 0; q < SP_G; ++q)"),
-                        ("atomicAdd(&lds[(uint32_t)(f[q].u4[e] - lo_id)], f[q].fx);", "atomicAdd(&lds[(uint32_t)(f[q].u4[e] - lo_id) & (direct_ids - 1u)], f[q].fx);")],
+    # table load factors: a hash piece holds up to num/den of its table's slots (product: 1/2)
+    "lf_3_4": [("    p.piece_paths = (1u << bits) / 2u;", "    p.piece_paths = (1u << bits) * 3u / 4u;"),
+               ("                    while (bits < p.table_bits && (1u << bits) < 2u * per) ++bits;", "                    while (bits < p.table_bits && (1u << bits) * 3u < 4u * per) ++bits;")],
+    "lf_5_8": [("    p.piece_paths = (1u << bits) / 2u;", "    p.piece_paths = (1u << bits) * 5u / 8u;"),
+               ("                    while (bits < p.table_bits && (1u << bits) < 2u * per) ++bits;", "                    while (bits < p.table_bits && (1u << bits) * 5u < 8u * per) ++bits;")],
+    "lf_3_8": [("    p.piece_paths = (1u << bits) / 2u;", "    p.piece_paths = (1u << bits) * 3u / 8u;"),
+               ("                    while (bits < p.table_bits && (1u << bits) < 2u * per) ++bits;", "                    while (bits < p.table_bits && (1u << bits) * 3u < 8u * per) ++bits;")],
 }
 
 def build():
