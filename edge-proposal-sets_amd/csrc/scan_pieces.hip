@@ -78,6 +78,11 @@ __device__ __forceinline__ uint32_t sp_wave_sum(uint32_t x)
 
 typedef float sp_v4f __attribute__((ext_vector_type(4)));
 
+// Hash of an id: Fibonacci hashing.  The table index is taken from the TOP of the 32-bit product, the probe step from the
+// middle, the pass of a partitioned window from the bottom.  (A full-rate 24 x 24-bit multiply was measured instead of the
+// quarter-rate 32-bit one: its weaker mixing lengthens the probe sequences -- 38.0 vs 30.7 ms per launch.)
+__device__ __forceinline__ uint32_t sp_mix(uint32_t x) { return x * 0x9E3779B1u; }
+
 struct sp_unit {
     sp_v4i u4;
     sp_v4f a4;                  // weighted graphs: the entries' stored values
@@ -90,7 +95,7 @@ struct sp_unit {
 // screening weight is formed per path: ceil(A[u,w] * rowf) + 1 with rowf = A[v,w] * node_w[w] * 2^shift * (1 + 2^-20) per
 // row (float32 products are within 2^-22 of the exact one: still an upper bound of the term's exact fixed-point value).
 template <int T, bool HV>
-__global__ __launch_bounds__(T) void scan_piece_kernel(sp_params p)
+__global__ __launch_bounds__(T, 4) void scan_piece_kernel(sp_params p)      // (4 waves per SIMD: <= 128 VGPRs, the LDS share decides the rest)
 {
     constexpr int W = T / 64;
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
@@ -156,6 +161,7 @@ __global__ __launch_bounds__(T) void scan_piece_kernel(sp_params p)
         s_out_end = 0u;
     }
     unsigned long long n_cand = 0;           // candidates seen by this thread
+    uint32_t new_keys = 0u;                  // ... of the current hash piece: keys this thread inserted, minus known edges it struck
     const unsigned int ncol = (unsigned int)p.n_columns;
     unsigned int t = blockIdx.x;
     sp_barrier();
@@ -412,7 +418,7 @@ __global__ __launch_bounds__(T) void scan_piece_kernel(sp_params p)
 #pragma unroll
                                 for (int i = 0; i < E; ++i) {
                                     const uint32_t id = (uint32_t)f[i >> 2].u4[i & 3];
-                                    const uint32_t mix = id * 0x9E3779B1u;
+                                    const uint32_t mix = sp_mix(id);
                                     key[i] = id + 1u;
                                     h[i] = (mix >> (32 - bits)) & mask;
                                     st[i] = ((mix >> 7) | 1u) & mask;
@@ -430,6 +436,7 @@ __global__ __launch_bounds__(T) void scan_piece_kernel(sp_params p)
                                             if (old[i] == SP_EMPTY || old[i] == key[i]) {
                                                 atomicAdd(&tval[h[i]], path_fx(f[i >> 2], i & 3));
                                                 pend &= ~(1u << i);
+                                                new_keys += old[i] == SP_EMPTY ? 1u : 0u;      // a candidate seen for the first time
                                             } else {
                                                 h[i] = (h[i] + st[i]) & mask;
                                             }
@@ -469,13 +476,14 @@ __global__ __launch_bounds__(T) void scan_piece_kernel(sp_params p)
                             if (direct) {
                                 lds[u - (uint32_t)lo_id] = 0u;
                             } else {
-                                const uint32_t mix = u * 0x9E3779B1u;
+                                const uint32_t mix = sp_mix(u);
                                 if ((mix & (parts - 1u)) == part) {
                                     uint32_t h = (mix >> (32 - bits)) & mask;
                                     const uint32_t st = ((mix >> 7) | 1u) & mask;
                                     for (uint32_t tries = 0; tries <= mask; ++tries) {
                                         const uint32_t k = tkey[h];
                                         if (k == u + 1u) {
+                                            if (tval[h]) --new_keys;                 // (a neighbour of v: no candidate after all)
                                             tval[h] = 0u;
                                             break;
                                         }
@@ -514,22 +522,19 @@ __global__ __launch_bounds__(T) void scan_piece_kernel(sp_params p)
                                 }
                         }
                     } else {
+                        // (the candidates were counted when their keys went in; the key words are only read for a survivor)
                         for (uint32_t i = 4u * tid; i < scan_slots; i += 4u * T) {
-                            const uint4 k4 = *(const uint4 *)(tkey + i);
                             const uint4 s4 = *(const uint4 *)(tval + i);
-                            *(uint4 *)(tkey + i) = make_uint4(0u, 0u, 0u, 0u);
-                            *(uint4 *)(tval + i) = make_uint4(0u, 0u, 0u, 0u);
-                            const uint32_t kk[4] = {k4.x, k4.y, k4.z, k4.w};
                             const uint32_t sv[4] = {s4.x, s4.y, s4.z, s4.w};
 #pragma unroll
                             for (int e = 0; e < 4; ++e)
-                                if (kk[e] != SP_EMPTY && sv[e]) {
-                                    ++cnt_here;
-                                    if (sv[e] >= thr32) emit(kk[e] - 1u, sv[e]);
-                                }
+                                if (sv[e] >= thr32) emit(tkey[i + e] - 1u, sv[e]);
+                            *(uint4 *)(tkey + i) = make_uint4(0u, 0u, 0u, 0u);
+                            *(uint4 *)(tval + i) = make_uint4(0u, 0u, 0u, 0u);
                         }
                     }
-                    n_cand += cnt_here;
+                    n_cand += (unsigned long long)cnt_here + (unsigned long long)(long long)(int32_t)new_keys;   // (may be negative per thread)
+                    new_keys = 0u;
                     sp_barrier();
                 }
             }
