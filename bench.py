@@ -485,14 +485,17 @@ def main():
                                                      "a one-shot filter.py --keep_top run pays",
                                  "serial_ms": "ms_per_step - slowest rank's main kernel - its sample launch: bar, selection, "
                                               "collectives, host"}},
-            "roofline": {"bound": pmc.get("bound", "hbm"), "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "hbm_frac": achieved / HBM_PEAK_GBPS, "traffic": pmc.get("traffic"),
+                         "binds": pmc.get("binds"),
                          "kernel": kernel_name, "kernel_ms": kmax, "launches_timed": len(main_ms),
                          "sample_launch_ms": samp,
                          "algorithmic_bytes_per_launch": abytes,
                          "issue": pmc.get("issue"),
-                         "note": "compulsory bytes: 4 B per two-hop half path + 24 B per stored entry + survivors; `traffic` = "
-                                 "fabric bytes per launch and `issue` = LDS / VALU occupancy of the same launch, both from the "
+                         "note": "`bound`: the unit of achieved / peak (bytes against the HBM peak, as the contract's vocabulary has "
+                                 "it); `binds`: what limits the launch according to the counters.  Compulsory bytes: 4 B per "
+                                 "two-hop half path + 24 B per stored entry + survivors; `traffic` = fabric bytes per launch "
+                                 "(2 x FETCH_SIZE + WRITE_SIZE) and `issue` = VALU / LDS occupancy of the same launch, from the "
                                  "rocprofv3 PMC passes committed under profiles/ (profiles/traffic.json)"},
         }
     if rank == 0 and world == 1 and not args.no_legs:

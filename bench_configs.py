@@ -86,7 +86,7 @@ def leg_config1(torch):
                                   "--num_sorted_edge", "150000", "--runs", "1", "--synthetic"])
         _sync(torch)
         t2 = time.perf_counter()
-        seen = [l for l in log.getvalue().splitlines() if l.startswith("using ")]
+        seen = [l for l in log.getvalue().splitlines() if l.startswith("using ") and " edges; scored in " in l]
     return {"workload": "configs[1] collab-like S2 (N=235,868, weighted, 128 features + 256-d embedding, H=256, L=3): filter.py --model gcn "
                         "--keep_top 150000 -> rank.py --model simple --num_sorted_edge 150000",
             "filter_s": t1 - t0, "rank_s": t2 - t1, "filter_log": seen[-1] if seen else None, "rank_curve": _jsonable(curves),
@@ -219,12 +219,16 @@ def leg_real_ppa(torch, keep_top):
 
 
 def _jsonable(x):
-    try:
-        import json
-        json.dumps(x)
+    """Curves come back as nested lists with 0-dim tensors: plain numbers for the JSON line."""
+    if isinstance(x, (list, tuple)):
+        return [_jsonable(y) for y in x]
+    if isinstance(x, dict):
+        return {str(k): _jsonable(v) for k, v in x.items()}
+    if hasattr(x, "item") and getattr(x, "numel", lambda: 2)() == 1:
+        return x.item()
+    if isinstance(x, (int, float, str, bool)) or x is None:
         return x
-    except TypeError:
-        return str(x)
+    return str(x)
 
 
 def run_all(torch, keep_top):

@@ -367,10 +367,9 @@ __global__ __launch_bounds__(T, 4) void scan_piece_kernel(sp_params p)      // (
                                 *(uint2 *)(wrank + 4 * lane) = pk;
                                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                             }
-                        // A GROUP of SP_G units per lane is looked up, loaded and inserted together: the binary searches of a
-                        // group run side by side (one LDS latency per step, not SP_G), its loads are in flight together, and its
-                        // 4 x SP_G table updates share the probing loop (a trip costs one LDS round trip however many of them are
-                        // still pending).  The next group is requested before the current one is consumed.
+                        // ---- walk: lane = one 4-entry unit.  A GROUP of SP_G units per lane is looked up, loaded and inserted
+                        // together: its look-ups run side by side, its loads are in flight together, and its 4 x SP_G table updates
+                        // share the probing loop (a trip costs one LDS round trip however many of them are still pending).
                         auto fetch_group = [&](int it0, sp_unit (&f)[SP_G]) {
                             int lo[SP_G];
 #pragma unroll

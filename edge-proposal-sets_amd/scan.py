@@ -327,7 +327,8 @@ def estimate_bar(g: CSRGraph, fixw: torch.Tensor, k: int, stride: Optional[int] 
     if m >= bound_all:                                   # (candidates <= half paths: the sample cannot hold that many)
         return None
     slack = _CHUNK_SLACK if screen is None else _PIECE_SLACK
-    res = _launch(g, fixw, mine, float("-inf"), min(2 * bound_mine + slack, ops.SURVIVOR_SLOTS_MAX), scores_only=True, screen=screen)
+    # (room for every candidate of the sample: at most its half paths -- a list that still overflows only thins the sample)
+    res = _launch(g, fixw, mine, float("-inf"), min(bound_mine + slack, ops.SURVIVOR_SLOTS_MAX), scores_only=True, screen=screen)
     # no bar: every candidate of the sample holds a slot, untouched slots are -inf (fewer than m candidates -> bar -inf).
     # (one-pass kernel: screening scores, at most a few 2^-shift above the exact ones -- an estimate either way)
     kth = ops.kth_largest_dist(res.val, m, world)
@@ -417,7 +418,9 @@ def scan_topk(g: CSRGraph, node_w: torch.Tensor, k: int, rank: int = 0, world: i
     if total_half > SMALL_SET and SAFETY * k < total_half:
         bar = estimate_bar(g, fixw, k, rank=rank, world=world, screen=screen)
         launches += 1
-    wanted = 2 * ((2 * total_half if bar is None else int(2 * SAFETY * k)) // world)
+    # unordered survivors expected: SAFETY x k / 2 over all ranks; the list holds four times that (the estimate has been within
+    # a factor 0.35 .. 1.7), or every candidate without a bar
+    wanted = (2 * total_half if bar is None else int(2 * SAFETY * k)) // world
     capacity = _capacity(wanted, slack)
     neg_inf = torch.full((1,), float("-inf"), device=dev)
     while True:
@@ -469,7 +472,7 @@ def scan_topk(g: CSRGraph, node_w: torch.Tensor, k: int, rank: int = 0, world: i
                                                          screen=screen)
             launches += 1
             if bar is None:
-                wanted = 2 * (2 * total_half // world)
+                wanted = 2 * total_half // world
                 capacity = _capacity(wanted, slack)
             continue
         break

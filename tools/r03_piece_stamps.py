@@ -8,7 +8,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "edge-proposal-sets_amd", "csrc")
 OUT = os.path.join(ROOT, "tools", "libeps_spstamp.so")
 NAMES = ["column setup (id, bounds)", "plan: paths per window (cut rows + wave sums)", "plan: pieces (wave 0) + barrier",
-         "describe (cut gathers, unit scan, 2 barriers)", "walk (fetch + table updates) + barrier", "known edges out + barrier",
+         "describe (cut gathers, unit scans, descriptors)", "walk (start bits, look-ups, loads, table updates) + barriers", "known edges out + barrier",
          "table scan + barrier", "ticket hand-over", "(count) pieces", "(count) direct pieces", "(count) rounds walked",
          "(count) hash-loop trips of wave 0", "(count) unit iterations of wave 0", "(count) columns"]
 
@@ -33,14 +33,14 @@ struct sp_params {''')
     rep('            // ---- plan: merge windows into pieces.', '            XS(t2); XA(1, t1, t2);\n            // ---- plan: merge windows into pieces.')
     rep('            const int np = s_np;\n', '            const int np = s_np;\n            XS(t3); XA(2, t2, t3);\n            xst[8] += np;\n')
     rep('                        // ---- describe the round\'s row segments', '                        XS(d0);\n                        xst[10] += 1;\n                        // ---- describe the round\'s row segments')
-    rep('                        // ---- walk: lane = one 4-entry unit;', '                        XS(d1); XA(3, d0, d1);\n                        // ---- walk: lane = one 4-entry unit;')
+    rep('                        for (uint32_t ulo = 0; ulo < (uint32_t)total; ulo += SP_UBITS) {', '                        XS(d1); XA(3, d0, d1);\n                        for (uint32_t ulo = 0; ulo < (uint32_t)total; ulo += SP_UBITS) {')
     rep('                                while (__ballot(pend != 0u)) {\n', '                                while (__ballot(pend != 0u)) {\n                                    xst[11] += 1;\n')
-    rep('                            for (int it = 0; it < n_iter; ++it) {\n', '                            xst[12] += n_iter;\n                            for (int it = 0; it < n_iter; ++it) {\n')
+    rep('                            sp_unit fa[SP_G], fb[SP_G];\n', '                            xst[12] += n_iter;\n                            sp_unit fa[SP_G], fb[SP_G];\n')
     rep('                        sp_barrier();        // the next round / the scan follows: descriptors and table updates are complete\n',
         '                        sp_barrier();        // the next round / the scan follows: descriptors and table updates are complete\n                        XS(d2); XA(4, d1, d2);\n')
     rep('                    // ---- known edges out: a neighbour of v is no candidate', '                    XS(e0);\n                    xst[9] += direct ? 1 : 0;\n                    // ---- known edges out: a neighbour of v is no candidate')
     rep('                    // ---- scan the table: count the candidates', '                    XS(e1); XA(5, e0, e1);\n                    // ---- scan the table: count the candidates')
-    rep('                    n_cand += cnt_here;\n                    sp_barrier();\n', '                    n_cand += cnt_here;\n                    sp_barrier();\n                    XS(e2); XA(6, e1, e2);\n')
+    rep('                    new_keys = 0u;\n                    sp_barrier();\n', '                    new_keys = 0u;\n                    sp_barrier();\n                    XS(e2); XA(6, e1, e2);\n')
     rep('        if (tid == 0) s_ticket = t_next;\n        sp_barrier();\n        t = s_ticket;\n        sp_barrier();\n',
         '        XS(t8);\n        if (tid == 0) s_ticket = t_next;\n        sp_barrier();\n        t = s_ticket;\n        sp_barrier();\n        XS(t9); XA(7, t8, t9);\n')
     rep('    // candidates scored by this workgroup: one atomic per wave\n', '    if (tid == 0)\n        for (int i = 0; i < 16; ++i) atomicAdd(&g_sp_stamp[i], xst[i]);\n    // candidates scored by this workgroup: one atomic per wave\n')
