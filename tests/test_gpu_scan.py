@@ -39,6 +39,35 @@ def _scan_all(eps, g, node_w, thr=float("-inf"), columns=None):
     return {(int(k & 0xFFFFFFFF), int(k >> 32)): float(s) for k, s in zip(keys, vals)}, n_cand
 
 
+def _screen_all(eps, g, node_w, thr=float("-inf"), columns=None, variant=2):
+    """The same through the one-pass kernel (eps_scan_screen + exact re-scoring): {(u, v): score}, candidate count."""
+    from eps_amd import scan
+    sc = scan.screen_weights(g, g, None, node_w)
+    assert sc.usable
+    bounds, cuts = scan.screen_tables(g)
+    cols = scan.column_order(g) if columns is None else columns
+    cap = 2 * int(scan.half_paths(g)[cols.long()].sum().item()) + scan._PIECE_SLACK
+    res = eps.ops.Survivors(cap, thr, g.device)
+    status = torch.zeros(1, dtype=torch.int32, device=g.device)
+    eps.ops.scan_screen(g.rowptr, g.col, scan.reverse_positions(g), sc.fx32, cuts, bounds, g.n_rows, cols, sc.shift, res, status,
+                        variant, sc.val, sc.node_w)
+    slots, n_cand = res.counts()
+    assert slots <= res.capacity and int(status) == 0
+    keys, approx = res.valid(slots)
+    assert torch.unique(keys).numel() == keys.numel(), "a candidate was reported twice"
+    k2, v2 = scan.rescore_exact(g, sc, keys, None if thr == float("-inf") else torch.tensor([thr], device=g.device))
+    if keys.numel():
+        o1, o2 = torch.argsort(keys), torch.argsort(k2.where(k2 >= 0, keys.max() + 1 + torch.arange(k2.numel(), device=k2.device)))
+        live = k2 >= 0
+        # screening scores are upper bounds of the exact ones (that is what makes the screening lossless)
+        exact_of = dict(zip(k2[live].tolist(), v2[live].tolist()))
+        for kk, aa in zip(keys[:2000].tolist(), approx[:2000].tolist()):
+            if kk in exact_of:
+                assert aa >= exact_of[kk] * (1 - 1e-6) - 1e-6
+    m = k2 >= 0
+    return {(int(k & 0xFFFFFFFF), int(k >> 32)): float(x) for k, x in zip(k2[m].tolist(), v2[m].tolist())}, n_cand
+
+
 def _unit_graph(d):
     import scipy.sparse as ssp
     n = len(d["rowptr"]) - 1
@@ -101,6 +130,17 @@ def test_scan_bar_and_column_subsets(eps, oracle, dev, seed, scale, ef):
     cn_got, _ = _scan_all(eps, g, ones)
     want_cn = {(int(u), int(v)): float(c) for (u, v), c in zip(pairs[lower], cnt[lower])}
     assert cn_got == want_cn
+    # the one-pass kernel on the same inputs: whole set, a high bar, a column shard, unit weights
+    for variant in (2, 0):
+        got, n3 = _screen_all(eps, g, wt, variant=variant)
+        assert n3 == n_cand and got == full
+        bar = float(sc[int(0.99 * (len(sc) - 1))])
+        got, _ = _screen_all(eps, g, wt, thr=bar, variant=variant)
+        assert got == {k: s for k, s in full.items() if s > bar}
+        got, n4 = _screen_all(eps, g, wt, columns=order[1::3].contiguous(), variant=variant)
+        assert got == parts[1][0] and n4 == parts[1][1]
+        got, _ = _screen_all(eps, g, ones, variant=variant)
+        assert got == want_cn
 
 
 def test_scan_topk_is_exact(eps, oracle, dev, monkeypatch):
@@ -409,3 +449,12 @@ def test_scan_and_unit_lists_on_structured_graphs(eps, dev, name):
         return
     found, n_cand = _scan_all(eps, g, wt)
     assert n_cand == len(full) and found == full
+    # the one-pass kernel, every geometry (a star's hub is a multi-round row, the dense graphs overflow a piece's hash table
+    # into partitioned passes): the same survivors, bit-identical scores, with and without a bar
+    if scan.max_degree(g) < 1 << 16:
+        bar = sorted(full.values())[len(full) // 2] if full else 0.0
+        for variant in (2, 0, 1):
+            got, nc = _screen_all(eps, g, wt, variant=variant)
+            assert nc == len(full) and got == full, (name, variant)
+            got, nc = _screen_all(eps, g, wt, thr=bar, variant=variant)
+            assert nc == len(full) and got == {k: x for k, x in full.items() if x > bar}, (name, variant)
