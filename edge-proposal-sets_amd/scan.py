@@ -170,6 +170,8 @@ def screen_tables(g: CSRGraph):
     of equal stored-entry mass (so a column's paths spread evenly over them), and per row the number of entries below each
     boundary."""
     if "screen_tables" not in g._cache:
+        if max_degree(g) >= 1 << 16:
+            raise ops._lib.EpsError("screen_tables: the cut table counts a row's entries in 16 bits (max degree < 65536)")
         m = ops.scan_windows()
         n = g.n_rows
         cdeg = torch.cumsum(g.degree(), 0).to(torch.float64)

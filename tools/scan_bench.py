@@ -26,7 +26,7 @@ for rep in range(a.reps):
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
     print(f"scan_topk: {dt*1e3:.1f} ms  {st}  -> {st['candidates']/dt/1e9:.1f} G cand/s", flush=True)
 # kernel-only timing of the main launch at the final bar
-bar = st["bar"]
+bar = float(st["bar"]) if st["bar"] is not None else float("-inf")      # (r03: the bar stays on the device)
 order = scan.column_order(g)
 for rep in range(3):
     res = ops.Survivors(64 << 20, bar, dev)

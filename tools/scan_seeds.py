@@ -14,4 +14,4 @@ for seed in (4, 5, 6):
         p0, s0 = scan.scan_topk(g, w, 4_000_000, stats=st)
         g2 = synth.ppa_like(seed=seed, device=dev)          # a fresh graph object: relabelled path
         p1, s1 = scan.scan_topk(g2, w, 4_000_000, relabel=True)
-        print(seed, "AA" if mode == ops.W_AA else "RA", st["candidates"], st["bar"], st["survivors"], st["launches"], torch.equal(p0, p1) and torch.equal(s0, s1))
+        print(seed, "AA" if mode == ops.W_AA else "RA", st["candidates"], (None if st["bar"] is None else round(float(st["bar"]), 4)), st["survivors"], st["launches"], torch.equal(p0, p1) and torch.equal(s0, s1))
