@@ -29,8 +29,11 @@
 #define SP_EMPTY 0u             // an empty key word; a key is stored as id + 1, so a clean table is all zeros in BOTH modes
 #define SP_MAXP (SP_M + 1)
 #define SP_UBITS 8192           // units per range of the unit -> row bitmap (64 lanes x 128 bits: one uint4 per lane)
+#ifndef SP_SB
+#define SP_SB 4                 // uint4 reads a thread issues together in the table sweeps
+#endif
 #ifndef SP_G
-#define SP_G 2                  // units (of 4 entries) a lane looks up, loads and inserts together
+#define SP_G 1                  // units (of 4 entries) a lane looks up, loads and inserts together
 #endif
 
 typedef int sp_v4i __attribute__((ext_vector_type(4)));
@@ -44,6 +47,7 @@ struct sp_params {
     const float *node_w;        // float node weights (weighted graphs): a path's term is (A[u,w] * A[v,w]) * node_w[w]
     float up;                   // weighted graphs: 2^shift * (1 + 2^-20), the scale of the per-row factor
     const uint16_t *cuts;       // [n_nodes][SP_M]
+    const uint32_t *wpaths;     // [n_nodes][SP_M] two-hop half paths of column v per id window (per-graph table) or NULL
     const int32_t *bounds;      // [SP_M + 1]
     const int32_t *columns;
     int32_t n_columns;
@@ -115,6 +119,7 @@ __global__ __launch_bounds__(T, 4) void scan_piece_kernel(sp_params p)      // (
     __shared__ int32_t s_pk0[SP_MAXP], s_pk1[SP_MAXP];   // pieces: window run [k0, k1)
     __shared__ int32_t s_plo[SP_MAXP], s_phi[SP_MAXP];   // ... = ids [lo, hi) (hi cut at v)
     __shared__ uint32_t s_pinfo[SP_MAXP];    // paths of the piece | direct flag << 31
+    __shared__ int32_t s_pna[SP_MAXP], s_pnb[SP_MAXP];   // the neighbours of v with ids inside the piece's windows: vcol[na, nb)
     __shared__ int s_np;
     __shared__ unsigned int s_ticket;
     __shared__ unsigned int s_out_cur, s_out_end;
@@ -177,10 +182,15 @@ __global__ __launch_bounds__(T, 4) void scan_piece_kernel(sp_params p)      // (
         const int rounds = (dv + T - 1) / T;
         const bool single = rounds == 1;
         if (dv > 0 && v > 0) {
-            // ---- paths of the column per id window: sum over its rows of the row head's entries inside the window --------
-            if (tid < SP_M) s_pw[tid] = 0u;
+            // ---- paths of the column per id window: the per-graph table, or summed here over the column's rows ----------------
             uint32_t my_w = 0, my_rev = 0, my_base = 0, my_fx = 0;      // this thread's row (of the last round)
-            {
+            if (p.wpaths) {
+                if (single && tid < dv) {
+                    my_w = (uint32_t)vcol[tid];
+                    my_rev = (uint32_t)vrev[tid];
+                }
+            } else {
+                if (tid < SP_M) s_pw[tid] = 0u;
                 uint32_t cnt[SP_M];
 #pragma unroll
                 for (int k = 0; k < SP_M; ++k) cnt[k] = 0u;
@@ -217,15 +227,17 @@ __global__ __launch_bounds__(T, 4) void scan_piece_kernel(sp_params p)      // (
                         if (lane == 0 && s) atomicAdd(&s_pw[k], s);
                     }
                 }
-                if (single && tid < dv) {
-                    my_base = rowptr_lo[2 * (size_t)my_w];
-                    my_fx = HV ? __builtin_bit_cast(uint32_t, (p.val[vb + tid] * p.node_w[my_w]) * p.up) : p.fx32[my_w];
-                }
+                sp_barrier();
             }
-            sp_barrier();
+            if (single && tid < dv) {
+                my_base = rowptr_lo[2 * (size_t)my_w];
+                my_fx = HV ? __builtin_bit_cast(uint32_t, (p.val[vb + tid] * p.node_w[my_w]) * p.up) : p.fx32[my_w];
+            }
             // ---- plan: merge windows into pieces.  Wave 0, lane k = window k: the extents are ballots over monotone predicates -
             if (wib == 0) {
-                const uint32_t pwk = lane < SP_M ? s_pw[lane] : 0u;
+                const uint32_t pwk = lane < SP_M ? (p.wpaths ? p.wpaths[(size_t)v * SP_M + lane] : s_pw[lane]) : 0u;
+                // lane k: neighbours of v below window boundary k (row v's own cuts: cuts[v][k - 1]; 0 for k = 0)
+                const int32_t nbk = lane >= 1 && lane <= SP_M ? (int32_t)p.cuts[(size_t)v * SP_M + lane - 1] : 0;
                 const uint32_t ek = (uint32_t)sp_wave_incl_scan((int)pwk) - pwk;      // paths in the windows before k (lane 32: all)
                 // windows 0 .. kv hold ids below v
                 const int kv = __popcll(__ballot(lane >= 1 && lane < SP_M && my_bound <= v - 1));
@@ -255,6 +267,8 @@ __global__ __launch_bounds__(T, 4) void scan_piece_kernel(sp_params p)      // (
                             s_plo[np] = lo;
                             s_phi[np] = __builtin_amdgcn_readlane(hi_k, k1);
                             s_pinfo[np] = sum | flag;
+                            s_pna[np] = __builtin_amdgcn_readlane(nbk, k0);
+                            s_pnb[np] = __builtin_amdgcn_readlane(nbk, k1);
                         }
                         ++np;
                     }
@@ -267,6 +281,7 @@ __global__ __launch_bounds__(T, 4) void scan_piece_kernel(sp_params p)      // (
 
             for (int pi = 0; pi < np; ++pi) {
                 const int k0 = s_pk0[pi], k1 = s_pk1[pi];
+                const int na = s_pna[pi], nb = s_pnb[pi];
                 const uint32_t info = s_pinfo[pi];
                 const bool direct = (info >> 31) != 0u;
                 const uint32_t ppaths = info & 0x7FFFFFFFu;
@@ -469,7 +484,7 @@ __global__ __launch_bounds__(T, 4) void scan_piece_kernel(sp_params p)      // (
                         sp_barrier();        // the next round / the scan follows: descriptors and table updates are complete
                     }
                     // ---- known edges out: a neighbour of v is no candidate ------------------------------------------------
-                    for (int j = tid; j < dv; j += T) {
+                    for (int j = na + tid; j < nb; j += T) {     // (rows ascend: only the neighbours inside the windows)
                         const uint32_t u = (uint32_t)vcol[j];
                         if ((int32_t)u >= lo_id && (int32_t)u < hi_id) {
                             if (direct) {
@@ -506,30 +521,52 @@ __global__ __launch_bounds__(T, 4) void scan_piece_kernel(sp_params p)      // (
                             out_val[pos] = (float)sum * p.scale;
                         }
                     };
+                    // (the sweeps read in batches of SP_SB uint4 per thread before they look at any of them: one LDS round trip per
+                    //  batch instead of one per 16 bytes; the trip counts are uniform over the workgroup)
                     uint32_t cnt_here = 0u;
                     if (direct) {
                         const uint32_t n4 = (scan_slots + 3u) & ~3u;
-                        for (uint32_t i = 4u * tid; i < n4; i += 4u * T) {
-                            const uint4 s4 = *(const uint4 *)(lds + i);
-                            *(uint4 *)(lds + i) = make_uint4(0u, 0u, 0u, 0u);
-                            const uint32_t sv[4] = {s4.x, s4.y, s4.z, s4.w};
+                        for (uint32_t i0 = 0; i0 < n4; i0 += 4u * SP_SB * T) {
+                            uint4 s4[SP_SB];
 #pragma unroll
-                            for (int e = 0; e < 4; ++e)
-                                if (sv[e]) {
-                                    ++cnt_here;
-                                    if (sv[e] >= thr32) emit((uint32_t)lo_id + i + e, sv[e]);
-                                }
+                            for (int b = 0; b < SP_SB; ++b) {
+                                const uint32_t i = i0 + 4u * T * b + 4u * tid;
+                                s4[b] = i < n4 ? *(const uint4 *)(lds + i) : make_uint4(0u, 0u, 0u, 0u);
+                            }
+#pragma unroll
+                            for (int b = 0; b < SP_SB; ++b) {
+                                const uint32_t i = i0 + 4u * T * b + 4u * tid;
+                                if (i < n4) *(uint4 *)(lds + i) = make_uint4(0u, 0u, 0u, 0u);
+                                const uint32_t sv[4] = {s4[b].x, s4[b].y, s4[b].z, s4[b].w};
+#pragma unroll
+                                for (int e = 0; e < 4; ++e)
+                                    if (sv[e]) {
+                                        ++cnt_here;
+                                        if (sv[e] >= thr32) emit((uint32_t)lo_id + i + e, sv[e]);
+                                    }
+                            }
                         }
                     } else {
                         // (the candidates were counted when their keys went in; the key words are only read for a survivor)
-                        for (uint32_t i = 4u * tid; i < scan_slots; i += 4u * T) {
-                            const uint4 s4 = *(const uint4 *)(tval + i);
-                            const uint32_t sv[4] = {s4.x, s4.y, s4.z, s4.w};
+                        for (uint32_t i0 = 0; i0 < scan_slots; i0 += 4u * SP_SB * T) {
+                            uint4 s4[SP_SB];
 #pragma unroll
-                            for (int e = 0; e < 4; ++e)
-                                if (sv[e] >= thr32) emit(tkey[i + e] - 1u, sv[e]);
-                            *(uint4 *)(tkey + i) = make_uint4(0u, 0u, 0u, 0u);
-                            *(uint4 *)(tval + i) = make_uint4(0u, 0u, 0u, 0u);
+                            for (int b = 0; b < SP_SB; ++b) {
+                                const uint32_t i = i0 + 4u * T * b + 4u * tid;
+                                s4[b] = i < scan_slots ? *(const uint4 *)(tval + i) : make_uint4(0u, 0u, 0u, 0u);
+                            }
+#pragma unroll
+                            for (int b = 0; b < SP_SB; ++b) {
+                                const uint32_t i = i0 + 4u * T * b + 4u * tid;
+                                const uint32_t sv[4] = {s4[b].x, s4[b].y, s4[b].z, s4[b].w};
+#pragma unroll
+                                for (int e = 0; e < 4; ++e)
+                                    if (sv[e] >= thr32) emit(tkey[i + e] - 1u, sv[e]);
+                                if (i < scan_slots) {
+                                    *(uint4 *)(tkey + i) = make_uint4(0u, 0u, 0u, 0u);
+                                    *(uint4 *)(tval + i) = make_uint4(0u, 0u, 0u, 0u);
+                                }
+                            }
                         }
                     }
                     n_cand += (unsigned long long)cnt_here + (unsigned long long)(long long)(int32_t)new_keys;   // (may be negative per thread)
@@ -569,6 +606,50 @@ __global__ void sp_cuts_kernel(const int64_t *__restrict__ rowptr, const int32_t
             if (col[mid] < bound) lo = mid + 1; else hi = mid;
         }
         cuts[i] = (uint16_t)(lo - wb);
+    }
+}
+
+// wpaths[v][k] = two-hop half paths of column v that end in id window k: the sum over v's rows of the row head's entries
+// inside the window (exact, from the cut table).  One wave per column; the scan's planner then reads 128 bytes per column
+// instead of a cut row per (column, neighbour).
+__global__ void sp_window_paths_kernel(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+                                       const int32_t *__restrict__ revpos, const uint16_t *__restrict__ cuts, int64_t n_nodes,
+                                       uint32_t *__restrict__ wpaths)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t v = wave; v < n_nodes; v += n_waves) {
+        const int64_t b = rowptr[v], e = rowptr[v + 1];
+        uint32_t cnt[SP_M];
+#pragma unroll
+        for (int k = 0; k < SP_M; ++k) cnt[k] = 0u;
+        for (int64_t i = b + lane; i < e; i += 64) {
+            const uint32_t rev = (uint32_t)revpos[i];
+            const uint4 *row = (const uint4 *)(cuts + (size_t)col[i] * SP_M);
+            uint32_t prev = 0u;
+#pragma unroll
+            for (int q = 0; q < SP_M / 8; ++q) {
+                const uint4 c = row[q];
+                const uint32_t wds[4] = {c.x, c.y, c.z, c.w};
+#pragma unroll
+                for (int h = 0; h < 4; ++h) {
+                    uint32_t a = wds[h] & 0xFFFFu, bb = wds[h] >> 16;
+                    a = a < rev ? a : rev;
+                    bb = bb < rev ? bb : rev;
+                    cnt[q * 8 + h * 2] += a - prev;
+                    cnt[q * 8 + h * 2 + 1] += bb - a;
+                    prev = bb;
+                }
+            }
+        }
+        uint32_t mine = 0u;
+#pragma unroll
+        for (int k = 0; k < SP_M; ++k) {
+            const uint32_t s = sp_wave_sum(cnt[k]);
+            if (lane == k) mine = s;
+        }
+        if (lane < SP_M) wpaths[v * SP_M + lane] = mine;
     }
 }
 
@@ -855,6 +936,21 @@ extern "C" int eps_scan_cuts(const int64_t *rowptr, const int32_t *col, int64_t 
     return EPS_OK;
 }
 
+extern "C" int eps_scan_window_paths(const int64_t *rowptr, const int32_t *col, const int32_t *revpos, const uint16_t *cuts,
+                                     int64_t n_nodes, uint32_t *wpaths, void *stream)
+{
+    EPS_REQUIRE(n_nodes >= 0, "eps_scan_window_paths: negative size");
+    if (n_nodes == 0) return EPS_OK;
+    EPS_REQUIRE(rowptr && col && revpos && cuts && wpaths && ((uintptr_t)cuts & 15) == 0, "eps_scan_window_paths: null or misaligned pointer");
+    int64_t blocks = (n_nodes + 3) / 4;
+    const int64_t cap = (int64_t)eps_num_cus() * 16;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(sp_window_paths_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, rowptr, col, revpos, cuts,
+                       n_nodes, wpaths);
+    EPS_CHECK_LAUNCH("eps_scan_window_paths");
+    return EPS_OK;
+}
+
 extern "C" int eps_scan_screen_weights(const int64_t *fixw, int64_t n, int32_t shift, uint32_t *fx32, uint32_t *bad,
                                        void *stream)
 {
@@ -879,34 +975,35 @@ extern "C" int eps_scan_screen_weights(const int64_t *fixw, int64_t n, int32_t s
 // variant: 0 = 512 threads, 8192-slot table (two workgroups per CU); 1 = 1024 threads, 16384 slots (one per CU);
 //          2 = 256 threads, 4096 slots (four per CU)
 static int sp_launch(const int64_t *rowptr, const int32_t *col, const float *val, const int32_t *revpos, const uint32_t *fx32,
-                     const float *node_w, const uint16_t *cuts, const int32_t *bounds, int64_t n_nodes, int64_t nnz,
-                     const int32_t *columns, int64_t n_columns, int32_t shift, int32_t variant, eps_survivors *out,
+                     const float *node_w, const uint16_t *cuts, const uint32_t *wpaths, const int32_t *bounds, int64_t n_nodes,
+                     int64_t nnz, const int32_t *columns, int64_t n_columns, int32_t shift, int32_t variant, eps_survivors *out,
                      uint32_t *status, void *stream);
 
 extern "C" int eps_scan_screen(const int64_t *rowptr, const int32_t *col, const int32_t *revpos, const uint32_t *fx32,
-                               const uint16_t *cuts, const int32_t *bounds, int64_t n_nodes, int64_t nnz,
-                               const int32_t *columns, int64_t n_columns, int32_t shift, int32_t variant,
+                               const uint16_t *cuts, const uint32_t *wpaths_or_null, const int32_t *bounds, int64_t n_nodes,
+                               int64_t nnz, const int32_t *columns, int64_t n_columns, int32_t shift, int32_t variant,
                                eps_survivors *out, uint32_t *status, void *stream)
 {
     EPS_REQUIRE(n_columns == 0 || n_nodes == 0 || fx32, "eps_scan_screen: null pointer");
-    return sp_launch(rowptr, col, nullptr, revpos, fx32, nullptr, cuts, bounds, n_nodes, nnz, columns, n_columns, shift, variant, out,
-                     status, stream);
+    return sp_launch(rowptr, col, nullptr, revpos, fx32, nullptr, cuts, wpaths_or_null, bounds, n_nodes, nnz, columns, n_columns, shift,
+                     variant, out, status, stream);
 }
 
 // The same scan on a SYMMETRIC adjacency with stored values (val[e] == val[mirror of e]); node_w = the float node weights.
 extern "C" int eps_scan_screen_weighted(const int64_t *rowptr, const int32_t *col, const float *val, const int32_t *revpos,
-                                        const float *node_w, const uint16_t *cuts, const int32_t *bounds, int64_t n_nodes,
-                                        int64_t nnz, const int32_t *columns, int64_t n_columns, int32_t shift, int32_t variant,
-                                        eps_survivors *out, uint32_t *status, void *stream)
+                                        const float *node_w, const uint16_t *cuts, const uint32_t *wpaths_or_null,
+                                        const int32_t *bounds, int64_t n_nodes, int64_t nnz, const int32_t *columns,
+                                        int64_t n_columns, int32_t shift, int32_t variant, eps_survivors *out, uint32_t *status,
+                                        void *stream)
 {
     EPS_REQUIRE(n_columns == 0 || n_nodes == 0 || (val && node_w), "eps_scan_screen_weighted: null pointer");
-    return sp_launch(rowptr, col, val, revpos, nullptr, node_w, cuts, bounds, n_nodes, nnz, columns, n_columns, shift, variant, out,
-                     status, stream);
+    return sp_launch(rowptr, col, val, revpos, nullptr, node_w, cuts, wpaths_or_null, bounds, n_nodes, nnz, columns, n_columns, shift,
+                     variant, out, status, stream);
 }
 
 static int sp_launch(const int64_t *rowptr, const int32_t *col, const float *val, const int32_t *revpos, const uint32_t *fx32,
-                     const float *node_w, const uint16_t *cuts, const int32_t *bounds, int64_t n_nodes, int64_t nnz,
-                     const int32_t *columns, int64_t n_columns, int32_t shift, int32_t variant, eps_survivors *out,
+                     const float *node_w, const uint16_t *cuts, const uint32_t *wpaths, const int32_t *bounds, int64_t n_nodes,
+                     int64_t nnz, const int32_t *columns, int64_t n_columns, int32_t shift, int32_t variant, eps_survivors *out,
                      uint32_t *status, void *stream)
 {
     EPS_REQUIRE(n_nodes >= 0 && n_columns >= 0 && nnz >= 0, "eps_scan_screen: negative size");
@@ -937,6 +1034,7 @@ static int sp_launch(const int64_t *rowptr, const int32_t *col, const float *val
     p.node_w = node_w;
     p.up = ldexpf(1.0f, shift) * (1.0f + ldexpf(1.0f, -20));
     p.cuts = cuts;
+    p.wpaths = wpaths;
     p.bounds = bounds;
     p.columns = columns;
     p.n_columns = (int32_t)n_columns;

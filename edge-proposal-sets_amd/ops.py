@@ -498,6 +498,18 @@ def scan_cuts(rowptr: torch.Tensor, col: torch.Tensor, bounds: torch.Tensor) -> 
     return out
 
 
+def scan_window_paths(rowptr, col, revpos, cuts) -> torch.Tensor:
+    """uint32 table [N, M] (int32 bits): two-hop half paths of every column per id window (per-graph table of the scan)."""
+    dev = _need_gpu(rowptr, col, revpos, cuts)
+    _chk(rowptr, torch.int64, "rowptr"); _chk(col, torch.int32, "col"); _chk(revpos, torch.int32, "revpos"); _chk(cuts, torch.int16, "cuts")
+    n = rowptr.numel() - 1
+    out = torch.empty((n, scan_windows()), dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.load().eps_scan_window_paths(_ptr(rowptr), _ptr(col), _ptr(revpos), _ptr(cuts), n, _ptr(out), _stream(dev)),
+                   "eps_scan_window_paths")
+    return out
+
+
 def scan_screen_weights(fixw: torch.Tensor, shift: int):
     """(fx32 int32-bits[N], bad int32[1]): the scan's fixed-point weights rounded UP to 2^-shift (at least 1)."""
     dev = _need_gpu(fixw)
@@ -538,10 +550,13 @@ SCAN_VARIANT = 2          # default workgroup / table geometry of eps_scan_scree
 
 def scan_screen(rowptr, col, revpos, fx32, cuts, bounds, n_nodes: int, columns: torch.Tensor, shift: int, out: "Survivors",
                 status: torch.Tensor, variant: Optional[int] = None, val: Optional[torch.Tensor] = None,
-                node_w: Optional[torch.Tensor] = None) -> None:
+                node_w: Optional[torch.Tensor] = None, wpaths: Optional[torch.Tensor] = None) -> None:
     """Launch eps_scan_screen over ``columns``; survivors (screening scores) accumulate in ``out``.  ``val`` / ``node_w``
     (float32 stored values / node weights): the weighted flavour (eps_scan_screen_weighted; ``fx32`` unused)."""
-    dev = _need_gpu(rowptr, col, revpos, fx32, cuts, bounds, columns, status, val, node_w)
+    dev = _need_gpu(rowptr, col, revpos, fx32, cuts, bounds, columns, status, val, node_w, wpaths)
+    _chk(wpaths, torch.int32, "wpaths")
+    if wpaths is not None and tuple(wpaths.shape) != (n_nodes, scan_windows()):
+        raise _lib.EpsError("scan_screen: wpaths does not match the graph")
     _chk(rowptr, torch.int64, "rowptr"); _chk(col, torch.int32, "col"); _chk(revpos, torch.int32, "revpos")
     _chk(fx32, torch.int32, "fx32"); _chk(cuts, torch.int16, "cuts"); _chk(bounds, torch.int32, "bounds")
     _chk(columns, torch.int32, "columns"); _chk(status, torch.int32, "status"); _chk(val, torch.float32, "val")
@@ -558,12 +573,12 @@ def scan_screen(rowptr, col, revpos, fx32, cuts, bounds, n_nodes: int, columns: 
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev[0].record(torch.cuda.current_stream(dev))
         if val is None:
-            _lib.check(lib.eps_scan_screen(_ptr(rowptr), _ptr(col), _ptr(revpos), _ptr(fx32), _ptr(cuts), _ptr(bounds), n_nodes,
+            _lib.check(lib.eps_scan_screen(_ptr(rowptr), _ptr(col), _ptr(revpos), _ptr(fx32), _ptr(cuts), _ptr(wpaths), _ptr(bounds), n_nodes,
                                            col.numel(), _ptr(columns), columns.numel(), int(shift), variant, _ptr(out.rec), _ptr(status),
                                            _stream(dev)), "eps_scan_screen")
         else:
             _lib.check(lib.eps_scan_screen_weighted(_ptr(rowptr), _ptr(col), _ptr(val), _ptr(revpos), _ptr(node_w), _ptr(cuts),
-                                                    _ptr(bounds), n_nodes, col.numel(), _ptr(columns), columns.numel(), int(shift),
+                                                    _ptr(wpaths), _ptr(bounds), n_nodes, col.numel(), _ptr(columns), columns.numel(), int(shift),
                                                     variant, _ptr(out.rec), _ptr(status), _stream(dev)), "eps_scan_screen_weighted")
         if ev is not None:
             ev[1].record(torch.cuda.current_stream(dev))

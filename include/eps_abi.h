@@ -213,6 +213,8 @@ int eps_filter_scan(const int64_t *rowptr, const int32_t *col, const int32_t *re
  *   eps_scan_cuts         : cuts[w * M + k] = entries of row w with id < bounds[k + 1] (uint16; 16-byte aligned), for the
  *                           caller's window boundaries bounds[0 .. M] (bounds[0] = 0, bounds[M] = n_nodes, non-decreasing;
  *                           windows of equal stored-entry mass balance the pieces).  Per-graph table.
+ *   eps_scan_window_paths : wpaths[v * M + k] = two-hop half paths of column v that end in id window k (uint32; exact, from
+ *                           the cut table).  Per-graph table, optional: with NULL the scan sums them per column itself.
  *   eps_scan_screen_weights: fx32[i] = max(1, ceil(fixw[i] / 2^(40 - shift))); *bad (device word, cleared by the call):
  *                           bit 1 a negative weight, bit 2 a weight that does not fit 32 bits.  shift must keep every
  *                           screening sum of the graph below 2^32 (the caller's score bound: eps_amd.scan.screen_shift).
@@ -232,18 +234,21 @@ int eps_rescore_weighted(const int64_t *rowptr, const int32_t *col, const float 
 int eps_scan_cuts(const int64_t *rowptr, const int32_t *col, int64_t n_nodes, const int32_t *bounds, uint16_t *cuts,
                   void *stream);
 int eps_scan_screen_weights(const int64_t *fixw, int64_t n, int32_t shift, uint32_t *fx32, uint32_t *bad, void *stream);
+int eps_scan_window_paths(const int64_t *rowptr, const int32_t *col, const int32_t *revpos, const uint16_t *cuts,
+                          int64_t n_nodes, uint32_t *wpaths, void *stream);
 int eps_scan_screen(const int64_t *rowptr, const int32_t *col, const int32_t *revpos, const uint32_t *fx32,
-                    const uint16_t *cuts, const int32_t *bounds, int64_t n_nodes, int64_t nnz, const int32_t *columns,
-                    int64_t n_columns, int32_t shift, int32_t variant, eps_survivors *out, uint32_t *status, void *stream);
+                    const uint16_t *cuts, const uint32_t *wpaths_or_null, const int32_t *bounds, int64_t n_nodes, int64_t nnz,
+                    const int32_t *columns, int64_t n_columns, int32_t shift, int32_t variant, eps_survivors *out,
+                    uint32_t *status, void *stream);
 /* eps_scan_screen_weighted: the scan on a SYMMETRIC adjacency WITH stored values (collab: rank.py:32-35 keeps the summed
  * multi-edge weights; val[e] must equal the value of e's mirror entry and be positive).  A path's term is
  * (A[u,w] * A[v,w]) * node_w[w] -- symmetric in (u, v), so the half scheme holds -- and its screening weight is formed per
  * path from the float values, rounded up.  node_w = the float32 node weights (no fx32 table); re-score with
  * eps_rescore_weighted. */
 int eps_scan_screen_weighted(const int64_t *rowptr, const int32_t *col, const float *val, const int32_t *revpos,
-                             const float *node_w, const uint16_t *cuts, const int32_t *bounds, int64_t n_nodes, int64_t nnz,
-                             const int32_t *columns, int64_t n_columns, int32_t shift, int32_t variant, eps_survivors *out,
-                             uint32_t *status, void *stream);
+                             const float *node_w, const uint16_t *cuts, const uint32_t *wpaths_or_null, const int32_t *bounds,
+                             int64_t n_nodes, int64_t nnz, const int32_t *columns, int64_t n_columns, int32_t shift,
+                             int32_t variant, eps_survivors *out, uint32_t *status, void *stream);
 
 /* ---- the candidate list of a block of columns of a graph WITHOUT stored values, on the scan kernel's structure ----------
  * Same results as eps_expand_count / eps_expand_fill above (filter.py:96-109: every 2-hop non-edge of columns

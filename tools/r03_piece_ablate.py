@@ -6,13 +6,8 @@ import ctypes, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "edge-proposal-sets_amd", "csrc")
 ABL = {
-    # table load factors: a hash piece holds up to num/den of its table's slots (product: 1/2)
-    "lf_3_4": [("    p.piece_paths = (1u << bits) / 2u;", "    p.piece_paths = (1u << bits) * 3u / 4u;"),
-               ("                    while (bits < p.table_bits && (1u << bits) < 2u * per) ++bits;", "                    while (bits < p.table_bits && (1u << bits) * 3u < 4u * per) ++bits;")],
-    "lf_5_8": [("    p.piece_paths = (1u << bits) / 2u;", "    p.piece_paths = (1u << bits) * 5u / 8u;"),
-               ("                    while (bits < p.table_bits && (1u << bits) < 2u * per) ++bits;", "                    while (bits < p.table_bits && (1u << bits) * 5u < 8u * per) ++bits;")],
-    "lf_3_8": [("    p.piece_paths = (1u << bits) / 2u;", "    p.piece_paths = (1u << bits) * 3u / 8u;"),
-               ("                    while (bits < p.table_bits && (1u << bits) < 2u * per) ++bits;", "                    while (bits < p.table_bits && (1u << bits) * 3u < 8u * per) ++bits;")],
+    "sb1": [("#define SP_SB 4 ", "#define SP_SB 1 ")],
+    "sb2": [("#define SP_SB 4 ", "#define SP_SB 2 ")],
 }
 
 def build():
@@ -59,7 +54,7 @@ def run():
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 rc = lib.eps_scan_screen(g.rowptr.data_ptr(), g.col.data_ptr(), scan.reverse_positions(g).data_ptr(), fx32.data_ptr(), cuts.data_ptr(),
-                                         bounds.data_ptr(), g.n_rows, g.nnz(), order.data_ptr(), order.numel(), shift, variant, res.rec.data_ptr(),
+                                         scan.window_paths(g).data_ptr(), bounds.data_ptr(), g.n_rows, g.nnz(), order.data_ptr(), order.numel(), shift, variant, res.rec.data_ptr(),
                                          status.data_ptr(), torch.cuda.current_stream().cuda_stream)
                 e1.record(); torch.cuda.synchronize()
                 assert rc == 0

@@ -85,7 +85,7 @@ def run():
             lib.eps_debug_piece_stamps(buf, 1)
         e0.record()
         rc = lib.eps_scan_screen(g.rowptr.data_ptr(), g.col.data_ptr(), scan.reverse_positions(g).data_ptr(), fx32.data_ptr(), cuts.data_ptr(),
-                                 bounds.data_ptr(), g.n_rows, g.nnz(), order.data_ptr(), order.numel(), shift, variant, res.rec.data_ptr(),
+                                 scan.window_paths(g).data_ptr(), bounds.data_ptr(), g.n_rows, g.nnz(), order.data_ptr(), order.numel(), shift, variant, res.rec.data_ptr(),
                                  status.data_ptr(), torch.cuda.current_stream().cuda_stream)
         e1.record(); torch.cuda.synchronize()
         assert rc == 0

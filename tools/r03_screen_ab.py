@@ -47,7 +47,7 @@ for variant in [int(x) for x in os.environ.get("VARIANTS", "0,1,2").split(",")]:
     for _ in range(reps):
         res = ops.Survivors(cap, bar, dev)
         status = torch.zeros(1, dtype=torch.int32, device=dev)
-        t, _ = timed(lambda: ops.scan_screen(g.rowptr, g.col, scan.reverse_positions(g), fx32, cuts, bounds, g.n_rows, order, shift, res, status, variant))
+        t, _ = timed(lambda: ops.scan_screen(g.rowptr, g.col, scan.reverse_positions(g), fx32, cuts, bounds, g.n_rows, order, shift, res, status, variant, wpaths=scan.window_paths(g)))
         ts.append(t)
     slots, nc2 = res.counts()
     keys, vals = res.valid(slots)

@@ -23,7 +23,7 @@ for _ in range(int(os.environ.get("REPS", "1"))):
     res = ops.Survivors(64 << 20, bar, dev)
     if kernel == "pieces":
         status = torch.zeros(1, dtype=torch.int32, device=dev)
-        ops.scan_screen(g.rowptr, g.col, scan.reverse_positions(g), fx32, cuts, bounds, g.n_rows, order, shift, res, status, variant)
+        ops.scan_screen(g.rowptr, g.col, scan.reverse_positions(g), fx32, cuts, bounds, g.n_rows, order, shift, res, status, variant, wpaths=scan.window_paths(g))
     else:
         ops.filter_scan(g.rowptr, g.col, scan.reverse_positions(g), fixw, g.n_rows, order, res, scan.max_degree(g), scan.window_splits(g))
 torch.cuda.synchronize()
