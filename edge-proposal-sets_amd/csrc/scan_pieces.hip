@@ -28,6 +28,7 @@
 #define SP_M 32                 // id windows per graph (one 64-byte row of cuts per node)
 #define SP_EMPTY 0u             // an empty key word; a key is stored as id + 1, so a clean table is all zeros in BOTH modes
 #define SP_MAXP (SP_M + 1)
+#define SP_FLAG 0x80000000u      // value word of a KNOWN EDGE's endpoint (put in before the walk): sums stay below 2^31, so the bit survives them
 #define SP_UBITS 8192           // units per range of the unit -> row bitmap (64 lanes x 128 bits: one uint4 per lane)
 #ifndef SP_SB
 #define SP_SB 4                 // uint4 reads a thread issues together in the table sweeps
@@ -141,7 +142,7 @@ __global__ __launch_bounds__(T, 4) void scan_piece_kernel(sp_params p)      // (
         const float thr = p.out->threshold;
         auto above = [&](long long a) { return (float)((double)a * (1.0 / (double)(1ll << 40))) > thr; };
         if (!above(0x7fffffffffffffffll)) {
-            thr32 = 0xFFFFFFFFu;                      // +inf / NaN bar: nothing passes (sums stay below 2^32 - 1)
+            thr32 = SP_FLAG;                          // +inf / NaN bar: nothing passes (sums stay below 2^31)
         } else if (!above(0ll)) {
             long long lo = 1ll, hi = 0x7fffffffffffffffll;      // smallest positive a with above(a)
             while (lo < hi) {
@@ -149,7 +150,7 @@ __global__ __launch_bounds__(T, 4) void scan_piece_kernel(sp_params p)      // (
                 if (above(mid)) hi = mid; else lo = mid + 1;
             }
             const unsigned long long q = (unsigned long long)lo >> (40 - p.shift);
-            thr32 = q > 0xFFFFFFFEull ? 0xFFFFFFFFu : (q ? (uint32_t)q : 1u);
+            thr32 = q >= (unsigned long long)SP_FLAG ? SP_FLAG : (q ? (uint32_t)q : 1u);
         }
     }
     const uint32_t direct_ids = 2u * (uint32_t)slots;
@@ -166,7 +167,7 @@ __global__ __launch_bounds__(T, 4) void scan_piece_kernel(sp_params p)      // (
         s_out_end = 0u;
     }
     unsigned long long n_cand = 0;           // candidates seen by this thread
-    uint32_t new_keys = 0u;                  // ... of the current hash piece: keys this thread inserted, minus known edges it struck
+    uint32_t new_keys = 0u;                  // ... of the current hash piece: candidate keys this thread inserted
     const unsigned int ncol = (unsigned int)p.n_columns;
     unsigned int t = blockIdx.x;
     sp_barrier();
@@ -248,7 +249,9 @@ __global__ __launch_bounds__(T, 4) void scan_piece_kernel(sp_params p)      // (
                     const uint32_t e0 = (uint32_t)__builtin_amdgcn_readlane((int)ek, k0);
                     const bool in = lane > k0 && lane <= kv + 1;
                     const int kd = k0 + __popcll(__ballot(in && (uint32_t)(hi_k - lo) <= direct_ids));
-                    const int kh = k0 + __popcll(__ballot(in && ek - e0 <= p.piece_paths));
+                    const int32_t nb0 = __builtin_amdgcn_readlane(nbk, k0);
+                    // (the known edges of v inside a hash piece own slots too: they count toward its limit)
+                    const int kh = k0 + __popcll(__ballot(in && (ek - e0) + (uint32_t)(nbk - nb0) <= p.piece_paths));
                     int k1;
                     uint32_t flag = 0u;
                     if (kd >= kh && kd > k0) {
@@ -287,13 +290,14 @@ __global__ __launch_bounds__(T, 4) void scan_piece_kernel(sp_params p)      // (
                 const uint32_t ppaths = info & 0x7FFFFFFFu;
                 const int32_t lo_id = s_plo[pi], hi_id = s_phi[pi];
                 // hash geometry: the smallest power-of-two table with load <= 1/2; a heavier single window goes in `parts` passes
+                const uint32_t pkeys = ppaths + (uint32_t)(nb - na);           // slots the piece can need: paths + known edges
                 uint32_t parts = 1u;
                 if (!direct)
-                    while (ppaths > p.piece_paths * parts) parts <<= 1;
+                    while (pkeys > p.piece_paths * parts) parts <<= 1;
                 if (parts > 1u) parts <<= 1;                             // (random split: aim at a quarter load)
                 int bits = 10;
                 {
-                    const uint32_t per = (ppaths + parts - 1) / parts;
+                    const uint32_t per = (pkeys + parts - 1) / parts;
                     while (bits < p.table_bits && (1u << bits) < 2u * per) ++bits;
                 }
                 const uint32_t mask = (1u << bits) - 1u;
@@ -310,6 +314,31 @@ __global__ __launch_bounds__(T, 4) void scan_piece_kernel(sp_params p)      // (
                     }
                 }
                 for (uint32_t part = 0; part < parts; ++part) {
+                    // ---- known edges in: the neighbours of v inside the piece take their slots BEFORE the walk, with the flag bit
+                    // in the value word -- whatever the paths add on top, the sweep sees that this id is no candidate (rows ascend:
+                    // the neighbours inside the piece's windows are vcol[na, nb)).  The first barrier of the describe orders this
+                    // against the walk.
+                    for (int j = na + tid; j < nb; j += T) {
+                        const uint32_t u = (uint32_t)vcol[j];
+                        if ((int32_t)u >= lo_id && (int32_t)u < hi_id) {
+                            if (direct) {
+                                lds[u - (uint32_t)lo_id] = SP_FLAG;
+                            } else {
+                                const uint32_t mix = sp_mix(u);
+                                if ((mix & (parts - 1u)) == part) {
+                                    uint32_t h = mix >> (32 - bits);
+                                    const uint32_t st = ((mix >> 7) | 1u) & mask;
+                                    for (uint32_t tries = 0; tries <= mask; ++tries) {
+                                        if (atomicCAS(&tkey[h], SP_EMPTY, u + 1u) == SP_EMPTY) {
+                                            tval[h] = SP_FLAG;
+                                            break;
+                                        }
+                                        h = (h + st) & mask;
+                                    }
+                                }
+                            }
+                        }
+                    }
                     for (int r = 0; r < rounds; ++r) {
                         // ---- describe the round's row segments inside the piece ------------------------------------------
                         const int j = r * T + tid;
@@ -427,16 +456,21 @@ __global__ __launch_bounds__(T, 4) void scan_piece_kernel(sp_params p)      // (
                                         if (e < f[q].nvalid) atomicAdd(&lds[(uint32_t)(f[q].u4[e] - lo_id)], path_fx(f[q], e));
                             } else {
                                 constexpr int E = 4 * SP_G;
-                                uint32_t key[E], h[E], st[E];
+                                uint32_t key[E], h[E], mixv[E];
                                 uint32_t pend = 0u;
+#pragma unroll
+                                for (int q = 0; q < SP_G; ++q) pend |= ((1u << f[q].nvalid) - 1u) << (4 * q);
 #pragma unroll
                                 for (int i = 0; i < E; ++i) {
                                     const uint32_t id = (uint32_t)f[i >> 2].u4[i & 3];
-                                    const uint32_t mix = sp_mix(id);
+                                    mixv[i] = sp_mix(id);
                                     key[i] = id + 1u;
-                                    h[i] = (mix >> (32 - bits)) & mask;
-                                    st[i] = ((mix >> 7) | 1u) & mask;
-                                    if ((i & 3) < f[i >> 2].nvalid && (mix & (parts - 1u)) == part) pend |= 1u << i;
+                                    h[i] = mixv[i] >> (32 - bits);           // (the probe step is only formed on a collision)
+                                }
+                                if (parts > 1u) {                            // (uniform: a partitioned window keeps its own pass's ids)
+#pragma unroll
+                                    for (int i = 0; i < E; ++i)
+                                        if ((mixv[i] & (parts - 1u)) != part) pend &= ~(1u << i);
                                 }
                                 uint32_t tries = 0;
                                 while (__ballot(pend != 0u)) {
@@ -452,7 +486,7 @@ __global__ __launch_bounds__(T, 4) void scan_piece_kernel(sp_params p)      // (
                                                 pend &= ~(1u << i);
                                                 new_keys += old[i] == SP_EMPTY ? 1u : 0u;      // a candidate seen for the first time
                                             } else {
-                                                h[i] = (h[i] + st[i]) & mask;
+                                                h[i] = (h[i] + (((mixv[i] >> 7) | 1u) & mask)) & mask;
                                             }
                                         }
                                     if (++tries > mask + 1u) {           // the table is full (backstop; never within the piece limits)
@@ -483,32 +517,6 @@ __global__ __launch_bounds__(T, 4) void scan_piece_kernel(sp_params p)      // (
                         }
                         sp_barrier();        // the next round / the scan follows: descriptors and table updates are complete
                     }
-                    // ---- known edges out: a neighbour of v is no candidate ------------------------------------------------
-                    for (int j = na + tid; j < nb; j += T) {     // (rows ascend: only the neighbours inside the windows)
-                        const uint32_t u = (uint32_t)vcol[j];
-                        if ((int32_t)u >= lo_id && (int32_t)u < hi_id) {
-                            if (direct) {
-                                lds[u - (uint32_t)lo_id] = 0u;
-                            } else {
-                                const uint32_t mix = sp_mix(u);
-                                if ((mix & (parts - 1u)) == part) {
-                                    uint32_t h = (mix >> (32 - bits)) & mask;
-                                    const uint32_t st = ((mix >> 7) | 1u) & mask;
-                                    for (uint32_t tries = 0; tries <= mask; ++tries) {
-                                        const uint32_t k = tkey[h];
-                                        if (k == u + 1u) {
-                                            if (tval[h]) --new_keys;                 // (a neighbour of v: no candidate after all)
-                                            tval[h] = 0u;
-                                            break;
-                                        }
-                                        if (k == SP_EMPTY) break;
-                                        h = (h + st) & mask;
-                                    }
-                                }
-                            }
-                        }
-                    }
-                    sp_barrier();
                     // ---- scan the table: count the candidates, report the survivors, leave it clean --------------------------
                     auto emit = [&](uint32_t u, uint32_t sum) {
                         uint32_t pos = atomicAdd(&s_out_cur, 1u);
@@ -540,7 +548,7 @@ __global__ __launch_bounds__(T, 4) void scan_piece_kernel(sp_params p)      // (
                                 const uint32_t sv[4] = {s4[b].x, s4[b].y, s4[b].z, s4[b].w};
 #pragma unroll
                                 for (int e = 0; e < 4; ++e)
-                                    if (sv[e]) {
+                                    if (sv[e] - 1u < SP_FLAG - 1u) {          // reached (non-zero) and not a known edge
                                         ++cnt_here;
                                         if (sv[e] >= thr32) emit((uint32_t)lo_id + i + e, sv[e]);
                                     }
@@ -561,7 +569,7 @@ __global__ __launch_bounds__(T, 4) void scan_piece_kernel(sp_params p)      // (
                                 const uint32_t sv[4] = {s4[b].x, s4[b].y, s4[b].z, s4[b].w};
 #pragma unroll
                                 for (int e = 0; e < 4; ++e)
-                                    if (sv[e] >= thr32) emit(tkey[i + e] - 1u, sv[e]);
+                                    if (sv[e] >= thr32 && sv[e] < SP_FLAG) emit(tkey[i + e] - 1u, sv[e]);
                                 if (i < scan_slots) {
                                     *(uint4 *)(tkey + i) = make_uint4(0u, 0u, 0u, 0u);
                                     *(uint4 *)(tval + i) = make_uint4(0u, 0u, 0u, 0u);
@@ -569,7 +577,7 @@ __global__ __launch_bounds__(T, 4) void scan_piece_kernel(sp_params p)      // (
                             }
                         }
                     }
-                    n_cand += (unsigned long long)cnt_here + (unsigned long long)(long long)(int32_t)new_keys;   // (may be negative per thread)
+                    n_cand += (unsigned long long)cnt_here + (unsigned long long)new_keys;
                     new_keys = 0u;
                     sp_barrier();
                 }

@@ -193,10 +193,10 @@ def window_paths(g: CSRGraph) -> torch.Tensor:
 
 
 def screen_shift(bound: float, max_deg: int) -> int:
-    """Fixed point 2^-shift of the screening sums: the finest one that keeps every sum of the graph below 2^32 (score bound
-    plus one rounding unit per term), at most MAX_SCREEN_SHIFT."""
+    """Fixed point 2^-shift of the screening sums: the finest one that keeps every sum of the graph below 2^31 (score bound
+    plus one rounding unit per term; bit 31 is the kernel's known-edge flag), at most MAX_SCREEN_SHIFT."""
     shift = MAX_SCREEN_SHIFT
-    while shift > 0 and bound * (1 << shift) + max_deg >= (1 << 32) - 2:
+    while shift > 0 and bound * (1 << shift) + max_deg >= (1 << 31) - 2:      # (bit 31 of a sum marks a known edge)
         shift -= 1
     return shift
 
@@ -218,7 +218,7 @@ def screen_weights(g0: CSRGraph, g: CSRGraph, perm, node_w: torch.Tensor) -> Scr
         from . import candidates
         bound = candidates.fused_score_bound(g0, node_w)
         shift = screen_shift(bound, 2 * max_degree(g))
-        fits = bound * (1 << shift) + 2 * max_degree(g) < (1 << 32) - 2
+        fits = bound * (1 << shift) + 2 * max_degree(g) < (1 << 31) - 2
         if g.val is not None:
             nw = (node_w if perm is None else node_w[perm]).contiguous()
             return Screen(None, shift, None, g.val, nw, fits and bool((nw >= 0).all().item()))

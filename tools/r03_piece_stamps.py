@@ -8,7 +8,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "edge-proposal-sets_amd", "csrc")
 OUT = os.path.join(ROOT, "tools", "libeps_spstamp.so")
 NAMES = ["column setup (id, bounds)", "plan: paths per window (cut rows + wave sums)", "plan: pieces (wave 0) + barrier",
-         "describe (cut gathers, unit scans, descriptors)", "walk (start bits, look-ups, loads, table updates) + barriers", "known edges out + barrier",
+         "describe (cut gathers, unit scans, descriptors)", "walk (start bits, look-ups, loads, table updates) + barriers", "known edges in (before the walk, no barrier of its own)",
          "table scan + barrier", "ticket hand-over", "(count) pieces", "(count) direct pieces", "(count) rounds walked",
          "(count) hash-loop trips of wave 0", "(count) unit iterations of wave 0", "(count) columns"]
 
@@ -38,8 +38,9 @@ struct sp_params {''')
     rep('                            sp_unit fa[SP_G], fb[SP_G];\n', '                            xst[12] += n_iter;\n                            sp_unit fa[SP_G], fb[SP_G];\n')
     rep('                        sp_barrier();        // the next round / the scan follows: descriptors and table updates are complete\n',
         '                        sp_barrier();        // the next round / the scan follows: descriptors and table updates are complete\n                        XS(d2); XA(4, d1, d2);\n')
-    rep('                    // ---- known edges out: a neighbour of v is no candidate', '                    XS(e0);\n                    xst[9] += direct ? 1 : 0;\n                    // ---- known edges out: a neighbour of v is no candidate')
-    rep('                    // ---- scan the table: count the candidates', '                    XS(e1); XA(5, e0, e1);\n                    // ---- scan the table: count the candidates')
+    rep('                    // ---- known edges in: the neighbours of v inside the piece take their slots BEFORE the walk', '                    XS(e0);\n                    xst[9] += direct ? 1 : 0;\n                    // ---- known edges in: the neighbours of v inside the piece take their slots BEFORE the walk')
+    rep('                    for (int r = 0; r < rounds; ++r) {\n', '                    XS(e01); XA(5, e0, e01);\n                    for (int r = 0; r < rounds; ++r) {\n')
+    rep('                    // ---- scan the table: count the candidates', '                    XS(e1);\n                    // ---- scan the table: count the candidates')
     rep('                    new_keys = 0u;\n                    sp_barrier();\n', '                    new_keys = 0u;\n                    sp_barrier();\n                    XS(e2); XA(6, e1, e2);\n')
     rep('        if (tid == 0) s_ticket = t_next;\n        sp_barrier();\n        t = s_ticket;\n        sp_barrier();\n',
         '        XS(t8);\n        if (tid == 0) s_ticket = t_next;\n        sp_barrier();\n        t = s_ticket;\n        sp_barrier();\n        XS(t9); XA(7, t8, t9);\n')
