@@ -10,7 +10,7 @@ OUT = os.path.join(ROOT, "tools", "libeps_spstamp.so")
 NAMES = ["column setup (id, bounds)", "plan: paths per window (cut rows + wave sums)", "plan: pieces (wave 0) + barrier",
          "describe (cut gathers, unit scans, descriptors)", "walk (start bits, look-ups, loads, table updates) + barriers", "known edges in (before the walk, no barrier of its own)",
          "table scan + barrier", "ticket hand-over", "(count) pieces", "(count) direct pieces", "(count) rounds walked",
-         "(count) hash-loop trips of wave 0", "(count) unit iterations of wave 0", "(count) columns"]
+         "  walk: start bits + barrier + word ranks (first range)", "  walk: first look-up + row load until it ARRIVED (vmcnt 0)", "(count) columns", "  walk: table updates (+ further units)"]
 
 def build():
     s = open(os.path.join(CSRC, "scan_pieces.hip")).read()
@@ -34,8 +34,8 @@ struct sp_params {''')
     rep('            const int np = s_np;\n', '            const int np = s_np;\n            XS(t3); XA(2, t2, t3);\n            xst[8] += np;\n')
     rep('                        // ---- describe the round\'s row segments', '                        XS(d0);\n                        xst[10] += 1;\n                        // ---- describe the round\'s row segments')
     rep('                        for (uint32_t ulo = 0; ulo < (uint32_t)total; ulo += SP_UBITS) {', '                        XS(d1); XA(3, d0, d1);\n                        for (uint32_t ulo = 0; ulo < (uint32_t)total; ulo += SP_UBITS) {')
-    rep('                                while (__ballot(pend != 0u)) {\n', '                                while (__ballot(pend != 0u)) {\n                                    xst[11] += 1;\n')
-    rep('                            sp_unit fa[SP_G], fb[SP_G];\n', '                            xst[12] += n_iter;\n                            sp_unit fa[SP_G], fb[SP_G];\n')
+    rep('                            sp_unit fa[SP_G], fb[SP_G];\n                            fetch_group(0, fa);\n', '                            sp_unit fa[SP_G], fb[SP_G];\n                            XS(w1); if (ulo == 0u) XA(11, d1, w1);\n                            fetch_group(0, fa);\n                            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");\n                            XS(w2); XA(12, w1, w2);\n')
+    rep('                            }\n                        }\n                            if (uhi < (uint32_t)total) sp_barrier();       // (the next range rewrites the start bits)\n', '                            }\n                            XS(w3); XA(14, w2, w3);\n                        }\n                            if (uhi < (uint32_t)total) sp_barrier();       // (the next range rewrites the start bits)\n')
     rep('                        sp_barrier();        // the next round / the scan follows: descriptors and table updates are complete\n',
         '                        sp_barrier();        // the next round / the scan follows: descriptors and table updates are complete\n                        XS(d2); XA(4, d1, d2);\n')
     rep('                    // ---- known edges in: the neighbours of v inside the piece take their slots BEFORE the walk', '                    XS(e0);\n                    xst[9] += direct ? 1 : 0;\n                    // ---- known edges in: the neighbours of v inside the piece take their slots BEFORE the walk')
@@ -96,7 +96,7 @@ def run():
     print(f"eps_scan_screen variant {variant} (stamped build) on the ppa-like graph, hubs-first labels, bar {bar}: {e0.elapsed_time(e1):.2f} ms; "
           f"slots, candidates {res.counts()}; s_memtime sums of thread 0 over all workgroups: {tot}")
     for i, nm in enumerate(NAMES):
-        print(f"{nm:52s} {x[i]:16d} {100.0 * x[i] / tot:7.2f}%" if i < 8 else f"{nm:52s} {x[i]:16d}")
+        print(f"{nm:52s} {x[i]:16d} {100.0 * x[i] / tot:7.2f}%" if (i < 8 or nm.startswith("  walk")) else f"{nm:52s} {x[i]:16d}")
 
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "build":
