@@ -75,6 +75,20 @@ def _worker(rank, world, port, tmp):
     h = epd.sharded_gnn_forward([layer, layer], feats, n)
     ref = orc.spmm_csr(rp, col, None, orc.spmm_csr(rp, col, None, feats.numpy(), mean=True), mean=True)
     assert np.array_equal(h.numpy(), ref)
+    # 5. the collectives of the sharded threshold scan (scan.scan_topk): histogram all-reduce, status all-gather, one padded
+    # gather of ragged per-rank lists whose lengths every rank already knows
+    hist = torch.arange(256, dtype=torch.int32) * (rank + 1)
+    epd.all_reduce_sum_(hist)
+    assert torch.equal(hist, torch.arange(256, dtype=torch.int32) * 3)
+    st = torch.tensor([10 + rank, 20 + rank, 3 + 4 * rank, 7, 0], dtype=torch.int64)
+    table = torch.stack(epd.all_gather_list(st)).tolist()
+    assert table == [[10, 20, 3, 7, 0], [11, 21, 7, 7, 0]]
+    lens = [t[2] for t in table]
+    mine = torch.arange(lens[rank], dtype=torch.int64) + 100 * rank
+    buf = torch.cat([mine, torch.full((5,), -7, dtype=torch.int64)])          # (the list sits at the front of a longer buffer)
+    got = epd.gather_ragged(buf, lens)
+    assert torch.equal(got, torch.cat([torch.arange(3), torch.arange(7) + 100]))
+    assert torch.equal(epd.gather_ragged(buf[:0], [0, 0]), buf[:0])
     torch.save(keys, os.path.join(tmp, f"keys_{rank}.pt"))
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()

@@ -255,3 +255,43 @@ def test_original_keys_after_relabelling():
     out = scan._original_keys(keys, perm)
     assert out.tolist() == [(1 << 32) | 0, (4 << 32) | 2, (3 << 32) | 0]
     assert scan._original_keys(keys, None) is keys
+
+
+def test_weight_keyed_cache_holds_the_tensor_not_its_address(eps):
+    """CSRGraph.weight_cached (scan tables derived from a weight tensor): an entry is found again for the SAME tensor object at
+    the same version, never for another tensor that happens to live at a recycled address; at most four tables are kept."""
+    g = eps.CSRGraph.from_edge_index(torch.tensor([[0, 1], [1, 0]]), None, sparse_sizes=(2, 2))
+    calls = []
+
+    def build(tag):
+        calls.append(tag)
+        return tag
+    w1 = torch.ones(2)
+    assert g.weight_cached("t", w1, lambda: build("a")) == "a" and g.weight_cached("t", w1, lambda: build("x")) == "a"
+    w1.add_(1.0)                                          # in-place update: a new version, a new table
+    assert g.weight_cached("t", w1, lambda: build("b")) == "b"
+    ptr = w1.data_ptr()
+    del w1
+    w2 = torch.ones(2)                                    # the allocator may hand out the same address again
+    assert g.weight_cached("t", w2, lambda: build("c")) == "c", (ptr, w2.data_ptr())
+    for i in range(6):
+        g.weight_cached("t", torch.ones(2) * i, lambda i=i: build(i))
+    assert len(g._cache[("by_weight", "t")]) == 4
+    assert g.weight_cached("other", None, lambda: build("none")) == "none" and g.weight_cached("other", None, lambda: build("z")) == "none"
+
+
+def test_scan_host_rules(eps):
+    """Host-side rules of the threshold scan that need no device: the screening fixed point leaves bit 31 free, the survivor
+    list refuses sizes its 32-bit slot positions cannot address, the exact selection in tensor ops."""
+    from eps_amd import ops, scan
+    for bound, deg in ((2646.0, 13230), (1.0, 3), (3.9e6, 1000), (0.0, 0)):
+        sh = scan.screen_shift(bound, deg)
+        assert 0 <= sh <= scan.MAX_SCREEN_SHIFT and bound * (1 << sh) + deg < (1 << 31) - 2
+        assert sh == scan.MAX_SCREEN_SHIFT or bound * (1 << (sh + 1)) + deg >= (1 << 31) - 2
+    assert scan._capacity(1000, 0) == 1000 and scan._capacity(10, 5) == 15
+    with pytest.raises(ops._lib.EpsError):
+        scan._capacity(ops.SURVIVOR_SLOTS_MAX + 1, 0)
+    keys = torch.tensor([(5 << 32) | 1, (7 << 32) | 2, (9 << 32) | 3], dtype=torch.int64)
+    vals = torch.tensor([2.0, 3.0, 2.0])
+    k, v = scan.select_topk_torch(keys, vals, 3)
+    assert k.tolist() == [(2 << 32) | 7, (7 << 32) | 2, (1 << 32) | 5] and v.tolist() == [3.0, 3.0, 2.0]
