@@ -10,17 +10,21 @@
 // piece owns a slot of an LDS table, and each path is read once and costs one table update:
 //   * the id space is cut per graph into SP_M windows of equal stored-entry mass (`bounds`); `cuts[w][k]` = entries of row w
 //     below bounds[k+1] (uint16) turns (row, window run) into a segment of col[] without searching;
-//   * a column's paths per window are summed from those cuts (exact), and windows are merged greedily into pieces:
-//     DIRECT when the run spans at most 2 x slots ids (hub ids: the accumulator of u is slot u - lo, no key, one LDS add
-//     per path -- under hubs-first labels half of all paths end there), HASH when it holds at most slots / 2 paths (open
-//     addressing, double hashing, a CAS on the key word + an add on the value word), hash-PARTITIONED passes for a single
-//     window that is both wide and heavy;
+//   * a column's paths per window are exact sums over the cut rows of its neighbours (a per-graph table, `wpaths`; summed here
+//     when the caller has none), and wave 0 merges windows greedily into pieces: DIRECT when the run spans at most 2 x slots
+//     ids (hub ids: the accumulator of u is slot u - lo, no key, one LDS add per path -- under hubs-first labels a third to a
+//     half of all paths end there), HASH when it holds at most slots / 2 paths and known edges (open addressing, double
+//     hashing, a CAS on the key word + an add on the value word), hash-PARTITIONED passes for a single window that is both
+//     wide and heavy.  The known edges of v inside a piece take their slots before the walk, flagged in the value word;
 //   * segments are packed: a lane takes 4 consecutive entries of one row segment (16-byte load), lanes are dealt over the
-//     virtual concatenation of the piece's segments (row found by a binary search over the unit prefix in LDS);
+//     virtual concatenation of the piece's segments (rows get dense indices; a bitmap of row starts over the unit numbering
+//     plus the rank of every 32-unit word maps a unit to its row with two independent LDS reads and a popcount);
 //   * the table holds 32-bit SCREENING sums: weights rounded UP to 2^-shift fixed point, so a sum is an upper bound of
 //     the exact 2^-40 fixed-point score of filter_scan.hip / expand_score.hip and `sum >= floor(bar)` loses no survivor.  The
-//     few candidates that pass (K of 10^10) are re-scored exactly by the caller (float64 pair kernel over weights that are
-//     multiples of 2^-40: order-independent, bit-identical to the fixed-point sum) -- the final list is bit-identical.
+//     few candidates that pass (K of 10^10) are re-scored exactly (eps_rescore_runs / eps_rescore_weighted below: int64 sums
+//     of the same 2^-40 fixed-point terms, order-independent) -- the final list is bit-identical.
+// Four workgroups of 256 threads per CU (variant 2) is the measured best: independent workgroups overlap each other's
+// barrier-separated phases; __launch_bounds__(T, 4) keeps the fourth wave per SIMD (130 VGPRs instead of 128 cost 25-100 %).
 // Symmetry, the survivor record and the dynamic column hand-out are as in filter_scan.hip.
 #include "eps_common.h"
 #include <string.h>
