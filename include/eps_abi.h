@@ -217,7 +217,7 @@ int eps_filter_scan(const int64_t *rowptr, const int32_t *col, const int32_t *re
  *                           the cut table).  Per-graph table, optional: with NULL the scan sums them per column itself.
  *   eps_scan_screen_weights: fx32[i] = max(1, ceil(fixw[i] / 2^(40 - shift))); *bad (device word, cleared by the call):
  *                           bit 1 a negative weight, bit 2 a weight that does not fit 32 bits.  shift must keep every
- *                           screening sum of the graph below 2^32 (the caller's score bound: eps_amd.scan.screen_shift).
+ *                           screening sum of the graph below 2^31 (bit 31 of a table word flags a known edge) (the caller's score bound: eps_amd.scan.screen_shift).
  *   eps_scan_screen       : out as for eps_filter_scan (slots are handed out in chunks of max(8192, 2 * table slots));
  *                           variant 0: 512 threads / 8192-slot table (2 workgroups per CU), 1: 1024 / 16384 (1), 2: 256 / 4096 (4);
  *                           *status (device word, cleared by the call): bit 2 = a table filled up (results invalid). */
