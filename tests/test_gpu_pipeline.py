@@ -208,3 +208,24 @@ def test_collab_recipe_with_valid_proposal(eps, oracle, workdir):
     v = oracle.hits_at_k(sc(A_eval, split_edge["valid"]["edge"]), sc(A_eval, split_edge["valid"]["edge_neg"]), 50)
     t = oracle.hits_at_k(sc(A_full, split_edge["test"]["edge"]), sc(A_full, split_edge["test"]["edge_neg"]), 50)
     assert float(curves[0][1]) == pytest.approx(100 * v, abs=1e-4) and float(curves[0][2]) == pytest.approx(100 * t, abs=1e-4)
+
+
+def test_bench_real_graph_hook_on_a_stand_in_file(eps, workdir, monkeypatch, tmp_path):
+    """bench.py's $EPS_DATA_ROOT hook ("if OGB raw files are present ... run the same on the real graphs") cannot see
+    real data here; a scaled stand-in saved in the export format exercises the whole path: data file ->
+    headline scan -> RA filter (4 M asked, fewer exist) -> RA rank -> curve."""
+    import sys
+    from eps_amd import datasets
+    monkeypatch.setenv("EPS_SYNTH_SCALE", "0.02")
+    raw = datasets.load_raw("ppa", synthetic=True)
+    torch.save({k: (v.cpu() if hasattr(v, "cpu") else v) for k, v in raw.items() if k != "split_edge"} |
+               {"split_edge": {a: {b: t.cpu() for b, t in d.items()} for a, d in raw["split_edge"].items()}}, tmp_path / "ppa.pt")
+    monkeypatch.setenv("EPS_DATA_ROOT", str(tmp_path))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench_configs
+    out = bench_configs.leg_real_ppa(torch, 20000)
+    assert out is not None and "error" not in out, out
+    assert out["candidates"] > 0 and out["value"] > 0 and out["ra_filter_ra_rank_curve"]
+    monkeypatch.delenv("EPS_DATA_ROOT")
+    assert bench_configs.leg_real_ppa(torch, 20000) is None
