@@ -10,7 +10,7 @@ OUT = os.path.join(ROOT, "tools", "libeps_spstamp.so")
 NAMES = ["column setup (id, bounds)", "plan: paths per window (cut rows + wave sums)", "plan: pieces (wave 0) + barrier",
          "describe (cut gathers, unit scans, descriptors)", "walk (start bits, look-ups, loads, table updates) + barriers", "known edges in (before the walk, no barrier of its own)",
          "table scan + barrier", "ticket hand-over", "(count) pieces", "(count) direct pieces", "(count) rounds walked",
-         "  walk: start bits + barrier + word ranks (first range)", "  walk: first look-up + row load until it ARRIVED (vmcnt 0)", "(count) columns", "  walk: table updates (+ further units)"]
+         "  walk: start bits + barrier + word ranks (first range)", "  walk: first look-up + row load until it ARRIVED (vmcnt 0)", "(count) columns", "  walk: table updates (+ further units)", "(count) paths of direct pieces (x parts)"]
 
 def build():
     s = open(os.path.join(CSRC, "scan_pieces.hip")).read()
@@ -38,7 +38,7 @@ struct sp_params {''')
     rep('                            }\n                        }\n                            if (uhi < (uint32_t)total) sp_barrier();       // (the next range rewrites the start bits)\n', '                            }\n                            XS(w3); XA(14, w2, w3);\n                        }\n                            if (uhi < (uint32_t)total) sp_barrier();       // (the next range rewrites the start bits)\n')
     rep('                        sp_barrier();        // the next round / the scan follows: descriptors and table updates are complete\n',
         '                        sp_barrier();        // the next round / the scan follows: descriptors and table updates are complete\n                        XS(d2); XA(4, d1, d2);\n')
-    rep('                    // ---- known edges in: the neighbours of v inside the piece take their slots BEFORE the walk', '                    XS(e0);\n                    xst[9] += direct ? 1 : 0;\n                    // ---- known edges in: the neighbours of v inside the piece take their slots BEFORE the walk')
+    rep('                    // ---- known edges in: the neighbours of v inside the piece take their slots BEFORE the walk', '                    XS(e0);\n                    xst[9] += direct ? 1 : 0;\n                    xst[15] += direct ? ppaths : 0;\n                    // ---- known edges in: the neighbours of v inside the piece take their slots BEFORE the walk')
     rep('                    for (int r = 0; r < rounds; ++r) {\n', '                    XS(e01); XA(5, e0, e01);\n                    for (int r = 0; r < rounds; ++r) {\n')
     rep('                    // ---- scan the table: count the candidates', '                    XS(e1);\n                    // ---- scan the table: count the candidates')
     rep('                    new_keys = 0u;\n                    sp_barrier();\n', '                    new_keys = 0u;\n                    sp_barrier();\n                    XS(e2); XA(6, e1, e2);\n')
