@@ -1,0 +1,10 @@
+#!/bin/bash
+# r03: the filter CLI end to end on the stand-ins (second run of each: the first pays the process's one-off code-object loads)
+cd $GRAFT_REPO_ROOT
+W=$(mktemp -d); cd $W
+for spec in "collab adamic_ogb 150000" "collab simple 150000" "ppa adamic_ogb 4000000" "ddi simple 100000"; do
+  set -- $spec
+  for rep in 1 2; do
+    python3 $GRAFT_REPO_ROOT/filter.py --dataset $1 --model $2 --checkpoint "$1_$2||0|$rep.pt" --synthetic --keep_top $3 2>&1 | grep -E "threshold scan|using [0-9]+ edges|fused" | sed "s/^/$1 $2 keep_top $3 run $rep: /"
+  done
+done
