@@ -15,10 +15,19 @@
 //     ids (hub ids: the accumulator of u is slot u - lo, no key, one LDS add per path -- under hubs-first labels a third to a
 //     half of all paths end there), HASH when it holds at most slots / 2 paths and known edges (open addressing, double
 //     hashing, a CAS on the key word + an add on the value word), hash-PARTITIONED passes for a single window that is both
-//     wide and heavy.  The known edges of v inside a piece take their slots before the walk, flagged in the value word;
+//     wide and heavy.  Unit-valued graphs with the caller's sum bounds (ssum / smax) get a third kind, PACKED: a hash piece
+//     whose slot is ONE word, key (id - lo) above flag + sum -- twice the candidates per table, i.e. half as many pieces where
+//     pieces are hashed, and a first-time candidate costs one LDS operation.  The field widths are set per piece: the key
+//     takes the bits its id span needs, the sum field the rest, and the weights drop low bits (rounded up) until
+//     min(S(v), max S(u)) + one unit per path fits -- S = a node's sum of weights over its row bounds every sum it can take
+//     part in.  Between a direct run and a longer hashed one the planner compares cost per path (a piece's fixed cost is
+//     worth ~2300 hashed paths, a direct path costs a quarter of a hashed one).  The known edges of v inside a piece take
+//     their slots before the walk, flagged in the value word;
 //   * segments are packed: a lane takes 4 consecutive entries of one row segment (16-byte load), lanes are dealt over the
 //     virtual concatenation of the piece's segments (rows get dense indices; a bitmap of row starts over the unit numbering
-//     plus the rank of every 32-unit word maps a unit to its row with two independent LDS reads and a popcount);
+//     plus the rank of every 32-unit word maps a unit to its row with two independent LDS reads and a popcount); a hashed
+//     unit probes all four entries at once, then finishes the stragglers one entry per lane and trip (a wave needs as many
+//     trips as its unluckiest entry -- 4.8 per unit -- so trips must be cheap);
 //   * the table holds 32-bit SCREENING sums: weights rounded UP to 2^-shift fixed point, so a sum is an upper bound of
 //     the exact 2^-40 fixed-point score of filter_scan.hip / expand_score.hip and `sum >= floor(bar)` loses no survivor.  The
 //     few candidates that pass (K of 10^10) are re-scored exactly (eps_rescore_runs / eps_rescore_weighted below: int64 sums
@@ -60,6 +69,11 @@ struct sp_params {
     uint32_t col_bytes;
     int32_t table_bits;         // slots = 1 << table_bits (keys) + as many values
     uint32_t piece_paths;       // a hash piece holds at most this many paths (<= slots / 2)
+    const uint32_t *ssum;       // [n_nodes] sum of fx32 over the node's neighbours (an upper bound of any of its pairs' sums) or NULL
+    const uint32_t *smax;       // [SP_M + 1] largest ssum among the ids >= bounds[k] (0 for k = SP_M); NULL with ssum
+    uint32_t packed_paths;      // a PACKED hash piece holds at most this many paths (<= slots: key and sum share a word)
+    int32_t packed_dmax;        // ... and may drop at most this many low bits of the screening weights
+    uint32_t mode_ratio;        // fixed cost of a piece in units of (a hashed path's cost - a direct path's cost)
     int32_t shift;              // screening fixed point: 2^-shift
     float scale;                // 2^-shift: screening sum -> approximate score
     unsigned int *next_col;
@@ -106,7 +120,6 @@ struct sp_unit {
 template <int T, bool HV>
 __global__ __launch_bounds__(T, 4) void scan_piece_kernel(sp_params p)      // (4 waves per SIMD: <= 128 VGPRs, the LDS share decides the rest)
 {
-    constexpr int W = T / 64;
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const int slots = 1 << p.table_bits;
     uint32_t *tkey = lds;                    // [slots]  hash mode: key (node id) or SP_EMPTY
@@ -119,11 +132,12 @@ __global__ __launch_bounds__(T, 4) void scan_piece_kernel(sp_params p)      // (
     uint32_t *ubits = lds + ((2 * slots + 4 * (T + 1) + 3) & ~3);      // [SP_UBITS / 32] bit s: a row starts at unit s (of the range)
     uint16_t *wrank = (uint16_t *)(ubits + SP_UBITS / 32);               // [SP_UBITS / 32] rows that start before the word
     __shared__ uint32_t s_pw[SP_M];          // paths of the column per id window
-    __shared__ int s_wtot[W], s_wtot2[W];
+    __shared__ unsigned long long s_alloc;   // units << 32 | rows handed out to the waves of a round (one 64-bit LDS add per wave)
     __shared__ int s_rbase;
     __shared__ int32_t s_pk0[SP_MAXP], s_pk1[SP_MAXP];   // pieces: window run [k0, k1)
     __shared__ int32_t s_plo[SP_MAXP], s_phi[SP_MAXP];   // ... = ids [lo, hi) (hi cut at v)
-    __shared__ uint32_t s_pinfo[SP_MAXP];    // paths of the piece | direct flag << 31
+    __shared__ uint32_t s_pinfo[SP_MAXP];    // paths of the piece | direct flag << 31 | packed flag << 30
+    __shared__ uint32_t s_pq[SP_MAXP];       // packed pieces: bits dropped from the weights | key bits << 8
     __shared__ int32_t s_pna[SP_MAXP], s_pnb[SP_MAXP];   // the neighbours of v with ids inside the piece's windows: vcol[na, nb)
     __shared__ int s_np;
     __shared__ unsigned int s_ticket;
@@ -166,9 +180,11 @@ __global__ __launch_bounds__(T, 4) void scan_piece_kernel(sp_params p)      // (
     const int32_t my_bound = p.bounds[lane <= SP_M ? lane : SP_M];      // lane k holds window boundary k (the plan runs in wave 0)
 
     for (int i = tid; i < 2 * slots; i += T) lds[i] = 0u;
+    for (int i = tid; i < SP_UBITS / 32; i += T) ubits[i] = 0u;
     if (tid == 0) {
         s_out_cur = 0u;
         s_out_end = 0u;
+        s_alloc = 0ull;
     }
     unsigned long long n_cand = 0;           // candidates seen by this thread
     uint32_t new_keys = 0u;                  // ... of the current hash piece: candidate keys this thread inserted
@@ -244,6 +260,9 @@ __global__ __launch_bounds__(T, 4) void scan_piece_kernel(sp_params p)      // (
                 // lane k: neighbours of v below window boundary k (row v's own cuts: cuts[v][k - 1]; 0 for k = 0)
                 const int32_t nbk = lane >= 1 && lane <= SP_M ? (int32_t)p.cuts[(size_t)v * SP_M + lane - 1] : 0;
                 const uint32_t ek = (uint32_t)sp_wave_incl_scan((int)pwk) - pwk;      // paths in the windows before k (lane 32: all)
+                const bool pk_on = !HV && p.ssum != nullptr;
+                const uint32_t sv = pk_on ? p.ssum[v] : 0u;
+                const uint32_t smk = pk_on ? p.smax[lane <= SP_M ? lane : SP_M] : 0u;
                 // windows 0 .. kv hold ids below v
                 const int kv = __popcll(__ballot(lane >= 1 && lane < SP_M && my_bound <= v - 1));
                 const int32_t hi_k = my_bound < v ? my_bound : v;                    // end of the run [.., k) in id space
@@ -256,11 +275,43 @@ __global__ __launch_bounds__(T, 4) void scan_piece_kernel(sp_params p)      // (
                     const int32_t nb0 = __builtin_amdgcn_readlane(nbk, k0);
                     // (the known edges of v inside a hash piece own slots too: they count toward its limit)
                     const int kh = k0 + __popcll(__ballot(in && (ek - e0) + (uint32_t)(nbk - nb0) <= p.piece_paths));
+                    // PACKED hash piece: key (id - lo) and sum share a 32-bit word -- twice the keys per table.  The sum field
+                    // must hold any pair's sum (at most min(S(v), S(u)) / 2^d + one rounding unit per path, flag bit on top)
+                    // next to the key bits the run's id span needs; the weights may lose up to packed_dmax bits for it.
+                    int kp = k0;
+                    uint32_t ms = 0u;
+                    if (pk_on) {
+                        const uint32_t sm0 = (uint32_t)__builtin_amdgcn_readlane((int)smk, k0);
+                        ms = sv < sm0 ? sv : sm0;
+                        const uint32_t need_s = (ms >> p.packed_dmax) + (uint32_t)dv + 2u;
+                        const uint32_t span = (uint32_t)(hi_k - lo);
+                        const int kb = 32 - __clz((int)((span > 2u ? span : 2u) - 1u));
+                        const uint32_t cap = kb >= 30 ? 0u : (1u << (31 - kb)) - 1u;
+                        kp = k0 + __popcll(__ballot(in && (ek - e0) + (uint32_t)(nbk - nb0) <= p.packed_paths && need_s < cap));
+                    }
                     int k1;
-                    uint32_t flag = 0u;
-                    if (kd >= kh && kd > k0) {
+                    uint32_t flag = 0u, pq = 0u;
+                    // DIRECT or PACKED when the packed run reaches further: a piece costs a fixed overhead worth `mode_ratio` extra
+                    // hashed paths (plan, describe, barriers, sweep), and a direct path a fraction of a hashed one -- the shorter
+                    // direct run wins iff (Pp - Pd) * mode_ratio < Pd * Pp  (cost per path: F / P + c_mode)
+                    bool take_direct = kd >= kh && kd >= kp && kd > k0;
+                    if (!take_direct && kd > k0 && kp > kd && kp >= kh) {
+                        const uint32_t pd = (uint32_t)__builtin_amdgcn_readlane((int)ek, kd) - e0;
+                        const uint32_t pp = (uint32_t)__builtin_amdgcn_readlane((int)ek, kp) - e0;
+                        take_direct = (unsigned long long)(pp - pd) * p.mode_ratio < (unsigned long long)pd * pp;
+                    }
+                    if (take_direct) {
                         k1 = kd;
                         flag = 0x80000000u;
+                    } else if (kp >= kh && kp > k0) {
+                        k1 = kp;
+                        flag = 0x40000000u;
+                        const uint32_t span = (uint32_t)(__builtin_amdgcn_readlane(hi_k, k1) - lo);
+                        const int kb = 32 - __clz((int)((span > 2u ? span : 2u) - 1u));
+                        const uint32_t cap = (1u << (31 - kb)) - 1u;
+                        uint32_t d = 0u;
+                        while ((ms >> d) + (uint32_t)dv + 2u >= cap) ++d;         // (<= packed_dmax: the run passed the test with it)
+                        pq = d | ((uint32_t)kb << 8);
                     } else if (kh > k0) {
                         k1 = kh;
                     } else {
@@ -274,6 +325,7 @@ __global__ __launch_bounds__(T, 4) void scan_piece_kernel(sp_params p)      // (
                             s_plo[np] = lo;
                             s_phi[np] = __builtin_amdgcn_readlane(hi_k, k1);
                             s_pinfo[np] = sum | flag;
+                            s_pq[np] = pq;
                             s_pna[np] = __builtin_amdgcn_readlane(nbk, k0);
                             s_pnb[np] = __builtin_amdgcn_readlane(nbk, k1);
                         }
@@ -285,24 +337,35 @@ __global__ __launch_bounds__(T, 4) void scan_piece_kernel(sp_params p)      // (
             }
             sp_barrier();
             const int np = s_np;
+            // A column of one round keeps its rows in registers, and its pieces are consecutive runs of windows: a row's segment
+            // starts where its segment in the previous piece ended (runs that were skipped hold no entry of any row), and the
+            // one cut a piece needs per row -- its end -- is loaded a piece ahead.
+            uint32_t cut_ahead = 0u, seg_from = 0u;
+            if (single && tid < dv && np > 0) cut_ahead = p.cuts[(size_t)my_w * SP_M + s_pk1[0] - 1];
 
             for (int pi = 0; pi < np; ++pi) {
                 const int k0 = s_pk0[pi], k1 = s_pk1[pi];
                 const int na = s_pna[pi], nb = s_pnb[pi];
                 const uint32_t info = s_pinfo[pi];
                 const bool direct = (info >> 31) != 0u;
-                const uint32_t ppaths = info & 0x7FFFFFFFu;
+                const bool packed = !HV && (info & 0x40000000u) != 0u;
+                const uint32_t ppaths = info & 0x3FFFFFFFu;
+                const uint32_t pq = packed ? s_pq[pi] : 0u;
+                const uint32_t pk_d = pq & 0xFFu, pk_sb = 32u - (pq >> 8);      // weight bits dropped; bits of the flag + sum field
+                const uint32_t pk_flag = packed ? 1u << (pk_sb - 1u) : 0u;
+                const uint32_t pk_thr = thr32 >= SP_FLAG ? 0xFFFFFFFFu : ((thr32 >> pk_d) ? (thr32 >> pk_d) : 1u);
                 const int32_t lo_id = s_plo[pi], hi_id = s_phi[pi];
                 // hash geometry: the smallest power-of-two table with load <= 1/2; a heavier single window goes in `parts` passes
                 const uint32_t pkeys = ppaths + (uint32_t)(nb - na);           // slots the piece can need: paths + known edges
                 uint32_t parts = 1u;
-                if (!direct)
+                if (!direct && !packed)
                     while (pkeys > p.piece_paths * parts) parts <<= 1;
                 if (parts > 1u) parts <<= 1;                             // (random split: aim at a quarter load)
                 int bits = 10;
                 {
                     const uint32_t per = (pkeys + parts - 1) / parts;
-                    while (bits < p.table_bits && (1u << bits) < 2u * per) ++bits;
+                    const int max_bits = packed ? p.table_bits + 1 : p.table_bits;
+                    while (bits < max_bits && (1u << bits) < 2u * per) ++bits;
                 }
                 const uint32_t mask = (1u << bits) - 1u;
                 const uint32_t scan_slots = direct ? (uint32_t)(hi_id - lo_id) : (1u << bits);
@@ -317,16 +380,34 @@ __global__ __launch_bounds__(T, 4) void scan_piece_kernel(sp_params p)      // (
                         s_out_end = b + chunk;
                     }
                 }
+                uint32_t seg_a = 0u, seg_len = 0u;
+                if (single && tid < dv) {
+                    const uint32_t b = cut_ahead < my_rev ? cut_ahead : my_rev;
+                    seg_a = seg_from;
+                    seg_len = b - seg_from;
+                    seg_from = b;
+                    if (pi + 1 < np) cut_ahead = p.cuts[(size_t)my_w * SP_M + s_pk1[pi + 1] - 1];
+                }
                 for (uint32_t part = 0; part < parts; ++part) {
                     // ---- known edges in: the neighbours of v inside the piece take their slots BEFORE the walk, with the flag bit
                     // in the value word -- whatever the paths add on top, the sweep sees that this id is no candidate (rows ascend:
                     // the neighbours inside the piece's windows are vcol[na, nb)).  The first barrier of the describe orders this
                     // against the walk.
-                    for (int j = na + tid; j < nb; j += T) {
-                        const uint32_t u = (uint32_t)vcol[j];
-                        if ((int32_t)u >= lo_id && (int32_t)u < hi_id) {
+                    // (a column of one round holds its rows in registers: lane j's row IS neighbour j)
+                    for (int j = single ? tid : na + tid; j < nb; j += T) {
+                        const uint32_t u = single ? my_w : (uint32_t)vcol[j];
+                        if (j >= na && (int32_t)u >= lo_id && (int32_t)u < hi_id) {
                             if (direct) {
                                 lds[u - (uint32_t)lo_id] = SP_FLAG;
+                            } else if (packed) {
+                                const uint32_t mix = sp_mix(u);
+                                uint32_t h = mix >> (32 - bits);
+                                const uint32_t st = ((mix >> 7) | 1u) & mask;
+                                const uint32_t word = ((u - (uint32_t)lo_id) << pk_sb) | pk_flag;
+                                for (uint32_t tries = 0; tries <= mask; ++tries) {
+                                    if (atomicCAS(&lds[h], 0u, word) == 0u) break;
+                                    h = (h + st) & mask;
+                                }
                             } else {
                                 const uint32_t mix = sp_mix(u);
                                 if ((mix & (parts - 1u)) == part) {
@@ -348,13 +429,14 @@ __global__ __launch_bounds__(T, 4) void scan_piece_kernel(sp_params p)      // (
                         const int j = r * T + tid;
                         uint32_t w = my_w, rev = my_rev, base = my_base, fx = my_fx;
                         uint32_t len = 0u, a = 0u;
-                        if (j < dv) {
-                            if (!single) {
-                                w = (uint32_t)vcol[j];
-                                rev = (uint32_t)vrev[j];
-                                base = rowptr_lo[2 * (size_t)w];
-                                fx = HV ? __builtin_bit_cast(uint32_t, (p.val[vb + j] * p.node_w[w]) * p.up) : p.fx32[w];
-                            }
+                        if (single) {
+                            a = seg_a;
+                            len = seg_len;
+                        } else if (j < dv) {
+                            w = (uint32_t)vcol[j];
+                            rev = (uint32_t)vrev[j];
+                            base = rowptr_lo[2 * (size_t)w];
+                            fx = HV ? __builtin_bit_cast(uint32_t, (p.val[vb + j] * p.node_w[w]) * p.up) : p.fx32[w];
                             const uint16_t *crow = p.cuts + (size_t)w * SP_M;
                             uint32_t b = crow[k1 - 1];
                             if (k0 > 0) a = crow[k0 - 1];
@@ -369,27 +451,21 @@ __global__ __launch_bounds__(T, 4) void scan_piece_kernel(sp_params p)      // (
                         const int units = (int)((len + 3u) >> 2);
                         const int flag = units > 0 ? 1 : 0;
                         const int incl = sp_wave_incl_scan(units), incl_f = sp_wave_incl_scan(flag);
-                        if (lane == 63) {
-                            s_wtot[wib] = incl;
-                            s_wtot2[wib] = incl_f;
-                        }
-                        for (int i = tid; i < SP_UBITS / 32; i += T) ubits[i] = 0u;
-                        sp_barrier();
-                        int woff = 0, total = 0, woff_f = 0;
-#pragma unroll
-                        for (int i = 0; i < W; ++i) {
-                            const int x = s_wtot[i], y = s_wtot2[i];
-                            if (i < wib) {
-                                woff += x;
-                                woff_f += y;
-                            }
-                            total += x;
-                        }
+                        // Each wave takes its range of unit numbers AND of dense row indices with one 64-bit LDS add: whatever
+                        // order the waves arrive in, both ranges are handed out in that same order -- a row that starts at a
+                        // later unit has a larger index, which is all the start-bit ranks need (no block scan, no barrier for it).
+                        unsigned long long got = 0ull;
+                        if (lane == 63) got = atomicAdd(&s_alloc, ((unsigned long long)(uint32_t)incl << 32) | (unsigned long long)(uint32_t)incl_f);
+                        const int woff = __builtin_amdgcn_readlane((int)(got >> 32), 63);
+                        const int woff_f = __builtin_amdgcn_readlane((int)(uint32_t)got, 63);
                         const uint32_t a_u = (uint32_t)(incl - units + woff);          // first unit of this thread's row
                         if (flag) {
                             const int d = incl_f - 1 + woff_f;
-                            r_desc[d] = make_uint4(base + a, len, fx, a_u);
+                            r_desc[d] = make_uint4(base + a, len, packed ? (fx + ((1u << pk_d) - 1u)) >> pk_d : fx, a_u);
+                            if (a_u < (uint32_t)SP_UBITS) atomicOr(&ubits[a_u >> 5], 1u << (a_u & 31u));      // (the first range's start bits)
                         }
+                        sp_barrier();
+                        const int total = (int)(s_alloc >> 32);
                         for (uint32_t ulo = 0; ulo < (uint32_t)total; ulo += SP_UBITS) {       // (one range unless > 32 k paths)
                             const uint32_t uhi = ulo + SP_UBITS < (uint32_t)total ? ulo + SP_UBITS : (uint32_t)total;
                             if (ulo > 0u) {
@@ -398,12 +474,12 @@ __global__ __launch_bounds__(T, 4) void scan_piece_kernel(sp_params p)      // (
                                 sp_barrier();
                                 const unsigned long long before = __ballot(flag && a_u + (uint32_t)units <= ulo);
                                 if (lane == 0 && before) atomicAdd(&s_rbase, __popcll(before));
+                                if (flag && a_u + (uint32_t)units > ulo && a_u < uhi) {
+                                    const uint32_t pos = (a_u > ulo ? a_u : ulo) - ulo;
+                                    atomicOr(&ubits[pos >> 5], 1u << (pos & 31));
+                                }
+                                sp_barrier();
                             }
-                            if (flag && a_u + (uint32_t)units > ulo && a_u < uhi) {
-                                const uint32_t pos = (a_u > ulo ? a_u : ulo) - ulo;
-                                atomicOr(&ubits[pos >> 5], 1u << (pos & 31));
-                            }
-                            sp_barrier();
                             const int rbase = ulo > 0u ? s_rbase : 0;
                             {   // rank of every word's first bit: every wave computes all of them (identical values: no barrier)
                                 const uint4 b4 = *(const uint4 *)(ubits + 4 * lane);
@@ -458,6 +534,75 @@ __global__ __launch_bounds__(T, 4) void scan_piece_kernel(sp_params p)      // (
 #pragma unroll
                                     for (int e = 0; e < 4; ++e)
                                         if (e < f[q].nvalid) atomicAdd(&lds[(uint32_t)(f[q].u4[e] - lo_id)], path_fx(f[q], e));
+                            } else if (packed) {
+                                // Round one: all of the lane's entries at once (most find their slot at the first probe).  What is
+                                // left -- an entry in six at load 1/2 -- is finished ONE entry per lane and trip: the trips a wave
+                                // needs are set by its unluckiest entry (the longest probe sequence among 256), and a trip that
+                                // looks at one entry costs a quarter of one that steps through four mostly idle ones.
+                                constexpr int E = 4 * SP_G;
+                                uint32_t lid[E], h[E], mixv[E], old[E];
+                                uint32_t pend = 0u;
+#pragma unroll
+                                for (int q = 0; q < SP_G; ++q) pend |= ((1u << f[q].nvalid) - 1u) << (4 * q);
+#pragma unroll
+                                for (int i = 0; i < E; ++i) {
+                                    const uint32_t id = (uint32_t)f[i >> 2].u4[i & 3];
+                                    mixv[i] = sp_mix(id);
+                                    lid[i] = id - (uint32_t)lo_id;
+                                    h[i] = mixv[i] >> (32 - bits);
+                                }
+#pragma unroll
+                                for (int i = 0; i < E; ++i)
+                                    if (pend & (1u << i)) old[i] = atomicCAS(&lds[h[i]], 0u, (lid[i] << pk_sb) | f[i >> 2].fx);
+#pragma unroll
+                                for (int i = 0; i < E; ++i)
+                                    if (pend & (1u << i)) {
+                                        if (old[i] == 0u) {                      // a candidate seen for the first time: key and weight went in at once
+                                            pend &= ~(1u << i);
+                                            ++new_keys;
+                                        } else if ((old[i] >> pk_sb) == lid[i]) {
+                                            atomicAdd(&lds[h[i]], f[i >> 2].fx);
+                                            pend &= ~(1u << i);
+                                        }
+                                    }
+                                uint32_t ch = 0u, cstep = 0u, clid = 0u, cfx = 0u, tries = 0u;
+                                bool have = false;
+                                while (__ballot(have || pend != 0u)) {
+                                    if (!have && pend != 0u) {                   // take up the next unfinished entry
+                                        const int e = __ffs((int)pend) - 1;
+                                        pend &= pend - 1u;
+                                        uint32_t m = mixv[0];
+                                        ch = h[0];
+                                        clid = lid[0];
+                                        cfx = f[0].fx;
+#pragma unroll
+                                        for (int i = 1; i < E; ++i)
+                                            if (e == i) {
+                                                m = mixv[i];
+                                                ch = h[i];
+                                                clid = lid[i];
+                                                cfx = f[i >> 2].fx;
+                                            }
+                                        cstep = ((m >> 7) | 1u) & mask;
+                                        have = true;
+                                    }
+                                    if (have) {
+                                        ch = (ch + cstep) & mask;
+                                        const uint32_t o = atomicCAS(&lds[ch], 0u, (clid << pk_sb) | cfx);
+                                        if (o == 0u) {
+                                            ++new_keys;
+                                            have = false;
+                                        } else if ((o >> pk_sb) == clid) {
+                                            atomicAdd(&lds[ch], cfx);
+                                            have = false;
+                                        }
+                                    }
+                                    if (++tries > 4u * (mask + 2u)) {            // the table is full (backstop; never within the piece limits)
+                                        if (have || pend) atomicOr(p.status, 2u);
+                                        have = false;
+                                        pend = 0u;
+                                    }
+                                }
                             } else {
                                 constexpr int E = 4 * SP_G;
                                 uint32_t key[E], h[E], mixv[E];
@@ -476,25 +621,53 @@ __global__ __launch_bounds__(T, 4) void scan_piece_kernel(sp_params p)      // (
                                     for (int i = 0; i < E; ++i)
                                         if ((mixv[i] & (parts - 1u)) != part) pend &= ~(1u << i);
                                 }
-                                uint32_t tries = 0;
-                                while (__ballot(pend != 0u)) {
-                                    uint32_t old[E];
+                                // (round one for all entries at once, then one unfinished entry per lane and trip: see the packed walk)
+                                uint32_t old[E], pfx[E];
 #pragma unroll
-                                    for (int i = 0; i < E; ++i)
-                                        if (pend & (1u << i)) old[i] = atomicCAS(&tkey[h[i]], SP_EMPTY, key[i]);
+                                for (int i = 0; i < E; ++i) pfx[i] = path_fx(f[i >> 2], i & 3);
 #pragma unroll
-                                    for (int i = 0; i < E; ++i)
-                                        if (pend & (1u << i)) {
-                                            if (old[i] == SP_EMPTY || old[i] == key[i]) {
-                                                atomicAdd(&tval[h[i]], path_fx(f[i >> 2], i & 3));
-                                                pend &= ~(1u << i);
-                                                new_keys += old[i] == SP_EMPTY ? 1u : 0u;      // a candidate seen for the first time
-                                            } else {
-                                                h[i] = (h[i] + (((mixv[i] >> 7) | 1u) & mask)) & mask;
+                                for (int i = 0; i < E; ++i)
+                                    if (pend & (1u << i)) old[i] = atomicCAS(&tkey[h[i]], SP_EMPTY, key[i]);
+#pragma unroll
+                                for (int i = 0; i < E; ++i)
+                                    if ((pend & (1u << i)) && (old[i] == SP_EMPTY || old[i] == key[i])) {
+                                        atomicAdd(&tval[h[i]], pfx[i]);
+                                        pend &= ~(1u << i);
+                                        new_keys += old[i] == SP_EMPTY ? 1u : 0u;      // a candidate seen for the first time
+                                    }
+                                uint32_t ch = 0u, cstep = 0u, ckey = 0u, cfx = 0u, tries = 0u;
+                                bool have = false;
+                                while (__ballot(have || pend != 0u)) {
+                                    if (!have && pend != 0u) {
+                                        const int e = __ffs((int)pend) - 1;
+                                        pend &= pend - 1u;
+                                        uint32_t m = mixv[0];
+                                        ch = h[0];
+                                        ckey = key[0];
+                                        cfx = pfx[0];
+#pragma unroll
+                                        for (int i = 1; i < E; ++i)
+                                            if (e == i) {
+                                                m = mixv[i];
+                                                ch = h[i];
+                                                ckey = key[i];
+                                                cfx = pfx[i];
                                             }
+                                        cstep = ((m >> 7) | 1u) & mask;
+                                        have = true;
+                                    }
+                                    if (have) {
+                                        ch = (ch + cstep) & mask;
+                                        const uint32_t o = atomicCAS(&tkey[ch], SP_EMPTY, ckey);
+                                        if (o == SP_EMPTY || o == ckey) {
+                                            atomicAdd(&tval[ch], cfx);
+                                            new_keys += o == SP_EMPTY ? 1u : 0u;
+                                            have = false;
                                         }
-                                    if (++tries > mask + 1u) {           // the table is full (backstop; never within the piece limits)
-                                        if (pend) atomicOr(p.status, 2u);
+                                    }
+                                    if (++tries > 4u * (mask + 2u)) {            // the table is full (backstop; never within the piece limits)
+                                        if (have || pend) atomicOr(p.status, 2u);
+                                        have = false;
                                         pend = 0u;
                                     }
                                 }
@@ -520,6 +693,11 @@ __global__ __launch_bounds__(T, 4) void scan_piece_kernel(sp_params p)      // (
                             if (uhi < (uint32_t)total) sp_barrier();       // (the next range rewrites the start bits)
                         }
                         sp_barrier();        // the next round / the scan follows: descriptors and table updates are complete
+                        // (leave the start bits and the hand-out counter clean for the next describe; a barrier separates them from
+                        //  it: the sweep's own, or -- columns of several rounds -- one more)
+                        for (int i = tid; i < SP_UBITS / 32; i += T) ubits[i] = 0u;
+                        if (tid == 0) s_alloc = 0ull;
+                        if (r + 1 < rounds) sp_barrier();
                     }
                     // ---- scan the table: count the candidates, report the survivors, leave it clean --------------------------
                     auto emit = [&](uint32_t u, uint32_t sum) {
@@ -556,6 +734,26 @@ __global__ __launch_bounds__(T, 4) void scan_piece_kernel(sp_params p)      // (
                                         ++cnt_here;
                                         if (sv[e] >= thr32) emit((uint32_t)lo_id + i + e, sv[e]);
                                     }
+                            }
+                        }
+                    } else if (packed) {
+                        const uint32_t smask = pk_flag - 1u;
+                        for (uint32_t i0 = 0; i0 < scan_slots; i0 += 4u * SP_SB * T) {
+                            uint4 s4[SP_SB];
+#pragma unroll
+                            for (int b = 0; b < SP_SB; ++b) {
+                                const uint32_t i = i0 + 4u * T * b + 4u * tid;
+                                s4[b] = i < scan_slots ? *(const uint4 *)(lds + i) : make_uint4(0u, 0u, 0u, 0u);
+                            }
+#pragma unroll
+                            for (int b = 0; b < SP_SB; ++b) {
+                                const uint32_t i = i0 + 4u * T * b + 4u * tid;
+                                if (i < scan_slots) *(uint4 *)(lds + i) = make_uint4(0u, 0u, 0u, 0u);
+                                const uint32_t sv[4] = {s4[b].x, s4[b].y, s4[b].z, s4[b].w};
+#pragma unroll
+                                for (int e = 0; e < 4; ++e)
+                                    if (!(sv[e] & pk_flag) && (sv[e] & smask) >= pk_thr)
+                                        emit((uint32_t)lo_id + (sv[e] >> pk_sb), (sv[e] & smask) << pk_d);
                             }
                         }
                     } else {
@@ -985,20 +1183,25 @@ extern "C" int eps_scan_screen_weights(const int64_t *fixw, int64_t n, int32_t s
 
 // ---- launch -------------------------------------------------------------------------------------------------------------
 // variant: 0 = 512 threads, 8192-slot table (two workgroups per CU); 1 = 1024 threads, 16384 slots (one per CU);
-//          2 = 256 threads, 4096 slots (four per CU)
+//          2 = 256 threads, 4096 slots (four per CU).  Also measured (27.8 ms for variant 2 at the time): 256 threads / 8192 slots
+//          (two per CU) 38.5 ms, 128 / 4096 (four) 38.2, 128 / 2048 (seven) 50.6, 64 / 2048 (seven) 71.6, 64 / 4096 (four) 61.6 --
+//          waves per CU and paths per piece both count, and LDS trades one for the other.
 static int sp_launch(const int64_t *rowptr, const int32_t *col, const float *val, const int32_t *revpos, const uint32_t *fx32,
-                     const float *node_w, const uint16_t *cuts, const uint32_t *wpaths, const int32_t *bounds, int64_t n_nodes,
+                     const float *node_w, const uint16_t *cuts, const uint32_t *wpaths, const uint32_t *ssum, const uint32_t *smax,
+                     const int32_t *bounds, int64_t n_nodes,
                      int64_t nnz, const int32_t *columns, int64_t n_columns, int32_t shift, int32_t variant, eps_survivors *out,
                      uint32_t *status, void *stream);
 
 extern "C" int eps_scan_screen(const int64_t *rowptr, const int32_t *col, const int32_t *revpos, const uint32_t *fx32,
-                               const uint16_t *cuts, const uint32_t *wpaths_or_null, const int32_t *bounds, int64_t n_nodes,
-                               int64_t nnz, const int32_t *columns, int64_t n_columns, int32_t shift, int32_t variant,
-                               eps_survivors *out, uint32_t *status, void *stream)
+                               const uint16_t *cuts, const uint32_t *wpaths_or_null, const uint32_t *ssum_or_null,
+                               const uint32_t *smax_or_null, const int32_t *bounds, int64_t n_nodes, int64_t nnz,
+                               const int32_t *columns, int64_t n_columns, int32_t shift, int32_t variant, eps_survivors *out,
+                               uint32_t *status, void *stream)
 {
     EPS_REQUIRE(n_columns == 0 || n_nodes == 0 || fx32, "eps_scan_screen: null pointer");
-    return sp_launch(rowptr, col, nullptr, revpos, fx32, nullptr, cuts, wpaths_or_null, bounds, n_nodes, nnz, columns, n_columns, shift,
-                     variant, out, status, stream);
+    EPS_REQUIRE((ssum_or_null == nullptr) == (smax_or_null == nullptr), "eps_scan_screen: ssum and smax come together");
+    return sp_launch(rowptr, col, nullptr, revpos, fx32, nullptr, cuts, wpaths_or_null, ssum_or_null, smax_or_null, bounds, n_nodes, nnz,
+                     columns, n_columns, shift, variant, out, status, stream);
 }
 
 // The same scan on a SYMMETRIC adjacency with stored values (val[e] == val[mirror of e]); node_w = the float node weights.
@@ -1009,12 +1212,13 @@ extern "C" int eps_scan_screen_weighted(const int64_t *rowptr, const int32_t *co
                                         void *stream)
 {
     EPS_REQUIRE(n_columns == 0 || n_nodes == 0 || (val && node_w), "eps_scan_screen_weighted: null pointer");
-    return sp_launch(rowptr, col, val, revpos, nullptr, node_w, cuts, wpaths_or_null, bounds, n_nodes, nnz, columns, n_columns, shift,
-                     variant, out, status, stream);
+    return sp_launch(rowptr, col, val, revpos, nullptr, node_w, cuts, wpaths_or_null, nullptr, nullptr, bounds, n_nodes, nnz, columns,
+                     n_columns, shift, variant, out, status, stream);
 }
 
 static int sp_launch(const int64_t *rowptr, const int32_t *col, const float *val, const int32_t *revpos, const uint32_t *fx32,
-                     const float *node_w, const uint16_t *cuts, const uint32_t *wpaths, const int32_t *bounds, int64_t n_nodes,
+                     const float *node_w, const uint16_t *cuts, const uint32_t *wpaths, const uint32_t *ssum, const uint32_t *smax,
+                     const int32_t *bounds, int64_t n_nodes,
                      int64_t nnz, const int32_t *columns, int64_t n_columns, int32_t shift, int32_t variant, eps_survivors *out,
                      uint32_t *status, void *stream)
 {
@@ -1054,6 +1258,13 @@ static int sp_launch(const int64_t *rowptr, const int32_t *col, const float *val
     p.col_bytes = (uint32_t)(nnz * 4);
     p.table_bits = bits;
     p.piece_paths = (1u << bits) / 2u;
+    p.ssum = ssum;
+    p.smax = smax;
+    p.packed_paths = 1u << bits;
+    p.packed_dmax = shift > 8 ? (shift - 8 < 24 ? shift - 8 : 24) : 0;      // (weights keep at least 2^-8 resolution)
+    // measured on the ppa-like graph (tools/r03_screen_ab.py): 1500 -> 23.8 ms, 2270 -> 23.5, 4000 -> 23.7; packed_paths 3584 / 4096 /
+    // 5120 -> 24.0 / 23.5 / 24.1 ms
+    p.mode_ratio = 2270u;
     p.shift = shift;
     p.scale = ldexpf(1.0f, -shift);
     p.next_col = counter;

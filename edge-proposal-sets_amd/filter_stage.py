@@ -246,7 +246,7 @@ def run(args) -> str:
         # streaming top-K; every rank ends with the same list
         st = {}
         with torch.no_grad():
-            best_pairs, best_scores = scan.scan_topk(data.adj_t, scan_w, keep, rank, world, stats=st)
+            best_pairs, best_scores = scan.scan_topk(data.adj_t, scan_w, keep, rank, world, stats=st, relabel=True)
         torch.cuda.synchronize(device)
         dt = time.perf_counter() - t0
         bar = None if st["bar"] is None else float(st["bar"])

@@ -550,11 +550,16 @@ SCAN_VARIANT = 2          # default workgroup / table geometry of eps_scan_scree
 
 def scan_screen(rowptr, col, revpos, fx32, cuts, bounds, n_nodes: int, columns: torch.Tensor, shift: int, out: "Survivors",
                 status: torch.Tensor, variant: Optional[int] = None, val: Optional[torch.Tensor] = None,
-                node_w: Optional[torch.Tensor] = None, wpaths: Optional[torch.Tensor] = None) -> None:
+                node_w: Optional[torch.Tensor] = None, wpaths: Optional[torch.Tensor] = None,
+                ssum: Optional[torch.Tensor] = None, smax: Optional[torch.Tensor] = None) -> None:
     """Launch eps_scan_screen over ``columns``; survivors (screening scores) accumulate in ``out``.  ``val`` / ``node_w``
-    (float32 stored values / node weights): the weighted flavour (eps_scan_screen_weighted; ``fx32`` unused)."""
-    dev = _need_gpu(rowptr, col, revpos, fx32, cuts, bounds, columns, status, val, node_w, wpaths)
-    _chk(wpaths, torch.int32, "wpaths")
+    (float32 stored values / node weights): the weighted flavour (eps_scan_screen_weighted; ``fx32`` unused).
+    ``ssum`` / ``smax`` (int32-bits [N] / [M + 1]; unit-valued graphs): per-node sums of fx32 over the row and their
+    suffix maxima at the window boundaries -- they let pieces keep key and sum in one table word (include/eps_abi.h)."""
+    dev = _need_gpu(rowptr, col, revpos, fx32, cuts, bounds, columns, status, val, node_w, wpaths, ssum, smax)
+    _chk(wpaths, torch.int32, "wpaths"); _chk(ssum, torch.int32, "ssum"); _chk(smax, torch.int32, "smax")
+    if (ssum is None) != (smax is None) or (ssum is not None and (ssum.numel() != n_nodes or smax.numel() != scan_windows() + 1)):
+        raise _lib.EpsError("scan_screen: ssum / smax do not match the graph")
     if wpaths is not None and tuple(wpaths.shape) != (n_nodes, scan_windows()):
         raise _lib.EpsError("scan_screen: wpaths does not match the graph")
     _chk(rowptr, torch.int64, "rowptr"); _chk(col, torch.int32, "col"); _chk(revpos, torch.int32, "revpos")
@@ -573,7 +578,8 @@ def scan_screen(rowptr, col, revpos, fx32, cuts, bounds, n_nodes: int, columns: 
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev[0].record(torch.cuda.current_stream(dev))
         if val is None:
-            _lib.check(lib.eps_scan_screen(_ptr(rowptr), _ptr(col), _ptr(revpos), _ptr(fx32), _ptr(cuts), _ptr(wpaths), _ptr(bounds), n_nodes,
+            _lib.check(lib.eps_scan_screen(_ptr(rowptr), _ptr(col), _ptr(revpos), _ptr(fx32), _ptr(cuts), _ptr(wpaths), _ptr(ssum),
+                                           _ptr(smax), _ptr(bounds), n_nodes,
                                            col.numel(), _ptr(columns), columns.numel(), int(shift), variant, _ptr(out.rec), _ptr(status),
                                            _stream(dev)), "eps_scan_screen")
         else:

@@ -36,6 +36,7 @@ SMALL_SET = 1 << 25        # candidate sets with at most this many two-hop half 
 MAX_K = 1 << 30            # rows a survivor list (< 2^32 slots, handed out in chunks) can be asked for; beyond: block streaming
 MAX_LAUNCHES = 8           # estimate -> scan -> correct rounds before giving up (two are the rule)
 _CHUNK_SLACK = 8192 * 320  # survivor slots are handed out in chunks of 8192 per workgroup
+PACKED_PIECES = True         # eps_scan_screen may keep key and sum of a candidate in one table word (see _sum_bounds)
 RELABEL_MIN_NODES = 100_000  # graphs at least this large are scanned under hubs-first labels (see scan_graph)
 ONE_PASS = True            # score with the one-pass piece kernel (csrc/scan_pieces.hip) where the graph qualifies, else eps_filter_scan
 _PIECE_SLACK = 8192 * 1024 + 65536   # eps_scan_screen hands slots out in chunks of <= 32768 per workgroup (<= 1024 workgroups)
@@ -138,9 +139,11 @@ def scan_graph(g: CSRGraph, build: bool = False):
     of up to 3.7 M half paths (several rounds of row descriptors, several windows of tiles, buckets far beyond the L2);
     hubs first no column has more than 64 k -- the same 8.35 G paths in uniform columns: 47.8 -> 44.8 ms per scan
     (tools/scan_ab.py RELABEL=1).  Scores do not depend on the labels (order-independent fixed-point sums).
-    Relabelling sorts the stored entries once (~35 ms for 42.5 M): worth it for a graph that is scanned repeatedly, not
-    for one scan -- so the relabelled copy is used when it exists (``build=True`` makes it; the GNN path builds the same
-    copy for its SpMM) and a one-shot caller (filter.py) scans the graph as it is."""
+    Relabelling sorts the stored entries once (9 ms for 42.5 M, tools/r03_cold_scan.py) and the one-pass kernel
+    (csrc/scan_pieces.hip) needs the even columns it gives, so even ONE scan repays it (first scan of a fresh ppa-like
+    graph 57.5 ms as labelled, 53.6 ms relabelled; every later scan 52 vs 33.6 ms): filter.py and bench.py pass
+    ``build=True`` / ``scan_topk(relabel=True)``; without it the relabelled copy is used when it already exists (the
+    GNN path builds the same copy for its SpMM) and the graph is scanned as labelled otherwise."""
     if g.val is not None:                 # stored values: only the piece kernel scans them, and it wants even columns
         gs, perm, _ = g.degree_ordered()
         return gs, perm
@@ -203,10 +206,24 @@ def screen_shift(bound: float, max_deg: int) -> int:
 
 class Screen:
     """What a launch of the piece kernel and the exact re-scoring of its survivors need, for one (graph, weight table)."""
-    __slots__ = ("fx32", "shift", "fixw", "val", "node_w", "usable")
+    __slots__ = ("fx32", "shift", "fixw", "val", "node_w", "usable", "ssum", "smax")
 
-    def __init__(self, fx32, shift, fixw, val, node_w, usable):
+    def __init__(self, fx32, shift, fixw, val, node_w, usable, ssum=None, smax=None):
         self.fx32, self.shift, self.fixw, self.val, self.node_w, self.usable = fx32, shift, fixw, val, node_w, usable
+        self.ssum, self.smax = ssum, smax
+
+
+def _sum_bounds(g: CSRGraph, fx32: torch.Tensor):
+    """(ssum int32-bits [N], smax int32-bits [M + 1]) for eps_scan_screen's packed pieces: ssum[v] = sum of the screening
+    weights over row v -- no pair with endpoint v sums to more -- and smax[k] = the largest ssum among ids >= bounds[k]."""
+    bounds, _ = screen_tables(g)
+    n = g.n_rows
+    per_entry = (fx32.to(torch.int64) & 0xFFFFFFFF)[g.col.long()]
+    pre = torch.cat([per_entry.new_zeros(1), torch.cumsum(per_entry, 0)])
+    ssum = (pre[g.rowptr[1:]] - pre[g.rowptr[:-1]]).clamp_(max=(1 << 31) - 1)
+    suffix = torch.cat([torch.cummax(ssum.flip(0), 0).values.flip(0), ssum.new_zeros(1)])
+    smax = suffix[bounds.long().clamp(max=n)]
+    return ssum.to(torch.int32).contiguous(), smax.to(torch.int32).contiguous()
 
 
 def screen_weights(g0: CSRGraph, g: CSRGraph, perm, node_w: torch.Tensor) -> Screen:
@@ -224,7 +241,9 @@ def screen_weights(g0: CSRGraph, g: CSRGraph, perm, node_w: torch.Tensor) -> Scr
             return Screen(None, shift, None, g.val, nw, fits and bool((nw >= 0).all().item()))
         fixw = _scan_weights(g0, g, perm, node_w)
         fx32, bad = ops.scan_screen_weights(fixw, shift)
-        return Screen(fx32, shift, fixw, None, None, fits and int(bad.item()) == 0)
+        usable = fits and int(bad.item()) == 0
+        ssum, smax = _sum_bounds(g, fx32) if usable and PACKED_PIECES and one_pass_available(g) else (None, None)
+        return Screen(fx32, shift, fixw, None, None, usable, ssum, smax)
     # (one entry per labelling: the tables are indexed by the SCANNED graph's node ids)
     return g0.weight_cached("screen_weights" if perm is None else "screen_weights_relabelled", node_w, build)
 
@@ -261,7 +280,7 @@ def _launch(g, fixw, columns, threshold, capacity, scores_only: bool = False, bo
             bounds, cuts = screen_tables(g)
             out.status = torch.empty(1, dtype=torch.int32, device=g.device)
             ops.scan_screen(g.rowptr, g.col, reverse_positions(g), screen.fx32, cuts, bounds, g.n_rows, columns, screen.shift, out,
-                            out.status, screen_variant(g), screen.val, screen.node_w, window_paths(g))
+                            out.status, screen_variant(g), screen.val, screen.node_w, window_paths(g), screen.ssum, screen.smax)
         else:
             ops.filter_scan(g.rowptr, g.col, reverse_positions(g), fixw, g.n_rows, columns, out, max_degree(g), window_splits(g))
     return out

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define EPS_ABI_VERSION 3   /* 2: eps_col_sums / eps_node_weights_f64 signatures (r02); 3: 64-bit survivor count, eps_scan_* (r03) */
+#define EPS_ABI_VERSION 4   /* 2: eps_col_sums / eps_node_weights_f64 signatures (r02); 3: 64-bit survivor count, eps_scan_* (r03); 4: eps_scan_screen takes ssum / smax */
 
 #define EPS_OK 0
 #define EPS_EINVAL (-1)   /* bad argument (null pointer, negative size, unsupported shape) */
@@ -219,6 +219,12 @@ int eps_filter_scan(const int64_t *rowptr, const int32_t *col, const int32_t *re
  *                           bit 1 a negative weight, bit 2 a weight that does not fit 32 bits.  shift must keep every
  *                           screening sum of the graph below 2^31 (bit 31 of a table word flags a known edge) (the caller's score bound: eps_amd.scan.screen_shift).
  *   eps_scan_screen       : out as for eps_filter_scan (slots are handed out in chunks of max(8192, 2 * table slots));
+ *                           ssum / smax (optional, both or neither; per graph and weight table): ssum[v] = sum of fx32 over
+ *                           row v (any pair's screening sum is at most the smaller of its two endpoints' ssum), smax[k] =
+ *                           the largest ssum among the ids >= bounds[k] (k = 0 .. M; smax[M] = 0).  With them, pieces whose
+ *                           sums provably fit next to their key bits keep key and sum in ONE table word (twice the
+ *                           candidates per piece); their weights drop up to shift - 8 low bits, rounded up (still an upper
+ *                           bound; out->val stays in units of 2^-shift);
  *                           variant 0: 512 threads / 8192-slot table (2 workgroups per CU), 1: 1024 / 16384 (1), 2: 256 / 4096 (4);
  *                           *status (device word, cleared by the call): bit 2 = a table filled up (results invalid). */
 int32_t eps_scan_windows(void);
@@ -237,7 +243,8 @@ int eps_scan_screen_weights(const int64_t *fixw, int64_t n, int32_t shift, uint3
 int eps_scan_window_paths(const int64_t *rowptr, const int32_t *col, const int32_t *revpos, const uint16_t *cuts,
                           int64_t n_nodes, uint32_t *wpaths, void *stream);
 int eps_scan_screen(const int64_t *rowptr, const int32_t *col, const int32_t *revpos, const uint32_t *fx32,
-                    const uint16_t *cuts, const uint32_t *wpaths_or_null, const int32_t *bounds, int64_t n_nodes, int64_t nnz,
+                    const uint16_t *cuts, const uint32_t *wpaths_or_null, const uint32_t *ssum_or_null,
+                    const uint32_t *smax_or_null, const int32_t *bounds, int64_t n_nodes, int64_t nnz,
                     const int32_t *columns, int64_t n_columns, int32_t shift, int32_t variant, eps_survivors *out,
                     uint32_t *status, void *stream);
 /* eps_scan_screen_weighted: the scan on a SYMMETRIC adjacency WITH stored values (collab: rank.py:32-35 keeps the summed

@@ -39,8 +39,9 @@ def _scan_all(eps, g, node_w, thr=float("-inf"), columns=None):
     return {(int(k & 0xFFFFFFFF), int(k >> 32)): float(s) for k, s in zip(keys, vals)}, n_cand
 
 
-def _screen_all(eps, g, node_w, thr=float("-inf"), columns=None, variant=2):
-    """The same through the one-pass kernel (eps_scan_screen + exact re-scoring): {(u, v): score}, candidate count."""
+def _screen_all(eps, g, node_w, thr=float("-inf"), columns=None, variant=2, packed=False):
+    """The same through the one-pass kernel (eps_scan_screen + exact re-scoring): {(u, v): score}, candidate count.
+    ``packed``: hand the kernel the per-node sum bounds, so pieces may keep key and sum in one table word."""
     from eps_amd import scan
     sc = scan.screen_weights(g, g, None, node_w)
     assert sc.usable
@@ -50,7 +51,8 @@ def _screen_all(eps, g, node_w, thr=float("-inf"), columns=None, variant=2):
     res = eps.ops.Survivors(cap, thr, g.device)
     status = torch.zeros(1, dtype=torch.int32, device=g.device)
     eps.ops.scan_screen(g.rowptr, g.col, scan.reverse_positions(g), sc.fx32, cuts, bounds, g.n_rows, cols, sc.shift, res, status,
-                        variant, sc.val, sc.node_w)
+                        variant, sc.val, sc.node_w, ssum=sc.ssum if packed else None, smax=sc.smax if packed else None)
+    assert not packed or sc.val is not None or sc.ssum is not None or not scan.one_pass_available(g)
     slots, n_cand = res.counts()
     assert slots <= res.capacity and int(status) == 0
     keys, approx = res.valid(slots)
@@ -131,15 +133,15 @@ def test_scan_bar_and_column_subsets(eps, oracle, dev, seed, scale, ef):
     want_cn = {(int(u), int(v)): float(c) for (u, v), c in zip(pairs[lower], cnt[lower])}
     assert cn_got == want_cn
     # the one-pass kernel on the same inputs: whole set, a high bar, a column shard, unit weights
-    for variant in (2, 0):
-        got, n3 = _screen_all(eps, g, wt, variant=variant)
+    for variant, packed in ((2, False), (2, True), (0, True)):
+        got, n3 = _screen_all(eps, g, wt, variant=variant, packed=packed)
         assert n3 == n_cand and got == full
         bar = float(sc[int(0.99 * (len(sc) - 1))])
-        got, _ = _screen_all(eps, g, wt, thr=bar, variant=variant)
+        got, _ = _screen_all(eps, g, wt, thr=bar, variant=variant, packed=packed)
         assert got == {k: s for k, s in full.items() if s > bar}
-        got, n4 = _screen_all(eps, g, wt, columns=order[1::3].contiguous(), variant=variant)
+        got, n4 = _screen_all(eps, g, wt, columns=order[1::3].contiguous(), variant=variant, packed=packed)
         assert got == parts[1][0] and n4 == parts[1][1]
-        got, _ = _screen_all(eps, g, ones, variant=variant)
+        got, _ = _screen_all(eps, g, ones, variant=variant, packed=packed)
         assert got == want_cn
 
 
@@ -453,8 +455,8 @@ def test_scan_and_unit_lists_on_structured_graphs(eps, dev, name):
     # into partitioned passes): the same survivors, bit-identical scores, with and without a bar
     if scan.max_degree(g) < 1 << 16:
         bar = sorted(full.values())[len(full) // 2] if full else 0.0
-        for variant in (2, 0, 1):
-            got, nc = _screen_all(eps, g, wt, variant=variant)
-            assert nc == len(full) and got == full, (name, variant)
-            got, nc = _screen_all(eps, g, wt, thr=bar, variant=variant)
-            assert nc == len(full) and got == {k: x for k, x in full.items() if x > bar}, (name, variant)
+        for variant, packed in ((2, False), (2, True), (0, False), (0, True), (1, True)):
+            got, nc = _screen_all(eps, g, wt, variant=variant, packed=packed)
+            assert nc == len(full) and got == full, (name, variant, packed)
+            got, nc = _screen_all(eps, g, wt, thr=bar, variant=variant, packed=packed)
+            assert nc == len(full) and got == {k: x for k, x in full.items() if x > bar}, (name, variant, packed)

@@ -10,7 +10,11 @@ OUT = os.path.join(ROOT, "tools", "libeps_spstamp.so")
 NAMES = ["column setup (id, bounds)", "plan: paths per window (cut rows + wave sums)", "plan: pieces (wave 0) + barrier",
          "describe (cut gathers, unit scans, descriptors)", "walk (start bits, look-ups, loads, table updates) + barriers", "known edges in (before the walk, no barrier of its own)",
          "table scan + barrier", "ticket hand-over", "(count) pieces", "(count) direct pieces", "(count) rounds walked",
-         "  walk: start bits + barrier + word ranks (first range)", "  walk: first look-up + row load until it ARRIVED (vmcnt 0)", "(count) columns", "  walk: table updates (+ further units)", "(count) paths of direct pieces (x parts)"]
+         "  walk: start bits + barrier + word ranks (first range)", "  walk: first look-up + row load until it ARRIVED (vmcnt 0)", "(count) columns", "  walk: table updates (+ further units)", "(count) paths of direct pieces (x parts)",
+         "(count) direct pieces x parts", "(count) their paths", "(count) packed pieces", "(count) their paths", "(count) hash pieces x parts", "(count) their paths x parts",
+         "  describe + walk of direct pieces", "  describe + walk of packed pieces", "  describe + walk of hash pieces",
+         "  table scan of direct pieces", "  table scan of packed pieces", "  table scan of hash pieces",
+         "(count) packed: unit groups walked by wave 0", "(count) packed: probe rounds of those", "(count) hash: unit groups walked by wave 0", "(count) hash: probe rounds of those"]
 
 def build():
     s = open(os.path.join(CSRC, "scan_pieces.hip")).read()
@@ -18,17 +22,17 @@ def build():
         nonlocal s
         assert s.count(old) == count, (s.count(old), old)
         s = s.replace(old, new)
-    rep('struct sp_params {', '''__device__ unsigned long long g_sp_stamp[16];
+    rep('struct sp_params {', '''__device__ unsigned long long g_sp_stamp[32];
 #define XS(var) unsigned long long var; asm volatile("s_memtime %0\\n\\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory")
 #define XA(i, a, b) xst[i] += (b) - (a)
-extern "C" int eps_debug_piece_stamps(unsigned long long *out16, int reset)
+extern "C" int eps_debug_piece_stamps(unsigned long long *out32, int reset)
 {
-    (void)hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_sp_stamp), sizeof(unsigned long long) * 16);
-    if (reset) { unsigned long long z[16] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_sp_stamp), z, sizeof(z)); }
+    (void)hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_sp_stamp), sizeof(unsigned long long) * 32);
+    if (reset) { unsigned long long z[32] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_sp_stamp), z, sizeof(z)); }
     return 0;
 }
 struct sp_params {''')
-    rep('    while (t < ncol) {\n', '    unsigned long long xst[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};\n    while (t < ncol) {\n        XS(t0);\n        xst[13] += 1;\n')
+    rep('    while (t < ncol) {\n', '    unsigned long long xst[32] = {0};\n    while (t < ncol) {\n        XS(t0);\n        xst[13] += 1;\n')
     rep('        if (dv > 0 && v > 0) {\n', '        XS(t1); XA(0, t0, t1);\n        if (dv > 0 && v > 0) {\n')
     rep('            // ---- plan: merge windows into pieces.', '            XS(t2); XA(1, t1, t2);\n            // ---- plan: merge windows into pieces.')
     rep('            const int np = s_np;\n', '            const int np = s_np;\n            XS(t3); XA(2, t2, t3);\n            xst[8] += np;\n')
@@ -37,14 +41,23 @@ struct sp_params {''')
     rep('                            sp_unit fa[SP_G], fb[SP_G];\n                            fetch_group(0, fa);\n', '                            sp_unit fa[SP_G], fb[SP_G];\n                            XS(w1); if (ulo == 0u) XA(11, d1, w1);\n                            fetch_group(0, fa);\n                            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");\n                            XS(w2); XA(12, w1, w2);\n')
     rep('                            }\n                        }\n                            if (uhi < (uint32_t)total) sp_barrier();       // (the next range rewrites the start bits)\n', '                            }\n                            XS(w3); XA(14, w2, w3);\n                        }\n                            if (uhi < (uint32_t)total) sp_barrier();       // (the next range rewrites the start bits)\n')
     rep('                        sp_barrier();        // the next round / the scan follows: descriptors and table updates are complete\n',
-        '                        sp_barrier();        // the next round / the scan follows: descriptors and table updates are complete\n                        XS(d2); XA(4, d1, d2);\n')
-    rep('                    // ---- known edges in: the neighbours of v inside the piece take their slots BEFORE the walk', '                    XS(e0);\n                    xst[9] += direct ? 1 : 0;\n                    xst[15] += direct ? ppaths : 0;\n                    // ---- known edges in: the neighbours of v inside the piece take their slots BEFORE the walk')
+        '                        sp_barrier();        // the next round / the scan follows: descriptors and table updates are complete\n                        XS(d2); XA(4, d1, d2); XA(22 + xmode, d0, d2);\n')
+    rep('                    // ---- known edges in: the neighbours of v inside the piece take their slots BEFORE the walk', '                    XS(e0);\n                    xst[9] += direct ? 1 : 0;\n                    xst[15] += direct ? ppaths : 0;\n                    const int xmode = direct ? 0 : packed ? 1 : 2;\n                    xst[16 + 2 * xmode] += 1; xst[17 + 2 * xmode] += ppaths;\n                    // ---- known edges in: the neighbours of v inside the piece take their slots BEFORE the walk')
     rep('                    for (int r = 0; r < rounds; ++r) {\n', '                    XS(e01); XA(5, e0, e01);\n                    for (int r = 0; r < rounds; ++r) {\n')
     rep('                    // ---- scan the table: count the candidates', '                    XS(e1);\n                    // ---- scan the table: count the candidates')
-    rep('                    new_keys = 0u;\n                    sp_barrier();\n', '                    new_keys = 0u;\n                    sp_barrier();\n                    XS(e2); XA(6, e1, e2);\n')
+    rep('                    new_keys = 0u;\n                    sp_barrier();\n', '                    new_keys = 0u;\n                    sp_barrier();\n                    XS(e2); XA(6, e1, e2); XA(25 + xmode, e1, e2);\n')
     rep('        if (tid == 0) s_ticket = t_next;\n        sp_barrier();\n        t = s_ticket;\n        sp_barrier();\n',
         '        XS(t8);\n        if (tid == 0) s_ticket = t_next;\n        sp_barrier();\n        t = s_ticket;\n        sp_barrier();\n        XS(t9); XA(7, t8, t9);\n')
-    rep('    // candidates scored by this workgroup: one atomic per wave\n', '    if (tid == 0)\n        for (int i = 0; i < 16; ++i) atomicAdd(&g_sp_stamp[i], xst[i]);\n    // candidates scored by this workgroup: one atomic per wave\n')
+    rep('    // candidates scored by this workgroup: one atomic per wave\n', '    if (tid == 0)\n        for (int i = 0; i < 32; ++i) atomicAdd(&g_sp_stamp[i], xst[i]);\n    // candidates scored by this workgroup: one atomic per wave\n')
+    pat = "                                uint32_t tries = 0;\n"
+    i1 = s.index(pat)
+    s = s[:i1] + pat[:-1] + " xst[28] += 1;\n" + s[i1 + len(pat):]
+    i2 = s.index(pat, i1 + 40)
+    s = s[:i2] + pat[:-1] + " xst[30] += 1;\n" + s[i2 + len(pat):]
+    j1 = s.index("if (++tries > mask + 1u) {")
+    s = s[:j1] + "xst[29] += 1; " + s[j1:]
+    j2 = s.index("if (++tries > mask + 1u) {", j1 + 60)
+    s = s[:j2] + "xst[31] += 1; " + s[j2:]
     tmp = os.path.join(CSRC, "_sp_stamp_tmp.hip")
     open(tmp, "w").write(s)
     try:
@@ -74,9 +87,10 @@ def run():
     lib.eps_scan_screen.restype = ctypes.c_int
     lib.eps_scan_screen.argtypes = _lib.SIGNATURES["eps_scan_screen"][1]
     lib.eps_debug_piece_stamps.argtypes = [ctypes.c_void_p, ctypes.c_int]
-    variant = int(os.environ.get("VARIANT", "0"))
+    variant = int(os.environ.get("VARIANT", "2"))
+    packed = os.environ.get("PACKED", "1") == "1"
     bar = float(os.environ.get("BAR", "2.378"))
-    buf = (ctypes.c_ulonglong * 16)()
+    buf = (ctypes.c_ulonglong * 32)()
     lib.eps_debug_piece_stamps(buf, 1)
     for rep in range(2):
         res = ops.Survivors(48 << 20, bar, dev)
@@ -86,17 +100,17 @@ def run():
             lib.eps_debug_piece_stamps(buf, 1)
         e0.record()
         rc = lib.eps_scan_screen(g.rowptr.data_ptr(), g.col.data_ptr(), scan.reverse_positions(g).data_ptr(), fx32.data_ptr(), cuts.data_ptr(),
-                                 scan.window_paths(g).data_ptr(), bounds.data_ptr(), g.n_rows, g.nnz(), order.data_ptr(), order.numel(), shift, variant, res.rec.data_ptr(),
+                                 scan.window_paths(g).data_ptr(), sc.ssum.data_ptr() if packed else None, sc.smax.data_ptr() if packed else None, bounds.data_ptr(), g.n_rows, g.nnz(), order.data_ptr(), order.numel(), shift, variant, res.rec.data_ptr(),
                                  status.data_ptr(), torch.cuda.current_stream().cuda_stream)
         e1.record(); torch.cuda.synchronize()
         assert rc == 0
     lib.eps_debug_piece_stamps(buf, 0)
     x = list(buf)
     tot = sum(x[:8])
-    print(f"eps_scan_screen variant {variant} (stamped build) on the ppa-like graph, hubs-first labels, bar {bar}: {e0.elapsed_time(e1):.2f} ms; "
+    print(f"eps_scan_screen variant {variant}{' with packed pieces' if packed else ''} (stamped build) on the ppa-like graph, hubs-first labels, bar {bar}: {e0.elapsed_time(e1):.2f} ms; "
           f"slots, candidates {res.counts()}; s_memtime sums of thread 0 over all workgroups: {tot}")
     for i, nm in enumerate(NAMES):
-        print(f"{nm:52s} {x[i]:16d} {100.0 * x[i] / tot:7.2f}%" if (i < 8 or nm.startswith("  walk")) else f"{nm:52s} {x[i]:16d}")
+        print(f"{nm:52s} {x[i]:16d} {100.0 * x[i] / tot:7.2f}%" if (i < 8 or nm.startswith("  ")) else f"{nm:52s} {x[i]:16d}")
 
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "build":
