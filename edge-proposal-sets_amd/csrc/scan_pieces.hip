@@ -278,12 +278,15 @@ __global__ __launch_bounds__(T, 4) void scan_piece_kernel(sp_params p)      // (
                     // PACKED hash piece: key (id - lo) and sum share a 32-bit word -- twice the keys per table.  The sum field
                     // must hold any pair's sum (at most min(S(v), S(u)) / 2^d + one rounding unit per path, flag bit on top)
                     // next to the key bits the run's id span needs; the weights may lose up to packed_dmax bits for it.
-                    int kp = k0;
+                    // DIRECT16: a direct piece of twice the ids, two 16-bit fields (flag + 15-bit sum) per table word, under the
+                    // same sum bound as a packed piece
+                    int kp = k0, kd16 = k0;
                     uint32_t ms = 0u;
                     if (pk_on) {
                         const uint32_t sm0 = (uint32_t)__builtin_amdgcn_readlane((int)smk, k0);
                         ms = sv < sm0 ? sv : sm0;
                         const uint32_t need_s = (ms >> p.packed_dmax) + (uint32_t)dv + 2u;
+                        if (need_s < 0x7FFFu) kd16 = k0 + __popcll(__ballot(in && (uint32_t)(hi_k - lo) <= 2u * direct_ids));
                         const uint32_t span = (uint32_t)(hi_k - lo);
                         const int kb = 32 - __clz((int)((span > 2u ? span : 2u) - 1u));
                         const uint32_t cap = kb >= 30 ? 0u : (1u << (31 - kb)) - 1u;
@@ -294,13 +297,20 @@ __global__ __launch_bounds__(T, 4) void scan_piece_kernel(sp_params p)      // (
                     // DIRECT or PACKED when the packed run reaches further: a piece costs a fixed overhead worth `mode_ratio` extra
                     // hashed paths (plan, describe, barriers, sweep), and a direct path a fraction of a hashed one -- the shorter
                     // direct run wins iff (Pp - Pd) * mode_ratio < Pd * Pp  (cost per path: F / P + c_mode)
-                    bool take_direct = kd >= kh && kd >= kp && kd > k0;
-                    if (!take_direct && kd > k0 && kp > kd && kp >= kh) {
-                        const uint32_t pd = (uint32_t)__builtin_amdgcn_readlane((int)ek, kd) - e0;
+                    const int kdd = kd16 > kd ? kd16 : kd;       // (the exact 32-bit sums when both kinds reach equally far)
+                    bool take_direct = kdd >= kh && kdd >= kp && kdd > k0;
+                    if (!take_direct && kdd > k0 && kp > kdd && kp >= kh) {
+                        const uint32_t pd = (uint32_t)__builtin_amdgcn_readlane((int)ek, kdd) - e0;
                         const uint32_t pp = (uint32_t)__builtin_amdgcn_readlane((int)ek, kp) - e0;
                         take_direct = (unsigned long long)(pp - pd) * p.mode_ratio < (unsigned long long)pd * pp;
                     }
-                    if (take_direct) {
+                    if (take_direct && kd16 > kd) {
+                        k1 = kd16;
+                        flag = 0xC0000000u;
+                        uint32_t d = 0u;
+                        while ((ms >> d) + (uint32_t)dv + 2u >= 0x7FFFu) ++d;
+                        pq = d | (16u << 8);
+                    } else if (take_direct) {
                         k1 = kd;
                         flag = 0x80000000u;
                     } else if (kp >= kh && kp > k0) {
@@ -347,12 +357,14 @@ __global__ __launch_bounds__(T, 4) void scan_piece_kernel(sp_params p)      // (
                 const int k0 = s_pk0[pi], k1 = s_pk1[pi];
                 const int na = s_pna[pi], nb = s_pnb[pi];
                 const uint32_t info = s_pinfo[pi];
-                const bool direct = (info >> 31) != 0u;
-                const bool packed = !HV && (info & 0x40000000u) != 0u;
+                const bool direct = (info >> 31) != 0u;                                   // direct, either kind
+                const bool d16 = !HV && (info >> 30) == 3u;
+                const bool packed = !HV && (info >> 30) == 1u;
+                const bool quant = packed || d16;                                        // weights drop pk_d low bits
                 const uint32_t ppaths = info & 0x3FFFFFFFu;
-                const uint32_t pq = packed ? s_pq[pi] : 0u;
+                const uint32_t pq = quant ? s_pq[pi] : 0u;
                 const uint32_t pk_d = pq & 0xFFu, pk_sb = 32u - (pq >> 8);      // weight bits dropped; bits of the flag + sum field
-                const uint32_t pk_flag = packed ? 1u << (pk_sb - 1u) : 0u;
+                const uint32_t pk_flag = quant ? 1u << (pk_sb - 1u) : 0u;
                 const uint32_t pk_thr = thr32 >= SP_FLAG ? 0xFFFFFFFFu : ((thr32 >> pk_d) ? (thr32 >> pk_d) : 1u);
                 const int32_t lo_id = s_plo[pi], hi_id = s_phi[pi];
                 // hash geometry: the smallest power-of-two table with load <= 1/2; a heavier single window goes in `parts` passes
@@ -368,10 +380,13 @@ __global__ __launch_bounds__(T, 4) void scan_piece_kernel(sp_params p)      // (
                     while (bits < max_bits && (1u << bits) < 2u * per) ++bits;
                 }
                 const uint32_t mask = (1u << bits) - 1u;
-                const uint32_t scan_slots = direct ? (uint32_t)(hi_id - lo_id) : (1u << bits);
+                const uint32_t span = (uint32_t)(hi_id - lo_id);
+                const uint32_t scan_slots = d16 ? (span + 1u) >> 1 : direct ? span : (1u << bits);      // table words to sweep
+                const uint32_t cand_max = direct ? span : (1u << bits);
                 if (tid == 0) {
-                    uint32_t need = ppaths < scan_slots ? ppaths : scan_slots;    // survivors <= distinct endpoints <= paths, slots
+                    uint32_t need = ppaths < cand_max ? ppaths : cand_max;        // survivors <= distinct endpoints <= paths, slots
                     if (!no_bar && need > 1024u) need = 1024u;
+                    if (need > chunk) need = chunk;                               // (a 16-bit direct piece without a bar: the rest takes single slots)
                     const uint32_t left = s_out_cur < s_out_end ? s_out_end - s_out_cur : 0u;
                     if (left < need) {
                         const unsigned long long b64 = atomicAdd(&p.out->count, (unsigned long long)chunk);
@@ -397,7 +412,10 @@ __global__ __launch_bounds__(T, 4) void scan_piece_kernel(sp_params p)      // (
                     for (int j = single ? tid : na + tid; j < nb; j += T) {
                         const uint32_t u = single ? my_w : (uint32_t)vcol[j];
                         if (j >= na && (int32_t)u >= lo_id && (int32_t)u < hi_id) {
-                            if (direct) {
+                            if (d16) {
+                                const uint32_t o = u - (uint32_t)lo_id;
+                                atomicOr(&lds[o >> 1], 0x8000u << ((o & 1u) << 4));
+                            } else if (direct) {
                                 lds[u - (uint32_t)lo_id] = SP_FLAG;
                             } else if (packed) {
                                 const uint32_t mix = sp_mix(u);
@@ -461,7 +479,7 @@ __global__ __launch_bounds__(T, 4) void scan_piece_kernel(sp_params p)      // (
                         const uint32_t a_u = (uint32_t)(incl - units + woff);          // first unit of this thread's row
                         if (flag) {
                             const int d = incl_f - 1 + woff_f;
-                            r_desc[d] = make_uint4(base + a, len, packed ? (fx + ((1u << pk_d) - 1u)) >> pk_d : fx, a_u);
+                            r_desc[d] = make_uint4(base + a, len, quant ? (fx + ((1u << pk_d) - 1u)) >> pk_d : fx, a_u);
                             if (a_u < (uint32_t)SP_UBITS) atomicOr(&ubits[a_u >> 5], 1u << (a_u & 31u));      // (the first range's start bits)
                         }
                         sp_barrier();
@@ -528,7 +546,16 @@ __global__ __launch_bounds__(T, 4) void scan_piece_kernel(sp_params p)      // (
                             return (uint32_t)__builtin_ceilf(f.a4[e] * __builtin_bit_cast(float, f.fx)) + 1u;
                         };
                         auto consume_group = [&](const sp_unit (&f)[SP_G]) {
-                            if (direct) {
+                            if (d16) {
+#pragma unroll
+                                for (int q = 0; q < SP_G; ++q)
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e)
+                                        if (e < f[q].nvalid) {
+                                            const uint32_t o = (uint32_t)(f[q].u4[e] - lo_id);
+                                            atomicAdd(&lds[o >> 1], f[q].fx << ((o & 1u) << 4));
+                                        }
+                            } else if (direct) {
 #pragma unroll
                                 for (int q = 0; q < SP_G; ++q)
 #pragma unroll
@@ -713,8 +740,14 @@ __global__ __launch_bounds__(T, 4) void scan_piece_kernel(sp_params p)      // (
                     };
                     // (the sweeps read in batches of SP_SB uint4 per thread before they look at any of them: one LDS round trip per
                     //  batch instead of one per 16 bytes; the trip counts are uniform over the workgroup)
+                    // A word is tested as a SIGNED number: a known edge's flag is its sign bit, so `(int)word >= bar` is false for it
+                    // (and for an empty word), and the largest of a uint4's four words decides with one branch whether any of them
+                    // needs a closer look -- survivors are a handful per piece.
                     uint32_t cnt_here = 0u;
-                    if (direct) {
+                    const int thr_s = thr32 >= SP_FLAG ? 0x7FFFFFFF : (int)thr32;      // (sums stay below 2^31 - 2)
+                    if (d16) {
+                        // (two fields per word: the low one shifted up, the high one masked, both signed as above)
+                        const int thr_h = pk_thr >= 0x8000u ? 0x7FFFFFFF : (int)(pk_thr << 16);
                         const uint32_t n4 = (scan_slots + 3u) & ~3u;
                         for (uint32_t i0 = 0; i0 < n4; i0 += 4u * SP_SB * T) {
                             uint4 s4[SP_SB];
@@ -727,17 +760,53 @@ __global__ __launch_bounds__(T, 4) void scan_piece_kernel(sp_params p)      // (
                             for (int b = 0; b < SP_SB; ++b) {
                                 const uint32_t i = i0 + 4u * T * b + 4u * tid;
                                 if (i < n4) *(uint4 *)(lds + i) = make_uint4(0u, 0u, 0u, 0u);
-                                const uint32_t sv[4] = {s4[b].x, s4[b].y, s4[b].z, s4[b].w};
+                                const uint32_t wv[4] = {s4[b].x, s4[b].y, s4[b].z, s4[b].w};
+                                int x[8];
 #pragma unroll
-                                for (int e = 0; e < 4; ++e)
-                                    if (sv[e] - 1u < SP_FLAG - 1u) {          // reached (non-zero) and not a known edge
-                                        ++cnt_here;
-                                        if (sv[e] >= thr32) emit((uint32_t)lo_id + i + e, sv[e]);
-                                    }
+                                for (int e = 0; e < 4; ++e) {
+                                    x[2 * e] = (int)(wv[e] << 16);
+                                    x[2 * e + 1] = (int)(wv[e] & 0xFFFF0000u);
+                                }
+#pragma unroll
+                                for (int e = 0; e < 8; ++e) cnt_here += x[e] > 0 ? 1u : 0u;
+                                int m = x[0];
+#pragma unroll
+                                for (int e = 1; e < 8; ++e) m = x[e] > m ? x[e] : m;
+                                if (m >= thr_h) {
+#pragma unroll
+                                    for (int e = 0; e < 8; ++e)
+                                        if (x[e] >= thr_h) emit((uint32_t)lo_id + 2u * i + e, ((uint32_t)x[e] >> 16) << pk_d);
+                                }
+                            }
+                        }
+                    } else if (direct) {
+                        const uint32_t n4 = (scan_slots + 3u) & ~3u;
+                        for (uint32_t i0 = 0; i0 < n4; i0 += 4u * SP_SB * T) {
+                            uint4 s4[SP_SB];
+#pragma unroll
+                            for (int b = 0; b < SP_SB; ++b) {
+                                const uint32_t i = i0 + 4u * T * b + 4u * tid;
+                                s4[b] = i < n4 ? *(const uint4 *)(lds + i) : make_uint4(0u, 0u, 0u, 0u);
+                            }
+#pragma unroll
+                            for (int b = 0; b < SP_SB; ++b) {
+                                const uint32_t i = i0 + 4u * T * b + 4u * tid;
+                                if (i < n4) *(uint4 *)(lds + i) = make_uint4(0u, 0u, 0u, 0u);
+                                const int sv[4] = {(int)s4[b].x, (int)s4[b].y, (int)s4[b].z, (int)s4[b].w};
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) cnt_here += sv[e] > 0 ? 1u : 0u;      // reached and not a known edge
+                                const int m01 = sv[0] > sv[1] ? sv[0] : sv[1], m23 = sv[2] > sv[3] ? sv[2] : sv[3];
+                                if ((m01 > m23 ? m01 : m23) >= thr_s) {
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e)
+                                        if (sv[e] >= thr_s) emit((uint32_t)lo_id + i + e, (uint32_t)sv[e]);
+                                }
                             }
                         }
                     } else if (packed) {
-                        const uint32_t smask = pk_flag - 1u;
+                        // (shifted left by the key bits a word is flag | sum at the top: signed again)
+                        const uint32_t kb = 32u - pk_sb;
+                        const int thr_p = pk_thr >= pk_flag ? 0x7FFFFFFF : (int)(pk_thr << kb);
                         for (uint32_t i0 = 0; i0 < scan_slots; i0 += 4u * SP_SB * T) {
                             uint4 s4[SP_SB];
 #pragma unroll
@@ -750,10 +819,13 @@ __global__ __launch_bounds__(T, 4) void scan_piece_kernel(sp_params p)      // (
                                 const uint32_t i = i0 + 4u * T * b + 4u * tid;
                                 if (i < scan_slots) *(uint4 *)(lds + i) = make_uint4(0u, 0u, 0u, 0u);
                                 const uint32_t sv[4] = {s4[b].x, s4[b].y, s4[b].z, s4[b].w};
+                                const int x[4] = {(int)(sv[0] << kb), (int)(sv[1] << kb), (int)(sv[2] << kb), (int)(sv[3] << kb)};
+                                const int m01 = x[0] > x[1] ? x[0] : x[1], m23 = x[2] > x[3] ? x[2] : x[3];
+                                if ((m01 > m23 ? m01 : m23) >= thr_p) {
 #pragma unroll
-                                for (int e = 0; e < 4; ++e)
-                                    if (!(sv[e] & pk_flag) && (sv[e] & smask) >= pk_thr)
-                                        emit((uint32_t)lo_id + (sv[e] >> pk_sb), (sv[e] & smask) << pk_d);
+                                    for (int e = 0; e < 4; ++e)
+                                        if (x[e] >= thr_p) emit((uint32_t)lo_id + (sv[e] >> pk_sb), ((uint32_t)x[e] >> kb) << pk_d);
+                                }
                             }
                         }
                     } else {
@@ -768,10 +840,13 @@ __global__ __launch_bounds__(T, 4) void scan_piece_kernel(sp_params p)      // (
 #pragma unroll
                             for (int b = 0; b < SP_SB; ++b) {
                                 const uint32_t i = i0 + 4u * T * b + 4u * tid;
-                                const uint32_t sv[4] = {s4[b].x, s4[b].y, s4[b].z, s4[b].w};
+                                const int sv[4] = {(int)s4[b].x, (int)s4[b].y, (int)s4[b].z, (int)s4[b].w};
+                                const int m01 = sv[0] > sv[1] ? sv[0] : sv[1], m23 = sv[2] > sv[3] ? sv[2] : sv[3];
+                                if ((m01 > m23 ? m01 : m23) >= thr_s) {
 #pragma unroll
-                                for (int e = 0; e < 4; ++e)
-                                    if (sv[e] >= thr32 && sv[e] < SP_FLAG) emit(tkey[i + e] - 1u, sv[e]);
+                                    for (int e = 0; e < 4; ++e)
+                                        if (sv[e] >= thr_s) emit(tkey[i + e] - 1u, (uint32_t)sv[e]);
+                                }
                                 if (i < scan_slots) {
                                     *(uint4 *)(tkey + i) = make_uint4(0u, 0u, 0u, 0u);
                                     *(uint4 *)(tval + i) = make_uint4(0u, 0u, 0u, 0u);

@@ -77,6 +77,52 @@ def plan(direct_ids, hash_paths, hash16_paths=0, span16=1 << 17, s16_max=0.0):
     return out, {k: torch.cat(x) if x else torch.zeros(0, dtype=torch.int64, device=dev) for k, x in hist.items()}
 
 
+def plan2(direct_ids, packed_paths, ratio=2270, direct16_ids=0, s16_max=0.0):
+    """The product planner (packed pieces for everything hashed; a direct run wins against a longer packed one iff
+    (Pp - Pd) * ratio < Pd * Pp), optionally with a second direct kind of `direct16_ids` ids for columns / windows whose sums
+    stay below s16_max."""
+    k0 = torch.zeros(N, dtype=torch.int64, device=dev)
+    live = (deg > 0) & (torch.arange(N, device=dev) > 0)
+    out = {k: [0, 0] for k in ("direct", "direct16", "packed", "part")}
+    hist = {k: [] for k in out}
+    smax_w = torch.stack([S[int(b[k]):int(b[k + 1])].max() if int(b[k + 1]) > int(b[k]) else S.new_zeros(()) for k in range(M)])
+    smax_run = torch.cummax(smax_w.flip(0), 0).values.flip(0)
+    for _ in range(M + 2):
+        act = live & (k0 <= kv)
+        if not bool(act.any()):
+            break
+        lo = b[k0].unsqueeze(1)
+        e0 = ek.gather(1, k0.unsqueeze(1))
+        nb0 = nbk.gather(1, k0.unsqueeze(1))
+        inr = (lane > k0.unsqueeze(1)) & (lane <= (kv + 1).unsqueeze(1))
+        kd32 = k0 + (inr & (hi_k - lo <= direct_ids)).sum(1)
+        kd16 = kd32.clone()
+        if direct16_ids:
+            ok16 = torch.minimum(S, smax_run[k0.clamp(max=M - 1)]) < s16_max
+            kd16 = torch.maximum(kd32, k0 + (inr & (hi_k - lo <= direct16_ids) & ok16.unsqueeze(1)).sum(1))
+        kd = kd16
+        keys = (ek - e0) + (nbk - nb0)
+        kp = k0 + (inr & (keys <= packed_paths)).sum(1)
+        pd = ek.gather(1, kd.clamp(max=M).unsqueeze(1)).squeeze(1) - e0.squeeze(1)
+        pp = ek.gather(1, kp.clamp(max=M).unsqueeze(1)).squeeze(1) - e0.squeeze(1)
+        take_d = (kd >= kp) & (kd > k0)
+        take_d |= (kd > k0) & (kp > kd) & ((pp - pd) * ratio < pd * pp)
+        is_16 = take_d & (kd > kd32)
+        is_d = take_d & ~is_16
+        is_p = ~take_d & (kp > k0)
+        is_x = ~take_d & ~is_p
+        k1 = torch.where(take_d, kd, torch.where(is_p, kp, k0 + 1)).clamp(max=M)
+        paths = ek.gather(1, k1.unsqueeze(1)).squeeze(1) - e0.squeeze(1)
+        nz = act & (paths > 0)
+        for name, m in (("direct", is_d), ("direct16", is_16), ("packed", is_p), ("part", is_x)):
+            sel = nz & m
+            out[name][0] += int(sel.sum())
+            out[name][1] += int(paths[sel].sum())
+            hist[name].append(paths[sel])
+        k0 = torch.where(act, k1, k0)
+    return out, {k: torch.cat(x) if x else torch.zeros(0, dtype=torch.int64, device=dev) for k, x in hist.items()}
+
+
 def show(title, res):
     out, hist = res
     tot_p = sum(x[0] for x in out.values())
@@ -98,3 +144,10 @@ for s16 in (32.0, 64.0, 128.0):
     show(f"+ 4-byte hash slots: 4096 paths, span <= 2^17, min(S(v), max S(u)) < {s16}", plan(8192, 2048, 4096, 1 << 17, s16))
 show("+ 4-byte hash slots, LF 3/4: 6144 paths, S < 64", plan(8192, 2048, 6144, 1 << 17, 64.0))
 show("+ 4-byte hash slots: 4096 paths, span <= 2^16, S < 64", plan(8192, 2048, 4096, 1 << 16, 64.0))
+
+print()
+show("product planner r03b (direct 8192 ids | packed 4096 paths, cost rule 2270)", plan2(8192, 4096))
+for s16 in (64.0, 128.0):
+    show(f"+ direct16 (16384 ids, two 16-bit sums per word) where min(S(v), max S(u)) < {s16}", plan2(8192, 4096, 2270, 16384, s16))
+show("+ direct16 everywhere (upper bound of what it can give)", plan2(8192, 4096, 2270, 16384, 1e30))
+show("direct 16384 ids everywhere, ratio 1500", plan2(16384, 4096, 1500))

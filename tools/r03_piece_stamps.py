@@ -14,7 +14,7 @@ NAMES = ["column setup (id, bounds)", "plan: paths per window (cut rows + wave s
          "(count) direct pieces x parts", "(count) their paths", "(count) packed pieces", "(count) their paths", "(count) hash pieces x parts", "(count) their paths x parts",
          "  describe + walk of direct pieces", "  describe + walk of packed pieces", "  describe + walk of hash pieces",
          "  table scan of direct pieces", "  table scan of packed pieces", "  table scan of hash pieces",
-         "(count) packed: unit groups walked by wave 0", "(count) packed: probe rounds of those", "(count) hash: unit groups walked by wave 0", "(count) hash: probe rounds of those"]
+         "(count) packed: unit groups walked by wave 0", "(count) packed: straggler trips of those (after the all-entries round)", "(count) hash: unit groups walked by wave 0", "(count) hash: straggler trips of those"]
 
 def build():
     s = open(os.path.join(CSRC, "scan_pieces.hip")).read()
@@ -49,14 +49,14 @@ struct sp_params {''')
     rep('        if (tid == 0) s_ticket = t_next;\n        sp_barrier();\n        t = s_ticket;\n        sp_barrier();\n',
         '        XS(t8);\n        if (tid == 0) s_ticket = t_next;\n        sp_barrier();\n        t = s_ticket;\n        sp_barrier();\n        XS(t9); XA(7, t8, t9);\n')
     rep('    // candidates scored by this workgroup: one atomic per wave\n', '    if (tid == 0)\n        for (int i = 0; i < 32; ++i) atomicAdd(&g_sp_stamp[i], xst[i]);\n    // candidates scored by this workgroup: one atomic per wave\n')
-    pat = "                                uint32_t tries = 0;\n"
+    pat = "                                bool have = false;\n"
     i1 = s.index(pat)
     s = s[:i1] + pat[:-1] + " xst[28] += 1;\n" + s[i1 + len(pat):]
     i2 = s.index(pat, i1 + 40)
     s = s[:i2] + pat[:-1] + " xst[30] += 1;\n" + s[i2 + len(pat):]
-    j1 = s.index("if (++tries > mask + 1u) {")
+    j1 = s.index("if (++tries > 4u * (mask + 2u)) {")
     s = s[:j1] + "xst[29] += 1; " + s[j1:]
-    j2 = s.index("if (++tries > mask + 1u) {", j1 + 60)
+    j2 = s.index("if (++tries > 4u * (mask + 2u)) {", j1 + 60)
     s = s[:j2] + "xst[31] += 1; " + s[j2:]
     tmp = os.path.join(CSRC, "_sp_stamp_tmp.hip")
     open(tmp, "w").write(s)
