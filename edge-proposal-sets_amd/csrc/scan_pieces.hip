@@ -968,6 +968,9 @@ __global__ void sp_screen_weights_kernel(const int64_t *__restrict__ fixw, int64
 #define RS_CHUNK 256
 #define RS_BITS (1 << 20)       // ids per bitmap window: 128 KiB of LDS
 #define RS_SHORT 512            // rows up to this long go through rescore_short_kernel
+#ifndef RS_NB
+#define RS_NB 16                // entries of N(v) a lane has in flight per trip: a trip is three dependent latencies (row, bitmap,
+#endif                          // weights), so the survivors' rows -- a few hundred entries -- should take ONE
 
 __global__ __launch_bounds__(RS_THREADS) void rescore_runs_kernel(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col,
                                                                  const int64_t *__restrict__ fixw, int32_t n_nodes,
@@ -1039,21 +1042,22 @@ __global__ __launch_bounds__(RS_THREADS) void rescore_runs_kernel(const int64_t 
                         const int64_t o = __shfl_xor(longest, 32);
                         longest = o > longest ? o : longest;
                     }
-                    for (int64_t off = 0; off < longest; off += 128) {     // (uniform trip count over the wave)
-                        int32_t wv[4];
+                    for (int64_t off = 0; off < longest; off += 32 * RS_NB) {     // (uniform trip count over the wave)
+                        int32_t wv[RS_NB];
 #pragma unroll
-                        for (int b = 0; b < 4; ++b) {
+                        for (int b = 0; b < RS_NB; ++b) {
                             const int64_t i = vb + off + b * 32 + hl;
                             wv[b] = i < ve ? col[i] : -1;
                         }
-                        long long add[4];
+                        long long add[RS_NB];
 #pragma unroll
-                        for (int b = 0; b < 4; ++b) {
+                        for (int b = 0; b < RS_NB; ++b) {
                             const uint32_t x = (uint32_t)(wv[b] - wlo);
                             const bool hit = wv[b] >= 0 && x < (uint32_t)RS_BITS && ((bm[x >> 5] >> (x & 31)) & 1u);
                             add[b] = hit ? (long long)fixw[wv[b]] : 0ll;
                         }
-                        acc += (add[0] + add[1]) + (add[2] + add[3]);
+#pragma unroll
+                        for (int b = 0; b < RS_NB; ++b) acc += add[b];
                     }
 #pragma unroll
                     for (int d = 16; d >= 1; d >>= 1) acc += __shfl_xor(acc, d);
