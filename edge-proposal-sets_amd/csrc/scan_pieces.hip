@@ -73,6 +73,8 @@ struct sp_params {
     const uint32_t *smax;       // [SP_M + 1] largest ssum among the ids >= bounds[k] (0 for k = SP_M); NULL with ssum
     uint32_t packed_paths;      // a PACKED hash piece holds at most this many paths (<= slots: key and sum share a word)
     int32_t packed_dmax;        // ... and may drop at most this many low bits of the screening weights
+    const uint32_t *pptr;       // [n_nodes + 1] first plan record of column v (per-graph plan table) or NULL: the kernel plans itself
+    const uint4 *plan;          // one record per piece: x = paths | kind bits, y = k0 | k1 << 8 | pq << 16, z = na | nb << 16, w = lo
     uint32_t mode_ratio;        // fixed cost of a piece in units of (a hashed path's cost - a direct path's cost)
     int32_t shift;              // screening fixed point: 2^-shift
     float scale;                // 2^-shift: screening sum -> approximate score
@@ -112,6 +114,92 @@ struct sp_unit {
     uint32_t fx;
     int nvalid;
 };
+
+// ---- the planner: one wave cuts a column into pieces (lane k = id window k; the extents are ballots over monotone predicates).
+// Used by the scan kernel itself (no plan table) and by sp_plan_kernel (the per-graph plan table): the same code, the same pieces.
+// emit(i, k0, k1, lo, hi, paths | kind bits, pq, na, nb) is called with wave-uniform arguments for piece i; returns the count.
+template <class Emit>
+__device__ __forceinline__ int sp_plan_column(const sp_params &p, int32_t v, int32_t dv, int lane, int32_t my_bound, uint32_t pwk,
+                                              int32_t nbk, uint32_t direct_ids, Emit emit)
+{
+    const uint32_t ek = (uint32_t)sp_wave_incl_scan((int)pwk) - pwk;      // paths in the windows before k (lane 32: all)
+    const bool pk_on = p.ssum != nullptr;      // (weighted graphs come without)
+    const uint32_t sv = pk_on ? p.ssum[v] : 0u;
+    const uint32_t smk = pk_on ? p.smax[lane <= SP_M ? lane : SP_M] : 0u;
+    // windows 0 .. kv hold ids below v
+    const int kv = __popcll(__ballot(lane >= 1 && lane < SP_M && my_bound <= v - 1));
+    const int32_t hi_k = my_bound < v ? my_bound : v;                    // end of the run [.., k) in id space
+    int np = 0, k0 = 0;
+    while (k0 <= kv) {
+        const int32_t lo = __builtin_amdgcn_readlane(my_bound, k0);
+        const uint32_t e0 = (uint32_t)__builtin_amdgcn_readlane((int)ek, k0);
+        const bool in = lane > k0 && lane <= kv + 1;
+        const int kd = k0 + __popcll(__ballot(in && (uint32_t)(hi_k - lo) <= direct_ids));
+        const int32_t nb0 = __builtin_amdgcn_readlane(nbk, k0);
+        // (the known edges of v inside a hash piece own slots too: they count toward its limit)
+        const int kh = k0 + __popcll(__ballot(in && (ek - e0) + (uint32_t)(nbk - nb0) <= p.piece_paths));
+        // PACKED hash piece: key (id - lo) and sum share a 32-bit word -- twice the keys per table.  The sum field
+        // must hold any pair's sum (at most min(S(v), S(u)) / 2^d + one rounding unit per path, flag bit on top)
+        // next to the key bits the run's id span needs; the weights may lose up to packed_dmax bits for it.
+        // DIRECT16: a direct piece of twice the ids, two 16-bit fields (flag + 15-bit sum) per table word, under the
+        // same sum bound as a packed piece
+        int kp = k0, kd16 = k0;
+        uint32_t ms = 0u;
+        if (pk_on) {
+            const uint32_t sm0 = (uint32_t)__builtin_amdgcn_readlane((int)smk, k0);
+            ms = sv < sm0 ? sv : sm0;
+            const uint32_t need_s = (ms >> p.packed_dmax) + (uint32_t)dv + 2u;
+            if (need_s < 0x7FFFu) kd16 = k0 + __popcll(__ballot(in && (uint32_t)(hi_k - lo) <= 2u * direct_ids));
+            const uint32_t span = (uint32_t)(hi_k - lo);
+            const int kb = 32 - __clz((int)((span > 2u ? span : 2u) - 1u));
+            const uint32_t cap = kb >= 30 ? 0u : (1u << (31 - kb)) - 1u;
+            kp = k0 + __popcll(__ballot(in && (ek - e0) + (uint32_t)(nbk - nb0) <= p.packed_paths && need_s < cap));
+        }
+        int k1;
+        uint32_t flag = 0u, pq = 0u;
+        // DIRECT or PACKED when the packed run reaches further: a piece costs a fixed overhead worth `mode_ratio` extra
+        // hashed paths (plan, describe, barriers, sweep), and a direct path a fraction of a hashed one -- the shorter
+        // direct run wins iff (Pp - Pd) * mode_ratio < Pd * Pp  (cost per path: F / P + c_mode)
+        const int kdd = kd16 > kd ? kd16 : kd;       // (the exact 32-bit sums when both kinds reach equally far)
+        bool take_direct = kdd >= kh && kdd >= kp && kdd > k0;
+        if (!take_direct && kdd > k0 && kp > kdd && kp >= kh) {
+            const uint32_t pd = (uint32_t)__builtin_amdgcn_readlane((int)ek, kdd) - e0;
+            const uint32_t pp = (uint32_t)__builtin_amdgcn_readlane((int)ek, kp) - e0;
+            take_direct = (unsigned long long)(pp - pd) * p.mode_ratio < (unsigned long long)pd * pp;
+        }
+        if (take_direct && kd16 > kd) {
+            k1 = kd16;
+            flag = 0xC0000000u;
+            uint32_t d = 0u;
+            while ((ms >> d) + (uint32_t)dv + 2u >= 0x7FFFu) ++d;
+            pq = d | (16u << 8);
+        } else if (take_direct) {
+            k1 = kd;
+            flag = 0x80000000u;
+        } else if (kp >= kh && kp > k0) {
+            k1 = kp;
+            flag = 0x40000000u;
+            const uint32_t span = (uint32_t)(__builtin_amdgcn_readlane(hi_k, k1) - lo);
+            const int kb = 32 - __clz((int)((span > 2u ? span : 2u) - 1u));
+            const uint32_t cap = (1u << (31 - kb)) - 1u;
+            uint32_t d = 0u;
+            while ((ms >> d) + (uint32_t)dv + 2u >= cap) ++d;         // (<= packed_dmax: the run passed the test with it)
+            pq = d | ((uint32_t)kb << 8);
+        } else if (kh > k0) {
+            k1 = kh;
+        } else {
+            k1 = k0 + 1;                                     // one window, wide and heavy: hash-partitioned passes
+        }
+        const uint32_t sum = (uint32_t)__builtin_amdgcn_readlane((int)ek, k1) - e0;
+        if (sum) {
+            emit(np, k0, k1, lo, __builtin_amdgcn_readlane(hi_k, k1), sum | flag, pq, __builtin_amdgcn_readlane(nbk, k0),
+                 __builtin_amdgcn_readlane(nbk, k1));
+            ++np;
+        }
+        k0 = k1;
+    }
+    return np;
+}
 
 // HV: the adjacency has stored values (collab: rank.py:32-35 keeps the summed multi-edge weights).  A path's term is then
 // (A[u,w] * A[v,w]) * node_w[w] -- symmetric in (u, v) like the unit-valued one, so the half scheme holds -- and its
@@ -255,95 +343,42 @@ __global__ __launch_bounds__(T, 4) void scan_piece_kernel(sp_params p)      // (
                 my_fx = HV ? __builtin_bit_cast(uint32_t, (p.val[vb + tid] * p.node_w[my_w]) * p.up) : p.fx32[my_w];
             }
             // ---- plan: merge windows into pieces.  Wave 0, lane k = window k: the extents are ballots over monotone predicates -
-            if (wib == 0) {
+            if (wib == 0 && !p.plan) {
                 const uint32_t pwk = lane < SP_M ? (p.wpaths ? p.wpaths[(size_t)v * SP_M + lane] : s_pw[lane]) : 0u;
                 // lane k: neighbours of v below window boundary k (row v's own cuts: cuts[v][k - 1]; 0 for k = 0)
                 const int32_t nbk = lane >= 1 && lane <= SP_M ? (int32_t)p.cuts[(size_t)v * SP_M + lane - 1] : 0;
-                const uint32_t ek = (uint32_t)sp_wave_incl_scan((int)pwk) - pwk;      // paths in the windows before k (lane 32: all)
-                const bool pk_on = !HV && p.ssum != nullptr;
-                const uint32_t sv = pk_on ? p.ssum[v] : 0u;
-                const uint32_t smk = pk_on ? p.smax[lane <= SP_M ? lane : SP_M] : 0u;
-                // windows 0 .. kv hold ids below v
-                const int kv = __popcll(__ballot(lane >= 1 && lane < SP_M && my_bound <= v - 1));
-                const int32_t hi_k = my_bound < v ? my_bound : v;                    // end of the run [.., k) in id space
-                int np = 0, k0 = 0;
-                while (k0 <= kv) {
-                    const int32_t lo = __builtin_amdgcn_readlane(my_bound, k0);
-                    const uint32_t e0 = (uint32_t)__builtin_amdgcn_readlane((int)ek, k0);
-                    const bool in = lane > k0 && lane <= kv + 1;
-                    const int kd = k0 + __popcll(__ballot(in && (uint32_t)(hi_k - lo) <= direct_ids));
-                    const int32_t nb0 = __builtin_amdgcn_readlane(nbk, k0);
-                    // (the known edges of v inside a hash piece own slots too: they count toward its limit)
-                    const int kh = k0 + __popcll(__ballot(in && (ek - e0) + (uint32_t)(nbk - nb0) <= p.piece_paths));
-                    // PACKED hash piece: key (id - lo) and sum share a 32-bit word -- twice the keys per table.  The sum field
-                    // must hold any pair's sum (at most min(S(v), S(u)) / 2^d + one rounding unit per path, flag bit on top)
-                    // next to the key bits the run's id span needs; the weights may lose up to packed_dmax bits for it.
-                    // DIRECT16: a direct piece of twice the ids, two 16-bit fields (flag + 15-bit sum) per table word, under the
-                    // same sum bound as a packed piece
-                    int kp = k0, kd16 = k0;
-                    uint32_t ms = 0u;
-                    if (pk_on) {
-                        const uint32_t sm0 = (uint32_t)__builtin_amdgcn_readlane((int)smk, k0);
-                        ms = sv < sm0 ? sv : sm0;
-                        const uint32_t need_s = (ms >> p.packed_dmax) + (uint32_t)dv + 2u;
-                        if (need_s < 0x7FFFu) kd16 = k0 + __popcll(__ballot(in && (uint32_t)(hi_k - lo) <= 2u * direct_ids));
-                        const uint32_t span = (uint32_t)(hi_k - lo);
-                        const int kb = 32 - __clz((int)((span > 2u ? span : 2u) - 1u));
-                        const uint32_t cap = kb >= 30 ? 0u : (1u << (31 - kb)) - 1u;
-                        kp = k0 + __popcll(__ballot(in && (ek - e0) + (uint32_t)(nbk - nb0) <= p.packed_paths && need_s < cap));
-                    }
-                    int k1;
-                    uint32_t flag = 0u, pq = 0u;
-                    // DIRECT or PACKED when the packed run reaches further: a piece costs a fixed overhead worth `mode_ratio` extra
-                    // hashed paths (plan, describe, barriers, sweep), and a direct path a fraction of a hashed one -- the shorter
-                    // direct run wins iff (Pp - Pd) * mode_ratio < Pd * Pp  (cost per path: F / P + c_mode)
-                    const int kdd = kd16 > kd ? kd16 : kd;       // (the exact 32-bit sums when both kinds reach equally far)
-                    bool take_direct = kdd >= kh && kdd >= kp && kdd > k0;
-                    if (!take_direct && kdd > k0 && kp > kdd && kp >= kh) {
-                        const uint32_t pd = (uint32_t)__builtin_amdgcn_readlane((int)ek, kdd) - e0;
-                        const uint32_t pp = (uint32_t)__builtin_amdgcn_readlane((int)ek, kp) - e0;
-                        take_direct = (unsigned long long)(pp - pd) * p.mode_ratio < (unsigned long long)pd * pp;
-                    }
-                    if (take_direct && kd16 > kd) {
-                        k1 = kd16;
-                        flag = 0xC0000000u;
-                        uint32_t d = 0u;
-                        while ((ms >> d) + (uint32_t)dv + 2u >= 0x7FFFu) ++d;
-                        pq = d | (16u << 8);
-                    } else if (take_direct) {
-                        k1 = kd;
-                        flag = 0x80000000u;
-                    } else if (kp >= kh && kp > k0) {
-                        k1 = kp;
-                        flag = 0x40000000u;
-                        const uint32_t span = (uint32_t)(__builtin_amdgcn_readlane(hi_k, k1) - lo);
-                        const int kb = 32 - __clz((int)((span > 2u ? span : 2u) - 1u));
-                        const uint32_t cap = (1u << (31 - kb)) - 1u;
-                        uint32_t d = 0u;
-                        while ((ms >> d) + (uint32_t)dv + 2u >= cap) ++d;         // (<= packed_dmax: the run passed the test with it)
-                        pq = d | ((uint32_t)kb << 8);
-                    } else if (kh > k0) {
-                        k1 = kh;
-                    } else {
-                        k1 = k0 + 1;                                     // one window, wide and heavy: hash-partitioned passes
-                    }
-                    const uint32_t sum = (uint32_t)__builtin_amdgcn_readlane((int)ek, k1) - e0;
-                    if (sum) {
-                        if (lane == 0) {
-                            s_pk0[np] = k0;
-                            s_pk1[np] = k1;
-                            s_plo[np] = lo;
-                            s_phi[np] = __builtin_amdgcn_readlane(hi_k, k1);
-                            s_pinfo[np] = sum | flag;
-                            s_pq[np] = pq;
-                            s_pna[np] = __builtin_amdgcn_readlane(nbk, k0);
-                            s_pnb[np] = __builtin_amdgcn_readlane(nbk, k1);
-                        }
-                        ++np;
-                    }
-                    k0 = k1;
-                }
+                const int np = sp_plan_column(p, v, dv, lane, my_bound, pwk, nbk, direct_ids,
+                                              [&](int i, int k0, int k1, int32_t lo, int32_t hi, uint32_t info, uint32_t pq, int32_t na, int32_t nb) {
+                                                  if (lane == 0) {
+                                                      s_pk0[i] = k0;
+                                                      s_pk1[i] = k1;
+                                                      s_plo[i] = lo;
+                                                      s_phi[i] = hi;
+                                                      s_pinfo[i] = info;
+                                                      s_pq[i] = pq;
+                                                      s_pna[i] = na;
+                                                      s_pnb[i] = nb;
+                                                  }
+                                              });
                 if (lane == 0) s_np = np;
+            } else if (p.plan) {
+                // the per-graph plan table: this column's records (one uint4 per piece) go straight into the piece arrays
+                const uint32_t pb = p.pptr[v];
+                const int np = (int)(p.pptr[v + 1] - pb);
+                if (tid < np) {
+                    const uint4 rec = p.plan[pb + (uint32_t)tid];
+                    const int k1 = (int)((rec.y >> 8) & 0xFFu);
+                    const int32_t bk = p.bounds[k1];
+                    s_pinfo[tid] = rec.x;
+                    s_pk0[tid] = (int)(rec.y & 0xFFu);
+                    s_pk1[tid] = k1;
+                    s_pq[tid] = rec.y >> 16;
+                    s_pna[tid] = (int32_t)(rec.z & 0xFFFFu);
+                    s_pnb[tid] = (int32_t)(rec.z >> 16);
+                    s_plo[tid] = (int32_t)rec.w;
+                    s_phi[tid] = bk < v ? bk : v;
+                }
+                if (tid == 0) s_np = np;
             }
             sp_barrier();
             const int np = s_np;
@@ -363,7 +398,7 @@ __global__ __launch_bounds__(T, 4) void scan_piece_kernel(sp_params p)      // (
                 const bool quant = packed || d16;                                        // weights drop pk_d low bits
                 const uint32_t ppaths = info & 0x3FFFFFFFu;
                 const uint32_t pq = quant ? s_pq[pi] : 0u;
-                const uint32_t pk_d = pq & 0xFFu, pk_sb = 32u - (pq >> 8);      // weight bits dropped; bits of the flag + sum field
+                const uint32_t pk_d = pq & 0xFFu, pk_sb = quant ? 32u - (pq >> 8) : 16u;      // weight bits dropped; bits of the flag + sum field
                 const uint32_t pk_flag = quant ? 1u << (pk_sb - 1u) : 0u;
                 const uint32_t pk_thr = thr32 >= SP_FLAG ? 0xFFFFFFFFu : ((thr32 >> pk_d) ? (thr32 >> pk_d) : 1u);
                 const int32_t lo_id = s_plo[pi], hi_id = s_phi[pi];
@@ -1267,20 +1302,21 @@ extern "C" int eps_scan_screen_weights(const int64_t *fixw, int64_t n, int32_t s
 //          waves per CU and paths per piece both count, and LDS trades one for the other.
 static int sp_launch(const int64_t *rowptr, const int32_t *col, const float *val, const int32_t *revpos, const uint32_t *fx32,
                      const float *node_w, const uint16_t *cuts, const uint32_t *wpaths, const uint32_t *ssum, const uint32_t *smax,
-                     const int32_t *bounds, int64_t n_nodes,
+                     const uint32_t *pptr, const uint32_t *plan, const int32_t *bounds, int64_t n_nodes,
                      int64_t nnz, const int32_t *columns, int64_t n_columns, int32_t shift, int32_t variant, eps_survivors *out,
                      uint32_t *status, void *stream);
 
 extern "C" int eps_scan_screen(const int64_t *rowptr, const int32_t *col, const int32_t *revpos, const uint32_t *fx32,
                                const uint16_t *cuts, const uint32_t *wpaths_or_null, const uint32_t *ssum_or_null,
-                               const uint32_t *smax_or_null, const int32_t *bounds, int64_t n_nodes, int64_t nnz,
+                               const uint32_t *smax_or_null, const uint32_t *pptr_or_null, const uint32_t *plan_or_null,
+                               const int32_t *bounds, int64_t n_nodes, int64_t nnz,
                                const int32_t *columns, int64_t n_columns, int32_t shift, int32_t variant, eps_survivors *out,
                                uint32_t *status, void *stream)
 {
     EPS_REQUIRE(n_columns == 0 || n_nodes == 0 || fx32, "eps_scan_screen: null pointer");
     EPS_REQUIRE((ssum_or_null == nullptr) == (smax_or_null == nullptr), "eps_scan_screen: ssum and smax come together");
-    return sp_launch(rowptr, col, nullptr, revpos, fx32, nullptr, cuts, wpaths_or_null, ssum_or_null, smax_or_null, bounds, n_nodes, nnz,
-                     columns, n_columns, shift, variant, out, status, stream);
+    return sp_launch(rowptr, col, nullptr, revpos, fx32, nullptr, cuts, wpaths_or_null, ssum_or_null, smax_or_null, pptr_or_null,
+                     plan_or_null, bounds, n_nodes, nnz, columns, n_columns, shift, variant, out, status, stream);
 }
 
 // The same scan on a SYMMETRIC adjacency with stored values (val[e] == val[mirror of e]); node_w = the float node weights.
@@ -1291,13 +1327,83 @@ extern "C" int eps_scan_screen_weighted(const int64_t *rowptr, const int32_t *co
                                         void *stream)
 {
     EPS_REQUIRE(n_columns == 0 || n_nodes == 0 || (val && node_w), "eps_scan_screen_weighted: null pointer");
-    return sp_launch(rowptr, col, val, revpos, nullptr, node_w, cuts, wpaths_or_null, nullptr, nullptr, bounds, n_nodes, nnz, columns,
-                     n_columns, shift, variant, out, status, stream);
+    return sp_launch(rowptr, col, val, revpos, nullptr, node_w, cuts, wpaths_or_null, nullptr, nullptr, nullptr, nullptr, bounds, n_nodes,
+                     nnz, columns, n_columns, shift, variant, out, status, stream);
+}
+
+static const int sp_threads_of[3] = {512, 1024, 256}, sp_bits_of[3] = {13, 14, 12}, sp_per_cu[3] = {2, 1, 4};
+
+// what the planner reads of the geometry: the scan launch and the plan-table launch must agree on it
+static void sp_plan_geometry(sp_params &p, const uint16_t *cuts, const uint32_t *wpaths, const uint32_t *ssum, const uint32_t *smax,
+                             const int32_t *bounds, int64_t n_nodes, int32_t shift, int32_t variant)
+{
+    const int bits = sp_bits_of[variant];
+    p.cuts = cuts;
+    p.wpaths = wpaths;
+    p.bounds = bounds;
+    p.n_nodes = (int32_t)n_nodes;
+    p.table_bits = bits;
+    p.piece_paths = (1u << bits) / 2u;
+    p.ssum = ssum;
+    p.smax = smax;
+    p.packed_paths = 1u << bits;
+    p.packed_dmax = shift > 8 ? (shift - 8 < 24 ? shift - 8 : 24) : 0;      // (weights keep at least 2^-8 resolution)
+    // measured on the ppa-like graph (tools/r03_screen_ab.py): 1500 -> 23.8 ms, 2270 -> 23.5, 4000 -> 23.7; packed_paths 3584 / 4096 /
+    // 5120 -> 24.0 / 23.5 / 24.1 ms
+    p.mode_ratio = 2270u;
+    p.shift = shift;
+}
+
+// The per-graph plan table: every column's pieces, planned once (they depend on the graph, the window tables and -- through the
+// sum bounds -- the weight table, not on the bar or the columns of a launch).  One wave per column runs the scan kernel's own
+// planner; out == NULL counts (pcount[v] = pieces of column v), else the records go to out[pptr[v] ..].
+__global__ __launch_bounds__(256) void sp_plan_kernel(sp_params p, const int64_t *__restrict__ rowptr, uint32_t direct_ids,
+                                                      uint32_t *__restrict__ pcount, const uint32_t *__restrict__ pptr, uint4 *__restrict__ out)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t v = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (v >= p.n_nodes) return;
+    const int32_t dv = (int32_t)(rowptr[v + 1] - rowptr[v]);
+    int np = 0;
+    if (dv > 0 && v > 0) {
+        const int32_t my_bound = p.bounds[lane <= SP_M ? lane : SP_M];
+        const uint32_t pwk = lane < SP_M ? p.wpaths[(size_t)v * SP_M + lane] : 0u;
+        const int32_t nbk = lane >= 1 && lane <= SP_M ? (int32_t)p.cuts[(size_t)v * SP_M + lane - 1] : 0;
+        const uint32_t pb = out ? pptr[v] : 0u;
+        np = sp_plan_column(p, (int32_t)v, dv, lane, my_bound, pwk, nbk, direct_ids,
+                            [&](int i, int k0, int k1, int32_t lo, int32_t hi, uint32_t info, uint32_t pq, int32_t na, int32_t nb) {
+                                if (out && lane == 0)
+                                    out[pb + (uint32_t)i] = make_uint4(info, (uint32_t)k0 | ((uint32_t)k1 << 8) | (pq << 16),
+                                                                       (uint32_t)na | ((uint32_t)nb << 16), (uint32_t)lo);
+                            });
+    }
+    if (!out && lane == 0) pcount[v] = (uint32_t)np;
+}
+
+extern "C" int eps_scan_plan(const int64_t *rowptr, const uint16_t *cuts, const uint32_t *wpaths, const uint32_t *ssum_or_null,
+                             const uint32_t *smax_or_null, const int32_t *bounds, int64_t n_nodes, int32_t shift, int32_t variant,
+                             uint32_t *pcount, const uint32_t *pptr_or_null, uint32_t *plan_or_null, void *stream)
+{
+    EPS_REQUIRE(n_nodes >= 0 && n_nodes < (1ll << 31), "eps_scan_plan: bad size");
+    if (n_nodes == 0) return EPS_OK;
+    EPS_REQUIRE(rowptr && cuts && wpaths && bounds, "eps_scan_plan: null pointer");
+    EPS_REQUIRE((ssum_or_null == nullptr) == (smax_or_null == nullptr), "eps_scan_plan: ssum and smax come together");
+    EPS_REQUIRE((pptr_or_null == nullptr) == (plan_or_null == nullptr), "eps_scan_plan: pptr and plan come together");
+    EPS_REQUIRE(pptr_or_null || pcount, "eps_scan_plan: nowhere to put the counts");
+    EPS_REQUIRE(shift >= 0 && shift <= 40 && variant >= 0 && variant <= 2, "eps_scan_plan: bad shift / variant");
+    EPS_REQUIRE(((uintptr_t)plan_or_null & 15) == 0, "eps_scan_plan: plan must be 16-byte aligned");
+    sp_params p;
+    memset(&p, 0, sizeof p);
+    sp_plan_geometry(p, cuts, wpaths, ssum_or_null, smax_or_null, bounds, n_nodes, shift, variant);
+    hipLaunchKernelGGL(sp_plan_kernel, dim3((unsigned)((n_nodes + 3) / 4)), dim3(256), 0, (hipStream_t)stream, p, rowptr,
+                       2u << sp_bits_of[variant], pcount, pptr_or_null, (uint4 *)plan_or_null);
+    EPS_CHECK_LAUNCH("eps_scan_plan");
+    return EPS_OK;
 }
 
 static int sp_launch(const int64_t *rowptr, const int32_t *col, const float *val, const int32_t *revpos, const uint32_t *fx32,
                      const float *node_w, const uint16_t *cuts, const uint32_t *wpaths, const uint32_t *ssum, const uint32_t *smax,
-                     const int32_t *bounds, int64_t n_nodes,
+                     const uint32_t *pptr, const uint32_t *plan, const int32_t *bounds, int64_t n_nodes,
                      int64_t nnz, const int32_t *columns, int64_t n_columns, int32_t shift, int32_t variant, eps_survivors *out,
                      uint32_t *status, void *stream)
 {
@@ -1314,8 +1420,8 @@ static int sp_launch(const int64_t *rowptr, const int32_t *col, const float *val
     EPS_REQUIRE(n_nodes < (1ll << 31) && n_columns < (1ll << 31), "eps_scan_screen: too many nodes / columns");
     EPS_REQUIRE(shift >= 0 && shift <= 40 && variant >= 0 && variant <= 2, "eps_scan_screen: bad shift / variant");
     EPS_REQUIRE(((uintptr_t)cuts & 15) == 0, "eps_scan_screen: cuts must be 16-byte aligned");
-    static const int threads_of[3] = {512, 1024, 256}, bits_of[3] = {13, 14, 12}, per_cu[3] = {2, 1, 4};
-    const int T = threads_of[variant], bits = bits_of[variant];
+    EPS_REQUIRE((pptr == nullptr) == (plan == nullptr) && ((uintptr_t)plan & 15) == 0, "eps_scan_screen: pptr and plan come together, 16-byte aligned");
+    const int T = sp_threads_of[variant], bits = sp_bits_of[variant];
     unsigned int *counter = nullptr;
     const int rc = eps_take_counter(&counter, s, "eps_scan_screen");
     if (rc) return rc;
@@ -1328,28 +1434,17 @@ static int sp_launch(const int64_t *rowptr, const int32_t *col, const float *val
     p.val = val;
     p.node_w = node_w;
     p.up = ldexpf(1.0f, shift) * (1.0f + ldexpf(1.0f, -20));
-    p.cuts = cuts;
-    p.wpaths = wpaths;
-    p.bounds = bounds;
+    sp_plan_geometry(p, cuts, wpaths, ssum, smax, bounds, n_nodes, shift, variant);
+    p.pptr = pptr;
+    p.plan = (const uint4 *)plan;
     p.columns = columns;
     p.n_columns = (int32_t)n_columns;
-    p.n_nodes = (int32_t)n_nodes;
     p.col_bytes = (uint32_t)(nnz * 4);
-    p.table_bits = bits;
-    p.piece_paths = (1u << bits) / 2u;
-    p.ssum = ssum;
-    p.smax = smax;
-    p.packed_paths = 1u << bits;
-    p.packed_dmax = shift > 8 ? (shift - 8 < 24 ? shift - 8 : 24) : 0;      // (weights keep at least 2^-8 resolution)
-    // measured on the ppa-like graph (tools/r03_screen_ab.py): 1500 -> 23.8 ms, 2270 -> 23.5, 4000 -> 23.7; packed_paths 3584 / 4096 /
-    // 5120 -> 24.0 / 23.5 / 24.1 ms
-    p.mode_ratio = 2270u;
-    p.shift = shift;
     p.scale = ldexpf(1.0f, -shift);
     p.next_col = counter;
     p.out = out;
     p.status = status;
-    int64_t blocks = (int64_t)eps_num_cus() * per_cu[variant];
+    int64_t blocks = (int64_t)eps_num_cus() * sp_per_cu[variant];
     if (blocks > n_columns) blocks = n_columns;
     const size_t lds = ((size_t)(2 << bits) + 4 * (size_t)(T + 1) + 8) * 4 + (SP_UBITS / 32) * 6 + 32;
     void (*kern)(sp_params) =

@@ -545,18 +545,42 @@ def rescore_weighted(rowptr, col, val, node_w: torch.Tensor, n_nodes: int, keys:
     return out
 
 
+def scan_plan(rowptr, cuts, wpaths, ssum, smax, bounds, n_nodes: int, shift: int, variant: int):
+    """(pptr int32-bits [N + 1], records int32 [P, 4]): eps_scan_screen's per-graph plan table (eps_scan_plan, two passes)."""
+    dev = _need_gpu(rowptr, cuts, wpaths, ssum, smax, bounds)
+    _chk(rowptr, torch.int64, "rowptr"); _chk(cuts, torch.int16, "cuts"); _chk(wpaths, torch.int32, "wpaths")
+    _chk(ssum, torch.int32, "ssum"); _chk(smax, torch.int32, "smax"); _chk(bounds, torch.int32, "bounds")
+    lib = _lib.load()
+    counts = torch.zeros(n_nodes, dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(lib.eps_scan_plan(_ptr(rowptr), _ptr(cuts), _ptr(wpaths), _ptr(ssum), _ptr(smax), _ptr(bounds), n_nodes, int(shift),
+                                     int(variant), _ptr(counts), None, None, _stream(dev)), "eps_scan_plan")
+        total = torch.cumsum(counts.to(torch.int64), 0)
+        pptr = torch.cat([total.new_zeros(1), total]).to(torch.int32).contiguous()
+        n_rec = int(total[-1].item()) if n_nodes else 0
+        recs = torch.empty((max(n_rec, 1), 4), dtype=torch.int32, device=dev)
+        _lib.check(lib.eps_scan_plan(_ptr(rowptr), _ptr(cuts), _ptr(wpaths), _ptr(ssum), _ptr(smax), _ptr(bounds), n_nodes, int(shift),
+                                     int(variant), None, _ptr(pptr), _ptr(recs), _stream(dev)), "eps_scan_plan")
+    return pptr, recs
+
+
 SCAN_VARIANT = 2          # default workgroup / table geometry of eps_scan_screen (include/eps_abi.h); scan.screen_variant picks per graph
 
 
 def scan_screen(rowptr, col, revpos, fx32, cuts, bounds, n_nodes: int, columns: torch.Tensor, shift: int, out: "Survivors",
                 status: torch.Tensor, variant: Optional[int] = None, val: Optional[torch.Tensor] = None,
                 node_w: Optional[torch.Tensor] = None, wpaths: Optional[torch.Tensor] = None,
-                ssum: Optional[torch.Tensor] = None, smax: Optional[torch.Tensor] = None) -> None:
+                ssum: Optional[torch.Tensor] = None, smax: Optional[torch.Tensor] = None, plan=None) -> None:
     """Launch eps_scan_screen over ``columns``; survivors (screening scores) accumulate in ``out``.  ``val`` / ``node_w``
     (float32 stored values / node weights): the weighted flavour (eps_scan_screen_weighted; ``fx32`` unused).
     ``ssum`` / ``smax`` (int32-bits [N] / [M + 1]; unit-valued graphs): per-node sums of fx32 over the row and their
-    suffix maxima at the window boundaries -- they let pieces keep key and sum in one table word (include/eps_abi.h)."""
-    dev = _need_gpu(rowptr, col, revpos, fx32, cuts, bounds, columns, status, val, node_w, wpaths, ssum, smax)
+    suffix maxima at the window boundaries -- they let pieces keep key and sum in one table word (include/eps_abi.h).
+    ``plan`` = (pptr, records) from ``scan_plan`` built with the same wpaths / ssum / smax / shift / variant."""
+    pptr, recs = plan if plan is not None else (None, None)
+    dev = _need_gpu(rowptr, col, revpos, fx32, cuts, bounds, columns, status, val, node_w, wpaths, ssum, smax, pptr, recs)
+    _chk(pptr, torch.int32, "pptr"); _chk(recs, torch.int32, "plan")
+    if pptr is not None and (val is not None or wpaths is None or pptr.numel() != n_nodes + 1):
+        raise _lib.EpsError("scan_screen: the plan table does not match the graph (unit-valued graphs with wpaths only)")
     _chk(wpaths, torch.int32, "wpaths"); _chk(ssum, torch.int32, "ssum"); _chk(smax, torch.int32, "smax")
     if (ssum is None) != (smax is None) or (ssum is not None and (ssum.numel() != n_nodes or smax.numel() != scan_windows() + 1)):
         raise _lib.EpsError("scan_screen: ssum / smax do not match the graph")
@@ -579,7 +603,7 @@ def scan_screen(rowptr, col, revpos, fx32, cuts, bounds, n_nodes: int, columns: 
             ev[0].record(torch.cuda.current_stream(dev))
         if val is None:
             _lib.check(lib.eps_scan_screen(_ptr(rowptr), _ptr(col), _ptr(revpos), _ptr(fx32), _ptr(cuts), _ptr(wpaths), _ptr(ssum),
-                                           _ptr(smax), _ptr(bounds), n_nodes,
+                                           _ptr(smax), _ptr(pptr), _ptr(recs), _ptr(bounds), n_nodes,
                                            col.numel(), _ptr(columns), columns.numel(), int(shift), variant, _ptr(out.rec), _ptr(status),
                                            _stream(dev)), "eps_scan_screen")
         else:

@@ -36,6 +36,7 @@ SMALL_SET = 1 << 25        # candidate sets with at most this many two-hop half 
 MAX_K = 1 << 30            # rows a survivor list (< 2^32 slots, handed out in chunks) can be asked for; beyond: block streaming
 MAX_LAUNCHES = 8           # estimate -> scan -> correct rounds before giving up (two are the rule)
 _CHUNK_SLACK = 8192 * 320  # survivor slots are handed out in chunks of 8192 per workgroup
+PLAN_TABLE = True            # eps_scan_screen reads a per-graph table of every column's pieces instead of planning in the launch
 PACKED_PIECES = True         # eps_scan_screen may keep key and sum of a candidate in one table word (see _sum_bounds)
 RELABEL_MIN_NODES = 100_000  # graphs at least this large are scanned under hubs-first labels (see scan_graph)
 ONE_PASS = True            # score with the one-pass piece kernel (csrc/scan_pieces.hip) where the graph qualifies, else eps_filter_scan
@@ -206,11 +207,11 @@ def screen_shift(bound: float, max_deg: int) -> int:
 
 class Screen:
     """What a launch of the piece kernel and the exact re-scoring of its survivors need, for one (graph, weight table)."""
-    __slots__ = ("fx32", "shift", "fixw", "val", "node_w", "usable", "ssum", "smax")
+    __slots__ = ("fx32", "shift", "fixw", "val", "node_w", "usable", "ssum", "smax", "plan")
 
-    def __init__(self, fx32, shift, fixw, val, node_w, usable, ssum=None, smax=None):
+    def __init__(self, fx32, shift, fixw, val, node_w, usable, ssum=None, smax=None, plan=None):
         self.fx32, self.shift, self.fixw, self.val, self.node_w, self.usable = fx32, shift, fixw, val, node_w, usable
-        self.ssum, self.smax = ssum, smax
+        self.ssum, self.smax, self.plan = ssum, smax, plan
 
 
 def _sum_bounds(g: CSRGraph, fx32: torch.Tensor):
@@ -243,7 +244,12 @@ def screen_weights(g0: CSRGraph, g: CSRGraph, perm, node_w: torch.Tensor) -> Scr
         fx32, bad = ops.scan_screen_weights(fixw, shift)
         usable = fits and int(bad.item()) == 0
         ssum, smax = _sum_bounds(g, fx32) if usable and PACKED_PIECES and one_pass_available(g) else (None, None)
-        return Screen(fx32, shift, fixw, None, None, usable, ssum, smax)
+        plan = None
+        if usable and PLAN_TABLE and one_pass_available(g):
+            # every column's pieces, planned once per (graph, weight table): a launch reads them instead of planning (5 %)
+            bounds, cuts = screen_tables(g)
+            plan = ops.scan_plan(g.rowptr, cuts, window_paths(g), ssum, smax, bounds, g.n_rows, shift, screen_variant(g))
+        return Screen(fx32, shift, fixw, None, None, usable, ssum, smax, plan)
     # (one entry per labelling: the tables are indexed by the SCANNED graph's node ids)
     return g0.weight_cached("screen_weights" if perm is None else "screen_weights_relabelled", node_w, build)
 
@@ -280,7 +286,7 @@ def _launch(g, fixw, columns, threshold, capacity, scores_only: bool = False, bo
             bounds, cuts = screen_tables(g)
             out.status = torch.empty(1, dtype=torch.int32, device=g.device)
             ops.scan_screen(g.rowptr, g.col, reverse_positions(g), screen.fx32, cuts, bounds, g.n_rows, columns, screen.shift, out,
-                            out.status, screen_variant(g), screen.val, screen.node_w, window_paths(g), screen.ssum, screen.smax)
+                            out.status, screen_variant(g), screen.val, screen.node_w, window_paths(g), screen.ssum, screen.smax, screen.plan)
         else:
             ops.filter_scan(g.rowptr, g.col, reverse_positions(g), fixw, g.n_rows, columns, out, max_degree(g), window_splits(g))
     return out

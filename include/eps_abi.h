@@ -244,9 +244,18 @@ int eps_scan_window_paths(const int64_t *rowptr, const int32_t *col, const int32
                           int64_t n_nodes, uint32_t *wpaths, void *stream);
 int eps_scan_screen(const int64_t *rowptr, const int32_t *col, const int32_t *revpos, const uint32_t *fx32,
                     const uint16_t *cuts, const uint32_t *wpaths_or_null, const uint32_t *ssum_or_null,
-                    const uint32_t *smax_or_null, const int32_t *bounds, int64_t n_nodes, int64_t nnz,
-                    const int32_t *columns, int64_t n_columns, int32_t shift, int32_t variant, eps_survivors *out,
-                    uint32_t *status, void *stream);
+                    const uint32_t *smax_or_null, const uint32_t *pptr_or_null, const uint32_t *plan_or_null,
+                    const int32_t *bounds, int64_t n_nodes, int64_t nnz, const int32_t *columns, int64_t n_columns,
+                    int32_t shift, int32_t variant, eps_survivors *out, uint32_t *status, void *stream);
+/* eps_scan_plan: the per-graph PLAN TABLE of eps_scan_screen -- every column's pieces, planned once by the scan kernel's own
+ * planner (they depend on the graph, the window tables, the variant and, through ssum / smax, the weight table; not on the bar
+ * or on the columns of a launch).  Two calls: with pptr / plan NULL it counts (pcount[v] = pieces of column v, uint32[n_nodes]);
+ * the caller forms pptr = exclusive prefix sum (uint32[n_nodes + 1]) and calls again with plan = uint32[4 * pptr[n_nodes]]
+ * (16-byte aligned; one 16-byte record per piece).  Pass the SAME wpaths / ssum / smax / shift / variant to eps_scan_screen
+ * together with pptr / plan: a launch then reads a column's records instead of planning it (5 % of the launch). */
+int eps_scan_plan(const int64_t *rowptr, const uint16_t *cuts, const uint32_t *wpaths, const uint32_t *ssum_or_null,
+                  const uint32_t *smax_or_null, const int32_t *bounds, int64_t n_nodes, int32_t shift, int32_t variant,
+                  uint32_t *pcount, const uint32_t *pptr_or_null, uint32_t *plan_or_null, void *stream);
 /* eps_scan_screen_weighted: the scan on a SYMMETRIC adjacency WITH stored values (collab: rank.py:32-35 keeps the summed
  * multi-edge weights; val[e] must equal the value of e's mirror entry and be positive).  A path's term is
  * (A[u,w] * A[v,w]) * node_w[w] -- symmetric in (u, v), so the half scheme holds -- and its screening weight is formed per

@@ -39,9 +39,10 @@ def _scan_all(eps, g, node_w, thr=float("-inf"), columns=None):
     return {(int(k & 0xFFFFFFFF), int(k >> 32)): float(s) for k, s in zip(keys, vals)}, n_cand
 
 
-def _screen_all(eps, g, node_w, thr=float("-inf"), columns=None, variant=2, packed=False):
+def _screen_all(eps, g, node_w, thr=float("-inf"), columns=None, variant=2, packed=False, table=False):
     """The same through the one-pass kernel (eps_scan_screen + exact re-scoring): {(u, v): score}, candidate count.
-    ``packed``: hand the kernel the per-node sum bounds, so pieces may keep key and sum in one table word."""
+    ``packed``: hand the kernel the per-node sum bounds, so pieces may keep key and sum in one table word (or two 16-bit sums);
+    ``table``: the per-graph plan table (eps_scan_plan) instead of planning inside the launch."""
     from eps_amd import scan
     sc = scan.screen_weights(g, g, None, node_w)
     assert sc.usable
@@ -50,8 +51,14 @@ def _screen_all(eps, g, node_w, thr=float("-inf"), columns=None, variant=2, pack
     cap = 2 * int(scan.half_paths(g)[cols.long()].sum().item()) + scan._PIECE_SLACK
     res = eps.ops.Survivors(cap, thr, g.device)
     status = torch.zeros(1, dtype=torch.int32, device=g.device)
+    plan = None
+    if table and sc.val is None and g.n_rows:
+        plan = eps.ops.scan_plan(g.rowptr, cuts, scan.window_paths(g), sc.ssum if packed else None, sc.smax if packed else None,
+                                 bounds, g.n_rows, sc.shift, variant)
+        assert int(plan[0][-1]) <= plan[1].shape[0] and bool((plan[0][1:] >= plan[0][:-1]).all())
     eps.ops.scan_screen(g.rowptr, g.col, scan.reverse_positions(g), sc.fx32, cuts, bounds, g.n_rows, cols, sc.shift, res, status,
-                        variant, sc.val, sc.node_w, ssum=sc.ssum if packed else None, smax=sc.smax if packed else None)
+                        variant, sc.val, sc.node_w, wpaths=scan.window_paths(g) if plan is not None else None,
+                        ssum=sc.ssum if packed else None, smax=sc.smax if packed else None, plan=plan)
     assert not packed or sc.val is not None or sc.ssum is not None or not scan.one_pass_available(g)
     slots, n_cand = res.counts()
     assert slots <= res.capacity and int(status) == 0
@@ -133,15 +140,15 @@ def test_scan_bar_and_column_subsets(eps, oracle, dev, seed, scale, ef):
     want_cn = {(int(u), int(v)): float(c) for (u, v), c in zip(pairs[lower], cnt[lower])}
     assert cn_got == want_cn
     # the one-pass kernel on the same inputs: whole set, a high bar, a column shard, unit weights
-    for variant, packed in ((2, False), (2, True), (0, True)):
-        got, n3 = _screen_all(eps, g, wt, variant=variant, packed=packed)
+    for variant, packed, table in ((2, False, False), (2, True, False), (2, True, True), (0, True, True)):
+        got, n3 = _screen_all(eps, g, wt, variant=variant, packed=packed, table=table)
         assert n3 == n_cand and got == full
         bar = float(sc[int(0.99 * (len(sc) - 1))])
-        got, _ = _screen_all(eps, g, wt, thr=bar, variant=variant, packed=packed)
+        got, _ = _screen_all(eps, g, wt, thr=bar, variant=variant, packed=packed, table=table)
         assert got == {k: s for k, s in full.items() if s > bar}
-        got, n4 = _screen_all(eps, g, wt, columns=order[1::3].contiguous(), variant=variant, packed=packed)
+        got, n4 = _screen_all(eps, g, wt, columns=order[1::3].contiguous(), variant=variant, packed=packed, table=table)
         assert got == parts[1][0] and n4 == parts[1][1]
-        got, _ = _screen_all(eps, g, ones, variant=variant, packed=packed)
+        got, _ = _screen_all(eps, g, ones, variant=variant, packed=packed, table=table)
         assert got == want_cn
 
 
@@ -455,8 +462,9 @@ def test_scan_and_unit_lists_on_structured_graphs(eps, dev, name):
     # into partitioned passes): the same survivors, bit-identical scores, with and without a bar
     if scan.max_degree(g) < 1 << 16:
         bar = sorted(full.values())[len(full) // 2] if full else 0.0
-        for variant, packed in ((2, False), (2, True), (0, False), (0, True), (1, True)):
-            got, nc = _screen_all(eps, g, wt, variant=variant, packed=packed)
-            assert nc == len(full) and got == full, (name, variant, packed)
-            got, nc = _screen_all(eps, g, wt, thr=bar, variant=variant, packed=packed)
-            assert nc == len(full) and got == {k: x for k, x in full.items() if x > bar}, (name, variant, packed)
+        for variant, packed, table in ((2, False, False), (2, True, False), (2, True, True), (2, False, True), (0, False, False),
+                                       (0, True, True), (1, True, True)):
+            got, nc = _screen_all(eps, g, wt, variant=variant, packed=packed, table=table)
+            assert nc == len(full) and got == full, (name, variant, packed, table)
+            got, nc = _screen_all(eps, g, wt, thr=bar, variant=variant, packed=packed, table=table)
+            assert nc == len(full) and got == {k: x for k, x in full.items() if x > bar}, (name, variant, packed, table)

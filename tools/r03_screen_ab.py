@@ -42,13 +42,16 @@ t_tab, _ = timed(lambda: scan.screen_tables(g))
 sc = scan.screen_weights(g0, g, perm, w); fx32, shift, usable = sc.fx32, sc.shift, sc.usable
 bounds, cuts = scan.screen_tables(g)
 print(f"screen tables built in {t_tab:.2f} ms; shift {shift}, usable {usable}, bounds {bounds.tolist()}")
-for variant, packed in [(int(x.rstrip("p")), x.endswith("p")) for x in os.environ.get("VARIANTS", "0,1,2,2p").split(",")]:
+for variant, packed, table in [(int(x.rstrip("pt")), "p" in x, "t" in x) for x in os.environ.get("VARIANTS", "0,1,2,2p,2pt").split(",")]:
+    plan = None
+    if table:      # suffix p: packed / 16-bit direct pieces (sum bounds), t: the per-graph plan table
+        plan = ops.scan_plan(g.rowptr, cuts, scan.window_paths(g), sc.ssum if packed else None, sc.smax if packed else None, bounds, g.n_rows, shift, variant)
     ts = []
     for _ in range(reps):
         res = ops.Survivors(cap, bar, dev)
         status = torch.zeros(1, dtype=torch.int32, device=dev)
         t, _ = timed(lambda: ops.scan_screen(g.rowptr, g.col, scan.reverse_positions(g), fx32, cuts, bounds, g.n_rows, order, shift, res, status, variant, wpaths=scan.window_paths(g),
-                                               ssum=sc.ssum if packed else None, smax=sc.smax if packed else None))
+                                               ssum=sc.ssum if packed else None, smax=sc.smax if packed else None, plan=plan))
         ts.append(t)
     slots, nc2 = res.counts()
     keys, vals = res.valid(slots)
@@ -56,7 +59,7 @@ for variant, packed in [(int(x.rstrip("p")), x.endswith("p")) for x in os.enviro
     m = k2 >= 0
     nk, nv = sorted_list(k2[m], v2[m])
     same = nk.numel() == rk.numel() and torch.equal(nk, rk) and torch.equal(nv, rv)
-    print(f"eps_scan_screen variant {variant}{' packed' if packed else ''}: {min(ts):.2f} ms (min of {reps}; all {[round(x, 2) for x in ts]}), candidates {nc2} "
+    print(f"eps_scan_screen variant {variant}{' packed' if packed else ''}{' + plan table' if table else ''}: {min(ts):.2f} ms (min of {reps}; all {[round(x, 2) for x in ts]}), candidates {nc2} "
           f"({'==' if nc2 == ncand else '!='}), screened {keys.numel()} -> exact {nk.numel()}, slots {slots}, status {int(status)}, "
           f"re-scoring {t_re:.2f} ms, identical to eps_filter_scan: {same}")
     if not same and nk.numel() and rk.numel():

@@ -26,7 +26,7 @@ for _ in range(int(os.environ.get("REPS", "1"))):
     if kernel == "pieces":
         status = torch.zeros(1, dtype=torch.int32, device=dev)
         ops.scan_screen(g.rowptr, g.col, scan.reverse_positions(g), fx32, cuts, bounds, g.n_rows, order, shift, res, status, variant, wpaths=scan.window_paths(g),
-                        ssum=sc.ssum if packed else None, smax=sc.smax if packed else None)
+                        ssum=sc.ssum if packed else None, smax=sc.smax if packed else None, plan=sc.plan if packed else None)
     else:
         ops.filter_scan(g.rowptr, g.col, scan.reverse_positions(g), fixw, g.n_rows, order, res, scan.max_degree(g), scan.window_splits(g))
 torch.cuda.synchronize()
