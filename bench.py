@@ -349,8 +349,8 @@ def main():
     srank, sworld = (rank, world) if strong else (0, 1)
     sync()
 
-    # what a one-shot `filter.py --keep_top K` pays: the first scan of a FRESH graph object, per-graph tables included (no
-    # hubs-first copy: one scan does not repay its sort)
+    # what a one-shot `filter.py --keep_top K` pays: the first scan of a FRESH graph object, hubs-first copy and per-graph
+    # tables included
     cold_ms = None
     if world == 1:
         # (the process's first use of each torch / HIP code object -- sort, cumsum, our own kernels -- is a one-off of the
@@ -364,7 +364,7 @@ def main():
         candidates.fused_scores_fit(g_cold, w_cold)
         sync()
         t0 = time.perf_counter()
-        scan.scan_topk(g_cold, w_cold, args.keep_top)
+        scan.scan_topk(g_cold, w_cold, args.keep_top, relabel=True)
         sync()
         cold_ms = (time.perf_counter() - t0) * 1e3
         del g_cold, w_cold
@@ -375,6 +375,10 @@ def main():
     gs, perm = scan.scan_graph(g, build=True)
     scan.column_order(gs)
     scan._scan_weights(g, gs, perm, w)
+    if scan.one_pass_available(gs):
+        scan.screen_tables(gs)
+        scan.window_paths(gs)
+    scan.screen_weights(g, gs, perm, w)          # screening weights, sum bounds, plan table
     scan.shard_columns(gs, srank, sworld)
     scan.sample_columns(gs, scan.SAMPLE_STRIDE, srank, sworld)
     half_paths_total = scan.total_half_paths(gs)
@@ -480,9 +484,12 @@ def main():
                        "notes": {"value": "DIRECTED candidates (both rows of the proposal file carry the score); each unordered "
                                           "pair is computed once: value_unordered_pairs_per_s",
                                  "prep_ms": "hubs-first relabelled copy + revpos / half paths / column order / fixed-point "
-                                            "weights / sample, built once per graph, OUTSIDE the timed region",
-                                 "cold_ms_per_step": "first scan of a fresh graph object incl. its tables, no relabelling: what "
-                                                     "a one-shot filter.py --keep_top run pays",
+                                            "weights / window tables / sum bounds / plan table / sample, built once per graph, "
+                                            "OUTSIDE the timed region",
+                                 "cold_ms_per_step": "first scan of a fresh graph object incl. relabelling and every table, in a "
+                                                     "process that has not grown its allocator yet (~1 GiB of first-time "
+                                                     "hipMalloc: ~130 ms of it; 47 ms once the pool is warm, "
+                                                     "tools/r03_cold_scan.py): what a one-shot filter.py --keep_top run pays",
                                  "serial_ms": "ms_per_step - slowest rank's main kernel - its sample launch: bar, selection, "
                                               "collectives, host"}},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",

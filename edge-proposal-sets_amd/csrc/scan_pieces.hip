@@ -205,7 +205,9 @@ __device__ __forceinline__ int sp_plan_column(const sp_params &p, int32_t v, int
 // (A[u,w] * A[v,w]) * node_w[w] -- symmetric in (u, v) like the unit-valued one, so the half scheme holds -- and its
 // screening weight is formed per path: ceil(A[u,w] * rowf) + 1 with rowf = A[v,w] * node_w[w] * 2^shift * (1 + 2^-20) per
 // row (float32 products are within 2^-22 of the exact one: still an upper bound of the term's exact fixed-point value).
-template <int T, bool HV>
+// WP: the caller brought the per-graph window paths (the launch's usual case): the in-kernel window sums -- 32 counters per
+// thread -- are compiled out, which is what keeps this instantiation clear of the 128-register line without spilling.
+template <int T, bool HV, bool WP = false>
 __global__ __launch_bounds__(T, 4) void scan_piece_kernel(sp_params p)      // (4 waves per SIMD: <= 128 VGPRs, the LDS share decides the rest)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
@@ -293,7 +295,7 @@ __global__ __launch_bounds__(T, 4) void scan_piece_kernel(sp_params p)      // (
         if (dv > 0 && v > 0) {
             // ---- paths of the column per id window: the per-graph table, or summed here over the column's rows ----------------
             uint32_t my_w = 0, my_rev = 0, my_base = 0, my_fx = 0;      // this thread's row (of the last round)
-            if (p.wpaths) {
+            if (WP || p.wpaths) {
                 if (single && tid < dv) {
                     my_w = (uint32_t)vcol[tid];
                     my_rev = (uint32_t)vrev[tid];
@@ -1299,7 +1301,8 @@ extern "C" int eps_scan_screen_weights(const int64_t *fixw, int64_t n, int32_t s
 // variant: 0 = 512 threads, 8192-slot table (two workgroups per CU); 1 = 1024 threads, 16384 slots (one per CU);
 //          2 = 256 threads, 4096 slots (four per CU).  Also measured (27.8 ms for variant 2 at the time): 256 threads / 8192 slots
 //          (two per CU) 38.5 ms, 128 / 4096 (four) 38.2, 128 / 2048 (seven) 50.6, 64 / 2048 (seven) 71.6, 64 / 4096 (four) 61.6 --
-//          waves per CU and paths per piece both count, and LDS trades one for the other.
+//          waves per CU and paths per piece both count, and LDS trades one for the other.  320 threads (five waves per SIMD at 96
+//          registers, 16 spilled) with the 4096-slot table: 21.8 ms against 17.9.
 static int sp_launch(const int64_t *rowptr, const int32_t *col, const float *val, const int32_t *revpos, const uint32_t *fx32,
                      const float *node_w, const uint16_t *cuts, const uint32_t *wpaths, const uint32_t *ssum, const uint32_t *smax,
                      const uint32_t *pptr, const uint32_t *plan, const int32_t *bounds, int64_t n_nodes,
@@ -1449,7 +1452,8 @@ static int sp_launch(const int64_t *rowptr, const int32_t *col, const float *val
     const size_t lds = ((size_t)(2 << bits) + 4 * (size_t)(T + 1) + 8) * 4 + (SP_UBITS / 32) * 6 + 32;
     void (*kern)(sp_params) =
         val ? (variant == 0 ? scan_piece_kernel<512, true> : variant == 1 ? scan_piece_kernel<1024, true> : scan_piece_kernel<256, true>)
-            : (variant == 0 ? scan_piece_kernel<512, false> : variant == 1 ? scan_piece_kernel<1024, false> : scan_piece_kernel<256, false>);
+            : (variant == 0 ? scan_piece_kernel<512, false> : variant == 1 ? scan_piece_kernel<1024, false> :
+               wpaths ? scan_piece_kernel<256, false, true> : scan_piece_kernel<256, false>);
     if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
         eps_set_error("eps_scan_screen: cannot reserve %zu bytes of LDS", lds);
         return EPS_ELAUNCH;
