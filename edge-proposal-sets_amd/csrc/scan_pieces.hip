@@ -406,15 +406,19 @@ __global__ __launch_bounds__(T, 4) void scan_piece_kernel(sp_params p)      // (
                 const int32_t lo_id = s_plo[pi], hi_id = s_phi[pi];
                 // hash geometry: the smallest power-of-two table with load <= 1/2; a heavier single window goes in `parts` passes
                 const uint32_t pkeys = ppaths + (uint32_t)(nb - na);           // slots the piece can need: paths + known edges
-                uint32_t parts = 1u;
-                if (!direct && !packed)
-                    while (pkeys > p.piece_paths * parts) parts <<= 1;
-                if (parts > 1u) parts <<= 1;                             // (random split: aim at a quarter load)
-                int bits = 10;
+                // (closed forms, no loops: hipcc unrolls and vectorises even a three-trip scalar loop into a hundred instructions)
+                int plog = 0;                                            // parts = 2^plog
+                if (!direct && !packed && pkeys > p.piece_paths) {
+                    const uint32_t q = (pkeys + p.piece_paths - 1u) / p.piece_paths;      // >= 2 (piece_paths is a power of two: a shift)
+                    plog = 32 - __clz((int)(q - 1u)) + 1;                // next power of two, doubled (random split: aim at a quarter load)
+                }
+                const uint32_t parts = 1u << plog;
+                int bits;
                 {
-                    const uint32_t per = (pkeys + parts - 1) / parts;
+                    const uint32_t per = (pkeys + parts - 1u) >> plog;
                     const int max_bits = packed ? p.table_bits + 1 : p.table_bits;
-                    while (bits < max_bits && (1u << bits) < 2u * per) ++bits;
+                    const int want = per > 1u ? 33 - __clz((int)(per - 1u)) : 1;          // smallest b with 2^b >= 2 * per
+                    bits = want < 10 ? 10 : (want > max_bits ? max_bits : want);
                 }
                 const uint32_t mask = (1u << bits) - 1u;
                 const uint32_t span = (uint32_t)(hi_id - lo_id);
@@ -505,7 +509,9 @@ __global__ __launch_bounds__(T, 4) void scan_piece_kernel(sp_params p)      // (
                         // search over the unit prefix -- ten dependent reads -- was 12 of the launch's 32 ms).
                         const int units = (int)((len + 3u) >> 2);
                         const int flag = units > 0 ? 1 : 0;
-                        const int incl = sp_wave_incl_scan(units), incl_f = sp_wave_incl_scan(flag);
+                        // (one wave scan for both: a row has < 2^14 units, a wave < 2^20; the non-empty flags count in bits 24 up)
+                        const int incl_c = sp_wave_incl_scan(units | (flag << 24));
+                        const int incl = incl_c & 0xFFFFFF, incl_f = (int)((uint32_t)incl_c >> 24);
                         // Each wave takes its range of unit numbers AND of dense row indices with one 64-bit LDS add: whatever
                         // order the waves arrive in, both ranges are handed out in that same order -- a row that starts at a
                         // later unit has a larger index, which is all the start-bit ranks need (no block scan, no barrier for it).
