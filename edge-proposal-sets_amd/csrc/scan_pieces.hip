@@ -1000,6 +1000,33 @@ __global__ void sp_screen_weights_kernel(const int64_t *__restrict__ fixw, int64
     }
 }
 
+// ssum[v] = sum of the screening weights over row v, clamped to 2^31 - 1: no pair with endpoint v sums to more (the bound the
+// packed and 16-bit direct pieces are sized by).  One wave per row.
+__global__ __launch_bounds__(256) void sp_row_sums_kernel(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+                                                          const uint32_t *__restrict__ fx32, int64_t n_nodes, uint32_t *__restrict__ ssum)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t v = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (v >= n_nodes) return;
+    unsigned long long acc = 0ull;
+    for (int64_t i = rowptr[v] + lane; i < rowptr[v + 1]; i += 64) acc += fx32[col[i]];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d);
+    if (lane == 0) ssum[v] = acc < 0x7FFFFFFFull ? (uint32_t)acc : 0x7FFFFFFFu;
+}
+
+extern "C" int eps_scan_row_sums(const int64_t *rowptr, const int32_t *col, const uint32_t *fx32, int64_t n_nodes, uint32_t *ssum,
+                                 void *stream)
+{
+    EPS_REQUIRE(n_nodes >= 0 && n_nodes < (1ll << 31), "eps_scan_row_sums: bad size");
+    if (n_nodes == 0) return EPS_OK;
+    EPS_REQUIRE(rowptr && col && fx32 && ssum, "eps_scan_row_sums: null pointer");
+    hipLaunchKernelGGL(sp_row_sums_kernel, dim3((unsigned)((n_nodes + 3) / 4)), dim3(256), 0, (hipStream_t)stream, rowptr, col, fx32,
+                       n_nodes, ssum);
+    EPS_CHECK_LAUNCH("eps_scan_row_sums");
+    return EPS_OK;
+}
+
 // ---- exact re-scoring of the screened survivors -----------------------------------------------------------------------------
 // The survivors of a scan are pairs of hubs: a few thousand nodes u recur in hundreds of pairs each.  The list comes sorted by
 // (u, v) as keys (u << 32) | v; a workgroup takes 256 consecutive pairs, and for every run of equal u inside them turns N(u)

@@ -545,6 +545,16 @@ def rescore_weighted(rowptr, col, val, node_w: torch.Tensor, n_nodes: int, keys:
     return out
 
 
+def scan_row_sums(rowptr, col, fx32: torch.Tensor, n_nodes: int) -> torch.Tensor:
+    """int32-bits [N]: the sum of the screening weights over every row, clamped to 2^31 - 1 (eps_scan_row_sums)."""
+    dev = _need_gpu(rowptr, col, fx32)
+    _chk(rowptr, torch.int64, "rowptr"); _chk(col, torch.int32, "col"); _chk(fx32, torch.int32, "fx32")
+    out = torch.empty(n_nodes, dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.load().eps_scan_row_sums(_ptr(rowptr), _ptr(col), _ptr(fx32), n_nodes, _ptr(out), _stream(dev)), "eps_scan_row_sums")
+    return out
+
+
 def scan_plan(rowptr, cuts, wpaths, ssum, smax, bounds, n_nodes: int, shift: int, variant: int):
     """(pptr int32-bits [N + 1], records int32 [P, 4]): eps_scan_screen's per-graph plan table (eps_scan_plan, two passes)."""
     dev = _need_gpu(rowptr, cuts, wpaths, ssum, smax, bounds)

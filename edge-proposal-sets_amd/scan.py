@@ -219,12 +219,10 @@ def _sum_bounds(g: CSRGraph, fx32: torch.Tensor):
     weights over row v -- no pair with endpoint v sums to more -- and smax[k] = the largest ssum among ids >= bounds[k]."""
     bounds, _ = screen_tables(g)
     n = g.n_rows
-    per_entry = (fx32.to(torch.int64) & 0xFFFFFFFF)[g.col.long()]
-    pre = torch.cat([per_entry.new_zeros(1), torch.cumsum(per_entry, 0)])
-    ssum = (pre[g.rowptr[1:]] - pre[g.rowptr[:-1]]).clamp_(max=(1 << 31) - 1)
+    ssum = ops.scan_row_sums(g.rowptr, g.col, fx32, n)              # (N-sized results only: no per-entry temporaries)
     suffix = torch.cat([torch.cummax(ssum.flip(0), 0).values.flip(0), ssum.new_zeros(1)])
     smax = suffix[bounds.long().clamp(max=n)]
-    return ssum.to(torch.int32).contiguous(), smax.to(torch.int32).contiguous()
+    return ssum, smax.contiguous()
 
 
 def screen_weights(g0: CSRGraph, g: CSRGraph, perm, node_w: torch.Tensor) -> Screen:
@@ -258,16 +256,18 @@ def screen_variant(g: CSRGraph):
     """Geometry of eps_scan_screen for this graph, or None when the piece kernel does not suit it (-> eps_filter_scan).
     A column's paths spread evenly over the M id windows (they have equal stored-entry mass), and a window that holds more
     paths than a hash piece takes is re-walked in hash-partitioned passes -- so the heaviest column decides: its paths / M
-    must fit a piece.  Smaller tables mean more workgroups per CU (31 ms vs 35 / 46 ms on the ppa-like graph under
-    hubs-first labels, whose heaviest column has 63 k half paths); a graph scanned as labelled (columns of millions of
+    must fit a piece (a packed one holds twice the paths of a two-word hash piece).  Smaller tables mean more workgroups per
+    CU (17.7 ms vs 19.7 / 32 ms on the ppa-like graph under hubs-first labels, whose heaviest column has 63 k half paths;
+    filter.py's own ppa stand-in -- 100 k -- 31 ms with 8192 slots); a graph scanned as labelled (columns of millions of
     paths) stays on the two-pass kernel.  Rows must be shorter than 2^16 (the cut table is uint16)."""
     if "screen_variant" not in g._cache:
         v = None
         if ONE_PASS and 0 < max_degree(g) < 1 << 16:
             hp_max = int(half_paths(g).max().item()) if g.n_rows else 0
             m = ops.scan_windows()
+            dense = 2 if PACKED_PIECES and g.val is None else 1      # packed pieces hold twice the paths of two-word hash slots
             for variant, piece_paths in ((2, 2048), (0, 4096), (1, 8192)):
-                if hp_max <= piece_paths * m:
+                if hp_max <= dense * piece_paths * m:
                     v = variant
                     break
         g._cache["screen_variant"] = v

@@ -253,6 +253,8 @@ int eps_scan_screen(const int64_t *rowptr, const int32_t *col, const int32_t *re
  * the caller forms pptr = exclusive prefix sum (uint32[n_nodes + 1]) and calls again with plan = uint32[4 * pptr[n_nodes]]
  * (16-byte aligned; one 16-byte record per piece).  Pass the SAME wpaths / ssum / smax / shift / variant to eps_scan_screen
  * together with pptr / plan: a launch then reads a column's records instead of planning it (5 % of the launch). */
+/* eps_scan_row_sums: ssum[v] = min(2^31 - 1, sum of fx32 over row v): the per-node sum bound of eps_scan_screen / eps_scan_plan. */
+int eps_scan_row_sums(const int64_t *rowptr, const int32_t *col, const uint32_t *fx32, int64_t n_nodes, uint32_t *ssum, void *stream);
 int eps_scan_plan(const int64_t *rowptr, const uint16_t *cuts, const uint32_t *wpaths, const uint32_t *ssum_or_null,
                   const uint32_t *smax_or_null, const int32_t *bounds, int64_t n_nodes, int32_t shift, int32_t variant,
                   uint32_t *pcount, const uint32_t *pptr_or_null, uint32_t *plan_or_null, void *stream);

@@ -11,9 +11,9 @@ NAMES = ["column setup (id, bounds)", "plan: paths per window (cut rows + wave s
          "describe (cut gathers, unit scans, descriptors)", "walk (start bits, look-ups, loads, table updates) + barriers", "known edges in (before the walk, no barrier of its own)",
          "table scan + barrier", "ticket hand-over", "(count) pieces", "(count) direct pieces", "(count) rounds walked",
          "  walk: start bits + barrier + word ranks (first range)", "  walk: first look-up + row load until it ARRIVED (vmcnt 0)", "(count) columns", "  walk: table updates (+ further units)", "(count) paths of direct pieces (x parts)",
-         "(count) direct pieces x parts", "(count) their paths", "(count) packed pieces", "(count) their paths", "(count) hash pieces x parts", "(count) their paths x parts",
-         "  describe + walk of direct pieces", "  describe + walk of packed pieces", "  describe + walk of hash pieces",
-         "  table scan of direct pieces", "  table scan of packed pieces", "  table scan of hash pieces",
+         "(count) 32-bit direct pieces", "(count) their paths", "(count) packed pieces", "(count) their paths", "(count) 16-bit direct pieces (+ two-word hash pieces x parts)", "(count) their paths",
+         "  describe + walk of 32-bit direct pieces", "  describe + walk of packed pieces", "  describe + walk of 16-bit direct (+ two-word hash) pieces",
+         "  table scan of 32-bit direct pieces", "  table scan of packed pieces", "  table scan of 16-bit direct (+ two-word hash) pieces",
          "(count) packed: unit groups walked by wave 0", "(count) packed: straggler trips of those (after the all-entries round)", "(count) hash: unit groups walked by wave 0", "(count) hash: straggler trips of those"]
 
 def build():
@@ -42,7 +42,7 @@ struct sp_params {''')
     rep('                            }\n                        }\n                            if (uhi < (uint32_t)total) sp_barrier();       // (the next range rewrites the start bits)\n', '                            }\n                            XS(w3); XA(14, w2, w3);\n                        }\n                            if (uhi < (uint32_t)total) sp_barrier();       // (the next range rewrites the start bits)\n')
     rep('                        sp_barrier();        // the next round / the scan follows: descriptors and table updates are complete\n',
         '                        sp_barrier();        // the next round / the scan follows: descriptors and table updates are complete\n                        XS(d2); XA(4, d1, d2); XA(22 + xmode, d0, d2);\n')
-    rep('                    // ---- known edges in: the neighbours of v inside the piece take their slots BEFORE the walk', '                    XS(e0);\n                    xst[9] += direct ? 1 : 0;\n                    xst[15] += direct ? ppaths : 0;\n                    const int xmode = direct ? 0 : packed ? 1 : 2;\n                    xst[16 + 2 * xmode] += 1; xst[17 + 2 * xmode] += ppaths;\n                    // ---- known edges in: the neighbours of v inside the piece take their slots BEFORE the walk')
+    rep('                    // ---- known edges in: the neighbours of v inside the piece take their slots BEFORE the walk', '                    XS(e0);\n                    xst[9] += direct ? 1 : 0;\n                    xst[15] += direct ? ppaths : 0;\n                    const int xmode = (direct && !d16) ? 0 : packed ? 1 : 2;\n                    xst[16 + 2 * xmode] += 1; xst[17 + 2 * xmode] += ppaths;\n                    // ---- known edges in: the neighbours of v inside the piece take their slots BEFORE the walk')
     rep('                    for (int r = 0; r < rounds; ++r) {\n', '                    XS(e01); XA(5, e0, e01);\n                    for (int r = 0; r < rounds; ++r) {\n')
     rep('                    // ---- scan the table: count the candidates', '                    XS(e1);\n                    // ---- scan the table: count the candidates')
     rep('                    new_keys = 0u;\n                    sp_barrier();\n', '                    new_keys = 0u;\n                    sp_barrier();\n                    XS(e2); XA(6, e1, e2); XA(25 + xmode, e1, e2);\n')
@@ -100,7 +100,8 @@ def run():
             lib.eps_debug_piece_stamps(buf, 1)
         e0.record()
         rc = lib.eps_scan_screen(g.rowptr.data_ptr(), g.col.data_ptr(), scan.reverse_positions(g).data_ptr(), fx32.data_ptr(), cuts.data_ptr(),
-                                 scan.window_paths(g).data_ptr(), sc.ssum.data_ptr() if packed else None, sc.smax.data_ptr() if packed else None, bounds.data_ptr(), g.n_rows, g.nnz(), order.data_ptr(), order.numel(), shift, variant, res.rec.data_ptr(),
+                                 scan.window_paths(g).data_ptr(), sc.ssum.data_ptr() if packed else None, sc.smax.data_ptr() if packed else None,
+                                 sc.plan[0].data_ptr() if packed else None, sc.plan[1].data_ptr() if packed else None, bounds.data_ptr(), g.n_rows, g.nnz(), order.data_ptr(), order.numel(), shift, variant, res.rec.data_ptr(),
                                  status.data_ptr(), torch.cuda.current_stream().cuda_stream)
         e1.record(); torch.cuda.synchronize()
         assert rc == 0
