@@ -102,6 +102,7 @@ __device__ __forceinline__ uint32_t sp_wave_sum(uint32_t x)
 }
 
 typedef float sp_v4f __attribute__((ext_vector_type(4)));
+typedef short sp_v2s __attribute__((ext_vector_type(2)));
 
 // Hash of an id: Fibonacci hashing.  The table index is taken from the TOP of the 32-bit product, the probe step from the
 // middle, the pass of a partitioned window from the bottom.  (A full-rate 24 x 24-bit multiply was measured instead of the
@@ -622,19 +623,25 @@ __global__ __launch_bounds__(T, 4) void scan_piece_kernel(sp_params p)      // (
                                     h[i] = mixv[i] >> (32 - bits);
                                 }
 #pragma unroll
-                                for (int i = 0; i < E; ++i)
-                                    if (pend & (1u << i)) old[i] = atomicCAS(&lds[h[i]], 0u, (lid[i] << pk_sb) | f[i >> 2].fx);
+                                for (int wide = 0; wide < 2; ++wide) {           // (two wide rounds: a fifth of the entries miss the first)
 #pragma unroll
-                                for (int i = 0; i < E; ++i)
-                                    if (pend & (1u << i)) {
-                                        if (old[i] == 0u) {                      // a candidate seen for the first time: key and weight went in at once
-                                            pend &= ~(1u << i);
-                                            ++new_keys;
-                                        } else if ((old[i] >> pk_sb) == lid[i]) {
-                                            atomicAdd(&lds[h[i]], f[i >> 2].fx);
-                                            pend &= ~(1u << i);
+                                    for (int i = 0; i < E; ++i)
+                                        if (pend & (1u << i)) old[i] = atomicCAS(&lds[h[i]], 0u, (lid[i] << pk_sb) | f[i >> 2].fx);
+#pragma unroll
+                                    for (int i = 0; i < E; ++i)
+                                        if (pend & (1u << i)) {
+                                            if (old[i] == 0u) {                  // a candidate seen for the first time: key and weight went in at once
+                                                pend &= ~(1u << i);
+                                                ++new_keys;
+                                            } else if ((old[i] >> pk_sb) == lid[i]) {
+                                                atomicAdd(&lds[h[i]], f[i >> 2].fx);
+                                                pend &= ~(1u << i);
+                                            } else if (wide == 0) {
+                                                h[i] = (h[i] + (((mixv[i] >> 7) | 1u) & mask)) & mask;
+                                            }
                                         }
-                                    }
+                                    if (wide == 0 && !__ballot(pend != 0u)) break;
+                                }
                                 uint32_t ch = 0u, cstep = 0u, clid = 0u, cfx = 0u, tries = 0u;
                                 bool have = false;
                                 while (__ballot(have || pend != 0u)) {
@@ -789,7 +796,9 @@ __global__ __launch_bounds__(T, 4) void scan_piece_kernel(sp_params p)      // (
                     uint32_t cnt_here = 0u;
                     const int thr_s = thr32 >= SP_FLAG ? 0x7FFFFFFF : (int)thr32;      // (sums stay below 2^31 - 2)
                     if (d16) {
-                        // (two fields per word: the low one shifted up, the high one masked, both signed as above)
+                        // (two fields per word: the low one shifted up, the high one masked, both signed as above.  The packed
+                        //  16-bit instructions -- v_pk_min / max / add_i16 on the word as it is, 5 instead of 9 per word -- were
+                        //  measured: 17.75 vs 17.57 ms on the same box)
                         const int thr_h = pk_thr >= 0x8000u ? 0x7FFFFFFF : (int)(pk_thr << 16);
                         const uint32_t n4 = (scan_slots + 3u) & ~3u;
                         for (uint32_t i0 = 0; i0 < n4; i0 += 4u * SP_SB * T) {
