@@ -142,7 +142,9 @@ def scan_graph(g: CSRGraph, build: bool = False):
     (tools/scan_ab.py RELABEL=1).  Scores do not depend on the labels (order-independent fixed-point sums).
     Relabelling sorts the stored entries once (9 ms for 42.5 M, tools/r03_cold_scan.py) and the one-pass kernel
     (csrc/scan_pieces.hip) needs the even columns it gives, so even ONE scan repays it (first scan of a fresh ppa-like
-    graph 57.5 ms as labelled, 53.6 ms relabelled; every later scan 52 vs 33.6 ms): filter.py and bench.py pass
+    graph 57 ms as labelled, 46 ms relabelled with every table built; every later scan 52 vs 23 ms -- in a process whose
+    allocator is cold the relabelled path's extra first-time hipMalloc costs ~30 ms more: profiles/r03/cold_scan.txt):
+    filter.py and bench.py pass
     ``build=True`` / ``scan_topk(relabel=True)``; without it the relabelled copy is used when it already exists (the
     GNN path builds the same copy for its SpMM) and the graph is scanned as labelled otherwise."""
     if g.val is not None:                 # stored values: only the piece kernel scans them, and it wants even columns
