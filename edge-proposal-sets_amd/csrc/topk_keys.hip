@@ -91,10 +91,24 @@ __global__ void kth_hist_kernel(const float *__restrict__ x, int64_t n, kth_stat
     for (int i = threadIdx.x; i < 256; i += blockDim.x) h[i] = 0u;
     __syncthreads();
     const uint32_t prefix = st->prefix, mask = st->mask;
+    const int lane = threadIdx.x & 63;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const uint32_t o = ordered_bits(x[i]);
-        if ((o & mask) == prefix) atomicAdd(&h[(o >> shift) & 255u], 1u);
+    const int64_t n_up = (n + 63) & ~63ll;                    // (whole waves run the loop: the ballots below need every lane)
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_up; i += stride) {
+        const uint32_t o = i < n ? ordered_bits(x[i]) : 0u;
+        const bool live = i < n && (o & mask) == prefix;
+        const uint32_t bin = (o >> shift) & 255u;
+        // The leading digits of a score list are nearly constant -- in the first rounds every lane of a wave wants the same
+        // bin, and 64 LDS atomics on one address run one after the other.  A wave whose live lanes agree adds their count once.
+        const unsigned long long m = __ballot(live);
+        if (m) {
+            const uint32_t b0 = (uint32_t)__builtin_amdgcn_readlane((int)bin, __builtin_ctzll(m));
+            if (__ballot(live && bin == b0) == m) {
+                if (lane == __builtin_ctzll(m)) atomicAdd(&h[b0], (uint32_t)__popcll(m));
+            } else if (live) {
+                atomicAdd(&h[bin], 1u);
+            }
+        }
     }
     __syncthreads();
     for (int i = threadIdx.x; i < 256; i += blockDim.x)
@@ -103,30 +117,53 @@ __global__ void kth_hist_kernel(const float *__restrict__ x, int64_t n, kth_stat
 
 __global__ void kth_pick_kernel(kth_state *__restrict__ st, int shift, float *__restrict__ out)
 {
-    // one thread: walk the bins from the top until the k-th largest falls inside one.  Fewer than k values in all (seen in the
-    // first round, whose histogram counts everything): the answer is -inf, and the later rounds leave it alone.
-    if (threadIdx.x == 0) {
-        if (st->mask != 0xFFFFFFFFu) {
-            uint64_t k = st->k, total = 0;
-            for (int i = 0; i < 256; ++i) total += st->hist[i];
-            if (shift == 24 && (k == 0 || k > total)) {
+    // one wave: lane l owns the bins 255 - 4 l .. 252 - 4 l (from the top); a wave scan of the lane totals finds the lane, and
+    // that lane the bin, in which the k-th largest falls.  Fewer than k values in all (seen in the first round, whose
+    // histogram counts everything): the answer is -inf, and the later rounds leave it alone.
+    const int lane = threadIdx.x & 63;
+    uint32_t c[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) c[j] = st->hist[255 - 4 * lane - j];
+    const uint64_t k = st->k;
+    const uint32_t mask = st->mask, prefix = st->prefix;
+    uint64_t incl = (uint64_t)c[0] + c[1] + c[2] + c[3];
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint64_t up = __shfl_up(incl, d);
+        if (lane >= d) incl += up;
+    }
+    const uint64_t total = __shfl(incl, 63);
+    __builtin_amdgcn_s_barrier();                             // (one wave: every lane has read its bins before they are cleared)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) st->hist[255 - 4 * lane - j] = 0u;
+    if (mask != 0xFFFFFFFFu) {
+        if (shift == 24 && (k == 0 || k > total)) {
+            if (lane == 0) {
                 st->prefix = ordered_bits(-__builtin_inff());
                 st->mask = 0xFFFFFFFFu;
-            } else {
-                int b = 255;
-                for (; b > 0; --b) {
-                    const uint32_t c = st->hist[b];
-                    if (k <= c) break;
-                    k -= c;
+            }
+        } else {
+            // the first lane (from the top) whose running total reaches k; k > total after the first round cannot happen
+            // (the matching values were counted by the round before) -- bin 0 takes the rest, as before
+            const unsigned long long reach = __ballot(incl >= k);
+            const int owner = reach ? __builtin_ctzll(reach) : 63;
+            if (lane == owner) {
+                uint64_t kk = k - (incl - ((uint64_t)c[0] + c[1] + c[2] + c[3]));      // rank inside this lane's four bins
+                int b = 255 - 4 * lane;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (b == 0 || kk <= c[j]) break;
+                    kk -= c[j];
+                    --b;
                 }
-                st->k = k;
-                st->prefix |= (uint32_t)b << shift;
-                st->mask |= 255u << shift;
+                st->k = kk;
+                st->prefix = prefix | ((uint32_t)b << shift);
+                st->mask = mask | (255u << shift);
+                if (shift == 0 && out) *out = unordered_bits(prefix | (uint32_t)b);
             }
         }
-        for (int i = 0; i < 256; ++i) st->hist[i] = 0u;
-        if (shift == 0 && out) *out = unordered_bits(st->prefix);
     }
+    if (mask == 0xFFFFFFFFu && shift == 0 && out && lane == 0) *out = unordered_bits(prefix);
 }
 
 extern "C" int64_t eps_kth_largest_workspace_bytes(void) { return (int64_t)sizeof(kth_state); }

@@ -259,6 +259,14 @@ def test_kth_largest_radix_select(eps, dev):
                 continue
             got = eps.ops.kth_largest(x, k)
             assert got.shape == (1,) and float(got) == float(ref[k - 1]), (n, k)
+    # every value in ONE bin in every round (the wave-aggregated histogram path), and two values that differ in the last bit
+    const = torch.full((200_001,), 1.5, device=dev)
+    assert float(eps.ops.kth_largest(const, 1)) == 1.5 and float(eps.ops.kth_largest(const, 200_001)) == 1.5
+    two = const.clone()
+    two[::3] = torch.nextafter(torch.tensor(1.5), torch.tensor(2.0)).item()
+    ref = torch.sort(two, descending=True).values
+    for k in (1, int((two > 1.5).sum()), int((two > 1.5).sum()) + 1, 200_001):
+        assert float(eps.ops.kth_largest(two, k)) == float(ref[k - 1]), k
     with pytest.raises(eps.EpsError):
         eps.ops.kth_largest(torch.zeros(4, device=dev), 5)
 
