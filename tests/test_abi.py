@@ -70,3 +70,15 @@ def test_product_package_never_imports_the_oracle():
     for f in glob.glob(os.path.join(ROOT, "edge-proposal-sets_amd", "*.py")) + [os.path.join(ROOT, n) for n in ("filter.py", "rank.py", "eps_amd.py")]:
         src = open(f).read()
         assert "import oracle" not in src and "from oracle" not in src and "eps_oracle" not in src, f
+
+
+def test_graft_entry_build():
+    """The driver's "does it build" check: __graft_entry__.build() compiles the library, the oracle and the example host and
+    verifies the ABI version the Python side expects (an incremental make here)."""
+    import importlib
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    entry = importlib.import_module("__graft_entry__")
+    entry.build()
