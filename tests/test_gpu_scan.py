@@ -468,3 +468,21 @@ def test_scan_and_unit_lists_on_structured_graphs(eps, dev, name):
             assert nc == len(full) and got == full, (name, variant, packed, table)
             got, nc = _screen_all(eps, g, wt, thr=bar, variant=variant, packed=packed, table=table)
             assert nc == len(full) and got == {k: x for k, x in full.items() if x > bar}, (name, variant, packed, table)
+
+
+def test_one_pass_scan_on_a_two_million_node_graph(eps, dev):
+    """Ids past 2^20 (21 key bits in a packed piece, windows of 10^5 ids): the one-pass kernel under hubs-first labels -- packed /
+    16-bit direct pieces, plan table -- returns the list the two-pass kernel returns on the graph as labelled, and counts the same
+    candidates."""
+    from eps_amd import scan, synth
+    from eps_amd.heuristics import node_weight_table
+    g = synth.rmat_graph(21, 4, 5, dev)
+    w = node_weight_table(g, eps.ops.W_AA)
+    st0, st1 = {}, {}
+    p0, s0 = scan.scan_topk(g, w, 300_000, stats=st0)
+    assert scan.scan_graph(g)[1] is None                      # as labelled: eps_filter_scan
+    p1, s1 = scan.scan_topk(g, w, 300_000, stats=st1, relabel=True)
+    gs, perm = scan.scan_graph(g)
+    sc = scan.screen_weights(g, gs, perm, w)
+    assert perm is not None and scan.one_pass_available(gs) and sc.ssum is not None and sc.plan is not None
+    assert st0["candidates"] == st1["candidates"] and torch.equal(p0, p1) and torch.equal(s0, s1)
