@@ -209,11 +209,26 @@ def screen_shift(bound: float, max_deg: int) -> int:
 
 class Screen:
     """What a launch of the piece kernel and the exact re-scoring of its survivors need, for one (graph, weight table)."""
-    __slots__ = ("fx32", "shift", "fixw", "val", "node_w", "usable", "ssum", "smax", "plan")
+    __slots__ = ("fx32", "shift", "fixw", "val", "node_w", "usable", "ssum", "smax", "plan", "d_used", "w_min")
 
-    def __init__(self, fx32, shift, fixw, val, node_w, usable, ssum=None, smax=None, plan=None):
+    def __init__(self, fx32, shift, fixw, val, node_w, usable, ssum=None, smax=None, plan=None, d_used=0, w_min=0.0):
         self.fx32, self.shift, self.fixw, self.val, self.node_w, self.usable = fx32, shift, fixw, val, node_w, usable
         self.ssum, self.smax, self.plan = ssum, smax, plan
+        self.d_used = d_used         # most low bits any packed / 16-bit direct piece drops from the screening weights
+        self.w_min = w_min           # smallest weight of a node that can be a common neighbour (0: no relative bound)
+
+    def lower_bound(self, s: torch.Tensor, max_deg: int) -> torch.Tensor:
+        """A lower bound of the exact score of a pair whose screening score is ``s`` (monotone in s).  A path's screening term
+        exceeds its exact 2^-40 term by less than (2^d + 1) x 2^-shift: once for the round-up to 2^-shift, once for the d low
+        bits a packed / 16-bit direct piece drops (d <= d_used).  A pair has at most max_deg paths -- and, when every node
+        weighs at least w_min > 0, at most exact / w_min <= s / w_min of them, which is what keeps the bound tight under the
+        coarse weights (3.7 % of s on the ppa-like graph against 13230 x 2^-8 = 52 absolute).  Weighted graphs form a term from
+        two roundings (no dropped bits)."""
+        unit = (2.0 ** self.d_used + 1.0) * 2.0 ** -self.shift * (2.0 if self.val is not None else 1.0)
+        low = s - max_deg * unit
+        if self.w_min > 0.0 and unit < self.w_min:
+            low = torch.maximum(low, s * (1.0 - 1.00001 * unit / self.w_min))       # (w_min itself is exact to 2^-40)
+        return low
 
 
 def _sum_bounds(g: CSRGraph, fx32: torch.Tensor):
@@ -244,32 +259,67 @@ def screen_weights(g0: CSRGraph, g: CSRGraph, perm, node_w: torch.Tensor) -> Scr
         fx32, bad = ops.scan_screen_weights(fixw, shift)
         usable = fits and int(bad.item()) == 0
         ssum, smax = _sum_bounds(g, fx32) if usable and PACKED_PIECES and one_pass_available(g) else (None, None)
-        plan = None
+        plan, d_used = None, 0
+        if ssum is not None:
+            d_used = max(0, min(24, shift - 8))                              # the launch's limit (csrc/scan_pieces.hip: packed_dmax)
         if usable and PLAN_TABLE and one_pass_available(g):
             # every column's pieces, planned once per (graph, weight table): a launch reads them instead of planning (5 %)
             bounds, cuts = screen_tables(g)
             plan = ops.scan_plan(g.rowptr, cuts, window_paths(g), ssum, smax, bounds, g.n_rows, shift, screen_variant(g))
-        return Screen(fx32, shift, fixw, None, None, usable, ssum, smax, plan)
+            n_rec = int(plan[0][-1].item())
+            if ssum is not None and n_rec:                                   # what the plan really uses (kinds 1, 3 = packed, direct16)
+                y = plan[1][:n_rec, 1].to(torch.int64)
+                quant = ((plan[1][:n_rec, 0].to(torch.int64) >> 30) & 1) == 1
+                d_used = int(torch.where(quant, (y >> 16) & 0xFF, torch.zeros_like(y)).max().item())
+        deg = g.degree()
+        w_here = (node_w if perm is None else node_w[perm])[deg > 1]       # (a common neighbour of two nodes has two neighbours)
+        w_min = float(w_here.min().item()) if w_here.numel() else 0.0
+        return Screen(fx32, shift, fixw, None, None, usable, ssum, smax, plan, d_used, max(w_min, 0.0))
     # (one entry per labelling: the tables are indexed by the SCANNED graph's node ids)
     return g0.weight_cached("screen_weights" if perm is None else "screen_weights_relabelled", node_w, build)
 
 
+REWALK_MAX = 0.25            # largest share of re-walked paths (hash-partitioned passes) the one-pass kernel is chosen with
+
+
+def _rewalk_fraction(g: CSRGraph, variant: int) -> float:
+    """Extra path visits of eps_scan_screen on this graph, as a share of its half paths: a single id window that is wider than a
+    direct piece AND holds more paths than a hash piece is walked in `parts` hash-partitioned passes.  Read off the plan table
+    (planned without sum bounds: two-word hash slots only -- packed pieces can only lower it)."""
+    bounds, cuts = screen_tables(g)
+    pptr, recs = ops.scan_plan(g.rowptr, cuts, window_paths(g), None, None, bounds, g.n_rows, 0, variant)
+    n_rec = int(pptr[-1].item())
+    if n_rec == 0:
+        return 0.0
+    info = recs[:n_rec, 0].to(torch.int64) & 0xFFFFFFFF
+    ends = recs[:n_rec, 2].to(torch.int64) & 0xFFFFFFFF
+    paths = info & 0x3FFFFFFF
+    keys = paths + ((ends >> 16) - (ends & 0xFFFF))
+    cap = {2: 2048, 0: 4096, 1: 8192}[variant]
+    q = (keys + cap - 1) // cap
+    split = ((info >> 30) == 0) & (q >= 2)
+    if not bool(split.any()):
+        return 0.0
+    qs = q[split]
+    parts = 2 * (1 << torch.ceil(torch.log2(qs.double())).to(torch.int64))     # next power of two, doubled (the kernel's rule)
+    return float((paths[split] * (parts - 1)).sum().item()) / max(1.0, float(paths.sum().item()))
+
+
 def screen_variant(g: CSRGraph):
     """Geometry of eps_scan_screen for this graph, or None when the piece kernel does not suit it (-> eps_filter_scan).
-    A column's paths spread evenly over the M id windows (they have equal stored-entry mass), and a window that holds more
-    paths than a hash piece takes is re-walked in hash-partitioned passes -- so the heaviest column decides: its paths / M
-    must fit a piece (a packed one holds twice the paths of a two-word hash piece).  Smaller tables mean more workgroups per
-    CU (17.7 ms vs 19.7 / 32 ms on the ppa-like graph under hubs-first labels, whose heaviest column has 63 k half paths;
-    filter.py's own ppa stand-in -- 100 k -- 31 ms with 8192 slots); a graph scanned as labelled (columns of millions of
-    paths) stays on the two-pass kernel.  Rows must be shorter than 2^16 (the cut table is uint16)."""
+    What decides is how much of the graph the kernel would have to RE-WALK: dense stretches of a column go through direct pieces
+    whatever they weigh, sparse ones through hash pieces of bounded capacity, and a single id window that is both wide and heavy
+    is walked in hash-partitioned passes.  Under hubs-first labels that share is ~0 for the ppa-like graph (heaviest column
+    63 k half paths) and small even for raw R-MAT graphs whose heaviest columns hold 0.3-0.85 M (13 / 48 / 55 ms against
+    65 / 175 / 170 ms for the two-pass kernel: profiles/r03/other_graphs.txt); a graph scanned AS LABELLED has columns of millions
+    of paths in sparse windows (147-686 ms against 48.7) and stays on the two-pass kernel.  The smallest table that keeps the
+    share below REWALK_MAX wins (more workgroups per CU: 17.6 ms vs 19.7 / 32 ms on the ppa-like graph).  Rows must be shorter
+    than 2^16 (the cut table is uint16)."""
     if "screen_variant" not in g._cache:
         v = None
-        if ONE_PASS and 0 < max_degree(g) < 1 << 16:
-            hp_max = int(half_paths(g).max().item()) if g.n_rows else 0
-            m = ops.scan_windows()
-            dense = 2 if PACKED_PIECES and g.val is None else 1      # packed pieces hold twice the paths of two-word hash slots
-            for variant, piece_paths in ((2, 2048), (0, 4096), (1, 8192)):
-                if hp_max <= dense * piece_paths * m:
+        if ONE_PASS and 0 < max_degree(g) < 1 << 16 and g.n_rows:
+            for variant in (2, 0, 1):
+                if _rewalk_fraction(g, variant) <= REWALK_MAX:
                     v = variant
                     break
         g._cache["screen_variant"] = v
@@ -470,12 +520,13 @@ def scan_topk(g: CSRGraph, node_w: torch.Tensor, k: int, rank: int = 0, world: i
         if screen is not None:
             # the one-pass kernel screens with upper bounds: its survivors are re-scored exactly (those that do not exceed the
             # bar after all drop out), so from here on the list holds eps_filter_scan's scores bit for bit
-            # Not all of them need it: a screening score is at most eps above the exact one (one rounding unit per term), so
-            # the k2 best exact scores all have screening scores >= (k2-th best screening score, job-wide) - eps -- only
-            # those are re-scored (about k2 of the SAFETY x k2 survivors).
+            # Not all of them need it: a screening score s exceeds the exact one by less than what `screen.lower_bound` takes
+            # off (a monotone lower bound of the exact score), and k2 pairs have screening scores >= cut_a (the k2-th best,
+            # job-wide), hence exact scores >= lower(cut_a): the k2 best exact scores all have screening scores >= lower(cut_a)
+            # -- only those are re-scored (about k2 of the SAFETY x k2 survivors).
             cut_a = ops.kth_largest_dist(l_vals, k2, world)
-            eps = (2 if screen.val is not None else 1) * max_degree(g) * 2.0 ** -screen.shift
-            c_keys, _, n_valid = ops.compact_at_least(l_keys, l_vals, cut_a - (eps + cut_a.abs() * 4e-6))
+            keep_from = screen.lower_bound(cut_a, max_degree(g))
+            c_keys, _, n_valid = ops.compact_at_least(l_keys, l_vals, keep_from - cut_a.abs() * 4e-6)
             nv = int(n_valid.item())                                                      # (one word: sizes the re-scoring)
             l_keys, l_vals = rescore_exact(g, screen, c_keys[:nv], bar)
             status = res.status
