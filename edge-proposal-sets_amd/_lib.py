@@ -44,8 +44,10 @@ SIGNATURES = {
     "eps_scan_screen_weights": (_int, [_vp, _i64, _i32, _vp, _vp, _vp]),
     "eps_scan_window_paths": (_int, [_vp, _vp, _vp, _vp, _i64, _vp, _vp]),
     "eps_scan_screen": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _i64, _i32, _i32, _vp, _vp, _vp]),
-    "eps_scan_row_sums": (_int, [_vp, _vp, _vp, _i64, _vp, _vp]),
-    "eps_scan_plan": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp]),
+    "eps_scan_bounds": (_int, [_vp, _i64, _vp, _vp]),
+    "eps_scan_row_sums": (_int, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
+    "eps_scan_plan_rewalk": (_int, [_vp, _i64, _i32, _vp, _vp]),
+    "eps_scan_plan": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "eps_scan_screen_weighted": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _i64, _i32, _i32, _vp, _vp, _vp]),
     "eps_rescore_weighted": (_int, [_vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _vp]),
     "eps_expand_unit_count": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _i64, _vp]),

@@ -1009,29 +1009,99 @@ __global__ void sp_screen_weights_kernel(const int64_t *__restrict__ fixw, int64
     }
 }
 
+// The window boundaries: M windows of equal stored-entry mass -- bounds[k] = 1 + the first node whose row ENDS at or beyond
+// k x nnz / M (rowptr is the prefix of the degrees), made non-decreasing; bounds[0] = 0, bounds[M] = N.  One small block.
+__global__ __launch_bounds__(64) void sp_bounds_kernel(const int64_t *__restrict__ rowptr, int64_t n_nodes, int32_t *__restrict__ bounds)
+{
+    __shared__ int32_t b[SP_M + 1];
+    const int k = threadIdx.x;
+    if (k <= SP_M) {
+        int64_t r = k == 0 ? 0 : n_nodes;
+        if (k > 0 && k < SP_M) {
+            const double target = (double)k * ((double)rowptr[n_nodes] / (double)SP_M);
+            int64_t lo = 0, hi = n_nodes;                     // smallest i with rowptr[i + 1] >= target (n_nodes if none)
+            while (lo < hi) {
+                const int64_t mid = lo + ((hi - lo) >> 1);
+                if ((double)rowptr[mid + 1] >= target) hi = mid; else lo = mid + 1;
+            }
+            r = lo + 1 < n_nodes ? lo + 1 : n_nodes;
+        }
+        b[k] = (int32_t)r;
+    }
+    __syncthreads();
+    if (k == 0) {
+        int32_t m = 0;
+        for (int i = 0; i <= SP_M; ++i) {
+            m = b[i] > m ? b[i] : m;
+            bounds[i] = m;
+        }
+    }
+}
+
+extern "C" int eps_scan_bounds(const int64_t *rowptr, int64_t n_nodes, int32_t *bounds, void *stream)
+{
+    EPS_REQUIRE(n_nodes >= 0 && n_nodes < (1ll << 31) && rowptr && bounds, "eps_scan_bounds: bad argument");
+    hipLaunchKernelGGL(sp_bounds_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, rowptr, n_nodes, bounds);
+    EPS_CHECK_LAUNCH("eps_scan_bounds");
+    return EPS_OK;
+}
+
 // ssum[v] = sum of the screening weights over row v, clamped to 2^31 - 1: no pair with endpoint v sums to more (the bound the
-// packed and 16-bit direct pieces are sized by).  One wave per row.
+// packed and 16-bit direct pieces are sized by).  One wave per row; on the way: the largest ssum per id window (-> smax, the
+// suffix maxima, by sp_suffix_max_kernel) and the smallest screening weight of a node with at least two neighbours (only such
+// a node is ever a common neighbour: the floor under a path's term that bounds the number of paths behind a sum).
 __global__ __launch_bounds__(256) void sp_row_sums_kernel(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col,
-                                                          const uint32_t *__restrict__ fx32, int64_t n_nodes, uint32_t *__restrict__ ssum)
+                                                          const uint32_t *__restrict__ fx32, const int32_t *__restrict__ bounds,
+                                                          int64_t n_nodes, uint32_t *__restrict__ ssum, uint32_t *__restrict__ wmax,
+                                                          uint32_t *__restrict__ min_fx)
 {
     const int lane = threadIdx.x & 63;
     const int64_t v = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (v >= n_nodes) return;
+    const int64_t b = rowptr[v], e = rowptr[v + 1];
     unsigned long long acc = 0ull;
-    for (int64_t i = rowptr[v] + lane; i < rowptr[v + 1]; i += 64) acc += fx32[col[i]];
+    for (int64_t i = b + lane; i < e; i += 64) acc += fx32[col[i]];
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d);
-    if (lane == 0) ssum[v] = acc < 0x7FFFFFFFull ? (uint32_t)acc : 0x7FFFFFFFu;
+    if (lane == 0) {
+        const uint32_t sv = acc < 0x7FFFFFFFull ? (uint32_t)acc : 0x7FFFFFFFu;
+        ssum[v] = sv;
+        int k = 0;                                            // the window of v: the last k with bounds[k] <= v
+        for (int step = 16; step >= 1; step >>= 1)
+            if (k + step < SP_M && bounds[k + step] <= (int32_t)v) k += step;
+        atomicMax(&wmax[k], sv);
+        if (e - b >= 2) atomicMin(min_fx, fx32[v]);
+    }
 }
 
-extern "C" int eps_scan_row_sums(const int64_t *rowptr, const int32_t *col, const uint32_t *fx32, int64_t n_nodes, uint32_t *ssum,
-                                 void *stream)
+__global__ void sp_suffix_max_kernel(const uint32_t *__restrict__ wmax, uint32_t *__restrict__ smax)
+{
+    if (threadIdx.x == 0) {
+        uint32_t m = 0u;
+        smax[SP_M] = 0u;
+        for (int k = SP_M - 1; k >= 0; --k) {
+            m = wmax[k] > m ? wmax[k] : m;
+            smax[k] = m;
+        }
+    }
+}
+
+extern "C" int eps_scan_row_sums(const int64_t *rowptr, const int32_t *col, const uint32_t *fx32, const int32_t *bounds,
+                                 int64_t n_nodes, uint32_t *ssum, uint32_t *smax, uint32_t *min_fx, void *workspace, void *stream)
 {
     EPS_REQUIRE(n_nodes >= 0 && n_nodes < (1ll << 31), "eps_scan_row_sums: bad size");
-    if (n_nodes == 0) return EPS_OK;
-    EPS_REQUIRE(rowptr && col && fx32 && ssum, "eps_scan_row_sums: null pointer");
-    hipLaunchKernelGGL(sp_row_sums_kernel, dim3((unsigned)((n_nodes + 3) / 4)), dim3(256), 0, (hipStream_t)stream, rowptr, col, fx32,
-                       n_nodes, ssum);
+    EPS_REQUIRE(smax && min_fx && workspace, "eps_scan_row_sums: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(workspace, 0, SP_M * sizeof(uint32_t), s) != hipSuccess || hipMemsetAsync(min_fx, 0xFF, sizeof(uint32_t), s) != hipSuccess) {
+        eps_set_error("eps_scan_row_sums: cannot clear the workspace");
+        return EPS_ELAUNCH;
+    }
+    if (n_nodes > 0) {
+        EPS_REQUIRE(rowptr && col && fx32 && bounds && ssum, "eps_scan_row_sums: null pointer");
+        hipLaunchKernelGGL(sp_row_sums_kernel, dim3((unsigned)((n_nodes + 3) / 4)), dim3(256), 0, s, rowptr, col, fx32, bounds, n_nodes,
+                           ssum, (uint32_t *)workspace, min_fx);
+    }
+    hipLaunchKernelGGL(sp_suffix_max_kernel, dim3(1), dim3(64), 0, s, (const uint32_t *)workspace, smax);
     EPS_CHECK_LAUNCH("eps_scan_row_sums");
     return EPS_OK;
 }
@@ -1404,7 +1474,8 @@ static void sp_plan_geometry(sp_params &p, const uint16_t *cuts, const uint32_t 
 // sum bounds -- the weight table, not on the bar or the columns of a launch).  One wave per column runs the scan kernel's own
 // planner; out == NULL counts (pcount[v] = pieces of column v), else the records go to out[pptr[v] ..].
 __global__ __launch_bounds__(256) void sp_plan_kernel(sp_params p, const int64_t *__restrict__ rowptr, uint32_t direct_ids,
-                                                      uint32_t *__restrict__ pcount, const uint32_t *__restrict__ pptr, uint4 *__restrict__ out)
+                                                      uint32_t *__restrict__ pcount, const uint32_t *__restrict__ pptr, uint4 *__restrict__ out,
+                                                      uint32_t *__restrict__ d_used)
 {
     const int lane = threadIdx.x & 63;
     const int64_t v = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -1418,9 +1489,11 @@ __global__ __launch_bounds__(256) void sp_plan_kernel(sp_params p, const int64_t
         const uint32_t pb = out ? pptr[v] : 0u;
         np = sp_plan_column(p, (int32_t)v, dv, lane, my_bound, pwk, nbk, direct_ids,
                             [&](int i, int k0, int k1, int32_t lo, int32_t hi, uint32_t info, uint32_t pq, int32_t na, int32_t nb) {
-                                if (out && lane == 0)
+                                if (out && lane == 0) {
                                     out[pb + (uint32_t)i] = make_uint4(info, (uint32_t)k0 | ((uint32_t)k1 << 8) | (pq << 16),
                                                                        (uint32_t)na | ((uint32_t)nb << 16), (uint32_t)lo);
+                                    if (d_used && (info & 0x40000000u) && (pq & 0xFFu)) atomicMax(d_used, pq & 0xFFu);
+                                }
                             });
     }
     if (!out && lane == 0) pcount[v] = (uint32_t)np;
@@ -1428,9 +1501,14 @@ __global__ __launch_bounds__(256) void sp_plan_kernel(sp_params p, const int64_t
 
 extern "C" int eps_scan_plan(const int64_t *rowptr, const uint16_t *cuts, const uint32_t *wpaths, const uint32_t *ssum_or_null,
                              const uint32_t *smax_or_null, const int32_t *bounds, int64_t n_nodes, int32_t shift, int32_t variant,
-                             uint32_t *pcount, const uint32_t *pptr_or_null, uint32_t *plan_or_null, void *stream)
+                             uint32_t *pcount, const uint32_t *pptr_or_null, uint32_t *plan_or_null, uint32_t *d_used_or_null,
+                             void *stream)
 {
     EPS_REQUIRE(n_nodes >= 0 && n_nodes < (1ll << 31), "eps_scan_plan: bad size");
+    if (d_used_or_null && hipMemsetAsync(d_used_or_null, 0, sizeof(uint32_t), (hipStream_t)stream) != hipSuccess) {
+        eps_set_error("eps_scan_plan: cannot clear d_used");
+        return EPS_ELAUNCH;
+    }
     if (n_nodes == 0) return EPS_OK;
     EPS_REQUIRE(rowptr && cuts && wpaths && bounds, "eps_scan_plan: null pointer");
     EPS_REQUIRE((ssum_or_null == nullptr) == (smax_or_null == nullptr), "eps_scan_plan: ssum and smax come together");
@@ -1442,8 +1520,57 @@ extern "C" int eps_scan_plan(const int64_t *rowptr, const uint16_t *cuts, const 
     memset(&p, 0, sizeof p);
     sp_plan_geometry(p, cuts, wpaths, ssum_or_null, smax_or_null, bounds, n_nodes, shift, variant);
     hipLaunchKernelGGL(sp_plan_kernel, dim3((unsigned)((n_nodes + 3) / 4)), dim3(256), 0, (hipStream_t)stream, p, rowptr,
-                       2u << sp_bits_of[variant], pcount, pptr_or_null, (uint4 *)plan_or_null);
+                       2u << sp_bits_of[variant], pcount, pptr_or_null, (uint4 *)plan_or_null, d_used_or_null);
     EPS_CHECK_LAUNCH("eps_scan_plan");
+    return EPS_OK;
+}
+
+// What a plan costs in RE-WALKED paths: a two-word hash piece (kind bits 00) whose paths + known edges exceed a piece's capacity is
+// walked in `parts` hash-partitioned passes (the scan kernel's rule: next power of two of the quotient, doubled).
+// out[0] += paths x (parts - 1) over such pieces, out[1] += paths over all pieces.
+__global__ __launch_bounds__(256) void sp_rewalk_kernel(const uint4 *__restrict__ plan, int64_t n_rec, uint32_t cap,
+                                                        unsigned long long *__restrict__ out)
+{
+    unsigned long long re = 0ull, all = 0ull;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_rec; i += (int64_t)gridDim.x * blockDim.x) {
+        const uint4 r = plan[i];
+        const uint32_t paths = r.x & 0x3FFFFFFFu;
+        all += paths;
+        if ((r.x >> 30) == 0u) {
+            const uint32_t keys = paths + ((r.z >> 16) - (r.z & 0xFFFFu));
+            if (keys > cap) {
+                const uint32_t q = (keys + cap - 1u) / cap;
+                const uint32_t parts = 2u << (32 - __clz((int)(q - 1u)));
+                re += (unsigned long long)paths * (parts - 1u);
+            }
+        }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        re += __shfl_xor(re, d);
+        all += __shfl_xor(all, d);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (re) atomicAdd(&out[0], re);
+        if (all) atomicAdd(&out[1], all);
+    }
+}
+
+extern "C" int eps_scan_plan_rewalk(const uint32_t *plan, int64_t n_rec, int32_t variant, unsigned long long *out2, void *stream)
+{
+    EPS_REQUIRE(n_rec >= 0 && out2 && variant >= 0 && variant <= 2, "eps_scan_plan_rewalk: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(out2, 0, 2 * sizeof(unsigned long long), s) != hipSuccess) {
+        eps_set_error("eps_scan_plan_rewalk: cannot clear the result");
+        return EPS_ELAUNCH;
+    }
+    if (n_rec == 0) return EPS_OK;
+    EPS_REQUIRE(plan && ((uintptr_t)plan & 15) == 0, "eps_scan_plan_rewalk: plan must be 16-byte aligned");
+    int64_t blocks = (n_rec + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(sp_rewalk_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (const uint4 *)plan, n_rec,
+                       (1u << sp_bits_of[variant]) / 2u, out2);
+    EPS_CHECK_LAUNCH("eps_scan_plan_rewalk");
     return EPS_OK;
 }
 

@@ -545,33 +545,63 @@ def rescore_weighted(rowptr, col, val, node_w: torch.Tensor, n_nodes: int, keys:
     return out
 
 
-def scan_row_sums(rowptr, col, fx32: torch.Tensor, n_nodes: int) -> torch.Tensor:
-    """int32-bits [N]: the sum of the screening weights over every row, clamped to 2^31 - 1 (eps_scan_row_sums)."""
-    dev = _need_gpu(rowptr, col, fx32)
-    _chk(rowptr, torch.int64, "rowptr"); _chk(col, torch.int32, "col"); _chk(fx32, torch.int32, "fx32")
-    out = torch.empty(n_nodes, dtype=torch.int32, device=dev)
+def scan_plan_rewalk(plan, variant: int):
+    """(paths walked again in hash-partitioned passes, all paths) of a plan table (eps_scan_plan_rewalk) -- two Python ints."""
+    pptr, recs = plan
+    dev = _need_gpu(pptr, recs)
+    out = torch.empty(2, dtype=torch.int64, device=dev)
+    n_rec = int(pptr[-1].item())
     with torch.cuda.device(dev):
-        _lib.check(_lib.load().eps_scan_row_sums(_ptr(rowptr), _ptr(col), _ptr(fx32), n_nodes, _ptr(out), _stream(dev)), "eps_scan_row_sums")
+        _lib.check(_lib.load().eps_scan_plan_rewalk(_ptr(recs), n_rec, int(variant), _ptr(out), _stream(dev)), "eps_scan_plan_rewalk")
+    re, total = out.tolist()
+    return re, total
+
+
+def scan_bounds(rowptr, n_nodes: int) -> torch.Tensor:
+    """int32 [M + 1]: the id windows of equal stored-entry mass eps_scan_cuts / eps_scan_screen work on (eps_scan_bounds)."""
+    dev = _need_gpu(rowptr)
+    _chk(rowptr, torch.int64, "rowptr")
+    out = torch.empty(scan_windows() + 1, dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.load().eps_scan_bounds(_ptr(rowptr), n_nodes, _ptr(out), _stream(dev)), "eps_scan_bounds")
     return out
 
 
-def scan_plan(rowptr, cuts, wpaths, ssum, smax, bounds, n_nodes: int, shift: int, variant: int):
-    """(pptr int32-bits [N + 1], records int32 [P, 4]): eps_scan_screen's per-graph plan table (eps_scan_plan, two passes)."""
+def scan_row_sums(rowptr, col, fx32: torch.Tensor, bounds: torch.Tensor, n_nodes: int):
+    """(ssum int32-bits [N], smax int32-bits [M + 1], min_fx int32-bits [1]): every row's sum of screening weights (clamped to
+    2^31 - 1), its suffix maxima at the window boundaries, and the smallest screening weight of a node with two neighbours or
+    more (-1 = none) -- eps_scan_row_sums."""
+    dev = _need_gpu(rowptr, col, fx32, bounds)
+    _chk(rowptr, torch.int64, "rowptr"); _chk(col, torch.int32, "col"); _chk(fx32, torch.int32, "fx32"); _chk(bounds, torch.int32, "bounds")
+    m = scan_windows()
+    buf = torch.empty(n_nodes + 2 * m + 2, dtype=torch.int32, device=dev)       # ssum | smax | min_fx | workspace
+    ssum, smax, min_fx, ws = buf[:n_nodes], buf[n_nodes:n_nodes + m + 1], buf[n_nodes + m + 1:n_nodes + m + 2], buf[n_nodes + m + 2:]
+    with torch.cuda.device(dev):
+        _lib.check(_lib.load().eps_scan_row_sums(_ptr(rowptr), _ptr(col), _ptr(fx32), _ptr(bounds), n_nodes, _ptr(ssum), _ptr(smax),
+                                                 _ptr(min_fx), _ptr(ws), _stream(dev)), "eps_scan_row_sums")
+    return ssum, smax, min_fx
+
+
+def scan_plan(rowptr, cuts, wpaths, ssum, smax, bounds, n_nodes: int, shift: int, variant: int, with_d: bool = False):
+    """(pptr int32-bits [N + 1], records int32 [P, 4]): eps_scan_screen's per-graph plan table (eps_scan_plan, two passes).
+    ``with_d``: also the device word that holds the largest number of weight bits a packed / 16-bit direct piece drops."""
     dev = _need_gpu(rowptr, cuts, wpaths, ssum, smax, bounds)
     _chk(rowptr, torch.int64, "rowptr"); _chk(cuts, torch.int16, "cuts"); _chk(wpaths, torch.int32, "wpaths")
     _chk(ssum, torch.int32, "ssum"); _chk(smax, torch.int32, "smax"); _chk(bounds, torch.int32, "bounds")
     lib = _lib.load()
-    counts = torch.zeros(n_nodes, dtype=torch.int32, device=dev)
+    counts = torch.empty(n_nodes, dtype=torch.int32, device=dev)
     with torch.cuda.device(dev):
         _lib.check(lib.eps_scan_plan(_ptr(rowptr), _ptr(cuts), _ptr(wpaths), _ptr(ssum), _ptr(smax), _ptr(bounds), n_nodes, int(shift),
-                                     int(variant), _ptr(counts), None, None, _stream(dev)), "eps_scan_plan")
-        total = torch.cumsum(counts.to(torch.int64), 0)
-        pptr = torch.cat([total.new_zeros(1), total]).to(torch.int32).contiguous()
-        n_rec = int(total[-1].item()) if n_nodes else 0
+                                     int(variant), _ptr(counts), None, None, None, _stream(dev)), "eps_scan_plan")
+        pptr = torch.zeros(n_nodes + 1, dtype=torch.int32, device=dev)
+        if n_nodes:
+            torch.cumsum(counts, 0, dtype=torch.int32, out=pptr[1:])
+        n_rec = int(pptr[-1].item()) if n_nodes else 0
         recs = torch.empty((max(n_rec, 1), 4), dtype=torch.int32, device=dev)
+        d_used = torch.zeros(1, dtype=torch.int32, device=dev) if with_d else None
         _lib.check(lib.eps_scan_plan(_ptr(rowptr), _ptr(cuts), _ptr(wpaths), _ptr(ssum), _ptr(smax), _ptr(bounds), n_nodes, int(shift),
-                                     int(variant), None, _ptr(pptr), _ptr(recs), _stream(dev)), "eps_scan_plan")
-    return pptr, recs
+                                     int(variant), None, _ptr(pptr), _ptr(recs), _ptr(d_used), _stream(dev)), "eps_scan_plan")
+    return (pptr, recs, d_used) if with_d else (pptr, recs)
 
 
 SCAN_VARIANT = 2          # default workgroup / table geometry of eps_scan_screen (include/eps_abi.h); scan.screen_variant picks per graph

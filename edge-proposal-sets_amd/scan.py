@@ -178,14 +178,9 @@ def screen_tables(g: CSRGraph):
     if "screen_tables" not in g._cache:
         if max_degree(g) >= 1 << 16:
             raise ops._lib.EpsError("screen_tables: the cut table counts a row's entries in 16 bits (max degree < 65536)")
-        m = ops.scan_windows()
-        n = g.n_rows
-        cdeg = torch.cumsum(g.degree(), 0).to(torch.float64)
-        targets = torch.arange(1, m, device=g.device, dtype=torch.float64) * (cdeg[-1] / m)
-        inner = torch.clamp(torch.searchsorted(cdeg, targets) + 1, max=n)
-        bounds = torch.cat([torch.zeros(1, dtype=torch.int64, device=g.device), inner,
-                            torch.full((1,), n, dtype=torch.int64, device=g.device)]).to(torch.int32)
-        bounds = torch.cummax(bounds, 0).values.contiguous()
+        # (small device kernels rather than tensor ops: a one-shot filter.py run pays ~10 ms of code-object loading for every
+        #  torch operator it is the first to use)
+        bounds = ops.scan_bounds(g.rowptr, g.n_rows)
         g._cache["screen_tables"] = (bounds, ops.scan_cuts(g.rowptr, g.col, bounds))
     return g._cache["screen_tables"]
 
@@ -232,14 +227,11 @@ class Screen:
 
 
 def _sum_bounds(g: CSRGraph, fx32: torch.Tensor):
-    """(ssum int32-bits [N], smax int32-bits [M + 1]) for eps_scan_screen's packed pieces: ssum[v] = sum of the screening
-    weights over row v -- no pair with endpoint v sums to more -- and smax[k] = the largest ssum among ids >= bounds[k]."""
+    """(ssum int32-bits [N], smax int32-bits [M + 1], min_fx int32-bits [1]) for eps_scan_screen's packed / 16-bit direct
+    pieces: ssum[v] = sum of the screening weights over row v -- no pair with endpoint v sums to more --, smax[k] = the largest
+    ssum among ids >= bounds[k], min_fx = the smallest screening weight of a node that can be a common neighbour."""
     bounds, _ = screen_tables(g)
-    n = g.n_rows
-    ssum = ops.scan_row_sums(g.rowptr, g.col, fx32, n)              # (N-sized results only: no per-entry temporaries)
-    suffix = torch.cat([torch.cummax(ssum.flip(0), 0).values.flip(0), ssum.new_zeros(1)])
-    smax = suffix[bounds.long().clamp(max=n)]
-    return ssum, smax.contiguous()
+    return ops.scan_row_sums(g.rowptr, g.col, fx32, bounds, g.n_rows)
 
 
 def screen_weights(g0: CSRGraph, g: CSRGraph, perm, node_w: torch.Tensor) -> Screen:
@@ -258,23 +250,23 @@ def screen_weights(g0: CSRGraph, g: CSRGraph, perm, node_w: torch.Tensor) -> Scr
         fixw = _scan_weights(g0, g, perm, node_w)
         fx32, bad = ops.scan_screen_weights(fixw, shift)
         usable = fits and int(bad.item()) == 0
-        ssum, smax = _sum_bounds(g, fx32) if usable and PACKED_PIECES and one_pass_available(g) else (None, None)
-        plan, d_used = None, 0
+        ssum, smax, min_fx = _sum_bounds(g, fx32) if usable and PACKED_PIECES and one_pass_available(g) else (None, None, None)
+        plan, d_used, w_min = None, 0, 0.0
         if ssum is not None:
             d_used = max(0, min(24, shift - 8))                              # the launch's limit (csrc/scan_pieces.hip: packed_dmax)
         if usable and PLAN_TABLE and one_pass_available(g):
             # every column's pieces, planned once per (graph, weight table): a launch reads them instead of planning (5 %)
             bounds, cuts = screen_tables(g)
-            plan = ops.scan_plan(g.rowptr, cuts, window_paths(g), ssum, smax, bounds, g.n_rows, shift, screen_variant(g))
-            n_rec = int(plan[0][-1].item())
-            if ssum is not None and n_rec:                                   # what the plan really uses (kinds 1, 3 = packed, direct16)
-                y = plan[1][:n_rec, 1].to(torch.int64)
-                quant = ((plan[1][:n_rec, 0].to(torch.int64) >> 30) & 1) == 1
-                d_used = int(torch.where(quant, (y >> 16) & 0xFF, torch.zeros_like(y)).max().item())
-        deg = g.degree()
-        w_here = (node_w if perm is None else node_w[perm])[deg > 1]       # (a common neighbour of two nodes has two neighbours)
-        w_min = float(w_here.min().item()) if w_here.numel() else 0.0
-        return Screen(fx32, shift, fixw, None, None, usable, ssum, smax, plan, d_used, max(w_min, 0.0))
+            pptr, recs, d_word = ops.scan_plan(g.rowptr, cuts, window_paths(g), ssum, smax, bounds, g.n_rows, shift, screen_variant(g),
+                                               with_d=True)
+            plan = (pptr, recs)
+            if ssum is not None:
+                d_used = int(d_word.item())                                  # what the plan really uses
+        if min_fx is not None:
+            # fx32 rounds the exact weight x 2^shift UP: one unit less is a floor under every common neighbour's exact weight
+            lowest = int(min_fx.item()) & 0xFFFFFFFF
+            w_min = 0.0 if lowest == 0xFFFFFFFF else max(0, lowest - 1) * 2.0 ** -shift
+        return Screen(fx32, shift, fixw, None, None, usable, ssum, smax, plan, d_used, w_min)
     # (one entry per labelling: the tables are indexed by the SCANNED graph's node ids)
     return g0.weight_cached("screen_weights" if perm is None else "screen_weights_relabelled", node_w, build)
 
@@ -287,22 +279,9 @@ def _rewalk_fraction(g: CSRGraph, variant: int) -> float:
     direct piece AND holds more paths than a hash piece is walked in `parts` hash-partitioned passes.  Read off the plan table
     (planned without sum bounds: two-word hash slots only -- packed pieces can only lower it)."""
     bounds, cuts = screen_tables(g)
-    pptr, recs = ops.scan_plan(g.rowptr, cuts, window_paths(g), None, None, bounds, g.n_rows, 0, variant)
-    n_rec = int(pptr[-1].item())
-    if n_rec == 0:
-        return 0.0
-    info = recs[:n_rec, 0].to(torch.int64) & 0xFFFFFFFF
-    ends = recs[:n_rec, 2].to(torch.int64) & 0xFFFFFFFF
-    paths = info & 0x3FFFFFFF
-    keys = paths + ((ends >> 16) - (ends & 0xFFFF))
-    cap = {2: 2048, 0: 4096, 1: 8192}[variant]
-    q = (keys + cap - 1) // cap
-    split = ((info >> 30) == 0) & (q >= 2)
-    if not bool(split.any()):
-        return 0.0
-    qs = q[split]
-    parts = 2 * (1 << torch.ceil(torch.log2(qs.double())).to(torch.int64))     # next power of two, doubled (the kernel's rule)
-    return float((paths[split] * (parts - 1)).sum().item()) / max(1.0, float(paths.sum().item()))
+    plan = ops.scan_plan(g.rowptr, cuts, window_paths(g), None, None, bounds, g.n_rows, 0, variant)
+    again, total = ops.scan_plan_rewalk(plan, variant)
+    return again / max(1, total)
 
 
 def screen_variant(g: CSRGraph):
@@ -318,10 +297,15 @@ def screen_variant(g: CSRGraph):
     if "screen_variant" not in g._cache:
         v = None
         if ONE_PASS and 0 < max_degree(g) < 1 << 16 and g.n_rows:
-            for variant in (2, 0, 1):
-                if _rewalk_fraction(g, variant) <= REWALK_MAX:
-                    v = variant
-                    break
+            # (no column heavier than M two-word hash pieces: nothing can need a partitioned pass -- the usual case, decided
+            #  without planning the graph three times)
+            if int(half_paths(g).max().item()) <= 2048 * ops.scan_windows():
+                v = 2
+            else:
+                for variant in (2, 0, 1):
+                    if _rewalk_fraction(g, variant) <= REWALK_MAX:
+                        v = variant
+                        break
         g._cache["screen_variant"] = v
     return g._cache["screen_variant"]
 

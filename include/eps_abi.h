@@ -252,12 +252,25 @@ int eps_scan_screen(const int64_t *rowptr, const int32_t *col, const int32_t *re
  * or on the columns of a launch).  Two calls: with pptr / plan NULL it counts (pcount[v] = pieces of column v, uint32[n_nodes]);
  * the caller forms pptr = exclusive prefix sum (uint32[n_nodes + 1]) and calls again with plan = uint32[4 * pptr[n_nodes]]
  * (16-byte aligned; one 16-byte record per piece).  Pass the SAME wpaths / ssum / smax / shift / variant to eps_scan_screen
- * together with pptr / plan: a launch then reads a column's records instead of planning it (5 % of the launch). */
-/* eps_scan_row_sums: ssum[v] = min(2^31 - 1, sum of fx32 over row v): the per-node sum bound of eps_scan_screen / eps_scan_plan. */
-int eps_scan_row_sums(const int64_t *rowptr, const int32_t *col, const uint32_t *fx32, int64_t n_nodes, uint32_t *ssum, void *stream);
+ * together with pptr / plan: a launch then reads a column's records instead of planning it (5 % of the launch).
+ * d_used_or_null (fill call): the largest number of low weight bits any packed / 16-bit direct piece of the plan drops -- what
+ * the caller's bound on (screening score - exact score) needs. */
+/* eps_scan_bounds: the window boundaries eps_scan_cuts / eps_scan_screen expect -- bounds[0 .. M], M = eps_scan_windows(), windows
+ * of equal stored-entry mass (bounds[k] = 1 + the first node whose row ends at or beyond k x nnz / M; non-decreasing).
+ * eps_scan_row_sums: the per-node sum bounds of eps_scan_screen / eps_scan_plan: ssum[v] = min(2^31 - 1, sum of fx32 over row v),
+ * smax[k] = the largest ssum among ids >= bounds[k] (k = 0 .. M; smax[M] = 0), *min_fx = the smallest fx32 of a node with at least
+ * two neighbours (0xFFFFFFFF when there is none): (min_fx - 1) x 2^-shift is a floor under every path's exact term -- what bounds
+ * the number of paths behind a screening sum.  workspace: M uint32. */
+int eps_scan_bounds(const int64_t *rowptr, int64_t n_nodes, int32_t *bounds, void *stream);
+int eps_scan_row_sums(const int64_t *rowptr, const int32_t *col, const uint32_t *fx32, const int32_t *bounds, int64_t n_nodes,
+                      uint32_t *ssum, uint32_t *smax, uint32_t *min_fx, void *workspace, void *stream);
+/* eps_scan_plan_rewalk: out2[0] = two-hop half paths that eps_scan_screen would walk AGAIN under this plan (hash-partitioned
+ * passes of windows that are both wide and heavy), out2[1] = all half paths of the plan: what decides whether the one-pass
+ * kernel suits a graph (eps_amd.scan.screen_variant). */
+int eps_scan_plan_rewalk(const uint32_t *plan, int64_t n_rec, int32_t variant, unsigned long long *out2, void *stream);
 int eps_scan_plan(const int64_t *rowptr, const uint16_t *cuts, const uint32_t *wpaths, const uint32_t *ssum_or_null,
                   const uint32_t *smax_or_null, const int32_t *bounds, int64_t n_nodes, int32_t shift, int32_t variant,
-                  uint32_t *pcount, const uint32_t *pptr_or_null, uint32_t *plan_or_null, void *stream);
+                  uint32_t *pcount, const uint32_t *pptr_or_null, uint32_t *plan_or_null, uint32_t *d_used_or_null, void *stream);
 /* eps_scan_screen_weighted: the scan on a SYMMETRIC adjacency WITH stored values (collab: rank.py:32-35 keeps the summed
  * multi-edge weights; val[e] must equal the value of e's mirror entry and be positive).  A path's term is
  * (A[u,w] * A[v,w]) * node_w[w] -- symmetric in (u, v), so the half scheme holds -- and its screening weight is formed per
