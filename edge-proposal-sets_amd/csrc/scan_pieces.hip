@@ -1069,8 +1069,13 @@ __global__ __launch_bounds__(256) void sp_row_sums_kernel(const int64_t *__restr
         int k = 0;                                            // the window of v: the last k with bounds[k] <= v
         for (int step = 16; step >= 1; step >>= 1)
             if (k + step < SP_M && bounds[k + step] <= (int32_t)v) k += step;
-        atomicMax(&wmax[k], sv);
-        if (e - b >= 2) atomicMin(min_fx, fx32[v]);
+        // (look before the atomic: the cells only move one way, so a value that cannot move them needs no atomic -- the last
+        //  window holds half the nodes, and 300 k atomics on one address would take 30 ms)
+        if (sv > __atomic_load_n(&wmax[k], __ATOMIC_RELAXED)) atomicMax(&wmax[k], sv);
+        if (e - b >= 2) {
+            const uint32_t fv = fx32[v];
+            if (fv < __atomic_load_n(min_fx, __ATOMIC_RELAXED)) atomicMin(min_fx, fv);
+        }
     }
 }
 
@@ -1492,7 +1497,9 @@ __global__ __launch_bounds__(256) void sp_plan_kernel(sp_params p, const int64_t
                                 if (out && lane == 0) {
                                     out[pb + (uint32_t)i] = make_uint4(info, (uint32_t)k0 | ((uint32_t)k1 << 8) | (pq << 16),
                                                                        (uint32_t)na | ((uint32_t)nb << 16), (uint32_t)lo);
-                                    if (d_used && (info & 0x40000000u) && (pq & 0xFFu)) atomicMax(d_used, pq & 0xFFu);
+                                    // (look first: two million atomics on one word would take 20 ms)
+                                    if (d_used && (info & 0x40000000u) && (pq & 0xFFu) > __atomic_load_n(d_used, __ATOMIC_RELAXED))
+                                        atomicMax(d_used, pq & 0xFFu);
                                 }
                             });
     }
