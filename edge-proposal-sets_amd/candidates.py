@@ -77,7 +77,10 @@ def fused_score_bound(g: CSRGraph, node_w: Optional[torch.Tensor]) -> float:
             return 0.0
         cs = torch.cat([torch.zeros(1, dtype=torch.float64, device=g.device), torch.cumsum(term, 0)])
         rowsum = cs[g.rowptr[1:]] - cs[g.rowptr[:-1]]
-        return float(rowsum.max().item()) * (1.0 + 1e-9) + 1e-12
+        both = torch.stack([rowsum.max(), cs[-1]]).tolist()                               # (one host read)
+        # a difference of two prefix values carries the rounding of the TOTAL, not of the row: each prefix value is within
+        # ~log2(nnz) x 2^-53 of the total (pairwise / blocked scans; 4x margin), so the slack is proportional to cs[-1]
+        return both[0] * (1.0 + 1e-9) + both[1] * max(1, g.nnz()).bit_length() * 2.0 ** -52 * 4.0 + 1e-12
     return g.weight_cached("score_bound", node_w, build)    # (keyed on the tensor itself, not on its recyclable address)
 
 

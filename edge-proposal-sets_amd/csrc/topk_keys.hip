@@ -96,7 +96,9 @@ __global__ void kth_hist_kernel(const float *__restrict__ x, int64_t n, kth_stat
     const int64_t n_up = (n + 63) & ~63ll;                    // (whole waves run the loop: the ballots below need every lane)
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_up; i += stride) {
         const uint32_t o = i < n ? ordered_bits(x[i]) : 0u;
-        const bool live = i < n && (o & mask) == prefix;
+        // (-inf is "no value": an untouched survivor slot.  Left out of the histogram, a list of 2^32 slots times any number of
+        //  ranks cannot wrap the 32-bit bins, and "fewer than k values" still answers -inf -- which is what counting them gave)
+        const bool live = i < n && o != 0x007FFFFFu && (o & mask) == prefix;
         const uint32_t bin = (o >> shift) & 255u;
         // The leading digits of a score list are nearly constant -- in the first rounds every lane of a wave wants the same
         // bin, and 64 LDS atomics on one address run one after the other.  A wave whose live lanes agree adds their count once.
@@ -216,8 +218,8 @@ extern "C" int eps_kth_begin(void *state, int64_t k, void *stream)
 
 extern "C" int eps_kth_hist_f32(const float *x, int64_t n, void *state, int32_t shift, void *stream)
 {
-    EPS_REQUIRE(n >= 0 && n < (1ll << 31) && state && (shift == 24 || shift == 16 || shift == 8 || shift == 0),
-                "eps_kth_hist_f32: bad argument");
+    EPS_REQUIRE(n >= 0 && state && (shift == 24 || shift == 16 || shift == 8 || shift == 0), "eps_kth_hist_f32: bad argument");
+    EPS_REQUIRE(n < (1ll << 32), "eps_kth_hist_f32: a rank's vector holds at most 2^32 - 1 values (32-bit bins; n=%lld)", (long long)n);
     if (n == 0) return EPS_OK;
     EPS_REQUIRE(x, "eps_kth_hist_f32: null pointer");
     hipLaunchKernelGGL(kth_hist_kernel, dim3(kth_blocks(n)), dim3(256), 0, (hipStream_t)stream, x, n, (kth_state *)state, (int)shift);

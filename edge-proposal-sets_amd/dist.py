@@ -24,17 +24,24 @@ import torch
 import torch.distributed as dist
 
 
-def init_from_env(backend: Optional[str] = None, device_index: Optional[int] = None) -> Tuple[int, int, torch.device]:
+def init_from_env(backend: Optional[str] = None, device_index: Optional[int] = None,
+                  host_only: bool = False) -> Tuple[int, int, torch.device]:
     """Join the job described by RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* (torchrun).  -> (rank, world, device).
     ``backend``: "nccl" (RCCL over xGMI; the default on a GPU box) or "gloo" (collectives staged through host memory).
-    ``device_index``: the HIP device of this rank; default LOCAL_RANK.  RCCL needs one device per rank; with gloo several
-    ranks may share a device (``filter.py --dist_backend gloo --device 0``: how a 1-GPU box runs the multi-rank path)."""
+    ``device_index``: the HIP device of this rank; default LOCAL_RANK (whatever the backend: ``torchrun --nproc-per-node N
+    filter.py --dist_backend gloo`` runs rank r on cuda:r).  RCCL needs one device per rank; with gloo several ranks may share
+    a device (``filter.py --dist_backend gloo --device 0``: how a 1-GPU box runs the multi-rank path).
+    ``host_only``: a job of CPU tensors also on a box with GPUs (the gloo tests of the sharding / merge logic)."""
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    # backend "gloo" without an explicit device keeps its old meaning: a host job (CPU tensors), also on a box with GPUs
-    if torch.cuda.is_available() and not (backend == "gloo" and device_index is None):
-        device = torch.device("cuda", local if device_index is None else int(device_index))
+    if torch.cuda.is_available() and not host_only:
+        n_dev = torch.cuda.device_count()
+        index = local if device_index is None else int(device_index)
+        if not 0 <= index < n_dev:
+            raise RuntimeError(f"init_from_env: rank {rank} wants HIP device {index}, the box has {n_dev} "
+                               "(pass --device to share one, or start fewer ranks per node)")
+        device = torch.device("cuda", index)
         torch.cuda.set_device(device)
     else:
         device = torch.device("cpu")

@@ -193,11 +193,21 @@ def window_paths(g: CSRGraph) -> torch.Tensor:
     return g._cache["window_paths"]
 
 
-def screen_shift(bound: float, max_deg: int) -> int:
+_VAL_INFLATION = 1.0 + 2.0 ** -19     # stored values: a term is ceil(A[u,w] x rowf) + 1 with rowf scaled by 2^shift x (1 + 2^-20) and two
+                                      # float32 roundings on the way -- the sum may exceed bound x 2^shift by that relative amount
+
+
+def screen_fits(bound: float, shift: int, max_deg: int, weighted: bool = False) -> bool:
+    """Every screening sum of the graph stays below 2^31 - 2 at this shift (bit 31 of a table word marks a known edge): score
+    bound -- inflated for stored values, whose per-path terms are rounded products -- plus one rounding unit per term."""
+    return bound * (_VAL_INFLATION if weighted else 1.0) * (1 << shift) + max_deg < (1 << 31) - 2
+
+
+def screen_shift(bound: float, max_deg: int, weighted: bool = False) -> int:
     """Fixed point 2^-shift of the screening sums: the finest one that keeps every sum of the graph below 2^31 (score bound
     plus one rounding unit per term; bit 31 is the kernel's known-edge flag), at most MAX_SCREEN_SHIFT."""
     shift = MAX_SCREEN_SHIFT
-    while shift > 0 and bound * (1 << shift) + max_deg >= (1 << 31) - 2:      # (bit 31 of a sum marks a known edge)
+    while shift > 0 and not screen_fits(bound, shift, max_deg, weighted):
         shift -= 1
     return shift
 
@@ -242,8 +252,8 @@ def screen_weights(g0: CSRGraph, g: CSRGraph, perm, node_w: torch.Tensor) -> Scr
     def build():
         from . import candidates
         bound = candidates.fused_score_bound(g0, node_w)
-        shift = screen_shift(bound, 2 * max_degree(g))
-        fits = bound * (1 << shift) + 2 * max_degree(g) < (1 << 31) - 2
+        shift = screen_shift(bound, 2 * max_degree(g), g.val is not None)
+        fits = screen_fits(bound, shift, 2 * max_degree(g), g.val is not None)
         if g.val is not None:
             nw = (node_w if perm is None else node_w[perm]).contiguous()
             return Screen(None, shift, None, g.val, nw, fits and bool((nw >= 0).all().item()))

@@ -206,9 +206,11 @@ int eps_filter_scan(const int64_t *rowptr, const int32_t *col, const int32_t *re
  * id windows of its endpoints) whose candidates each own a slot of an LDS table, so every path is read once and costs one
  * table update.  The table holds 32-bit SCREENING sums of weights rounded UP to 2^-shift fixed point: an upper bound of the
  * exact 2^-40 fixed-point score, so no candidate above the bar is lost and a few just below it pass as well; out->val holds
- * the screening score (sum * 2^-shift).  The caller re-scores the survivors exactly (eps_pair_scores_f64 over the weights
- * fixw * 2^-40 as doubles: exact and order-independent, bit-identical to eps_filter_scan's sums) and drops those <= the bar.
- * Needs what eps_filter_scan needs (symmetric unit-valued adjacency, revpos) plus max degree < 65536 and weights >= 0.
+ * the screening score (sum * 2^-shift).  The caller re-scores the survivors exactly (eps_rescore_runs; for a graph with
+ * stored values eps_rescore_weighted: int64 sums of the 2^-40 fixed-point terms, order-independent, bit-identical to
+ * eps_filter_scan's sums) and drops those <= the bar.
+ * Needs what eps_filter_scan needs (symmetric adjacency, revpos) plus max degree < 65536 and weights >= 0; unit-valued
+ * adjacencies go through eps_scan_screen, adjacencies with stored values through eps_scan_screen_weighted.
  *   eps_scan_windows      : M, the number of id windows per graph (32).
  *   eps_scan_cuts         : cuts[w * M + k] = entries of row w with id < bounds[k + 1] (uint16; 16-byte aligned), for the
  *                           caller's window boundaries bounds[0 .. M] (bounds[0] = 0, bounds[M] = n_nodes, non-decreasing;
@@ -218,7 +220,9 @@ int eps_filter_scan(const int64_t *rowptr, const int32_t *col, const int32_t *re
  *   eps_scan_screen_weights: fx32[i] = max(1, ceil(fixw[i] / 2^(40 - shift))); *bad (device word, cleared by the call):
  *                           bit 1 a negative weight, bit 2 a weight that does not fit 32 bits.  shift must keep every
  *                           screening sum of the graph below 2^31 (bit 31 of a table word flags a known edge) (the caller's score bound: eps_amd.scan.screen_shift).
- *   eps_scan_screen       : out as for eps_filter_scan (slots are handed out in chunks of max(8192, 2 * table slots));
+ *   eps_scan_screen       : out as for eps_filter_scan (slots are handed out in chunks: 8192 per request under a bar, 2 x table
+ *                           slots -- 8192 / 16384 / 32768 for variant 2 / 0 / 1 -- without one, where a piece's whole yield
+ *                           survives; a survivor beyond its workgroup's reservation takes a slot of its own);
  *                           ssum / smax (optional, both or neither; per graph and weight table): ssum[v] = sum of fx32 over
  *                           row v (any pair's screening sum is at most the smaller of its two endpoints' ssum), smax[k] =
  *                           the largest ssum among the ids >= bounds[k] (k = 0 .. M; smax[M] = 0).  With them, pieces whose
@@ -226,7 +230,8 @@ int eps_filter_scan(const int64_t *rowptr, const int32_t *col, const int32_t *re
  *                           candidates per piece); their weights drop up to shift - 8 low bits, rounded up (still an upper
  *                           bound; out->val stays in units of 2^-shift);
  *                           variant 0: 512 threads / 8192-slot table (2 workgroups per CU), 1: 1024 / 16384 (1), 2: 256 / 4096 (4);
- *                           *status (device word, cleared by the call): bit 2 = a table filled up (results invalid). */
+ *                           *status (device word, cleared by the call): value 2 (bit 1) = a table filled up (results
+ *                           invalid; cannot happen within the planner's piece limits: a backstop). */
 int32_t eps_scan_windows(void);
 /* eps_rescore_runs: exact scores of screened survivors.  keys = (u << 32) | v, sorted ascending (runs of equal u: the hubs
  * recur); fixw = eps_fixed_weights(node_w); out[i] = float32 of the exact int64 sum of the 2^-40 fixed-point weights over the

@@ -251,17 +251,27 @@ def candidates_scipy_columns(A, lo: int, hi: int):
 
 
 # ------------------------------------------------ GNN forward restatements
-def gcn_dense_forward(A_dense: np.ndarray, x: np.ndarray, weights, biases) -> np.ndarray:
-    """Independent dense-formula check for tiny graphs (float64):
-    H' = D^-1/2 (A with diag:=1) D^-1/2 (X W) + b, ReLU between layers, none after the last
-    (models.py:181-187; GCNConv per torch_geometric 1.7.0 [3p]). weights[l] is [in,out]."""
+def gcn_norm_dense(A_dense: np.ndarray) -> np.ndarray:
+    """D^-1/2 (A with diag := 1) D^-1/2 in float64 (gcn_norm of torch_geometric 1.7.0 [3p] on a SparseTensor: fill_diag(1),
+    row sums, pow(-0.5), inf -> 0, scale rows and columns).  The only text of this formula the reference itself holds is the
+    commented-out pre-computation at email_data/mlp_common.py:274-280 (= reddit/mlp_common.py:280-286): set_diag -> sum(dim=1)
+    -> pow(-0.5) -> inf := 0 -> dis.view(-1, 1) * adj * dis.view(1, -1); tests/test_oracle_golden.py evaluates exactly that
+    expression against this function."""
     Ah = A_dense.astype(np.float64).copy()
     np.fill_diagonal(Ah, 1.0)
     deg = Ah.sum(1)
     with np.errstate(divide="ignore"):
         dis = deg ** -0.5
     dis[np.isinf(dis)] = 0
-    An = dis[:, None] * Ah * dis[None, :]
+    return dis[:, None] * Ah * dis[None, :]
+
+
+def gcn_dense_forward(A_dense: np.ndarray, x: np.ndarray, weights, biases) -> np.ndarray:
+    """Independent dense-formula check for tiny graphs (float64):
+    H' = D^-1/2 (A with diag:=1) D^-1/2 (X W) + b, ReLU between layers, none after the last
+    (models.py:181-187; GCNConv per torch_geometric 1.7.0 [3p]; normalisation: ``gcn_norm_dense``, witnessed in-tree by
+    email_data/mlp_common.py:274-280). weights[l] is [in,out]."""
+    An = gcn_norm_dense(A_dense)
     h = x.astype(np.float64)
     for l, (W, b) in enumerate(zip(weights, biases)):
         h = An @ (h @ W.astype(np.float64)) + b.astype(np.float64)

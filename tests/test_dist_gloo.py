@@ -37,7 +37,7 @@ def _worker(rank, world, port, tmp):
     import eps_amd  # noqa: F401
     from eps_amd import dist as epd, synth
     from oracle import eps_oracle as orc
-    r, w, dev = epd.init_from_env(backend="gloo")
+    r, w, dev = epd.init_from_env(backend="gloo", host_only=True)
     assert (r, w) == (rank, world) and dev.type == "cpu"
     g = synth.rmat_graph(10, 8, 5, "cpu")
     n = g.n_rows

@@ -106,6 +106,16 @@ def test_scan_without_bar_is_the_whole_candidate_set(eps, oracle, dev, path):
         ex = {(int(u), int(v)): float(s) for u, v, s in zip(cu.cpu().numpy(), cv.cpu().numpy(), sc.cpu().numpy())}
         for (u, v), s in got.items():
             assert ex[(u, v)] == s and ex[(v, u)] == s
+    # the PRODUCTION kernel (eps_scan_screen + exact re-scoring) meets every reference-generated graph directly: all four
+    # variant / packed / plan-table combinations against the oracle truth, not through the two-pass kernel's list
+    from eps_amd import scan
+    if scan.one_pass_available(g):
+        for variant, packed, table in ((2, False, False), (2, True, False), (2, True, True), (0, True, True)):
+            got_s, n_s = _screen_all(eps, g, wt, variant=variant, packed=packed, table=table)
+            assert n_s == len(want) and set(got_s) == set(want)
+            if want:
+                assert rel_err(np.array([got_s[k] for k in ks], np.float32), np.array([want[k] for k in ks], np.float32)) <= 1e-6
+                assert got_s == got                       # (and bit-identical to the two-pass kernel's scores)
 
 
 @pytest.mark.parametrize("seed,scale,ef", [(5, 12, 10), (9, 13, 6), (2, 11, 40)])

@@ -93,6 +93,35 @@ def test_gnn_stack_structure(oracle, kind, L):
     assert rel_err(prob, d["prob"]) <= 1e-5
 
 
+def test_gcn_norm_matches_the_in_tree_witness(oracle):
+    """The GCN normalisation against the only text of it the reference holds -- the commented-out pre-computation at
+    email_data/mlp_common.py:274-280 (= reddit/mlp_common.py:280-286): ``adj_t.set_diag()`` (every diagonal entry := 1),
+    ``deg = adj_t.sum(dim=1)``, ``deg.pow(-0.5)``, ``inf := 0``, ``dis.view(-1, 1) * adj_t * dis.view(1, -1)`` -- evaluated
+    here exactly as written, on dense torch tensors, incl. weighted entries, an existing diagonal entry and an empty row."""
+    import torch
+    rng = np.random.default_rng(3)
+    n = 23
+    A = (rng.random((n, n)) < 0.2) * rng.integers(1, 4, (n, n))
+    A = (A + A.T).astype(np.float32)
+    A[5, :] = 0; A[:, 5] = 0                    # an isolated node (its row is the self loop alone)
+    A[7, 7] = 3.0                               # a stored diagonal entry: set_diag overwrites it with 1
+    adj_t = torch.from_numpy(A.copy())
+    adj_t.fill_diagonal_(1.0)                                          # adj_t = data.adj_t.set_diag()
+    deg = adj_t.sum(dim=1).to(torch.float)                             # deg = adj_t.sum(dim=1).to(torch.float)
+    deg_inv_sqrt = deg.pow(-0.5)                                       # deg_inv_sqrt = deg.pow(-0.5)
+    deg_inv_sqrt[deg_inv_sqrt == float('inf')] = 0                     # deg_inv_sqrt[deg_inv_sqrt == float('inf')] = 0
+    want = deg_inv_sqrt.view(-1, 1) * adj_t * deg_inv_sqrt.view(1, -1)
+    got = oracle.gcn_norm_dense(A)
+    assert np.abs(got - want.numpy().astype(np.float64)).max() <= 1e-6
+    # ... and the CSR float32 restatement the HIP path is tested against uses the same matrix
+    Acsr = ssp.csr_matrix(A)
+    Acsr.sort_indices()
+    x = rng.standard_normal((n, 4)).astype(np.float32)
+    W = np.eye(4, dtype=np.float32)
+    h = oracle.gcn_forward_csr(Acsr.indptr, Acsr.indices, Acsr.data, x, [W], [np.zeros(4, np.float32)])
+    assert np.abs(h - got @ x.astype(np.float64)).max() <= 1e-5
+
+
 @pytest.mark.parametrize("tag", ["plain", "weighted"])
 def test_sage_conv_matches_reference_witness(oracle, tag):
     """The SAGE conv arithmetic against the reference's OWN conv code: models.SAGEConv2.forward (models.py:358-384) run
