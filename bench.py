@@ -360,7 +360,7 @@ def main():
             scan.window_paths(gs_)
         scan.screen_weights(graph, gs_, perm_, weights)          # screening weights, sum bounds, plan table
         scan.shard_columns(gs_, srank, sworld)
-        scan.sample_columns(gs_, scan.SAMPLE_STRIDE, srank, sworld)
+        scan.sample_columns(gs_, scan.sample_stride(args.keep_top), srank, sworld)
         paths = scan.total_half_paths(gs_)
         candidates.fused_scores_fit(graph, weights)
         sync()

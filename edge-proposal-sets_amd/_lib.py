@@ -59,6 +59,12 @@ SIGNATURES = {
     "eps_mlp_decode": (_int, [_vp, _i64, _i32, _vp, _vp, _i64, _c.POINTER(_vp), _c.POINTER(_vp), _i32, _int, _vp, _vp]),
     "eps_kth_largest_workspace_bytes": (_i64, []),
     "eps_kth_largest_f32": (_int, [_vp, _i64, _i64, _vp, _vp, _vp]),
+    "eps_select_topk_rows_relabelled": (_int, [_vp, _vp, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _i64, _vp]),
+    "eps_sort_pairs_by_u_workspace_bytes": (_i64, [_i64]),
+    "eps_sort_pairs_by_u": (_int, [_vp, _i64, _i32, _vp, _vp, _i64, _vp]),
+    "eps_compact_between": (_int, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "eps_select_compact_workspace_bytes": (_i64, []),
+    "eps_select_compact": (_int, [_vp, _vp, _i64, _vp, _i64, _i32, _c.c_float, _c.c_float, _c.c_float, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "eps_kth_begin": (_int, [_vp, _i64, _vp]),
     "eps_kth_hist_f32": (_int, [_vp, _i64, _vp, _i32, _vp]),
     "eps_kth_pick": (_int, [_vp, _i32, _vp, _vp]),
@@ -72,7 +78,7 @@ SIGNATURES = {
     "eps_unpack_keys": (_int, [_vp, _i64, _vp, _vp, _vp]),
 }
 
-ABI_VERSION = 4        # include/eps_abi.h EPS_ABI_VERSION
+ABI_VERSION = 5        # include/eps_abi.h EPS_ABI_VERSION
 _lib = None
 
 

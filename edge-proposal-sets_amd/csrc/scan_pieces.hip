@@ -233,6 +233,7 @@ __global__ __launch_bounds__(T, 4) void scan_piece_kernel(sp_params p)      // (
     __shared__ int s_np;
     __shared__ unsigned int s_ticket;
     __shared__ unsigned int s_out_cur, s_out_end;
+    __shared__ unsigned int s_fill_lo, s_fill_hi;       // what is left of an abandoned reservation: filled with "no survivor"
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wib = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -275,6 +276,8 @@ __global__ __launch_bounds__(T, 4) void scan_piece_kernel(sp_params p)      // (
     if (tid == 0) {
         s_out_cur = 0u;
         s_out_end = 0u;
+        s_fill_lo = 0u;
+        s_fill_hi = 0u;
         s_alloc = 0ull;
     }
     unsigned long long n_cand = 0;           // candidates seen by this thread
@@ -431,6 +434,10 @@ __global__ __launch_bounds__(T, 4) void scan_piece_kernel(sp_params p)      // (
                     if (need > chunk) need = chunk;                               // (a 16-bit direct piece without a bar: the rest takes single slots)
                     const uint32_t left = s_out_cur < s_out_end ? s_out_end - s_out_cur : 0u;
                     if (left < need) {
+                        // (the slots of the old reservation that nobody took: the workgroup marks them "no survivor" after the
+                        //  next barrier, so the list needs no fill before the launch and its readers stop at the slot counter)
+                        s_fill_lo = s_out_cur < out_cap ? s_out_cur : out_cap;
+                        s_fill_hi = left ? (s_out_end < out_cap ? s_out_end : out_cap) : s_fill_lo;
                         const unsigned long long b64 = atomicAdd(&p.out->count, (unsigned long long)chunk);
                         const uint32_t b = b64 < (unsigned long long)out_cap ? (uint32_t)b64 : out_cap;
                         s_out_cur = b;
@@ -527,6 +534,13 @@ __global__ __launch_bounds__(T, 4) void scan_piece_kernel(sp_params p)      // (
                             if (a_u < (uint32_t)SP_UBITS) atomicOr(&ubits[a_u >> 5], 1u << (a_u & 31u));      // (the first range's start bits)
                         }
                         sp_barrier();
+                        if (s_fill_hi > s_fill_lo) {                     // (uniform; rare: one reservation in ~a thousand pieces)
+                            const uint32_t f0 = s_fill_lo, f1 = s_fill_hi;
+                            for (uint32_t i = f0 + (uint32_t)tid; i < f1; i += T) {
+                                out_key[i] = -1;
+                                out_val[i] = -__builtin_inff();
+                            }
+                        }                                                // (tid 0 closes the range after the walk's barrier)
                         const int total = (int)(s_alloc >> 32);
                         for (uint32_t ulo = 0; ulo < (uint32_t)total; ulo += SP_UBITS) {       // (one range unless > 32 k paths)
                             const uint32_t uhi = ulo + SP_UBITS < (uint32_t)total ? ulo + SP_UBITS : (uint32_t)total;
@@ -773,7 +787,10 @@ __global__ __launch_bounds__(T, 4) void scan_piece_kernel(sp_params p)      // (
                         // (leave the start bits and the hand-out counter clean for the next describe; a barrier separates them from
                         //  it: the sweep's own, or -- columns of several rounds -- one more)
                         for (int i = tid; i < SP_UBITS / 32; i += T) ubits[i] = 0u;
-                        if (tid == 0) s_alloc = 0ull;
+                        if (tid == 0) {
+                            s_alloc = 0ull;
+                            s_fill_hi = 0u;
+                        }
                         if (r + 1 < rounds) sp_barrier();
                     }
                     // ---- scan the table: count the candidates, report the survivors, leave it clean --------------------------
@@ -916,6 +933,14 @@ __global__ __launch_bounds__(T, 4) void scan_piece_kernel(sp_params p)      // (
         sp_barrier();
         t = s_ticket;
         sp_barrier();
+    }
+    // what is left of the workgroup's last reservation
+    {
+        const uint32_t f0 = s_out_cur < out_cap ? s_out_cur : out_cap, f1 = s_out_end < out_cap ? s_out_end : out_cap;
+        for (uint32_t i = f0 + (uint32_t)tid; i < f1; i += T) {
+            out_key[i] = -1;
+            out_val[i] = -__builtin_inff();
+        }
     }
     // candidates scored by this workgroup: one atomic per wave
     {

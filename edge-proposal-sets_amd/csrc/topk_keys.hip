@@ -234,3 +234,229 @@ extern "C" int eps_kth_pick(void *state, int32_t shift, float *out_or_null, void
     EPS_CHECK_LAUNCH("eps_kth_pick");
     return EPS_OK;
 }
+
+// ---- radix select + compaction in ONE launch --------------------------------------------------------------------------
+// The selections of a filter step (filter.py:160-161 keeps the K best rows; rank.py:294 reads them) are short lists -- a few
+// million survivor slots -- and each was ten launches (init, 4 x histogram + pick) plus a compaction: launch latency, not data.
+// Here one grid does all of it: four rounds of 256-bin histograms with a grid-wide hand-over between them (every workgroup
+// adds its LDS histogram to the round's global one, waits until all have, then picks the bin itself -- the same arithmetic on
+// the same counters, so every workgroup agrees without a broadcast), then -- optionally -- the threshold derived from the
+// k-th value and the compaction of the entries at or above it.  The grid is at most one workgroup per CU: all resident, so
+// the hand-over cannot deadlock.
+//   n = min(*n_dev, n_max) when n_dev is given (the slot counter of an eps_survivors list: its readers stop there);
+//   -inf values and entries with key < 0 are "no value" (untouched slots);
+//   *kth = the k-th largest value (-inf when fewer than k values);
+//   *thr = mode 0: kth; mode 1: the largest float below kth (an inclusive bar for a kernel that keeps scores ABOVE its
+//          threshold); mode 2: max(kth - a, kth * b) - |kth| * c (a lower bound of what a screening score kth can be worth
+//          exactly: eps_amd.scan.Screen.lower_bound);
+//   out_keys / out_vals (optional) receive the entries with value >= *thr (and key >= 0), *n_out their number.
+struct fsel_state {
+    uint32_t hist[4][256];
+    uint32_t arrived;
+    uint32_t pad;
+    unsigned long long n_out;
+};
+
+__device__ __forceinline__ void fsel_grid_sync(uint32_t *arrived, uint32_t target)
+{
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        atomicAdd(arrived, 1u);
+        while (__atomic_load_n(arrived, __ATOMIC_RELAXED) < target) __builtin_amdgcn_s_sleep(2);
+        __threadfence();
+    }
+    __syncthreads();
+}
+
+#define FSEL_T 1024
+#define FSEL_U 8        // independent loads a thread has in flight per trip
+
+__global__ __launch_bounds__(FSEL_T) void fsel_kernel(const int64_t *__restrict__ keys, const float *__restrict__ vals, int64_t n_max,
+                                                     const unsigned long long *__restrict__ n_dev, uint64_t k, int mode, float pa,
+                                                     float pb, float pc, fsel_state *__restrict__ st, float *__restrict__ kth_out,
+                                                     float *__restrict__ thr_out, int64_t *__restrict__ out_keys,
+                                                     float *__restrict__ out_vals, int64_t *__restrict__ n_out)
+{
+    __shared__ uint32_t h[256];
+    __shared__ uint32_t s_prefix, s_mask, s_done;
+    __shared__ uint64_t s_k;
+    const int tid = threadIdx.x, lane = tid & 63;
+    int64_t n = n_max;
+    if (n_dev) {
+        const unsigned long long c = *n_dev;
+        n = c < (unsigned long long)n_max ? (int64_t)c : n_max;
+    }
+    const int64_t stride = (int64_t)gridDim.x * FSEL_T * FSEL_U;
+    uint32_t prefix = 0u, mask = 0u;
+    uint64_t kk = k;
+    bool none = k == 0;                                        // fewer than k values: the answer is -inf
+#pragma unroll 1
+    for (int r = 0; r < 4 && k != 0; ++r) {
+        const int shift = 24 - 8 * r;
+        if (tid < 256) h[tid] = 0u;
+        __syncthreads();
+        // (a value of -inf is "no value": untouched and dropped slots carry it next to their key -1, so the rounds read the
+        //  scores alone; whole waves run the loop: the ballots need every lane)
+        for (int64_t base = (int64_t)blockIdx.x * FSEL_T * FSEL_U; base < n; base += stride) {
+            float x[FSEL_U];
+#pragma unroll
+            for (int j = 0; j < FSEL_U; ++j) {
+                const int64_t i = base + (int64_t)j * FSEL_T + tid;
+                x[j] = i < n ? vals[i] : -__builtin_inff();
+            }
+#pragma unroll
+            for (int j = 0; j < FSEL_U; ++j) {
+                const uint32_t o = ordered_bits(x[j]);
+                const bool live = o != 0x007FFFFFu && (o & mask) == prefix;
+                const uint32_t bin = (o >> shift) & 255u;
+                const unsigned long long m = __ballot(live);
+                if (m) {                                       // (a wave whose live lanes agree adds their count once)
+                    const uint32_t b0 = (uint32_t)__builtin_amdgcn_readlane((int)bin, __builtin_ctzll(m));
+                    if (__ballot(live && bin == b0) == m) {
+                        if (lane == __builtin_ctzll(m)) atomicAdd(&h[b0], (uint32_t)__popcll(m));
+                    } else if (live) {
+                        atomicAdd(&h[bin], 1u);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if (tid < 256 && h[tid]) atomicAdd(&st->hist[r][tid], h[tid]);
+        fsel_grid_sync(&st->arrived, (uint32_t)(r + 1) * gridDim.x);
+        if (tid < 64) {            // wave 0: lane l owns bins 255 - 4 l .. 252 - 4 l (from the top)
+            uint32_t c[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) c[j] = __atomic_load_n(&st->hist[r][255 - 4 * lane - j], __ATOMIC_RELAXED);
+            uint64_t incl = (uint64_t)c[0] + c[1] + c[2] + c[3];
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint64_t up = __shfl_up(incl, d);
+                if (lane >= d) incl += up;
+            }
+            const uint64_t total = __shfl(incl, 63);
+            if (r == 0 && kk > total) {
+                if (lane == 0) s_done = 1u;
+            } else {
+                if (r == 0 && lane == 0) s_done = 0u;
+                const unsigned long long reach = __ballot(incl >= kk);
+                const int owner = reach ? __builtin_ctzll(reach) : 63;
+                if (lane == owner) {
+                    uint64_t k2 = kk - (incl - ((uint64_t)c[0] + c[1] + c[2] + c[3]));
+                    int b = 255 - 4 * lane;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if (b == 0 || k2 <= c[j]) break;
+                        k2 -= c[j];
+                        --b;
+                    }
+                    s_k = k2;
+                    s_prefix = prefix | ((uint32_t)b << shift);
+                    s_mask = mask | (255u << shift);
+                }
+            }
+        }
+        __syncthreads();
+        if (r == 0 && s_done) none = true;
+        if (none) break;                                       // (uniform over the grid: every workgroup read the same counters)
+        prefix = s_prefix;
+        mask = s_mask;
+        kk = s_k;
+        __syncthreads();
+    }
+    const float kth = none ? -__builtin_inff() : unordered_bits(prefix);
+    float thr = kth;
+    if (!none && mode == 1) {
+        // the largest float below kth (kth is finite here): one step down in the ordered bit pattern
+        const uint32_t ob = ordered_bits(kth);
+        thr = unordered_bits(ob == 0x80000000u ? ob - 2u : ob - 1u);       // (below +0.0 comes -0.0 == 0: one more step)
+    } else if (!none && mode == 2) {
+        const float low = kth - pa, rel = kth * pb;
+        thr = (low > rel ? low : rel) - __builtin_fabsf(kth) * pc;
+    }
+    if (blockIdx.x == 0 && tid == 0) {
+        if (kth_out) *kth_out = kth;
+        if (thr_out) *thr_out = thr;
+    }
+    if (!out_keys) return;
+    // compaction: a wave takes 512 consecutive entries at a time and reserves room for all its hits with one atomic
+    const int64_t wave = ((int64_t)blockIdx.x * FSEL_T + tid) >> 6, n_waves = ((int64_t)gridDim.x * FSEL_T) >> 6;
+    for (int64_t c0 = wave * 64 * FSEL_U; c0 < n; c0 += n_waves * 64 * FSEL_U) {
+        int64_t kq[FSEL_U];
+        float sq[FSEL_U];
+        unsigned int bits = 0;
+#pragma unroll
+        for (int j = 0; j < FSEL_U; ++j) {
+            const int64_t i = c0 + j * 64 + lane;
+            sq[j] = i < n ? vals[i] : -__builtin_inff();
+        }
+#pragma unroll
+        for (int j = 0; j < FSEL_U; ++j) {
+            const int64_t i = c0 + j * 64 + lane;
+            kq[j] = -1;
+            if (i < n && sq[j] >= thr) kq[j] = keys[i];          // (the key is read for the few entries that pass)
+            if (kq[j] >= 0) bits |= 1u << j;
+        }
+        const int cnt = __popc(bits);
+        int incl = cnt;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int t = __shfl_up(incl, d);
+            if (lane >= d) incl += t;
+        }
+        const int total = __shfl(incl, 63);
+        if (total == 0) continue;
+        unsigned long long base = 0;
+        if (lane == 0) base = atomicAdd(&st->n_out, (unsigned long long)total);
+        const unsigned int blo = __shfl((unsigned int)base, 0), bhi = __shfl((unsigned int)(base >> 32), 0);
+        unsigned long long pos = (((unsigned long long)bhi << 32) | blo) + (unsigned long long)(incl - cnt);
+#pragma unroll
+        for (int j = 0; j < FSEL_U; ++j)
+            if (bits & (1u << j)) {
+                out_keys[pos] = kq[j];
+                out_vals[pos] = sq[j];
+                ++pos;
+            }
+    }
+    // the last workgroup to finish publishes the count (st->n_out is complete then)
+    __syncthreads();
+    if (tid == 0) {
+        __threadfence();
+        const uint32_t done = atomicAdd(&st->arrived, 1u) + 1u;
+        // (rounds that ran: 4 unless the list held fewer than k values)
+        const uint32_t rounds_run = none && k != 0 ? 1u : (k == 0 ? 0u : 4u);
+        if (done == (rounds_run + 1u) * gridDim.x && n_out) *n_out = (int64_t)__atomic_load_n(&st->n_out, __ATOMIC_RELAXED);
+    }
+}
+
+extern "C" int64_t eps_select_compact_workspace_bytes(void) { return (int64_t)sizeof(fsel_state); }
+
+// k >= 0 (0: no selection, *kth = *thr = -inf: every entry with key >= 0 is kept); keys may be NULL when there is no compaction
+// (then every slot counts, -inf apart); out_keys / out_vals NULL: selection only.  state: eps_select_compact_workspace_bytes()
+// bytes, 8-byte aligned, for this call alone until the stream has passed it.
+extern "C" int eps_select_compact(const int64_t *keys, const float *vals, int64_t n_max, const unsigned long long *n_dev_or_null,
+                                  int64_t k, int32_t mode, float pa, float pb, float pc, float *kth_or_null, float *thr_or_null,
+                                  int64_t *out_keys_or_null, float *out_vals_or_null, int64_t *n_out_or_null, void *state,
+                                  void *stream)
+{
+    EPS_REQUIRE(n_max >= 0 && n_max < (1ll << 32) && k >= 0 && mode >= 0 && mode <= 2, "eps_select_compact: bad argument");
+    EPS_REQUIRE(state && ((uintptr_t)state & 7) == 0, "eps_select_compact: null or misaligned state");
+    EPS_REQUIRE((out_keys_or_null == nullptr) == (out_vals_or_null == nullptr), "eps_select_compact: out_keys and out_vals come together");
+    EPS_REQUIRE(!out_keys_or_null || (keys && n_out_or_null), "eps_select_compact: the compaction needs keys and n_out");
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(state, 0, sizeof(fsel_state), s) != hipSuccess ||
+        (n_out_or_null && hipMemsetAsync(n_out_or_null, 0, sizeof(int64_t), s) != hipSuccess)) {
+        eps_set_error("eps_select_compact: cannot initialise the state");
+        return EPS_ELAUNCH;
+    }
+    EPS_REQUIRE(n_max == 0 || vals, "eps_select_compact: null pointer");
+    // k == 0: the rounds are skipped inside (none = true from the start) -- the kernel's `rounds_run` bookkeeping counts on it
+    int64_t blocks = (n_max + FSEL_T * FSEL_U - 1) / (FSEL_T * FSEL_U);
+    const int64_t cap = (int64_t)eps_num_cus();                // one workgroup per CU at most: all resident (the grid-wide hand-over)
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(fsel_kernel, dim3((unsigned)blocks), dim3(FSEL_T), 0, s, keys, vals, n_max, n_dev_or_null, (uint64_t)k, (int)mode,
+                       pa, pb, pc, (fsel_state *)state, kth_or_null, thr_or_null, out_keys_or_null, out_vals_or_null, n_out_or_null);
+    EPS_CHECK_LAUNCH("eps_select_compact");
+    return EPS_OK;
+}

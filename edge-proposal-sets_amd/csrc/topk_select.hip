@@ -30,9 +30,12 @@ struct sel_state {
 // 64 entries on a single counter costs more than the whole selection (0.9 ms for 4.8 M entries).
 __global__ void sel_cut_kernel(const int64_t *__restrict__ keys, const float *__restrict__ vals, int64_t n,
                                const float *__restrict__ cut_or_null, unsigned long long *__restrict__ n_sel,
-                               int64_t *__restrict__ sel_keys, float *__restrict__ sel_vals)
+                               int64_t *__restrict__ sel_keys, float *__restrict__ sel_vals,
+                               const float *__restrict__ below_or_null = nullptr)
 {
     const float cut = cut_or_null ? *cut_or_null : -__builtin_inff();
+    const float below = below_or_null ? *below_or_null : __builtin_inff();      // (exclusive upper end of a score range, or none)
+    const bool ranged = below_or_null != nullptr;
     const int lane = threadIdx.x & 63;
     const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
@@ -46,7 +49,7 @@ __global__ void sel_cut_kernel(const int64_t *__restrict__ keys, const float *__
             const bool in = i < n;
             s[j] = in ? vals[i] : 0.f;
             k[j] = in ? keys[i] : -1;
-            if (in && s[j] >= cut && k[j] >= 0) bits |= 1u << j;
+            if (in && s[j] >= cut && k[j] >= 0 && (!ranged || s[j] < below)) bits |= 1u << j;
         }
         const int cnt = __popc(bits);
         int incl = cnt;                                         // inclusive prefix over the lanes
@@ -74,12 +77,16 @@ __global__ void sel_cut_kernel(const int64_t *__restrict__ keys, const float *__
 __global__ void sel_count_kernel(const sel_state *__restrict__ st, int64_t *__restrict__ n_sel) { *n_sel = (int64_t)st->n_sel; }
 
 __global__ void sel_mirror_kernel(const int64_t *__restrict__ keys, const float *__restrict__ vals, int64_t m,
-                                  int64_t *__restrict__ dkeys, float *__restrict__ dvals)
+                                  const int64_t *__restrict__ perm, int64_t *__restrict__ dkeys, float *__restrict__ dvals)
 {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += stride) {
-        const int64_t k = keys[i];
+        int64_t k = keys[i];
         const float s = vals[i];
+        if (perm) {      // ids of a relabelled graph back to the caller's: new id i is old id perm[i]; the larger one is "v" again
+            const int64_t a = perm[(uint64_t)k & 0xFFFFFFFFull], b = perm[(uint64_t)k >> 32];
+            k = a < b ? ((b << 32) | a) : ((a << 32) | b);
+        }
         dkeys[i] = k;
         dkeys[m + i] = (int64_t)((((uint64_t)k & 0xFFFFFFFFull) << 32) | ((uint64_t)k >> 32));
         dvals[i] = s;
@@ -211,8 +218,27 @@ extern "C" int64_t eps_select_topk_rows_workspace_bytes(int64_t m)
 
 // Step 2: the m selected pairs (m read back by the caller) -> both orientations, sorted by the declared rule; the first
 // min(k, 2 m) rows go to out_keys / out_vals.  id_bits: every id is below 2^id_bits (1..32): the key sort skips the other bits.
+static int sel_rows(const int64_t *sel_keys, const float *sel_vals, int64_t m, int64_t k, int32_t id_bits, const int64_t *perm,
+                    int64_t *out_keys, float *out_vals, void *workspace, int64_t workspace_bytes, void *stream);
+
 extern "C" int eps_select_topk_rows(const int64_t *sel_keys, const float *sel_vals, int64_t m, int64_t k, int32_t id_bits,
                                     int64_t *out_keys, float *out_vals, void *workspace, int64_t workspace_bytes, void *stream)
+{
+    return sel_rows(sel_keys, sel_vals, m, k, id_bits, nullptr, out_keys, out_vals, workspace, workspace_bytes, stream);
+}
+
+// The same with the pairs' ids mapped through perm first (int64[n_nodes]: id i of the scanned, relabelled graph is the caller's
+// id perm[i]): the rows come out in the caller's labels, ordered by the declared rule in THOSE labels.
+extern "C" int eps_select_topk_rows_relabelled(const int64_t *sel_keys, const float *sel_vals, int64_t m, int64_t k, int32_t id_bits,
+                                               const int64_t *perm, int64_t *out_keys, float *out_vals, void *workspace,
+                                               int64_t workspace_bytes, void *stream)
+{
+    EPS_REQUIRE(perm || m == 0, "eps_select_topk_rows_relabelled: null pointer");
+    return sel_rows(sel_keys, sel_vals, m, k, id_bits, perm, out_keys, out_vals, workspace, workspace_bytes, stream);
+}
+
+static int sel_rows(const int64_t *sel_keys, const float *sel_vals, int64_t m, int64_t k, int32_t id_bits, const int64_t *perm,
+                    int64_t *out_keys, float *out_vals, void *workspace, int64_t workspace_bytes, void *stream)
 {
     EPS_REQUIRE(m >= 0 && k >= 0 && id_bits >= 1 && id_bits <= 32, "eps_select_topk_rows: bad argument");
     if (m == 0 || k == 0) return EPS_OK;
@@ -229,7 +255,7 @@ extern "C" int eps_select_topk_rows(const int64_t *sel_keys, const float *sel_va
     float *v1 = (float *)w;                            w += sel_align(rows * 4);
     void *temp = w;
     size_t temp_bytes = sel_sort_temp_bytes((int64_t)rows);
-    hipLaunchKernelGGL(sel_mirror_kernel, dim3(sel_blocks(m)), dim3(256), 0, s, sel_keys, sel_vals, m, k0, v0);
+    hipLaunchKernelGGL(sel_mirror_kernel, dim3(sel_blocks(m)), dim3(256), 0, s, sel_keys, sel_vals, m, perm, k0, v0);
     // stable LSD sorts, least significant criterion first: u (low id bits), v (high id bits), then the score, descending
     hipError_t e;
     if (id_bits >= 24) {         // (nearly) all bits count: one sort over the whole key (non-negative: the sign bit is idle)
@@ -252,5 +278,75 @@ extern "C" int eps_select_topk_rows(const int64_t *sel_keys, const float *sel_va
         return EPS_ELAUNCH;
     }
     EPS_CHECK_LAUNCH("eps_select_topk_rows");
+    return EPS_OK;
+}
+
+// ---- survivor keys grouped by their smaller endpoint, for eps_rescore_runs ------------------------------------------------------
+// keys = v << 32 | u (u < v, any order) -> out = u << 32 | v sorted by (u, v): runs of equal u, v ascending inside a run -- two
+// stable radix sorts over the id bits of v, then of u (six passes for 2^20 nodes instead of the eight of a 64-bit sort).
+__global__ void sel_swap_kernel(const int64_t *__restrict__ keys, int64_t n, int64_t *__restrict__ out)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const uint64_t k = (uint64_t)keys[i];
+        out[i] = (int64_t)((k << 32) | (k >> 32));
+    }
+}
+
+static size_t sel_by_u_temp_bytes(int64_t n)
+{
+    size_t a = 0;
+    (void)rocprim::radix_sort_keys((void *)nullptr, a, (const int64_t *)nullptr, (int64_t *)nullptr, (size_t)n, 0u, 64u, (hipStream_t)0);
+    return a;
+}
+
+extern "C" int64_t eps_sort_pairs_by_u_workspace_bytes(int64_t n)
+{
+    if (n <= 0) return 256;
+    return (int64_t)(sel_align((size_t)n * 8) + sel_align(sel_by_u_temp_bytes(n)));
+}
+
+extern "C" int eps_sort_pairs_by_u(const int64_t *keys, int64_t n, int32_t id_bits, int64_t *out_by_u, void *workspace,
+                                   int64_t workspace_bytes, void *stream)
+{
+    EPS_REQUIRE(n >= 0 && n < (1ll << 31) && id_bits >= 1 && id_bits <= 32, "eps_sort_pairs_by_u: bad argument");
+    if (n == 0) return EPS_OK;
+    EPS_REQUIRE(keys && out_by_u, "eps_sort_pairs_by_u: null pointer");
+    EPS_REQUIRE(workspace && ((uintptr_t)workspace & 255) == 0 && workspace_bytes >= eps_sort_pairs_by_u_workspace_bytes(n),
+                "eps_sort_pairs_by_u: needs a 256-byte aligned workspace of eps_sort_pairs_by_u_workspace_bytes(n) bytes");
+    hipStream_t s = (hipStream_t)stream;
+    int64_t *swapped = (int64_t *)workspace;
+    void *temp = (char *)workspace + sel_align((size_t)n * 8);
+    size_t temp_bytes = sel_by_u_temp_bytes(n);
+    hipLaunchKernelGGL(sel_swap_kernel, dim3(sel_blocks(n)), dim3(256), 0, s, keys, n, out_by_u);
+    // (LSD: v first, then u -- inside a run the rows N(v) are then streamed in ascending v, which is worth 0.4 of 3.3 ms to
+    //  eps_rescore_runs on the ppa-like graph: neighbouring pairs read neighbouring rows)
+    if (rocprim::radix_sort_keys(temp, temp_bytes, out_by_u, swapped, (size_t)n, 0u, (unsigned)id_bits, s) != hipSuccess ||
+        rocprim::radix_sort_keys(temp, temp_bytes, swapped, out_by_u, (size_t)n, 32u, 32u + (unsigned)id_bits, s) != hipSuccess) {
+        eps_set_error("eps_sort_pairs_by_u: radix sort failed");
+        return EPS_ELAUNCH;
+    }
+    EPS_CHECK_LAUNCH("eps_sort_pairs_by_u");
+    return EPS_OK;
+}
+
+// The entries (key >= 0) of a list whose score lies in [*lo, *hi) -- either end may be NULL: open -- compacted in arbitrary order;
+// *n_out (DEVICE int64, zeroed by the call) = how many.  The final ordering of a sharded filter step is dealt over the ranks by
+// score range (filter.py:160-161 sorts all rows on one host): rank r orders the rows of range r, the ranges concatenate.
+extern "C" int eps_compact_between(const int64_t *keys, const float *vals, int64_t n, const float *lo_or_null, const float *hi_or_null,
+                                   int64_t *out_keys, float *out_vals, int64_t *n_out, void *stream)
+{
+    EPS_REQUIRE(n >= 0 && n < (1ll << 32), "eps_compact_between: bad size");
+    EPS_REQUIRE(n_out, "eps_compact_between: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(n_out, 0, sizeof(int64_t), s) != hipSuccess) {
+        eps_set_error("eps_compact_between: cannot clear the count");
+        return EPS_ELAUNCH;
+    }
+    if (n == 0) return EPS_OK;
+    EPS_REQUIRE(keys && vals && out_keys && out_vals, "eps_compact_between: null pointer");
+    hipLaunchKernelGGL(sel_cut_kernel, dim3(sel_blocks((n + 3) / 4)), dim3(256), 0, s, keys, vals, n, lo_or_null,
+                       (unsigned long long *)n_out, out_keys, out_vals, hi_or_null);
+    EPS_CHECK_LAUNCH("eps_compact_between");
     return EPS_OK;
 }

@@ -71,6 +71,20 @@ def all_gather_list(t: torch.Tensor) -> List[torch.Tensor]:
     return parts
 
 
+def all_reduce_min_(t: torch.Tensor) -> torch.Tensor:
+    """In-place minimum over the ranks of a small device tensor (the ranks' bar estimates); transport as ``all_reduce_sum_``."""
+    rank, world = world_info()
+    if world == 1:
+        return t
+    if dist.get_backend() == "gloo" and t.device.type != "cpu":
+        h = t.cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.MIN)
+        t.copy_(h)
+        return t
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return t
+
+
 def all_reduce_sum_(t: torch.Tensor) -> torch.Tensor:
     """In-place sum over the ranks of a small device tensor (histograms, counters).  RCCL reduces device memory directly and
     stays on the stream; gloo (the one-device test hook) goes through host memory."""

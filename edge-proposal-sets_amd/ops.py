@@ -402,17 +402,24 @@ class Survivors:
     """Device-resident eps_survivors record + its key / val arrays.  ``threshold`` may be a Python float or a 0-dim /
     1-element float32 DEVICE tensor (copied on the stream: no host round trip)."""
 
-    def __init__(self, capacity: int, threshold, device, scores_only: bool = False, both: bool = False):
+    def __init__(self, capacity: int, threshold, device, scores_only: bool = False, both: bool = False, prefill: bool = True):
         """``scores_only``: the caller will read the scores alone (the bar estimate): untouched slots are then recognisable
         in ``val`` (-inf) instead of in ``key`` (-1), so no compaction pass is needed before a k-th-largest query.
         ``both``: both fills (key -1 AND val -inf): the list can go through a k-th-largest query as it is and be compacted
-        afterwards (scan_topk's selection)."""
+        afterwards (scan_topk's selection).
+        ``prefill=False`` (eps_scan_screen only): no fill at all -- that kernel marks the unused slots of its reservations
+        (key -1, val -inf) itself, and the list's readers stop at the slot counter (``count_ptr``): a step saves two passes
+        over a list that is sized for the worst case."""
         import struct
         self.capacity = int(capacity)
         if not 0 < self.capacity <= SURVIVOR_SLOTS_MAX:
             raise _lib.EpsError(f"Survivors: capacity {capacity} outside (0, {SURVIVOR_SLOTS_MAX}]")
         self.scores_only = bool(scores_only) and not both
-        if both:
+        self.prefilled = bool(prefill)
+        if not prefill:
+            self.key = torch.empty(self.capacity, dtype=torch.int64, device=device)
+            self.val = torch.empty(self.capacity, dtype=torch.float32, device=device)
+        elif both:
             self.key = torch.full((self.capacity,), -1, dtype=torch.int64, device=device)
             self.val = torch.full((self.capacity,), float("-inf"), dtype=torch.float32, device=device)
         elif scores_only:
@@ -426,6 +433,11 @@ class Survivors:
         self.rec = torch.tensor([head, 0, self.key.data_ptr(), self.val.data_ptr(), 0], dtype=torch.int64, device=device)
         if isinstance(threshold, torch.Tensor):
             self.rec.view(torch.float32)[0:1].copy_(threshold.reshape(1).to(torch.float32))
+
+    @property
+    def count_ptr(self) -> int:
+        """Device address of the slot counter (uint64): how many slots the launches have handed out so far."""
+        return self.rec.data_ptr() + 8
 
     def counts(self):
         """(slots handed out, unordered candidates scored) -- one device read-back."""
@@ -755,6 +767,41 @@ def kth_largest_dist(x: torch.Tensor, k: int, world: int = 1) -> torch.Tensor:
     return out
 
 
+_SEL_STATE = {}
+
+
+def select_compact(keys: Optional[torch.Tensor], vals: torch.Tensor, k: int, count_ptr: Optional[int] = None, mode: int = 0,
+                   params=(0.0, 0.0, 0.0), compact: bool = True):
+    """Radix select + threshold + compaction of a list on ONE device in one launch (eps_select_compact; the sharded job-wide
+    select is ``kth_largest_dist``).  -> (out_keys, out_vals, n_out, kth, thr): the entries with key >= 0 and score >= thr
+    compacted to the front of fresh arrays (None, None, None without ``compact``), their number, the k-th largest score and
+    the threshold derived from it -- all DEVICE tensors, no host read.  ``count_ptr``: device address of a uint64 that bounds the
+    list (``Survivors.count_ptr``).  ``mode`` / ``params``: 0 thr = kth; 1 the largest float below kth; 2 max(kth - a, kth * b) -
+    |kth| * c with params (a, b, c)."""
+    dev = _need_gpu(keys, vals)
+    _chk(keys, torch.int64, "keys"); _chk(vals, torch.float32, "vals")
+    n = vals.numel()
+    lib = _lib.load()
+    words = (int(lib.eps_select_compact_workspace_bytes()) + 7) // 8
+    # (one state per call, from a small ring per device: a state must stay untouched until the stream has passed its launch)
+    ring = _SEL_STATE.setdefault((dev.type, dev.index), {"buf": torch.empty(16 * words, dtype=torch.int64, device=dev), "i": 0})
+    ring["i"] = (ring["i"] + 1) % 16
+    state = ring["buf"][ring["i"] * words:(ring["i"] + 1) * words]
+    kth = torch.empty(2, dtype=torch.float32, device=dev)
+    out_k = out_v = n_out = None
+    if compact:
+        if keys is None:
+            raise _lib.EpsError("select_compact: the compaction needs keys")
+        out_k = torch.empty(n, dtype=torch.int64, device=dev)
+        out_v = torch.empty(n, dtype=torch.float32, device=dev)
+        n_out = torch.empty(1, dtype=torch.int64, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(lib.eps_select_compact(_ptr(keys), _ptr(vals), n, count_ptr, int(k), int(mode), float(params[0]), float(params[1]),
+                                          float(params[2]), kth.data_ptr(), kth.data_ptr() + 4, _ptr(out_k), _ptr(out_v), _ptr(n_out),
+                                          _ptr(state), _stream(dev)), "eps_select_compact")
+    return out_k, out_v, n_out, kth[0:1], kth[1:2]
+
+
 def compact_at_least(keys: torch.Tensor, vals: torch.Tensor, cut: Optional[torch.Tensor]):
     """(keys, vals, n) -- the survivors (key >= 0) with score >= ``cut`` (1-element float32 DEVICE tensor; None: all of them)
     compacted to the front of fresh arrays, ``n`` a 1-element int64 device tensor (no host read)."""
@@ -770,11 +817,44 @@ def compact_at_least(keys: torch.Tensor, vals: torch.Tensor, cut: Optional[torch
     return out_k, out_v, n_out
 
 
-def select_rows(sel_keys: torch.Tensor, sel_vals: torch.Tensor, k: int, id_bits: int = 32) -> Tuple[torch.Tensor, torch.Tensor]:
+def compact_between(keys: torch.Tensor, vals: torch.Tensor, lo: Optional[torch.Tensor], hi: Optional[torch.Tensor]):
+    """(keys, vals, n) -- the entries (key >= 0) with lo <= score < hi (1-element float32 DEVICE tensors; None: open end)
+    compacted to the front of fresh arrays, ``n`` a 1-element int64 device tensor (no host read)."""
+    dev = _need_gpu(keys, vals, lo, hi)
+    _chk(keys, torch.int64, "keys"); _chk(vals, torch.float32, "vals"); _chk(lo, torch.float32, "lo"); _chk(hi, torch.float32, "hi")
+    n = keys.numel()
+    out_k = torch.empty(n, dtype=torch.int64, device=dev)
+    out_v = torch.empty(n, dtype=torch.float32, device=dev)
+    n_out = torch.empty(1, dtype=torch.int64, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.load().eps_compact_between(_ptr(keys), _ptr(vals), n, _ptr(lo), _ptr(hi), _ptr(out_k), _ptr(out_v), _ptr(n_out),
+                                                   _stream(dev)), "eps_compact_between")
+    return out_k, out_v, n_out
+
+
+def sort_pairs_by_u(keys: torch.Tensor, id_bits: int = 32) -> torch.Tensor:
+    """Survivor keys v << 32 | u (u < v, any order) -> u << 32 | v sorted by (u, v), what ``rescore_runs`` wants: two stable
+    radix sorts over the id bits (eps_sort_pairs_by_u)."""
+    dev = _need_gpu(keys)
+    _chk(keys, torch.int64, "keys")
+    n = keys.numel()
+    out = torch.empty(n, dtype=torch.int64, device=dev)
+    if n:
+        lib = _lib.load()
+        with torch.cuda.device(dev):
+            _, wsp, wsb = _aligned_ws(dev, lib.eps_sort_pairs_by_u_workspace_bytes(n))
+            _lib.check(lib.eps_sort_pairs_by_u(_ptr(keys), n, int(id_bits), _ptr(out), wsp, wsb, _stream(dev)), "eps_sort_pairs_by_u")
+    return out
+
+
+def select_rows(sel_keys: torch.Tensor, sel_vals: torch.Tensor, k: int, id_bits: int = 32,
+                perm: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
     """The first min(k, 2 m) DIRECTED rows, in the declared order, of m selected unordered pairs (every pair at or above the
-    job-wide cut): mirror + stable radix sorts (eps_select_topk_rows).  No host read: m is the arrays' length."""
-    dev = _need_gpu(sel_keys, sel_vals)
-    _chk(sel_keys, torch.int64, "sel_keys"); _chk(sel_vals, torch.float32, "sel_vals")
+    job-wide cut): mirror + stable radix sorts (eps_select_topk_rows).  No host read: m is the arrays' length.
+    ``perm`` (int64 [n_nodes]): the pairs are in the labels of a relabelled graph whose id i is the caller's perm[i]; the rows
+    come out -- and are ordered -- in the caller's labels."""
+    dev = _need_gpu(sel_keys, sel_vals, perm)
+    _chk(sel_keys, torch.int64, "sel_keys"); _chk(sel_vals, torch.float32, "sel_vals"); _chk(perm, torch.int64, "perm")
     m, k = sel_keys.numel(), int(k)
     take = min(k, 2 * m)
     out_k = torch.empty(take, dtype=torch.int64, device=dev)
@@ -783,8 +863,12 @@ def select_rows(sel_keys: torch.Tensor, sel_vals: torch.Tensor, k: int, id_bits:
         lib = _lib.load()
         with torch.cuda.device(dev):
             _, wsp, wsb = _aligned_ws(dev, lib.eps_select_topk_rows_workspace_bytes(m))
-            _lib.check(lib.eps_select_topk_rows(_ptr(sel_keys), _ptr(sel_vals), m, k, int(id_bits), _ptr(out_k), _ptr(out_v), wsp, wsb,
-                                                _stream(dev)), "eps_select_topk_rows")
+            if perm is None:
+                _lib.check(lib.eps_select_topk_rows(_ptr(sel_keys), _ptr(sel_vals), m, k, int(id_bits), _ptr(out_k), _ptr(out_v), wsp, wsb,
+                                                    _stream(dev)), "eps_select_topk_rows")
+            else:
+                _lib.check(lib.eps_select_topk_rows_relabelled(_ptr(sel_keys), _ptr(sel_vals), m, k, int(id_bits), _ptr(perm), _ptr(out_k),
+                                                               _ptr(out_v), wsp, wsb, _stream(dev)), "eps_select_topk_rows_relabelled")
     return out_k, out_v
 
 

@@ -229,11 +229,17 @@ class Screen:
         weighs at least w_min > 0, at most exact / w_min <= s / w_min of them, which is what keeps the bound tight under the
         coarse weights (3.7 % of s on the ppa-like graph against 13230 x 2^-8 = 52 absolute).  Weighted graphs form a term from
         two roundings (no dropped bits)."""
+        a, b = self.lower_params(max_deg)
+        return torch.maximum(s - a, s * b)
+
+    def lower_params(self, max_deg: int):
+        """(a, b) with lower_bound(s) = max(s - a, s * b) -- the form eps_select_compact evaluates on the device (mode 2).
+        b = 0 without a relative bound: scores are sums of non-negative weights, so 0 is a floor under all of them."""
         unit = (2.0 ** self.d_used + 1.0) * 2.0 ** -self.shift * (2.0 if self.val is not None else 1.0)
-        low = s - max_deg * unit
+        b = 0.0
         if self.w_min > 0.0 and unit < self.w_min:
-            low = torch.maximum(low, s * (1.0 - 1.00001 * unit / self.w_min))       # (w_min itself is exact to 2^-40)
-        return low
+            b = 1.0 - 1.00001 * unit / self.w_min                                     # (w_min itself is exact to 2^-40)
+        return max_deg * unit, b
 
 
 def _sum_bounds(g: CSRGraph, fx32: torch.Tensor):
@@ -326,11 +332,13 @@ def one_pass_available(g: CSRGraph) -> bool:
 
 def _launch(g, fixw, columns, threshold, capacity, scores_only: bool = False, both: bool = False, screen=None) -> ops.Survivors:
     """``screen`` (a Screen) -> the one-pass kernel (screening scores in ``val``), else eps_filter_scan (exact scores)."""
-    out = ops.Survivors(capacity, threshold, g.device, scores_only, both)
+    # (the piece kernel marks the unused slots of its reservations itself: no fill, readers stop at the slot counter)
+    out = ops.Survivors(capacity, threshold, g.device, scores_only, both, prefill=screen is None)
+    if screen is not None:
+        out.status = torch.zeros(1, dtype=torch.int32, device=g.device)
     if columns.numel():
         if screen is not None:
             bounds, cuts = screen_tables(g)
-            out.status = torch.empty(1, dtype=torch.int32, device=g.device)
             ops.scan_screen(g.rowptr, g.col, reverse_positions(g), screen.fx32, cuts, bounds, g.n_rows, columns, screen.shift, out,
                             out.status, screen_variant(g), screen.val, screen.node_w, window_paths(g), screen.ssum, screen.smax, screen.plan)
         else:
@@ -351,7 +359,7 @@ def rescore_exact(g: CSRGraph, screen: Screen, keys: torch.Tensor, bar):
     if screen.val is not None:
         vals = ops.rescore_weighted(g.rowptr, g.col, screen.val, screen.node_w, g.n_rows, keys)
     else:
-        by_u = torch.sort(((keys & 0xFFFFFFFF) << 32) | (keys >> 32)).values          # (u << 32 | v): runs of equal u
+        by_u = ops.sort_pairs_by_u(keys, max(1, int(g.n_rows - 1).bit_length()))       # (u << 32 | v): runs of equal u
         vals = ops.rescore_runs(g.rowptr, g.col, screen.fixw, g.n_rows, by_u)
         keys = ((by_u & 0xFFFFFFFF) << 32) | (by_u >> 32)
     if bar is not None:
@@ -391,6 +399,21 @@ def sample_columns(g: CSRGraph, stride: int, rank: int = 0, world: int = 1):
     return g._cache[key]
 
 
+SAMPLE_RANK = 4096         # the sample is thinned (stride doubled) while the rank read off it stays at least this large
+
+
+def sample_stride(k: int, safety: Optional[float] = None) -> int:
+    """Stride of the bar sample for a top-``k`` request: ``SAMPLE_STRIDE``, doubled while the rank m = safety x k / 2 / stride
+    that is read off the sample stays >= SAMPLE_RANK (an order statistic of rank m is good to ~1 / sqrt(m): 1.6 % at 4096, far
+    inside what SAFETY absorbs) -- a large k does not need a sample that grows with it.  (Module globals read at CALL time:
+    tests patch them.)"""
+    safety = SAFETY if safety is None else float(safety)
+    stride = int(SAMPLE_STRIDE)
+    while safety * k / 2 / (2 * stride) >= SAMPLE_RANK and stride < 1 << 16:
+        stride *= 2
+    return stride
+
+
 def estimate_bar(g: CSRGraph, fixw: torch.Tensor, k: int, stride: Optional[int] = None, safety: Optional[float] = None,
                  rank: int = 0, world: int = 1, screen=None):
     """Score bar (1-element float32 device tensor) that about ``safety * k`` directed candidates are expected to reach,
@@ -399,8 +422,8 @@ def estimate_bar(g: CSRGraph, fixw: torch.Tensor, k: int, stride: Optional[int] 
     a run of tied scores at the estimate passes as a whole.  ``world`` > 1: rank r scans its share of the sample and the m-th
     best of the union comes from all-reduced radix-select histograms (ops.kth_largest_dist) -- same bar on every rank, no
     host round trip after the first call on a graph."""
-    stride = SAMPLE_STRIDE if stride is None else int(stride)          # module globals read at CALL time (tests patch them)
     safety = SAFETY if safety is None else float(safety)
+    stride = sample_stride(k, safety) if stride is None else int(stride)
     mine, bound_mine, bound_all = sample_columns(g, stride, rank, world)
     if bound_all == 0:
         return None
@@ -412,8 +435,22 @@ def estimate_bar(g: CSRGraph, fixw: torch.Tensor, k: int, stride: Optional[int] 
     res = _launch(g, fixw, mine, float("-inf"), min(bound_mine + slack, ops.SURVIVOR_SLOTS_MAX), scores_only=True, screen=screen)
     # no bar: every candidate of the sample holds a slot, untouched slots are -inf (fewer than m candidates -> bar -inf).
     # (one-pass kernel: screening scores, at most a few 2^-shift above the exact ones -- an estimate either way)
-    kth = ops.kth_largest_dist(res.val, m, world)
-    return torch.nextafter(kth, torch.full_like(kth, float("-inf")))
+    if screen is None:
+        kth = ops.kth_largest_dist(res.val, m, world)
+        return torch.nextafter(kth, torch.full_like(kth, float("-inf")))
+    # One launch (select + "one float below"), and on a job NO round of histogram all-reduces: every rank reads the
+    # (m / world)-th best of its own share of the sample -- the same strata, so an estimate of the same quantile -- and the job
+    # takes the lowest of them (one all-reduce of a word).  Any bar is a valid bar: the verification after the main launch is
+    # what makes the result exact.
+    m_loc = m if world == 1 else (m + world - 1) // world
+    bar = ops.select_compact(None, res.val, m_loc, res.count_ptr, mode=1, compact=False)[4]
+    if world > 1:
+        from . import dist as epd
+        # (a rank whose share of the sample holds fewer than m_loc candidates has no estimate: it does not vote)
+        inf = torch.full_like(bar, float("inf"))
+        vote = epd.all_reduce_min_(torch.where(torch.isinf(bar), inf, bar))
+        bar = torch.where(torch.isinf(vote), -inf, vote)
+    return bar
 
 
 def _gather_varlen(t: torch.Tensor, world: int):
@@ -450,6 +487,49 @@ def select_topk_torch(keys: torch.Tensor, vals: torch.Tensor, k: int) -> Tuple[t
     keys, vals = keys[o], vals[o]
     o = torch.sort(vals, descending=True, stable=True).indices[:k]     # ... kept among equal scores
     return keys[o], vals[o]
+
+
+DIST_ROWS_MIN = 1 << 15      # selected pairs from which the final ordering of a sharded step is dealt over the ranks
+
+
+def score_splitters(vals: torch.Tensor, world: int) -> torch.Tensor:
+    """``world - 1`` scores, descending, that cut a list of scores into ``world`` ranges of about equal size: range r holds the
+    scores in [splitter[r], splitter[r - 1]) (open at both ends of the list).  Read off a sorted thinning of the list (every
+    n / 32768-th value): every rank holds the same gathered list in the same order, so every rank computes the same splitters
+    without a collective; equal scores always fall into one range, so the ranges concatenate to the declared order."""
+    n = vals.numel()
+    samp = torch.sort(vals[::max(1, n // 32768)], descending=True).values
+    idx = (torch.arange(1, world, device=vals.device) * samp.numel()) // world
+    return samp[idx.clamp(max=samp.numel() - 1)]
+
+
+def score_range_counts(vals: torch.Tensor, splitters: torch.Tensor) -> torch.Tensor:
+    """int64[world]: how many scores fall into each range of ``score_splitters`` (range 0 = the best scores)."""
+    r = (vals.unsqueeze(1) < splitters.unsqueeze(0)).sum(1)              # range of every score: splitters it lies below
+    return torch.bincount(r, minlength=splitters.numel() + 1)
+
+
+def _ordered_rows_distributed(keys: torch.Tensor, vals: torch.Tensor, k: int, bits: int, perm, rank: int, world: int):
+    """The k best directed rows of the selected pairs (all of them, gathered: the same arrays on every rank), ordered by the
+    declared rule, with the ORDERING dealt over the ranks: rank r mirrors and sorts the pairs of score range r (1 / world of the
+    rows: filter.py:160-161 sorts all E rows on one host), the sorted chunks are gathered in rank order -- which is the declared
+    order, because a score range holds every pair of its scores.  One host read (the ranges' sizes, from one small tensor)."""
+    from . import dist as epd
+    sp = score_splitters(vals, world)
+    counts = score_range_counts(vals, sp).tolist()                       # the one host read: pairs per range, on every rank alike
+    lo = sp[rank:rank + 1] if rank < world - 1 else None
+    hi = sp[rank - 1:rank] if rank > 0 else None
+    mk, mv, _ = ops.compact_between(keys, vals, lo, hi)
+    m = counts[rank]
+    rk, rv = ops.select_rows(mk[:m].contiguous(), mv[:m].contiguous(), 2 * m, bits, perm)      # all 2 m rows of the range, ordered
+    lens = [2 * c for c in counts]
+    rows_k, rows_v = epd.gather_ragged(rk, lens), epd.gather_ragged(rv, lens)
+    return rows_k[:k], rows_v[:k]
+
+
+def _f32_from_bits(word: int) -> float:
+    import struct
+    return struct.unpack("<f", struct.pack("<I", int(word) & 0xFFFFFFFF))[0]
 
 
 def _capacity(slots_wanted: int, slack: Optional[int] = None) -> int:
@@ -496,6 +576,7 @@ def scan_topk(g: CSRGraph, node_w: torch.Tensor, k: int, rank: int = 0, world: i
     slack = _CHUNK_SLACK if screen is None else _PIECE_SLACK
     launches = 0
     bar = None
+    rescore_all = False                  # (set when a rank's pre-filter threshold turned out to lie above the job-wide cut)
     if total_half > SMALL_SET and SAFETY * k < total_half:
         bar = estimate_bar(g, fixw, k, rank=rank, world=world, screen=screen)
         launches += 1
@@ -510,25 +591,34 @@ def scan_topk(g: CSRGraph, node_w: torch.Tensor, k: int, rank: int = 0, world: i
         res = _launch(g, fixw, mine, float("-inf") if bar is None else bar, capacity, both=True, screen=screen)
         launches += 1
         l_keys, l_vals = res.key, res.val
-        status = None
+        status, pre_thr = None, None
         if screen is not None:
             # the one-pass kernel screens with upper bounds: its survivors are re-scored exactly (those that do not exceed the
-            # bar after all drop out), so from here on the list holds eps_filter_scan's scores bit for bit
+            # bar after all drop out), so from here on the list holds eps_filter_scan's scores bit for bit.
             # Not all of them need it: a screening score s exceeds the exact one by less than what `screen.lower_bound` takes
-            # off (a monotone lower bound of the exact score), and k2 pairs have screening scores >= cut_a (the k2-th best,
-            # job-wide), hence exact scores >= lower(cut_a): the k2 best exact scores all have screening scores >= lower(cut_a)
-            # -- only those are re-scored (about k2 of the SAFETY x k2 survivors).
-            cut_a = ops.kth_largest_dist(l_vals, k2, world)
-            keep_from = screen.lower_bound(cut_a, max_degree(g))
-            c_keys, _, n_valid = ops.compact_at_least(l_keys, l_vals, keep_from - cut_a.abs() * 4e-6)
+            # off (a monotone lower bound of the exact score).  With t = lower(the k_pre-th best screening score of THIS rank's
+            # list), every pair that is not re-scored has an exact score < t; the job-wide cut found below (the k2-th best exact
+            # score among the re-scored pairs of all ranks) is then final iff it is >= every rank's t -- which the status
+            # table verifies.  k_pre = k2 / world: the shards are dealt round-robin out of one heaviest-first order, so a rank's
+            # (k2 / world)-th best sits at the job's k2-th best, and lower() leaves ~4 % of margin; world = 1: the r03 rule.
+            # One launch: select + threshold + compaction, bounded by the list's slot counter (no collective, no pass over the
+            # list's unused capacity).
+            a, b = screen.lower_params(max_degree(g))
+            k_pre = 0 if rescore_all else (k2 + world - 1) // world
+            c_keys, _, n_valid, _, pre_thr = ops.select_compact(l_keys, l_vals, k_pre, res.count_ptr, mode=2, params=(a, b, 4e-6))
             nv = int(n_valid.item())                                                      # (one word: sizes the re-scoring)
             l_keys, l_vals = rescore_exact(g, screen, c_keys[:nv], bar)
             status = res.status
         # the job-wide cut: the k2-th best survivor score over all ranks (-inf when fewer survived); untouched slots are -inf
-        cut = ops.kth_largest_dist(l_vals, k2, world)
-        sel_k, sel_v, n_sel = ops.compact_at_least(l_keys, l_vals, cut)
-        st = torch.cat([res.rec[[1, 4]], n_sel, cut.view(torch.int32).to(torch.int64),      # slots, candidates, selected, cut bits,
-                        (status if status is not None else torch.zeros(1, dtype=torch.int32, device=dev)).to(torch.int64)])
+        if world == 1 and screen is not None:
+            sel_k, sel_v, n_sel, cut, _ = ops.select_compact(l_keys, l_vals, k2)          # (one launch: select + compaction)
+        else:
+            cut = ops.kth_largest_dist(l_vals, k2, world)
+            sel_k, sel_v, n_sel = ops.compact_at_least(l_keys, l_vals, cut)
+        zero = torch.zeros(1, dtype=torch.int64, device=dev)
+        st = torch.cat([res.rec[1:2], res.rec[4:5], n_sel, cut.view(torch.int32).to(torch.int64),     # slots, candidates, selected, cut bits,
+                        status.to(torch.int64) if status is not None else zero,                          # kernel status,
+                        pre_thr.view(torch.int32).to(torch.int64) if pre_thr is not None else zero])     # pre-filter threshold bits
         if world > 1:
             from . import dist as epd
             table = torch.stack(epd.all_gather_list(st)).tolist()                          # the host read of the step
@@ -539,6 +629,15 @@ def scan_topk(g: CSRGraph, node_w: torch.Tensor, k: int, rank: int = 0, world: i
             raise ops._lib.EpsError("scan_topk: eps_scan_screen reported a full hash table (status %s)" % [t[4] for t in table])
         n_cand_all, n_sel_all = sum(ncand_r), sum(nsel_r)
         cut_is_inf = (table[0][3] & 0xFFFFFFFF) == 0xFF800000
+        if screen is not None and not rescore_all and not any(sl > capacity for sl in slots_r):
+            # the pre-filter was sound iff the cut reaches every rank's threshold (floats compared through their bits on the host)
+            cut_f = _f32_from_bits(table[0][3])
+            if any(cut_f < _f32_from_bits(t[5]) for t in table):
+                rescore_all = True         # (never seen with round-robin shards: a rank's list would have to sit far above the job's)
+                launches -= 1              # (the repeat is the same launch again, not a corrected bar)
+                if launches + 2 > MAX_LAUNCHES:
+                    raise ops._lib.EpsError("scan_topk: the re-scoring pre-filter kept failing")
+                continue
         if any(sl > capacity for sl in slots_r):
             # the bar was too low for the list.  What was kept is a subset of the survivors, so the k2-th best score among
             # it (the cut just computed, job-wide) is a lower bound of the final cut: scan again just below it, with more
@@ -558,11 +657,14 @@ def scan_topk(g: CSRGraph, node_w: torch.Tensor, k: int, rank: int = 0, world: i
                 capacity = _capacity(wanted, slack)
             continue
         break
-    keys, vals = _original_keys(sel_k[:nsel_r[rank]], perm), sel_v[:nsel_r[rank]]
+    keys, vals = sel_k[:nsel_r[rank]], sel_v[:nsel_r[rank]]      # (still in the scanned graph's labels: select_rows maps them back)
+    bits = max(1, min(32, int(g.n_rows - 1).bit_length()))
     if world > 1:
         keys, vals = epd.gather_ragged(keys, nsel_r), epd.gather_ragged(vals, nsel_r)
-    bits = max(1, min(32, int(g.n_rows - 1).bit_length()))
-    keys, vals = ops.select_rows(keys.contiguous(), vals.contiguous(), k, bits)
+    if world > 1 and n_sel_all >= DIST_ROWS_MIN:
+        keys, vals = _ordered_rows_distributed(keys.contiguous(), vals.contiguous(), k, bits, perm, rank, world)
+    else:
+        keys, vals = ops.select_rows(keys.contiguous(), vals.contiguous(), k, bits, perm)
     if stats is not None:
         # survivors: DIRECTED rows at or above the job-wide cut (what the selection orders); survivor_slots: list slots the
         # launches handed out (chunks: holes included); bar: None or a 1-element device tensor (float(bar) reads it)

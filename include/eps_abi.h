@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define EPS_ABI_VERSION 4   /* 2: eps_col_sums / eps_node_weights_f64 signatures (r02); 3: 64-bit survivor count, eps_scan_* (r03); 4: eps_scan_screen takes ssum / smax */
+#define EPS_ABI_VERSION 5   /* 2: eps_col_sums / eps_node_weights_f64 signatures (r02); 3: 64-bit survivor count, eps_scan_* (r03); 4: eps_scan_screen takes ssum / smax; 5: eps_select_compact, eps_scan_screen marks unused slots itself (r04) */
 
 #define EPS_OK 0
 #define EPS_EINVAL (-1)   /* bad argument (null pointer, negative size, unsupported shape) */
@@ -368,6 +368,22 @@ int eps_kth_largest_f32(const float *x, int64_t n, int64_t k, float *kth, void *
  * (shift = 24, 16, 8, 0): eps_kth_hist_f32 adds the histogram of this rank's values (n may be 0), the caller sums hist over
  * the ranks (one all-reduce of 1 KiB), eps_kth_pick narrows the prefix and clears hist.  After the round with shift 0,
  * *out = the k-th largest of the union, -inf when the union holds fewer than k values. */
+/* eps_select_compact: radix select + threshold + compaction of a short list in ONE launch (the selections of a filter step --
+ * filter.py:160-161 keeps the K best rows -- were launch-latency bound: ten launches per select, one more per compaction).
+ *   n = min(*n_dev_or_null, n_max): the slot counter of an eps_survivors list (eps_scan_screen marks the unused slots of its
+ *   reservations "no survivor" itself, so a reader stops at the counter and the list needs no fill before the launch);
+ *   entries with value -inf (and, when keys is given, key < 0) are no values;
+ *   *kth = the k-th largest value, -inf when there are fewer than k (k == 0: -inf, nothing selected);
+ *   *thr = mode 0: kth; mode 1: the largest float below kth (an inclusive bar for a scan that keeps scores above its
+ *          threshold); mode 2: max(kth - pa, kth * pb) - |kth| * pc (a lower bound of the exact score behind a screening
+ *          score: eps_amd.scan.Screen.lower_bound);
+ *   out_keys / out_vals (n_max entries each; both NULL: selection only) receive the entries with key >= 0 and value >= *thr in
+ *   arbitrary order, *n_out (DEVICE int64) their number.  state: eps_select_compact_workspace_bytes() bytes, 8-byte aligned.
+ * Single device; the sharded job-wide select stays eps_kth_begin / _hist_f32 / _pick with one all-reduce per round. */
+int64_t eps_select_compact_workspace_bytes(void);
+int eps_select_compact(const int64_t *keys_or_null, const float *vals, int64_t n_max, const unsigned long long *n_dev_or_null,
+                       int64_t k, int32_t mode, float pa, float pb, float pc, float *kth_or_null, float *thr_or_null,
+                       int64_t *out_keys_or_null, float *out_vals_or_null, int64_t *n_out_or_null, void *state, void *stream);
 int eps_kth_begin(void *state, int64_t k, void *stream);
 int eps_kth_hist_f32(const float *x, int64_t n, void *state, int32_t shift, void *stream);
 int eps_kth_pick(void *state, int32_t shift, float *out_or_null, void *stream);
@@ -382,6 +398,22 @@ int eps_kth_pick(void *state, int32_t shift, float *out_or_null, void *stream);
 /* eps_compact_survivors: the survivors among the first n slots of an eps_survivors list (untouched slots keep key -1),
  * compacted in arbitrary order into out_keys / out_vals (n entries each); *n_out (DEVICE word) = how many.  workspace as for
  * eps_select_topk_cut. */
+/* eps_select_topk_rows_relabelled: eps_select_topk_rows with the pairs' ids mapped through perm first (int64[n_nodes]: id i of a
+ * relabelled, scanned graph is the caller's id perm[i]) -- rows and their order are in the caller's labels.
+ * eps_sort_pairs_by_u: survivor keys v << 32 | u (u < v) -> u << 32 | v sorted by (u, v) (two stable radix sorts over the
+ * id_bits bits of v, then of u): runs of equal u with ascending v, the input eps_rescore_runs wants.  workspace: eps_sort_pairs_by_u_workspace_bytes(n) bytes,
+ * 256-byte aligned. */
+/* eps_compact_between: the entries (key >= 0) whose score lies in [*lo, *hi) (DEVICE floats; either may be NULL: open end),
+ * compacted in arbitrary order; *n_out (DEVICE int64) = how many.  A sharded filter step deals its final ordering over the
+ * ranks by score range. */
+int eps_compact_between(const int64_t *keys, const float *vals, int64_t n, const float *lo_or_null, const float *hi_or_null,
+                        int64_t *out_keys, float *out_vals, int64_t *n_out, void *stream);
+int eps_select_topk_rows_relabelled(const int64_t *sel_keys, const float *sel_vals, int64_t m, int64_t k, int32_t id_bits,
+                                    const int64_t *perm, int64_t *out_keys, float *out_vals, void *workspace,
+                                    int64_t workspace_bytes, void *stream);
+int64_t eps_sort_pairs_by_u_workspace_bytes(int64_t n);
+int eps_sort_pairs_by_u(const int64_t *keys, int64_t n, int32_t id_bits, int64_t *out_by_u, void *workspace,
+                        int64_t workspace_bytes, void *stream);
 int64_t eps_select_topk_cut_workspace_bytes(void);
 int eps_compact_survivors(const int64_t *keys, const float *vals, int64_t n, int64_t *out_keys, float *out_vals,
                           int64_t *n_out, void *workspace, int64_t workspace_bytes, void *stream);

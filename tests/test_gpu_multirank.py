@@ -145,7 +145,7 @@ def test_bench_self_launch_from_plain_shell(dev, tmp_path):
     assert 0 < line["roofline"]["frac"] <= 1 and line["value_unordered_pairs_per_s"] * 2 == pytest.approx(line["value"])
 
 
-def _relabelled_scan_rank_main(rank, world, port, workdir):
+def _relabelled_scan_rank_main(rank, world, port, workdir, dist_rows_min=0):
     sys.path.insert(0, ROOT)
     os.chdir(workdir)
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
@@ -156,6 +156,7 @@ def _relabelled_scan_rank_main(rank, world, port, workdir):
     epd.init_from_env("gloo", 0)
     scan.RELABEL_MIN_NODES = 0
     scan.SMALL_SET = 0                               # the estimated-bar path
+    scan.DIST_ROWS_MIN = dist_rows_min               # 0: the final ordering is dealt over the ranks by score range
     dev = torch.device("cuda:0")
     g = synth.rmat_graph(13, 10, 21, dev)
     pairs, scores = scan.scan_topk(g, node_weight_table(g, ops.W_AA), 30000, rank, world, relabel=True)
@@ -164,15 +165,17 @@ def _relabelled_scan_rank_main(rank, world, port, workdir):
     torch.distributed.destroy_process_group()
 
 
-def test_scan_two_ranks_hubs_first_labels(eps, dev, tmp_path):
-    """The sharded threshold scan on the hubs-first relabelled copy (what bench.py --scaling strong runs): both ranks end
-    with the single-process list as scanned under the original labels, bit for bit."""
+@pytest.mark.parametrize("world,dist_rows_min", [(2, 0), (4, 0), (2, 1 << 30)])
+def test_scan_two_ranks_hubs_first_labels(eps, dev, tmp_path, world, dist_rows_min):
+    """The sharded threshold scan on the hubs-first relabelled copy (what bench.py --scaling strong runs): every rank ends
+    with the single-process list as scanned under the original labels, bit for bit -- with the final ordering dealt over the
+    ranks by score range (2 and 4 ranks on this one GPU) and with every rank ordering all rows itself."""
     from eps_amd import scan, synth
     from eps_amd.heuristics import node_weight_table
     g = synth.rmat_graph(13, 10, 21, dev)
     want_p, want_s = scan.scan_topk(g, node_weight_table(g, eps.ops.W_AA), 30000)
     assert scan.scan_graph(g)[1] is None
-    mp.spawn(_relabelled_scan_rank_main, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
-    for r in (0, 1):
+    mp.spawn(_relabelled_scan_rank_main, args=(world, _free_port(), str(tmp_path), dist_rows_min), nprocs=world, join=True)
+    for r in range(world):
         p, s = torch.load(os.path.join(tmp_path, f"scan_rank{r}.pt"))
         assert torch.equal(p, want_p.cpu()) and torch.equal(s, want_s.cpu())

@@ -496,3 +496,45 @@ def test_one_pass_scan_on_a_two_million_node_graph(eps, dev):
     sc = scan.screen_weights(g, gs, perm, w)
     assert perm is not None and scan.one_pass_available(gs) and sc.ssum is not None and sc.plan is not None
     assert st0["candidates"] == st1["candidates"] and torch.equal(p0, p1) and torch.equal(s0, s1)
+
+
+@pytest.mark.parametrize("n,k", [(0, 5), (1, 1), (777, 100), (200_000, 1), (200_000, 65_432), (3_000_000, 1_000_000), (50_000, 60_000)])
+def test_select_compact_one_launch(eps, dev, n, k):
+    """eps_select_compact (radix select + threshold + compaction in one launch, grid-wide hand-over between the rounds) against
+    torch: k-th largest with heavy ties, -inf / key -1 slots that are no values, a device-side bound on the list, the three
+    threshold modes, fewer than k values."""
+    import struct
+    gen = torch.Generator(device=dev).manual_seed(n + k)
+    cap = n + 1000                                               # slots past the device-side count hold garbage that must not count
+    vals = (torch.randint(0, 5000, (cap,), generator=gen, device=dev).float() / 7.0 - 100.0)      # heavy ties, both signs
+    keys = torch.randint(0, 1 << 40, (cap,), generator=gen, device=dev, dtype=torch.int64)
+    dead = torch.rand(cap, generator=gen, device=dev) < 0.2
+    vals[dead] = float("-inf")
+    keys[dead] = -1
+    count = torch.tensor([n], dtype=torch.int64, device=dev)
+    live_v, live_k = vals[:n][~dead[:n]], keys[:n][~dead[:n]]
+    want_kth = float("-inf") if live_v.numel() < k or k == 0 else float(torch.sort(live_v, descending=True).values[k - 1])
+    for mode, params in ((0, (0.0, 0.0, 0.0)), (1, (0.0, 0.0, 0.0)), (2, (3.5, 0.9, 4e-6))):
+        ok, ov, n_out, kth, thr = eps.ops.select_compact(keys, vals, k, count.data_ptr(), mode=mode, params=params)
+        assert float(kth) == want_kth
+        if want_kth == float("-inf"):
+            want_thr = want_kth
+        elif mode == 0:
+            want_thr = want_kth
+        elif mode == 1:
+            want_thr = float(torch.nextafter(torch.tensor(want_kth), torch.tensor(float("-inf"))))
+        else:
+            f = lambda x: struct.unpack("<f", struct.pack("<f", x))[0]
+            low, rel = f(f(want_kth) - f(params[0])), f(f(want_kth) * f(params[1]))
+            want_thr = f(max(low, rel) - f(abs(want_kth) * f(params[2])))
+        assert float(thr) == pytest.approx(want_thr, rel=1e-6, abs=1e-30) and (mode == 2 or float(thr) == want_thr)
+        m = int(n_out)
+        keep = live_v >= float(thr)
+        assert m == int(keep.sum())
+        got = torch.sort(ok[:m]).values
+        assert torch.equal(got, torch.sort(live_k[keep]).values)
+        o1, o2 = torch.argsort(ok[:m]), torch.argsort(live_k[keep])
+        assert torch.equal(ov[:m][o1], live_v[keep][o2]) or live_k[keep].unique().numel() != m     # (duplicate random keys: order free)
+    # selection only, scores alone (the bar estimate's call)
+    _, _, _, kth, thr = eps.ops.select_compact(None, vals, k, count.data_ptr(), mode=1, compact=False)
+    assert float(kth) == want_kth

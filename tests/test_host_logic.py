@@ -295,3 +295,39 @@ def test_scan_host_rules(eps):
     vals = torch.tensor([2.0, 3.0, 2.0])
     k, v = scan.select_topk_torch(keys, vals, 3)
     assert k.tolist() == [(2 << 32) | 7, (7 << 32) | 2, (1 << 32) | 5] and v.tolist() == [3.0, 3.0, 2.0]
+
+
+@pytest.mark.parametrize("world", [1, 2, 4, 8])
+@pytest.mark.parametrize("ties", [False, True])
+def test_distributed_final_ordering_concatenates_to_the_declared_order(world, ties):
+    """scan._ordered_rows_distributed's host logic on CPU tensors: score ranges from ``score_splitters`` partition the selected
+    pairs (equal scores never straddle a boundary), their sizes match ``score_range_counts``, and the per-range orderings --
+    mirror, key ascending, score descending: ``select_topk_torch`` -- concatenate in rank order to exactly the rows a single
+    rank orders: byte-identical for 1, 2, 4 and 8 logical shards."""
+    from eps_amd import scan
+    gen = torch.Generator().manual_seed(17 + world)
+    n = 50_000
+    u = torch.randint(0, 3000, (n,), generator=gen)
+    v = u + 1 + torch.randint(0, 3000, (n,), generator=gen)
+    keys = torch.unique((v << 32) | u)
+    n = keys.numel()
+    vals = torch.rand(n, generator=gen) * 5
+    if ties:
+        vals = torch.round(vals * 3) / 3                       # a handful of distinct scores: whole levels of ties
+    k = 2 * n - 7
+    want_k, want_v = scan.select_topk_torch(keys, vals, k)
+    sp = scan.score_splitters(vals, world)
+    assert sp.numel() == world - 1 and bool((sp[:-1] >= sp[1:]).all())
+    counts = scan.score_range_counts(vals, sp).tolist()
+    assert sum(counts) == n
+    chunks_k, chunks_v = [], []
+    for r in range(world):
+        lo = float(sp[r]) if r < world - 1 else float("-inf")
+        hi = float(sp[r - 1]) if r > 0 else float("inf")
+        m = (vals >= lo) & (vals < hi)
+        assert int(m.sum()) == counts[r]
+        rk, rv = scan.select_topk_torch(keys[m], vals[m], 2 * int(m.sum()))
+        chunks_k.append(rk)
+        chunks_v.append(rv)
+    got_k, got_v = torch.cat(chunks_k)[:k], torch.cat(chunks_v)[:k]
+    assert torch.equal(got_k, want_k) and torch.equal(got_v, want_v)
