@@ -19,6 +19,7 @@ SIGNATURES = {
     "eps_version": (_int, []),
     "eps_last_error": (_c.c_char_p, []),
     "eps_device_info": (_int, [_c.POINTER(_int), _c.c_char_p, _int]),
+    "eps_warm_up": (_int, []),
     "eps_col_sums": (_int, [_vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp]),
     "eps_node_weights": (_int, [_vp, _i64, _int, _vp, _vp]),
     "eps_node_weights_f64": (_int, [_vp, _i64, _int, _vp, _vp]),
@@ -34,6 +35,12 @@ SIGNATURES = {
     "eps_filter_scan_max_nodes": (_i64, []),
     "eps_filter_scan_workspace_bytes": (_i64, [_i64]),
     "eps_reverse_positions": (_int, [_vp, _vp, _i64, _vp, _vp, _vp, _vp]),
+    "eps_relabel_graph_workspace_bytes": (_i64, [_i64, _i64, _i32]),
+    "eps_relabel_graph": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _vp, _vp, _vp, _i64, _vp]),
+    "eps_reverse_positions_symmetric": (_int, [_vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp]),
+    "eps_node_order_workspace_bytes": (_i64, [_i64]),
+    "eps_node_order": (_int, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
+    "eps_score_bound": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp]),
     "eps_fixed_weights": (_int, [_vp, _i64, _vp, _vp]),
     "eps_filter_scan_windows": (_int, [_i64, _c.POINTER(_i64), _c.POINTER(_i64)]),
     "eps_row_window_splits": (_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp]),
@@ -64,7 +71,7 @@ SIGNATURES = {
     "eps_sort_pairs_by_u": (_int, [_vp, _i64, _i32, _vp, _vp, _i64, _vp]),
     "eps_compact_between": (_int, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "eps_select_compact_workspace_bytes": (_i64, []),
-    "eps_select_compact": (_int, [_vp, _vp, _i64, _vp, _i64, _i32, _c.c_float, _c.c_float, _c.c_float, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "eps_select_compact": (_int, [_vp, _vp, _i64, _vp, _i64, _i32, _c.c_float, _c.c_float, _c.c_float, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp]),
     "eps_kth_begin": (_int, [_vp, _i64, _vp]),
     "eps_kth_hist_f32": (_int, [_vp, _i64, _vp, _i32, _vp]),
     "eps_kth_pick": (_int, [_vp, _i32, _vp, _vp]),
@@ -116,6 +123,43 @@ def load() -> ctypes.CDLL:
         raise EpsError(f"libeps_hip.so ABI version {lib.eps_version()} != {ABI_VERSION}: rebuild (make -C {CSRC})")
     _lib = lib
     return lib
+
+
+_warm = None
+
+
+def warm_up_async(device=None):
+    """Start loading the library's code objects (eps_warm_up) -- and the handful of torch operators the filter step uses -- in a
+    daemon thread, and return at once.  A fresh process pays 10-30 ms per larger code object at the first launch of one of its
+    kernels; filter.py / rank.py are one process per graph (submit_job.py:20-21) and spend their first hundreds of
+    milliseconds reading the dataset on the host: the loads ride along.  Idempotent; errors are left for the first real call
+    to report."""
+    global _warm
+    if _warm is not None:
+        return _warm
+    import threading
+    import torch
+
+    def work():
+        try:
+            if not torch.cuda.is_available():
+                return
+            dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+            with torch.cuda.device(dev):
+                load().eps_warm_up()
+                # (torch's own code objects: the few element-wise / copy operators between the library calls of a step)
+                z = torch.zeros(4, dtype=torch.int64, device=dev)
+                f = torch.full((4,), float("-inf"), dtype=torch.float32, device=dev)
+                torch.cat([z, z[1:2] + 1]).tolist()
+                torch.stack([z & 3, z >> 1]); f.view(torch.int32).to(torch.int64); torch.empty(4, device=dev)[:2].contiguous()
+                torch.tensor([1, 2], dtype=torch.int64, device=dev)
+                torch.cuda.synchronize(dev)
+        except Exception:       # noqa: BLE001  (a warm-up must never be the thing that fails a run)
+            pass
+
+    _warm = threading.Thread(target=work, name="eps-warm-up", daemon=True)
+    _warm.start()
+    return _warm
 
 
 def check(rc: int, what: str) -> None:

@@ -1,0 +1,374 @@
+// Per-graph tables of the filter stage, built by kernels of the library (r04), gfx950.
+//
+// filter.py runs ONCE per graph (submit_job.py:20-21: one process per filter), so what the scan needs of a graph -- the
+// hubs-first relabelled copy, the reverse positions, the score bound -- is on the critical path of every run, not an amortised
+// cost.  r03 built them from tensor ops (a 64-bit sort of all stored entries for the copy: 9 ms; a lower-bound search per
+// stored entry for the reverse positions: 4.9 ms; gathers + a float64 prefix sum for the bound: 1.1 ms on the ppa-like graph):
+//   * eps_relabel_graph: the copy of a graph under a node permutation.  Row i of the copy IS row perm[i] of the graph with its
+//     ids mapped -- so the rows are gathered as they are (one wave per row, coalesced) and only SORTED INSIDE each row: a
+//     segmented radix sort over the id bits (rocPRIM, called directly), not a global sort of 64-bit keys;
+//   * eps_reverse_positions_symmetric: on a symmetric pattern the position of v in row w and the position of w in row v are
+//     found by ONE search -- the entry (v, w), w > v, looks v up in row w (the shorter row under hubs-first labels), and the
+//     place it finds it at IS the mirror entry, which takes this entry's own position: half the searches, in the short rows;
+//   * eps_score_bound: max over the rows of sum |node_w[col]| (x |val| x the column's largest |val| with stored values):
+//     the bound candidates.fused_score_bound puts on every fused score of the graph, one pass, float64 row sums.
+#include "eps_common.h"
+
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
+#include <rocprim/device/device_segmented_radix_sort.hpp>
+
+static unsigned gp_blocks(int64_t n, int per_block)
+{
+    int64_t blocks = (n + per_block - 1) / per_block;
+    const int64_t cap = (int64_t)eps_num_cus() * 16;
+    if (blocks > cap) blocks = cap;
+    return (unsigned)(blocks < 1 ? 1 : blocks);
+}
+
+// row i of the copy = row perm[i] of the graph, ids through inv (unsorted: the segmented sort follows)
+__global__ __launch_bounds__(256) void gp_gather_rows_kernel(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+                                                            const float *__restrict__ val, const int64_t *__restrict__ perm,
+                                                            const int32_t *__restrict__ inv, const int64_t *__restrict__ new_rowptr,
+                                                            int64_t n_nodes, int32_t *__restrict__ out_col, float *__restrict__ out_val)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t i = wave; i < n_nodes; i += n_waves) {
+        const int64_t src = perm[i];
+        const int64_t b = rowptr[src], e = rowptr[src + 1], nb = new_rowptr[i];
+        for (int64_t j = b + lane; j < e; j += 64) {
+            out_col[nb + (j - b)] = inv[col[j]];
+            if (val) out_val[nb + (j - b)] = val[j];
+        }
+    }
+}
+
+static size_t gp_align(size_t x) { return (x + 255) & ~(size_t)255; }
+
+static size_t gp_sort_temp_bytes(int64_t nnz, int64_t n_nodes, bool pairs)
+{
+    size_t t = 0;
+    if (pairs)
+        (void)rocprim::segmented_radix_sort_pairs((void *)nullptr, t, (const int32_t *)nullptr, (int32_t *)nullptr, (const float *)nullptr,
+                                                  (float *)nullptr, (unsigned)nnz, (unsigned)n_nodes, (const int64_t *)nullptr,
+                                                  (const int64_t *)nullptr, 0u, 32u, (hipStream_t)0);
+    else
+        (void)rocprim::segmented_radix_sort_keys((void *)nullptr, t, (const int32_t *)nullptr, (int32_t *)nullptr, (unsigned)nnz,
+                                                 (unsigned)n_nodes, (const int64_t *)nullptr, (const int64_t *)nullptr, 0u, 32u,
+                                                 (hipStream_t)0);
+    return t;
+}
+
+extern "C" int64_t eps_relabel_graph_workspace_bytes(int64_t n_nodes, int64_t nnz, int32_t with_values)
+{
+    if (nnz <= 0 || n_nodes <= 0) return 256;
+    return (int64_t)(gp_align((size_t)nnz * 4) + (with_values ? gp_align((size_t)nnz * 4) : 0) +
+                     gp_align(gp_sort_temp_bytes(nnz, n_nodes, with_values != 0)));
+}
+
+// new_rowptr[i + 1] - new_rowptr[i] = degree of row perm[i] (the caller's prefix sum); inv[perm[i]] = i (int32).
+extern "C" int eps_relabel_graph(const int64_t *rowptr, const int32_t *col, const float *val_or_null, const int64_t *perm,
+                                 const int32_t *inv, const int64_t *new_rowptr, int64_t n_nodes, int64_t nnz, int32_t id_bits,
+                                 int32_t *out_col, float *out_val_or_null, void *workspace, int64_t workspace_bytes, void *stream)
+{
+    EPS_REQUIRE(n_nodes >= 0 && nnz >= 0 && nnz < (1ll << 31) && n_nodes < (1ll << 31) && id_bits >= 1 && id_bits <= 32,
+                "eps_relabel_graph: bad size");
+    EPS_REQUIRE((val_or_null == nullptr) == (out_val_or_null == nullptr), "eps_relabel_graph: val and out_val come together");
+    if (nnz == 0 || n_nodes == 0) return EPS_OK;
+    EPS_REQUIRE(rowptr && col && perm && inv && new_rowptr && out_col, "eps_relabel_graph: null pointer");
+    EPS_REQUIRE(workspace && ((uintptr_t)workspace & 255) == 0 &&
+                    workspace_bytes >= eps_relabel_graph_workspace_bytes(n_nodes, nnz, val_or_null != nullptr),
+                "eps_relabel_graph: needs a 256-byte aligned workspace of eps_relabel_graph_workspace_bytes() bytes");
+    hipStream_t s = (hipStream_t)stream;
+    char *w = (char *)workspace;
+    int32_t *tmp_col = (int32_t *)w;                 w += gp_align((size_t)nnz * 4);
+    float *tmp_val = nullptr;
+    if (val_or_null) {
+        tmp_val = (float *)w;
+        w += gp_align((size_t)nnz * 4);
+    }
+    void *temp = w;
+    size_t temp_bytes = gp_sort_temp_bytes(nnz, n_nodes, val_or_null != nullptr);
+    hipLaunchKernelGGL(gp_gather_rows_kernel, dim3(gp_blocks(n_nodes, 4)), dim3(256), 0, s, rowptr, col, val_or_null, perm, inv, new_rowptr,
+                       n_nodes, tmp_col, tmp_val);
+    hipError_t e;
+    if (val_or_null)
+        e = rocprim::segmented_radix_sort_pairs(temp, temp_bytes, tmp_col, out_col, tmp_val, out_val_or_null, (unsigned)nnz,
+                                                (unsigned)n_nodes, new_rowptr, new_rowptr + 1, 0u, (unsigned)id_bits, s);
+    else
+        e = rocprim::segmented_radix_sort_keys(temp, temp_bytes, tmp_col, out_col, (unsigned)nnz, (unsigned)n_nodes, new_rowptr,
+                                               new_rowptr + 1, 0u, (unsigned)id_bits, s);
+    if (e != hipSuccess) {
+        eps_set_error("eps_relabel_graph: segmented sort failed: %s", hipGetErrorString(e));
+        return EPS_ELAUNCH;
+    }
+    EPS_CHECK_LAUNCH("eps_relabel_graph");
+    return EPS_OK;
+}
+
+// ---- reverse positions of a symmetric pattern: one search per UNORDERED stored pair -----------------------------------------
+__global__ __launch_bounds__(256) void gp_revpos_half_kernel(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+                                                            int64_t n_nodes, int32_t *__restrict__ revpos,
+                                                            unsigned int *__restrict__ asymmetric)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t v = wave; v < n_nodes; v += n_waves) {
+        const int64_t b = rowptr[v], e = rowptr[v + 1];
+        bool odd = false;
+        for (int64_t i = b + lane; i < e; i += 64) {
+            const int32_t w = col[i];
+            if ((int64_t)w < v) continue;                      // (its mirror entry (w, v) does the search and writes this one)
+            if ((int64_t)w == v) {                             // a diagonal entry is its own mirror
+                revpos[i] = (int32_t)(i - b);
+                continue;
+            }
+            int64_t lo = rowptr[w], hi = rowptr[w + 1];
+            const int64_t wb = lo, we = hi;
+            while (lo < hi) {
+                const int64_t mid = (lo + hi) >> 1;
+                if (col[mid] < (int32_t)v) lo = mid + 1; else hi = mid;
+            }
+            revpos[i] = (int32_t)(lo - wb);                    // entries of row w below v: the position of v in row w
+            if (lo < we && col[lo] == (int32_t)v)
+                revpos[lo] = (int32_t)(i - b);                 // ... and there sits the mirror entry: w is at position i - b of row v
+            else
+                odd = true;                                    // (v, w) without (w, v)
+        }
+        if (__ballot(odd) && lane == 0) atomicOr(asymmetric, 1u);
+    }
+}
+
+// half_paths[v] = sum of revpos over row v (the column's two-hop half paths); on the way: a lower entry (w < v) whose mirror
+// never wrote it -- (v, w) stored without (w, v) searching for it -- shows as the poison the caller filled the table with
+__global__ __launch_bounds__(256) void gp_half_paths_kernel(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ revpos,
+                                                           int64_t n_nodes, int64_t *__restrict__ half_paths,
+                                                           unsigned int *__restrict__ asymmetric, unsigned long long *__restrict__ stats)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    unsigned long long max_deg = 0ull, max_half = 0ull, total = 0ull;       // (of this wave's rows; lane 0 publishes them once)
+    for (int64_t v = wave; v < n_nodes; v += n_waves) {
+        const int64_t b = rowptr[v], e = rowptr[v + 1];
+        long long below = 0;
+        bool odd = false;
+        for (int64_t i = b + lane; i < e; i += 64) {
+            const int32_t r = revpos[i];
+            odd |= r < 0;
+            below += r;
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) below += __shfl_xor(below, d);
+        if (lane == 0) half_paths[v] = below;
+        if (__ballot(odd) && lane == 0) atomicOr(asymmetric, 1u);
+        const unsigned long long dg = (unsigned long long)(e - b), hp = (unsigned long long)below;
+        max_deg = dg > max_deg ? dg : max_deg;
+        max_half = hp > max_half ? hp : max_half;
+        total += hp;
+    }
+    if (stats && lane == 0) {
+        if (max_deg > __atomic_load_n(&stats[0], __ATOMIC_RELAXED)) atomicMax(&stats[0], max_deg);
+        if (max_half > __atomic_load_n(&stats[1], __ATOMIC_RELAXED)) atomicMax(&stats[1], max_half);
+        if (total) atomicAdd(&stats[2], total);
+    }
+}
+
+// revpos / half_paths / *asymmetric as eps_reverse_positions reports them -- for a SYMMETRIC pattern.  On any other pattern the
+// flag comes back set and revpos is not usable (the caller falls back to eps_reverse_positions, or refuses the graph).
+extern "C" int eps_reverse_positions_symmetric(const int64_t *rowptr, const int32_t *col, int64_t n_nodes, int64_t nnz,
+                                               int32_t *revpos, int64_t *half_paths, uint32_t *asymmetric,
+                                               unsigned long long *stats_or_null, void *stream)
+{
+    EPS_REQUIRE(n_nodes >= 0 && nnz >= 0, "eps_reverse_positions_symmetric: negative size");
+    EPS_REQUIRE(asymmetric, "eps_reverse_positions_symmetric: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(asymmetric, 0, sizeof(uint32_t), s) != hipSuccess ||
+        (stats_or_null && hipMemsetAsync(stats_or_null, 0, 3 * sizeof(unsigned long long), s) != hipSuccess)) {
+        eps_set_error("eps_reverse_positions_symmetric: cannot clear the flag");
+        return EPS_ELAUNCH;
+    }
+    if (n_nodes == 0) return EPS_OK;
+    EPS_REQUIRE(rowptr && col && revpos && half_paths, "eps_reverse_positions_symmetric: null pointer");
+    if (nnz && hipMemsetAsync(revpos, 0xFF, (size_t)nnz * 4, s) != hipSuccess) {      // -1: "nobody wrote this entry"
+        eps_set_error("eps_reverse_positions_symmetric: cannot fill the table");
+        return EPS_ELAUNCH;
+    }
+    hipLaunchKernelGGL(gp_revpos_half_kernel, dim3(gp_blocks(n_nodes, 4)), dim3(256), 0, s, rowptr, col, n_nodes, revpos, asymmetric);
+    hipLaunchKernelGGL(gp_half_paths_kernel, dim3(gp_blocks(n_nodes, 4)), dim3(256), 0, s, rowptr, revpos, n_nodes, half_paths, asymmetric,
+                       stats_or_null);
+    EPS_CHECK_LAUNCH("eps_reverse_positions_symmetric");
+    return EPS_OK;
+}
+
+// ---- the score bound of a graph -------------------------------------------------------------------------------------------------
+// bound[0] = max over rows v of  sum_w |A[v,w]| x |node_w[w]| x colmax[w]   (float64 row sums; colmax = the column's largest
+// |A[.,w]|, all ones without stored values), bound[1] = the same sum over all stored entries (what a caller adds slack from).
+__global__ __launch_bounds__(256) void gp_col_absmax_kernel(const int32_t *__restrict__ col, const float *__restrict__ val, int64_t nnz,
+                                                           unsigned int *__restrict__ colmax_bits)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nnz; i += stride) {
+        const unsigned int a = __builtin_bit_cast(unsigned int, __builtin_fabsf(val[i]));     // (non-negative floats order like their bits)
+        if (a > __atomic_load_n(&colmax_bits[col[i]], __ATOMIC_RELAXED)) atomicMax(&colmax_bits[col[i]], a);
+    }
+}
+
+__global__ __launch_bounds__(256) void gp_score_bound_kernel(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+                                                            const float *__restrict__ val, const float *__restrict__ node_w,
+                                                            const unsigned int *__restrict__ colmax_bits, int64_t n_nodes,
+                                                            unsigned long long *__restrict__ bound_bits)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    double best = 0.0;
+    for (int64_t v = wave; v < n_nodes; v += n_waves) {
+        const int64_t b = rowptr[v], e = rowptr[v + 1];
+        double acc = 0.0;
+        for (int64_t i = b + lane; i < e; i += 64) {
+            const int32_t w = col[i];
+            double t = node_w ? (double)__builtin_fabsf(node_w[w]) : 1.0;
+            if (val) t *= (double)__builtin_fabsf(val[i]) * (double)__builtin_bit_cast(float, colmax_bits[w]);
+            acc += t;
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d);
+        best = acc > best ? acc : best;
+    }
+    // (non-negative doubles order like their bit patterns)
+    if (lane == 0 && best > 0.0) atomicMax(bound_bits, (unsigned long long)__builtin_bit_cast(long long, best));
+}
+
+// workspace: n_cols uint32 (used with stored values only; may be NULL without); *bound: one DEVICE double.
+extern "C" int eps_score_bound(const int64_t *rowptr, const int32_t *col, const float *val_or_null, const float *node_w_or_null,
+                               int64_t n_rows, int64_t n_cols, int64_t nnz, double *bound, void *workspace, void *stream)
+{
+    EPS_REQUIRE(n_rows >= 0 && n_cols >= 0 && nnz >= 0 && bound, "eps_score_bound: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(bound, 0, sizeof(double), s) != hipSuccess) {
+        eps_set_error("eps_score_bound: cannot clear the result");
+        return EPS_ELAUNCH;
+    }
+    if (n_rows == 0) return EPS_OK;
+    EPS_REQUIRE(rowptr && col, "eps_score_bound: null pointer");
+    if (val_or_null) {
+        EPS_REQUIRE(workspace, "eps_score_bound: stored values need a workspace of n_cols uint32");
+        if (hipMemsetAsync(workspace, 0, (size_t)n_cols * 4, s) != hipSuccess) {
+            eps_set_error("eps_score_bound: cannot clear the workspace");
+            return EPS_ELAUNCH;
+        }
+        if (nnz > 0)
+            hipLaunchKernelGGL(gp_col_absmax_kernel, dim3(gp_blocks(nnz, 256)), dim3(256), 0, s, col, val_or_null, nnz,
+                               (unsigned int *)workspace);
+    }
+    hipLaunchKernelGGL(gp_score_bound_kernel, dim3(gp_blocks(n_rows, 4)), dim3(256), 0, s, rowptr, col, val_or_null, node_w_or_null,
+                       (const unsigned int *)workspace, n_rows, (unsigned long long *)bound);
+    EPS_CHECK_LAUNCH("eps_score_bound");
+    return EPS_OK;
+}
+
+// ---- node orders: by descending key, ties in ascending id (stable) -----------------------------------------------------------
+// The hubs-first labels of a graph (key = degree) and the scan's heaviest-first column order (key = two-hop half paths) were
+// torch.argsort calls: the first use of that operator costs a fresh process 10-13 ms of code-object loading -- more than the
+// sort of half a million keys -- and filter.py is one process per graph.
+__global__ __launch_bounds__(256) void gp_order_keys_kernel(const int64_t *__restrict__ rowptr_or_null, const int64_t *__restrict__ keys_or_null,
+                                                           int64_t n, int64_t *__restrict__ k_out, int32_t *__restrict__ iota)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        k_out[i] = rowptr_or_null ? rowptr_or_null[i + 1] - rowptr_or_null[i] : keys_or_null[i];
+        iota[i] = (int32_t)i;
+    }
+}
+
+__global__ __launch_bounds__(256) void gp_order_finish_kernel(const int32_t *__restrict__ order, const int64_t *__restrict__ sorted_keys,
+                                                             int64_t n, int64_t *__restrict__ perm64, int32_t *__restrict__ inv32,
+                                                             int64_t *__restrict__ deg_in_order)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const int32_t src = order[i];
+        if (perm64) perm64[i] = src;
+        if (inv32) inv32[src] = (int32_t)i;
+        if (deg_in_order) deg_in_order[i] = sorted_keys[i];
+    }
+}
+
+static size_t gp_order_sort_temp(int64_t n)
+{
+    size_t t = 0;
+    (void)rocprim::radix_sort_pairs_desc((void *)nullptr, t, (const int64_t *)nullptr, (int64_t *)nullptr, (const int32_t *)nullptr,
+                                         (int32_t *)nullptr, (size_t)n, 0u, 64u, (hipStream_t)0);
+    return t;
+}
+
+static size_t gp_order_scan_temp(int64_t n)
+{
+    size_t t = 0;
+    (void)rocprim::inclusive_scan((void *)nullptr, t, (const int64_t *)nullptr, (int64_t *)nullptr, (size_t)n, rocprim::plus<int64_t>(),
+                                  (hipStream_t)0);
+    return t;
+}
+
+extern "C" int64_t eps_node_order_workspace_bytes(int64_t n)
+{
+    if (n <= 0) return 256;
+    const size_t a = gp_order_sort_temp(n), b = gp_order_scan_temp(n);
+    return (int64_t)(3 * gp_align((size_t)n * 8) + 2 * gp_align((size_t)n * 4) + gp_align(a > b ? a : b));
+}
+
+// order[i] (int32) = the node with the i-th largest key -- keys = the degrees (rowptr given) or keys[] --, ties by ascending id.
+// Optional by-products for the hubs-first copy: perm64[i] = order[i] as int64, inv32[order[i]] = i, new_rowptr (n + 1 entries) =
+// exclusive prefix of the keys in that order (with degrees: the row pointers of the relabelled copy).
+extern "C" int eps_node_order(const int64_t *rowptr_or_null, const int64_t *keys_or_null, int64_t n, int32_t *order_or_null,
+                              int64_t *perm64_or_null, int32_t *inv32_or_null, int64_t *new_rowptr_or_null, void *workspace,
+                              int64_t workspace_bytes, void *stream)
+{
+    EPS_REQUIRE(n >= 0 && n < (1ll << 31), "eps_node_order: bad size");
+    EPS_REQUIRE((rowptr_or_null != nullptr) != (keys_or_null != nullptr), "eps_node_order: give the row pointers or the keys");
+    hipStream_t s = (hipStream_t)stream;
+    if (new_rowptr_or_null && hipMemsetAsync(new_rowptr_or_null, 0, sizeof(int64_t), s) != hipSuccess) {
+        eps_set_error("eps_node_order: cannot clear the first row pointer");
+        return EPS_ELAUNCH;
+    }
+    if (n == 0) return EPS_OK;
+    EPS_REQUIRE(workspace && ((uintptr_t)workspace & 255) == 0 && workspace_bytes >= eps_node_order_workspace_bytes(n),
+                "eps_node_order: needs a 256-byte aligned workspace of eps_node_order_workspace_bytes(n) bytes");
+    char *w = (char *)workspace;
+    int64_t *k0 = (int64_t *)w;        w += gp_align((size_t)n * 8);
+    int64_t *k1 = (int64_t *)w;        w += gp_align((size_t)n * 8);
+    int64_t *dg = (int64_t *)w;        w += gp_align((size_t)n * 8);
+    int32_t *i0 = (int32_t *)w;        w += gp_align((size_t)n * 4);
+    int32_t *i1 = (int32_t *)w;        w += gp_align((size_t)n * 4);
+    void *temp = w;
+    size_t sort_temp = gp_order_sort_temp(n), scan_temp = gp_order_scan_temp(n);
+    hipLaunchKernelGGL(gp_order_keys_kernel, dim3(gp_blocks(n, 256)), dim3(256), 0, s, rowptr_or_null, keys_or_null, n, k0, i0);
+    // (keys are non-negative: 63 bits; the descending radix sort is stable, so equal keys keep ascending ids)
+    if (rocprim::radix_sort_pairs_desc(temp, sort_temp, k0, k1, i0, i1, (size_t)n, 0u, 63u, s) != hipSuccess) {
+        eps_set_error("eps_node_order: radix sort failed");
+        return EPS_ELAUNCH;
+    }
+    int32_t *order = order_or_null ? order_or_null : i1;
+    if (order_or_null && hipMemcpyAsync(order_or_null, i1, (size_t)n * 4, hipMemcpyDeviceToDevice, s) != hipSuccess) {
+        eps_set_error("eps_node_order: cannot copy the order out");
+        return EPS_ELAUNCH;
+    }
+    if (perm64_or_null || inv32_or_null || new_rowptr_or_null)
+        hipLaunchKernelGGL(gp_order_finish_kernel, dim3(gp_blocks(n, 256)), dim3(256), 0, s, order, k1, n, perm64_or_null, inv32_or_null,
+                           new_rowptr_or_null ? dg : (int64_t *)nullptr);
+    if (new_rowptr_or_null &&
+        rocprim::inclusive_scan(temp, scan_temp, dg, new_rowptr_or_null + 1, (size_t)n, rocprim::plus<int64_t>(), s) != hipSuccess) {
+        eps_set_error("eps_node_order: prefix sum failed");
+        return EPS_ELAUNCH;
+    }
+    EPS_CHECK_LAUNCH("eps_node_order");
+    return EPS_OK;
+}
+
+// (one empty kernel per translation unit: launching it makes the HIP runtime load this unit's code object -- eps_warm_up)
+__global__ void graph_prep_warm_kernel() {}
+extern "C" void eps_warm_graph_prep(void *stream) { hipLaunchKernelGGL(graph_prep_warm_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream); }

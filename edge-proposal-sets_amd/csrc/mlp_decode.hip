@@ -233,3 +233,7 @@ extern "C" int eps_mlp_decode(const float *h, int64_t n_nodes, int32_t hdim, con
     EPS_CHECK_LAUNCH("eps_mlp_decode");
     return EPS_OK;
 }
+
+// (one empty kernel per translation unit: launching it makes the HIP runtime load this unit's code object -- eps_warm_up)
+__global__ void mlp_decode_warm_kernel() {}
+extern "C" void eps_warm_mlp_decode(void *stream) { hipLaunchKernelGGL(mlp_decode_warm_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream); }

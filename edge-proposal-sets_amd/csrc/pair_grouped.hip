@@ -402,3 +402,7 @@ extern "C" int eps_pair_scores_grouped_f64(const int64_t *rowptr, const int32_t 
                                               (hipStream_t)stream);
 }
 
+
+// (one empty kernel per translation unit: launching it makes the HIP runtime load this unit's code object -- eps_warm_up)
+__global__ void pair_grouped_warm_kernel() {}
+extern "C" void eps_warm_pair_grouped(void *stream) { hipLaunchKernelGGL(pair_grouped_warm_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream); }

@@ -350,3 +350,7 @@ extern "C" int eps_node_weights_f64(const double *colsum, int64_t n, int mode, d
     return EPS_OK;
 }
 
+
+// (one empty kernel per translation unit: launching it makes the HIP runtime load this unit's code object -- eps_warm_up)
+__global__ void pair_intersect_warm_kernel() {}
+extern "C" void eps_warm_pair_intersect(void *stream) { hipLaunchKernelGGL(pair_intersect_warm_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream); }

@@ -249,7 +249,8 @@ extern "C" int eps_kth_pick(void *state, int32_t shift, float *out_or_null, void
 //   *thr = mode 0: kth; mode 1: the largest float below kth (an inclusive bar for a kernel that keeps scores ABOVE its
 //          threshold); mode 2: max(kth - a, kth * b) - |kth| * c (a lower bound of what a screening score kth can be worth
 //          exactly: eps_amd.scan.Screen.lower_bound);
-//   out_keys / out_vals (optional) receive the entries with value >= *thr (and key >= 0), *n_out their number.
+//   out_keys / out_vals (optional, out_cap entries each) receive the entries with value >= *thr (and key >= 0), *n_out their
+//   number -- which may exceed out_cap: the entries beyond it are counted, not stored (the caller comes back with more room).
 struct fsel_state {
     uint32_t hist[4][256];
     uint32_t arrived;
@@ -276,7 +277,7 @@ __global__ __launch_bounds__(FSEL_T) void fsel_kernel(const int64_t *__restrict_
                                                      const unsigned long long *__restrict__ n_dev, uint64_t k, int mode, float pa,
                                                      float pb, float pc, fsel_state *__restrict__ st, float *__restrict__ kth_out,
                                                      float *__restrict__ thr_out, int64_t *__restrict__ out_keys,
-                                                     float *__restrict__ out_vals, int64_t *__restrict__ n_out)
+                                                     float *__restrict__ out_vals, int64_t out_cap, int64_t *__restrict__ n_out)
 {
     __shared__ uint32_t h[256];
     __shared__ uint32_t s_prefix, s_mask, s_done;
@@ -413,8 +414,10 @@ __global__ __launch_bounds__(FSEL_T) void fsel_kernel(const int64_t *__restrict_
 #pragma unroll
         for (int j = 0; j < FSEL_U; ++j)
             if (bits & (1u << j)) {
-                out_keys[pos] = kq[j];
-                out_vals[pos] = sq[j];
+                if (pos < (unsigned long long)out_cap) {       // (entries past the arrays' room are counted, not stored)
+                    out_keys[pos] = kq[j];
+                    out_vals[pos] = sq[j];
+                }
                 ++pos;
             }
     }
@@ -436,9 +439,10 @@ extern "C" int64_t eps_select_compact_workspace_bytes(void) { return (int64_t)si
 // bytes, 8-byte aligned, for this call alone until the stream has passed it.
 extern "C" int eps_select_compact(const int64_t *keys, const float *vals, int64_t n_max, const unsigned long long *n_dev_or_null,
                                   int64_t k, int32_t mode, float pa, float pb, float pc, float *kth_or_null, float *thr_or_null,
-                                  int64_t *out_keys_or_null, float *out_vals_or_null, int64_t *n_out_or_null, void *state,
-                                  void *stream)
+                                  int64_t *out_keys_or_null, float *out_vals_or_null, int64_t out_cap, int64_t *n_out_or_null,
+                                  void *state, void *stream)
 {
+    EPS_REQUIRE(out_cap >= 0, "eps_select_compact: negative room");
     EPS_REQUIRE(n_max >= 0 && n_max < (1ll << 32) && k >= 0 && mode >= 0 && mode <= 2, "eps_select_compact: bad argument");
     EPS_REQUIRE(state && ((uintptr_t)state & 7) == 0, "eps_select_compact: null or misaligned state");
     EPS_REQUIRE((out_keys_or_null == nullptr) == (out_vals_or_null == nullptr), "eps_select_compact: out_keys and out_vals come together");
@@ -456,7 +460,11 @@ extern "C" int eps_select_compact(const int64_t *keys, const float *vals, int64_
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(fsel_kernel, dim3((unsigned)blocks), dim3(FSEL_T), 0, s, keys, vals, n_max, n_dev_or_null, (uint64_t)k, (int)mode,
-                       pa, pb, pc, (fsel_state *)state, kth_or_null, thr_or_null, out_keys_or_null, out_vals_or_null, n_out_or_null);
+                       pa, pb, pc, (fsel_state *)state, kth_or_null, thr_or_null, out_keys_or_null, out_vals_or_null, out_cap, n_out_or_null);
     EPS_CHECK_LAUNCH("eps_select_compact");
     return EPS_OK;
 }
+
+// (one empty kernel per translation unit: launching it makes the HIP runtime load this unit's code object -- eps_warm_up)
+__global__ void topk_keys_warm_kernel() {}
+extern "C" void eps_warm_topk_keys(void *stream) { hipLaunchKernelGGL(topk_keys_warm_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream); }

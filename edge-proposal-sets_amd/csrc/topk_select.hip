@@ -350,3 +350,7 @@ extern "C" int eps_compact_between(const int64_t *keys, const float *vals, int64
     EPS_CHECK_LAUNCH("eps_compact_between");
     return EPS_OK;
 }
+
+// (one empty kernel per translation unit: launching it makes the HIP runtime load this unit's code object -- eps_warm_up)
+__global__ void topk_select_warm_kernel() {}
+extern "C" void eps_warm_topk_select(void *stream) { hipLaunchKernelGGL(topk_select_warm_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream); }

@@ -224,12 +224,22 @@ class CSRGraph:
         spmm_reorder.py).  Square graphs only; cached."""
         if "deg_order" not in self._cache:
             assert self.n_rows == self.n_cols
-            perm = torch.argsort(self.degree(), descending=True, stable=True)
-            inv = torch.empty_like(perm)
-            inv[perm] = torch.arange(self.n_rows, device=self.device)
-            row, col, val = self.coo()
-            rowptr, c, v = _coalesce(inv[row], inv[col], self.values_or_ones() if val is not None else None,
-                                     self.n_rows, self.n_cols)
+            if self.device.type == "cuda" and self.nnz() < 1 << 31 and self.n_rows:
+                # Row i of the copy IS row perm[i] with its ids mapped: order the nodes (a stable radix sort of the degrees),
+                # gather the rows, sort INSIDE each (eps_node_order + eps_relabel_graph: 9 -> 1.4 ms for the 42.5 M entries of
+                # the ppa-like graph against the 64-bit sort of all entries below; and no torch operator on the way -- a
+                # one-shot filter.py pays ~10 ms for each one it is the first to use)
+                from . import ops
+                perm, inv32, rowptr = ops.node_order(rowptr=self.rowptr, relabel=True)
+                c, v = ops.relabel_graph(self.rowptr, self.col, self.val, perm, inv32, rowptr)
+                inv = inv32.to(torch.int64)
+            else:
+                perm = torch.argsort(self.degree(), descending=True, stable=True)
+                inv = torch.empty_like(perm)
+                inv[perm] = torch.arange(self.n_rows, device=self.device)
+                row, col, val = self.coo()
+                rowptr, c, v = _coalesce(inv[row], inv[col], self.values_or_ones() if val is not None else None,
+                                         self.n_rows, self.n_cols)
             self._cache["deg_order"] = (CSRGraph(rowptr, c, v, self.n_rows, self.n_cols), perm, inv)
         return self._cache["deg_order"]
 

@@ -350,6 +350,78 @@ def reverse_positions(rowptr: torch.Tensor, col: torch.Tensor, with_stats: bool 
     return (out, hp, flag) if with_stats else out
 
 
+def reverse_positions_symmetric(rowptr: torch.Tensor, col: torch.Tensor):
+    """(revpos, half_paths, asymmetric flag) as ``reverse_positions(with_stats=True)`` for a SYMMETRIC pattern, with one search
+    per unordered stored pair (eps_reverse_positions_symmetric); the flag comes back 1 on any other pattern and revpos is then
+    not usable."""
+    dev = _need_gpu(rowptr, col)
+    _chk(rowptr, torch.int64, "rowptr"); _chk(col, torch.int32, "col")
+    n = rowptr.numel() - 1
+    out = torch.empty(col.numel(), dtype=torch.int32, device=dev)
+    hp = torch.empty(n, dtype=torch.int64, device=dev)
+    # one small buffer for everything the caller reads back: [asymmetric flag (low word), max degree, max half paths, their sum]
+    info = torch.empty(4, dtype=torch.int64, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.load().eps_reverse_positions_symmetric(_ptr(rowptr), _ptr(col), n, col.numel(), _ptr(out), _ptr(hp),
+                                                               info.data_ptr(), info.data_ptr() + 8, _stream(dev)),
+                   "eps_reverse_positions_symmetric")
+    return out, hp, info
+
+
+def node_order(rowptr: Optional[torch.Tensor] = None, keys: Optional[torch.Tensor] = None, relabel: bool = False):
+    """Nodes by descending key (the degrees when ``rowptr`` is given, else ``keys`` int64 >= 0), ties by ascending id
+    (eps_node_order: a stable radix sort of the library).  -> order int32[n]; with ``relabel`` -> (perm int64[n], inv int32[n],
+    new_rowptr int64[n + 1]): what ``relabel_graph`` needs for the copy under that order."""
+    src = rowptr if rowptr is not None else keys
+    dev = _need_gpu(src)
+    _chk(src, torch.int64, "rowptr / keys")
+    n = src.numel() - 1 if rowptr is not None else src.numel()
+    lib = _lib.load()
+    order = perm = inv = new_rp = None
+    if relabel:
+        perm = torch.empty(n, dtype=torch.int64, device=dev)
+        inv = torch.empty(n, dtype=torch.int32, device=dev)
+        new_rp = torch.empty(n + 1, dtype=torch.int64, device=dev)
+    else:
+        order = torch.empty(n, dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        _, wsp, wsb = _aligned_ws(dev, lib.eps_node_order_workspace_bytes(n))
+        _lib.check(lib.eps_node_order(_ptr(rowptr), _ptr(keys) if rowptr is None else None, n, _ptr(order), _ptr(perm), _ptr(inv),
+                                      _ptr(new_rp), wsp, wsb, _stream(dev)), "eps_node_order")
+    return (perm, inv, new_rp) if relabel else order
+
+
+def relabel_graph(rowptr, col, val, perm: torch.Tensor, inv32: torch.Tensor, new_rowptr: torch.Tensor):
+    """(col, val) of the copy of a coalesced CSR graph under a node permutation: row i = row perm[i] with ids through inv32,
+    sorted inside the row (eps_relabel_graph: gather + segmented radix sort)."""
+    dev = _need_gpu(rowptr, col, val, perm, inv32, new_rowptr)
+    _chk(rowptr, torch.int64, "rowptr"); _chk(col, torch.int32, "col"); _chk(val, torch.float32, "val")
+    _chk(perm, torch.int64, "perm"); _chk(inv32, torch.int32, "inv"); _chk(new_rowptr, torch.int64, "new_rowptr")
+    n, nnz = rowptr.numel() - 1, col.numel()
+    out_c = torch.empty(nnz, dtype=torch.int32, device=dev)
+    out_v = None if val is None else torch.empty(nnz, dtype=torch.float32, device=dev)
+    if nnz:
+        lib = _lib.load()
+        with torch.cuda.device(dev):
+            _, wsp, wsb = _aligned_ws(dev, lib.eps_relabel_graph_workspace_bytes(n, nnz, int(val is not None)))
+            _lib.check(lib.eps_relabel_graph(_ptr(rowptr), _ptr(col), _ptr(val), _ptr(perm), _ptr(inv32), _ptr(new_rowptr), n, nnz,
+                                             max(1, int(n - 1).bit_length()), _ptr(out_c), _ptr(out_v), wsp, wsb, _stream(dev)),
+                       "eps_relabel_graph")
+    return out_c, out_v
+
+
+def score_bound(rowptr, col, val, node_w, n_rows: int, n_cols: int) -> torch.Tensor:
+    """1-element float64 DEVICE tensor: max over the rows of sum |A[v,w]| |node_w[w]| max_u |A[u,w]| (eps_score_bound)."""
+    dev = _need_gpu(rowptr, col, val, node_w)
+    _chk(rowptr, torch.int64, "rowptr"); _chk(col, torch.int32, "col"); _chk(val, torch.float32, "val"); _chk(node_w, torch.float32, "node_w")
+    out = torch.empty(1, dtype=torch.float64, device=dev)
+    ws = torch.empty(n_cols, dtype=torch.int32, device=dev) if val is not None else None
+    with torch.cuda.device(dev):
+        _lib.check(_lib.load().eps_score_bound(_ptr(rowptr), _ptr(col), _ptr(val), _ptr(node_w), int(n_rows), int(n_cols), col.numel(),
+                                               _ptr(out), _ptr(ws), _stream(dev)), "eps_score_bound")
+    return out
+
+
 def filter_scan_windows(n_nodes: int):
     """(ids per window, number of windows) eps_filter_scan uses for an id space of ``n_nodes``."""
     w, k = ctypes.c_int64(0), ctypes.c_int64(0)
@@ -771,13 +843,15 @@ _SEL_STATE = {}
 
 
 def select_compact(keys: Optional[torch.Tensor], vals: torch.Tensor, k: int, count_ptr: Optional[int] = None, mode: int = 0,
-                   params=(0.0, 0.0, 0.0), compact: bool = True):
+                   params=(0.0, 0.0, 0.0), compact: bool = True, room: Optional[int] = None):
     """Radix select + threshold + compaction of a list on ONE device in one launch (eps_select_compact; the sharded job-wide
     select is ``kth_largest_dist``).  -> (out_keys, out_vals, n_out, kth, thr): the entries with key >= 0 and score >= thr
     compacted to the front of fresh arrays (None, None, None without ``compact``), their number, the k-th largest score and
     the threshold derived from it -- all DEVICE tensors, no host read.  ``count_ptr``: device address of a uint64 that bounds the
     list (``Survivors.count_ptr``).  ``mode`` / ``params``: 0 thr = kth; 1 the largest float below kth; 2 max(kth - a, kth * b) -
-    |kth| * c with params (a, b, c)."""
+    |kth| * c with params (a, b, c).  ``room``: entries the output arrays hold (default: the list's length) -- n_out may come
+    back LARGER: the entries beyond ``room`` were counted, not stored (a list sized for the worst case need not be mirrored by
+    outputs of that size; the caller repeats the call with more room in the rare case)."""
     dev = _need_gpu(keys, vals)
     _chk(keys, torch.int64, "keys"); _chk(vals, torch.float32, "vals")
     n = vals.numel()
@@ -792,13 +866,14 @@ def select_compact(keys: Optional[torch.Tensor], vals: torch.Tensor, k: int, cou
     if compact:
         if keys is None:
             raise _lib.EpsError("select_compact: the compaction needs keys")
-        out_k = torch.empty(n, dtype=torch.int64, device=dev)
-        out_v = torch.empty(n, dtype=torch.float32, device=dev)
+        room = n if room is None else max(1, min(int(room), n))
+        out_k = torch.empty(room, dtype=torch.int64, device=dev)
+        out_v = torch.empty(room, dtype=torch.float32, device=dev)
         n_out = torch.empty(1, dtype=torch.int64, device=dev)
     with torch.cuda.device(dev):
         _lib.check(lib.eps_select_compact(_ptr(keys), _ptr(vals), n, count_ptr, int(k), int(mode), float(params[0]), float(params[1]),
-                                          float(params[2]), kth.data_ptr(), kth.data_ptr() + 4, _ptr(out_k), _ptr(out_v), _ptr(n_out),
-                                          _ptr(state), _stream(dev)), "eps_select_compact")
+                                          float(params[2]), kth.data_ptr(), kth.data_ptr() + 4, _ptr(out_k), _ptr(out_v),
+                                          0 if room is None else int(room), _ptr(n_out), _ptr(state), _stream(dev)), "eps_select_compact")
     return out_k, out_v, n_out, kth[0:1], kth[1:2]
 
 

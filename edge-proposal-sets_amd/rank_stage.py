@@ -108,6 +108,8 @@ def run(args):
     if not torch.cuda.is_available():
         raise RuntimeError("rank stage needs a HIP device: the scoring path has no CPU fallback")
     device = torch.device(f'cuda:{args.device}')
+    from . import _lib
+    _lib.warm_up_async(device)           # (code objects load in the background while the dataset is read on the host)
     Path("curves").mkdir(exist_ok=True)
     Path("models").mkdir(exist_ok=True)
     assert not (args.only_supervision and args.also_supervision)

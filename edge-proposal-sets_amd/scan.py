@@ -80,19 +80,33 @@ def values_symmetric(g: CSRGraph) -> bool:
 
 
 def reverse_positions(g: CSRGraph) -> torch.Tensor:
-    """revpos of the graph (cached); the same kernel pass leaves the half-path counts and the symmetry flag in the cache."""
+    """revpos of the graph (cached); the same pass leaves the half-path counts and the symmetry verdict in the cache.
+    Built by the symmetric-pattern kernel (one search per unordered stored pair: 4.9 -> ~1.7 ms on the ppa-like graph); a
+    pattern that turns out NOT to be symmetric gets the general table (eps_reverse_positions) -- the scan refuses it anyway."""
     if "revpos" not in g._cache:
-        rev, hp, flag = ops.reverse_positions(g.rowptr, g.col, with_stats=True)
-        g._cache["revpos"], g._cache["half_paths"], g._cache["asymmetric_flag"] = rev, hp, flag
+        rev, hp, info = ops.reverse_positions_symmetric(g.rowptr, g.col)
+        # one host read for the verdict AND the graph's scalars the scan asks for later (each used to be a read of its own)
+        flag_h, max_deg, max_half, total = info.tolist()
+        sym = (flag_h & 0xFFFFFFFF) == 0
+        if not sym:
+            rev, hp, _ = ops.reverse_positions(g.rowptr, g.col, with_stats=True)
+        else:
+            g._cache.setdefault("max_degree", int(max_deg))
+            g._cache.setdefault("max_half", int(max_half))
+            g._cache.setdefault("total_half", int(total))
+        g._cache["revpos"], g._cache["half_paths"], g._cache["symmetric"] = rev, hp, sym
     return g._cache["revpos"]
 
 
 def is_symmetric(g: CSRGraph) -> bool:
     """Whether the stored pattern is symmetric (cached): every entry (v, w) finds v at its position in row w (checked by the
-    reverse-positions pass itself)."""
+    reverse-positions pass itself).  A relabelled copy answers for its original (symmetry does not depend on the labels), so a
+    graph that is scanned under hubs-first labels pays for ONE reverse-positions table, the copy's."""
     if "symmetric" not in g._cache:
-        reverse_positions(g)
-        g._cache["symmetric"] = int(g._cache["asymmetric_flag"].item()) == 0
+        if "deg_order" in g._cache and g._cache["deg_order"][0] is not g:
+            g._cache["symmetric"] = is_symmetric(g._cache["deg_order"][0])
+        else:
+            reverse_positions(g)
     return g._cache["symmetric"]
 
 
@@ -106,7 +120,9 @@ def half_paths(g: CSRGraph) -> torch.Tensor:
 def column_order(g: CSRGraph) -> torch.Tensor:
     """int32[N]: all columns, heaviest first (a hub column is one workgroup's work for a long time: it must not start last)."""
     if "scan_order" not in g._cache:
-        g._cache["scan_order"] = torch.argsort(half_paths(g), descending=True, stable=True).to(torch.int32)
+        hp = half_paths(g)
+        g._cache["scan_order"] = (ops.node_order(keys=hp) if hp.is_cuda and hp.numel() else
+                                  torch.argsort(hp, descending=True, stable=True).to(torch.int32))
     return g._cache["scan_order"]
 
 
@@ -116,6 +132,15 @@ def window_splits(g: CSRGraph):
         win_ids, n_win = ops.filter_scan_windows(g.n_rows)
         g._cache["scan_splits"] = ops.row_window_splits(g.rowptr, g.col, win_ids, n_win)
     return g._cache["scan_splits"]
+
+
+def max_half_paths(g: CSRGraph) -> int:
+    """Two-hop half paths of the graph's heaviest column (cached host number; the reverse-positions pass leaves it)."""
+    if "max_half" not in g._cache:
+        hp = half_paths(g)
+        if "max_half" not in g._cache:
+            g._cache["max_half"] = int(hp.max().item()) if g.n_rows else 0
+    return g._cache["max_half"]
 
 
 def max_degree(g: CSRGraph) -> int:
@@ -265,22 +290,29 @@ def screen_weights(g0: CSRGraph, g: CSRGraph, perm, node_w: torch.Tensor) -> Scr
             return Screen(None, shift, None, g.val, nw, fits and bool((nw >= 0).all().item()))
         fixw = _scan_weights(g0, g, perm, node_w)
         fx32, bad = ops.scan_screen_weights(fixw, shift)
-        usable = fits and int(bad.item()) == 0
-        ssum, smax, min_fx = _sum_bounds(g, fx32) if usable and PACKED_PIECES and one_pass_available(g) else (None, None, None)
-        plan, d_used, w_min = None, 0, 0.0
-        if ssum is not None:
-            d_used = max(0, min(24, shift - 8))                              # the launch's limit (csrc/scan_pieces.hip: packed_dmax)
-        if usable and PLAN_TABLE and one_pass_available(g):
+        # Everything is launched before anything is read back: the verdict on the weights (`bad`), the bits the plan drops and the
+        # smallest weight come back in ONE host read at the end (tables built from unusable weights are simply not used).
+        one_pass = fits and one_pass_available(g)
+        ssum, smax, min_fx = _sum_bounds(g, fx32) if one_pass and PACKED_PIECES else (None, None, None)
+        plan, d_word = None, None
+        if one_pass and PLAN_TABLE:
             # every column's pieces, planned once per (graph, weight table): a launch reads them instead of planning (5 %)
             bounds, cuts = screen_tables(g)
             pptr, recs, d_word = ops.scan_plan(g.rowptr, cuts, window_paths(g), ssum, smax, bounds, g.n_rows, shift, screen_variant(g),
                                                with_d=True)
             plan = (pptr, recs)
-            if ssum is not None:
-                d_used = int(d_word.item())                                  # what the plan really uses
-        if min_fx is not None:
+        zero = torch.zeros(1, dtype=torch.int32, device=g.device)
+        bad_h, d_h, min_h = torch.cat([bad.view(torch.int32), d_word if d_word is not None else zero,
+                                       min_fx if min_fx is not None else zero - 1]).tolist()
+        usable = fits and bad_h == 0
+        if not usable:
+            ssum = smax = plan = None
+        d_used, w_min = 0, 0.0
+        if ssum is not None:
+            # the launch's limit (csrc/scan_pieces.hip: packed_dmax), or what the plan really uses
+            d_used = d_h if plan is not None else max(0, min(24, shift - 8))
             # fx32 rounds the exact weight x 2^shift UP: one unit less is a floor under every common neighbour's exact weight
-            lowest = int(min_fx.item()) & 0xFFFFFFFF
+            lowest = min_h & 0xFFFFFFFF
             w_min = 0.0 if lowest == 0xFFFFFFFF else max(0, lowest - 1) * 2.0 ** -shift
         return Screen(fx32, shift, fixw, None, None, usable, ssum, smax, plan, d_used, w_min)
     # (one entry per labelling: the tables are indexed by the SCANNED graph's node ids)
@@ -315,7 +347,7 @@ def screen_variant(g: CSRGraph):
         if ONE_PASS and 0 < max_degree(g) < 1 << 16 and g.n_rows:
             # (no column heavier than M two-word hash pieces: nothing can need a partitioned pass -- the usual case, decided
             #  without planning the graph three times)
-            if int(half_paths(g).max().item()) <= 2048 * ops.scan_windows():
+            if max_half_paths(g) <= 2048 * ops.scan_windows():
                 v = 2
             else:
                 for variant in (2, 0, 1):
@@ -550,6 +582,8 @@ def scan_topk(g: CSRGraph, node_w: torch.Tensor, k: int, rank: int = 0, world: i
     ceil(k/2)-th best survivor score (device, ops.kth_largest_dist) -> compaction of the survivors at or above it -> ONE host
     read (slot counter, candidate count, selected count, cut; all-gathered when world > 1) -> the selected pairs of all ranks
     (about k / 2 / world each) gathered -> mirrored + ordered (ops.select_rows)."""
+    if relabel and g.device.type == "cuda" and g.n_rows == g.n_cols:
+        scan_graph(g, build=True)        # (first: the symmetry check below then reads the copy's table, the one the scan needs)
     if not scan_available(g):
         raise ops._lib.EpsError("scan_topk: graph not supported by eps_filter_scan (see scan_available)")
     k = int(k)
@@ -605,8 +639,15 @@ def scan_topk(g: CSRGraph, node_w: torch.Tensor, k: int, rank: int = 0, world: i
             # list's unused capacity).
             a, b = screen.lower_params(max_degree(g))
             k_pre = 0 if rescore_all else (k2 + world - 1) // world
-            c_keys, _, n_valid, _, pre_thr = ops.select_compact(l_keys, l_vals, k_pre, res.count_ptr, mode=2, params=(a, b, 4e-6))
+            # (the outputs hold 2 x k_pre pairs -- lower() keeps ~10 % more than k_pre -- not a copy of the list's worst-case size;
+            #  a level of tied scores at the threshold may hold more: then the call is repeated with room for all of them)
+            room = res.capacity if rescore_all else min(res.capacity, 2 * k_pre + (1 << 16))
+            c_keys, _, n_valid, _, pre_thr = ops.select_compact(l_keys, l_vals, k_pre, res.count_ptr, mode=2, params=(a, b, 4e-6), room=room)
             nv = int(n_valid.item())                                                      # (one word: sizes the re-scoring)
+            if nv > room:
+                c_keys, _, n_valid, _, pre_thr = ops.select_compact(l_keys, l_vals, k_pre, res.count_ptr, mode=2, params=(a, b, 4e-6),
+                                                                    room=min(res.capacity, nv))
+                nv = int(n_valid.item())
             l_keys, l_vals = rescore_exact(g, screen, c_keys[:nv], bar)
             status = res.status
         # the job-wide cut: the k2-th best survivor score over all ranks (-inf when fewer survived); untouched slots are -inf

@@ -41,6 +41,11 @@ extern "C" {
 int eps_version(void);
 const char *eps_last_error(void);
 
+/* eps_warm_up: load every code object of the library now (one empty kernel per translation unit on a private stream, waited
+ * for) instead of at the first use of each -- a fresh process pays 10-30 ms per larger unit, and filter.py is one process per
+ * graph (submit_job.py:20-21).  Thread-safe; meant for a background thread at start-up.  Blocking. */
+int eps_warm_up(void);
+
 /* Number of compute units / name of the current device (host query; for launch sizing
  * reports in bench.py).  name may be NULL. */
 int eps_device_info(int *n_cu, char *name, int name_len);
@@ -194,6 +199,36 @@ int eps_row_window_splits(const int64_t *rowptr, const int32_t *col, int64_t n_n
                           int64_t n_win, int32_t *splits, void *stream);
 int eps_reverse_positions(const int64_t *rowptr, const int32_t *col, int64_t n_nodes, int32_t *revpos,
                           int64_t *half_paths_or_null, uint32_t *asymmetric_or_null, void *stream);
+/* ---- per-graph tables built by the library (r04; csrc/graph_prep.hip): filter.py runs once per graph (submit_job.py:20-21), so
+ * these are on the critical path of every run --------------------------------------------------------------------------------
+ * eps_relabel_graph: the copy of a coalesced CSR graph under a node permutation -- row i of the copy = row perm[i] of the graph
+ *   with every id x replaced by inv[x] (inv[perm[i]] = i, int32), rows sorted ascending again (a segmented radix sort over the
+ *   id_bits bits of the ids; values travel with their entries).  new_rowptr = the caller's prefix sum of the degrees in perm
+ *   order (int64[n_nodes + 1]).  workspace: eps_relabel_graph_workspace_bytes(n_nodes, nnz, with_values) bytes, 256-byte aligned.
+ * eps_reverse_positions_symmetric: what eps_reverse_positions reports (revpos, half_paths = its row sums, *asymmetric) for a
+ *   SYMMETRIC pattern with half the searches: entry (v, w), w > v, looks v up in row w and writes both its own position and --
+ *   at the place it found v -- its mirror's.  On any other pattern *asymmetric comes back 1 and revpos is not usable.
+ *   stats (optional, 3 DEVICE uint64): largest degree, largest half_paths[v], sum of half_paths -- the scalars the scan reads.
+ * eps_score_bound: *bound (DEVICE double) = max over rows v of sum_w |A[v,w]| |node_w[w]| max_u |A[u,w]| in float64 (without
+ *   stored values: sum of |node_w| over the row; node_w NULL: the degree) -- an upper bound of every fused score of the graph.
+ *   workspace: n_cols uint32 with stored values, else may be NULL. */
+int64_t eps_relabel_graph_workspace_bytes(int64_t n_nodes, int64_t nnz, int32_t with_values);
+int eps_relabel_graph(const int64_t *rowptr, const int32_t *col, const float *val_or_null, const int64_t *perm, const int32_t *inv,
+                      const int64_t *new_rowptr, int64_t n_nodes, int64_t nnz, int32_t id_bits, int32_t *out_col,
+                      float *out_val_or_null, void *workspace, int64_t workspace_bytes, void *stream);
+int eps_reverse_positions_symmetric(const int64_t *rowptr, const int32_t *col, int64_t n_nodes, int64_t nnz, int32_t *revpos,
+                                    int64_t *half_paths, uint32_t *asymmetric, unsigned long long *stats_or_null, void *stream);
+/* eps_node_order: order[i] (int32) = the node with the i-th largest key, ties by ascending id (a stable descending radix sort)
+ * -- keys = the degrees (rowptr given: the hubs-first labels) or keys[] (int64, non-negative: the scan's heaviest-first column
+ * order from the half paths).  Optional by-products for eps_relabel_graph: perm64[i] = order[i], inv32[order[i]] = i,
+ * new_rowptr[0 .. n] = exclusive prefix of the keys in that order.  workspace: eps_node_order_workspace_bytes(n) bytes, 256-byte
+ * aligned. */
+int64_t eps_node_order_workspace_bytes(int64_t n);
+int eps_node_order(const int64_t *rowptr_or_null, const int64_t *keys_or_null, int64_t n, int32_t *order_or_null,
+                   int64_t *perm64_or_null, int32_t *inv32_or_null, int64_t *new_rowptr_or_null, void *workspace,
+                   int64_t workspace_bytes, void *stream);
+int eps_score_bound(const int64_t *rowptr, const int32_t *col, const float *val_or_null, const float *node_w_or_null,
+                    int64_t n_rows, int64_t n_cols, int64_t nnz, double *bound, void *workspace, void *stream);
 int eps_fixed_weights(const float *node_w, int64_t n, int64_t *fixw, void *stream);
 int eps_filter_scan(const int64_t *rowptr, const int32_t *col, const int32_t *revpos, const int64_t *fixw,
                     const int32_t *splits_or_null, int64_t n_nodes, int64_t nnz, int64_t max_degree,
@@ -377,13 +412,14 @@ int eps_kth_largest_f32(const float *x, int64_t n, int64_t k, float *kth, void *
  *   *thr = mode 0: kth; mode 1: the largest float below kth (an inclusive bar for a scan that keeps scores above its
  *          threshold); mode 2: max(kth - pa, kth * pb) - |kth| * pc (a lower bound of the exact score behind a screening
  *          score: eps_amd.scan.Screen.lower_bound);
- *   out_keys / out_vals (n_max entries each; both NULL: selection only) receive the entries with key >= 0 and value >= *thr in
- *   arbitrary order, *n_out (DEVICE int64) their number.  state: eps_select_compact_workspace_bytes() bytes, 8-byte aligned.
+ *   out_keys / out_vals (out_cap entries each; both NULL: selection only) receive the entries with key >= 0 and value >= *thr in
+ *   arbitrary order, *n_out (DEVICE int64) their number -- entries beyond out_cap are counted, not stored.  state: eps_select_compact_workspace_bytes() bytes, 8-byte aligned.
  * Single device; the sharded job-wide select stays eps_kth_begin / _hist_f32 / _pick with one all-reduce per round. */
 int64_t eps_select_compact_workspace_bytes(void);
 int eps_select_compact(const int64_t *keys_or_null, const float *vals, int64_t n_max, const unsigned long long *n_dev_or_null,
                        int64_t k, int32_t mode, float pa, float pb, float pc, float *kth_or_null, float *thr_or_null,
-                       int64_t *out_keys_or_null, float *out_vals_or_null, int64_t *n_out_or_null, void *state, void *stream);
+                       int64_t *out_keys_or_null, float *out_vals_or_null, int64_t out_cap, int64_t *n_out_or_null, void *state,
+                       void *stream);
 int eps_kth_begin(void *state, int64_t k, void *stream);
 int eps_kth_hist_f32(const float *x, int64_t n, void *state, int32_t shift, void *stream);
 int eps_kth_pick(void *state, int32_t shift, float *out_or_null, void *stream);

@@ -1,0 +1,102 @@
+"""GPU parity of the per-graph table builders of csrc/graph_prep.hip (r04) against the tensor-op / general-kernel paths they
+replace: the hubs-first relabelled copy (rank.py / filter.py never relabel -- this is the engine's own layout, so the check is
+that the copy IS the same graph), the reverse positions of a symmetric pattern, the score bound."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("valued", [False, True])
+@pytest.mark.parametrize("scale,ef,seed", [(10, 8, 1), (13, 12, 4), (8, 40, 9)])
+def test_relabel_graph_is_the_same_graph(eps, dev, valued, scale, ef, seed):
+    from eps_amd import synth
+    from eps_amd.graph import CSRGraph, _coalesce
+    g = synth.rmat_graph(scale, ef, seed, dev)
+    if valued:
+        gen = torch.Generator(device=dev).manual_seed(seed)
+        g = CSRGraph(g.rowptr, g.col, torch.rand(g.nnz(), generator=gen, device=dev) + 0.5, g.n_rows, g.n_cols)
+    gs, perm, inv = g.degree_ordered()
+    # the tensor-op construction (a global sort of all stored entries)
+    row, col, val = g.coo()
+    rp, c, v = _coalesce(inv[row], inv[col], g.values_or_ones() if val is not None else None, g.n_rows, g.n_cols)
+    assert torch.equal(gs.rowptr, rp) and torch.equal(gs.col, c)
+    assert (gs.val is None) == (v is None) and (v is None or torch.equal(gs.val, v))
+    deg = gs.degree()
+    assert bool((deg[:-1] >= deg[1:]).all()) and torch.equal(inv[perm], torch.arange(g.n_rows, device=dev))
+    # rows ascend strictly (coalesced), and mapping back gives the original rows
+    i = int(perm[5])
+    back = torch.sort(perm[gs.col[gs.rowptr[5]:gs.rowptr[6]].long()]).values
+    assert torch.equal(back, g.col[g.rowptr[i]:g.rowptr[i + 1]].long())
+
+
+@pytest.mark.parametrize("scale,ef,seed", [(10, 8, 1), (13, 12, 4), (8, 40, 9)])
+def test_reverse_positions_symmetric_vs_general(eps, dev, scale, ef, seed):
+    from eps_amd import synth
+    from eps_amd.graph import CSRGraph
+    g = synth.rmat_graph(scale, ef, seed, dev)
+    r0, h0, f0 = eps.ops.reverse_positions(g.rowptr, g.col, with_stats=True)
+    r1, h1, f1 = eps.ops.reverse_positions_symmetric(g.rowptr, g.col)
+    assert int(f0) == 0 and int(f1[0]) & 0xFFFFFFFF == 0 and torch.equal(r0, r1) and torch.equal(h0, h1)
+    assert f1[1:].tolist() == [int(g.degree().max()), int(h0.max()), int(h0.sum())]
+    # diagonal entries are their own mirrors
+    gd = g.with_self_loops(1.0)
+    gd = CSRGraph(gd.rowptr, gd.col, None, gd.n_rows, gd.n_cols)
+    r0, h0, f0 = eps.ops.reverse_positions(gd.rowptr, gd.col, with_stats=True)
+    r1, h1, f1 = eps.ops.reverse_positions_symmetric(gd.rowptr, gd.col)
+    assert int(f0) == 0 and int(f1[0]) & 0xFFFFFFFF == 0 and torch.equal(r0, r1) and torch.equal(h0, h1)
+    # an asymmetric pattern is reported, whichever half the odd entry is in
+    for drop_upper in (True, False):
+        row, col, _ = g.coo()
+        pick = torch.nonzero(row < col if drop_upper else row > col)[7]
+        keep = torch.ones(row.numel(), dtype=torch.bool, device=dev)
+        keep[pick] = False
+        ga = CSRGraph.from_edge_index(torch.stack([row[keep], col[keep]]), None, sparse_sizes=(g.n_rows, g.n_cols))
+        _, _, fa = eps.ops.reverse_positions_symmetric(ga.rowptr, ga.col)
+        assert int(fa[0]) & 0xFFFFFFFF == 1
+        from eps_amd import scan
+        assert not scan.is_symmetric(ga)
+        assert torch.equal(scan.reverse_positions(ga), eps.ops.reverse_positions(ga.rowptr, ga.col))
+
+
+@pytest.mark.parametrize("valued", [False, True])
+def test_score_bound_vs_tensor_ops(eps, dev, valued):
+    from eps_amd import candidates, synth
+    from eps_amd.graph import CSRGraph
+    from eps_amd.heuristics import node_weight_table
+    g = synth.rmat_graph(12, 10, 3, dev)
+    if valued:
+        gen = torch.Generator(device=dev).manual_seed(5)
+        vals = torch.rand(g.nnz(), generator=gen, device=dev) * 9 + 0.1
+        row, col, _ = g.coo()
+        key_lo, key_hi = torch.minimum(row, col), torch.maximum(row, col)
+        vals = (torch.sin((key_lo * 7919 + key_hi).double()).abs() * 9 + 0.1).float()      # symmetric values
+        g = CSRGraph(g.rowptr, g.col, vals, g.n_rows, g.n_cols)
+    w = node_weight_table(g, eps.ops.W_AA)
+    got = candidates.fused_score_bound(g, w)
+    colidx = g.col.long()
+    term = w[colidx].abs().double()
+    if valued:
+        colmax = torch.zeros(g.n_cols, device=dev).scatter_reduce_(0, colidx, g.val.abs(), reduce="amax", include_self=True)
+        term = term * g.val.abs().double() * colmax[colidx].double()
+    rows = torch.zeros(g.n_rows, dtype=torch.float64, device=dev).index_add_(0, g.row_index(), term)
+    want = float(rows.max())
+    assert want <= got <= want * (1 + 1e-6) + 1e-9
+    # no weights: the largest degree (x the values)
+    got0 = candidates.fused_score_bound(g, None)
+    if not valued:
+        assert got0 == pytest.approx(float(g.degree().max()), rel=1e-8)
+
+
+def test_node_order_is_the_stable_descending_argsort(eps, dev):
+    from eps_amd import scan, synth
+    g = synth.rmat_graph(13, 12, 4, dev)
+    deg = g.degree()
+    want = torch.argsort(deg, descending=True, stable=True)
+    assert torch.equal(eps.ops.node_order(rowptr=g.rowptr).long(), want)
+    perm, inv, rp = eps.ops.node_order(rowptr=g.rowptr, relabel=True)
+    assert torch.equal(perm, want) and torch.equal(inv.long()[want], torch.arange(g.n_rows, device=dev))
+    assert int(rp[0]) == 0 and torch.equal(rp[1:], torch.cumsum(deg[want], 0))
+    hp = scan.half_paths(g)                      # heavy ties at 0 and large values
+    assert torch.equal(eps.ops.node_order(keys=hp).long(), torch.argsort(hp, descending=True, stable=True))

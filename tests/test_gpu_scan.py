@@ -535,6 +535,11 @@ def test_select_compact_one_launch(eps, dev, n, k):
         assert torch.equal(got, torch.sort(live_k[keep]).values)
         o1, o2 = torch.argsort(ok[:m]), torch.argsort(live_k[keep])
         assert torch.equal(ov[:m][o1], live_v[keep][o2]) or live_k[keep].unique().numel() != m     # (duplicate random keys: order free)
+    # outputs smaller than the selection: everything is counted, the first `room` entries are stored
+    if int(keep.sum()) > 10:
+        ok, ov, n_out, _, thr2 = eps.ops.select_compact(keys, vals, k, count.data_ptr(), mode=2, params=(3.5, 0.9, 4e-6), room=10)
+        assert int(n_out) == int(keep.sum()) and ok.numel() == 10 and float(thr2) == float(thr)
+        assert bool(torch.isin(ok, live_k[keep]).all())
     # selection only, scores alone (the bar estimate's call)
     _, _, _, kth, thr = eps.ops.select_compact(None, vals, k, count.data_ptr(), mode=1, compact=False)
     assert float(kth) == want_kth
