@@ -10,20 +10,25 @@ Workload (synthetic, seeded; no dataset / network exists on either box)
           unit weights; replicated on every GPU (0.35 GB + 0.7 GB of per-graph tables).
   step  : the PRODUCTION filter pass over the FULL candidate set of that graph -- what
           `filter.py --dataset ppa --model adamic_ogb --keep_top 4000000` runs between loading the graph and writing
-          the proposal file: every 2-hop non-edge (filter.py:96-109; 12.7 G directed candidates) gets its
-          Adamic-Adar score (adamic_utils.py:13-25) and the 4,000,000 best rows under the declared order
-          (filter.py:160-161) come out, on the device.  One step = scan.scan_topk: bar estimate from a column sample,
-          ONE eps_filter_scan launch over all columns, verification, selection.
+          the proposal file: every 2-hop non-edge (filter.py:96-109; 12.7 G directed candidates) is scored by
+          Adamic-Adar (adamic_utils.py:13-25) and the 4,000,000 best rows under the declared order (filter.py:160-161)
+          come out, on the device.  One step = scan.scan_topk: bar estimate from a column sample (one small launch of the
+          scan kernel + a select), ONE eps_scan_screen launch over all columns (csrc/scan_pieces.hip: every candidate's
+          sum is formed in an LDS table as a 15 / 31-bit SCREENING upper bound), exact 2^-40 fixed-point re-scoring of
+          the survivors that can reach the top-K (eps_rescore_runs), verification, selection and ordering of the K rows.
   value : directed candidates scored per second, whole job (the kernel's own candidate count, both orientations of
           each pair; each unordered pair is computed once -- the score is symmetric).
-  N > 1 : "weak" (default): every rank runs the full single-GPU workload on its own replica (per-GPU work fixed);
-          "strong" (--scaling strong): the columns of ONE graph are dealt round-robin over the ranks in heaviest-first
-          order, survivors are all-gathered and every rank selects the same top-K -- the north-star target
-          ("sharded candidate set").
-Reported next to it: the roofline of the dominant kernel (filter_scan_kernel; HIP events on its stream), secondary
-legs for the other hot-path kernels (pair intersection, SpMM, GEMM, decode) with their SURVEY 8(d) rooflines, and the
-reference's CPU path (SciPy mirror of adamic_utils.AA) timed on a bounded sample of the same candidates -- one
-thread like the reference, and split over all host cores.
+  N > 1 : "strong" (default): the columns of ONE graph are dealt round-robin over the ranks in heaviest-first order; every
+          rank scans, re-scores and selects its own share, ONE all-reduce (the bar) + one job-wide radix select (the cut) +
+          one all-gather of the selected pairs are the collectives, and the final ordering is dealt over the ranks by score
+          range -- the north-star target ("sharded candidate set").  "weak" (--scaling weak): every rank runs the full
+          single-GPU workload on its own replica (per-GPU work fixed).
+Reported next to it: the roofline of the dominant kernel (scan_piece_kernel<256,false,true>; HIP events on its stream), what
+the step spends outside it (`serial_ms`; for N > 1 `replicated_ms`: everything that does not shrink with N), a sustained run
+of >= 5 s, secondary legs for the other hot-path kernels (pair intersection, SpMM, GEMM, decode) and one leg per BASELINE
+config (bench_configs.py) with their SURVEY 8(d) rooflines, and the reference's CPU path (SciPy mirror of adamic_utils.AA)
+timed on a bounded sample of the same candidates -- one thread like the reference, and split over all host cores.
+A rank that fails still prints ONE JSON line (with "error") and exits non-zero.
 """
 import argparse
 import json
@@ -274,6 +279,47 @@ def hits_at_100_parity(torch, g, orc):
                      "random pairs, AA on the remaining graph (seed 7)"}
 
 
+class _ClockSampler:
+    """Best-effort shader-clock samples while a loop runs: `rocm-smi --showclocks --json` as a CHILD process every 0.5 s from a
+    thread (never an exec of this process; returns None when the tool is missing or prints something else)."""
+
+    def __init__(self):
+        import threading
+        self.samples, self._stop = [], threading.Event()
+        self._t = threading.Thread(target=self._run, daemon=True)
+
+    def _once(self):
+        import re
+        import subprocess
+        try:
+            out = subprocess.run(["rocm-smi", "--showclocks", "--json"], capture_output=True, text=True, timeout=5).stdout
+            card = next(iter(json.loads(out).values()))
+            for k, v in card.items():
+                if "sclk" in k.lower():
+                    m = re.search(r"(\d+)\s*Mhz", str(v), re.I)
+                    if m:
+                        return int(m.group(1))
+        except Exception:      # noqa: BLE001
+            return None
+        return None
+
+    def _run(self):
+        while not self._stop.is_set():
+            v = self._once()
+            if v:
+                self.samples.append(v)
+            self._stop.wait(0.5)
+
+    def __enter__(self):
+        self._t.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._stop.set()
+        self._t.join(timeout=10)
+        return False
+
+
 # ------------------------------------------------------------------------------------------------ main
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
@@ -289,6 +335,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-config-legs", action="store_true", help="skip the per-config end-to-end legs (bench_configs.py)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (tests on a 1-GPU box: gloo)")
     ap.add_argument("--one-device", action="store_true", help="every rank on cuda:0 (tests on a 1-GPU box, with --backend gloo)")
+    ap.add_argument("--sustain", type=float, default=5.0, help="seconds of the extra sustained loop (0: skip)")
     ap.add_argument("--nodes", type=int, default=576_289, help="graph size (tests use a small one)")
     ap.add_argument("--edges", type=int, default=21_231_931)
     return ap.parse_args(argv)
@@ -315,6 +362,23 @@ def main():
     args = parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(launch_ranks(args))
+    try:
+        run(args)
+    except SystemExit:
+        raise
+    except BaseException as exc:       # noqa: BLE001  a failing rank still leaves ONE parseable line, then a non-zero exit
+        import traceback
+        tb = traceback.format_exc()
+        sys.stderr.write(tb)
+        print(json.dumps({"metric": "candidate edges scored/sec on ogbl-ppa (ppa-like synthetic)", "value": None, "unit": "edges/s",
+                          "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True,
+                          "error": f"{type(exc).__name__}: {exc}", "rank": int(os.environ.get("RANK", "0")),
+                          "traceback_tail": tb.strip().splitlines()[-6:]}), flush=True)
+        # (no re-exec, no clean-up collectives: the other ranks are torn down by the launcher when this one exits non-zero)
+        os._exit(1)
+
+
+def run(args):
 
     import torch
     import torch.distributed as dist
@@ -415,16 +479,22 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
     half = g.n_rows // (2 * sworld)
-    kernel_name = sorted({name for name, a, b, ncol in events if ncol > half})
+    scans = [e for e in events if e[0] in ("scan_piece_kernel", "filter_scan_kernel")]
+    kernel_name = sorted({name for name, a, b, ncol in scans if ncol > half})
     kernel_name = kernel_name[0] if len(kernel_name) == 1 else "+".join(kernel_name)
-    main_ms = [a.elapsed_time(b) for name, a, b, ncol in events if ncol > half]
-    samp_ms = [a.elapsed_time(b) for name, a, b, ncol in events if ncol <= half]
+    main_ms = [a.elapsed_time(b) for name, a, b, ncol in scans if ncol > half]
+    samp_ms = [a.elapsed_time(b) for name, a, b, ncol in scans if ncol <= half]
     kern_ms = sum(main_ms) / max(1, len(main_ms))
     samp = sum(samp_ms) / max(1, len(samp_ms))
-    per_rank = [[kern_ms, samp]]
+    # what a rank does on ITS share (shrinks with N): both scan launches, the local selects, the sort + exact re-scoring of its survivors
+    per_step = {}
+    for name, a, b, _ in events:
+        per_step[name] = per_step.get(name, 0.0) + a.elapsed_time(b) / args.steps
+    sharded_ms = sum(per_step.values())
+    per_rank = [[kern_ms, samp, sharded_ms]]
     if world > 1:
         from eps_amd import dist as epd
-        per_rank = torch.stack(epd.all_gather_list(torch.tensor([kern_ms, samp], device=dev, dtype=torch.float64))).tolist()
+        per_rank = torch.stack(epd.all_gather_list(torch.tensor([kern_ms, samp, sharded_ms], device=dev, dtype=torch.float64))).tolist()
     n_cand = stats["candidates"]                   # directed candidates of the graph (kernel-counted)
     job_cand = n_cand if strong or world == 1 else n_cand * world
     bar = None if stats["bar"] is None else float(stats["bar"])
@@ -444,6 +514,27 @@ def main():
         tw = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
         dist.all_reduce(tw, op=dist.ReduceOp.MAX)
         weak_value = n_cand * world * wsteps / tw.item()
+
+    # the same step over >= `--sustain` seconds (the timed region above is 20 steps = 0.5 s in a driver run): clocks settle, the
+    # figure is what a long job sees
+    sustained = None
+    if args.sustain > 0:
+        est = max(dt / args.steps, 1e-4)
+        n_sus = max(args.steps, int(args.sustain / est) + 1)
+        barrier()
+        with _ClockSampler() as clk:
+            t0 = time.perf_counter()
+            for _ in range(n_sus):
+                step()
+            barrier()
+            ts = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([ts], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            ts = tt.item()
+        sustained = {"steps": n_sus, "seconds": ts, "ms_per_step": ts / n_sus * 1e3, "value": job_cand * n_sus / ts,
+                     "sclk_mhz_mean": (sum(clk.samples) / len(clk.samples)) if clk.samples else None,
+                     "sclk_mhz_min": min(clk.samples) if clk.samples else None, "sclk_samples": len(clk.samples)}
 
     line = None
     if rank == 0:
@@ -476,6 +567,10 @@ def main():
             "prep_ms": prep_ms, "cold_ms_per_step": cold_ms,
             "kernel_ms_per_rank": [r[0] for r in per_rank], "sample_ms_per_rank": [r[1] for r in per_rank],
             "serial_ms": ms_step - kmax - max(r[1] for r in per_rank),
+            "sharded_ms_per_rank": [r[2] for r in per_rank],
+            "replicated_ms": ms_step - max(r[2] for r in per_rank),
+            "step_breakdown_ms": per_step,
+            "sustained": sustained,
             "config": {"workload": "configs[2] ppa-like S3, full candidate set: N=%d, nnz=%d, %d directed 2-hop non-edge "
                                    "candidates per graph, filter.py --model adamic_ogb --keep_top %d (scan.scan_topk)"
                                    % (g.n_rows, g.nnz(), n_cand, args.keep_top),
@@ -485,7 +580,23 @@ def main():
                        "keep_top": args.keep_top, "bar": bar, "survivors": stats["survivors"],
                        "launches_per_step": stats["launches"], "graph_replicated": True, "device": dev_name, "n_cu": n_cu,
                        "notes": {"value": "DIRECTED candidates (both rows of the proposal file carry the score); each unordered "
-                                          "pair is computed once: value_unordered_pairs_per_s",
+                                          "pair is computed once: value_unordered_pairs_per_s.  'Scored' means: every candidate's sum "
+                                          "over its common neighbours is accumulated -- SCREENED with >= upper bounds at 15 / 31 bits "
+                                          "(weights rounded up to 2^-shift) -- and the survivors that can reach the top-K get their "
+                                          "EXACT 2^-40 fixed-point score (eps_rescore_runs); the K rows are identical to the exact "
+                                          "scan's (eps_filter_scan: tests, profiles/r03/two_kernels_same_list.txt).  The literal "
+                                          "filter.py:113-165 -- every candidate's exact score written out -- is the leg "
+                                          "full_list_every_candidate_scored",
+                                 "data": "synthetic stand-in (seeded R-MAT of ogbl-ppa's size): no dataset exists on the build or the GPU "
+                                         "box, so Hits@100 parity is shown on a held-out split of the stand-in (cpu_baseline.hits_at_100) "
+                                         "and the published 53.24 (README.md:11-17) is reachable only through the $EPS_DATA_ROOT/ppa.pt "
+                                         "hook (legs.real_ppa)",
+                                 "replicated_ms": "ms_per_step minus the slowest rank's sharded work (both scan launches, its local "
+                                                  "selects, the sort and exact re-scoring of its survivors -- HIP events, step_breakdown_ms): "
+                                                  "collectives, host reads, the gathered selection and this rank's range of the final "
+                                                  "ordering -- what does not shrink with N",
+                                 "sustained": "the same step repeated for >= --sustain seconds after the timed region; sclk from rocm-smi "
+                                              "samples taken by a child process during the loop (null when the tool is unavailable)",
                                  "prep_ms": "hubs-first relabelled copy + revpos / half paths / column order / fixed-point "
                                             "weights / window tables / sum bounds / plan table / sample, built once per graph, "
                                             "OUTSIDE the timed region (timed on a fresh graph object after the loop: allocator warm)",

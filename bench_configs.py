@@ -39,6 +39,70 @@ def _sync(torch):
     torch.cuda.synchronize()
 
 
+def _gpu_ms(torch, fn, reps=1):
+    """Mean HIP-event milliseconds of ``fn`` on the current stream (one warm call first)."""
+    fn()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        r = fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / reps, r
+
+
+def _cpu_gnn_filter_baseline(torch, model, x_in, g, edges, layers_timed=None, batch=65536):
+    """SURVEY 8(d) / BASELINE.md 2: the reference's GNN filter on the host cores.  Its scoring loop (filter.py:113-121) calls
+    the WHOLE model for every batch of 65,536 candidates -- LinkGNN.forward recomputes the GNN embeddings each time
+    (models.py:505) -- so one batch costs one GNN forward + one decode: FAITHFUL = batch / (t_gnn + t_decode); FAIR = the same
+    loop with the embeddings computed once = batch / t_decode.  Host libraries as its CPU run would use them: SciPy CSR x dense
+    for the aggregation (one thread), BLAS for the dense layers (the threads numpy's BLAS takes).  ``layers_timed``: time only
+    the first n GCN layers and scale to the model's depth (a bounded sample: a full ppa-sized forward is ~40 s on one SpMM
+    thread)."""
+    import numpy as np
+    import scipy.sparse as ssp
+    n = g.n_rows
+    gh = g.cpu()
+    A = gh.to_scipy().astype(np.float32)
+    An = (A + ssp.identity(n, dtype=np.float32, format="csr")).tocsr()
+    An.setdiag(1.0)                                   # gcn_norm: the diagonal is SET to 1 (fill_diag), not added to
+    with np.errstate(divide="ignore"):
+        dis = 1.0 / np.sqrt(np.asarray(An.sum(1)).ravel())
+    dis[np.isinf(dis)] = 0
+    An = (ssp.diags(dis) @ An @ ssp.diags(dis)).tocsr().astype(np.float32)
+    sd = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
+    ws = [sd[k] for k in sorted(sd) if k.startswith("gnn.convs.") and k.endswith(".weight")]
+    bs = [sd[k] for k in sorted(sd) if k.startswith("gnn.convs.") and k.endswith(".bias")]
+    h = x_in.detach().cpu().numpy()
+    n_layers = len(ws)
+    do = n_layers if layers_timed is None else min(layers_timed, n_layers)
+    t0 = time.perf_counter()
+    for i in range(do):
+        h = An @ (h @ ws[i]) + bs[i]
+        if i < n_layers - 1:
+            h = np.maximum(h, 0)
+    t_gnn = (time.perf_counter() - t0) * (n_layers / do)
+    if do < n_layers:                                 # (the decode below only needs SOME embeddings of the right shape to be timed)
+        h = np.ascontiguousarray(h[:, :ws[-1].shape[1]]) if h.shape[1] >= ws[-1].shape[1] else np.pad(h, ((0, 0), (0, ws[-1].shape[1] - h.shape[1])))
+    lw = [sd[k] for k in sorted(sd) if k.startswith("linkpred.lins.") and k.endswith(".weight")]
+    lb = [sd[k] for k in sorted(sd) if k.startswith("linkpred.lins.") and k.endswith(".bias")]
+    ub, vb = edges[0][:batch].cpu().numpy(), edges[1][:batch].cpu().numpy()
+    t0 = time.perf_counter()
+    z = h[ub] * h[vb]
+    for i, (W, b) in enumerate(zip(lw, lb)):
+        z = z @ W.T + b
+        if i < len(lw) - 1:
+            z = np.maximum(z, 0)
+    z = 1 / (1 + np.exp(-z))
+    t_dec = time.perf_counter() - t0
+    return {"kind": "port", "unit": "edges/s", "gnn_forward_s": t_gnn, "decode_batch_s": t_dec, "batch": int(len(ub)),
+            "faithful_value": len(ub) / (t_gnn + t_dec), "fair_value": len(ub) / t_dec, "cores": {"spmm": 1, "blas": os.cpu_count()},
+            "sample": f"one GNN forward ({do} of {n_layers} layers timed" + (", scaled to the depth" if do < n_layers else "") +
+                      f") + the decode of one batch of {len(ub)} candidates: what ONE iteration of filter.py:113-121 costs on the host; "
+                      "faithful = embeddings recomputed per batch (models.py:505), fair = computed once",
+            "full_ok": do == n_layers, "probabilities_checked": None}
+
+
 def _checkpoint(torch, models, datasets, filter_stage, dataset, model, cli):
     """A seeded random-init checkpoint under models/ (no trained weights exist offline): the filter loads it like a real one."""
     p = filter_stage.make_parser()
@@ -60,16 +124,26 @@ def leg_config0(torch):
         f = filter_stage.main(["--dataset", "ddi", "--model", "simple", "--checkpoint", "ddi_simple||0|0.pt", "--synthetic"])
         _sync(torch)
         t1 = time.perf_counter()
+        ft = dict(filter_stage.LAST_TIMING)
         rows = torch.load(f).shape[0]
         curves = rank_stage.main(["--dataset", "ddi", "--model", "simple", "--sorted_edge_path", os.path.basename(f),
                                   "--num_sorted_edge", "100000", "--runs", "1", "--synthetic"])
         _sync(torch)
         t2 = time.perf_counter()
+    tm = dict(ft)
     return {"workload": "configs[0] ddi-like S1 (N=4,267, full size): filter.py --model simple (all candidates, full [E,3] file) -> "
                         "rank.py --model simple, 100 k proposals",
-            "filter_s": t1 - t0, "candidates": rows, "candidates_per_s": rows / (t1 - t0), "rank_s": t2 - t1,
-            "rank_curve": _jsonable(curves), "note": "wall clock incl. stand-in generation and file I/O; on the GPU (the reference runs "
-                                                     "this config on the CPU)"}
+            "candidates": rows, "scored_s": tm.get("scored_s"), "gpu_ms": tm.get("gpu_ms"),
+            "candidates_per_s": rows / max(tm.get("scored_s") or (t1 - t0), 1e-9),
+            "bound": "hbm", "rows_GBps": rows * 12 / max((tm.get("gpu_ms") or 1e9) * 1e-3, 1e-9) / 1e9,
+            "frac": rows * 12 / max((tm.get("gpu_ms") or 1e9) * 1e-3, 1e-9) / 1e9 / HBM_PEAK_GBPS,
+            "wall_s": {"filter_cli": t1 - t0, "rank_cli": t2 - t1},
+            "rank_curve": _jsonable(curves),
+            "note": "scored_s / gpu_ms: the filter's scoring section (graph on the device -> all rows ordered on the device) on the host "
+                    "clock and between two HIP events; wall_s: the whole CLI incl. stand-in generation, [E,3] file write / read and "
+                    "the rank stage's training-free evaluation.  16 M candidates are a LAUNCH-bound job (a few ms of kernels): the "
+                    "roofline fraction of writing the rows says so.  The reference runs this config on the CPU; there is no CPU "
+                    "product path here"}
 
 
 def leg_config1(torch):
@@ -82,15 +156,40 @@ def leg_config1(torch):
         f = filter_stage.main(["--dataset", "collab", "--model", "gcn", "--checkpoint", name, "--synthetic", "--keep_top", "150000"])
         _sync(torch)
         t1 = time.perf_counter()
+        ft = dict(filter_stage.LAST_TIMING)
         curves = rank_stage.main(["--dataset", "collab", "--model", "simple", "--sorted_edge_path", os.path.basename(f),
                                   "--num_sorted_edge", "150000", "--runs", "1", "--synthetic"])
         _sync(torch)
         t2 = time.perf_counter()
         seen = [l for l in log.getvalue().splitlines() if l.startswith("using ") and " edges; scored in " in l]
+        # the reference's CPU path for this filter, on the same model and graph (bounded: one forward + one batch)
+        dev = torch.device("cuda", torch.cuda.current_device())
+        data = data.to(dev)
+        model = models.build_model(args, data, dev)
+        model.load_state_dict(torch.load(os.path.join("models", name), map_location=dev))
+        model.eval()
+        g = data.adj_t
+        x_in = torch.cat([model.emb.weight.detach(), data.x], 1) if getattr(model, "emb", None) is not None else data.x
+        gen = torch.Generator(device=dev).manual_seed(3)
+        edges = torch.randint(0, g.n_rows, (2, 65536), generator=gen, device=dev)
+        cpu = _cpu_gnn_filter_baseline(torch, model, x_in, g, edges)
+    h, layers = 256, 3
+    n_c = ft.get("candidates") or 0
+    flops = (n_c / 2) * (h + 2 * h * h * (layers - 1) + 2 * h)           # each unordered pair decoded once
+    gms = ft.get("gpu_ms") or 0.0
     return {"workload": "configs[1] collab-like S2 (N=235,868, weighted, 128 features + 256-d embedding, H=256, L=3): filter.py --model gcn "
                         "--keep_top 150000 -> rank.py --model simple --num_sorted_edge 150000",
-            "filter_s": t1 - t0, "rank_s": t2 - t1, "filter_log": seen[-1] if seen else None, "rank_curve": _jsonable(curves),
-            "note": "wall clock incl. stand-in generation, checkpoint load and file I/O"}
+            "candidates": n_c, "scored_s": ft.get("scored_s"), "gpu_ms": gms, "candidates_per_s": n_c / max(ft.get("scored_s") or 1e9, 1e-9),
+            "bound": "mfma", "TFLOPs_decode_over_gpu_ms": flops / max(gms * 1e-3, 1e-9) / 1e12,
+            "frac": flops / max(gms * 1e-3, 1e-9) / 1e12 / MFMA_F32_PEAK_TF,
+            "wall_s": {"filter_cli": t1 - t0, "rank_cli": t2 - t1}, "filter_log": seen[-1] if seen else None,
+            "rank_curve": _jsonable(curves), "cpu_baseline": cpu,
+            "gpu_over_cpu": {"faithful": n_c / max(ft.get("scored_s") or 1e9, 1e-9) / cpu["faithful_value"],
+                             "fair": n_c / max(ft.get("scored_s") or 1e9, 1e-9) / cpu["fair_value"]},
+            "note": "scored_s / gpu_ms: the filter's scoring section (GCN embeddings once, candidate blocks, fused MFMA decode of each "
+                    "unordered pair, streaming top-K) on the host clock / between HIP events; frac = decode flops of that section over "
+                    "gpu_ms against the fp32 MFMA peak (the section also holds the embeddings and the list generation); wall_s: whole "
+                    "CLIs incl. stand-in generation, checkpoint and file I/O"}
 
 
 def leg_config3(torch, min_candidates=1_000_000_000):
@@ -132,6 +231,44 @@ def leg_config3(torch, min_candidates=1_000_000_000):
                 del r, pairs, sc
                 if seen >= min_candidates:
                     break
+            # ---- the CPU path of the same filter (bounded: one GCN layer timed, scaled to three; one batch decoded)
+            x_in = torch.cat([model.emb.weight.detach(), data.x], 1)
+            gen = torch.Generator(device=dev).manual_seed(3)
+            cpu = _cpu_gnn_filter_baseline(torch, model, x_in, g, torch.randint(0, g.n_rows, (2, 65536), generator=gen, device=dev),
+                                           layers_timed=1)
+            # ---- the RANK half of configs[3] (rank.py --model sage on ppa): one evaluation pass of train_and_eval.test
+            # (train_and_eval.py:98-136): SAGE embeddings once, then the LinkPredictor decode of every evaluation edge -- ppa's
+            # splits hold 3 M valid + 3 M test positives, 3 M shared negatives per split and the eval_train sample: ~21 M decodes per
+            # epoch of evaluation -- and the AA heuristic over the same lists (test_adamic, :160-173: 6.06 M positive, 3 M negative)
+            sage = models.SAGE(x_in.shape[1], 256, 256, 3, 0.0).to(dev).eval()
+            lp = models.LinkPredictor(256, 256, 1, 3, 0.0).to(dev).eval()
+            ms_sage, hs = _gpu_ms(torch, lambda: sage(x_in, g), reps=3)
+            n_eval = 21_000_000
+            eu = torch.randint(0, g.n_rows, (n_eval,), generator=gen, device=dev, dtype=torch.int32)
+            ev = torch.randint(0, g.n_rows, (n_eval,), generator=gen, device=dev, dtype=torch.int32)
+            lws = [l.weight.detach() for l in lp.lins]
+            lbs = [l.bias.detach() for l in lp.lins]
+            ms_dec, _ = _gpu_ms(torch, lambda: ops.mlp_decode(hs, eu, ev, lws, lbs), reps=3)
+            from eps_amd.heuristics import node_weight_table
+            w_aa = node_weight_table(g, ops.W_AA)
+            row, colx, _ = g.coo()
+            sel = torch.randint(0, row.numel(), (6_060_000,), generator=gen, device=dev)
+            pu, pv = row[sel].to(torch.int32).contiguous(), colx[sel].to(torch.int32).contiguous()        # positive-like: stored edges
+            nu, nv = eu[:3_000_000].contiguous(), ev[:3_000_000].contiguous()                              # negatives: uniform pairs
+            ms_pos, _ = _gpu_ms(torch, lambda: ops.pair_scores(g.rowptr, g.col, None, w_aa, g.n_rows, pu, pv, want_cn=False, grouped=False), reps=3)
+            ms_neg, _ = _gpu_ms(torch, lambda: ops.pair_scores(g.rowptr, g.col, None, w_aa, g.n_rows, nu, nv, want_cn=False, grouped=False), reps=3)
+            deg = g.degree()
+            b_pos = 4 * int(deg[pu.long()].sum() + deg[pv.long()].sum()) + 48 * pu.numel()
+            b_neg = 4 * int(deg[nu.long()].sum() + deg[nv.long()].sum()) + 48 * nu.numel()
+            fl_dec = float(n_eval) * (256 + 2 * 256 * 256 * 2 + 2 * 256)
+            rank_half = {"what": "rank.py --model sage on the ppa stand-in, one evaluation pass (train_and_eval.py:98-136) + the AA heuristic "
+                                 "over the evaluation lists (:160-173); random-init weights, synthetic lists of the splits' sizes",
+                         "sage_forward_ms": ms_sage, "decode_edges": n_eval, "decode_ms": ms_dec, "decode_edges_per_s": n_eval / ms_dec * 1e3,
+                         "decode_TFLOPs": fl_dec / ms_dec / 1e9, "decode_frac_mfma": fl_dec / ms_dec / 1e9 / MFMA_F32_PEAK_TF,
+                         "aa_pos_pairs": pu.numel(), "aa_pos_ms": ms_pos, "aa_pos_GBps_8d": b_pos / ms_pos / 1e6,
+                         "aa_pos_frac_hbm": b_pos / ms_pos / 1e6 / HBM_PEAK_GBPS,
+                         "aa_neg_pairs": nu.numel(), "aa_neg_ms": ms_neg, "aa_neg_GBps_8d": b_neg / ms_neg / 1e6,
+                         "aa_neg_frac_hbm": b_neg / ms_neg / 1e6 / HBM_PEAK_GBPS}
     h, layers = 256, 3
     flops = (seen / 2) * (h + 2 * h * h * (layers - 1) + 2 * h)          # each unordered pair decoded once
     t = t_list + t_dec
@@ -141,7 +278,54 @@ def leg_config3(torch, min_candidates=1_000_000_000):
             "directed_candidates": seen, "embeddings_s": t_emb, "list_s": t_list, "decode_s": t_dec,
             "candidates_per_s": seen / t, "bound": "mfma", "TFLOPs_incl_list_generation": flops / t / 1e12,
             "frac_incl_list_generation": flops / t / 1e12 / MFMA_F32_PEAK_TF, "TFLOPs_decode_only": flops / t_dec / 1e12,
-            "frac_decode_only": flops / t_dec / 1e12 / MFMA_F32_PEAK_TF}
+            "frac_decode_only": flops / t_dec / 1e12 / MFMA_F32_PEAK_TF,
+            "gpu_ms": {"embeddings": t_emb * 1e3, "list": t_list * 1e3, "decode": t_dec * 1e3},
+            "cpu_baseline": cpu,
+            "gpu_over_cpu": {"faithful": seen / t / cpu["faithful_value"], "fair": seen / t / cpu["fair_value"]},
+            "rank_half": rank_half}
+
+
+def leg_full_list(torch):
+    """The literal filter.py:113-165 on the bench graph: EVERY candidate gets its exact score, written out in candidate order
+    (no bar, no top-K): eps_expand_unit_count + eps_expand_unit_fill over column blocks of < 2^31 two-hop paths -- column-major,
+    both orientations, u ascending, float32 of the exact 2^-40 fixed-point sums.  The list itself is 8 bytes per candidate
+    (u + score; v is the block's column pointer): 102 GB leave the chip for 12.7 G candidates, which is why the production
+    path never writes it."""
+    from eps_amd import candidates, ops, scan, synth
+    from eps_amd.heuristics import node_weight_table
+    dev = torch.device("cuda", torch.cuda.current_device())
+    g = synth.ppa_like(seed=3, device=dev)
+    w = node_weight_table(g, ops.W_AA)
+    md, sp = scan.max_degree(g), scan.window_splits(g)
+    blocks = list(candidates.column_blocks(g))
+
+    def all_blocks():
+        n = 0
+        for v_lo, v_hi in blocks:
+            r = ops.expand_unit(g.rowptr, g.col, w, g.n_rows, v_lo, v_hi, md, sp, want_score=True, want_v=False,
+                                col_order=candidates.heaviest_first(g, v_lo, v_hi))
+            n += int(r[1].numel())                    # (cand_u; the column of candidate i is the colptr range that holds i)
+            del r
+        return n
+    all_blocks()
+    _sync(torch)
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    a.record()
+    n_cand = all_blocks()
+    b.record()
+    _sync(torch)
+    wall = time.perf_counter() - t0
+    ms = a.elapsed_time(b)
+    paths = int(candidates.path_counts(g).sum().item())
+    abytes = 4 * paths * 2 + 8 * n_cand + 24 * g.nnz()      # every two-hop path read in the counting and in the fill pass + the list
+    return {"workload": "full list (filter.py:113-165 as written): every 2-hop non-edge of the ppa-like bench graph with its exact AA "
+                        "score, in candidate order, %d column blocks" % len(blocks),
+            "kernel": "filter_scan_kernel<FS_COUNT> + <FS_EMIT> (eps_expand_unit_count / _fill)", "candidates": n_cand,
+            "two_hop_paths": paths, "gpu_ms": ms, "wall_s": wall, "candidates_per_s": n_cand / ms * 1e3, "bound": "hbm",
+            "algorithmic_bytes": abytes, "GBps": abytes / ms / 1e6, "frac": abytes / ms / 1e6 / HBM_PEAK_GBPS,
+            "note": "gpu_ms: HIP events around all blocks incl. the one host read per block (its candidate count sizes the list); "
+                    "algorithmic bytes = 4 B x two-hop paths x 2 passes + 8 B x candidates written + 24 B x nnz"}
 
 
 def leg_config4(torch, n_pairs=125_000_000):
@@ -234,7 +418,7 @@ def _jsonable(x):
 def run_all(torch, keep_top):
     legs = {}
     for name, fn in (("config0_ddi_cn", leg_config0), ("config1_collab_gcn_cn", leg_config1), ("config3_ppa_gcn_decode", leg_config3),
-                     ("config4_rmat24_share", leg_config4)):
+                     ("full_list_every_candidate_scored", leg_full_list), ("config4_rmat24_share", leg_config4)):
         t0 = time.perf_counter()
         try:
             legs[name] = fn(torch)

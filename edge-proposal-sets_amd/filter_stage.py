@@ -200,6 +200,30 @@ def scored_blocks(args, model, data, ra_graph, col_lo: int = 0, col_hi: int = No
         yield v_lo, v_hi, blk, blk.score
 
 
+LAST_TIMING = {}      # the last run's scoring section: {"scored_s": host stopwatch, "gpu_ms": HIP events on the stream, "candidates": n}
+
+
+class _Stopwatch:
+    """The scoring section of a run on both clocks: host wall (what the stage prints) and a pair of HIP events on the current
+    stream around the same section (bench_configs.py reports both: `wall_s` of a CLI leg also holds stand-in generation,
+    checkpoint and file I/O, which say nothing about the engine)."""
+
+    def __init__(self, device):
+        self.device = device
+        self.e0 = torch.cuda.Event(enable_timing=True)
+        self.e1 = torch.cuda.Event(enable_timing=True)
+        self.e0.record(torch.cuda.current_stream(device))
+        self.t0 = time.perf_counter()
+
+    def stop(self, candidates: int) -> float:
+        self.e1.record(torch.cuda.current_stream(self.device))
+        torch.cuda.synchronize(self.device)
+        dt = time.perf_counter() - self.t0
+        LAST_TIMING.clear()
+        LAST_TIMING.update(scored_s=dt, gpu_ms=self.e0.elapsed_time(self.e1), candidates=int(candidates))
+        return dt
+
+
 def run(args) -> str:
     args = default_model_configs(args)
     print(args)
@@ -236,7 +260,7 @@ def run(args) -> str:
     model.eval()
     ra_graph = train_only_graph(split_edge, data.num_nodes, device) if args.model == "resource_allocation" else None
 
-    t0 = time.perf_counter()
+    watch = _Stopwatch(device)
     keep = int(args.keep_top)
     if 0 < keep <= scan.MAX_K and data.adj_t.n_rows == data.adj_t.n_cols:
         # (the hubs-first copy first: the symmetry check of scan_available then reads the COPY's reverse positions -- the table
@@ -252,8 +276,7 @@ def run(args) -> str:
         st = {}
         with torch.no_grad():
             best_pairs, best_scores = scan.scan_topk(data.adj_t, scan_w, keep, rank, world, stats=st, relabel=True)
-        torch.cuda.synchronize(device)
-        dt = time.perf_counter() - t0
+        dt = watch.stop(st["candidates"])
         bar = None if st["bar"] is None else float(st["bar"])
         print(f'threshold scan ({args.model}): bar {bar}, {st["survivors"]} survivors, {st["launches"]} launches')
         print(f'using {st["candidates"]} edges; scored in {dt:.2f} s ({st["candidates"] / max(dt, 1e-9):.3e} candidate edges/s '
@@ -285,9 +308,8 @@ def run(args) -> str:
             keys, vals = scan._gather_varlen(keys, world), scan._gather_varlen(vals, world)
         if keys.numel():
             rows_k, rows_v = scan.select_topk(keys, vals, 2 * keys.numel(), g.n_rows)
-            torch.cuda.synchronize(device)
-            dt = time.perf_counter() - t0
             n_seen = rows_k.numel()
+            dt = watch.stop(n_seen)
             print(f'using {n_seen} edges; scored in {dt:.2f} s ({n_seen / max(dt, 1e-9):.3e} candidate edges/s incl. generation)')
             rows = torch.stack([(rows_k & 0xFFFFFFFF).to(torch.float32), (rows_k >> 32).to(torch.float32), rows_v], 1)
             return _save(args, spec, sorted_edge_path, num_sorted_edge, run_id, rank, world, rows)
@@ -297,8 +319,7 @@ def run(args) -> str:
             and (keep > 0 or int(scan.half_paths(data.adj_t).sum().item()) < 1 << 29)):     # (the whole file: lists that fit)
         with torch.no_grad():
             best_pairs, best_scores, n_seen = gnn_half_topk(args, model, data, keep if keep else scan.MAX_K, rank, world)
-        torch.cuda.synchronize(device)
-        dt = time.perf_counter() - t0
+        dt = watch.stop(n_seen)
         print(f'GNN filter, each unordered pair decoded once ({args.model})')
         print(f'using {n_seen} edges; scored in {dt:.2f} s ({n_seen / max(dt, 1e-9):.3e} candidate edges/s incl. generation)')
         return _save(args, spec, sorted_edge_path, num_sorted_edge, run_id, rank, world,
@@ -327,8 +348,7 @@ def run(args) -> str:
                 all_pairs.append(pairs)
                 all_scores.append(score)
             n_seen += n_blk
-    torch.cuda.synchronize(device)
-    dt = time.perf_counter() - t0
+    dt = watch.stop(n_seen)
     print(f'using {n_seen} edges; scored in {dt:.2f} s ({n_seen / max(dt, 1e-9):.3e} candidate edges/s incl. generation)')
 
     if keep:

@@ -456,6 +456,25 @@ _SCAN_WS = {}
 KERNEL_EVENTS = None      # a list while bench.py times kernels: (kernel name, start event, end event, work size) per launch
 
 
+class _timed:
+    """``with _timed(dev, name, size):`` -- HIP events around a library call on its stream while bench.py collects KERNEL_EVENTS."""
+
+    def __init__(self, dev, name, size):
+        self.dev, self.name, self.size, self.ev = dev, name, int(size), None
+
+    def __enter__(self):
+        if KERNEL_EVENTS is not None:
+            self.ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            self.ev[0].record(torch.cuda.current_stream(self.dev))
+        return self
+
+    def __exit__(self, *exc):
+        if self.ev is not None and exc[0] is None:
+            self.ev[1].record(torch.cuda.current_stream(self.dev))
+            KERNEL_EVENTS.append((self.name, self.ev[0], self.ev[1], self.size))
+        return False
+
+
 def _scan_scratch(dev, max_degree: int) -> torch.Tensor:
     """Scratch of eps_filter_scan (1 GiB of bucket records on 256 CUs + max_degree weights per workgroup): one grow-only
     buffer per device, stream-ordered."""
@@ -611,7 +630,7 @@ def rescore_runs(rowptr, col, fixw: torch.Tensor, n_nodes: int, keys_by_u: torch
     dev = _need_gpu(rowptr, col, fixw, keys_by_u)
     _chk(rowptr, torch.int64, "rowptr"); _chk(col, torch.int32, "col"); _chk(fixw, torch.int64, "fixw"); _chk(keys_by_u, torch.int64, "keys")
     out = torch.empty(keys_by_u.numel(), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with torch.cuda.device(dev), _timed(dev, "rescore_runs", keys_by_u.numel()):
         _lib.check(_lib.load().eps_rescore_runs(_ptr(rowptr), _ptr(col), _ptr(fixw), n_nodes, _ptr(keys_by_u), keys_by_u.numel(),
                                                 _ptr(out), _stream(dev)), "eps_rescore_runs")
     return out
@@ -870,7 +889,7 @@ def select_compact(keys: Optional[torch.Tensor], vals: torch.Tensor, k: int, cou
         out_k = torch.empty(room, dtype=torch.int64, device=dev)
         out_v = torch.empty(room, dtype=torch.float32, device=dev)
         n_out = torch.empty(1, dtype=torch.int64, device=dev)
-    with torch.cuda.device(dev):
+    with torch.cuda.device(dev), _timed(dev, "select_compact", n):
         _lib.check(lib.eps_select_compact(_ptr(keys), _ptr(vals), n, count_ptr, int(k), int(mode), float(params[0]), float(params[1]),
                                           float(params[2]), kth.data_ptr(), kth.data_ptr() + 4, _ptr(out_k), _ptr(out_v),
                                           0 if room is None else int(room), _ptr(n_out), _ptr(state), _stream(dev)), "eps_select_compact")
@@ -916,7 +935,7 @@ def sort_pairs_by_u(keys: torch.Tensor, id_bits: int = 32) -> torch.Tensor:
     out = torch.empty(n, dtype=torch.int64, device=dev)
     if n:
         lib = _lib.load()
-        with torch.cuda.device(dev):
+        with torch.cuda.device(dev), _timed(dev, "sort_pairs_by_u", n):
             _, wsp, wsb = _aligned_ws(dev, lib.eps_sort_pairs_by_u_workspace_bytes(n))
             _lib.check(lib.eps_sort_pairs_by_u(_ptr(keys), n, int(id_bits), _ptr(out), wsp, wsb, _stream(dev)), "eps_sort_pairs_by_u")
     return out

@@ -115,7 +115,7 @@ def test_bench_two_ranks_child_process(dev, tmp_path, scaling):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
            "--scaling", scaling, "--nodes", "30000", "--edges", "600000", "--keep_top", "20000", "--no-cpu", "--no-legs",
-           "--backend", "gloo", "--one-device"]
+           "--backend", "gloo", "--one-device", "--sustain", "0.3"]
     out = subprocess.run(cmd, cwd=tmp_path, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
@@ -126,6 +126,8 @@ def test_bench_two_ranks_child_process(dev, tmp_path, scaling):
     per_graph = line["config"]["candidates_per_step_all_ranks"] // (2 if scaling == "weak" else 1)
     assert per_graph > 0 and 0 < line["roofline"]["frac"] <= 1
     assert (line["weak_value"] is not None) == (scaling == "strong")
+    assert line["replicated_ms"] <= line["ms_per_step"] and len(line["sharded_ms_per_rank"]) == 2
+    assert line["sustained"]["steps"] >= 2 and line["sustained"]["value"] > 0
 
 
 def test_bench_self_launch_from_plain_shell(dev, tmp_path):
@@ -136,7 +138,7 @@ def test_bench_self_launch_from_plain_shell(dev, tmp_path):
     import subprocess
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--nodes", "30000",
-           "--edges", "600000", "--keep_top", "20000", "--no-cpu", "--no-legs", "--backend", "gloo", "--one-device"]
+           "--edges", "600000", "--keep_top", "20000", "--no-cpu", "--no-legs", "--backend", "gloo", "--one-device", "--sustain", "0.3"]
     out = subprocess.run(cmd, cwd=tmp_path, capture_output=True, text=True, timeout=600, env=env)
     assert out.returncode == 0, out.stderr[-2000:]
     line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
@@ -179,3 +181,20 @@ def test_scan_two_ranks_hubs_first_labels(eps, dev, tmp_path, world, dist_rows_m
     for r in range(world):
         p, s = torch.load(os.path.join(tmp_path, f"scan_rank{r}.pt"))
         assert torch.equal(p, want_p.cpu()) and torch.equal(s, want_s.cpu())
+
+
+@pytest.mark.parametrize("gpus", [1, 2])
+def test_bench_failure_still_prints_one_json_line(dev, tmp_path, gpus):
+    """A rank that fails inside the bench (here: an impossible --keep_top) leaves ONE parseable JSON line with "error" and a
+    non-zero exit code -- alone, and under the launcher with a second rank."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--steps", "1", "--warmup", "0", "--nodes", "5000",
+           "--edges", "60000", "--keep_top", "0", "--no-cpu", "--no-legs", "--backend", "gloo", "--one-device", "--sustain", "0"]
+    out = subprocess.run(cmd, cwd=tmp_path, capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode != 0
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert lines, out.stderr[-2000:]
+    line = json.loads(lines[-1])
+    assert line["value"] is None and "EpsError" in line["error"] and line["n_gpus"] == gpus
