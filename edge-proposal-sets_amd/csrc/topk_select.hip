@@ -306,10 +306,11 @@ extern "C" int64_t eps_sort_pairs_by_u_workspace_bytes(int64_t n)
     return (int64_t)(sel_align((size_t)n * 8) + sel_align(sel_by_u_temp_bytes(n)));
 }
 
-extern "C" int eps_sort_pairs_by_u(const int64_t *keys, int64_t n, int32_t id_bits, int64_t *out_by_u, void *workspace,
-                                   int64_t workspace_bytes, void *stream)
+extern "C" int eps_sort_pairs_by_u(const int64_t *keys, int64_t n, int32_t id_bits, int32_t v_block_shift, int64_t *out_by_u,
+                                   void *workspace, int64_t workspace_bytes, void *stream)
 {
-    EPS_REQUIRE(n >= 0 && n < (1ll << 31) && id_bits >= 1 && id_bits <= 32, "eps_sort_pairs_by_u: bad argument");
+    EPS_REQUIRE(n >= 0 && n < (1ll << 31) && id_bits >= 1 && id_bits <= 32 && v_block_shift >= 0 && v_block_shift <= 32,
+                "eps_sort_pairs_by_u: bad argument");
     if (n == 0) return EPS_OK;
     EPS_REQUIRE(keys && out_by_u, "eps_sort_pairs_by_u: null pointer");
     EPS_REQUIRE(workspace && ((uintptr_t)workspace & 255) == 0 && workspace_bytes >= eps_sort_pairs_by_u_workspace_bytes(n),
@@ -325,6 +326,15 @@ extern "C" int eps_sort_pairs_by_u(const int64_t *keys, int64_t n, int32_t id_bi
         rocprim::radix_sort_keys(temp, temp_bytes, swapped, out_by_u, (size_t)n, 32u, 32u + (unsigned)id_bits, s) != hipSuccess) {
         eps_set_error("eps_sort_pairs_by_u: radix sort failed");
         return EPS_ELAUNCH;
+    }
+    if (v_block_shift > 0 && v_block_shift < id_bits) {
+        // blocks of 2^v_block_shift consecutive v first: (v block, u, v) -- the workgroups that run side by side then stream the
+        // rows of ONE block of v, which stay in the L2 (the same row is wanted by every u it is paired with)
+        if (rocprim::radix_sort_keys(temp, temp_bytes, out_by_u, swapped, (size_t)n, (unsigned)v_block_shift, (unsigned)id_bits, s) != hipSuccess ||
+            hipMemcpyAsync(out_by_u, swapped, (size_t)n * 8, hipMemcpyDeviceToDevice, s) != hipSuccess) {
+            eps_set_error("eps_sort_pairs_by_u: radix sort failed");
+            return EPS_ELAUNCH;
+        }
     }
     EPS_CHECK_LAUNCH("eps_sort_pairs_by_u");
     return EPS_OK;

@@ -926,7 +926,7 @@ def compact_between(keys: torch.Tensor, vals: torch.Tensor, lo: Optional[torch.T
     return out_k, out_v, n_out
 
 
-def sort_pairs_by_u(keys: torch.Tensor, id_bits: int = 32) -> torch.Tensor:
+def sort_pairs_by_u(keys: torch.Tensor, id_bits: int = 32, v_block_shift: int = 0) -> torch.Tensor:
     """Survivor keys v << 32 | u (u < v, any order) -> u << 32 | v sorted by (u, v), what ``rescore_runs`` wants: two stable
     radix sorts over the id bits (eps_sort_pairs_by_u)."""
     dev = _need_gpu(keys)
@@ -937,7 +937,8 @@ def sort_pairs_by_u(keys: torch.Tensor, id_bits: int = 32) -> torch.Tensor:
         lib = _lib.load()
         with torch.cuda.device(dev), _timed(dev, "sort_pairs_by_u", n):
             _, wsp, wsb = _aligned_ws(dev, lib.eps_sort_pairs_by_u_workspace_bytes(n))
-            _lib.check(lib.eps_sort_pairs_by_u(_ptr(keys), n, int(id_bits), _ptr(out), wsp, wsb, _stream(dev)), "eps_sort_pairs_by_u")
+            _lib.check(lib.eps_sort_pairs_by_u(_ptr(keys), n, int(id_bits), int(v_block_shift), _ptr(out), wsp, wsb, _stream(dev)),
+                       "eps_sort_pairs_by_u")
     return out
 
 

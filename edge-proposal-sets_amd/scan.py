@@ -391,7 +391,7 @@ def rescore_exact(g: CSRGraph, screen: Screen, keys: torch.Tensor, bar):
     if screen.val is not None:
         vals = ops.rescore_weighted(g.rowptr, g.col, screen.val, screen.node_w, g.n_rows, keys)
     else:
-        by_u = ops.sort_pairs_by_u(keys, max(1, int(g.n_rows - 1).bit_length()))       # (u << 32 | v): runs of equal u
+        by_u = ops.sort_pairs_by_u(keys, max(1, int(g.n_rows - 1).bit_length()), RESCORE_V_BLOCK)     # (u << 32 | v): runs of equal u
         vals = ops.rescore_runs(g.rowptr, g.col, screen.fixw, g.n_rows, by_u)
         keys = ((by_u & 0xFFFFFFFF) << 32) | (by_u >> 32)
     if bar is not None:
@@ -521,6 +521,9 @@ def select_topk_torch(keys: torch.Tensor, vals: torch.Tensor, k: int) -> Tuple[t
     return keys[o], vals[o]
 
 
+RESCORE_V_BLOCK = 12         # the survivors are re-scored in blocks of 2^12 consecutive v (then u, then v): the workgroups that run side
+                             # by side stream the rows of one block of v out of the L2 -- eps_rescore_runs 2.92 -> 2.60 ms on the ppa-like
+                             # graph for 0.06 ms more sorting (2^8: 3.32, 2^10: 2.78, 2^14: 2.77; profiles/r04/step_timeline.txt)
 DIST_ROWS_MIN = 1 << 15      # selected pairs from which the final ordering of a sharded step is dealt over the ranks
 
 

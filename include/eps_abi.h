@@ -437,7 +437,9 @@ int eps_kth_pick(void *state, int32_t shift, float *out_or_null, void *stream);
 /* eps_select_topk_rows_relabelled: eps_select_topk_rows with the pairs' ids mapped through perm first (int64[n_nodes]: id i of a
  * relabelled, scanned graph is the caller's id perm[i]) -- rows and their order are in the caller's labels.
  * eps_sort_pairs_by_u: survivor keys v << 32 | u (u < v) -> u << 32 | v sorted by (u, v) (two stable radix sorts over the
- * id_bits bits of v, then of u): runs of equal u with ascending v, the input eps_rescore_runs wants.  workspace: eps_sort_pairs_by_u_workspace_bytes(n) bytes,
+ * id_bits bits of v, then of u): runs of equal u with ascending v, the input eps_rescore_runs wants.  v_block_shift > 0: by
+ * (v >> v_block_shift, u, v) instead -- blocks of consecutive v first, so that concurrent workgroups of eps_rescore_runs stream
+ * the same rows (0: off).  workspace: eps_sort_pairs_by_u_workspace_bytes(n) bytes,
  * 256-byte aligned. */
 /* eps_compact_between: the entries (key >= 0) whose score lies in [*lo, *hi) (DEVICE floats; either may be NULL: open end),
  * compacted in arbitrary order; *n_out (DEVICE int64) = how many.  A sharded filter step deals its final ordering over the
@@ -448,7 +450,7 @@ int eps_select_topk_rows_relabelled(const int64_t *sel_keys, const float *sel_va
                                     const int64_t *perm, int64_t *out_keys, float *out_vals, void *workspace,
                                     int64_t workspace_bytes, void *stream);
 int64_t eps_sort_pairs_by_u_workspace_bytes(int64_t n);
-int eps_sort_pairs_by_u(const int64_t *keys, int64_t n, int32_t id_bits, int64_t *out_by_u, void *workspace,
+int eps_sort_pairs_by_u(const int64_t *keys, int64_t n, int32_t id_bits, int32_t v_block_shift, int64_t *out_by_u, void *workspace,
                         int64_t workspace_bytes, void *stream);
 int64_t eps_select_topk_cut_workspace_bytes(void);
 int eps_compact_survivors(const int64_t *keys, const float *vals, int64_t n, int64_t *out_keys, float *out_vals,
