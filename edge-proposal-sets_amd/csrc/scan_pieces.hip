@@ -1652,10 +1652,15 @@ static int sp_launch(const int64_t *rowptr, const int32_t *col, const float *val
     int64_t blocks = (int64_t)eps_num_cus() * sp_per_cu[variant];
     if (blocks > n_columns) blocks = n_columns;
     const size_t lds = ((size_t)(2 << bits) + 4 * (size_t)(T + 1) + 8) * 4 + (SP_UBITS / 32) * 6 + 32;
+    // (with the caller's window-path table -- the usual case: scan.py always brings it -- the in-kernel window sums are compiled
+    //  out of EVERY geometry and flavour: no instantiation a caller of the Python host can reach spills a vector register)
     void (*kern)(sp_params) =
-        val ? (variant == 0 ? scan_piece_kernel<512, true> : variant == 1 ? scan_piece_kernel<1024, true> : scan_piece_kernel<256, true>)
-            : (variant == 0 ? scan_piece_kernel<512, false> : variant == 1 ? scan_piece_kernel<1024, false> :
-               wpaths ? scan_piece_kernel<256, false, true> : scan_piece_kernel<256, false>);
+        wpaths ? (val ? (variant == 0 ? scan_piece_kernel<512, true, true> : variant == 1 ? scan_piece_kernel<1024, true, true> :
+                         scan_piece_kernel<256, true, true>)
+                      : (variant == 0 ? scan_piece_kernel<512, false, true> : variant == 1 ? scan_piece_kernel<1024, false, true> :
+                         scan_piece_kernel<256, false, true>))
+               : (val ? (variant == 0 ? scan_piece_kernel<512, true> : variant == 1 ? scan_piece_kernel<1024, true> : scan_piece_kernel<256, true>)
+                      : (variant == 0 ? scan_piece_kernel<512, false> : variant == 1 ? scan_piece_kernel<1024, false> : scan_piece_kernel<256, false>));
     if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
         eps_set_error("eps_scan_screen: cannot reserve %zu bytes of LDS", lds);
         return EPS_ELAUNCH;
