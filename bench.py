@@ -441,7 +441,7 @@ def run(args):
     out = {}
 
     def step():
-        out["r"] = scan.scan_topk(g, w, args.keep_top, srank, sworld, stats=stats)
+        out["r"] = scan.scan_topk(g, w, args.keep_top, srank, sworld, stats=stats, rows_on=0 if sworld > 1 else None)
 
     for _ in range(args.warmup):
         step()

@@ -275,14 +275,16 @@ def run(args) -> str:
         # streaming top-K; every rank ends with the same list
         st = {}
         with torch.no_grad():
-            best_pairs, best_scores = scan.scan_topk(data.adj_t, scan_w, keep, rank, world, stats=st, relabel=True)
+            # (the file is written by rank 0: the ordered rows travel there alone)
+            best_pairs, best_scores = scan.scan_topk(data.adj_t, scan_w, keep, rank, world, stats=st, relabel=True,
+                                                     rows_on=0 if world > 1 else None)
         dt = watch.stop(st["candidates"])
         bar = None if st["bar"] is None else float(st["bar"])
         print(f'threshold scan ({args.model}): bar {bar}, {st["survivors"]} survivors, {st["launches"]} launches')
         print(f'using {st["candidates"]} edges; scored in {dt:.2f} s ({st["candidates"] / max(dt, 1e-9):.3e} candidate edges/s '
               f'incl. generation)')
         return _save(args, spec, sorted_edge_path, num_sorted_edge, run_id, rank, world,
-                     torch.cat([best_pairs.t().to(torch.float32), best_scores.unsqueeze(1)], 1))
+                     None if best_pairs is None else torch.cat([best_pairs.t().to(torch.float32), best_scores.unsqueeze(1)], 1))
     full_w = (fused_node_weights(args, data.adj_t, ra_graph)
               if keep == 0 and data.adj_t.val is None and scan.scan_available(data.adj_t) else None)
     if (full_w is not None and candidates.fused_scores_fit(data.adj_t, full_w)

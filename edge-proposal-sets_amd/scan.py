@@ -544,7 +544,8 @@ def score_range_counts(vals: torch.Tensor, splitters: torch.Tensor) -> torch.Ten
     return torch.bincount(r, minlength=splitters.numel() + 1)
 
 
-def _ordered_rows_distributed(keys: torch.Tensor, vals: torch.Tensor, k: int, bits: int, perm, rank: int, world: int):
+def _ordered_rows_distributed(keys: torch.Tensor, vals: torch.Tensor, k: int, bits: int, perm, rank: int, world: int,
+                              rows_on: Optional[int] = None):
     """The k best directed rows of the selected pairs (all of them, gathered: the same arrays on every rank), ordered by the
     declared rule, with the ORDERING dealt over the ranks: rank r mirrors and sorts the pairs of score range r (1 / world of the
     rows: filter.py:160-161 sorts all E rows on one host), the sorted chunks are gathered in rank order -- which is the declared
@@ -558,7 +559,12 @@ def _ordered_rows_distributed(keys: torch.Tensor, vals: torch.Tensor, k: int, bi
     m = counts[rank]
     rk, rv = ops.select_rows(mk[:m].contiguous(), mv[:m].contiguous(), 2 * m, bits, perm)      # all 2 m rows of the range, ordered
     lens = [2 * c for c in counts]
-    rows_k, rows_v = epd.gather_ragged(rk, lens), epd.gather_ragged(rv, lens)
+    if rows_on is None:
+        rows_k, rows_v = epd.gather_ragged(rk, lens), epd.gather_ragged(rv, lens)
+    else:                                  # (the rows are wanted on one rank only: a gather instead of an all-gather)
+        rows_k, rows_v = epd.gather_ragged_to(rk, lens, rows_on), epd.gather_ragged_to(rv, lens, rows_on)
+        if rows_k is None:
+            return None, None
     return rows_k[:k], rows_v[:k]
 
 
@@ -576,10 +582,12 @@ def _capacity(slots_wanted: int, slack: Optional[int] = None) -> int:
 
 
 def scan_topk(g: CSRGraph, node_w: torch.Tensor, k: int, rank: int = 0, world: int = 1, stats: Optional[dict] = None,
-              relabel: bool = False):
+              relabel: bool = False, rows_on: Optional[int] = None):
     """Exact top-``k`` candidates of the whole graph: (pairs int64 [2,<=k] as (u; v), scores float32), best first.
     ``stats`` (optional dict) receives ``candidates`` (directed candidates scored), ``launches``, ``survivors``, ``bar``.
     ``relabel``: build the hubs-first copy of a large graph if it does not exist yet (see ``scan_graph``).
+    ``rows_on`` (world > 1): the rank that wants the rows -- every other rank returns (None, None) and the ordered chunks travel
+    to that rank alone (the proposal file is written by one rank); default: every rank gets them.
 
     Per call, in the steady state (tables cached on the graph): sample launch -> bar (device) -> main launch -> job-wide
     ceil(k/2)-th best survivor score (device, ops.kth_largest_dist) -> compaction of the survivors at or above it -> ONE host
@@ -706,12 +714,16 @@ def scan_topk(g: CSRGraph, node_w: torch.Tensor, k: int, rank: int = 0, world: i
     if world > 1:
         keys, vals = epd.gather_ragged(keys, nsel_r), epd.gather_ragged(vals, nsel_r)
     if world > 1 and n_sel_all >= DIST_ROWS_MIN:
-        keys, vals = _ordered_rows_distributed(keys.contiguous(), vals.contiguous(), k, bits, perm, rank, world)
-    else:
+        keys, vals = _ordered_rows_distributed(keys.contiguous(), vals.contiguous(), k, bits, perm, rank, world, rows_on)
+    elif rows_on is None or rows_on == rank or world == 1:
         keys, vals = ops.select_rows(keys.contiguous(), vals.contiguous(), k, bits, perm)
+    else:
+        keys = vals = None
     if stats is not None:
         # survivors: DIRECTED rows at or above the job-wide cut (what the selection orders); survivor_slots: list slots the
         # launches handed out (chunks: holes included); bar: None or a 1-element device tensor (float(bar) reads it)
         stats.update(candidates=2 * n_cand_all, launches=launches, survivors=2 * n_sel_all,
                      survivor_slots=sum(min(s_, capacity) for s_ in slots_r), bar=bar)
+    if keys is None:
+        return None, None
     return torch.stack([keys & 0xFFFFFFFF, keys >> 32]), vals

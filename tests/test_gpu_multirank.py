@@ -147,7 +147,7 @@ def test_bench_self_launch_from_plain_shell(dev, tmp_path):
     assert 0 < line["roofline"]["frac"] <= 1 and line["value_unordered_pairs_per_s"] * 2 == pytest.approx(line["value"])
 
 
-def _relabelled_scan_rank_main(rank, world, port, workdir, dist_rows_min=0):
+def _relabelled_scan_rank_main(rank, world, port, workdir, dist_rows_min=0, rows_on=None):
     sys.path.insert(0, ROOT)
     os.chdir(workdir)
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
@@ -161,25 +161,31 @@ def _relabelled_scan_rank_main(rank, world, port, workdir, dist_rows_min=0):
     scan.DIST_ROWS_MIN = dist_rows_min               # 0: the final ordering is dealt over the ranks by score range
     dev = torch.device("cuda:0")
     g = synth.rmat_graph(13, 10, 21, dev)
-    pairs, scores = scan.scan_topk(g, node_weight_table(g, ops.W_AA), 30000, rank, world, relabel=True)
+    pairs, scores = scan.scan_topk(g, node_weight_table(g, ops.W_AA), 30000, rank, world, relabel=True, rows_on=rows_on)
     assert scan.scan_graph(g)[1] is not None
-    torch.save((pairs.cpu(), scores.cpu()), f"scan_rank{rank}.pt")
+    assert (pairs is None) == (rows_on is not None and rank != rows_on)
+    torch.save(None if pairs is None else (pairs.cpu(), scores.cpu()), f"scan_rank{rank}.pt")
     torch.distributed.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,dist_rows_min", [(2, 0), (4, 0), (2, 1 << 30)])
-def test_scan_two_ranks_hubs_first_labels(eps, dev, tmp_path, world, dist_rows_min):
+@pytest.mark.parametrize("world,dist_rows_min,rows_on", [(2, 0, None), (4, 0, None), (2, 1 << 30, None), (3, 0, 0), (2, 1 << 30, 1)])
+def test_scan_two_ranks_hubs_first_labels(eps, dev, tmp_path, world, dist_rows_min, rows_on):
     """The sharded threshold scan on the hubs-first relabelled copy (what bench.py --scaling strong runs): every rank ends
     with the single-process list as scanned under the original labels, bit for bit -- with the final ordering dealt over the
-    ranks by score range (2 and 4 ranks on this one GPU) and with every rank ordering all rows itself."""
+    ranks by score range (2 and 4 ranks on this one GPU) and with every rank ordering all rows itself; ``rows_on``: the rows
+    gathered onto one rank alone (what filter.py and bench.py ask for: the file is written by rank 0)."""
     from eps_amd import scan, synth
     from eps_amd.heuristics import node_weight_table
     g = synth.rmat_graph(13, 10, 21, dev)
     want_p, want_s = scan.scan_topk(g, node_weight_table(g, eps.ops.W_AA), 30000)
     assert scan.scan_graph(g)[1] is None
-    mp.spawn(_relabelled_scan_rank_main, args=(world, _free_port(), str(tmp_path), dist_rows_min), nprocs=world, join=True)
+    mp.spawn(_relabelled_scan_rank_main, args=(world, _free_port(), str(tmp_path), dist_rows_min, rows_on), nprocs=world, join=True)
     for r in range(world):
-        p, s = torch.load(os.path.join(tmp_path, f"scan_rank{r}.pt"))
+        got = torch.load(os.path.join(tmp_path, f"scan_rank{r}.pt"))
+        if rows_on is not None and r != rows_on:          # (the rows travel to one rank only)
+            assert got is None
+            continue
+        p, s = got
         assert torch.equal(p, want_p.cpu()) and torch.equal(s, want_s.cpu())
 
 
