@@ -455,7 +455,10 @@ extern "C" int eps_select_compact(const int64_t *keys, const float *vals, int64_
     }
     EPS_REQUIRE(n_max == 0 || vals, "eps_select_compact: null pointer");
     // k == 0: the rounds are skipped inside (none = true from the start) -- the kernel's `rounds_run` bookkeeping counts on it
-    int64_t blocks = (n_max + FSEL_T * FSEL_U - 1) / (FSEL_T * FSEL_U);
+    // (at least 64 K entries per workgroup: a grid-wide hand-over costs the more the more workgroups take part, and a list of a
+    //  couple of million entries is four of them long -- fsel_kernel averaged 0.21 ms per call in the r04 step with one
+    //  workgroup per 8 K entries)
+    int64_t blocks = (n_max + FSEL_T * 64 - 1) / (FSEL_T * 64);
     const int64_t cap = (int64_t)eps_num_cus();                // one workgroup per CU at most: all resident (the grid-wide hand-over)
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
