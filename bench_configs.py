@@ -124,23 +124,30 @@ def leg_config0(torch):
         f = filter_stage.main(["--dataset", "ddi", "--model", "simple", "--checkpoint", "ddi_simple||0|0.pt", "--synthetic"])
         _sync(torch)
         t1 = time.perf_counter()
+        first = dict(filter_stage.LAST_TIMING)
+        # (once more: the first run of a kind in this process also loads the code objects of every kernel it is the first to use)
+        filter_stage.main(["--dataset", "ddi", "--model", "simple", "--checkpoint", "ddi_simple||0|1.pt", "--synthetic"])
+        _sync(torch)
         ft = dict(filter_stage.LAST_TIMING)
+        ft["first_run_scored_s"] = first.get("scored_s")
+        t1b = time.perf_counter()
         rows = torch.load(f).shape[0]
         curves = rank_stage.main(["--dataset", "ddi", "--model", "simple", "--sorted_edge_path", os.path.basename(f),
                                   "--num_sorted_edge", "100000", "--runs", "1", "--synthetic"])
         _sync(torch)
-        t2 = time.perf_counter()
+        t2 = time.perf_counter() - (t1b - t1)
     tm = dict(ft)
     return {"workload": "configs[0] ddi-like S1 (N=4,267, full size): filter.py --model simple (all candidates, full [E,3] file) -> "
                         "rank.py --model simple, 100 k proposals",
-            "candidates": rows, "scored_s": tm.get("scored_s"), "gpu_ms": tm.get("gpu_ms"),
+            "candidates": rows, "scored_s": tm.get("scored_s"), "gpu_ms": tm.get("gpu_ms"), "first_run_scored_s": tm.get("first_run_scored_s"),
             "candidates_per_s": rows / max(tm.get("scored_s") or (t1 - t0), 1e-9),
             "bound": "hbm", "rows_GBps": rows * 12 / max((tm.get("gpu_ms") or 1e9) * 1e-3, 1e-9) / 1e9,
             "frac": rows * 12 / max((tm.get("gpu_ms") or 1e9) * 1e-3, 1e-9) / 1e9 / HBM_PEAK_GBPS,
             "wall_s": {"filter_cli": t1 - t0, "rank_cli": t2 - t1},
             "rank_curve": _jsonable(curves),
             "note": "scored_s / gpu_ms: the filter's scoring section (graph on the device -> all rows ordered on the device) on the host "
-                    "clock and between two HIP events; wall_s: the whole CLI incl. stand-in generation, [E,3] file write / read and "
+                    "clock and between two HIP events, SECOND run in this process (first_run_scored_s: the first, which also loads the "
+                    "code objects of the kernels it is the first to use); wall_s: the whole CLI incl. stand-in generation, [E,3] file write / read and "
                     "the rank stage's training-free evaluation.  16 M candidates are a LAUNCH-bound job (a few ms of kernels): the "
                     "roofline fraction of writing the rows says so.  The reference runs this config on the CPU; there is no CPU "
                     "product path here"}
@@ -156,11 +163,19 @@ def leg_config1(torch):
         f = filter_stage.main(["--dataset", "collab", "--model", "gcn", "--checkpoint", name, "--synthetic", "--keep_top", "150000"])
         _sync(torch)
         t1 = time.perf_counter()
+        first = dict(filter_stage.LAST_TIMING)
+        # (once more: the first run of a kind in this process also loads the code objects of every kernel it is the first to use)
+        import shutil
+        shutil.copy(os.path.join("models", name), os.path.join("models", "collab_gcn||0|1.pt"))
+        filter_stage.main(["--dataset", "collab", "--model", "gcn", "--checkpoint", "collab_gcn||0|1.pt", "--synthetic", "--keep_top", "150000"])
+        _sync(torch)
         ft = dict(filter_stage.LAST_TIMING)
+        ft["first_run_scored_s"] = first.get("scored_s")
+        t1b = time.perf_counter()
         curves = rank_stage.main(["--dataset", "collab", "--model", "simple", "--sorted_edge_path", os.path.basename(f),
                                   "--num_sorted_edge", "150000", "--runs", "1", "--synthetic"])
         _sync(torch)
-        t2 = time.perf_counter()
+        t2 = time.perf_counter() - (t1b - t1)
         seen = [l for l in log.getvalue().splitlines() if l.startswith("using ") and " edges; scored in " in l]
         # the reference's CPU path for this filter, on the same model and graph (bounded: one forward + one batch)
         dev = torch.device("cuda", torch.cuda.current_device())
@@ -179,7 +194,8 @@ def leg_config1(torch):
     gms = ft.get("gpu_ms") or 0.0
     return {"workload": "configs[1] collab-like S2 (N=235,868, weighted, 128 features + 256-d embedding, H=256, L=3): filter.py --model gcn "
                         "--keep_top 150000 -> rank.py --model simple --num_sorted_edge 150000",
-            "candidates": n_c, "scored_s": ft.get("scored_s"), "gpu_ms": gms, "candidates_per_s": n_c / max(ft.get("scored_s") or 1e9, 1e-9),
+            "candidates": n_c, "scored_s": ft.get("scored_s"), "gpu_ms": gms, "first_run_scored_s": ft.get("first_run_scored_s"),
+            "candidates_per_s": n_c / max(ft.get("scored_s") or 1e9, 1e-9),
             "bound": "mfma", "TFLOPs_decode_over_gpu_ms": flops / max(gms * 1e-3, 1e-9) / 1e12,
             "frac": flops / max(gms * 1e-3, 1e-9) / 1e12 / MFMA_F32_PEAK_TF,
             "wall_s": {"filter_cli": t1 - t0, "rank_cli": t2 - t1}, "filter_log": seen[-1] if seen else None,
@@ -187,7 +203,8 @@ def leg_config1(torch):
             "gpu_over_cpu": {"faithful": n_c / max(ft.get("scored_s") or 1e9, 1e-9) / cpu["faithful_value"],
                              "fair": n_c / max(ft.get("scored_s") or 1e9, 1e-9) / cpu["fair_value"]},
             "note": "scored_s / gpu_ms: the filter's scoring section (GCN embeddings once, candidate blocks, fused MFMA decode of each "
-                    "unordered pair, streaming top-K) on the host clock / between HIP events; frac = decode flops of that section over "
+                    "unordered pair, streaming top-K) on the host clock / between HIP events, SECOND run in this process "
+                    "(first_run_scored_s: the first, code-object loads included); frac = decode flops of that section over "
                     "gpu_ms against the fp32 MFMA peak (the section also holds the embeddings and the list generation); wall_s: whole "
                     "CLIs incl. stand-in generation, checkpoint and file I/O"}
 
