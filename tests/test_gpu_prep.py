@@ -100,3 +100,13 @@ def test_node_order_is_the_stable_descending_argsort(eps, dev):
     assert int(rp[0]) == 0 and torch.equal(rp[1:], torch.cumsum(deg[want], 0))
     hp = scan.half_paths(g)                      # heavy ties at 0 and large values
     assert torch.equal(eps.ops.node_order(keys=hp).long(), torch.argsort(hp, descending=True, stable=True))
+
+
+def test_warm_up_loads_every_code_object(eps, dev):
+    """eps_warm_up launches one empty kernel per translation unit on a private stream (0 = every code object loaded); the host
+    wrapper runs it from a daemon thread and is idempotent."""
+    assert eps.load().eps_warm_up() == 0
+    t = eps._lib.warm_up_async(dev)
+    assert eps._lib.warm_up_async(dev) is t
+    t.join(timeout=120)
+    assert not t.is_alive()
