@@ -89,6 +89,33 @@ def _worker(rank, world, port, tmp):
     got = epd.gather_ragged(buf, lens)
     assert torch.equal(got, torch.cat([torch.arange(3), torch.arange(7) + 100]))
     assert torch.equal(epd.gather_ragged(buf[:0], [0, 0]), buf[:0])
+    # 6. r04: the bar vote (minimum of the ranks' estimates; a rank without an estimate does not vote), the one-rank gather of
+    # ragged lists, and the final ordering of a sharded step dealt over the ranks by score range -- scan._ordered_rows_distributed
+    # with the tensor-op ordering standing in for eps_select_topk_rows: rank 0 ends with exactly the rows one rank orders alone
+    from eps_amd import scan
+    est = torch.tensor([3.5 - rank], dtype=torch.float32)
+    assert float(epd.all_reduce_min_(est.clone())) == 2.5
+    one = epd.gather_ragged_to(buf, lens, 1)
+    assert (one is None) == (rank != 1) and (rank != 1 or torch.equal(one, got))
+    gen2 = torch.Generator().manual_seed(11)
+    uu = torch.randint(0, 2000, (30000,), generator=gen2)
+    pk = torch.unique(((uu + 1 + torch.randint(0, 2000, (30000,), generator=gen2)) << 32) | uu)
+    pv = torch.round(torch.rand(pk.numel(), generator=gen2) * 40) / 8           # levels of tied scores
+    k_rows = 2 * pk.numel() - 5
+    want_k, want_v = scan.select_topk_torch(pk, pv, k_rows)
+    sp = scan.score_splitters(pv, world)
+    counts = scan.score_range_counts(pv, sp).tolist()
+    lo_s = float(sp[rank]) if rank < world - 1 else float("-inf")
+    hi_s = float(sp[rank - 1]) if rank > 0 else float("inf")
+    m = (pv >= lo_s) & (pv < hi_s)
+    assert int(m.sum()) == counts[rank]
+    rk, rv = scan.select_topk_torch(pk[m], pv[m], 2 * counts[rank])
+    lens2 = [2 * c for c in counts]
+    rows_k, rows_v = epd.gather_ragged_to(rk, lens2, 0), epd.gather_ragged_to(rv, lens2, 0)
+    if rank == 0:
+        assert torch.equal(rows_k[:k_rows], want_k) and torch.equal(rows_v[:k_rows], want_v)
+    else:
+        assert rows_k is None and rows_v is None
     torch.save(keys, os.path.join(tmp, f"keys_{rank}.pt"))
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()
