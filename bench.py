@@ -283,8 +283,9 @@ class _ClockSampler:
     """Best-effort shader-clock samples while a loop runs: `rocm-smi --showclocks --json` as a CHILD process every 0.5 s from a
     thread (never an exec of this process; returns None when the tool is missing or prints something else)."""
 
-    def __init__(self):
+    def __init__(self, enabled=True):
         import threading
+        self.enabled = enabled
         self.samples, self._stop = [], threading.Event()
         self._t = threading.Thread(target=self._run, daemon=True)
 
@@ -311,12 +312,14 @@ class _ClockSampler:
             self._stop.wait(0.5)
 
     def __enter__(self):
-        self._t.start()
+        if self.enabled:
+            self._t.start()
         return self
 
     def __exit__(self, *exc):
         self._stop.set()
-        self._t.join(timeout=10)
+        if self.enabled:
+            self._t.join(timeout=10)
         return False
 
 
@@ -522,7 +525,7 @@ def run(args):
         est = max(dt / args.steps, 1e-4)
         n_sus = max(args.steps, int(args.sustain / est) + 1)
         barrier()
-        with _ClockSampler() as clk:
+        with _ClockSampler(enabled=rank == 0) as clk:           # (one sampler per job: rank 0's)
             t0 = time.perf_counter()
             for _ in range(n_sus):
                 step()
