@@ -681,7 +681,8 @@ def scan_topk(g: CSRGraph, node_w: torch.Tensor, k: int, rank: int = 0, world: i
             raise ops._lib.EpsError("scan_topk: eps_scan_screen reported a full hash table (status %s)" % [t[4] for t in table])
         n_cand_all, n_sel_all = sum(ncand_r), sum(nsel_r)
         cut_is_inf = (table[0][3] & 0xFFFFFFFF) == 0xFF800000
-        if screen is not None and not rescore_all and not any(sl > capacity for sl in slots_r):
+        if screen is not None and not rescore_all and not cut_is_inf and not any(sl > capacity for sl in slots_r):
+            # (a cut of -inf means fewer than k2 pairs survived at all: the bar is lowered below, nothing to verify here)
             # the pre-filter was sound iff the cut reaches every rank's threshold (floats compared through their bits on the host)
             cut_f = _f32_from_bits(table[0][3])
             if any(cut_f < _f32_from_bits(t[5]) for t in table):
