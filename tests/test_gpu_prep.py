@@ -110,3 +110,45 @@ def test_warm_up_loads_every_code_object(eps, dev):
     assert eps._lib.warm_up_async(dev) is t
     t.join(timeout=120)
     assert not t.is_alive()
+
+
+def test_round4_entry_points_on_empty_and_tiny_inputs(eps, dev):
+    """The r04 entry points on the inputs the reference's data hands over at the small end: a graph without edges, one node,
+    one edge; empty survivor lists.  No launch with an empty grid, outputs of the documented shapes."""
+    from eps_amd.graph import CSRGraph
+    ops = eps.ops
+    i64 = dict(dtype=torch.int64, device=dev)
+    # a graph of 5 nodes without edges
+    rp = torch.zeros(6, **i64)
+    col = torch.zeros(0, dtype=torch.int32, device=dev)
+    rev, hp, info = ops.reverse_positions_symmetric(rp, col)
+    assert rev.numel() == 0 and hp.tolist() == [0] * 5 and info.tolist() == [0, 0, 0, 0]
+    perm, inv, nrp = ops.node_order(rowptr=rp, relabel=True)
+    assert perm.tolist() == list(range(5)) and inv.tolist() == list(range(5)) and nrp.tolist() == [0] * 6
+    c, v = ops.relabel_graph(rp, col, None, perm, inv, nrp)
+    assert c.numel() == 0 and v is None
+    assert float(ops.score_bound(rp, col, None, torch.ones(5, device=dev), 5, 5)) == 0.0
+    assert ops.node_order(keys=torch.zeros(0, **i64)).numel() == 0
+    # one node, no edge; two nodes, one edge
+    g1 = CSRGraph(torch.zeros(2, **i64), col, None, 1, 1)
+    gs, p, q = g1.degree_ordered()
+    assert gs.nnz() == 0 and p.tolist() == [0] and q.tolist() == [0]
+    g2 = CSRGraph.from_edge_index(torch.tensor([[0, 1], [1, 0]], device=dev), None, sparse_sizes=(2, 2))
+    rev, hp, info = ops.reverse_positions_symmetric(g2.rowptr, g2.col)
+    # (revpos = the position of v INSIDE row w: both mirrors sit at place 0 of their one-entry rows)
+    assert rev.tolist() == [0, 0] and info.tolist()[0] & 0xFFFFFFFF == 0 and info.tolist()[1] == 1
+    gs, p, q = g2.degree_ordered()
+    assert gs.col.tolist() == [1, 0] and p.tolist() == [0, 1]
+    # empty and one-entry survivor lists
+    k0, v0 = torch.zeros(0, **i64), torch.zeros(0, device=dev)
+    ok, ov, n, kth, thr = ops.select_compact(k0, v0, 3)
+    assert int(n) == 0 and float(kth) == float("-inf")
+    ok, ov, n = ops.compact_between(k0, v0, None, None)
+    assert int(n) == 0
+    assert ops.sort_pairs_by_u(k0).numel() == 0
+    one = torch.tensor([(7 << 32) | 3], **i64)
+    assert ops.sort_pairs_by_u(one, id_bits=4).tolist() == [(3 << 32) | 7]
+    ok, ov, n, kth, thr = ops.select_compact(one, torch.tensor([2.5], device=dev), 1)
+    assert int(n) == 1 and ok[:1].tolist() == one.tolist() and float(kth) == 2.5 and float(thr) == 2.5
+    ok, ov, n, kth, thr = ops.select_compact(one, torch.tensor([2.5], device=dev), 2)     # fewer entries than k: everything
+    assert int(n) == 1 and float(kth) == float("-inf")
