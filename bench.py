@@ -546,7 +546,25 @@ def run(args):
         # Algorithmic bytes per launch: every two-hop half path read once (4 B), the per-(v,w) descriptors
         # (col 4 + revpos 4 + rowptr 8 + weight 8), rowptr of the columns, and the survivors (12 B each); the per-rank
         # share under strong scaling.  The same unit for both kernels, so the fractions compare.
-        abytes = (4 * half_paths_total + 24 * g.nnz() + 16 * g.n_rows) // sworld + 12 * (stats["survivors"] // 2 // sworld)
+        # r05, skipped heads: a column does not walk its heaviest hub rows under the bar, so the launch reads the WALKED half paths
+        # and rows only, and writes the slots that pass at bar - T_v (the walked list) -- that is what `achieved` counts.  The r02-r04
+        # unit (every half path of the graph) stays next to it as `all_paths_unit`, so the rounds compare.
+        all_bytes = (4 * half_paths_total + 24 * g.nnz() + 16 * g.n_rows) // sworld + 12 * (stats["survivors"] // 2 // sworld)
+        heads_info = None
+        abytes = all_bytes
+        if stats.get("heads"):
+            gs_, perm_ = scan.scan_graph(g)
+            ht = scan.screen_weights(g, gs_, perm_, w).head_cur
+            if ht is not None:
+                walked_paths = int(ht.wpaths.to(torch.int64).bitwise_and(0xFFFFFFFF).sum())
+                skipped_rows = int(ht.heads[:, 0].to(torch.int64).sum())
+                slots = int(stats.get("walked_slots") or 0)
+                abytes = (4 * walked_paths + 24 * (g.nnz() - skipped_rows) + 16 * g.n_rows) // sworld + 12 * (slots // sworld)
+                heads_info = {"budget_share_of_bar": None if not bar else stats["head_budget"] / bar, "budget": stats["head_budget"],
+                              "walked_half_paths": walked_paths, "walked_share": walked_paths / max(1, half_paths_total),
+                              "rows_skipped": skipped_rows, "walked_list_slots_all_ranks": slots,
+                              "pieces": int(ht.plan[1].shape[0]), "hub_rows": int(scan.hub_rows(gs_).shape[0]),
+                              "candidates_touched_by_the_walk": stats.get("touched")}
         kmax = max(r[0] for r in per_rank)
         achieved = abytes / (kmax * 1e-3) / 1e9
         pmc = {}
@@ -586,7 +604,11 @@ def run(args):
                                           "pair is computed once: value_unordered_pairs_per_s.  'Scored' means: every candidate's sum "
                                           "over its common neighbours is accumulated -- SCREENED with >= upper bounds at 15 / 31 bits "
                                           "(weights rounded up to 2^-shift) -- and the survivors that can reach the top-K get their "
-                                          "EXACT 2^-40 fixed-point score (eps_rescore_runs); the K rows are identical to the exact "
+                                          "EXACT 2^-40 fixed-point score (eps_rescore_runs); r05: under the bar a column's heaviest hub "
+                                          "rows are not walked at all -- their weights (at most half the bar per column) enter every "
+                                          "pair of the column as a BOUND, and the slots that pass get the exact head term from the hub "
+                                          "row bitmaps (eps_scan_refine) -- so a candidate reached through hub rows only is bounded, "
+                                          "never touched (roofline.skipped_heads); the K rows are identical to the exact "
                                           "scan's (eps_filter_scan: tests, profiles/r03/two_kernels_same_list.txt).  The literal "
                                           "filter.py:113-165 -- every candidate's exact score written out -- is the leg "
                                           "full_list_every_candidate_scored",
@@ -615,6 +637,11 @@ def run(args):
                          "kernel": kernel_name, "kernel_ms": kmax, "launches_timed": len(main_ms),
                          "sample_launch_ms": samp,
                          "algorithmic_bytes_per_launch": abytes,
+                         "all_paths_unit": {"bytes_per_launch": all_bytes, "GBps": all_bytes / (kmax * 1e-3) / 1e9,
+                                            "frac": all_bytes / (kmax * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                                            "note": "the r02-r04 unit: 4 B x EVERY two-hop half path of the graph (walked or not) + "
+                                                    "24 B x nnz + 16 B x N + 12 B x survivors, over the same kernel time"},
+                         "skipped_heads": heads_info,
                          "issue": pmc.get("issue"),
                          "note": "`bound`: the unit of achieved / peak (bytes against the HBM peak, as the contract's vocabulary has "
                                  "it); `binds`: what limits the launch according to the counters.  Compulsory bytes: 4 B per "

@@ -6,6 +6,7 @@ from __future__ import annotations
 import ctypes
 import os
 import subprocess
+import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("EPS_LIB_PATH") or os.path.join(_HERE, "libeps_hip.so")  # override: kernel A/B experiments
@@ -49,12 +50,16 @@ SIGNATURES = {
     "eps_rescore_runs": (_int, [_vp, _vp, _vp, _i64, _vp, _i64, _vp, _vp]),
     "eps_scan_cuts": (_int, [_vp, _vp, _i64, _vp, _vp, _vp]),
     "eps_scan_screen_weights": (_int, [_vp, _i64, _i32, _vp, _vp, _vp]),
-    "eps_scan_window_paths": (_int, [_vp, _vp, _vp, _vp, _i64, _vp, _vp]),
-    "eps_scan_screen": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _i64, _i32, _i32, _vp, _vp, _vp]),
+    "eps_scan_window_paths": (_int, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp]),
+    "eps_scan_screen": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _i64, _i64, _i32, _i32, _vp, _vp, _vp]),
+    "eps_scan_heads": (_int, [_vp, _vp, _vp, _i64, _i32, _c.c_uint32, _vp, _vp]),
+    "eps_scan_hub_rows": (_int, [_vp, _vp, _i64, _i32, _vp, _vp]),
+    "eps_scan_hub_row_words": (_i64, [_i64]),
+    "eps_scan_refine": (_int, [_vp, _vp, _vp, _i32, _vp, _vp, _vp, _i64, _i32, _vp, _vp]),
     "eps_scan_bounds": (_int, [_vp, _i64, _vp, _vp]),
     "eps_scan_row_sums": (_int, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
     "eps_scan_plan_rewalk": (_int, [_vp, _i64, _i32, _vp, _vp]),
-    "eps_scan_plan": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
+    "eps_scan_plan": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "eps_scan_screen_weighted": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _i64, _i32, _i32, _vp, _vp, _vp]),
     "eps_rescore_weighted": (_int, [_vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _vp]),
     "eps_expand_unit_count": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _i64, _vp]),
@@ -85,8 +90,9 @@ SIGNATURES = {
     "eps_unpack_keys": (_int, [_vp, _i64, _vp, _vp, _vp]),
 }
 
-ABI_VERSION = 5        # include/eps_abi.h EPS_ABI_VERSION
+ABI_VERSION = 6        # include/eps_abi.h EPS_ABI_VERSION
 _lib = None
+_load_lock = threading.RLock()
 
 
 class EpsError(RuntimeError):
@@ -107,6 +113,14 @@ def load() -> ctypes.CDLL:
     """Load libeps_hip.so.  torch is imported first so that the HIP runtime torch ships
     (same soname, libamdhip64.so.7) is the one the library binds to -- device pointers are
     only meaningful inside one runtime."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _load_lock:             # (the warm-up thread and the main thread may both arrive here first: one dlopen, one signature pass)
+        return _load_locked()
+
+
+def _load_locked() -> ctypes.CDLL:
     global _lib
     if _lib is not None:
         return _lib
@@ -137,7 +151,7 @@ def warm_up_async(device=None):
     global _warm
     if _warm is not None:
         return _warm
-    import threading
+    import atexit
     import torch
 
     def work():
@@ -145,7 +159,10 @@ def warm_up_async(device=None):
             if not torch.cuda.is_available():
                 return
             dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
-            with torch.cuda.device(dev):
+            # (a stream of its own: nothing the main thread launches on the default stream queues behind the warm-up, and the
+            #  thread waits for ITS stream only -- never for the device)
+            side = torch.cuda.Stream(dev)
+            with torch.cuda.device(dev), torch.cuda.stream(side):
                 load().eps_warm_up()
                 # (torch's own code objects: the few element-wise / copy operators between the library calls of a step)
                 z = torch.zeros(4, dtype=torch.int64, device=dev)
@@ -153,13 +170,21 @@ def warm_up_async(device=None):
                 torch.cat([z, z[1:2] + 1]).tolist()
                 torch.stack([z & 3, z >> 1]); f.view(torch.int32).to(torch.int64); torch.empty(4, device=dev)[:2].contiguous()
                 torch.tensor([1, 2], dtype=torch.int64, device=dev)
-                torch.cuda.synchronize(dev)
+                side.synchronize()
         except Exception:       # noqa: BLE001  (a warm-up must never be the thing that fails a run)
             pass
 
     _warm = threading.Thread(target=work, name="eps-warm-up", daemon=True)
     _warm.start()
+    atexit.register(warm_up_join)        # (the interpreter must not tear down while the thread is inside the HIP runtime)
     return _warm
+
+
+def warm_up_join(timeout: float = 30.0) -> None:
+    """Wait for the warm-up thread (no-op without one): before a timed section, and at interpreter exit."""
+    t = _warm
+    if t is not None and t.is_alive():
+        t.join(timeout)
 
 
 def check(rc: int, what: str) -> None:

@@ -81,6 +81,7 @@ int eps_take_counter(unsigned int **counter, hipStream_t stream, const char *who
 // them: the host calls it from a background thread while the process is still reading its dataset.
 extern "C" void eps_warm_graph_prep(void *stream);
 extern "C" void eps_warm_scan_pieces(void *stream);
+extern "C" void eps_warm_scan_heads(void *stream);
 extern "C" void eps_warm_pair_intersect(void *stream);
 extern "C" void eps_warm_pair_grouped(void *stream);
 extern "C" void eps_warm_expand_score(void *stream);
@@ -100,6 +101,7 @@ extern "C" int eps_warm_up(void)
     }
     eps_warm_graph_prep(s);
     eps_warm_scan_pieces(s);
+    eps_warm_scan_heads(s);
     eps_warm_pair_intersect(s);
     eps_warm_pair_grouped(s);
     eps_warm_expand_score(s);

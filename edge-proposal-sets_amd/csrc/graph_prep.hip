@@ -47,16 +47,16 @@ __global__ __launch_bounds__(256) void gp_gather_rows_kernel(const int64_t *__re
 
 static size_t gp_align(size_t x) { return (x + 255) & ~(size_t)255; }
 
-static size_t gp_sort_temp_bytes(int64_t nnz, int64_t n_nodes, bool pairs)
+static size_t gp_sort_temp_bytes(int64_t nnz, int64_t n_nodes, bool pairs, unsigned end_bit = 32u)
 {
     size_t t = 0;
     if (pairs)
         (void)rocprim::segmented_radix_sort_pairs((void *)nullptr, t, (const int32_t *)nullptr, (int32_t *)nullptr, (const float *)nullptr,
                                                   (float *)nullptr, (unsigned)nnz, (unsigned)n_nodes, (const int64_t *)nullptr,
-                                                  (const int64_t *)nullptr, 0u, 32u, (hipStream_t)0);
+                                                  (const int64_t *)nullptr, 0u, end_bit, (hipStream_t)0);
     else
         (void)rocprim::segmented_radix_sort_keys((void *)nullptr, t, (const int32_t *)nullptr, (int32_t *)nullptr, (unsigned)nnz,
-                                                 (unsigned)n_nodes, (const int64_t *)nullptr, (const int64_t *)nullptr, 0u, 32u,
+                                                 (unsigned)n_nodes, (const int64_t *)nullptr, (const int64_t *)nullptr, 0u, end_bit,
                                                  (hipStream_t)0);
     return t;
 }
@@ -91,6 +91,9 @@ extern "C" int eps_relabel_graph(const int64_t *rowptr, const int32_t *col, cons
     }
     void *temp = w;
     size_t temp_bytes = gp_sort_temp_bytes(nnz, n_nodes, val_or_null != nullptr);
+    // (sized by a query over 32 bits; the sort below runs over id_bits of them: ask about that range too)
+    EPS_REQUIRE(gp_sort_temp_bytes(nnz, n_nodes, val_or_null != nullptr, (unsigned)id_bits) <= temp_bytes,
+                "eps_relabel_graph: the workspace is too small for a %d-bit segmented sort", (int)id_bits);
     hipLaunchKernelGGL(gp_gather_rows_kernel, dim3(gp_blocks(n_nodes, 4)), dim3(256), 0, s, rowptr, col, val_or_null, perm, inv, new_rowptr,
                        n_nodes, tmp_col, tmp_val);
     hipError_t e;

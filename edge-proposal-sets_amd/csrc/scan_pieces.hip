@@ -36,15 +36,17 @@
 // barrier-separated phases; __launch_bounds__(T, 4) keeps the fourth wave per SIMD (130 VGPRs instead of 128 cost 25-100 %).
 // Symmetry, the survivor record and the dynamic column hand-out are as in filter_scan.hip.
 #include "eps_common.h"
+#include "scan_common.h"
 #include <string.h>
 
-#define SP_M 32                 // id windows per graph (one 64-byte row of cuts per node); 48 windows: 1.99 M instead of 2.03 M pieces, -0.5 % (r04)
 #define SP_EMPTY 0u             // an empty key word; a key is stored as id + 1, so a clean table is all zeros in BOTH modes
 #define SP_MAXP (SP_M + 1)
-#define SP_FLAG 0x80000000u      // value word of a KNOWN EDGE's endpoint (put in before the walk): sums stay below 2^31, so the bit survives them
 #define SP_UBITS 8192           // units per range of the unit -> row bitmap (64 lanes x 128 bits: one uint4 per lane)
 #ifndef SP_SB
 #define SP_SB 4                 // uint4 reads a thread issues together in the table sweeps
+#endif
+#ifndef SP_BATCH
+#define SP_BATCH 8              // columns per ticket in the light tail of the column order
 #endif
 #ifndef SP_G
 #define SP_G 1                  // units (of 4 entries) a lane looks up, loads and inserts together
@@ -80,7 +82,11 @@ struct sp_params {
     float scale;                // 2^-shift: screening sum -> approximate score
     unsigned int *next_col;
     eps_survivors *out;
-    unsigned int *status;       // bit 1: a hash table filled up (cannot happen within the piece limits; backstop)
+    unsigned int *status;       // bit 1: a hash table filled up (cannot happen within the piece limits; backstop); bit 2: a column's
+                                //        skipped head weighs as much as the bar (the head table was built for a higher bar: nothing valid)
+    uint32_t batch_from;        // tickets below stand for one column, tickets from here on for SP_BATCH consecutive ones (>= n_columns: none)
+    const uint2 *heads;         // [n_nodes] or NULL: column v does NOT walk its first heads[v].x rows (its heaviest hub neighbours under
+                                //        hubs-first labels); heads[v].y = the sum of their screening weights.  See eps_scan_heads.
 };
 
 __device__ __forceinline__ void sp_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
@@ -125,7 +131,8 @@ __device__ __forceinline__ int sp_plan_column(const sp_params &p, int32_t v, int
 {
     const uint32_t ek = (uint32_t)sp_wave_incl_scan((int)pwk) - pwk;      // paths in the windows before k (lane 32: all)
     const bool pk_on = p.ssum != nullptr;      // (weighted graphs come without)
-    const uint32_t sv = pk_on ? p.ssum[v] : 0u;
+    // (what the column's walked rows can add up to: its row sum without the skipped head)
+    const uint32_t sv = pk_on ? p.ssum[v] - (p.heads ? (p.heads[v].y < p.ssum[v] ? p.heads[v].y : p.ssum[v]) : 0u) : 0u;
     const uint32_t smk = pk_on ? p.smax[lane <= SP_M ? lane : SP_M] : 0u;
     // windows 0 .. kv hold ids below v
     const int kv = __popcll(__ballot(lane >= 1 && lane < SP_M && my_bound <= v - 1));
@@ -206,9 +213,10 @@ __device__ __forceinline__ int sp_plan_column(const sp_params &p, int32_t v, int
 // (A[u,w] * A[v,w]) * node_w[w] -- symmetric in (u, v) like the unit-valued one, so the half scheme holds -- and its
 // screening weight is formed per path: ceil(A[u,w] * rowf) + 1 with rowf = A[v,w] * node_w[w] * 2^shift * (1 + 2^-20) per
 // row (float32 products are within 2^-22 of the exact one: still an upper bound of the term's exact fixed-point value).
-// WP: the caller brought the per-graph window paths (the launch's usual case): the in-kernel window sums -- 32 counters per
-// thread -- are compiled out, which is what keeps this instantiation clear of the 128-register line without spilling.
-template <int T, bool HV, bool WP = false>
+// (r05: the per-graph window paths are mandatory.  Until r04 a launch without them summed the window paths of every column
+//  itself -- 32 counters per thread, the one code path of this kernel that spilled vector registers, reached by no caller of the
+//  Python host.)
+template <int T, bool HV>
 __global__ __launch_bounds__(T, 4) void scan_piece_kernel(sp_params p)      // (4 waves per SIMD: <= 128 VGPRs, the LDS share decides the rest)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
@@ -222,7 +230,6 @@ __global__ __launch_bounds__(T, 4) void scan_piece_kernel(sp_params p)      // (
     //  into FLAT loads, which count on vmcnt and make every look-up drain the row loads in flight)
     uint32_t *ubits = lds + ((2 * slots + 4 * (T + 1) + 3) & ~3);      // [SP_UBITS / 32] bit s: a row starts at unit s (of the range)
     uint16_t *wrank = (uint16_t *)(ubits + SP_UBITS / 32);               // [SP_UBITS / 32] rows that start before the word
-    __shared__ uint32_t s_pw[SP_M];          // paths of the column per id window
     __shared__ unsigned long long s_alloc;   // units << 32 | rows handed out to the waves of a round (one 64-bit LDS add per wave)
     __shared__ int s_rbase;
     __shared__ int32_t s_pk0[SP_MAXP], s_pk1[SP_MAXP];   // pieces: window run [k0, k1)
@@ -244,30 +251,13 @@ __global__ __launch_bounds__(T, 4) void scan_piece_kernel(sp_params p)      // (
     const __amdgpu_buffer_rsrc_t col_rs = __builtin_amdgcn_make_buffer_rsrc((void *)p.col, 0, p.col_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t val_rs = __builtin_amdgcn_make_buffer_rsrc((void *)(HV ? (const void *)p.val : (const void *)p.col), 0,
                                                                             p.col_bytes, 0x00020000);
-    // the bar in the table's domain.  filter_scan.hip keeps a candidate when its 2^-40 fixed-point sum a satisfies
-    // float(a * 2^-40) > threshold, i.e. a >= thr_fix (monotone: found by bisection); a screening sum s >= a / 2^(40 - shift),
-    // so s >= floor(thr_fix / 2^(40 - shift)) holds for every such candidate.  Any bar <= 0 (or -inf): every candidate.
-    uint32_t thr32 = 1u;
-    {
-        const float thr = p.out->threshold;
-        auto above = [&](long long a) { return (float)((double)a * (1.0 / (double)(1ll << 40))) > thr; };
-        if (!above(0x7fffffffffffffffll)) {
-            thr32 = SP_FLAG;                          // +inf / NaN bar: nothing passes (sums stay below 2^31)
-        } else if (!above(0ll)) {
-            long long lo = 1ll, hi = 0x7fffffffffffffffll;      // smallest positive a with above(a)
-            while (lo < hi) {
-                const long long mid = lo + ((hi - lo) >> 1);
-                if (above(mid)) hi = mid; else lo = mid + 1;
-            }
-            const unsigned long long q = (unsigned long long)lo >> (40 - p.shift);
-            thr32 = q >= (unsigned long long)SP_FLAG ? SP_FLAG : (q ? (uint32_t)q : 1u);
-        }
-    }
+    const uint32_t thr32 = sp_bar_units(p.out->threshold, p.shift);
     const uint32_t direct_ids = 2u * (uint32_t)slots;
     // Survivor slots are reserved in chunks (one global atomic each).  Without a bar every candidate of a piece survives: the
     // chunk holds a whole piece's yield.  With one, survivors are rare: a piece asks for room for 1024, and a survivor that
     // does not fit its workgroup's reservation takes a slot of its own (one more global atomic: rare).
     const bool no_bar = thr32 <= 1u;
+    const bool raw_sums = p.heads != nullptr;
     const uint32_t chunk = no_bar && direct_ids > 8192u ? direct_ids : 8192u;
     const int32_t my_bound = p.bounds[lane <= SP_M ? lane : SP_M];      // lane k holds window boundary k (the plan runs in wave 0)
 
@@ -283,12 +273,19 @@ __global__ __launch_bounds__(T, 4) void scan_piece_kernel(sp_params p)      // (
     unsigned long long n_cand = 0;           // candidates seen by this thread
     uint32_t new_keys = 0u;                  // ... of the current hash piece: candidate keys this thread inserted
     const unsigned int ncol = (unsigned int)p.n_columns;
-    unsigned int t = blockIdx.x;
+    // Columns are handed out by tickets on ONE device word; the L2 serves same-address atomics at ~11 ns each, and the light
+    // columns at the end of the heaviest-first order take a workgroup ~10 us -- with 1024 workgroups drawing, the tickets, not
+    // the columns, set the pace there.  So a ticket beyond `batch_from` stands for SP_BATCH consecutive columns.
+    const unsigned int batch_from = p.batch_from;
+    auto first_of = [&](unsigned int tk) { return tk < batch_from ? tk : batch_from + (tk - batch_from) * SP_BATCH; };
+    unsigned int t = blockIdx.x < batch_from ? blockIdx.x : first_of(blockIdx.x);
+    unsigned int t_end = t + (blockIdx.x < batch_from ? 1u : SP_BATCH);
     sp_barrier();
 
     while (t < ncol) {
+        const bool last_of_ticket = t + 1u >= t_end || t + 1u >= ncol;
         unsigned int t_next = 0;
-        if (tid == 0) t_next = gridDim.x + atomicAdd(p.next_col, 1u);     // in flight while this column is scored
+        if (tid == 0 && last_of_ticket) t_next = gridDim.x + atomicAdd(p.next_col, 1u);     // in flight while this column is scored
         const int32_t v = p.columns[t];
         const uint32_t vb = rowptr_lo[2 * (size_t)v];
         const int32_t dv = (int32_t)(rowptr_lo[2 * (size_t)v + 2] - vb);
@@ -296,53 +293,31 @@ __global__ __launch_bounds__(T, 4) void scan_piece_kernel(sp_params p)      // (
         const int32_t *__restrict__ vrev = p.revpos + vb;
         const int rounds = (dv + T - 1) / T;
         const bool single = rounds == 1;
-        if (dv > 0 && v > 0) {
-            // ---- paths of the column per id window: the per-graph table, or summed here over the column's rows ----------------
+        // Skipped head (eps_scan_heads): the first xv rows of the column are not walked; whatever they could add to a pair of
+        // this column is at most tv, so a slot passes at thr32 - tv and eps_scan_refine adds the exact head term afterwards.
+        // (the plan table that comes with a head table counts the walked rows only: the two are used together or not at all, so a
+        //  head that cannot be honoured -- no bar, or a head as heavy as the bar: the table was built for a higher one -- leaves
+        //  the column out and says so in the status word)
+        uint32_t xv = 0u, thr_v = thr32;
+        bool bad_head = false;
+        if (p.heads) {
+            const uint2 hd = p.heads[v];
+            xv = hd.x;
+            if (thr32 < SP_FLAG) {
+                bad_head = hd.y >= thr32;
+                thr_v = thr32 - hd.y;
+            }
+            if (bad_head && tid == 0) atomicOr(p.status, 4u);
+            // a DEAD column: no pair of v sums to more than the row sum of v's screening weights -- below the bar, nothing of
+            // this column can pass (a quarter of the ppa-like graph's columns at K = 4 M: a tenth of the pieces, 4 % of the paths.
+            // Launches with heads only: a plain launch counts every candidate of its columns)
+            if (p.ssum && thr32 < SP_FLAG && p.ssum[v] < thr32) bad_head = true;
+        }
+        if (dv > 0 && v > 0 && !bad_head) {
             uint32_t my_w = 0, my_rev = 0, my_base = 0, my_fx = 0;      // this thread's row (of the last round)
-            if (WP || p.wpaths) {
-                if (single && tid < dv) {
-                    my_w = (uint32_t)vcol[tid];
-                    my_rev = (uint32_t)vrev[tid];
-                }
-            } else {
-                if (tid < SP_M) s_pw[tid] = 0u;
-                uint32_t cnt[SP_M];
-#pragma unroll
-                for (int k = 0; k < SP_M; ++k) cnt[k] = 0u;
-                bool any = false;
-                for (int r = 0; r < rounds; ++r) {
-                    const int j = r * T + tid;
-                    if (j < dv) {
-                        any = true;
-                        my_w = (uint32_t)vcol[j];
-                        my_rev = (uint32_t)vrev[j];
-                        const uint4 *row = (const uint4 *)(p.cuts + (size_t)my_w * SP_M);
-                        uint32_t prev = 0u;
-#pragma unroll
-                        for (int q = 0; q < SP_M / 8; ++q) {
-                            const uint4 c = row[q];
-                            const uint32_t wds[4] = {c.x, c.y, c.z, c.w};
-#pragma unroll
-                            for (int h = 0; h < 4; ++h) {
-                                uint32_t a = wds[h] & 0xFFFFu, b = wds[h] >> 16;
-                                a = a < my_rev ? a : my_rev;
-                                b = b < my_rev ? b : my_rev;
-                                cnt[q * 8 + h * 2] += a - prev;
-                                cnt[q * 8 + h * 2 + 1] += b - a;
-                                prev = b;
-                            }
-                        }
-                    }
-                }
-                sp_barrier();                                            // s_pw cleared
-                if (__ballot(any)) {
-#pragma unroll
-                    for (int k = 0; k < SP_M; ++k) {
-                        const uint32_t s = sp_wave_sum(cnt[k]);
-                        if (lane == 0 && s) atomicAdd(&s_pw[k], s);
-                    }
-                }
-                sp_barrier();
+            if (single && tid < dv) {
+                my_w = (uint32_t)vcol[tid];
+                my_rev = (uint32_t)vrev[tid];
             }
             if (single && tid < dv) {
                 my_base = rowptr_lo[2 * (size_t)my_w];
@@ -350,7 +325,7 @@ __global__ __launch_bounds__(T, 4) void scan_piece_kernel(sp_params p)      // (
             }
             // ---- plan: merge windows into pieces.  Wave 0, lane k = window k: the extents are ballots over monotone predicates -
             if (wib == 0 && !p.plan) {
-                const uint32_t pwk = lane < SP_M ? (p.wpaths ? p.wpaths[(size_t)v * SP_M + lane] : s_pw[lane]) : 0u;
+                const uint32_t pwk = lane < SP_M ? p.wpaths[(size_t)v * SP_M + lane] : 0u;
                 // lane k: neighbours of v below window boundary k (row v's own cuts: cuts[v][k - 1]; 0 for k = 0)
                 const int32_t nbk = lane >= 1 && lane <= SP_M ? (int32_t)p.cuts[(size_t)v * SP_M + lane - 1] : 0;
                 const int np = sp_plan_column(p, v, dv, lane, my_bound, pwk, nbk, direct_ids,
@@ -406,7 +381,7 @@ __global__ __launch_bounds__(T, 4) void scan_piece_kernel(sp_params p)      // (
                 const uint32_t pq = quant ? s_pq[pi] : 0u;
                 const uint32_t pk_d = pq & 0xFFu, pk_sb = quant ? 32u - (pq >> 8) : 16u;      // weight bits dropped; bits of the flag + sum field
                 const uint32_t pk_flag = quant ? 1u << (pk_sb - 1u) : 0u;
-                const uint32_t pk_thr = thr32 >= SP_FLAG ? 0xFFFFFFFFu : ((thr32 >> pk_d) ? (thr32 >> pk_d) : 1u);
+                const uint32_t pk_thr = thr_v >= SP_FLAG ? 0xFFFFFFFFu : ((thr_v >> pk_d) ? (thr_v >> pk_d) : 1u);
                 const int32_t lo_id = s_plo[pi], hi_id = s_phi[pi];
                 // hash geometry: the smallest power-of-two table with load <= 1/2; a heavier single window goes in `parts` passes
                 const uint32_t pkeys = ppaths + (uint32_t)(nb - na);           // slots the piece can need: paths + known edges
@@ -448,7 +423,7 @@ __global__ __launch_bounds__(T, 4) void scan_piece_kernel(sp_params p)      // (
                 if (single && tid < dv) {
                     const uint32_t b = cut_ahead < my_rev ? cut_ahead : my_rev;
                     seg_a = seg_from;
-                    seg_len = b - seg_from;
+                    seg_len = (uint32_t)tid < xv ? 0u : b - seg_from;
                     seg_from = b;
                     if (pi + 1 < np) cut_ahead = p.cuts[(size_t)my_w * SP_M + s_pk1[pi + 1] - 1];
                 }
@@ -509,7 +484,7 @@ __global__ __launch_bounds__(T, 4) void scan_piece_kernel(sp_params p)      // (
                             if (k0 > 0) a = crow[k0 - 1];
                             a = a < rev ? a : rev;
                             b = b < rev ? b : rev;
-                            len = b - a;
+                            len = (uint32_t)j < xv ? 0u : b - a;
                         }
                         // Rows with entries in the piece get DENSE indices (block scans of the unit counts and of the non-empty
                         // flags), and the unit -> row map is a bitmap of row starts over the unit numbering plus the rank of every
@@ -802,7 +777,8 @@ __global__ __launch_bounds__(T, 4) void scan_piece_kernel(sp_params p)      // (
                         }
                         if (pos < out_cap) {
                             out_key[pos] = ((int64_t)v << 32) | (int64_t)u;
-                            out_val[pos] = (float)sum * p.scale;
+                            // (a launch with skipped heads reports the WALKED sum as it is: eps_scan_refine completes it)
+                            out_val[pos] = raw_sums ? __builtin_bit_cast(float, sum) : (float)sum * p.scale;
                         }
                     };
                     // (the sweeps read in batches of SP_SB uint4 per thread before they look at any of them: one LDS round trip per
@@ -811,7 +787,7 @@ __global__ __launch_bounds__(T, 4) void scan_piece_kernel(sp_params p)      // (
                     // (and for an empty word), and the largest of a uint4's four words decides with one branch whether any of them
                     // needs a closer look -- survivors are a handful per piece.
                     uint32_t cnt_here = 0u;
-                    const int thr_s = thr32 >= SP_FLAG ? 0x7FFFFFFF : (int)thr32;      // (sums stay below 2^31 - 2)
+                    const int thr_s = thr_v >= SP_FLAG ? 0x7FFFFFFF : (int)thr_v;      // (sums stay below 2^31 - 2)
                     if (d16) {
                         // (two fields per word: the low one shifted up, the high one masked, both signed as above.  The packed
                         //  16-bit instructions -- v_pk_min / max / add_i16 on the word as it is, 5 instead of 9 per word -- were
@@ -929,10 +905,17 @@ __global__ __launch_bounds__(T, 4) void scan_piece_kernel(sp_params p)      // (
                 }
             }
         }
+        if (!last_of_ticket) {
+            ++t;
+            sp_barrier();                    // (a column without pieces has no barrier of its own: s_np and the piece arrays change hands here)
+            continue;
+        }
         if (tid == 0) s_ticket = t_next;
         sp_barrier();
-        t = s_ticket;
+        const unsigned int tk = s_ticket;
         sp_barrier();
+        t = first_of(tk);
+        t_end = t + (tk < batch_from ? 1u : SP_BATCH);
     }
     // what is left of the workgroup's last reservation
     {
@@ -976,13 +959,13 @@ __global__ void sp_cuts_kernel(const int64_t *__restrict__ rowptr, const int32_t
 // instead of a cut row per (column, neighbour).
 __global__ void sp_window_paths_kernel(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col,
                                        const int32_t *__restrict__ revpos, const uint16_t *__restrict__ cuts, int64_t n_nodes,
-                                       uint32_t *__restrict__ wpaths)
+                                       const uint2 *__restrict__ heads, uint32_t *__restrict__ wpaths)
 {
     const int lane = threadIdx.x & 63;
     const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
     for (int64_t v = wave; v < n_nodes; v += n_waves) {
-        const int64_t b = rowptr[v], e = rowptr[v + 1];
+        const int64_t b = rowptr[v] + (heads ? (int64_t)heads[v].x : 0ll), e = rowptr[v + 1];      // (a skipped head is not walked)
         uint32_t cnt[SP_M];
 #pragma unroll
         for (int k = 0; k < SP_M; ++k) cnt[k] = 0u;
@@ -1406,7 +1389,7 @@ extern "C" int eps_scan_cuts(const int64_t *rowptr, const int32_t *col, int64_t 
 }
 
 extern "C" int eps_scan_window_paths(const int64_t *rowptr, const int32_t *col, const int32_t *revpos, const uint16_t *cuts,
-                                     int64_t n_nodes, uint32_t *wpaths, void *stream)
+                                     int64_t n_nodes, const uint32_t *heads_or_null, uint32_t *wpaths, void *stream)
 {
     EPS_REQUIRE(n_nodes >= 0, "eps_scan_window_paths: negative size");
     if (n_nodes == 0) return EPS_OK;
@@ -1415,7 +1398,7 @@ extern "C" int eps_scan_window_paths(const int64_t *rowptr, const int32_t *col, 
     const int64_t cap = (int64_t)eps_num_cus() * 16;
     if (blocks > cap) blocks = cap;
     hipLaunchKernelGGL(sp_window_paths_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, rowptr, col, revpos, cuts,
-                       n_nodes, wpaths);
+                       n_nodes, (const uint2 *)heads_or_null, wpaths);
     EPS_CHECK_LAUNCH("eps_scan_window_paths");
     return EPS_OK;
 }
@@ -1448,33 +1431,34 @@ extern "C" int eps_scan_screen_weights(const int64_t *fixw, int64_t n, int32_t s
 //          registers, 16 spilled) with the 4096-slot table: 21.8 ms against 17.9.
 static int sp_launch(const int64_t *rowptr, const int32_t *col, const float *val, const int32_t *revpos, const uint32_t *fx32,
                      const float *node_w, const uint16_t *cuts, const uint32_t *wpaths, const uint32_t *ssum, const uint32_t *smax,
-                     const uint32_t *pptr, const uint32_t *plan, const int32_t *bounds, int64_t n_nodes,
-                     int64_t nnz, const int32_t *columns, int64_t n_columns, int32_t shift, int32_t variant, eps_survivors *out,
-                     uint32_t *status, void *stream);
+                     const uint32_t *pptr, const uint32_t *plan, const uint32_t *heads, const int32_t *bounds, int64_t n_nodes,
+                     int64_t nnz, const int32_t *columns, int64_t n_columns, int64_t batch_from, int32_t shift, int32_t variant,
+                     eps_survivors *out, uint32_t *status, void *stream);
 
 extern "C" int eps_scan_screen(const int64_t *rowptr, const int32_t *col, const int32_t *revpos, const uint32_t *fx32,
-                               const uint16_t *cuts, const uint32_t *wpaths_or_null, const uint32_t *ssum_or_null,
+                               const uint16_t *cuts, const uint32_t *wpaths, const uint32_t *ssum_or_null,
                                const uint32_t *smax_or_null, const uint32_t *pptr_or_null, const uint32_t *plan_or_null,
-                               const int32_t *bounds, int64_t n_nodes, int64_t nnz,
-                               const int32_t *columns, int64_t n_columns, int32_t shift, int32_t variant, eps_survivors *out,
-                               uint32_t *status, void *stream)
+                               const uint32_t *heads_or_null, const int32_t *bounds, int64_t n_nodes, int64_t nnz,
+                               const int32_t *columns, int64_t n_columns, int64_t batch_from, int32_t shift, int32_t variant,
+                               eps_survivors *out, uint32_t *status, void *stream)
 {
     EPS_REQUIRE(n_columns == 0 || n_nodes == 0 || fx32, "eps_scan_screen: null pointer");
     EPS_REQUIRE((ssum_or_null == nullptr) == (smax_or_null == nullptr), "eps_scan_screen: ssum and smax come together");
-    return sp_launch(rowptr, col, nullptr, revpos, fx32, nullptr, cuts, wpaths_or_null, ssum_or_null, smax_or_null, pptr_or_null,
-                     plan_or_null, bounds, n_nodes, nnz, columns, n_columns, shift, variant, out, status, stream);
+    EPS_REQUIRE(!heads_or_null || plan_or_null, "eps_scan_screen: a head table comes with the plan table built for it");
+    return sp_launch(rowptr, col, nullptr, revpos, fx32, nullptr, cuts, wpaths, ssum_or_null, smax_or_null, pptr_or_null,
+                     plan_or_null, heads_or_null, bounds, n_nodes, nnz, columns, n_columns, batch_from, shift, variant, out, status, stream);
 }
 
 // The same scan on a SYMMETRIC adjacency with stored values (val[e] == val[mirror of e]); node_w = the float node weights.
 extern "C" int eps_scan_screen_weighted(const int64_t *rowptr, const int32_t *col, const float *val, const int32_t *revpos,
-                                        const float *node_w, const uint16_t *cuts, const uint32_t *wpaths_or_null,
+                                        const float *node_w, const uint16_t *cuts, const uint32_t *wpaths,
                                         const int32_t *bounds, int64_t n_nodes, int64_t nnz, const int32_t *columns,
                                         int64_t n_columns, int32_t shift, int32_t variant, eps_survivors *out, uint32_t *status,
                                         void *stream)
 {
     EPS_REQUIRE(n_columns == 0 || n_nodes == 0 || (val && node_w), "eps_scan_screen_weighted: null pointer");
-    return sp_launch(rowptr, col, val, revpos, nullptr, node_w, cuts, wpaths_or_null, nullptr, nullptr, nullptr, nullptr, bounds, n_nodes,
-                     nnz, columns, n_columns, shift, variant, out, status, stream);
+    return sp_launch(rowptr, col, val, revpos, nullptr, node_w, cuts, wpaths, nullptr, nullptr, nullptr, nullptr, nullptr, bounds, n_nodes,
+                     nnz, columns, n_columns, n_columns, shift, variant, out, status, stream);
 }
 
 static const int sp_threads_of[3] = {512, 1024, 256}, sp_bits_of[3] = {13, 14, 12}, sp_per_cu[3] = {2, 1, 4};
@@ -1532,9 +1516,9 @@ __global__ __launch_bounds__(256) void sp_plan_kernel(sp_params p, const int64_t
 }
 
 extern "C" int eps_scan_plan(const int64_t *rowptr, const uint16_t *cuts, const uint32_t *wpaths, const uint32_t *ssum_or_null,
-                             const uint32_t *smax_or_null, const int32_t *bounds, int64_t n_nodes, int32_t shift, int32_t variant,
-                             uint32_t *pcount, const uint32_t *pptr_or_null, uint32_t *plan_or_null, uint32_t *d_used_or_null,
-                             void *stream)
+                             const uint32_t *smax_or_null, const uint32_t *heads_or_null, const int32_t *bounds, int64_t n_nodes,
+                             int32_t shift, int32_t variant, uint32_t *pcount, const uint32_t *pptr_or_null, uint32_t *plan_or_null,
+                             uint32_t *d_used_or_null, void *stream)
 {
     EPS_REQUIRE(n_nodes >= 0 && n_nodes < (1ll << 31), "eps_scan_plan: bad size");
     if (d_used_or_null && hipMemsetAsync(d_used_or_null, 0, sizeof(uint32_t), (hipStream_t)stream) != hipSuccess) {
@@ -1551,6 +1535,7 @@ extern "C" int eps_scan_plan(const int64_t *rowptr, const uint16_t *cuts, const 
     sp_params p;
     memset(&p, 0, sizeof p);
     sp_plan_geometry(p, cuts, wpaths, ssum_or_null, smax_or_null, bounds, n_nodes, shift, variant);
+    p.heads = (const uint2 *)heads_or_null;
     hipLaunchKernelGGL(sp_plan_kernel, dim3((unsigned)((n_nodes + 3) / 4)), dim3(256), 0, (hipStream_t)stream, p, rowptr,
                        2u << sp_bits_of[variant], pcount, pptr_or_null, (uint4 *)plan_or_null, d_used_or_null);
     EPS_CHECK_LAUNCH("eps_scan_plan");
@@ -1608,9 +1593,9 @@ extern "C" int eps_scan_plan_rewalk(const uint32_t *plan, int64_t n_rec, int32_t
 
 static int sp_launch(const int64_t *rowptr, const int32_t *col, const float *val, const int32_t *revpos, const uint32_t *fx32,
                      const float *node_w, const uint16_t *cuts, const uint32_t *wpaths, const uint32_t *ssum, const uint32_t *smax,
-                     const uint32_t *pptr, const uint32_t *plan, const int32_t *bounds, int64_t n_nodes,
-                     int64_t nnz, const int32_t *columns, int64_t n_columns, int32_t shift, int32_t variant, eps_survivors *out,
-                     uint32_t *status, void *stream)
+                     const uint32_t *pptr, const uint32_t *plan, const uint32_t *heads, const int32_t *bounds, int64_t n_nodes,
+                     int64_t nnz, const int32_t *columns, int64_t n_columns, int64_t batch_from, int32_t shift, int32_t variant,
+                     eps_survivors *out, uint32_t *status, void *stream)
 {
     EPS_REQUIRE(n_nodes >= 0 && n_columns >= 0 && nnz >= 0, "eps_scan_screen: negative size");
     EPS_REQUIRE(status, "eps_scan_screen: null pointer");
@@ -1620,7 +1605,7 @@ static int sp_launch(const int64_t *rowptr, const int32_t *col, const float *val
         return EPS_ELAUNCH;
     }
     if (n_columns == 0 || n_nodes == 0) return EPS_OK;
-    EPS_REQUIRE(rowptr && col && revpos && cuts && bounds && columns && out, "eps_scan_screen: null pointer");
+    EPS_REQUIRE(rowptr && col && revpos && cuts && wpaths && bounds && columns && out, "eps_scan_screen: null pointer");
     EPS_REQUIRE(nnz < (1ll << 30), "eps_scan_screen: col[] is addressed with 32-bit byte offsets (nnz < 2^30)");
     EPS_REQUIRE(n_nodes < (1ll << 31) && n_columns < (1ll << 31), "eps_scan_screen: too many nodes / columns");
     EPS_REQUIRE(shift >= 0 && shift <= 40 && variant >= 0 && variant <= 2, "eps_scan_screen: bad shift / variant");
@@ -1642,8 +1627,10 @@ static int sp_launch(const int64_t *rowptr, const int32_t *col, const float *val
     sp_plan_geometry(p, cuts, wpaths, ssum, smax, bounds, n_nodes, shift, variant);
     p.pptr = pptr;
     p.plan = (const uint4 *)plan;
+    p.heads = (const uint2 *)heads;
     p.columns = columns;
     p.n_columns = (int32_t)n_columns;
+    p.batch_from = batch_from < 0 || batch_from > n_columns ? (uint32_t)n_columns : (uint32_t)batch_from;
     p.col_bytes = (uint32_t)(nnz * 4);
     p.scale = ldexpf(1.0f, -shift);
     p.next_col = counter;
@@ -1652,15 +1639,9 @@ static int sp_launch(const int64_t *rowptr, const int32_t *col, const float *val
     int64_t blocks = (int64_t)eps_num_cus() * sp_per_cu[variant];
     if (blocks > n_columns) blocks = n_columns;
     const size_t lds = ((size_t)(2 << bits) + 4 * (size_t)(T + 1) + 8) * 4 + (SP_UBITS / 32) * 6 + 32;
-    // (with the caller's window-path table -- the usual case: scan.py always brings it -- the in-kernel window sums are compiled
-    //  out of EVERY geometry and flavour: no instantiation a caller of the Python host can reach spills a vector register)
     void (*kern)(sp_params) =
-        wpaths ? (val ? (variant == 0 ? scan_piece_kernel<512, true, true> : variant == 1 ? scan_piece_kernel<1024, true, true> :
-                         scan_piece_kernel<256, true, true>)
-                      : (variant == 0 ? scan_piece_kernel<512, false, true> : variant == 1 ? scan_piece_kernel<1024, false, true> :
-                         scan_piece_kernel<256, false, true>))
-               : (val ? (variant == 0 ? scan_piece_kernel<512, true> : variant == 1 ? scan_piece_kernel<1024, true> : scan_piece_kernel<256, true>)
-                      : (variant == 0 ? scan_piece_kernel<512, false> : variant == 1 ? scan_piece_kernel<1024, false> : scan_piece_kernel<256, false>));
+        val ? (variant == 0 ? scan_piece_kernel<512, true> : variant == 1 ? scan_piece_kernel<1024, true> : scan_piece_kernel<256, true>)
+            : (variant == 0 ? scan_piece_kernel<512, false> : variant == 1 ? scan_piece_kernel<1024, false> : scan_piece_kernel<256, false>);
     if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
         eps_set_error("eps_scan_screen: cannot reserve %zu bytes of LDS", lds);
         return EPS_ELAUNCH;

@@ -241,8 +241,8 @@ extern "C" int eps_kth_pick(void *state, int32_t shift, float *out_or_null, void
 // Here one grid does all of it: four rounds of 256-bin histograms with a grid-wide hand-over between them (every workgroup
 // adds its LDS histogram to the round's global one, waits until all have, then picks the bin itself -- the same arithmetic on
 // the same counters, so every workgroup agrees without a broadcast), then -- optionally -- the threshold derived from the
-// k-th value and the compaction of the entries at or above it.  The grid is at most one workgroup per CU: all resident, so
-// the hand-over cannot deadlock.
+// k-th value and the compaction of the entries at or above it.  The grid is at most one workgroup per CU and goes out as a
+// COOPERATIVE launch (hipLaunchCooperativeKernel): resident as a whole, so the hand-over cannot deadlock.
 //   n = min(*n_dev, n_max) when n_dev is given (the slot counter of an eps_survivors list: its readers stop there);
 //   -inf values and entries with key < 0 are "no value" (untouched slots);
 //   *kth = the k-th largest value (-inf when fewer than k values);
@@ -459,12 +459,29 @@ extern "C" int eps_select_compact(const int64_t *keys, const float *vals, int64_
     //  couple of million entries is four of them long -- fsel_kernel averaged 0.21 ms per call in the r04 step with one
     //  workgroup per 8 K entries)
     int64_t blocks = (n_max + FSEL_T * 64 - 1) / (FSEL_T * 64);
-    const int64_t cap = (int64_t)eps_num_cus();                // one workgroup per CU at most: all resident (the grid-wide hand-over)
+    const int64_t cap = (int64_t)eps_num_cus();                // one workgroup per CU at most
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(fsel_kernel, dim3((unsigned)blocks), dim3(FSEL_T), 0, s, keys, vals, n_max, n_dev_or_null, (uint64_t)k, (int)mode,
-                       pa, pb, pc, (fsel_state *)state, kth_or_null, thr_or_null, out_keys_or_null, out_vals_or_null, out_cap, n_out_or_null);
-    EPS_CHECK_LAUNCH("eps_select_compact");
+    // A COOPERATIVE launch: the runtime places the whole grid at once or not at all, so the hand-over between the rounds cannot
+    // wait for a workgroup that a persistent kernel of another stream -- or another process on the same device (ranks sharing a
+    // GPU) -- keeps off the CUs (r04 launched it plainly and relied on "one workgroup per CU is always resident").  Should the
+    // device refuse the grid, one workgroup does the job: slow, never stuck.
+    uint64_t k64 = (uint64_t)k;
+    int mode_i = (int)mode;
+    fsel_state *st = (fsel_state *)state;
+    void *args[] = {(void *)&keys, (void *)&vals, (void *)&n_max, (void *)&n_dev_or_null, (void *)&k64, (void *)&mode_i, (void *)&pa,
+                    (void *)&pb, (void *)&pc, (void *)&st, (void *)&kth_or_null, (void *)&thr_or_null, (void *)&out_keys_or_null,
+                    (void *)&out_vals_or_null, (void *)&out_cap, (void *)&n_out_or_null};
+    hipError_t err = hipLaunchCooperativeKernel((const void *)fsel_kernel, dim3((unsigned)blocks), dim3(FSEL_T), args, 0, s);
+    if (err != hipSuccess && blocks > 1) {
+        (void)hipGetLastError();
+        err = hipLaunchCooperativeKernel((const void *)fsel_kernel, dim3(1), dim3(FSEL_T), args, 0, s);
+    }
+    if (err != hipSuccess) {
+        (void)hipGetLastError();
+        eps_set_error("eps_select_compact: cooperative launch failed: %s", hipGetErrorString(err));
+        return EPS_ELAUNCH;
+    }
     return EPS_OK;
 }
 

@@ -318,7 +318,17 @@ extern "C" int eps_sort_pairs_by_u(const int64_t *keys, int64_t n, int32_t id_bi
     hipStream_t s = (hipStream_t)stream;
     int64_t *swapped = (int64_t *)workspace;
     void *temp = (char *)workspace + sel_align((size_t)n * 8);
-    size_t temp_bytes = sel_by_u_temp_bytes(n);
+    size_t temp_bytes = (size_t)workspace_bytes - sel_align((size_t)n * 8);
+    {   // (the workspace was sized by a query over all 64 bits; the passes below sort narrower ranges -- ask rocPRIM about each of
+        //  them instead of trusting that its temporary storage does not depend on the range)
+        const unsigned ranges[3][2] = {{0u, (unsigned)id_bits}, {32u, 32u + (unsigned)id_bits}, {(unsigned)v_block_shift, (unsigned)id_bits}};
+        for (int r = 0; r < (v_block_shift > 0 && v_block_shift < id_bits ? 3 : 2); ++r) {
+            size_t need = 0;
+            (void)rocprim::radix_sort_keys((void *)nullptr, need, (const int64_t *)nullptr, (int64_t *)nullptr, (size_t)n, ranges[r][0],
+                                           ranges[r][1], (hipStream_t)0);
+            EPS_REQUIRE(need <= temp_bytes, "eps_sort_pairs_by_u: the workspace is too small for a %u..%u-bit pass", ranges[r][0], ranges[r][1]);
+        }
+    }
     hipLaunchKernelGGL(sel_swap_kernel, dim3(sel_blocks(n)), dim3(256), 0, s, keys, n, out_by_u);
     // (LSD: v first, then u -- inside a run the rows N(v) are then streamed in ascending v, which is worth 0.4 of 3.3 ms to
     //  eps_rescore_runs on the ppa-like graph: neighbouring pairs read neighbouring rows)

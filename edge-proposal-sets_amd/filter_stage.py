@@ -260,9 +260,10 @@ def run(args) -> str:
     model.eval()
     ra_graph = train_only_graph(split_edge, data.num_nodes, device) if args.model == "resource_allocation" else None
 
+    _lib.warm_up_join()                  # (the background loads are done -- or given up on -- before anything is timed)
     watch = _Stopwatch(device)
     keep = int(args.keep_top)
-    if 0 < keep <= scan.MAX_K and data.adj_t.n_rows == data.adj_t.n_cols:
+    if 0 < keep <= scan.MAX_K and scan.scan_plausible(data.adj_t):
         # (the hubs-first copy first: the symmetry check of scan_available then reads the COPY's reverse positions -- the table
         #  the scan needs anyway -- instead of building one for the graph as labelled, 3-5 ms on a ppa-sized graph)
         scan.scan_graph(data.adj_t, build=True)

@@ -601,16 +601,71 @@ def scan_cuts(rowptr: torch.Tensor, col: torch.Tensor, bounds: torch.Tensor) -> 
     return out
 
 
-def scan_window_paths(rowptr, col, revpos, cuts) -> torch.Tensor:
-    """uint32 table [N, M] (int32 bits): two-hop half paths of every column per id window (per-graph table of the scan)."""
-    dev = _need_gpu(rowptr, col, revpos, cuts)
+def scan_window_paths(rowptr, col, revpos, cuts, heads: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """uint32 table [N, M] (int32 bits): two-hop half paths of every column per id window (per-graph table of the scan).
+    ``heads`` (``scan_heads``): the paths of the rows a column still walks."""
+    dev = _need_gpu(rowptr, col, revpos, cuts, heads)
     _chk(rowptr, torch.int64, "rowptr"); _chk(col, torch.int32, "col"); _chk(revpos, torch.int32, "revpos"); _chk(cuts, torch.int16, "cuts")
     n = rowptr.numel() - 1
+    _chk_heads(heads, n)
     out = torch.empty((n, scan_windows()), dtype=torch.int32, device=dev)
     with torch.cuda.device(dev):
-        _lib.check(_lib.load().eps_scan_window_paths(_ptr(rowptr), _ptr(col), _ptr(revpos), _ptr(cuts), n, _ptr(out), _stream(dev)),
-                   "eps_scan_window_paths")
+        _lib.check(_lib.load().eps_scan_window_paths(_ptr(rowptr), _ptr(col), _ptr(revpos), _ptr(cuts), n, _ptr(heads), _ptr(out),
+                                                     _stream(dev)), "eps_scan_window_paths")
     return out
+
+
+def _chk_heads(heads: Optional[torch.Tensor], n_nodes: int) -> None:
+    _chk(heads, torch.int32, "heads")
+    if heads is not None and tuple(heads.shape) != (n_nodes, 2):
+        raise _lib.EpsError("heads: expected the int32 [N, 2] table of scan_heads")
+
+
+HUB_MAX = 4096            # most hub rows eps_scan_hub_rows / eps_scan_refine take
+
+
+def scan_heads(rowptr, col, fx32: torch.Tensor, n_hub: int, budget: int) -> torch.Tensor:
+    """int32-bits [N, 2] (x_v, T_v): per column the longest prefix of its row with ids < ``n_hub`` whose screening weights sum
+    to T_v <= ``budget`` (table units) -- the rows eps_scan_screen does not walk under a bar (eps_scan_heads)."""
+    dev = _need_gpu(rowptr, col, fx32)
+    _chk(rowptr, torch.int64, "rowptr"); _chk(col, torch.int32, "col"); _chk(fx32, torch.int32, "fx32")
+    n = rowptr.numel() - 1
+    if fx32.numel() != n or not 0 <= int(budget) < 1 << 31:
+        raise _lib.EpsError("scan_heads: fx32 does not match the graph, or budget outside [0, 2^31)")
+    out = torch.empty((n, 2), dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.load().eps_scan_heads(_ptr(rowptr), _ptr(col), _ptr(fx32), n, int(n_hub), int(budget), _ptr(out), _stream(dev)),
+                   "eps_scan_heads")
+    return out
+
+
+def scan_hub_row_words(n_nodes: int) -> int:
+    return int(_lib.load().eps_scan_hub_row_words(int(n_nodes)))
+
+
+def scan_hub_rows(rowptr, col, n_hub: int) -> torch.Tensor:
+    """int32-bits [n_hub, words]: bit x of row w = "x is a neighbour of hub w" -- the adjacency rows of the first ``n_hub`` ids as
+    bitmaps over the id space (eps_scan_hub_rows; per-graph table)."""
+    dev = _need_gpu(rowptr, col)
+    _chk(rowptr, torch.int64, "rowptr"); _chk(col, torch.int32, "col")
+    n = rowptr.numel() - 1
+    out = torch.empty((max(int(n_hub), 1), scan_hub_row_words(n)), dtype=torch.int32, device=dev)[:int(n_hub)]
+    with torch.cuda.device(dev):
+        _lib.check(_lib.load().eps_scan_hub_rows(_ptr(rowptr), _ptr(col), n, int(n_hub), _ptr(out), _stream(dev)), "eps_scan_hub_rows")
+    return out
+
+
+def scan_refine(walked: "Survivors", heads, hubrows, fx32, rowptr, col, n_nodes: int, shift: int, out: "Survivors") -> None:
+    """Complete the walked sums of a launch with skipped heads (eps_scan_refine): every valid slot of ``walked`` gets its pair's
+    exact head term added; sums at or above ``out``'s bar are appended to ``out`` (compact, scores in 2^-shift units x 2^-shift)."""
+    dev = _need_gpu(heads, hubrows, fx32, rowptr, col)
+    _chk_heads(heads, n_nodes); _chk(hubrows, torch.int32, "hubrows"); _chk(fx32, torch.int32, "fx32")
+    _chk(rowptr, torch.int64, "rowptr"); _chk(col, torch.int32, "col")
+    if hubrows.dim() != 2 or hubrows.shape[1] != scan_hub_row_words(n_nodes) or fx32.numel() != n_nodes:
+        raise _lib.EpsError("scan_refine: hubrows / fx32 do not match the graph")
+    with torch.cuda.device(dev), _timed(dev, "scan_refine", walked.capacity):
+        _lib.check(_lib.load().eps_scan_refine(_ptr(walked.rec), _ptr(heads), _ptr(hubrows), hubrows.shape[0], _ptr(fx32), _ptr(rowptr),
+                                               _ptr(col), n_nodes, int(shift), _ptr(out.rec), _stream(dev)), "eps_scan_refine")
 
 
 def scan_screen_weights(fixw: torch.Tensor, shift: int):
@@ -685,25 +740,28 @@ def scan_row_sums(rowptr, col, fx32: torch.Tensor, bounds: torch.Tensor, n_nodes
     return ssum, smax, min_fx
 
 
-def scan_plan(rowptr, cuts, wpaths, ssum, smax, bounds, n_nodes: int, shift: int, variant: int, with_d: bool = False):
+def scan_plan(rowptr, cuts, wpaths, ssum, smax, bounds, n_nodes: int, shift: int, variant: int, with_d: bool = False,
+              heads: Optional[torch.Tensor] = None):
     """(pptr int32-bits [N + 1], records int32 [P, 4]): eps_scan_screen's per-graph plan table (eps_scan_plan, two passes).
-    ``with_d``: also the device word that holds the largest number of weight bits a packed / 16-bit direct piece drops."""
-    dev = _need_gpu(rowptr, cuts, wpaths, ssum, smax, bounds)
+    ``with_d``: also the device word that holds the largest number of weight bits a packed / 16-bit direct piece drops.
+    ``heads``: the head table ``wpaths`` was built with (a column's sum bound then leaves its skipped head out)."""
+    dev = _need_gpu(rowptr, cuts, wpaths, ssum, smax, bounds, heads)
+    _chk_heads(heads, n_nodes)
     _chk(rowptr, torch.int64, "rowptr"); _chk(cuts, torch.int16, "cuts"); _chk(wpaths, torch.int32, "wpaths")
     _chk(ssum, torch.int32, "ssum"); _chk(smax, torch.int32, "smax"); _chk(bounds, torch.int32, "bounds")
     lib = _lib.load()
     counts = torch.empty(n_nodes, dtype=torch.int32, device=dev)
     with torch.cuda.device(dev):
-        _lib.check(lib.eps_scan_plan(_ptr(rowptr), _ptr(cuts), _ptr(wpaths), _ptr(ssum), _ptr(smax), _ptr(bounds), n_nodes, int(shift),
-                                     int(variant), _ptr(counts), None, None, None, _stream(dev)), "eps_scan_plan")
+        _lib.check(lib.eps_scan_plan(_ptr(rowptr), _ptr(cuts), _ptr(wpaths), _ptr(ssum), _ptr(smax), _ptr(heads), _ptr(bounds), n_nodes,
+                                     int(shift), int(variant), _ptr(counts), None, None, None, _stream(dev)), "eps_scan_plan")
         pptr = torch.zeros(n_nodes + 1, dtype=torch.int32, device=dev)
         if n_nodes:
             torch.cumsum(counts, 0, dtype=torch.int32, out=pptr[1:])
         n_rec = int(pptr[-1].item()) if n_nodes else 0
         recs = torch.empty((max(n_rec, 1), 4), dtype=torch.int32, device=dev)
         d_used = torch.zeros(1, dtype=torch.int32, device=dev) if with_d else None
-        _lib.check(lib.eps_scan_plan(_ptr(rowptr), _ptr(cuts), _ptr(wpaths), _ptr(ssum), _ptr(smax), _ptr(bounds), n_nodes, int(shift),
-                                     int(variant), None, _ptr(pptr), _ptr(recs), _ptr(d_used), _stream(dev)), "eps_scan_plan")
+        _lib.check(lib.eps_scan_plan(_ptr(rowptr), _ptr(cuts), _ptr(wpaths), _ptr(ssum), _ptr(smax), _ptr(heads), _ptr(bounds), n_nodes,
+                                     int(shift), int(variant), None, _ptr(pptr), _ptr(recs), _ptr(d_used), _stream(dev)), "eps_scan_plan")
     return (pptr, recs, d_used) if with_d else (pptr, recs)
 
 
@@ -713,14 +771,21 @@ SCAN_VARIANT = 2          # default workgroup / table geometry of eps_scan_scree
 def scan_screen(rowptr, col, revpos, fx32, cuts, bounds, n_nodes: int, columns: torch.Tensor, shift: int, out: "Survivors",
                 status: torch.Tensor, variant: Optional[int] = None, val: Optional[torch.Tensor] = None,
                 node_w: Optional[torch.Tensor] = None, wpaths: Optional[torch.Tensor] = None,
-                ssum: Optional[torch.Tensor] = None, smax: Optional[torch.Tensor] = None, plan=None) -> None:
+                ssum: Optional[torch.Tensor] = None, smax: Optional[torch.Tensor] = None, plan=None,
+                heads: Optional[torch.Tensor] = None, batch_from: Optional[int] = None) -> None:
     """Launch eps_scan_screen over ``columns``; survivors (screening scores) accumulate in ``out``.  ``val`` / ``node_w``
     (float32 stored values / node weights): the weighted flavour (eps_scan_screen_weighted; ``fx32`` unused).
     ``ssum`` / ``smax`` (int32-bits [N] / [M + 1]; unit-valued graphs): per-node sums of fx32 over the row and their
     suffix maxima at the window boundaries -- they let pieces keep key and sum in one table word (include/eps_abi.h).
-    ``plan`` = (pptr, records) from ``scan_plan`` built with the same wpaths / ssum / smax / shift / variant."""
+    ``plan`` = (pptr, records) from ``scan_plan`` built with the same wpaths / ssum / smax / shift / variant.
+    ``heads`` (``scan_heads``; with the wpaths / plan built for it): the launch skips every column's head and ``out.val`` holds
+    the walked sums as raw bits -- ``scan_refine`` turns that list into the one a launch without heads reports.
+    ``batch_from``: ``columns[batch_from:]`` are handed out eight per draw (light columns at the end of a heaviest-first list)."""
     pptr, recs = plan if plan is not None else (None, None)
-    dev = _need_gpu(rowptr, col, revpos, fx32, cuts, bounds, columns, status, val, node_w, wpaths, ssum, smax, pptr, recs)
+    dev = _need_gpu(rowptr, col, revpos, fx32, cuts, bounds, columns, status, val, node_w, wpaths, ssum, smax, pptr, recs, heads)
+    _chk_heads(heads, n_nodes)
+    if heads is not None and (pptr is None or val is not None):
+        raise _lib.EpsError("scan_screen: a head table comes with the plan table built for it (unit-valued graphs)")
     _chk(pptr, torch.int32, "pptr"); _chk(recs, torch.int32, "plan")
     if pptr is not None and (val is not None or wpaths is None or pptr.numel() != n_nodes + 1):
         raise _lib.EpsError("scan_screen: the plan table does not match the graph (unit-valued graphs with wpaths only)")
@@ -746,9 +811,9 @@ def scan_screen(rowptr, col, revpos, fx32, cuts, bounds, n_nodes: int, columns: 
             ev[0].record(torch.cuda.current_stream(dev))
         if val is None:
             _lib.check(lib.eps_scan_screen(_ptr(rowptr), _ptr(col), _ptr(revpos), _ptr(fx32), _ptr(cuts), _ptr(wpaths), _ptr(ssum),
-                                           _ptr(smax), _ptr(pptr), _ptr(recs), _ptr(bounds), n_nodes,
-                                           col.numel(), _ptr(columns), columns.numel(), int(shift), variant, _ptr(out.rec), _ptr(status),
-                                           _stream(dev)), "eps_scan_screen")
+                                           _ptr(smax), _ptr(pptr), _ptr(recs), _ptr(heads), _ptr(bounds), n_nodes,
+                                           col.numel(), _ptr(columns), columns.numel(), -1 if batch_from is None else int(batch_from),
+                                           int(shift), variant, _ptr(out.rec), _ptr(status), _stream(dev)), "eps_scan_screen")
         else:
             _lib.check(lib.eps_scan_screen_weighted(_ptr(rowptr), _ptr(col), _ptr(val), _ptr(revpos), _ptr(node_w), _ptr(cuts),
                                                     _ptr(wpaths), _ptr(bounds), n_nodes, col.numel(), _ptr(columns), columns.numel(), int(shift),
@@ -858,9 +923,6 @@ def kth_largest_dist(x: torch.Tensor, k: int, world: int = 1) -> torch.Tensor:
     return out
 
 
-_SEL_STATE = {}
-
-
 def select_compact(keys: Optional[torch.Tensor], vals: torch.Tensor, k: int, count_ptr: Optional[int] = None, mode: int = 0,
                    params=(0.0, 0.0, 0.0), compact: bool = True, room: Optional[int] = None):
     """Radix select + threshold + compaction of a list on ONE device in one launch (eps_select_compact; the sharded job-wide
@@ -876,10 +938,9 @@ def select_compact(keys: Optional[torch.Tensor], vals: torch.Tensor, k: int, cou
     n = vals.numel()
     lib = _lib.load()
     words = (int(lib.eps_select_compact_workspace_bytes()) + 7) // 8
-    # (one state per call, from a small ring per device: a state must stay untouched until the stream has passed its launch)
-    ring = _SEL_STATE.setdefault((dev.type, dev.index), {"buf": torch.empty(16 * words, dtype=torch.int64, device=dev), "i": 0})
-    ring["i"] = (ring["i"] + 1) % 16
-    state = ring["buf"][ring["i"] * words:(ring["i"] + 1) * words]
+    # (one state per call, from the caching allocator: stream-ordered -- the block is handed out again only behind this launch on
+    #  this stream, whatever other streams or however many calls are pending; r04's ring of 16 per device was neither)
+    state = torch.empty(words, dtype=torch.int64, device=dev)
     kth = torch.empty(2, dtype=torch.float32, device=dev)
     out_k = out_v = n_out = None
     if compact:

@@ -102,6 +102,97 @@ def sweep_schedule(args):
     return index_ends
 
 
+def _default_out_name(args) -> str:
+    suffix = ("_onlys" if args.only_supervision else "_alsos" if args.also_supervision else
+              "_validproposal" if args.valid_proposal else "")
+    return f"{args.dataset}_{args.model}{suffix}"
+
+
+def _load_proposals(args, split_edge) -> torch.Tensor:
+    """The proposal file of the filter stage (rank.py:214-257): float rows (u, v, score), best first."""
+    if not args.sorted_edge_path:
+        return torch.zeros(42, 2)
+    rows = torch.load(f"filtered_edges/{args.sorted_edge_path}")
+    print('sorted test edges', rows.size())
+    return splice_valid_proposals(rows, split_edge['valid']['edge']) if args.valid_proposal else rows
+
+
+_HEURISTIC_EVAL = {"adamic_ogb": test_adamic, "resource_allocation": test_resource_allocation}
+
+
+def _evaluate(args, model, data, split_edge, evaluator, device):
+    """{Hits@K: (train, valid, test)} of the model on the current graphs (the dispatch of rank.py:337-349)."""
+    if args.model == "katz":
+        raise NotImplementedError("katz (sparse inverse) is outside the accelerated path")
+    if args.model in _HEURISTIC_EVAL:
+        return _HEURISTIC_EVAL[args.model](model, data, split_edge, evaluator, args.batch_size, args, device)
+    return test(model, data, split_edge, evaluator, args.batch_size or (1 << 16), args, device)
+
+
+class _SweepPoint:
+    """One point of the sweep: the graphs with the ``index_end`` best proposals added (rank.py:294-314), the per-K loggers of its
+    runs, and -- per run -- the model-selection state: the MIDDLE K's validation score decides which checkpoint is kept
+    (rank.py:356-361) and which evaluation becomes the run's curve point (rank.py:376-379)."""
+
+    def __init__(self, args, index_end: int, ks, proposals, data, split_edge, ei_dev, ew_dev, device):
+        self.args, self.index_end = args, int(index_end)
+        self.select_key = f"Hits@{ks[1]}"
+        self.loggers = {f'Hits@{k}': Logger(args.runs, args) for k in ks}
+        extra = proposals[:self.index_end, :2].t().long()
+        assert extra.size(0) == 2 and extra.size(1) == self.index_end
+        if not args.only_supervision:
+            data.adj_t = add_edges(args.dataset, ei_dev, ew_dev, extra.to(device), data.num_nodes)
+        append_supervision(args, split_edge, extra)
+        data.full_adj_t = data.adj_t
+        if args.dataset in ("collab", "email", "reddit"):       # validation edges join the graph the TEST edges are scored on
+            with_valid = torch.cat([extra, to_undirected(split_edge['valid']['edge'].t())], dim=-1)
+            data.full_adj_t = add_edges(args.dataset, ei_dev, ew_dev, with_valid.to(device), data.num_nodes)
+        self.best_valid = 0
+
+    def start_run(self) -> None:
+        self.best_valid = 0
+
+    def record(self, run_i: int, results) -> None:
+        for key, triple in results.items():
+            self.loggers[key].add_result(run_i, triple)
+
+    def is_best_logged(self, results) -> bool:
+        """True when this LOGGED evaluation's selection score does not fall behind the run's best logged one (rank.py:352-361
+        looks at the score only on epochs it logs)."""
+        valid = results[self.select_key][1] if self.select_key in results else None
+        if valid is None or valid < self.best_valid:
+            return False
+        self.best_valid = valid
+        return True
+
+    def checkpoint_name(self, run_i) -> str:
+        return f'{self.args.out_name}|{self.args.sorted_edge_path.split(".")[0]}|{self.index_end}|{run_i}.pt'
+
+    def curve_point(self, run_i: int):
+        evals = 100 * torch.tensor(self.loggers[self.select_key].results[run_i])
+        best = evals[:, 1].argmax().item()
+        return [self.index_end, evals[best, 1], evals[best, 2]]
+
+    def print_run(self, run_i: int) -> None:
+        for key, lg in self.loggers.items():
+            print(key)
+            lg.print_statistics(run_i)
+
+    def print_all(self) -> None:
+        for key, lg in self.loggers.items():
+            print(key)
+            lg.print_statistics()
+
+
+def _print_epoch(results, run_i: int, epoch: int, loss: float) -> None:
+    for key, (train_hits, valid_hits, test_hits) in results.items():
+        print(key)
+        print(f'Run: {run_i + 1:02d}, Epoch: {epoch:02d}, Loss: {loss:.4f}, '
+              f'Train: {100 * train_hits:.2f}%, Valid: {100 * valid_hits:.2f}%, '
+              f'Test: {100 * test_hits:.2f}%')
+    print('---')
+
+
 def run(args):
     args = default_model_configs(args)
     print(args)
@@ -114,13 +205,7 @@ def run(args):
     Path("models").mkdir(exist_ok=True)
     assert not (args.only_supervision and args.also_supervision)
     if args.out_name is None:
-        args.out_name = args.dataset + "_" + str(args.model)
-        if args.only_supervision:
-            args.out_name += "_onlys"
-        elif args.also_supervision:
-            args.out_name += "_alsos"
-        elif args.valid_proposal:
-            args.out_name += "_validproposal"
+        args.out_name = _default_out_name(args)
 
     edge_index, edge_weight, split_edge, data = get_data(args)
     if args.gen_dataset_only:
@@ -130,102 +215,57 @@ def run(args):
     data = data.to(device)
     model = build_model(args, data, device)
     print(f'using model {model}')
-    evaluator = evaluators[args.dataset]
-    K = hits[args.dataset]
-    print("Evaluating at hits: ", K)
-
-    if args.sorted_edge_path:
-        sorted_test_edges = torch.load(f"filtered_edges/{args.sorted_edge_path}")
-        print('sorted test edges', sorted_test_edges.size())
-        if args.valid_proposal:
-            sorted_test_edges = splice_valid_proposals(sorted_test_edges, split_edge['valid']['edge'])
-    else:
-        sorted_test_edges = torch.zeros(42, 2)
-
+    evaluator, ks = evaluators[args.dataset], hits[args.dataset]
+    print("Evaluating at hits: ", ks)
+    proposals = _load_proposals(args, split_edge)
     index_ends = sweep_schedule(args)
     print(f"Scheduled extra edges sweep: {index_ends} x {args.runs}")
-    use_params = sum(p.numel() for p in model.parameters() if p.requires_grad) > 0
-    trained = use_params and not args.load_model     # rank.py:317-333: reset + train every run
-    if use_params and args.load_model:
+
+    # what a run does with the model: heuristics are evaluated once; a parametrised model is trained from scratch every run
+    # (rank.py:317-333) unless --load_model brings its weights, in which case it is evaluated once as well
+    has_params = sum(p.numel() for p in model.parameters() if p.requires_grad) > 0
+    trains = has_params and not args.load_model
+    if has_params and args.load_model:
         model.load_state_dict(torch.load(args.load_model, map_location=device))
+    if not has_params:
+        args.epochs = 1
+    n_epochs = (args.epochs or 1) if trains or not has_params else 1
     ei_dev, ew_dev = edge_index.to(device), edge_weight.to(device)
+    _lib.warm_up_join()
 
     curves = []
     for index_end in index_ends:
-        loggers = {f'Hits@{k}': Logger(args.runs, args) for k in K}
         print('---------------------')
         print(f'Using {index_end} highest scoring edges')
         print('---------------------')
-        extra_edges = sorted_test_edges[:int(index_end), :2].t().long()
-        assert extra_edges.size(0) == 2 and extra_edges.size(1) == index_end
-        if not args.only_supervision:
-            data.adj_t = add_edges(args.dataset, ei_dev, ew_dev, extra_edges.to(device), data.num_nodes)
-        append_supervision(args, split_edge, extra_edges)
-        if args.dataset in ["collab", "email", "reddit"]:
-            val_edge_index = to_undirected(split_edge['valid']['edge'].t())
-            full_extra_edges = torch.cat([extra_edges, val_edge_index], dim=-1)
-            data.full_adj_t = add_edges(args.dataset, ei_dev, ew_dev, full_extra_edges.to(device), data.num_nodes)
-        else:
-            data.full_adj_t = data.adj_t
-
-        curve_point = []
+        point = _SweepPoint(args, index_end, ks, proposals, data, split_edge, ei_dev, ew_dev, device)
         for run_i in range(args.runs):
+            point.start_run()
             optimizer = None
-            if not use_params:
-                model.reset_parameters()
-                args.epochs = 1
-            elif trained:
-                model.reset_parameters()                                    # rank.py:318
-                optimizer = torch.optim.Adam(model.parameters(), lr=args.lr)   # rank.py:322
-            highest_eval = 0
-            for epoch in range(1, 1 + (args.epochs or 1)):
-                loss = -1
-                if trained:
-                    loss = train(model, data, args.dataset, split_edge, optimizer, args.batch_size, use_params, args.model,
-                                 device)
-                if epoch % args.eval_steps == 0:
-                    if args.model == "adamic_ogb":
-                        results = test_adamic(model, data, split_edge, evaluator, args.batch_size, args, device)
-                    elif args.model == "resource_allocation":
-                        results = test_resource_allocation(model, data, split_edge, evaluator, args.batch_size, args,
-                                                           device)
-                    elif args.model == "katz":
-                        raise NotImplementedError("katz (sparse inverse) is outside the accelerated path")
-                    else:
-                        results = test(model, data, split_edge, evaluator, args.batch_size or (1 << 16), args, device)
-                    for key, result in results.items():
-                        loggers[key].add_result(run_i, result)
-                    if epoch % args.log_steps == 0:
-                        for key, result in results.items():
-                            train_hits, valid_hits, test_hits = result
-                            if key == f"Hits@{K[1]}" and valid_hits >= highest_eval:
-                                highest_eval = valid_hits
-                                if args.save_models and use_params:          # rank.py:356-361
-                                    fn = f'{args.out_name}|{args.sorted_edge_path.split(".")[0]}|{index_end}|{run_i}.pt'
-                                    torch.save(model.state_dict(), os.path.join('models', fn))
-                            print(key)
-                            print(f'Run: {run_i + 1:02d}, Epoch: {epoch:02d}, Loss: {loss:.4f}, '
-                                  f'Train: {100 * train_hits:.2f}%, Valid: {100 * valid_hits:.2f}%, '
-                                  f'Test: {100 * test_hits:.2f}%')
-                        print('---')
-                if use_params and not trained:
-                    break  # a loaded model is evaluated once
-            for key in loggers.keys():
-                print(key)
-                loggers[key].print_statistics(run_i)
-                if key == f"Hits@{K[1]}":                          # model selection on the MIDDLE K (rank.py:376)
-                    result = 100 * torch.tensor(loggers[key].results[run_i])
-                    argmax = result[:, 1].argmax().item()
-                    curve_point = [index_end, result[argmax, 1], result[argmax, 2]]
+            if trains or not has_params:
+                model.reset_parameters()                                          # rank.py:318
+            if trains:
+                optimizer = torch.optim.Adam(model.parameters(), lr=args.lr)      # rank.py:322
+            for epoch in range(1, n_epochs + 1):
+                loss = (train(model, data, args.dataset, split_edge, optimizer, args.batch_size, has_params, args.model, device)
+                        if trains else -1)
+                if epoch % args.eval_steps:
+                    continue
+                results = _evaluate(args, model, data, split_edge, evaluator, device)
+                point.record(run_i, results)
+                if epoch % args.log_steps == 0:
+                    if point.is_best_logged(results) and args.save_models and has_params:
+                        torch.save(model.state_dict(), os.path.join('models', point.checkpoint_name(run_i)))
+                    _print_epoch(results, run_i, epoch, loss)
+            point.print_run(run_i)
+            curve_point = point.curve_point(run_i)
             stamp = datetime.now().strftime('%Y-%m-%d-%H:%M:%S')
             filename = f'{args.out_name}|{args.sorted_edge_path.split(".")[0]}|{index_end}|{stamp}.pt'
             print(curve_point)
             print("Saving curve to ", filename)
             torch.save(curve_point, os.path.join('curves', filename))
             curves.append(curve_point)
-        for key in loggers.keys():
-            print(key)
-            loggers[key].print_statistics()
+        point.print_all()
     return curves
 
 

@@ -42,6 +42,12 @@ RELABEL_MIN_NODES = 100_000  # graphs at least this large are scanned under hubs
 ONE_PASS = True            # score with the one-pass piece kernel (csrc/scan_pieces.hip) where the graph qualifies, else eps_filter_scan
 _PIECE_SLACK = 8192 * 1024 + 65536   # eps_scan_screen hands slots out in chunks of <= 32768 per workgroup (<= 1024 workgroups)
 MAX_SCREEN_SHIFT = 30
+HEADS = True               # under a bar a column does not walk its heaviest hub rows (csrc/scan_heads.hip; see head_tables)
+HEAD_BETA = 0.5            # ... as long as their screening weights sum to at most this share of the bar
+HEAD_KEEP = (0.3, 0.58)    # a head table is used again while its budget stays within this range of the current bar
+HEAD_LIST = 6              # the walked list (slots that pass at bar - T_v) is sized this many times the survivor list
+HEAD_CACHE = 4             # head tables kept per (graph, weight table)
+BATCH_PATHS = 1 << 13      # columns of a heaviest-first list with fewer half paths are handed out eight per ticket (see batch_from)
 
 
 def scan_available(g: CSRGraph) -> bool:
@@ -49,10 +55,15 @@ def scan_available(g: CSRGraph) -> bool:
     column of its larger endpoint -- on an asymmetric pattern that would silently be a different sum).  Unit values: either
     kernel.  Stored values (collab, rank.py:32-35): positive, symmetric like the pattern, and a graph the piece kernel suits
     (``screen_variant``) -- eps_filter_scan has no weighted flavour."""
-    if not (g.device.type == "cuda" and g.n_rows == g.n_cols and 0 < g.n_rows <= ops.filter_scan_max_nodes()
-            and g.nnz() < 1 << 30 and is_symmetric(g)):       # (any id space: wider ones are scanned in id windows)
+    if not (scan_plausible(g) and is_symmetric(g)):           # (any id space: wider ones are scanned in id windows)
         return False
     return g.val is None or (values_symmetric(g) and screen_variant(scan_graph(g)[0]) is not None)
+
+
+def scan_plausible(g: CSRGraph) -> bool:
+    """The cheap part of ``scan_available`` (no table, no kernel): on the GPU, square, within the node and entry limits.  What a
+    caller checks BEFORE it pays for the hubs-first copy of a graph the scan would refuse anyway."""
+    return bool(g.device.type == "cuda" and g.n_rows == g.n_cols and 0 < g.n_rows <= ops.filter_scan_max_nodes() and g.nnz() < 1 << 30)
 
 
 def scan_usable(g: CSRGraph, node_w: torch.Tensor) -> bool:
@@ -239,13 +250,15 @@ def screen_shift(bound: float, max_deg: int, weighted: bool = False) -> int:
 
 class Screen:
     """What a launch of the piece kernel and the exact re-scoring of its survivors need, for one (graph, weight table)."""
-    __slots__ = ("fx32", "shift", "fixw", "val", "node_w", "usable", "ssum", "smax", "plan", "d_used", "w_min")
+    __slots__ = ("fx32", "shift", "fixw", "val", "node_w", "usable", "ssum", "smax", "plan", "d_used", "w_min", "heads", "head_cur")
 
     def __init__(self, fx32, shift, fixw, val, node_w, usable, ssum=None, smax=None, plan=None, d_used=0, w_min=0.0):
         self.fx32, self.shift, self.fixw, self.val, self.node_w, self.usable = fx32, shift, fixw, val, node_w, usable
         self.ssum, self.smax, self.plan = ssum, smax, plan
         self.d_used = d_used         # most low bits any packed / 16-bit direct piece drops from the screening weights
         self.w_min = w_min           # smallest weight of a node that can be a common neighbour (0: no relative bound)
+        self.heads = {}              # budget (table units) -> HeadTables (see head_tables)
+        self.head_cur = None         # the HeadTables the last launch under a bar used
 
     def lower_bound(self, s: torch.Tensor, max_deg: int) -> torch.Tensor:
         """A lower bound of the exact score of a pair whose screening score is ``s`` (monotone in s).  A path's screening term
@@ -257,10 +270,12 @@ class Screen:
         a, b = self.lower_params(max_deg)
         return torch.maximum(s - a, s * b)
 
-    def lower_params(self, max_deg: int):
+    def lower_params(self, max_deg: int, d_used: Optional[int] = None):
         """(a, b) with lower_bound(s) = max(s - a, s * b) -- the form eps_select_compact evaluates on the device (mode 2).
-        b = 0 without a relative bound: scores are sums of non-negative weights, so 0 is a floor under all of them."""
-        unit = (2.0 ** self.d_used + 1.0) * 2.0 ** -self.shift * (2.0 if self.val is not None else 1.0)
+        b = 0 without a relative bound: scores are sums of non-negative weights, so 0 is a floor under all of them.
+        ``d_used``: the dropped bits of the plan the launch ran with (a head table has its own plan)."""
+        d_used = self.d_used if d_used is None else max(int(d_used), 0)
+        unit = (2.0 ** d_used + 1.0) * 2.0 ** -self.shift * (2.0 if self.val is not None else 1.0)
         b = 0.0
         if self.w_min > 0.0 and unit < self.w_min:
             b = 1.0 - 1.00001 * unit / self.w_min                                     # (w_min itself is exact to 2^-40)
@@ -319,6 +334,69 @@ def screen_weights(g0: CSRGraph, g: CSRGraph, perm, node_w: torch.Tensor) -> Scr
     return g0.weight_cached("screen_weights" if perm is None else "screen_weights_relabelled", node_w, build)
 
 
+class HeadTables:
+    """What a launch with skipped heads brings (one set per budget): the head table, the window paths and the plan of the rows
+    that are still walked, and that plan's dropped weight bits."""
+    __slots__ = ("budget", "heads", "wpaths", "plan", "d_used")
+
+    def __init__(self, budget, heads, wpaths, plan, d_used):
+        self.budget, self.heads, self.wpaths, self.plan, self.d_used = budget, heads, wpaths, plan, d_used
+
+
+HUB_TABLE_BYTES = 1 << 30   # the hub row bitmaps of a graph take at most this much
+
+
+def hub_rows(g: CSRGraph) -> torch.Tensor:
+    """int32-bits [n_hub, words], cached per graph: the adjacency rows of the first n_hub ids (the hubs, under hubs-first
+    labels) as bitmaps over the id space -- where eps_scan_refine looks a pair's skipped rows up."""
+    if "hub_rows" not in g._cache:
+        n_hub = min(ops.HUB_MAX, g.n_rows, HUB_TABLE_BYTES // (4 * ops.scan_hub_row_words(g.n_rows)))
+        g._cache["hub_rows"] = ops.scan_hub_rows(g.rowptr, g.col, n_hub)
+    return g._cache["hub_rows"]
+
+
+def head_budget(bar_units: float) -> int:
+    """Budget of a column's skipped head for a bar (both in table units): HEAD_BETA x bar, rounded down to four significant
+    bits -- bars that differ by a few per cent share a table."""
+    b = int(HEAD_BETA * bar_units)
+    if b <= 0:
+        return 0
+    drop = max(0, b.bit_length() - 4)
+    return (b >> drop) << drop
+
+
+def head_tables(g: CSRGraph, screen: Screen, budget: int) -> HeadTables:
+    """The tables of a launch whose columns skip heads of at most ``budget`` (table units), cached on the Screen: the head table
+    (eps_scan_heads), the window paths and the plan table of the walked rows.  ~1.5 ms on the ppa-like graph, once per bar
+    level; one host read (the plan's size and dropped bits)."""
+    if budget not in screen.heads:
+        n_hub = hub_rows(g).shape[0]
+        heads = ops.scan_heads(g.rowptr, g.col, screen.fx32, n_hub, budget)
+        bounds, cuts = screen_tables(g)
+        wp = ops.scan_window_paths(g.rowptr, g.col, reverse_positions(g), cuts, heads)
+        pptr, recs, d_word = ops.scan_plan(g.rowptr, cuts, wp, screen.ssum, screen.smax, bounds, g.n_rows, screen.shift, screen_variant(g),
+                                           with_d=True, heads=heads)
+        while len(screen.heads) >= HEAD_CACHE:
+            screen.heads.pop(next(iter(screen.heads)))
+        screen.heads[budget] = HeadTables(budget, heads, wp, (pptr, recs), int(d_word.item()))
+    return screen.heads[budget]
+
+
+def _heads_for(g: CSRGraph, screen: Screen, bar) -> Optional[HeadTables]:
+    """The head tables for a launch under ``bar`` (1-element device tensor): the set the last launch used, without looking at the
+    bar -- the kernel itself refuses a head as heavy as the bar (status bit 2), and scan_topk compares budget and bar after
+    the step's one host read --, or, the first time, a set built for the bar (one host read of it)."""
+    if screen.head_cur is None:
+        b = float(bar)
+        if not (b > 0.0 and b < float("inf")):
+            return None
+        budget = head_budget(b * 2.0 ** screen.shift)
+        if budget <= 0:
+            return None
+        screen.head_cur = head_tables(g, screen, budget)
+    return screen.head_cur
+
+
 REWALK_MAX = 0.25            # largest share of re-walked paths (hash-partitioned passes) the one-pass kernel is chosen with
 
 
@@ -362,20 +440,58 @@ def one_pass_available(g: CSRGraph) -> bool:
     return screen_variant(g) is not None
 
 
-def _launch(g, fixw, columns, threshold, capacity, scores_only: bool = False, both: bool = False, screen=None) -> ops.Survivors:
-    """``screen`` (a Screen) -> the one-pass kernel (screening scores in ``val``), else eps_filter_scan (exact scores)."""
+def _launch(g, fixw, columns, threshold, capacity, scores_only: bool = False, both: bool = False, screen=None,
+            heads: Optional[HeadTables] = None, walked_capacity: int = 0) -> ops.Survivors:
+    """``screen`` (a Screen) -> the one-pass kernel (screening scores in ``val``), else eps_filter_scan (exact scores).
+    ``heads``: the launch skips the columns' heads (its list -- ``walked_capacity`` slots -- holds walked sums) and
+    eps_scan_refine completes them into the list that is returned: the same survivors and scores as without heads, compact;
+    ``walked_slots`` (device word) = slots the walked list handed out."""
     # (the piece kernel marks the unused slots of its reservations itself: no fill, readers stop at the slot counter)
     out = ops.Survivors(capacity, threshold, g.device, scores_only, both, prefill=screen is None)
+    out.walked_slots = None
     if screen is not None:
         out.status = torch.zeros(1, dtype=torch.int32, device=g.device)
     if columns.numel():
-        if screen is not None:
+        if screen is not None and heads is not None:
+            bounds, cuts = screen_tables(g)
+            walked = ops.Survivors(walked_capacity, threshold, g.device, prefill=False)
+            ops.scan_screen(g.rowptr, g.col, reverse_positions(g), screen.fx32, cuts, bounds, g.n_rows, columns, screen.shift, walked,
+                            out.status, screen_variant(g), None, None, heads.wpaths, screen.ssum, screen.smax, heads.plan, heads.heads,
+                            batch_from(g, columns))
+            ops.scan_refine(walked, heads.heads, hub_rows(g), screen.fx32, g.rowptr, g.col, g.n_rows, screen.shift, out)
+            out.rec[4:5].copy_(walked.rec[4:5])              # (candidates the walk touched)
+            out.walked_slots = walked.rec[1:2]
+        elif screen is not None:
             bounds, cuts = screen_tables(g)
             ops.scan_screen(g.rowptr, g.col, reverse_positions(g), screen.fx32, cuts, bounds, g.n_rows, columns, screen.shift, out,
-                            out.status, screen_variant(g), screen.val, screen.node_w, window_paths(g), screen.ssum, screen.smax, screen.plan)
+                            out.status, screen_variant(g), screen.val, screen.node_w, window_paths(g), screen.ssum, screen.smax, screen.plan,
+                            None, batch_from(g, columns))
         else:
             ops.filter_scan(g.rowptr, g.col, reverse_positions(g), fixw, g.n_rows, columns, out, max_degree(g), window_splits(g))
     return out
+
+
+def batch_from(g: CSRGraph, columns: torch.Tensor) -> int:
+    """How many columns of the heaviest-first list ``columns`` are handed to the workgroups one at a time: those with at least
+    BATCH_PATHS half paths; the light rest goes eight per draw (the hand-out is an atomic on one device word, ~11 ns each, and a
+    light column is ~10 us of one of 1024 workgroups: singly, the tickets would set the pace).  Cached per list (one host read)."""
+    key = ("batch_from", columns.data_ptr(), columns.numel(), BATCH_PATHS)
+    if key not in g._cache:
+        g._cache[key] = int((half_paths(g)[columns.long()] >= BATCH_PATHS).sum().item()) if columns.numel() else 0
+    return g._cache[key]
+
+
+def candidate_count(g: CSRGraph, screen: Optional[Screen], fixw, rank: int = 0, world: int = 1) -> int:
+    """Unordered 2-hop non-edges of the whole graph (cached): one scan that reports nothing (bar +inf, no skipped heads) and
+    counts.  A launch with skipped heads counts only the candidates its walk touches; this is the number the filter covers."""
+    if "n_candidates" not in g._cache:
+        res = _launch(g, fixw, shard_columns(g, rank, world), float("inf"), 1 << 16, screen=screen)
+        n = res.rec[4:5].clone()
+        if world > 1:
+            from . import dist as epd
+            n = epd.all_reduce_sum_(n)
+        g._cache["n_candidates"] = int(n.item())
+    return g._cache["n_candidates"]
 
 
 def rescore_exact(g: CSRGraph, screen: Screen, keys: torch.Tensor, bar):
@@ -589,11 +705,16 @@ def scan_topk(g: CSRGraph, node_w: torch.Tensor, k: int, rank: int = 0, world: i
     ``rows_on`` (world > 1): the rank that wants the rows -- every other rank returns (None, None) and the ordered chunks travel
     to that rank alone (the proposal file is written by one rank); default: every rank gets them.
 
-    Per call, in the steady state (tables cached on the graph): sample launch -> bar (device) -> main launch -> job-wide
-    ceil(k/2)-th best survivor score (device, ops.kth_largest_dist) -> compaction of the survivors at or above it -> ONE host
-    read (slot counter, candidate count, selected count, cut; all-gathered when world > 1) -> the selected pairs of all ranks
-    (about k / 2 / world each) gathered -> mirrored + ordered (ops.select_rows)."""
-    if relabel and g.device.type == "cuda" and g.n_rows == g.n_cols:
+    Per call, in the steady state (tables cached on the graph): sample launch -> bar (device; the lowest of the ranks' own
+    estimates) -> main launch, under a bar with skipped heads + eps_scan_refine -> LOCAL pre-filter of this rank's list (its
+    k2 / world-th best screening score, lowered to what such a score can be worth exactly; no collective) -> exact re-scoring of
+    what passed -> job-wide cut (the ceil(k/2)-th best exact score: one launch on one rank, all-reduced histograms on a job) +
+    compaction -> ONE host read of a status vector (slots, candidates, selected, cut, kernel status, the rank's pre-filter
+    threshold, walked slots, the bar; all-gathered when world > 1), which VERIFIES the step: enough survivors, no list overflow,
+    the cut at or above every rank's pre-filter threshold, usable heads -- else the launch repeats with what was learnt -> the
+    selected pairs of all ranks gathered -> mirrored + ordered, the ordering dealt over the ranks by score range, the rows sent
+    to ``rows_on`` alone (ops.select_rows, _ordered_rows_distributed)."""
+    if relabel and scan_plausible(g):
         scan_graph(g, build=True)        # (first: the symmetry check below then reads the copy's table, the one the scan needs)
     if not scan_available(g):
         raise ops._lib.EpsError("scan_topk: graph not supported by eps_filter_scan (see scan_available)")
@@ -630,10 +751,17 @@ def scan_topk(g: CSRGraph, node_w: torch.Tensor, k: int, rank: int = 0, world: i
     wanted = (2 * total_half if bar is None else int(2 * SAFETY * k)) // world
     capacity = _capacity(wanted, slack)
     neg_inf = torch.full((1,), float("-inf"), device=dev)
+    # skipped heads (csrc/scan_heads.hip): unit-valued graphs with a plan table, under a bar
+    use_heads = HEADS and screen is not None and screen.plan is not None and screen.ssum is not None and g.val is None
+    head_list, head_trouble = HEAD_LIST, 0
+    ht = None
     while True:
         if launches >= MAX_LAUNCHES:
             raise ops._lib.EpsError(f"scan_topk: no usable bar after {launches} launches (k = {k}, capacity {capacity})")
-        res = _launch(g, fixw, mine, float("-inf") if bar is None else bar, capacity, both=True, screen=screen)
+        ht = _heads_for(g, screen, bar) if use_heads and bar is not None else None
+        walked_cap = max(1, min(int(head_list * capacity), ops.SURVIVOR_SLOTS_MAX)) if ht is not None else 0
+        res = _launch(g, fixw, mine, float("-inf") if bar is None else bar, capacity, both=True, screen=screen, heads=ht,
+                      walked_capacity=walked_cap)
         launches += 1
         l_keys, l_vals = res.key, res.val
         status, pre_thr = None, None
@@ -648,7 +776,7 @@ def scan_topk(g: CSRGraph, node_w: torch.Tensor, k: int, rank: int = 0, world: i
             # (k2 / world)-th best sits at the job's k2-th best, and lower() leaves ~4 % of margin; world = 1: the r03 rule.
             # One launch: select + threshold + compaction, bounded by the list's slot counter (no collective, no pass over the
             # list's unused capacity).
-            a, b = screen.lower_params(max_degree(g))
+            a, b = screen.lower_params(max_degree(g), None if ht is None else ht.d_used)
             k_pre = 0 if rescore_all else (k2 + world - 1) // world
             # (the outputs hold 2 x k_pre pairs -- lower() keeps ~10 % more than k_pre -- not a copy of the list's worst-case size;
             #  a level of tied scores at the threshold may hold more: then the call is repeated with room for all of them)
@@ -670,21 +798,42 @@ def scan_topk(g: CSRGraph, node_w: torch.Tensor, k: int, rank: int = 0, world: i
         zero = torch.zeros(1, dtype=torch.int64, device=dev)
         st = torch.cat([res.rec[1:2], res.rec[4:5], n_sel, cut.view(torch.int32).to(torch.int64),     # slots, candidates, selected, cut bits,
                         status.to(torch.int64) if status is not None else zero,                          # kernel status,
-                        pre_thr.view(torch.int32).to(torch.int64) if pre_thr is not None else zero])     # pre-filter threshold bits
+                        pre_thr.view(torch.int32).to(torch.int64) if pre_thr is not None else zero,      # pre-filter threshold bits,
+                        res.walked_slots if res.walked_slots is not None else zero,                      # slots of the walked list,
+                        bar.view(torch.int32).to(torch.int64) if ht is not None else zero])              # the bar's bits (head launches)
         if world > 1:
             from . import dist as epd
             table = torch.stack(epd.all_gather_list(st)).tolist()                          # the host read of the step
         else:
             table = [st.tolist()]
         slots_r, ncand_r, nsel_r = [t[0] for t in table], [t[1] for t in table], [t[2] for t in table]
-        if any(t[4] for t in table):
+        if any(t[4] & ~4 for t in table):
             raise ops._lib.EpsError("scan_topk: eps_scan_screen reported a full hash table (status %s)" % [t[4] for t in table])
+        if ht is not None:
+            # The head table was taken without looking at the bar.  A head as heavy as the bar (status bit 2: the bar fell since the
+            # table was built) or a walked list that overflowed: the launch is void -- a table for THIS bar is built (head_cur
+            # dropped: the next _heads_for reads the bar), the list grows; twice in a row: this call goes on without heads.
+            bar_units = _f32_from_bits(table[0][7]) * 2.0 ** screen.shift
+            void = any(t[4] & 4 for t in table) or any(t[6] > walked_cap for t in table)
+            if void or not HEAD_KEEP[0] * bar_units <= ht.budget <= HEAD_KEEP[1] * bar_units:
+                screen.head_cur = None                       # (a budget out of range only costs time: the NEXT launch rebuilds)
+            if void:
+                head_trouble += 1
+                head_list *= 2
+                use_heads = head_trouble < 2
+                launches -= 1                                # (the repeat is the same launch again, not a corrected bar)
+                if launches + 2 > MAX_LAUNCHES:
+                    raise ops._lib.EpsError("scan_topk: launches with skipped heads kept failing")
+                continue
         n_cand_all, n_sel_all = sum(ncand_r), sum(nsel_r)
         cut_is_inf = (table[0][3] & 0xFFFFFFFF) == 0xFF800000
-        if screen is not None and not rescore_all and not cut_is_inf and not any(sl > capacity for sl in slots_r):
-            # (a cut of -inf means fewer than k2 pairs survived at all: the bar is lowered below, nothing to verify here)
-            # the pre-filter was sound iff the cut reaches every rank's threshold (floats compared through their bits on the host)
-            cut_f = _f32_from_bits(table[0][3])
+        if screen is not None and not rescore_all and not any(sl > capacity for sl in slots_r):
+            # the pre-filter was sound iff the cut reaches every rank's threshold (floats compared through their bits on the host).
+            # A cut of -inf -- fewer than k2 re-scored pairs job-wide -- is NOT exempt: with uneven shards one rank's
+            # pre-filter may have held back pairs that belong to the k2 best while another rank had too few to fill its share, so
+            # any finite threshold above a -inf cut sends the step round again with everything re-scored.  Only when no rank
+            # filtered at all (every threshold -inf) does -inf mean "fewer than k2 pairs survived": the bar is lowered below.
+            cut_f = float("-inf") if cut_is_inf else _f32_from_bits(table[0][3])
             if any(cut_f < _f32_from_bits(t[5]) for t in table):
                 rescore_all = True         # (never seen with round-robin shards: a rank's list would have to sit far above the job's)
                 launches -= 1              # (the repeat is the same launch again, not a corrected bar)
@@ -700,7 +849,9 @@ def scan_topk(g: CSRGraph, node_w: torch.Tensor, k: int, rank: int = 0, world: i
             wanted *= 4
             capacity = _capacity(wanted, slack)
             continue
-        if bar is not None and n_sel_all < min(k2, n_cand_all):
+        # (a launch with skipped heads counts the candidates its walk touched, not all of them: fewer than k2 selected under a bar
+        #  then always means "lower the bar" -- the launch without one counts them all)
+        if bar is not None and n_sel_all < (k2 if ht is not None else min(k2, n_cand_all)):
             # fewer than k above the bar: lower it (a quarter of the sample rank each time, then no bar at all)
             bar = None if launches > 3 else estimate_bar(g, fixw, k, safety=SAFETY * 8 ** (launches - 1), rank=rank, world=world,
                                                          screen=screen)
@@ -723,7 +874,19 @@ def scan_topk(g: CSRGraph, node_w: torch.Tensor, k: int, rank: int = 0, world: i
     if stats is not None:
         # survivors: DIRECTED rows at or above the job-wide cut (what the selection orders); survivor_slots: list slots the
         # launches handed out (chunks: holes included); bar: None or a 1-element device tensor (float(bar) reads it)
-        stats.update(candidates=2 * n_cand_all, launches=launches, survivors=2 * n_sel_all,
+        # candidates: DIRECTED 2-hop non-edges the filter covered.  A launch with skipped heads only counts those its walk touched
+        # (`touched`); the exact number then comes from `candidate_count` (one counting scan per graph, cached) unless the caller
+        # put count=False into ``stats`` (then candidates = None).
+        touched = 2 * n_cand_all
+        if ht is None:
+            n_all = touched
+            if world == 1:
+                g._cache.setdefault("n_candidates", n_cand_all)
+        else:
+            n_all = 2 * candidate_count(g, screen, fixw, rank, world) if stats.get("count", True) else None
+        stats.update(candidates=n_all, touched=touched, launches=launches, survivors=2 * n_sel_all, heads=ht is not None,
+                     head_budget=None if ht is None else ht.budget * 2.0 ** -screen.shift,
+                     walked_slots=sum(t[6] for t in table) if ht is not None else None,
                      survivor_slots=sum(min(s_, capacity) for s_ in slots_r), bar=bar)
     if keys is None:
         return None, None

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define EPS_ABI_VERSION 5   /* 2: eps_col_sums / eps_node_weights_f64 signatures (r02); 3: 64-bit survivor count, eps_scan_* (r03); 4: eps_scan_screen takes ssum / smax; 5: eps_select_compact, eps_scan_screen marks unused slots itself (r04) */
+#define EPS_ABI_VERSION 6   /* 6: skipped heads -- eps_scan_heads / _hub_rows / _refine; eps_scan_window_paths / _plan / _screen take a head table (r05); 2: eps_col_sums / eps_node_weights_f64 signatures (r02); 3: 64-bit survivor count, eps_scan_* (r03); 4: eps_scan_screen takes ssum / smax; 5: eps_select_compact, eps_scan_screen marks unused slots itself (r04) */
 
 #define EPS_OK 0
 #define EPS_EINVAL (-1)   /* bad argument (null pointer, negative size, unsupported shape) */
@@ -251,7 +251,7 @@ int eps_filter_scan(const int64_t *rowptr, const int32_t *col, const int32_t *re
  *                           caller's window boundaries bounds[0 .. M] (bounds[0] = 0, bounds[M] = n_nodes, non-decreasing;
  *                           windows of equal stored-entry mass balance the pieces).  Per-graph table.
  *   eps_scan_window_paths : wpaths[v * M + k] = two-hop half paths of column v that end in id window k (uint32; exact, from
- *                           the cut table).  Per-graph table, optional: with NULL the scan sums them per column itself.
+ *                           the cut table).  Per-graph table; mandatory since v6 (a launch used to sum them itself without).
  *   eps_scan_screen_weights: fx32[i] = max(1, ceil(fixw[i] / 2^(40 - shift))); *bad (device word, cleared by the call):
  *                           bit 1 a negative weight, bit 2 a weight that does not fit 32 bits.  shift must keep every
  *                           screening sum of the graph below 2^31 (bit 31 of a table word flags a known edge) (the caller's score bound: eps_amd.scan.screen_shift).
@@ -264,6 +264,9 @@ int eps_filter_scan(const int64_t *rowptr, const int32_t *col, const int32_t *re
  *                           sums provably fit next to their key bits keep key and sum in ONE table word (twice the
  *                           candidates per piece); their weights drop up to shift - 8 low bits, rounded up (still an upper
  *                           bound; out->val stays in units of 2^-shift);
+ *                           batch_from: columns[0 .. batch_from) are handed to the workgroups one at a time, the rest eight per
+ *                           draw (the hand-out is an atomic on one word, ~11 ns each: light columns -- give the list
+ *                           heaviest first -- would wait for it); n_columns or more, or negative: one at a time throughout;
  *                           variant 0: 512 threads / 8192-slot table (2 workgroups per CU), 1: 1024 / 16384 (1), 2: 256 / 4096 (4);
  *                           *status (device word, cleared by the call): value 2 (bit 1) = a table filled up (results
  *                           invalid; cannot happen within the planner's piece limits: a backstop). */
@@ -281,12 +284,38 @@ int eps_scan_cuts(const int64_t *rowptr, const int32_t *col, int64_t n_nodes, co
                   void *stream);
 int eps_scan_screen_weights(const int64_t *fixw, int64_t n, int32_t shift, uint32_t *fx32, uint32_t *bad, void *stream);
 int eps_scan_window_paths(const int64_t *rowptr, const int32_t *col, const int32_t *revpos, const uint16_t *cuts,
-                          int64_t n_nodes, uint32_t *wpaths, void *stream);
+                          int64_t n_nodes, const uint32_t *heads_or_null, uint32_t *wpaths, void *stream);
 int eps_scan_screen(const int64_t *rowptr, const int32_t *col, const int32_t *revpos, const uint32_t *fx32,
-                    const uint16_t *cuts, const uint32_t *wpaths_or_null, const uint32_t *ssum_or_null,
+                    const uint16_t *cuts, const uint32_t *wpaths, const uint32_t *ssum_or_null,
                     const uint32_t *smax_or_null, const uint32_t *pptr_or_null, const uint32_t *plan_or_null,
-                    const int32_t *bounds, int64_t n_nodes, int64_t nnz, const int32_t *columns, int64_t n_columns,
-                    int32_t shift, int32_t variant, eps_survivors *out, uint32_t *status, void *stream);
+                    const uint32_t *heads_or_null, const int32_t *bounds, int64_t n_nodes, int64_t nnz, const int32_t *columns,
+                    int64_t n_columns, int64_t batch_from, int32_t shift, int32_t variant, eps_survivors *out, uint32_t *status,
+                    void *stream);
+/* ---- skipped heads (r05; csrc/scan_heads.hip): half of all two-hop paths run through a few thousand hub rows whose weights are
+ * the smallest there are, so under a bar a column need not walk them (still filter.py:96-142 + :160-161 under --keep_top) ------
+ *   eps_scan_heads     : heads[2 v] = x_v, heads[2 v + 1] = T_v (uint32 pairs, 8-byte aligned): the longest prefix of row v with
+ *                        ids < n_hub whose screening weights fx32 sum to T_v <= budget.  Built per (graph, weight table, budget);
+ *                        the budget is a fraction of the bar IN TABLE UNITS (bar x 2^shift).
+ *   eps_scan_window_paths / eps_scan_plan / eps_scan_screen with heads: the column walks its rows from x_v on (window paths and
+ *                        plan count those rows only; the three tables go together, and a head table needs the plan table built
+ *                        for it), a table slot passes at bar - T_v, and out->val holds the WALKED sum as raw uint32 bits.
+ *                        *status bit 2 (value 4): some T_v >= the bar in table units (the tables were built for a higher bar):
+ *                        those columns were left out, the list is not valid.  A launch without a bar must not bring heads.
+ *   eps_scan_hub_rows  : hubrows[w * words + (x >> 5)] bit (x & 31) = "x is a neighbour of w" for w < n_hub <= min(4096, n_nodes),
+ *                        words = eps_scan_hub_row_words(n_nodes) (16-byte aligned rows): the adjacency rows of the first
+ *                        n_hub ids as bitmaps over the id space.  Per-graph table (cleared and filled by the call).
+ *   eps_scan_refine    : completes a walked list: every valid slot (key >= 0) of `walked` gets the exact head term -- the sum
+ *                        of fx32[w] over the skipped rows w = col[rowptr[v] + j], j < x_v, that hold u (bit u of hub row w) -- added;
+ *                        sums at or above out->threshold (in table units, as eps_scan_screen rounds it) are appended to `out`
+ *                        (compact: out->count = their number; val = sum x 2^-shift) -- the list a launch without heads reports,
+ *                        in another order.  out->count must be zeroed by the caller. */
+int eps_scan_heads(const int64_t *rowptr, const int32_t *col, const uint32_t *fx32, int64_t n_nodes, int32_t n_hub,
+                   uint32_t budget, uint32_t *heads, void *stream);
+int64_t eps_scan_hub_row_words(int64_t n_nodes);
+int eps_scan_hub_rows(const int64_t *rowptr, const int32_t *col, int64_t n_nodes, int32_t n_hub, uint32_t *hubrows, void *stream);
+int eps_scan_refine(const eps_survivors *walked, const uint32_t *heads, const uint32_t *hubrows, int32_t n_hub,
+                    const uint32_t *fx32, const int64_t *rowptr, const int32_t *col, int64_t n_nodes, int32_t shift,
+                    eps_survivors *out, void *stream);
 /* eps_scan_plan: the per-graph PLAN TABLE of eps_scan_screen -- every column's pieces, planned once by the scan kernel's own
  * planner (they depend on the graph, the window tables, the variant and, through ssum / smax, the weight table; not on the bar
  * or on the columns of a launch).  Two calls: with pptr / plan NULL it counts (pcount[v] = pieces of column v, uint32[n_nodes]);
@@ -309,15 +338,16 @@ int eps_scan_row_sums(const int64_t *rowptr, const int32_t *col, const uint32_t 
  * kernel suits a graph (eps_amd.scan.screen_variant). */
 int eps_scan_plan_rewalk(const uint32_t *plan, int64_t n_rec, int32_t variant, unsigned long long *out2, void *stream);
 int eps_scan_plan(const int64_t *rowptr, const uint16_t *cuts, const uint32_t *wpaths, const uint32_t *ssum_or_null,
-                  const uint32_t *smax_or_null, const int32_t *bounds, int64_t n_nodes, int32_t shift, int32_t variant,
-                  uint32_t *pcount, const uint32_t *pptr_or_null, uint32_t *plan_or_null, uint32_t *d_used_or_null, void *stream);
+                  const uint32_t *smax_or_null, const uint32_t *heads_or_null, const int32_t *bounds, int64_t n_nodes, int32_t shift,
+                  int32_t variant, uint32_t *pcount, const uint32_t *pptr_or_null, uint32_t *plan_or_null, uint32_t *d_used_or_null,
+                  void *stream);
 /* eps_scan_screen_weighted: the scan on a SYMMETRIC adjacency WITH stored values (collab: rank.py:32-35 keeps the summed
  * multi-edge weights; val[e] must equal the value of e's mirror entry and be positive).  A path's term is
  * (A[u,w] * A[v,w]) * node_w[w] -- symmetric in (u, v), so the half scheme holds -- and its screening weight is formed per
  * path from the float values, rounded up.  node_w = the float32 node weights (no fx32 table); re-score with
  * eps_rescore_weighted. */
 int eps_scan_screen_weighted(const int64_t *rowptr, const int32_t *col, const float *val, const int32_t *revpos,
-                             const float *node_w, const uint16_t *cuts, const uint32_t *wpaths_or_null, const int32_t *bounds,
+                             const float *node_w, const uint16_t *cuts, const uint32_t *wpaths, const int32_t *bounds,
                              int64_t n_nodes, int64_t nnz, const int32_t *columns, int64_t n_columns, int32_t shift,
                              int32_t variant, eps_survivors *out, uint32_t *status, void *stream);
 

@@ -207,3 +207,47 @@ def test_bench_failure_still_prints_one_json_line(dev, tmp_path, gpus):
     assert lines, out.stderr[-2000:]
     line = json.loads(lines[-1])
     assert line["value"] is None and "EpsError" in line["error"] and line["n_gpus"] == gpus
+
+
+def _uneven_scan_rank_main(rank, world, port, workdir, k):
+    sys.path.insert(0, ROOT)
+    os.chdir(workdir)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    import eps_amd  # noqa: F401
+    from eps_amd import dist as epd, ops, scan, synth
+    from eps_amd.heuristics import node_weight_table
+    epd.init_from_env("gloo", 0)
+    scan.SMALL_SET = 1 << 40                         # no bar: every candidate is a survivor
+
+    def lopsided(g, r, w):                           # rank 0 scans nine tenths of the heaviest-first order, rank 1 the light rest
+        order = scan.column_order(g)
+        cut = order.numel() * 9 // 10
+        return (order[:cut] if r == 0 else order[cut:]).contiguous()
+    scan.shard_columns = lopsided
+    dev = torch.device("cuda:0")
+    g = synth.rmat_graph(11, 8, 5, dev)
+    pairs, scores = scan.scan_topk(g, node_weight_table(g, ops.W_AA), k, rank, world)
+    torch.save((pairs.cpu(), scores.cpu()), f"uneven_rank{rank}.pt")
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.parametrize("k_of_all", [0.98, 1.0, 1.5])
+def test_scan_two_ranks_uneven_shards_without_bar(eps, dev, tmp_path, k_of_all):
+    """uneven shards, no bar, k at or beyond the candidate count.  Rank 1 holds far fewer survivors than its share of
+    k, so the union of the locally pre-filtered lists can fall short of k2 while enough candidates exist: the job-wide cut comes
+    back -inf next to a finite pre-filter threshold, and the step must go round again with everything re-scored instead of
+    returning a short list.  Both ranks end with the single-process rows."""
+    from eps_amd import scan, synth
+    from eps_amd.heuristics import node_weight_table
+    g = synth.rmat_graph(11, 8, 5, dev)
+    w = node_weight_table(g, eps.ops.W_AA)
+    st = {}
+    scan.scan_topk(g, w, 10, stats=st)
+    k = int(st["candidates"] * k_of_all)
+    want_p, want_s = scan.scan_topk(g, w, k)
+    assert want_p.shape[1] == min(k, st["candidates"])
+    mp.spawn(_uneven_scan_rank_main, args=(2, _free_port(), str(tmp_path), k), nprocs=2, join=True)
+    for r in range(2):
+        p, s = torch.load(os.path.join(tmp_path, f"uneven_rank{r}.pt"))
+        assert torch.equal(p, want_p.cpu()) and torch.equal(s, want_s.cpu())

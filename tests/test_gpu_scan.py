@@ -57,7 +57,7 @@ def _screen_all(eps, g, node_w, thr=float("-inf"), columns=None, variant=2, pack
                                  bounds, g.n_rows, sc.shift, variant)
         assert int(plan[0][-1]) <= plan[1].shape[0] and bool((plan[0][1:] >= plan[0][:-1]).all())
     eps.ops.scan_screen(g.rowptr, g.col, scan.reverse_positions(g), sc.fx32, cuts, bounds, g.n_rows, cols, sc.shift, res, status,
-                        variant, sc.val, sc.node_w, wpaths=scan.window_paths(g) if plan is not None else None,
+                        variant, sc.val, sc.node_w, wpaths=scan.window_paths(g),
                         ssum=sc.ssum if packed else None, smax=sc.smax if packed else None, plan=plan)
     assert not packed or sc.val is not None or sc.ssum is not None or not scan.one_pass_available(g)
     slots, n_cand = res.counts()
