@@ -55,7 +55,8 @@ extern "C" int eps_scan_heads(const int64_t *rowptr, const int32_t *col, const u
 // piece reports share their column (the same few hub rows w) and lie in one id window (nearby bits of those rows), so the
 // look-ups of eps_scan_refine hit lines their neighbours just touched.  The table is cleared first, then one wave per hub row sets
 // its bits.
-#define SH_MAX_HUB 4096
+#define SH_MAX_HUB 65536       // most hub rows a table may hold
+#define SH_LDS_HUB 4096        // eps_scan_refine keeps the weights of this many hubs in LDS
 __global__ __launch_bounds__(256) void sp_hub_rows_kernel(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col,
                                                           int32_t n_hub, int64_t words, uint32_t *__restrict__ hubrows)
 {
@@ -76,7 +77,7 @@ extern "C" int eps_scan_hub_rows(const int64_t *rowptr, const int32_t *col, int6
                                  void *stream)
 {
     EPS_REQUIRE(n_nodes >= 0 && n_nodes < (1ll << 31), "eps_scan_hub_rows: bad size");
-    EPS_REQUIRE(n_hub >= 0 && n_hub <= SH_MAX_HUB && n_hub <= n_nodes, "eps_scan_hub_rows: n_hub must be at most 4096 and at most n_nodes");
+    EPS_REQUIRE(n_hub >= 0 && n_hub <= SH_MAX_HUB && n_hub <= n_nodes, "eps_scan_hub_rows: n_hub must be at most 65536 and at most n_nodes");
     if (n_nodes == 0 || n_hub == 0) return EPS_OK;
     EPS_REQUIRE(rowptr && col && hubrows && ((uintptr_t)hubrows & 15) == 0, "eps_scan_hub_rows: null or misaligned pointer");
     const int64_t words = eps_scan_hub_row_words(n_nodes);
@@ -102,10 +103,11 @@ __global__ __launch_bounds__(256) void sp_refine_kernel(const eps_survivors *__r
                                                         const int32_t *__restrict__ col, int32_t n_nodes, int32_t shift, float scale,
                                                         eps_survivors *__restrict__ out)
 {
-    __shared__ uint32_t s_fx[SH_MAX_HUB];
+    __shared__ uint32_t s_fx[SH_LDS_HUB];
     __shared__ int64_t s_key[4][SH_WBUF];
     __shared__ float s_val[4][SH_WBUF];
-    for (int i = threadIdx.x; i < n_hub; i += 256) s_fx[i] = fx32[i];
+    const bool fx_lds = n_hub <= SH_LDS_HUB;                     // (a wider hub table: the weights come from the L2)
+    for (int i = threadIdx.x; i < n_hub && fx_lds; i += 256) s_fx[i] = fx32[i];
     __syncthreads();
     const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
     int64_t *wkey = s_key[wib];
@@ -155,7 +157,7 @@ __global__ __launch_bounds__(256) void sp_refine_kernel(const eps_survivors *__r
                 for (int q = 0; q < 4; ++q) mq[q] = ubit[(size_t)wq[q] * words];
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
-                    if (j0 + q < hd.x && ((mq[q] >> ((uint32_t)u & 31u)) & 1u)) c += s_fx[wq[q]];
+                    if (j0 + q < hd.x && ((mq[q] >> ((uint32_t)u & 31u)) & 1u)) c += fx_lds ? s_fx[wq[q]] : fx32[wq[q]];
             }
             total = in_val[i] + c;
             pass = total >= thr32 && thr32 < SP_FLAG;
@@ -179,7 +181,7 @@ extern "C" int eps_scan_refine(const eps_survivors *walked, const uint32_t *head
                                eps_survivors *out, void *stream)
 {
     EPS_REQUIRE(n_nodes >= 0 && n_nodes < (1ll << 31) && shift >= 0 && shift <= 40, "eps_scan_refine: bad argument");
-    EPS_REQUIRE(n_hub >= 0 && n_hub <= SH_MAX_HUB && n_hub <= n_nodes, "eps_scan_refine: n_hub must be at most 4096 and at most n_nodes");
+    EPS_REQUIRE(n_hub >= 0 && n_hub <= SH_MAX_HUB && n_hub <= n_nodes, "eps_scan_refine: n_hub must be at most 65536 and at most n_nodes");
     EPS_REQUIRE(walked && out && heads && (hubrows || n_hub == 0) && fx32 && rowptr && col, "eps_scan_refine: null pointer");
     EPS_REQUIRE(((uintptr_t)hubrows & 15) == 0 && ((uintptr_t)heads & 7) == 0, "eps_scan_refine: misaligned table");
     hipLaunchKernelGGL(sp_refine_kernel, dim3((unsigned)(eps_num_cus() * 8)), dim3(256), 0, (hipStream_t)stream, walked,

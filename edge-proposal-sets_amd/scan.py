@@ -47,6 +47,7 @@ HEAD_BETA = 0.5            # ... as long as their screening weights sum to at mo
 HEAD_KEEP = (0.3, 0.58)    # a head table is used again while its budget stays within this range of the current bar
 HEAD_LIST = 6              # the walked list (slots that pass at bar - T_v) is sized this many times the survivor list
 HEAD_CACHE = 4             # head tables kept per (graph, weight table)
+BATCH_MIN_COLUMNS = 1 << 16   # lists shorter than this are handed out one column at a time throughout
 BATCH_PATHS = 1 << 13      # columns of a heaviest-first list with fewer half paths are handed out eight per ticket (see batch_from)
 
 
@@ -343,7 +344,7 @@ class HeadTables:
         self.budget, self.heads, self.wpaths, self.plan, self.d_used = budget, heads, wpaths, plan, d_used
 
 
-HUB_TABLE_BYTES = 1 << 30   # the hub row bitmaps of a graph take at most this much
+HUB_TABLE_BYTES = 2 << 30   # the hub row bitmaps of a graph take at most this much (ppa-like: 16384 rows x 72 KB = 1.2 GB of 288)
 
 
 def hub_rows(g: CSRGraph) -> torch.Tensor:
@@ -475,9 +476,11 @@ def batch_from(g: CSRGraph, columns: torch.Tensor) -> int:
     """How many columns of the heaviest-first list ``columns`` are handed to the workgroups one at a time: those with at least
     BATCH_PATHS half paths; the light rest goes eight per draw (the hand-out is an atomic on one device word, ~11 ns each, and a
     light column is ~10 us of one of 1024 workgroups: singly, the tickets would set the pace).  Cached per list (one host read)."""
+    if columns.numel() < BATCH_MIN_COLUMNS:          # (a short list -- the bar sample -- has fewer columns than workgroups to feed)
+        return columns.numel()
     key = ("batch_from", columns.data_ptr(), columns.numel(), BATCH_PATHS)
     if key not in g._cache:
-        g._cache[key] = int((half_paths(g)[columns.long()] >= BATCH_PATHS).sum().item()) if columns.numel() else 0
+        g._cache[key] = int((half_paths(g)[columns.long()] >= BATCH_PATHS).sum().item())
     return g._cache[key]
 
 

@@ -301,7 +301,7 @@ int eps_scan_screen(const int64_t *rowptr, const int32_t *col, const int32_t *re
  *                        for it), a table slot passes at bar - T_v, and out->val holds the WALKED sum as raw uint32 bits.
  *                        *status bit 2 (value 4): some T_v >= the bar in table units (the tables were built for a higher bar):
  *                        those columns were left out, the list is not valid.  A launch without a bar must not bring heads.
- *   eps_scan_hub_rows  : hubrows[w * words + (x >> 5)] bit (x & 31) = "x is a neighbour of w" for w < n_hub <= min(4096, n_nodes),
+ *   eps_scan_hub_rows  : hubrows[w * words + (x >> 5)] bit (x & 31) = "x is a neighbour of w" for w < n_hub <= min(65536, n_nodes),
  *                        words = eps_scan_hub_row_words(n_nodes) (16-byte aligned rows): the adjacency rows of the first
  *                        n_hub ids as bitmaps over the id space.  Per-graph table (cleared and filled by the call).
  *   eps_scan_refine    : completes a walked list: every valid slot (key >= 0) of `walked` gets the exact head term -- the sum

@@ -20,6 +20,9 @@ order = scan.column_order(g)
 reps = int(os.environ.get("REPS", "5"))
 if "HUB" in os.environ:
     ops.HUB_MAX = int(os.environ["HUB"])
+    scan.HUB_TABLE_BYTES = 8 << 30
+if "BATCH_PATHS" in os.environ:
+    scan.BATCH_PATHS = int(os.environ["BATCH_PATHS"])
 sc = scan.screen_weights(g0, g, perm, w)
 bounds, cuts = scan.screen_tables(g)
 variant = scan.screen_variant(g)
