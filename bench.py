@@ -401,6 +401,19 @@ def run(args):
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(args.backend)
+    # what each rank SEES of the job -- world size and rank as the process group reports them, its HIP device, the device's bus
+    # id -- gathered onto rank 0 and printed with the line: a scaling record then checks itself (N distinct devices, one
+    # backend, every rank part of the same group), which matters for the first run of this path on RCCL
+    props = torch.cuda.get_device_properties(dev)
+    me = {"rank": dist.get_rank() if world > 1 else 0, "world": dist.get_world_size() if world > 1 else 1, "env_rank": rank,
+          "local_rank": int(os.environ.get("LOCAL_RANK", "0")), "device_index": dev.index, "device": props.name,
+          "pci_bus_id": getattr(props, "pci_bus_id", None), "uuid": str(getattr(props, "uuid", "")) or None,
+          "backend": dist.get_backend() if world > 1 else None, "visible_devices": torch.cuda.device_count(),
+          "ipc_mode_legacy": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")}
+    ranks_seen = [me]
+    if world > 1:
+        ranks_seen = [None] * world
+        dist.all_gather_object(ranks_seen, me)
 
     import eps_amd  # noqa: F401
     from eps_amd import candidates, ops, scan, synth
@@ -580,6 +593,8 @@ def run(args):
             "value": job_cand * args.steps / dt,
             "unit": "edges/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ranks": ranks_seen,
+            "distinct_devices": len({(r["device_index"], r["pci_bus_id"], r["uuid"]) for r in ranks_seen}),
             "ms_per_step": ms_step,
             "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": "int64", "data": "synthetic",

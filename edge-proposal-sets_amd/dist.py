@@ -133,6 +133,20 @@ def gather_ragged_to(t: torch.Tensor, lens: Sequence[int], dst: int) -> Optional
     return out.to(t.device) if via_host else out
 
 
+def all_to_all_ragged(t: torch.Tensor, send_counts: Sequence[int], recv_counts: Sequence[int]) -> torch.Tensor:
+    """One all-to-all of a 1-D tensor cut into per-destination pieces: this rank sends ``t[sum(send_counts[:q]) : ...]`` to rank q
+    and receives ``recv_counts[r]`` elements from rank r, concatenated in rank order.  Every rank knows both count lists already
+    (no length round trip).  RCCL moves device memory directly; gloo (the one-device test hook) goes through host memory."""
+    rank, world = world_info()
+    if world == 1:
+        return t[:send_counts[0]]
+    via_host = dist.get_backend() == "gloo" and t.device.type != "cpu"
+    src = (t.cpu() if via_host else t).contiguous()
+    out = torch.empty(int(sum(recv_counts)), dtype=src.dtype, device=src.device)
+    dist.all_to_all_single(out, src[:int(sum(send_counts))], [int(x) for x in recv_counts], [int(x) for x in send_counts])
+    return out.to(t.device) if via_host else out
+
+
 def world_info() -> Tuple[int, int]:
     if dist.is_available() and dist.is_initialized():
         return dist.get_rank(), dist.get_world_size()

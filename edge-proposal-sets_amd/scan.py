@@ -687,6 +687,41 @@ def _ordered_rows_distributed(keys: torch.Tensor, vals: torch.Tensor, k: int, bi
     return rows_k[:k], rows_v[:k]
 
 
+_XCHG_HEAD = 16                    # int32 words in front of a rank's scores in the step's one exchange (six int64 status words, padded)
+_NEG_INF_BITS = -8388608           # float32 -inf as int32
+
+
+def _deal_rows(keys: torch.Tensor, vals: torch.Tensor, scores_all: torch.Tensor, cut: torch.Tensor, k: int, bits: int, perm,
+               rank: int, world: int, rows_on: Optional[int]):
+    """The k best directed rows, ordered by the declared rule, when every rank holds its OWN selected pairs (keys, vals) and
+    everybody's re-scored scores (``scores_all`` [world, room], -inf = none; the step's one exchange).  The final ordering
+    is dealt over the ranks by score range: the splitters come off the gathered scores (the same on every rank, no collective),
+    so does the table of who sends how many pairs of which range to whom; ONE all-to-all moves each selected pair to the rank that
+    orders its range (1 / world of the pairs arrive per rank, not all of them on every rank as in r04), the rank mirrors and sorts
+    them, and the sorted chunks go to ``rows_on`` (or to everyone) in rank order = the declared order.  One host read (the table)."""
+    from . import dist as epd
+    live = (scores_all >= cut) & (scores_all > float("-inf"))
+    sp = score_splitters(scores_all[live], world)
+    rng_all = (scores_all.unsqueeze(2) < sp.view(1, 1, -1)).sum(2)                     # range of every gathered score
+    cell = torch.arange(world, device=rng_all.device).unsqueeze(1) * world + rng_all    # (sender, range) of every gathered score
+    c = torch.bincount(cell[live], minlength=world * world).view(world, world).tolist()                                                               # the one host read: c[r][q] = pairs of rank r in range q
+    rng = (vals.unsqueeze(1) < sp.unsqueeze(0)).sum(1)
+    order = torch.sort(rng, stable=True).indices                                      # own pairs, grouped by destination
+    packed = torch.stack([keys[order], vals[order].view(torch.int32).to(torch.int64)], 1).reshape(-1)       # (key, score bits) pairs
+    got = epd.all_to_all_ragged(packed, [2 * x for x in c[rank]], [2 * c[r][rank] for r in range(world)]).view(-1, 2)
+    mk, mv = got[:, 0].contiguous(), got[:, 1].to(torch.int32).view(torch.float32).contiguous()
+    m = mk.numel()
+    rk, rv = ops.select_rows(mk, mv, 2 * m, bits, perm)                                # all 2 m rows of the range, ordered
+    lens = [2 * sum(c[r][q] for r in range(world)) for q in range(world)]
+    if rows_on is None:
+        rows_k, rows_v = epd.gather_ragged(rk, lens), epd.gather_ragged(rv, lens)
+    else:
+        rows_k, rows_v = epd.gather_ragged_to(rk, lens, rows_on), epd.gather_ragged_to(rv, lens, rows_on)
+        if rows_k is None:
+            return None, None
+    return rows_k[:k], rows_v[:k]
+
+
 def _f32_from_bits(word: int) -> float:
     import struct
     return struct.unpack("<f", struct.pack("<I", int(word) & 0xFFFFFFFF))[0]
@@ -793,22 +828,44 @@ def scan_topk(g: CSRGraph, node_w: torch.Tensor, k: int, rank: int = 0, world: i
             l_keys, l_vals = rescore_exact(g, screen, c_keys[:nv], bar)
             status = res.status
         # the job-wide cut: the k2-th best survivor score over all ranks (-inf when fewer survived); untouched slots are -inf
-        if world == 1 and screen is not None:
-            sel_k, sel_v, n_sel, cut, _ = ops.select_compact(l_keys, l_vals, k2)          # (one launch: select + compaction)
-        else:
-            cut = ops.kth_largest_dist(l_vals, k2, world)
-            sel_k, sel_v, n_sel = ops.compact_at_least(l_keys, l_vals, cut)
         zero = torch.zeros(1, dtype=torch.int64, device=dev)
-        st = torch.cat([res.rec[1:2], res.rec[4:5], n_sel, cut.view(torch.int32).to(torch.int64),     # slots, candidates, selected, cut bits,
-                        status.to(torch.int64) if status is not None else zero,                          # kernel status,
-                        pre_thr.view(torch.int32).to(torch.int64) if pre_thr is not None else zero,      # pre-filter threshold bits,
-                        res.walked_slots if res.walked_slots is not None else zero,                      # slots of the walked list,
-                        bar.view(torch.int32).to(torch.int64) if ht is not None else zero])              # the bar's bits (head launches)
-        if world > 1:
+        st_tail = [status.to(torch.int64) if status is not None else zero,                          # kernel status,
+                   pre_thr.view(torch.int32).to(torch.int64) if pre_thr is not None else zero,      # pre-filter threshold bits,
+                   res.walked_slots if res.walked_slots is not None else zero,                      # slots of the walked list,
+                   bar.view(torch.int32).to(torch.int64) if ht is not None else zero]               # the bar's bits (head launches)
+        scores_all = None
+        if world > 1 and screen is not None and not rescore_all:
+            # ONE exchange for the cut AND the step's status: every rank's re-scored scores (at most `room`, -inf beyond its own) behind
+            # six status words, all-gathered.  Each rank then finds the job-wide cut itself -- one select launch over the gathered
+            # scores: the same values in the same order everywhere, so the same cut without a broadcast -- and knows every rank's
+            # selection count, the splitters of the final ordering and who sends how much to whom (_deal_rows) without asking again.
+            # (r04: four all-reduced histogram rounds for the cut, one all-gather for the status, two for the selected pairs.)
             from . import dist as epd
-            table = torch.stack(epd.all_gather_list(st)).tolist()                          # the host read of the step
+            head = torch.cat([res.rec[1:2], res.rec[4:5]] + st_tail).view(torch.int32)                 # 6 x int64
+            send = torch.full((_XCHG_HEAD + room,), _NEG_INF_BITS, dtype=torch.int32, device=dev)
+            send[:head.numel()] = head
+            send[_XCHG_HEAD:_XCHG_HEAD + l_vals.numel()] = l_vals.view(torch.int32)
+            got = epd._gather_into(send, world).view(world, _XCHG_HEAD + room)
+            scores_all = got[:, _XCHG_HEAD:].contiguous().view(torch.float32)
+            cut = ops.select_compact(None, scores_all.reshape(-1), k2, compact=False)[3]
+            sel_k, sel_v, n_sel = ops.compact_at_least(l_keys, l_vals, cut)
+            nsel_all = ((scores_all >= cut) & (scores_all > float("-inf"))).sum(1)
+            heads6 = got[:, :12].contiguous().view(torch.int64)                                          # [world, 6]
+            st_all = torch.cat([heads6[:, :2], nsel_all.unsqueeze(1), cut.view(torch.int32).to(torch.int64).expand(world, 1),
+                                heads6[:, 2:]], 1)
+            table = st_all.tolist()                                                           # the host read of the step
         else:
-            table = [st.tolist()]
+            if world == 1 and screen is not None:
+                sel_k, sel_v, n_sel, cut, _ = ops.select_compact(l_keys, l_vals, k2)          # (one launch: select + compaction)
+            else:
+                cut = ops.kth_largest_dist(l_vals, k2, world)
+                sel_k, sel_v, n_sel = ops.compact_at_least(l_keys, l_vals, cut)
+            st = torch.cat([res.rec[1:2], res.rec[4:5], n_sel, cut.view(torch.int32).to(torch.int64)] + st_tail)
+            if world > 1:
+                from . import dist as epd
+                table = torch.stack(epd.all_gather_list(st)).tolist()                          # the host read of the step
+            else:
+                table = [st.tolist()]
         slots_r, ncand_r, nsel_r = [t[0] for t in table], [t[1] for t in table], [t[2] for t in table]
         if any(t[4] & ~4 for t in table):
             raise ops._lib.EpsError("scan_topk: eps_scan_screen reported a full hash table (status %s)" % [t[4] for t in table])
@@ -866,10 +923,16 @@ def scan_topk(g: CSRGraph, node_w: torch.Tensor, k: int, rank: int = 0, world: i
         break
     keys, vals = sel_k[:nsel_r[rank]], sel_v[:nsel_r[rank]]      # (still in the scanned graph's labels: select_rows maps them back)
     bits = max(1, min(32, int(g.n_rows - 1).bit_length()))
-    if world > 1:
+    if world > 1 and scores_all is not None and n_sel_all >= DIST_ROWS_MIN:
+        keys, vals = _deal_rows(keys.contiguous(), vals.contiguous(), scores_all, cut, k, bits, perm, rank, world, rows_on)
+    elif world > 1:
         keys, vals = epd.gather_ragged(keys, nsel_r), epd.gather_ragged(vals, nsel_r)
-    if world > 1 and n_sel_all >= DIST_ROWS_MIN:
-        keys, vals = _ordered_rows_distributed(keys.contiguous(), vals.contiguous(), k, bits, perm, rank, world, rows_on)
+        if n_sel_all >= DIST_ROWS_MIN:
+            keys, vals = _ordered_rows_distributed(keys.contiguous(), vals.contiguous(), k, bits, perm, rank, world, rows_on)
+        elif rows_on is None or rows_on == rank:
+            keys, vals = ops.select_rows(keys.contiguous(), vals.contiguous(), k, bits, perm)
+        else:
+            keys = vals = None
     elif rows_on is None or rows_on == rank or world == 1:
         keys, vals = ops.select_rows(keys.contiguous(), vals.contiguous(), k, bits, perm)
     else:
