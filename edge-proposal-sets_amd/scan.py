@@ -691,20 +691,38 @@ _XCHG_HEAD = 16                    # int32 words in front of a rank's scores in 
 _NEG_INF_BITS = -8388608           # float32 -inf as int32
 
 
-def _deal_rows(keys: torch.Tensor, vals: torch.Tensor, scores_all: torch.Tensor, cut: torch.Tensor, k: int, bits: int, perm,
-               rank: int, world: int, rows_on: Optional[int]):
-    """The k best directed rows, ordered by the declared rule, when every rank holds its OWN selected pairs (keys, vals) and
-    everybody's re-scored scores (``scores_all`` [world, room], -inf = none; the step's one exchange).  The final ordering
-    is dealt over the ranks by score range: the splitters come off the gathered scores (the same on every rank, no collective),
-    so does the table of who sends how many pairs of which range to whom; ONE all-to-all moves each selected pair to the rank that
-    orders its range (1 / world of the pairs arrive per rank, not all of them on every rank as in r04), the rank mirrors and sorts
-    them, and the sorted chunks go to ``rows_on`` (or to everyone) in rank order = the declared order.  One host read (the table)."""
-    from . import dist as epd
+_DEAL_SAMPLE = 1 << 15             # gathered scores the splitters are read off
+
+
+def _deal_plan(scores_all: torch.Tensor, cut: torch.Tensor, world: int):
+    """(splitters float32 [world - 1], counts int64 [world, world]) of the final ordering of a sharded step, from everybody's
+    re-scored scores (``scores_all`` [world, room], -inf = none) and the job-wide cut -- device tensors of fixed shape, the same on
+    every rank.  Range q holds the selected scores in [splitter[q], splitter[q - 1]); counts[r][q] = selected pairs of rank r in
+    range q.  The splitters are order statistics of a fixed-stride sample of the gathered scores (sorted descending: the m
+    sample values at or above the cut come first; splitter q = the (q m / world)-th of them) -- equal scores never straddle a
+    boundary, so the ranges concatenate to the declared order however uneven they turn out."""
+    flat = scores_all.reshape(-1)
+    samp = torch.sort(flat[::max(1, flat.numel() // _DEAL_SAMPLE)], descending=True).values
+    m = ((samp >= cut) & (samp > float("-inf"))).sum()
+    idx = (torch.arange(1, world, device=flat.device) * m) // world
+    sp = samp[idx.clamp(max=samp.numel() - 1)]
+    sp = torch.where(m > 0, sp, torch.full_like(sp, float("inf")))                      # (no sample above the cut: one range takes all)
     live = (scores_all >= cut) & (scores_all > float("-inf"))
-    sp = score_splitters(scores_all[live], world)
     rng_all = (scores_all.unsqueeze(2) < sp.view(1, 1, -1)).sum(2)                     # range of every gathered score
-    cell = torch.arange(world, device=rng_all.device).unsqueeze(1) * world + rng_all    # (sender, range) of every gathered score
-    c = torch.bincount(cell[live], minlength=world * world).view(world, world).tolist()                                                               # the one host read: c[r][q] = pairs of rank r in range q
+    cell = torch.arange(world, device=flat.device).unsqueeze(1) * world + rng_all       # (sender, range); a dead score counts nowhere
+    cell = torch.where(live, cell, torch.full_like(cell, world * world))
+    counts = torch.bincount(cell.reshape(-1), minlength=world * world + 1)[:world * world].view(world, world)
+    return sp, counts
+
+
+def _deal_rows(keys: torch.Tensor, vals: torch.Tensor, sp: torch.Tensor, c: List[List[int]], k: int, bits: int, perm,
+               rank: int, world: int, rows_on: Optional[int]):
+    """The k best directed rows, ordered by the declared rule, when every rank holds its OWN selected pairs (keys, vals) and the
+    deal plan (``_deal_plan``: splitters on the device, the counts table read back with the step's status).  The final ordering
+    is dealt over the ranks by score range: ONE all-to-all moves each selected pair to the rank that orders its range (1 / world
+    of the pairs arrive per rank, not all of them on every rank as in r04), the rank mirrors and sorts them, and the sorted chunks
+    go to ``rows_on`` (or to everyone) in rank order = the declared order.  No host read of its own."""
+    from . import dist as epd
     rng = (vals.unsqueeze(1) < sp.unsqueeze(0)).sum(1)
     order = torch.sort(rng, stable=True).indices                                      # own pairs, grouped by destination
     packed = torch.stack([keys[order], vals[order].view(torch.int32).to(torch.int64)], 1).reshape(-1)       # (key, score bits) pairs
@@ -853,7 +871,12 @@ def scan_topk(g: CSRGraph, node_w: torch.Tensor, k: int, rank: int = 0, world: i
             heads6 = got[:, :12].contiguous().view(torch.int64)                                          # [world, 6]
             st_all = torch.cat([heads6[:, :2], nsel_all.unsqueeze(1), cut.view(torch.int32).to(torch.int64).expand(world, 1),
                                 heads6[:, 2:]], 1)
-            table = st_all.tolist()                                                           # the host read of the step
+            # (the splitters of the final ordering and the table of who sends how many pairs of which range to whom ride along
+            #  in the same host read: fixed shapes, nothing here waits for a size)
+            deal_sp, deal_counts = _deal_plan(scores_all, cut, world)
+            flat = torch.cat([st_all.reshape(-1), deal_counts.reshape(-1)]).tolist()            # the host read of the step
+            table = [flat[r * 8:(r + 1) * 8] for r in range(world)]
+            deal_c = [flat[8 * world + r * world:8 * world + (r + 1) * world] for r in range(world)]
         else:
             if world == 1 and screen is not None:
                 sel_k, sel_v, n_sel, cut, _ = ops.select_compact(l_keys, l_vals, k2)          # (one launch: select + compaction)
@@ -924,7 +947,7 @@ def scan_topk(g: CSRGraph, node_w: torch.Tensor, k: int, rank: int = 0, world: i
     keys, vals = sel_k[:nsel_r[rank]], sel_v[:nsel_r[rank]]      # (still in the scanned graph's labels: select_rows maps them back)
     bits = max(1, min(32, int(g.n_rows - 1).bit_length()))
     if world > 1 and scores_all is not None and n_sel_all >= DIST_ROWS_MIN:
-        keys, vals = _deal_rows(keys.contiguous(), vals.contiguous(), scores_all, cut, k, bits, perm, rank, world, rows_on)
+        keys, vals = _deal_rows(keys.contiguous(), vals.contiguous(), deal_sp, deal_c, k, bits, perm, rank, world, rows_on)
     elif world > 1:
         keys, vals = epd.gather_ragged(keys, nsel_r), epd.gather_ragged(vals, nsel_r)
         if n_sel_all >= DIST_ROWS_MIN:

@@ -237,3 +237,30 @@ def test_streaming_topk_lazy_column_block_cpu():
             c.push(pairs, scores + rep * (rep == 1)); d.push(padded, s_pad + rep * (rep == 1))
         pc, sc = c.result(); pd_, sd = d.result()
         assert torch.equal(pc, pd_) and torch.equal(sc, sd)
+
+
+def _a2a_worker(rank, world, port):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    import eps_amd  # noqa: F401
+    from eps_amd import dist as epd
+    epd.init_from_env(backend="gloo", host_only=True)
+    # rank r sends (r + 1) * (q + 1) - (1 if r == q else 0) elements to rank q, each tagged with sender and receiver
+    cnt = lambda r, q: (r + 1) * (q + 1) - (1 if r == q else 0)  # noqa: E731
+    send = torch.cat([torch.full((cnt(rank, q),), 100 * rank + q, dtype=torch.int64) for q in range(world)])
+    got = epd.all_to_all_ragged(send, [cnt(rank, q) for q in range(world)], [cnt(r, rank) for r in range(world)])
+    want = torch.cat([torch.full((cnt(r, rank),), 100 * r + rank, dtype=torch.int64) for r in range(world)])
+    assert torch.equal(got, want)
+    # a rank with nothing to send to anybody
+    none = epd.all_to_all_ragged(torch.zeros(0, dtype=torch.int64) if rank == 0 else torch.arange(world, dtype=torch.int64),
+                                 [0] * world if rank == 0 else [1] * world, [0 if r == 0 else 1 for r in range(world)])
+    assert none.tolist() == [rank] * (world - 1)
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_all_to_all_ragged_gloo(world):
+    """dist.all_to_all_ragged (the exchange of the sharded step's selected pairs by score range): per-destination pieces of
+    different lengths, empty pieces, a rank that sends nothing -- world 2 and 4 on CPU tensors."""
+    mp.spawn(_a2a_worker, args=(world, _free_port()), nprocs=world, join=True)

@@ -331,3 +331,51 @@ def test_distributed_final_ordering_concatenates_to_the_declared_order(world, ti
         chunks_v.append(rv)
     got_k, got_v = torch.cat(chunks_k)[:k], torch.cat(chunks_v)[:k]
     assert torch.equal(got_k, want_k) and torch.equal(got_v, want_v)
+
+
+@pytest.mark.parametrize("world,ties", [(2, False), (4, True), (8, False), (3, True)])
+def test_deal_plan_partitions_the_selection_for_one_all_to_all(world, ties):
+    """scan._deal_plan / _deal_rows' host logic on CPU tensors (the sharded step's one exchange, r05): from everybody's gathered
+    scores and the cut every rank derives the same splitters and the same table counts[r][q] of who sends how many selected pairs
+    of range q; emulating the all-to-all with slices, the per-range orderings concatenate in rank order to exactly the rows a
+    single rank orders -- uneven shards, padding, ties at the cut and at the splitters included."""
+    from eps_amd import scan
+    gen = torch.Generator().manual_seed(5 + world)
+    sizes = [int(x) for x in torch.randint(50, 4000, (world,), generator=gen)]
+    sizes[0] = 7                                               # a rank with next to nothing
+    room = max(sizes) + 100
+    keys_r, vals_r = [], []
+    base = 0
+    for n in sizes:
+        u = torch.arange(base, base + n)
+        keys_r.append(((u + 100_000) << 32) | u)
+        v = torch.rand(n, generator=gen) * 5
+        vals_r.append(torch.round(v * 4) / 4 if ties else v)
+        base += n
+    scores_all = torch.full((world, room), float("-inf"))
+    for r in range(world):
+        scores_all[r, :sizes[r]] = vals_r[r]
+    all_k, all_v = torch.cat(keys_r), torch.cat(vals_r)
+    for k2 in (1, sum(sizes) // 3, sum(sizes), sum(sizes) + 50):
+        srt = torch.sort(all_v, descending=True).values
+        cut = srt[k2 - 1:k2] if k2 <= srt.numel() else torch.tensor([float("-inf")])
+        sp, counts = scan._deal_plan(scores_all, cut, world)
+        n_sel = int((all_v >= cut).sum())
+        assert sp.numel() == world - 1 and bool((sp[:-1] >= sp[1:]).all()) and int(counts.sum()) == n_sel
+        c = counts.tolist()
+        # every rank groups its own selected pairs by range; range q's owner receives the pieces in rank order
+        recv_k, recv_v = [[] for _ in range(world)], [[] for _ in range(world)]
+        for r in range(world):
+            m = vals_r[r] >= cut
+            sk, sv = keys_r[r][m], vals_r[r][m]
+            rng = (sv.unsqueeze(1) < sp.unsqueeze(0)).sum(1)
+            assert torch.bincount(rng, minlength=world).tolist() == c[r]
+            for q in range(world):
+                recv_k[q].append(sk[rng == q])
+                recv_v[q].append(sv[rng == q])
+        k = 2 * n_sel - 3 if n_sel > 2 else 2 * n_sel
+        chunks = [scan.select_topk_torch(torch.cat(recv_k[q]), torch.cat(recv_v[q]), 2 * sum(c[r][q] for r in range(world)))
+                  for q in range(world)]
+        got_k, got_v = torch.cat([ck for ck, _ in chunks])[:k], torch.cat([cv for _, cv in chunks])[:k]
+        want_k, want_v = scan.select_topk_torch(all_k[all_v >= cut], all_v[all_v >= cut], k)
+        assert torch.equal(got_k, want_k) and torch.equal(got_v, want_v), (world, ties, k2)
