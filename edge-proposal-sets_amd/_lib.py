@@ -68,6 +68,9 @@ SIGNATURES = {
     "eps_spmm_csr": (_int, [_vp, _vp, _vp, _i64, _vp, _i64, _i32, _vp, _int, _int, _vp, _i64, _vp]),
     "eps_gcn_norm": (_int, [_vp, _vp, _vp, _i64, _vp, _vp, _vp]),
     "eps_gemm_f32": (_int, [_vp, _i64, _vp, _i64, _vp, _int, _int, _vp, _i64, _i64, _i32, _i32, _vp]),
+    "eps_dense_adjacency": (_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp]),
+    "eps_dense_candidates": (_int, [_vp, _vp, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "eps_dense_mirror_lower": (_int, [_vp, _i64, _i64, _vp]),
     "eps_mlp_decode": (_int, [_vp, _i64, _i32, _vp, _vp, _i64, _c.POINTER(_vp), _c.POINTER(_vp), _i32, _int, _vp, _vp]),
     "eps_kth_largest_workspace_bytes": (_i64, []),
     "eps_kth_largest_f32": (_int, [_vp, _i64, _i64, _vp, _vp, _vp]),

@@ -58,6 +58,17 @@ def hip_expand_available(g: CSRGraph, scored: bool = True) -> bool:
 FUSED_SCORE_LIMIT = float(1 << 22)   # the 2^-40 fixed-point accumulators of the fused kernels hold |sums| < 2^23; keep half
 
 
+DENSE_MIN_DENSITY = 0.03     # stored entries / N^2 from which the common-neighbour list of a graph goes through the dense product
+DENSE_MAX_NODES = 8192       # ... up to this many nodes (two N x N float matrices; N^3 flops)
+
+
+def dense_cn_suits(g: CSRGraph) -> bool:
+    """Unit-valued graph on the GPU, small and dense enough that CN = A A^T as ONE dense product on the matrix cores beats the
+    sparse expansion (ogbl-ddi: N = 4,267, density 0.117)."""
+    return bool(g.device.type == "cuda" and g.val is None and g.n_rows == g.n_cols and 0 < g.n_rows <= DENSE_MAX_NODES
+                and g.nnz() >= DENSE_MIN_DENSITY * g.n_rows * g.n_rows)
+
+
 def fused_score_bound(g: CSRGraph, node_w: Optional[torch.Tensor]) -> float:
     """Upper bound of every fused score sum_w A[u,w] * A[v,w] * node_w[w] of the graph:
     max_v sum_w |A[v,w]| * |node_w[w]| * max_u |A[u,w]|  (one pass over the stored entries; cached).  Unit-valued graphs

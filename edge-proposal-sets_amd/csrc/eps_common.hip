@@ -88,6 +88,7 @@ extern "C" void eps_warm_expand_score(void *stream);
 extern "C" void eps_warm_filter_scan(void *stream);
 extern "C" void eps_warm_spmm_csr(void *stream);
 extern "C" void eps_warm_gemm_f32(void *stream);
+extern "C" void eps_warm_dense_cn(void *stream);
 extern "C" void eps_warm_mlp_decode(void *stream);
 extern "C" void eps_warm_topk_keys(void *stream);
 extern "C" void eps_warm_topk_select(void *stream);
@@ -108,6 +109,7 @@ extern "C" int eps_warm_up(void)
     eps_warm_filter_scan(s);
     eps_warm_spmm_csr(s);
     eps_warm_gemm_f32(s);
+    eps_warm_dense_cn(s);
     eps_warm_mlp_decode(s);
     eps_warm_topk_keys(s);
     eps_warm_topk_select(s);

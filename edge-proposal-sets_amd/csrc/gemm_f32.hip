@@ -89,6 +89,10 @@ __global__ __launch_bounds__(256, ALIGNED ? 4 : 2) void gemm_f32_kernel(const fl
     const int n_nblk = (N + G_BN - 1) / G_BN;
     const int64_t m0 = (int64_t)(blockIdx.x / n_nblk) * G_BM;
     const int n0 = (blockIdx.x % n_nblk) * G_BN;
+    // (flag bit 1 of `relu`: the caller wants the tiles on and below the diagonal only -- a symmetric product, e.g. A A^T of a
+    //  dense adjacency: csrc/dense_cn.hip -- so a workgroup whose tile lies strictly above it has nothing to do)
+    if ((relu & 2) && (int64_t)n0 > m0) return;
+    relu &= 1;
     const __amdgpu_buffer_rsrc_t ra_rs = tile_rsrc(A, m0, M, lda);
     const __amdgpu_buffer_rsrc_t rb_rs = tile_rsrc(B, n0, N, ldb);
     const int ilda = (int)lda, ildb = (int)ldb;

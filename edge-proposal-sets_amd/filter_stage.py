@@ -263,6 +263,22 @@ def run(args) -> str:
     _lib.warm_up_join()                  # (the background loads are done -- or given up on -- before anything is timed)
     watch = _Stopwatch(device)
     keep = int(args.keep_top)
+    if keep == 0 and args.model == "simple" and world == 1 and candidates.dense_cn_suits(data.adj_t):
+        # configs[0]: a small DENSE graph (ddi: N = 4,267, 11.7 % of all pairs are edges).  Common-neighbour counts = A A^T, ONE
+        # product on the matrix cores (exact: counts < 2^24), the reference's candidate list a masked read of it in its own
+        # column-major order, and the file's order ONE stable sort by the integer count -- no per-graph table, a dozen launches
+        # (csrc/dense_cn.hip; the sparse path took 7.5 ms of GPU time in hundreds of launches for the same 16 M rows)
+        g = data.adj_t
+        with torch.no_grad():
+            got = ops.dense_cn_candidates(g.rowptr, g.col, g.n_rows, directed=True, check_symmetric=True, as_rows=True)
+        if got is not None:                      # (an asymmetric pattern takes the general path below)
+            rows, cnt = got
+            rows = rows[torch.sort(cnt.to(torch.int16), descending=True, stable=True).indices]  # counts <= N - 2 < 2^15
+            n_seen = int(rows.shape[0])
+            dt = watch.stop(n_seen)
+            print('dense common-neighbour product (A A^T on the f32 MFMA)')
+            print(f'using {n_seen} edges; scored in {dt:.2f} s ({n_seen / max(dt, 1e-9):.3e} candidate edges/s incl. generation)')
+            return _save(args, spec, sorted_edge_path, num_sorted_edge, run_id, rank, world, rows)
     if 0 < keep <= scan.MAX_K and scan.scan_plausible(data.adj_t):
         # (the hubs-first copy first: the symmetry check of scan_available then reads the COPY's reverse positions -- the table
         #  the scan needs anyway -- instead of building one for the graph as labelled, 3-5 ms on a ppa-sized graph)

@@ -850,8 +850,9 @@ def gcn_norm(rowptr, col, val) -> torch.Tensor:
     return out
 
 
-def gemm(a: torch.Tensor, b_nk: torch.Tensor, bias=None, relu=False, out=None, accumulate=False) -> torch.Tensor:
-    """C = act(a @ b_nk.T + bias (+ C)); b_nk is [N,K] (torch.nn.Linear layout)."""
+def gemm(a: torch.Tensor, b_nk: torch.Tensor, bias=None, relu=False, out=None, accumulate=False, lower_only=False) -> torch.Tensor:
+    """C = act(a @ b_nk.T + bias (+ C)); b_nk is [N,K] (torch.nn.Linear layout).  ``lower_only``: the product is symmetric and
+    only its 128 x 128 tiles on and below the diagonal are computed (the rest of ``out`` is left as it is)."""
     dev = _need_gpu(a, b_nk, bias, out, row_strided=(a, b_nk, out))
     _chk(a, torch.float32, "a"); _chk(b_nk, torch.float32, "b"); _chk(bias, torch.float32, "bias")
     m, k = a.shape
@@ -863,10 +864,55 @@ def gemm(a: torch.Tensor, b_nk: torch.Tensor, bias=None, relu=False, out=None, a
             raise _lib.EpsError("gemm: accumulate needs out")
         out = torch.empty((m, n), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
-        _lib.check(_lib.load().eps_gemm_f32(_ptr(a), a.stride(0), _ptr(b_nk), b_nk.stride(0), _ptr(bias), int(relu),
+        _lib.check(_lib.load().eps_gemm_f32(_ptr(a), a.stride(0), _ptr(b_nk), b_nk.stride(0), _ptr(bias), int(relu) | (2 if lower_only else 0),
                                             int(accumulate), _ptr(out), out.stride(0), m, n, k, _stream(dev)),
                    "eps_gemm_f32")
     return out
+
+
+def dense_adjacency(rowptr, col, n_nodes: int, pad_to: int = 128) -> torch.Tensor:
+    """float32 [Np, Np] (Np = n_nodes rounded up to ``pad_to``): 1.0 at every stored entry, 0 elsewhere (eps_dense_adjacency)."""
+    dev = _need_gpu(rowptr, col)
+    _chk(rowptr, torch.int64, "rowptr"); _chk(col, torch.int32, "col")
+    np_ = (int(n_nodes) + pad_to - 1) // pad_to * pad_to
+    a = torch.empty((max(np_, 1), max(np_, 1)), dtype=torch.float32, device=dev)[:np_, :np_]
+    with torch.cuda.device(dev):
+        _lib.check(_lib.load().eps_dense_adjacency(_ptr(rowptr), _ptr(col), int(n_nodes), np_, np_, _ptr(a), _stream(dev)), "eps_dense_adjacency")
+    return a
+
+
+def dense_cn_candidates(rowptr, col, n_nodes: int, directed: bool = False, check_symmetric: bool = False, as_rows: bool = False):
+    """(keys int64 (v << 32) | u, counts float32) of the 2-hop non-edges of a DENSE unit-valued symmetric graph, column-major (v
+    ascending, then u), with their common-neighbour counts: A A^T on the f32 MFMA + a masked read (csrc/dense_cn.hip).  Default:
+    every unordered pair once (u < v; lower tiles of the product only); ``directed``: both orientations -- the reference's
+    candidate list (filter.py:96-109) in its own order.  ``check_symmetric``: None comes back when A != A^T (a transposed
+    compare of the dense matrix: the check costs no table).  ``as_rows``: (rows float32 [E, 3] = (u, v, count), counts) instead
+    of keys -- the proposal file's rows written by the kernel itself.  One host read (the list's length; with the check, one more)."""
+    dev = _need_gpu(rowptr, col)
+    a = dense_adjacency(rowptr, col, n_nodes)
+    if check_symmetric and not bool(torch.equal(a, a.t())):
+        return None
+    c = torch.empty_like(a)
+    gemm(a, a, out=c, lower_only=True)               # (symmetric: half the tiles ...
+    lib = _lib.load()
+    if directed:                                     #  ... and a transposed copy for the readers of whole rows)
+        with torch.cuda.device(dev):
+            _lib.check(lib.eps_dense_mirror_lower(_ptr(c), n_nodes, c.stride(0), _stream(dev)), "eps_dense_mirror_lower")
+    counts = torch.empty(n_nodes + 1, dtype=torch.int64, device=dev)
+    counts[n_nodes:] = 0
+    with torch.cuda.device(dev):
+        _lib.check(lib.eps_dense_candidates(_ptr(a), _ptr(c), n_nodes, a.stride(0), 0 if directed else 1, _ptr(counts), None, None, None,
+                                            None, _stream(dev)), "eps_dense_candidates")
+        colptr = torch.zeros(n_nodes + 1, dtype=torch.int64, device=dev)
+        torch.cumsum(counts[:n_nodes], 0, out=colptr[1:])
+        total = int(colptr[-1].item())
+        keys = torch.empty((total, 3), dtype=torch.float32, device=dev) if as_rows else torch.empty(total, dtype=torch.int64, device=dev)
+        vals = torch.empty(total, dtype=torch.float32, device=dev)
+        if total:
+            _lib.check(lib.eps_dense_candidates(_ptr(a), _ptr(c), n_nodes, a.stride(0), 0 if directed else 1, None, _ptr(colptr),
+                                                None if as_rows else _ptr(keys), _ptr(vals), _ptr(keys) if as_rows else None,
+                                                _stream(dev)), "eps_dense_candidates")
+    return keys, vals
 
 
 def mlp_decode(h: torch.Tensor, u, v, weights: Sequence[torch.Tensor], biases: Sequence[torch.Tensor],

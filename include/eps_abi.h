@@ -399,6 +399,27 @@ int eps_gcn_norm(const int64_t *rowptr, const int32_t *col, const float *val, in
 int eps_gemm_f32(const float *a, int64_t lda, const float *b, int64_t ldb, const float *bias,
                  int relu, int accumulate, float *c, int64_t ldc, int64_t m, int32_t n, int32_t k,
                  void *stream);
+/* `relu`: bit 0 = ReLU; bit 1 (value 2) = the product is symmetric and only the 128 x 128 tiles on and below the diagonal are
+ * computed (the rest of C is left untouched).
+ *
+ * ---- common neighbours of a DENSE graph through the matrix cores (r05; csrc/dense_cn.hip) --------------------------------
+ * filter.py:96-121 with CommonNeighborsPredictor('simple') (models.py:536-542) on a graph like ogbl-ddi (N = 4,267, 11.7 % of
+ * all pairs are edges): CN = A A^T as one dense float32 product (exact below 2^24), the candidate list a masked read of it.
+ *   eps_dense_adjacency : a[v * ld + w] = 1.0f for every stored entry, 0 elsewhere; the matrix has `rows` >= n_nodes rows of
+ *                         ld >= n_nodes floats (padding rows / columns zero: the product's tiles want multiples of 128).
+ *   eps_dense_candidates: the candidates of column v -- c[v * ld + u] > 0, a[v * ld + u] == 0, u < v (below_only: each unordered
+ *                         pair once; c needs its lower tiles) or u != v (the reference's directed list; c needs all tiles) -- in
+ *                         ascending u.  First call (colptr NULL): counts[v] = their number; the caller forms colptr = exclusive
+ *                         prefix sum; second call: keys[colptr[v] + i] = (v << 32) | u, vals[..] = c[v * ld + u], and / or
+ *                         rows[3 (colptr[v] + i) ..] = (float u, float v, count): the proposal file's row (filter.py:119).
+ *   eps_dense_mirror_lower: c[u * ld + v] = c[v * ld + u] for u < v -- the upper triangle of a product computed with the triangle
+ *                         flag, for readers that want whole rows. */
+int eps_dense_adjacency(const int64_t *rowptr, const int32_t *col, int64_t n_nodes, int64_t ld, int64_t rows, float *a,
+                        void *stream);
+int eps_dense_candidates(const float *a, const float *c, int64_t n_nodes, int64_t ld, int32_t below_only, int64_t *counts,
+                         const int64_t *colptr_or_null, int64_t *keys_or_null, float *vals_or_null, float *rows_or_null,
+                         void *stream);
+int eps_dense_mirror_lower(float *c, int64_t n, int64_t ld, void *stream);
 
 /* ---- K6: fused LinkPredictor decode ------------------------------------------------------
  * Replaces h[edges[0]], h[edges[1]] gathers (models.py:506) + LinkPredictor.forward

@@ -306,3 +306,58 @@ def test_select_topk_random_sizes_and_id_widths(eps, dev):
         for b in (bits, 32):
             got_k, got_v = eps.ops.select_topk(keys.to(dev), vals.to(dev), k, b)
             assert torch.equal(got_k.cpu(), want_k) and torch.equal(got_v.cpu(), want_v), (trial, bits, b, n, k)
+
+
+@pytest.mark.parametrize("n,p", [(300, 0.2), (1000, 0.1), (1031, 0.04), (129, 0.5)])
+def test_dense_common_neighbours_match_oracle_and_sparse_path(eps, oracle, dev, n, p):
+    """csrc/dense_cn.hip (configs[0]: a dense graph's CN list = A A^T on the f32 MFMA, lower tiles only, + a masked read): the
+    unordered candidates u < v of every column in ascending order with their counts -- bit-exact against the oracle's
+    candidate set (filter.py:96-109 restated) and counts (models.py:536-542), and against the sparse list kernel."""
+    import scipy.sparse as ssp
+    from eps_amd import candidates, ops, scan
+    rng = np.random.default_rng(n)
+    M = ssp.random(n, n, density=p / 2, random_state=rng, format="csr")
+    A = ((M + M.T) > 0).astype(np.float32).tocsr()
+    A.setdiag(0)
+    A.eliminate_zeros()
+    A.sort_indices()
+    g = eps.CSRGraph.from_scipy(A, device=dev)
+    g.val = None
+    assert candidates.dense_cn_suits(g)
+    keys, vals = ops.dense_cn_candidates(g.rowptr, g.col, g.n_rows)
+    pairs, _ = oracle.candidates_scipy(A)
+    lower = pairs[:, 0] < pairs[:, 1]
+    want_pairs = pairs[lower]                                    # column-major: v ascending, then u
+    cnt = oracle.pair_scores(A.indptr.astype(np.int64), A.indices.astype(np.int32), None, None, want_pairs[:, 0], want_pairs[:, 1])[1]
+    k = keys.cpu().numpy()
+    assert np.array_equal(k >> 32, want_pairs[:, 1]) and np.array_equal(k & 0xFFFFFFFF, want_pairs[:, 0])
+    assert np.array_equal(vals.cpu().numpy(), cnt.astype(np.float32))
+    # both orientations, the reference's own order (filter.py:96-109: column-major, v then u), None for an asymmetric pattern
+    dk, dvals = ops.dense_cn_candidates(g.rowptr, g.col, g.n_rows, directed=True, check_symmetric=True)
+    cnt_all = oracle.pair_scores(A.indptr.astype(np.int64), A.indices.astype(np.int32), None, None, pairs[:, 0], pairs[:, 1])[1]
+    dkn = dk.cpu().numpy()
+    assert np.array_equal(dkn >> 32, pairs[:, 1]) and np.array_equal(dkn & 0xFFFFFFFF, pairs[:, 0])
+    assert np.array_equal(dvals.cpu().numpy(), cnt_all.astype(np.float32))
+    rws, rc = ops.dense_cn_candidates(g.rowptr, g.col, g.n_rows, directed=True, as_rows=True)
+    assert torch.equal(rc, dvals) and np.array_equal(rws.cpu().numpy(), np.stack([pairs[:, 0], pairs[:, 1], cnt_all], 1).astype(np.float32))
+    B = A.tolil(copy=True)
+    i, j = np.argwhere(A.toarray() == 0)[5]
+    if i != j:
+        B[i, j] = 1.0
+        gb = eps.CSRGraph.from_scipy(B.tocsr(), device=dev)
+        assert ops.dense_cn_candidates(gb.rowptr, gb.col, gb.n_rows, directed=True, check_symmetric=True) is None
+    # the sparse list kernel: same pairs, same bits
+    ones = torch.ones(n, dtype=torch.float32, device=dev)
+    r = ops.expand_unit(g.rowptr, g.col, ones, n, 0, n, scan.max_degree(g), scan.window_splits(g), revpos=scan.reverse_positions(g))
+    sk = (r.pairs[1].to(torch.int64) << 32) | r.pairs[0].to(torch.int64)
+    o = torch.argsort(sk)
+    assert torch.equal(sk[o], keys) and torch.equal(r[4][o], vals)
+    # the triangle flag of the product: tiles above the diagonal are left alone
+    a = ops.dense_adjacency(g.rowptr, g.col, n)
+    c = torch.full_like(a, -7.0)
+    ops.gemm(a, a, out=c, lower_only=True)
+    full = ops.gemm(a, a)
+    np_ = a.shape[0]
+    tile = torch.arange(np_, device=dev) // 128
+    low = tile.unsqueeze(1) >= tile.unsqueeze(0)
+    assert torch.equal(c[low], full[low]) and bool((c[~low] == -7.0).all())
