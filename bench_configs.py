@@ -141,15 +141,22 @@ def leg_config0(torch):
                         "rank.py --model simple, 100 k proposals",
             "candidates": rows, "scored_s": tm.get("scored_s"), "gpu_ms": tm.get("gpu_ms"), "first_run_scored_s": tm.get("first_run_scored_s"),
             "candidates_per_s": rows / max(tm.get("scored_s") or (t1 - t0), 1e-9),
-            "bound": "hbm", "rows_GBps": rows * 12 / max((tm.get("gpu_ms") or 1e9) * 1e-3, 1e-9) / 1e9,
-            "frac": rows * 12 / max((tm.get("gpu_ms") or 1e9) * 1e-3, 1e-9) / 1e9 / HBM_PEAK_GBPS,
+            # r05: the list comes out of ONE dense product A A^T on the f32 MFMA (csrc/dense_cn.hip): the tiles on and below the
+            # diagonal of a 4352^3 product, against the 157.3 TF fp32 matrix peak over the WHOLE scoring section
+            "bound": "mfma", "product_flops": 4352 ** 3,
+            "TFLOPs_over_section": 4352 ** 3 / max((tm.get("gpu_ms") or 1e9) * 1e-3, 1e-9) / 1e12,
+            "frac": 4352 ** 3 / max((tm.get("gpu_ms") or 1e9) * 1e-3, 1e-9) / 1e12 / 157.3,
+            "rows_GBps": rows * 12 / max((tm.get("gpu_ms") or 1e9) * 1e-3, 1e-9) / 1e9,
             "wall_s": {"filter_cli": t1 - t0, "rank_cli": t2 - t1},
             "rank_curve": _jsonable(curves),
             "note": "scored_s / gpu_ms: the filter's scoring section (graph on the device -> all rows ordered on the device) on the host "
                     "clock and between two HIP events, SECOND run in this process (first_run_scored_s: the first, which also loads the "
                     "code objects of the kernels it is the first to use); wall_s: the whole CLI incl. stand-in generation, [E,3] file write / read and "
-                    "the rank stage's training-free evaluation.  16 M candidates are a LAUNCH-bound job (a few ms of kernels): the "
-                    "roofline fraction of writing the rows says so.  The reference runs this config on the CPU; there is no CPU "
+                    "the rank stage's training-free evaluation.  r05: a dense graph's common-neighbour list = A A^T on the matrix cores "
+                    "(lower tiles, mirrored), a masked read in the reference's candidate order and ONE stable sort by the integer "
+                    "count -- about twenty launches, 2.3 ms (r04: column blocks through the sparse kernels, 7.5 ms in hundreds of "
+                    "launches); `frac` = the product's flops over the whole section against the fp32 MFMA peak (the product itself: "
+                    "0.9-1.1 ms = 77-93 TF, profiles/r05/dense_cn.txt).  The reference runs this config on the CPU; there is no CPU "
                     "product path here"}
 
 

@@ -28,6 +28,7 @@
 #define PI_CAP 1024          // long-row entries staged per wave and pass (4 KiB of LDS per wave)
 #define PI_QCAP 256          // per-wave hit queue (1 KiB): deferred node_w gathers
 #define PI_INPLACE_RATIO 32  // long row searched in place when long > PI_CAP && long >= ratio*short
+#define PI_SMALL 256         // pairs whose LONGER row has at most this many entries are scored four at a time (16 lanes each)
 
 // Lower bound over a sorted LDS array of 2^lg entries (padded with INT_MAX): fully unrolled, branch-free steps,
 // trip count selected by a wave-uniform switch.  Returns pos in [0, 2^lg - 1]; the caller tests L[pos] == t.
@@ -114,9 +115,84 @@ __global__ __launch_bounds__(PI_WAVES * 64) void pair_scores_kernel(
             __builtin_amdgcn_wave_barrier();
         };
 
+        // SMALL pairs, four at a time (r05).  An evaluation list (train_and_eval.py:108-136: uniform negatives, stored edges) is
+        // mostly pairs of two short rows; scored one after the other by the whole wave each of them is a memory round trip with
+        // a handful of busy lanes -- 0.28 of the HBM roofline on 3 M uniform pairs of the ppa-like graph.  Here a quarter of the
+        // wave takes a pair: its 16 lanes stage the longer row (<= 256 entries) in their quarter of the wave's LDS, spread the
+        // shorter row over themselves and search; four pairs' loads are in flight together.  Unit-valued graphs, float32 weights.
+        int32_t du_left = du, dv_left = dv;
+        if (!HAS_VAL && sizeof(WT) == 4) {
+            const int32_t mx = du > dv ? du : dv, mn = du < dv ? du : dv;
+            uint64_t small = __ballot(valid && mn > 0 && mx <= PI_SMALL);
+            if (valid && mn > 0 && mx <= PI_SMALL) du_left = dv_left = 0;         // (the loop below skips them)
+            const int g = lane >> 4, gl = lane & 15;
+            while (small) {
+                int jg[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    jg[q] = small ? __builtin_ctzll(small) : -1;
+                    small &= small - 1ull;
+                }
+                const int j = g == 0 ? jg[0] : g == 1 ? jg[1] : g == 2 ? jg[2] : jg[3];
+                const int js = j < 0 ? 0 : j;
+                // (every lane takes part in the shuffles: a group without a pair must still SERVE its lanes' values to the others)
+                const int32_t du_j = __shfl(du, js), dv_j = __shfl(dv, js);
+                const int64_t bju = __shfl(ub, js), bjv = __shfl(vb, js);
+                const int32_t dju = j < 0 ? 0 : du_j, djv = j < 0 ? 0 : dv_j;
+                const bool swapped = dju > djv;
+                const int32_t slen = swapped ? djv : dju, llen = swapped ? dju : djv;
+                const int32_t *__restrict__ srow = col + (swapped ? bjv : bju), *__restrict__ lrow = col + (swapped ? bju : bjv);
+                int32_t *Lg = L + g * PI_SMALL;
+                // the longer row of each group, every load issued before the first LDS write; INT_MAX beyond its end
+                int32_t x[PI_SMALL / 16];
+#pragma unroll
+                for (int r = 0; r < PI_SMALL / 16; ++r) {
+                    const int idx = r * 16 + gl;
+                    x[r] = idx < llen ? lrow[idx] : 0x7fffffff;
+                }
+                const int32_t t0 = gl < slen ? srow[gl] : 0;                    // (the first slice of the shorter row rides along)
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int r = 0; r < PI_SMALL / 16; ++r) Lg[r * 16 + gl] = x[r];
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                int32_t s_max = slen;                                          // rounds: the longest of the four shorter rows
+                s_max = max(s_max, __shfl_xor(s_max, 16));
+                s_max = max(s_max, __shfl_xor(s_max, 32));
+                int cnt = 0;
+                float acc = 0.0f;
+                for (int s0 = 0; s0 < s_max; s0 += 16) {
+                    const int si = s0 + gl;
+                    const int32_t t = s0 == 0 ? t0 : (si < slen ? srow[si] : 0);
+                    const int pos = lb_pow2(Lg, 8, t);
+                    if (si < slen && Lg[pos] == t) {
+                        ++cnt;
+                        if (HAS_W) acc += (float)node_w[t];
+                    }
+                }
+#pragma unroll
+                for (int d = 8; d >= 1; d >>= 1) {                              // (within the 16 lanes of a group)
+                    cnt += __shfl_xor(cnt, d);
+                    acc += __shfl_xor(acc, d);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int cq = __builtin_amdgcn_readlane(cnt, q * 16);
+                    const float aq = lane_get(acc, q * 16);
+                    if (jg[q] >= 0 && lane == jg[q]) {
+                        my_count = cq;
+                        my_cn = (float)cq;
+                        my_ws = (WT)aq;
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();                               // (the next four overwrite the staged rows)
+            }
+        }
+
         for (int j = 0; j < 64; ++j) {
-            const int32_t dju = __builtin_amdgcn_readlane(du, j);
-            const int32_t djv = __builtin_amdgcn_readlane(dv, j);
+            const int32_t dju = __builtin_amdgcn_readlane(du_left, j);
+            const int32_t djv = __builtin_amdgcn_readlane(dv_left, j);
             if (dju == 0 || djv == 0) continue;  // wave-uniform (also: lanes past the end of the list)
             const int64_t bju = bcast64(ub, j), bjv = bcast64(vb, j);
             const bool swapped = dju > djv;  // short row = v
