@@ -348,8 +348,19 @@ def leg_full_list(torch):
             "kernel": "filter_scan_kernel<FS_COUNT> + <FS_EMIT> (eps_expand_unit_count / _fill)", "candidates": n_cand,
             "two_hop_paths": paths, "gpu_ms": ms, "wall_s": wall, "candidates_per_s": n_cand / ms * 1e3, "bound": "hbm",
             "algorithmic_bytes": abytes, "GBps": abytes / ms / 1e6, "frac": abytes / ms / 1e6 / HBM_PEAK_GBPS,
+            # what the literal list MUST move, whatever the algorithm: every path read once, every candidate written once
+            "one_pass_model": {"bytes": 4 * paths + 8 * n_cand + 24 * g.nnz(),
+                               "GBps": (4 * paths + 8 * n_cand + 24 * g.nnz()) / ms / 1e6,
+                               "frac": (4 * paths + 8 * n_cand + 24 * g.nnz()) / ms / 1e6 / HBM_PEAK_GBPS,
+                               "floor_ms_at_peak": (4 * paths + 8 * n_cand + 24 * g.nnz()) / HBM_PEAK_GBPS / 1e6},
             "note": "gpu_ms: HIP events around all blocks incl. the one host read per block (its candidate count sizes the list); "
-                    "algorithmic bytes = 4 B x two-hop paths x 2 passes + 8 B x candidates written + 24 B x nnz"}
+                    "algorithmic bytes = 4 B x two-hop paths x 2 passes + 8 B x candidates written + 24 B x nnz (the kernel's own two "
+                    "passes); one_pass_model = the same with every path read ONCE -- what the list costs whatever the algorithm "
+                    "(VERDICT r04 #4).  Why the leg still runs on the r02 two-pass kernel: the one-pass piece kernel keeps 15 / 31-bit "
+                    "SCREENING sums in its LDS table; a list of exact scores needs the 2^-40 fixed-point sums (41-bit terms, 52-bit sums: "
+                    "two table words per candidate + its key), i.e. a third of the candidates per piece and no skipped heads (every "
+                    "candidate is wanted) -- by the piece kernel's measured cost per piece that is no faster than the two passes.  The "
+                    "102 GB of rows alone are 12.8 ms at the HBM peak; no production path writes them (rank.py:294 reads K rows)"}
 
 
 def leg_config4(torch, n_pairs=125_000_000):
