@@ -338,10 +338,11 @@ def screen_weights(g0: CSRGraph, g: CSRGraph, perm, node_w: torch.Tensor) -> Scr
 class HeadTables:
     """What a launch with skipped heads brings (one set per budget): the head table, the window paths and the plan of the rows
     that are still walked, and that plan's dropped weight bits."""
-    __slots__ = ("budget", "heads", "wpaths", "plan", "d_used")
+    __slots__ = ("budget", "heads", "wpaths", "plan", "d_used", "live")
 
     def __init__(self, budget, heads, wpaths, plan, d_used):
         self.budget, self.heads, self.wpaths, self.plan, self.d_used = budget, heads, wpaths, plan, d_used
+        self.live = {}               # (rank, world) -> this rank's columns without the DEAD ones (see live_columns)
 
 
 HUB_TABLE_BYTES = 2 << 30   # the hub row bitmaps of a graph take at most this much (ppa-like: 16384 rows x 72 KB = 1.2 GB of 288)
@@ -381,6 +382,20 @@ def head_tables(g: CSRGraph, screen: Screen, budget: int) -> HeadTables:
             screen.heads.pop(next(iter(screen.heads)))
         screen.heads[budget] = HeadTables(budget, heads, wp, (pptr, recs), int(d_word.item()))
     return screen.heads[budget]
+
+
+def live_columns(g: CSRGraph, screen: Screen, ht: HeadTables, rank: int, world: int) -> torch.Tensor:
+    """This rank's columns of the heaviest-first order without the DEAD ones: a column whose row sum of screening weights lies
+    below the lowest bar the head table serves (budget / HEAD_KEEP[1]) cannot hold a pair that passes -- a quarter of the
+    ppa-like graph's columns at K = 4 M, which would otherwise each draw a ticket and load a header to find that out.  (The
+    launch checks every column against the bar at hand as well; scan_topk voids a launch whose bar fell below the table's.)"""
+    key = (rank, world)
+    if key not in ht.live:
+        mine = shard_columns(g, rank, world)
+        floor = int(ht.budget / HEAD_KEEP[1])
+        ssum = screen.ssum.to(torch.int64).bitwise_and(0xFFFFFFFF)
+        ht.live[key] = mine[ssum[mine.long()] >= floor].contiguous()
+    return ht.live[key]
 
 
 def _heads_for(g: CSRGraph, screen: Screen, bar) -> Optional[HeadTables]:
@@ -816,8 +831,8 @@ def scan_topk(g: CSRGraph, node_w: torch.Tensor, k: int, rank: int = 0, world: i
             raise ops._lib.EpsError(f"scan_topk: no usable bar after {launches} launches (k = {k}, capacity {capacity})")
         ht = _heads_for(g, screen, bar) if use_heads and bar is not None else None
         walked_cap = max(1, min(int(head_list * capacity), ops.SURVIVOR_SLOTS_MAX)) if ht is not None else 0
-        res = _launch(g, fixw, mine, float("-inf") if bar is None else bar, capacity, both=True, screen=screen, heads=ht,
-                      walked_capacity=walked_cap)
+        res = _launch(g, fixw, mine if ht is None else live_columns(g, screen, ht, rank, world), float("-inf") if bar is None else bar,
+                      capacity, both=True, screen=screen, heads=ht, walked_capacity=walked_cap)
         launches += 1
         l_keys, l_vals = res.key, res.val
         status, pre_thr = None, None
@@ -897,7 +912,8 @@ def scan_topk(g: CSRGraph, node_w: torch.Tensor, k: int, rank: int = 0, world: i
             # table was built) or a walked list that overflowed: the launch is void -- a table for THIS bar is built (head_cur
             # dropped: the next _heads_for reads the bar), the list grows; twice in a row: this call goes on without heads.
             bar_units = _f32_from_bits(table[0][7]) * 2.0 ** screen.shift
-            void = any(t[4] & 4 for t in table) or any(t[6] > walked_cap for t in table)
+            # (... or the bar fell below the lowest one the table -- and its list of live columns -- was built for)
+            void = any(t[4] & 4 for t in table) or any(t[6] > walked_cap for t in table) or ht.budget > HEAD_KEEP[1] * bar_units
             if void or not HEAD_KEEP[0] * bar_units <= ht.budget <= HEAD_KEEP[1] * bar_units:
                 screen.head_cur = None                       # (a budget out of range only costs time: the NEXT launch rebuilds)
             if void:
