@@ -84,6 +84,8 @@ struct sp_params {
     eps_survivors *out;
     unsigned int *status;       // bit 1: a hash table filled up (cannot happen within the piece limits; backstop); bit 2: a column's
                                 //        skipped head weighs as much as the bar (the head table was built for a higher bar: nothing valid)
+    const uint32_t *rowrec;     // [n_nodes][32] or NULL: per node ONE 128-byte line with everything the walk wants of a row -- words
+                                //        0..15 its 32 cuts, word 16 its first entry (rowptr), word 17 its screening weight (eps_scan_row_records)
     uint32_t batch_from;        // tickets below stand for one column, tickets from here on for SP_BATCH consecutive ones (>= n_columns: none)
     const uint2 *heads;         // [n_nodes] or NULL: column v does NOT walk its first heads[v].x rows (its heaviest hub neighbours under
                                 //        hubs-first labels); heads[v].y = the sum of their screening weights.  See eps_scan_heads.
@@ -320,8 +322,11 @@ __global__ __launch_bounds__(T, 4) void scan_piece_kernel(sp_params p)      // (
                 my_rev = (uint32_t)vrev[tid];
             }
             if (single && tid < dv) {
-                my_base = rowptr_lo[2 * (size_t)my_w];
-                my_fx = HV ? __builtin_bit_cast(uint32_t, (p.val[vb + tid] * p.node_w[my_w]) * p.up) : p.fx32[my_w];
+                // (with row records the row's first entry, its weight and -- below -- its cuts come out of ONE 128-byte line: three
+                //  gathers into three tables were 384 bytes of fabric traffic per walked row for 24 bytes wanted)
+                my_base = p.rowrec ? p.rowrec[(size_t)my_w * 32 + 16] : rowptr_lo[2 * (size_t)my_w];
+                my_fx = HV ? __builtin_bit_cast(uint32_t, (p.val[vb + tid] * p.node_w[my_w]) * p.up)
+                           : (p.rowrec ? p.rowrec[(size_t)my_w * 32 + 17] : p.fx32[my_w]);
             }
             // ---- plan: merge windows into pieces.  Wave 0, lane k = window k: the extents are ballots over monotone predicates -
             if (wib == 0 && !p.plan) {
@@ -367,7 +372,9 @@ __global__ __launch_bounds__(T, 4) void scan_piece_kernel(sp_params p)      // (
             // starts where its segment in the previous piece ended (runs that were skipped hold no entry of any row), and the
             // one cut a piece needs per row -- its end -- is loaded a piece ahead.
             uint32_t cut_ahead = 0u, seg_from = 0u;
-            if (single && tid < dv && np > 0) cut_ahead = p.cuts[(size_t)my_w * SP_M + s_pk1[0] - 1];
+            const uint16_t *__restrict__ cut_tab = p.rowrec ? (const uint16_t *)p.rowrec : p.cuts;      // (a row's cuts: 64 B of its record,
+            const size_t cut_ld = p.rowrec ? 64u : (size_t)SP_M;                                        //  or its row of the cut table)
+            if (single && tid < dv && np > 0) cut_ahead = cut_tab[(size_t)my_w * cut_ld + s_pk1[0] - 1];
 
             for (int pi = 0; pi < np; ++pi) {
                 const int k0 = s_pk0[pi], k1 = s_pk1[pi];
@@ -425,7 +432,7 @@ __global__ __launch_bounds__(T, 4) void scan_piece_kernel(sp_params p)      // (
                     seg_a = seg_from;
                     seg_len = (uint32_t)tid < xv ? 0u : b - seg_from;
                     seg_from = b;
-                    if (pi + 1 < np) cut_ahead = p.cuts[(size_t)my_w * SP_M + s_pk1[pi + 1] - 1];
+                    if (pi + 1 < np) cut_ahead = cut_tab[(size_t)my_w * cut_ld + s_pk1[pi + 1] - 1];
                 }
                 for (uint32_t part = 0; part < parts; ++part) {
                     // ---- known edges in: the neighbours of v inside the piece take their slots BEFORE the walk, with the flag bit
@@ -477,9 +484,10 @@ __global__ __launch_bounds__(T, 4) void scan_piece_kernel(sp_params p)      // (
                         } else if (j < dv) {
                             w = (uint32_t)vcol[j];
                             rev = (uint32_t)vrev[j];
-                            base = rowptr_lo[2 * (size_t)w];
-                            fx = HV ? __builtin_bit_cast(uint32_t, (p.val[vb + j] * p.node_w[w]) * p.up) : p.fx32[w];
-                            const uint16_t *crow = p.cuts + (size_t)w * SP_M;
+                            base = p.rowrec ? p.rowrec[(size_t)w * 32 + 16] : rowptr_lo[2 * (size_t)w];
+                            fx = HV ? __builtin_bit_cast(uint32_t, (p.val[vb + j] * p.node_w[w]) * p.up)
+                                    : (p.rowrec ? p.rowrec[(size_t)w * 32 + 17] : p.fx32[w]);
+                            const uint16_t *crow = cut_tab + (size_t)w * cut_ld;
                             uint32_t b = crow[k1 - 1];
                             if (k0 > 0) a = crow[k0 - 1];
                             a = a < rev ? a : rev;
@@ -1373,6 +1381,39 @@ extern "C" int eps_rescore_weighted(const int64_t *rowptr, const int32_t *col, c
 
 extern "C" int32_t eps_scan_windows(void) { return SP_M; }
 
+// rowrec[w * 32 + 0 .. 15] = the 32 cuts of row w, [16] = its first entry (rowptr, low word), [17] = its screening weight, rest 0:
+// one 128-byte line per node holds what the scan's walk gathers per row.
+__global__ __launch_bounds__(256) void sp_rowrec_kernel(const uint16_t *__restrict__ cuts, const int64_t *__restrict__ rowptr,
+                                                        const uint32_t *__restrict__ fx32, int64_t n_nodes, uint32_t *__restrict__ rowrec)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_nodes * 32; i += stride) {
+        const int64_t w = i >> 5;
+        const int k = (int)(i & 31);
+        uint32_t x = 0u;
+        if (k < SP_M / 2) x = ((const uint32_t *)cuts)[w * (SP_M / 2) + k];
+        else if (k == 16) x = (uint32_t)rowptr[w];
+        else if (k == 17) x = fx32[w];
+        rowrec[i] = x;
+    }
+}
+
+extern "C" int eps_scan_row_records(const uint16_t *cuts, const int64_t *rowptr, const uint32_t *fx32, int64_t n_nodes, uint32_t *rowrec,
+                                    void *stream)
+{
+    EPS_REQUIRE(n_nodes >= 0 && n_nodes < (1ll << 31), "eps_scan_row_records: bad size");
+    if (n_nodes == 0) return EPS_OK;
+    EPS_REQUIRE(cuts && rowptr && fx32 && rowrec && ((uintptr_t)rowrec & 127) == 0 && ((uintptr_t)cuts & 3) == 0,
+                "eps_scan_row_records: null or misaligned pointer (row records are 128-byte lines)");
+    static_assert(SP_M == 32, "a row record holds 32 cuts in its first 64 bytes");
+    int64_t blocks = (n_nodes * 32 + 255) / 256;
+    const int64_t cap = (int64_t)eps_num_cus() * 16;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(sp_rowrec_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, cuts, rowptr, fx32, n_nodes, rowrec);
+    EPS_CHECK_LAUNCH("eps_scan_row_records");
+    return EPS_OK;
+}
+
 extern "C" int eps_scan_cuts(const int64_t *rowptr, const int32_t *col, int64_t n_nodes, const int32_t *bounds, uint16_t *cuts,
                              void *stream)
 {
@@ -1431,14 +1472,15 @@ extern "C" int eps_scan_screen_weights(const int64_t *fixw, int64_t n, int32_t s
 //          registers, 16 spilled) with the 4096-slot table: 21.8 ms against 17.9.
 static int sp_launch(const int64_t *rowptr, const int32_t *col, const float *val, const int32_t *revpos, const uint32_t *fx32,
                      const float *node_w, const uint16_t *cuts, const uint32_t *wpaths, const uint32_t *ssum, const uint32_t *smax,
-                     const uint32_t *pptr, const uint32_t *plan, const uint32_t *heads, const int32_t *bounds, int64_t n_nodes,
-                     int64_t nnz, const int32_t *columns, int64_t n_columns, int64_t batch_from, int32_t shift, int32_t variant,
-                     eps_survivors *out, uint32_t *status, void *stream);
+                     const uint32_t *pptr, const uint32_t *plan, const uint32_t *heads, const uint32_t *rowrec, const int32_t *bounds,
+                     int64_t n_nodes, int64_t nnz, const int32_t *columns, int64_t n_columns, int64_t batch_from, int32_t shift,
+                     int32_t variant, eps_survivors *out, uint32_t *status, void *stream);
 
 extern "C" int eps_scan_screen(const int64_t *rowptr, const int32_t *col, const int32_t *revpos, const uint32_t *fx32,
                                const uint16_t *cuts, const uint32_t *wpaths, const uint32_t *ssum_or_null,
                                const uint32_t *smax_or_null, const uint32_t *pptr_or_null, const uint32_t *plan_or_null,
-                               const uint32_t *heads_or_null, const int32_t *bounds, int64_t n_nodes, int64_t nnz,
+                               const uint32_t *heads_or_null, const uint32_t *rowrec_or_null, const int32_t *bounds, int64_t n_nodes,
+                               int64_t nnz,
                                const int32_t *columns, int64_t n_columns, int64_t batch_from, int32_t shift, int32_t variant,
                                eps_survivors *out, uint32_t *status, void *stream)
 {
@@ -1446,7 +1488,8 @@ extern "C" int eps_scan_screen(const int64_t *rowptr, const int32_t *col, const 
     EPS_REQUIRE((ssum_or_null == nullptr) == (smax_or_null == nullptr), "eps_scan_screen: ssum and smax come together");
     EPS_REQUIRE(!heads_or_null || plan_or_null, "eps_scan_screen: a head table comes with the plan table built for it");
     return sp_launch(rowptr, col, nullptr, revpos, fx32, nullptr, cuts, wpaths, ssum_or_null, smax_or_null, pptr_or_null,
-                     plan_or_null, heads_or_null, bounds, n_nodes, nnz, columns, n_columns, batch_from, shift, variant, out, status, stream);
+                     plan_or_null, heads_or_null, rowrec_or_null, bounds, n_nodes, nnz, columns, n_columns, batch_from, shift, variant, out,
+                     status, stream);
 }
 
 // The same scan on a SYMMETRIC adjacency with stored values (val[e] == val[mirror of e]); node_w = the float node weights.
@@ -1457,8 +1500,8 @@ extern "C" int eps_scan_screen_weighted(const int64_t *rowptr, const int32_t *co
                                         void *stream)
 {
     EPS_REQUIRE(n_columns == 0 || n_nodes == 0 || (val && node_w), "eps_scan_screen_weighted: null pointer");
-    return sp_launch(rowptr, col, val, revpos, nullptr, node_w, cuts, wpaths, nullptr, nullptr, nullptr, nullptr, nullptr, bounds, n_nodes,
-                     nnz, columns, n_columns, n_columns, shift, variant, out, status, stream);
+    return sp_launch(rowptr, col, val, revpos, nullptr, node_w, cuts, wpaths, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, bounds,
+                     n_nodes, nnz, columns, n_columns, n_columns, shift, variant, out, status, stream);
 }
 
 static const int sp_threads_of[3] = {512, 1024, 256}, sp_bits_of[3] = {13, 14, 12}, sp_per_cu[3] = {2, 1, 4};
@@ -1593,9 +1636,9 @@ extern "C" int eps_scan_plan_rewalk(const uint32_t *plan, int64_t n_rec, int32_t
 
 static int sp_launch(const int64_t *rowptr, const int32_t *col, const float *val, const int32_t *revpos, const uint32_t *fx32,
                      const float *node_w, const uint16_t *cuts, const uint32_t *wpaths, const uint32_t *ssum, const uint32_t *smax,
-                     const uint32_t *pptr, const uint32_t *plan, const uint32_t *heads, const int32_t *bounds, int64_t n_nodes,
-                     int64_t nnz, const int32_t *columns, int64_t n_columns, int64_t batch_from, int32_t shift, int32_t variant,
-                     eps_survivors *out, uint32_t *status, void *stream)
+                     const uint32_t *pptr, const uint32_t *plan, const uint32_t *heads, const uint32_t *rowrec, const int32_t *bounds,
+                     int64_t n_nodes, int64_t nnz, const int32_t *columns, int64_t n_columns, int64_t batch_from, int32_t shift,
+                     int32_t variant, eps_survivors *out, uint32_t *status, void *stream)
 {
     EPS_REQUIRE(n_nodes >= 0 && n_columns >= 0 && nnz >= 0, "eps_scan_screen: negative size");
     EPS_REQUIRE(status, "eps_scan_screen: null pointer");
@@ -1628,6 +1671,7 @@ static int sp_launch(const int64_t *rowptr, const int32_t *col, const float *val
     p.pptr = pptr;
     p.plan = (const uint4 *)plan;
     p.heads = (const uint2 *)heads;
+    p.rowrec = rowrec;
     p.columns = columns;
     p.n_columns = (int32_t)n_columns;
     p.batch_from = batch_from < 0 || batch_from > n_columns ? (uint32_t)n_columns : (uint32_t)batch_from;

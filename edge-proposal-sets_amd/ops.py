@@ -625,6 +625,22 @@ HUB_MAX = 16384           # hub rows a graph's bitmap table holds (eps_scan_hub_
                           # ppa-like graph with 4096 / 8192 / 16384 / 32768 rows: 11.27 / 10.40 / 10.00 / 9.87 ms (72 KB per row)
 
 
+def scan_row_records(cuts: torch.Tensor, rowptr: torch.Tensor, fx32: torch.Tensor) -> torch.Tensor:
+    """int32-bits [N, 32]: per node ONE 128-byte line -- its 32 cuts, its first entry, its screening weight (eps_scan_row_records):
+    what eps_scan_screen gathers per walked row, out of one table instead of three.  Per (graph, weight table)."""
+    dev = _need_gpu(cuts, rowptr, fx32)
+    _chk(cuts, torch.int16, "cuts"); _chk(rowptr, torch.int64, "rowptr"); _chk(fx32, torch.int32, "fx32")
+    n = fx32.numel()
+    if cuts.shape[0] != n or rowptr.numel() != n + 1:
+        raise _lib.EpsError("scan_row_records: cuts / rowptr / fx32 do not match")
+    buf = torch.empty(n * 32 + 32, dtype=torch.int32, device=dev)           # (128-byte aligned start inside the allocation)
+    off = (-buf.data_ptr() % 128) // 4
+    out = buf[off:off + n * 32].view(n, 32)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.load().eps_scan_row_records(_ptr(cuts), _ptr(rowptr), _ptr(fx32), n, _ptr(out), _stream(dev)), "eps_scan_row_records")
+    return out
+
+
 def scan_heads(rowptr, col, fx32: torch.Tensor, n_hub: int, budget: int) -> torch.Tensor:
     """int32-bits [N, 2] (x_v, T_v): per column the longest prefix of its row with ids < ``n_hub`` whose screening weights sum
     to T_v <= ``budget`` (table units) -- the rows eps_scan_screen does not walk under a bar (eps_scan_heads)."""
@@ -773,7 +789,7 @@ def scan_screen(rowptr, col, revpos, fx32, cuts, bounds, n_nodes: int, columns: 
                 status: torch.Tensor, variant: Optional[int] = None, val: Optional[torch.Tensor] = None,
                 node_w: Optional[torch.Tensor] = None, wpaths: Optional[torch.Tensor] = None,
                 ssum: Optional[torch.Tensor] = None, smax: Optional[torch.Tensor] = None, plan=None,
-                heads: Optional[torch.Tensor] = None, batch_from: Optional[int] = None) -> None:
+                heads: Optional[torch.Tensor] = None, batch_from: Optional[int] = None, rowrec: Optional[torch.Tensor] = None) -> None:
     """Launch eps_scan_screen over ``columns``; survivors (screening scores) accumulate in ``out``.  ``val`` / ``node_w``
     (float32 stored values / node weights): the weighted flavour (eps_scan_screen_weighted; ``fx32`` unused).
     ``ssum`` / ``smax`` (int32-bits [N] / [M + 1]; unit-valued graphs): per-node sums of fx32 over the row and their
@@ -781,7 +797,8 @@ def scan_screen(rowptr, col, revpos, fx32, cuts, bounds, n_nodes: int, columns: 
     ``plan`` = (pptr, records) from ``scan_plan`` built with the same wpaths / ssum / smax / shift / variant.
     ``heads`` (``scan_heads``; with the wpaths / plan built for it): the launch skips every column's head and ``out.val`` holds
     the walked sums as raw bits -- ``scan_refine`` turns that list into the one a launch without heads reports.
-    ``batch_from``: ``columns[batch_from:]`` are handed out eight per draw (light columns at the end of a heaviest-first list)."""
+    ``batch_from``: ``columns[batch_from:]`` are handed out eight per draw (light columns at the end of a heaviest-first list).
+    ``rowrec`` (``scan_row_records``): per node one 128-byte line with its cuts, first entry and weight."""
     pptr, recs = plan if plan is not None else (None, None)
     dev = _need_gpu(rowptr, col, revpos, fx32, cuts, bounds, columns, status, val, node_w, wpaths, ssum, smax, pptr, recs, heads)
     _chk_heads(heads, n_nodes)
@@ -812,7 +829,7 @@ def scan_screen(rowptr, col, revpos, fx32, cuts, bounds, n_nodes: int, columns: 
             ev[0].record(torch.cuda.current_stream(dev))
         if val is None:
             _lib.check(lib.eps_scan_screen(_ptr(rowptr), _ptr(col), _ptr(revpos), _ptr(fx32), _ptr(cuts), _ptr(wpaths), _ptr(ssum),
-                                           _ptr(smax), _ptr(pptr), _ptr(recs), _ptr(heads), _ptr(bounds), n_nodes,
+                                           _ptr(smax), _ptr(pptr), _ptr(recs), _ptr(heads), _ptr(rowrec), _ptr(bounds), n_nodes,
                                            col.numel(), _ptr(columns), columns.numel(), -1 if batch_from is None else int(batch_from),
                                            int(shift), variant, _ptr(out.rec), _ptr(status), _stream(dev)), "eps_scan_screen")
         else:

@@ -47,6 +47,7 @@ HEAD_BETA = 0.5            # ... as long as their screening weights sum to at mo
 HEAD_KEEP = (0.3, 0.58)    # a head table is used again while its budget stays within this range of the current bar
 HEAD_LIST = 6              # the walked list (slots that pass at bar - T_v) is sized this many times the survivor list
 HEAD_CACHE = 4             # head tables kept per (graph, weight table)
+ROW_RECORDS = True            # the launch gathers a row's cuts, first entry and weight out of ONE 128-byte line (ops.scan_row_records)
 BATCH_MIN_COLUMNS = 1 << 16   # lists shorter than this are handed out one column at a time throughout
 BATCH_PATHS = 1 << 13      # columns of a heaviest-first list with fewer half paths are handed out eight per ticket (see batch_from)
 
@@ -251,7 +252,7 @@ def screen_shift(bound: float, max_deg: int, weighted: bool = False) -> int:
 
 class Screen:
     """What a launch of the piece kernel and the exact re-scoring of its survivors need, for one (graph, weight table)."""
-    __slots__ = ("fx32", "shift", "fixw", "val", "node_w", "usable", "ssum", "smax", "plan", "d_used", "w_min", "heads", "head_cur")
+    __slots__ = ("fx32", "shift", "fixw", "val", "node_w", "usable", "ssum", "smax", "plan", "d_used", "w_min", "heads", "head_cur", "rowrec")
 
     def __init__(self, fx32, shift, fixw, val, node_w, usable, ssum=None, smax=None, plan=None, d_used=0, w_min=0.0):
         self.fx32, self.shift, self.fixw, self.val, self.node_w, self.usable = fx32, shift, fixw, val, node_w, usable
@@ -260,6 +261,7 @@ class Screen:
         self.w_min = w_min           # smallest weight of a node that can be a common neighbour (0: no relative bound)
         self.heads = {}              # budget (table units) -> HeadTables (see head_tables)
         self.head_cur = None         # the HeadTables the last launch under a bar used
+        self.rowrec = None           # ops.scan_row_records: one 128-byte line per node with what the walk gathers per row
 
     def lower_bound(self, s: torch.Tensor, max_deg: int) -> torch.Tensor:
         """A lower bound of the exact score of a pair whose screening score is ``s`` (monotone in s).  A path's screening term
@@ -321,6 +323,7 @@ def screen_weights(g0: CSRGraph, g: CSRGraph, perm, node_w: torch.Tensor) -> Scr
         bad_h, d_h, min_h = torch.cat([bad.view(torch.int32), d_word if d_word is not None else zero,
                                        min_fx if min_fx is not None else zero - 1]).tolist()
         usable = fits and bad_h == 0
+        rowrec = ops.scan_row_records(screen_tables(g)[1], g.rowptr, fx32) if usable and one_pass and ROW_RECORDS else None
         if not usable:
             ssum = smax = plan = None
         d_used, w_min = 0, 0.0
@@ -330,7 +333,9 @@ def screen_weights(g0: CSRGraph, g: CSRGraph, perm, node_w: torch.Tensor) -> Scr
             # fx32 rounds the exact weight x 2^shift UP: one unit less is a floor under every common neighbour's exact weight
             lowest = min_h & 0xFFFFFFFF
             w_min = 0.0 if lowest == 0xFFFFFFFF else max(0, lowest - 1) * 2.0 ** -shift
-        return Screen(fx32, shift, fixw, None, None, usable, ssum, smax, plan, d_used, w_min)
+        sc = Screen(fx32, shift, fixw, None, None, usable, ssum, smax, plan, d_used, w_min)
+        sc.rowrec = rowrec
+        return sc
     # (one entry per labelling: the tables are indexed by the SCANNED graph's node ids)
     return g0.weight_cached("screen_weights" if perm is None else "screen_weights_relabelled", node_w, build)
 
@@ -473,7 +478,7 @@ def _launch(g, fixw, columns, threshold, capacity, scores_only: bool = False, bo
             walked = ops.Survivors(walked_capacity, threshold, g.device, prefill=False)
             ops.scan_screen(g.rowptr, g.col, reverse_positions(g), screen.fx32, cuts, bounds, g.n_rows, columns, screen.shift, walked,
                             out.status, screen_variant(g), None, None, heads.wpaths, screen.ssum, screen.smax, heads.plan, heads.heads,
-                            batch_from(g, columns))
+                            batch_from(g, columns), screen.rowrec)
             ops.scan_refine(walked, heads.heads, hub_rows(g), screen.fx32, g.rowptr, g.col, g.n_rows, screen.shift, out)
             out.rec[4:5].copy_(walked.rec[4:5])              # (candidates the walk touched)
             out.walked_slots = walked.rec[1:2]
@@ -481,7 +486,7 @@ def _launch(g, fixw, columns, threshold, capacity, scores_only: bool = False, bo
             bounds, cuts = screen_tables(g)
             ops.scan_screen(g.rowptr, g.col, reverse_positions(g), screen.fx32, cuts, bounds, g.n_rows, columns, screen.shift, out,
                             out.status, screen_variant(g), screen.val, screen.node_w, window_paths(g), screen.ssum, screen.smax, screen.plan,
-                            None, batch_from(g, columns))
+                            None, batch_from(g, columns), screen.rowrec)
         else:
             ops.filter_scan(g.rowptr, g.col, reverse_positions(g), fixw, g.n_rows, columns, out, max_degree(g), window_splits(g))
     return out

@@ -288,9 +288,14 @@ int eps_scan_window_paths(const int64_t *rowptr, const int32_t *col, const int32
 int eps_scan_screen(const int64_t *rowptr, const int32_t *col, const int32_t *revpos, const uint32_t *fx32,
                     const uint16_t *cuts, const uint32_t *wpaths, const uint32_t *ssum_or_null,
                     const uint32_t *smax_or_null, const uint32_t *pptr_or_null, const uint32_t *plan_or_null,
-                    const uint32_t *heads_or_null, const int32_t *bounds, int64_t n_nodes, int64_t nnz, const int32_t *columns,
-                    int64_t n_columns, int64_t batch_from, int32_t shift, int32_t variant, eps_survivors *out, uint32_t *status,
-                    void *stream);
+                    const uint32_t *heads_or_null, const uint32_t *rowrec_or_null, const int32_t *bounds, int64_t n_nodes, int64_t nnz,
+                    const int32_t *columns, int64_t n_columns, int64_t batch_from, int32_t shift, int32_t variant, eps_survivors *out,
+                    uint32_t *status, void *stream);
+/* eps_scan_row_records: rowrec[w * 32 + 0 .. 15] = the 32 cuts of row w, [16] = rowptr[w] (low word), [17] = fx32[w], rest 0 -- ONE
+ * 128-byte line per node with everything eps_scan_screen gathers per walked row (r05: three gathers into three tables were 384
+ * bytes of fabric traffic per row for 24 bytes wanted).  Per (graph, weight table); 128-byte aligned; optional for eps_scan_screen. */
+int eps_scan_row_records(const uint16_t *cuts, const int64_t *rowptr, const uint32_t *fx32, int64_t n_nodes, uint32_t *rowrec,
+                         void *stream);
 /* ---- skipped heads (r05; csrc/scan_heads.hip): half of all two-hop paths run through a few thousand hub rows whose weights are
  * the smallest there are, so under a bar a column need not walk them (still filter.py:96-142 + :160-161 under --keep_top) ------
  *   eps_scan_heads     : heads[2 v] = x_v, heads[2 v + 1] = T_v (uint32 pairs, 8-byte aligned): the longest prefix of row v with

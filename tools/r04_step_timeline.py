@@ -26,7 +26,7 @@ def wrap(mod, name, label=None):
         log.append((label or name, e0, e1))
         return r
     setattr(mod, name, inner)
-for n in ("scan_screen", "filter_scan", "kth_largest_dist", "compact_at_least", "rescore_runs", "rescore_weighted", "select_rows",
+for n in ("scan_screen", "scan_refine", "filter_scan", "kth_largest_dist", "compact_at_least", "rescore_runs", "rescore_weighted", "select_rows",
           "select_compact", "sort_pairs_by_u", "select_splitters", "compact_range"):
     if hasattr(ops, n):
         wrap(ops, n)
