@@ -84,6 +84,9 @@ struct sp_params {
     eps_survivors *out;
     unsigned int *status;       // bit 1: a hash table filled up (cannot happen within the piece limits; backstop); bit 2: a column's
                                 //        skipped head weighs as much as the bar (the head table was built for a higher bar: nothing valid)
+    const uint4 *colrec;        // [n_columns][2] or NULL: what a column's set-up reads of five tables, in hand-out order (one 32-byte load
+                                //        at the ticket's index instead of a chain id -> row start / head / row sum / plan pointer):
+                                //        {v, rowptr[v], degree, head rows | head weight, row sum, first plan record, pieces}
     const uint32_t *rowrec;     // [n_nodes][32] or NULL: per node ONE 128-byte line with everything the walk wants of a row -- words
                                 //        0..15 its 32 cuts, word 16 its first entry (rowptr), word 17 its screening weight (eps_scan_row_records)
     uint32_t batch_from;        // tickets below stand for one column, tickets from here on for SP_BATCH consecutive ones (>= n_columns: none)
@@ -288,9 +291,20 @@ __global__ __launch_bounds__(T, 4) void scan_piece_kernel(sp_params p)      // (
         const bool last_of_ticket = t + 1u >= t_end || t + 1u >= ncol;
         unsigned int t_next = 0;
         if (tid == 0 && last_of_ticket) t_next = gridDim.x + atomicAdd(p.next_col, 1u);     // in flight while this column is scored
-        const int32_t v = p.columns[t];
-        const uint32_t vb = rowptr_lo[2 * (size_t)v];
-        const int32_t dv = (int32_t)(rowptr_lo[2 * (size_t)v + 2] - vb);
+        int32_t v, dv;
+        uint32_t vb;
+        uint4 cra = make_uint4(0u, 0u, 0u, 0u), crb = make_uint4(0u, 0u, 0u, 0u);
+        if (p.colrec) {
+            cra = p.colrec[2 * (size_t)t];
+            crb = p.colrec[2 * (size_t)t + 1];
+            v = (int32_t)cra.x;
+            vb = cra.y;
+            dv = (int32_t)cra.z;
+        } else {
+            v = p.columns[t];
+            vb = rowptr_lo[2 * (size_t)v];
+            dv = (int32_t)(rowptr_lo[2 * (size_t)v + 2] - vb);
+        }
         const int32_t *__restrict__ vcol = p.col + vb;
         const int32_t *__restrict__ vrev = p.revpos + vb;
         const int rounds = (dv + T - 1) / T;
@@ -303,7 +317,7 @@ __global__ __launch_bounds__(T, 4) void scan_piece_kernel(sp_params p)      // (
         uint32_t xv = 0u, thr_v = thr32;
         bool bad_head = false;
         if (p.heads) {
-            const uint2 hd = p.heads[v];
+            const uint2 hd = p.colrec ? make_uint2(cra.w, crb.x) : p.heads[v];
             xv = hd.x;
             if (thr32 < SP_FLAG) {
                 bad_head = hd.y >= thr32;
@@ -313,7 +327,7 @@ __global__ __launch_bounds__(T, 4) void scan_piece_kernel(sp_params p)      // (
             // a DEAD column: no pair of v sums to more than the row sum of v's screening weights -- below the bar, nothing of
             // this column can pass (a quarter of the ppa-like graph's columns at K = 4 M: a tenth of the pieces, 4 % of the paths.
             // Launches with heads only: a plain launch counts every candidate of its columns)
-            if (p.ssum && thr32 < SP_FLAG && p.ssum[v] < thr32) bad_head = true;
+            if (p.ssum && thr32 < SP_FLAG && (p.colrec ? crb.y : p.ssum[v]) < thr32) bad_head = true;
         }
         if (dv > 0 && v > 0 && !bad_head) {
             uint32_t my_w = 0, my_rev = 0, my_base = 0, my_fx = 0;      // this thread's row (of the last round)
@@ -349,8 +363,8 @@ __global__ __launch_bounds__(T, 4) void scan_piece_kernel(sp_params p)      // (
                 if (lane == 0) s_np = np;
             } else if (p.plan) {
                 // the per-graph plan table: this column's records (one uint4 per piece) go straight into the piece arrays
-                const uint32_t pb = p.pptr[v];
-                const int np = (int)(p.pptr[v + 1] - pb);
+                const uint32_t pb = p.colrec ? crb.z : p.pptr[v];
+                const int np = p.colrec ? (int)crb.w : (int)(p.pptr[v + 1] - pb);
                 if (tid < np) {
                     const uint4 rec = p.plan[pb + (uint32_t)tid];
                     const int k1 = (int)((rec.y >> 8) & 0xFFu);
@@ -1473,23 +1487,24 @@ extern "C" int eps_scan_screen_weights(const int64_t *fixw, int64_t n, int32_t s
 static int sp_launch(const int64_t *rowptr, const int32_t *col, const float *val, const int32_t *revpos, const uint32_t *fx32,
                      const float *node_w, const uint16_t *cuts, const uint32_t *wpaths, const uint32_t *ssum, const uint32_t *smax,
                      const uint32_t *pptr, const uint32_t *plan, const uint32_t *heads, const uint32_t *rowrec, const int32_t *bounds,
-                     int64_t n_nodes, int64_t nnz, const int32_t *columns, int64_t n_columns, int64_t batch_from, int32_t shift,
-                     int32_t variant, eps_survivors *out, uint32_t *status, void *stream);
+                     int64_t n_nodes, int64_t nnz, const int32_t *columns, const uint32_t *colrec, int64_t n_columns, int64_t batch_from,
+                     int32_t shift, int32_t variant, eps_survivors *out, uint32_t *status, void *stream);
 
 extern "C" int eps_scan_screen(const int64_t *rowptr, const int32_t *col, const int32_t *revpos, const uint32_t *fx32,
                                const uint16_t *cuts, const uint32_t *wpaths, const uint32_t *ssum_or_null,
                                const uint32_t *smax_or_null, const uint32_t *pptr_or_null, const uint32_t *plan_or_null,
                                const uint32_t *heads_or_null, const uint32_t *rowrec_or_null, const int32_t *bounds, int64_t n_nodes,
                                int64_t nnz,
-                               const int32_t *columns, int64_t n_columns, int64_t batch_from, int32_t shift, int32_t variant,
+                               const int32_t *columns, const uint32_t *colrec_or_null, int64_t n_columns, int64_t batch_from, int32_t shift,
+                               int32_t variant,
                                eps_survivors *out, uint32_t *status, void *stream)
 {
     EPS_REQUIRE(n_columns == 0 || n_nodes == 0 || fx32, "eps_scan_screen: null pointer");
     EPS_REQUIRE((ssum_or_null == nullptr) == (smax_or_null == nullptr), "eps_scan_screen: ssum and smax come together");
     EPS_REQUIRE(!heads_or_null || plan_or_null, "eps_scan_screen: a head table comes with the plan table built for it");
     return sp_launch(rowptr, col, nullptr, revpos, fx32, nullptr, cuts, wpaths, ssum_or_null, smax_or_null, pptr_or_null,
-                     plan_or_null, heads_or_null, rowrec_or_null, bounds, n_nodes, nnz, columns, n_columns, batch_from, shift, variant, out,
-                     status, stream);
+                     plan_or_null, heads_or_null, rowrec_or_null, bounds, n_nodes, nnz, columns, colrec_or_null, n_columns, batch_from, shift,
+                     variant, out, status, stream);
 }
 
 // The same scan on a SYMMETRIC adjacency with stored values (val[e] == val[mirror of e]); node_w = the float node weights.
@@ -1501,7 +1516,7 @@ extern "C" int eps_scan_screen_weighted(const int64_t *rowptr, const int32_t *co
 {
     EPS_REQUIRE(n_columns == 0 || n_nodes == 0 || (val && node_w), "eps_scan_screen_weighted: null pointer");
     return sp_launch(rowptr, col, val, revpos, nullptr, node_w, cuts, wpaths, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, bounds,
-                     n_nodes, nnz, columns, n_columns, n_columns, shift, variant, out, status, stream);
+                     n_nodes, nnz, columns, nullptr, n_columns, n_columns, shift, variant, out, status, stream);
 }
 
 static const int sp_threads_of[3] = {512, 1024, 256}, sp_bits_of[3] = {13, 14, 12}, sp_per_cu[3] = {2, 1, 4};
@@ -1637,8 +1652,8 @@ extern "C" int eps_scan_plan_rewalk(const uint32_t *plan, int64_t n_rec, int32_t
 static int sp_launch(const int64_t *rowptr, const int32_t *col, const float *val, const int32_t *revpos, const uint32_t *fx32,
                      const float *node_w, const uint16_t *cuts, const uint32_t *wpaths, const uint32_t *ssum, const uint32_t *smax,
                      const uint32_t *pptr, const uint32_t *plan, const uint32_t *heads, const uint32_t *rowrec, const int32_t *bounds,
-                     int64_t n_nodes, int64_t nnz, const int32_t *columns, int64_t n_columns, int64_t batch_from, int32_t shift,
-                     int32_t variant, eps_survivors *out, uint32_t *status, void *stream)
+                     int64_t n_nodes, int64_t nnz, const int32_t *columns, const uint32_t *colrec, int64_t n_columns, int64_t batch_from,
+                     int32_t shift, int32_t variant, eps_survivors *out, uint32_t *status, void *stream)
 {
     EPS_REQUIRE(n_nodes >= 0 && n_columns >= 0 && nnz >= 0, "eps_scan_screen: negative size");
     EPS_REQUIRE(status, "eps_scan_screen: null pointer");
@@ -1653,6 +1668,8 @@ static int sp_launch(const int64_t *rowptr, const int32_t *col, const float *val
     EPS_REQUIRE(n_nodes < (1ll << 31) && n_columns < (1ll << 31), "eps_scan_screen: too many nodes / columns");
     EPS_REQUIRE(shift >= 0 && shift <= 40 && variant >= 0 && variant <= 2, "eps_scan_screen: bad shift / variant");
     EPS_REQUIRE(((uintptr_t)cuts & 15) == 0, "eps_scan_screen: cuts must be 16-byte aligned");
+    EPS_REQUIRE(((uintptr_t)colrec & 15) == 0 && ((uintptr_t)rowrec & 127) == 0, "eps_scan_screen: misaligned column / row records");
+    EPS_REQUIRE(!colrec || plan, "eps_scan_screen: column records come with the plan table they were built from");
     EPS_REQUIRE((pptr == nullptr) == (plan == nullptr) && ((uintptr_t)plan & 15) == 0, "eps_scan_screen: pptr and plan come together, 16-byte aligned");
     const int T = sp_threads_of[variant], bits = sp_bits_of[variant];
     unsigned int *counter = nullptr;
@@ -1672,6 +1689,7 @@ static int sp_launch(const int64_t *rowptr, const int32_t *col, const float *val
     p.plan = (const uint4 *)plan;
     p.heads = (const uint2 *)heads;
     p.rowrec = rowrec;
+    p.colrec = (const uint4 *)colrec;
     p.columns = columns;
     p.n_columns = (int32_t)n_columns;
     p.batch_from = batch_from < 0 || batch_from > n_columns ? (uint32_t)n_columns : (uint32_t)batch_from;

@@ -789,7 +789,8 @@ def scan_screen(rowptr, col, revpos, fx32, cuts, bounds, n_nodes: int, columns: 
                 status: torch.Tensor, variant: Optional[int] = None, val: Optional[torch.Tensor] = None,
                 node_w: Optional[torch.Tensor] = None, wpaths: Optional[torch.Tensor] = None,
                 ssum: Optional[torch.Tensor] = None, smax: Optional[torch.Tensor] = None, plan=None,
-                heads: Optional[torch.Tensor] = None, batch_from: Optional[int] = None, rowrec: Optional[torch.Tensor] = None) -> None:
+                heads: Optional[torch.Tensor] = None, batch_from: Optional[int] = None, rowrec: Optional[torch.Tensor] = None,
+                colrec: Optional[torch.Tensor] = None) -> None:
     """Launch eps_scan_screen over ``columns``; survivors (screening scores) accumulate in ``out``.  ``val`` / ``node_w``
     (float32 stored values / node weights): the weighted flavour (eps_scan_screen_weighted; ``fx32`` unused).
     ``ssum`` / ``smax`` (int32-bits [N] / [M + 1]; unit-valued graphs): per-node sums of fx32 over the row and their
@@ -798,7 +799,8 @@ def scan_screen(rowptr, col, revpos, fx32, cuts, bounds, n_nodes: int, columns: 
     ``heads`` (``scan_heads``; with the wpaths / plan built for it): the launch skips every column's head and ``out.val`` holds
     the walked sums as raw bits -- ``scan_refine`` turns that list into the one a launch without heads reports.
     ``batch_from``: ``columns[batch_from:]`` are handed out eight per draw (light columns at the end of a heaviest-first list).
-    ``rowrec`` (``scan_row_records``): per node one 128-byte line with its cuts, first entry and weight."""
+    ``rowrec`` (``scan_row_records``): per node one 128-byte line with its cuts, first entry and weight.
+    ``colrec`` (int32 [len(columns), 8]; ``scan.column_records``): the columns' headers in hand-out order."""
     pptr, recs = plan if plan is not None else (None, None)
     dev = _need_gpu(rowptr, col, revpos, fx32, cuts, bounds, columns, status, val, node_w, wpaths, ssum, smax, pptr, recs, heads)
     _chk_heads(heads, n_nodes)
@@ -830,7 +832,7 @@ def scan_screen(rowptr, col, revpos, fx32, cuts, bounds, n_nodes: int, columns: 
         if val is None:
             _lib.check(lib.eps_scan_screen(_ptr(rowptr), _ptr(col), _ptr(revpos), _ptr(fx32), _ptr(cuts), _ptr(wpaths), _ptr(ssum),
                                            _ptr(smax), _ptr(pptr), _ptr(recs), _ptr(heads), _ptr(rowrec), _ptr(bounds), n_nodes,
-                                           col.numel(), _ptr(columns), columns.numel(), -1 if batch_from is None else int(batch_from),
+                                           col.numel(), _ptr(columns), _ptr(colrec), columns.numel(), -1 if batch_from is None else int(batch_from),
                                            int(shift), variant, _ptr(out.rec), _ptr(status), _stream(dev)), "eps_scan_screen")
         else:
             _lib.check(lib.eps_scan_screen_weighted(_ptr(rowptr), _ptr(col), _ptr(val), _ptr(revpos), _ptr(node_w), _ptr(cuts),

@@ -403,6 +403,27 @@ def live_columns(g: CSRGraph, screen: Screen, ht: HeadTables, rank: int, world: 
     return ht.live[key]
 
 
+COLUMN_RECORDS = True         # a launch reads a column's header as one 32-byte record in hand-out order (column_records)
+
+
+def column_records(g: CSRGraph, screen: Screen, columns: torch.Tensor, plan, heads: Optional[torch.Tensor], cache: dict, key):
+    """int32 [len(columns), 8], cached in ``cache[key]``: per column of the hand-out list {v, rowptr[v], degree, head rows, head
+    weight, row sum, first plan record, pieces} -- what the kernel's column set-up otherwise reads through a chain of dependent
+    loads into five tables (plain gathers here: the list, the plan and the head table are fixed once built)."""
+    if not COLUMN_RECORDS or plan is None or columns.numel() == 0:
+        return None
+    if key not in cache:
+        c = columns.long()
+        rp = g.rowptr
+        pptr = plan[0].to(torch.int64).bitwise_and(0xFFFFFFFF)
+        zero = torch.zeros_like(c)
+        hx, hy = (heads[c, 0].to(torch.int64), heads[c, 1].to(torch.int64)) if heads is not None else (zero, zero)
+        ss = screen.ssum[c].to(torch.int64) if screen.ssum is not None else zero
+        rec = torch.stack([c, rp[c], rp[c + 1] - rp[c], hx, hy, ss, pptr[c], pptr[c + 1] - pptr[c]], 1)
+        cache[key] = rec.to(torch.int32).contiguous()           # (two's-complement wrap keeps the low 32 bits of every field)
+    return cache[key]
+
+
 def _heads_for(g: CSRGraph, screen: Screen, bar) -> Optional[HeadTables]:
     """The head tables for a launch under ``bar`` (1-element device tensor): the set the last launch used, without looking at the
     bar -- the kernel itself refuses a head as heavy as the bar (status bit 2), and scan_topk compares budget and bar after
@@ -478,7 +499,8 @@ def _launch(g, fixw, columns, threshold, capacity, scores_only: bool = False, bo
             walked = ops.Survivors(walked_capacity, threshold, g.device, prefill=False)
             ops.scan_screen(g.rowptr, g.col, reverse_positions(g), screen.fx32, cuts, bounds, g.n_rows, columns, screen.shift, walked,
                             out.status, screen_variant(g), None, None, heads.wpaths, screen.ssum, screen.smax, heads.plan, heads.heads,
-                            batch_from(g, columns), screen.rowrec)
+                            batch_from(g, columns), screen.rowrec,
+                            column_records(g, screen, columns, heads.plan, heads.heads, heads.live, ("colrec", columns.data_ptr(), columns.numel())))
             ops.scan_refine(walked, heads.heads, hub_rows(g), screen.fx32, g.rowptr, g.col, g.n_rows, screen.shift, out)
             out.rec[4:5].copy_(walked.rec[4:5])              # (candidates the walk touched)
             out.walked_slots = walked.rec[1:2]

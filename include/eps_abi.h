@@ -289,8 +289,12 @@ int eps_scan_screen(const int64_t *rowptr, const int32_t *col, const int32_t *re
                     const uint16_t *cuts, const uint32_t *wpaths, const uint32_t *ssum_or_null,
                     const uint32_t *smax_or_null, const uint32_t *pptr_or_null, const uint32_t *plan_or_null,
                     const uint32_t *heads_or_null, const uint32_t *rowrec_or_null, const int32_t *bounds, int64_t n_nodes, int64_t nnz,
-                    const int32_t *columns, int64_t n_columns, int64_t batch_from, int32_t shift, int32_t variant, eps_survivors *out,
-                    uint32_t *status, void *stream);
+                    const int32_t *columns, const uint32_t *colrec_or_null, int64_t n_columns, int64_t batch_from, int32_t shift,
+                    int32_t variant, eps_survivors *out, uint32_t *status, void *stream);
+/* colrec (optional; needs the plan table; 16-byte aligned): 8 words per entry of `columns`, in the same order -- {v, rowptr[v] (low
+ * word), degree, heads[2 v], heads[2 v + 1], ssum[v], pptr[v], pptr[v + 1] - pptr[v]} (zeros where a table is absent) -- what a
+ * column's set-up otherwise reads through a chain id -> five tables, as ONE 32-byte load at the hand-out index.  The caller builds
+ * it with plain gathers (eps_amd.scan.column_records). */
 /* eps_scan_row_records: rowrec[w * 32 + 0 .. 15] = the 32 cuts of row w, [16] = rowptr[w] (low word), [17] = fx32[w], rest 0 -- ONE
  * 128-byte line per node with everything eps_scan_screen gathers per walked row (r05: three gathers into three tables were 384
  * bytes of fabric traffic per row for 24 bytes wanted).  Per (graph, weight table); 128-byte aligned; optional for eps_scan_screen. */

@@ -80,6 +80,7 @@ for beta in [float(x) for x in (sys.argv[1:] or ["0", "0.25", "0.5", "0.625"])]:
             wk = ops.Survivors(256 << 20, bar, dev, prefill=False)
             ops.scan_screen(g.rowptr, g.col, scan.reverse_positions(g), sc.fx32, cuts, bounds, g.n_rows, order, sc.shift, wk, status, variant,
                             wpaths=ht.wpaths, ssum=sc.ssum, smax=sc.smax, plan=ht.plan, heads=ht.heads,
+                            colrec=None if os.environ.get('COLREC', '1') == '0' else scan.column_records(g, sc, order, ht.plan, ht.heads, ht.live, "ab"),
                             batch_from=int(os.environ['BATCH_FROM']) if 'BATCH_FROM' in os.environ else scan.batch_from(g, order),
                             rowrec=None if os.environ.get('ROWREC', '1') == '0' else sc.rowrec)
             return wk
