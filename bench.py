@@ -406,7 +406,7 @@ def run(args):
     # backend, every rank part of the same group), which matters for the first run of this path on RCCL
     props = torch.cuda.get_device_properties(dev)
     me = {"rank": dist.get_rank() if world > 1 else 0, "world": dist.get_world_size() if world > 1 else 1, "env_rank": rank,
-          "local_rank": int(os.environ.get("LOCAL_RANK", "0")), "device_index": dev.index, "device": props.name,
+          "local_rank": int(os.environ.get("LOCAL_RANK", "0")), "device_index": dev.index, "device": torch.cuda.get_device_name(dev),
           "pci_bus_id": getattr(props, "pci_bus_id", None), "uuid": str(getattr(props, "uuid", "")) or None,
           "backend": dist.get_backend() if world > 1 else None, "visible_devices": torch.cuda.device_count(),
           "ipc_mode_legacy": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")}
