@@ -152,3 +152,82 @@ def test_round4_entry_points_on_empty_and_tiny_inputs(eps, dev):
     assert int(n) == 1 and ok[:1].tolist() == one.tolist() and float(kth) == 2.5 and float(thr) == 2.5
     ok, ov, n, kth, thr = ops.select_compact(one, torch.tensor([2.5], device=dev), 2)     # fewer entries than k: everything
     assert int(n) == 1 and float(kth) == float("-inf")
+
+
+def test_round5_entry_points_on_empty_and_tiny_inputs(eps, dev):
+    """The r05 entry points at the small end: head tables / hub rows / row records of a graph without edges and of one edge, a
+    refine pass over an empty walked list, the dense product on one and two nodes, a launch whose whole column list is handed out in
+    batches, column records of an empty list."""
+    from eps_amd import scan
+    from eps_amd.graph import CSRGraph
+    ops = eps.ops
+    i64 = dict(dtype=torch.int64, device=dev)
+    i32 = dict(dtype=torch.int32, device=dev)
+    # a graph of 5 nodes without edges
+    rp = torch.zeros(6, **i64)
+    col = torch.zeros(0, **i32)
+    fx = torch.ones(5, **i32)
+    assert ops.scan_heads(rp, col, fx, 5, 100).tolist() == [[0, 0]] * 5
+    assert ops.scan_heads(rp, col, fx, 0, 100).tolist() == [[0, 0]] * 5
+    hub = ops.scan_hub_rows(rp, col, 5)
+    assert tuple(hub.shape) == (5, ops.scan_hub_row_words(5)) and int(hub.abs().sum()) == 0
+    assert tuple(ops.scan_hub_rows(rp, col, 0).shape) == (0, ops.scan_hub_row_words(5))
+    cuts = ops.scan_cuts(rp, col, ops.scan_bounds(rp, 5))
+    rec = ops.scan_row_records(cuts, rp, fx)
+    assert tuple(rec.shape) == (5, 32) and rec.data_ptr() % 128 == 0 and rec[:, 17].tolist() == [1] * 5 and int(rec[:, :17].abs().sum()) == 0
+    # one edge: heads under a budget that admits the row / does not; the hub row bitmaps hold both directions
+    g2 = CSRGraph.from_edge_index(torch.tensor([[0, 1], [1, 0]], device=dev), None, sparse_sizes=(2, 2))
+    fx2 = torch.tensor([3, 5], **i32)
+    assert ops.scan_heads(g2.rowptr, g2.col, fx2, 2, 10).tolist() == [[1, 5], [1, 3]]
+    assert ops.scan_heads(g2.rowptr, g2.col, fx2, 2, 4).tolist() == [[0, 0], [1, 3]]
+    assert ops.scan_heads(g2.rowptr, g2.col, fx2, 1, 10).tolist() == [[0, 0], [1, 3]]      # (node 1 is no hub: row 0 keeps its entry)
+    assert ops.scan_hub_rows(g2.rowptr, g2.col, 2)[:, 0].tolist() == [2, 1]
+    # refine over an empty walked list, and over one slot whose head term decides
+    heads = ops.scan_heads(g2.rowptr, g2.col, fx2, 2, 10)
+    hub2 = ops.scan_hub_rows(g2.rowptr, g2.col, 2)
+    walked = ops.Survivors(16, 0.0, dev, prefill=False)
+    out = ops.Survivors(16, 0.0, dev, prefill=False)
+    ops.scan_refine(walked, heads, hub2, fx2, g2.rowptr, g2.col, 2, 0, out)
+    assert out.counts()[0] == 0
+    # (a path graph 0 - 1 - 2: pair (0, 2) has the common neighbour 1; column 2 skips its row 1 -- weight 7 -- and the walked sum 0
+    #  plus the head term reaches a bar of 7, stays below one of 9)
+    g3 = CSRGraph.from_edge_index(torch.tensor([[0, 1, 1, 2], [1, 0, 2, 1]], device=dev), None, sparse_sizes=(3, 3))
+    fx3 = torch.tensor([1, 7, 1], **i32)
+    h3 = ops.scan_heads(g3.rowptr, g3.col, fx3, 3, 7)
+    assert h3.tolist() == [[1, 7], [2, 2], [1, 7]]
+    hub3 = ops.scan_hub_rows(g3.rowptr, g3.col, 3)
+    for bar, kept in ((7.0, 1), (9.0, 0)):
+        walked = ops.Survivors(16, bar - 0.5, dev, prefill=False)
+        walked.key[0] = (2 << 32) | 0
+        walked.val.view(torch.int32)[0] = 0
+        walked.rec[1] = 1
+        out = ops.Survivors(16, bar - 0.5, dev, prefill=False)
+        ops.scan_refine(walked, h3, hub3, fx3, g3.rowptr, g3.col, 3, 0, out)
+        assert out.counts()[0] == kept
+        if kept:
+            assert out.key[:1].tolist() == [(2 << 32) | 0] and out.val[:1].tolist() == [7.0]
+    # the dense product on one node, on two nodes (an edge: no candidate), on the path (one candidate each way)
+    for g, want in ((CSRGraph(torch.zeros(2, **i64), col, None, 1, 1), []), (g2, []), (g3, [(2, 0, 1.0), (0, 2, 1.0)])):
+        rows, cnt = ops.dense_cn_candidates(g.rowptr, g.col, g.n_rows, directed=True, check_symmetric=True, as_rows=True)
+        assert [tuple(r) for r in rows.tolist()] == want and cnt.tolist() == [w[2] for w in want]
+        keys, cnt = ops.dense_cn_candidates(g.rowptr, g.col, g.n_rows)
+        assert keys.tolist() == [(v << 32) | u for u, v, _ in want if u < v]
+    # column records of an empty list; every column of a list handed out in batches (batch_from = 0), fewer columns than a batch
+    assert scan.column_records(g3, None, torch.zeros(0, **i32), (None, None), None, {}, "k") is None
+    from eps_amd import synth
+    g = synth.rmat_graph(9, 6, 4, dev)
+    w = torch.ones(g.n_rows, device=dev)
+    sc = scan.screen_weights(g, g, None, w)
+    bounds, cuts = scan.screen_tables(g)
+    order = scan.column_order(g)
+    got = []
+    for cols, bf in ((order, 0), (order[:5].contiguous(), 0), (order, None)):
+        res = ops.Survivors(scan._capacity(2 * scan.total_half_paths(g), scan._PIECE_SLACK), float("-inf"), dev, prefill=False)
+        status = torch.zeros(1, **i32)
+        ops.scan_screen(g.rowptr, g.col, scan.reverse_positions(g), sc.fx32, cuts, bounds, g.n_rows, cols, sc.shift, res, status,
+                        scan.screen_variant(g), wpaths=scan.window_paths(g), ssum=sc.ssum, smax=sc.smax, plan=sc.plan, batch_from=bf,
+                        rowrec=sc.rowrec, colrec=scan.column_records(g, sc, cols, sc.plan, None, {}, "k"))
+        assert int(status) == 0
+        k, _ = res.valid(res.counts()[0])
+        got.append((torch.sort(k).values, res.counts()[1]))
+    assert torch.equal(got[0][0], got[2][0]) and got[0][1] == got[2][1] and 0 < got[1][1] <= got[0][1]
