@@ -45,6 +45,12 @@
 #ifndef SP_SB
 #define SP_SB 4                 // uint4 reads a thread issues together in the table sweeps
 #endif
+#ifndef SP_PACKED_X8
+#define SP_PACKED_X8 8u         // a packed piece holds at most this many eighths of 2^table_bits paths
+#endif
+#ifndef SP_MODE_RATIO
+#define SP_MODE_RATIO 2270u     // fixed cost of a piece in hashed-path units (the planner's direct-vs-packed choice); r05: 1000 / 4000 re-measured
+#endif
 #ifndef SP_BATCH
 #define SP_BATCH 8              // columns per ticket in the light tail of the column order
 #endif
@@ -1534,11 +1540,11 @@ static void sp_plan_geometry(sp_params &p, const uint16_t *cuts, const uint32_t 
     p.piece_paths = (1u << bits) / 2u;
     p.ssum = ssum;
     p.smax = smax;
-    p.packed_paths = 1u << bits;
+    p.packed_paths = (SP_PACKED_X8 << bits) / 8u;      // (8: load factor 1/2 of the 2^(bits + 1)-word table)
     p.packed_dmax = shift > 8 ? (shift - 8 < 24 ? shift - 8 : 24) : 0;      // (weights keep at least 2^-8 resolution)
     // measured on the ppa-like graph (tools/r03_screen_ab.py): 1500 -> 23.8 ms, 2270 -> 23.5, 4000 -> 23.7; packed_paths 3584 / 4096 /
     // 5120 -> 24.0 / 23.5 / 24.1 ms
-    p.mode_ratio = 2270u;
+    p.mode_ratio = SP_MODE_RATIO;
     p.shift = shift;
 }
 
