@@ -19,6 +19,8 @@ ABL = {
     # no walk at all: describe, barriers, sweeps
     "nowalk": [("                            const int n_iter = (int)(uhi - ulo + T - 1) / T;      // uniform over the workgroup", "                            const int n_iter = (int)(uhi - ulo) < 0 ? 1 : 0;      // uniform over the workgroup"),
                ("                            sp_unit fa[SP_G], fb[SP_G];\n                            fetch_group(0, fa);\n                            if (n_iter <= SP_G) {", "                            sp_unit fa[SP_G], fb[SP_G];\n                            if (n_iter > 0) fetch_group(0, fa);\n                            if (n_iter == 0) {} else if (n_iter <= SP_G) {")],
+    # the packed walk without its straggler loop (entries that missed two probes are dropped): what deferring them could save at most
+    "nostraggle": [("                                uint32_t ch = 0u, cstep = 0u, clid = 0u, cfx = 0u, tries = 0u;\n                                bool have = false;\n                                while (__ballot(have || pend != 0u)) {", "                                uint32_t ch = 0u, cstep = 0u, clid = 0u, cfx = 0u, tries = 0u;\n                                bool have = false;\n                                pend = 0u;\n                                while (__ballot(have || pend != 0u)) {")],
     # no known-edge marking
     "noknown": [("                    for (int j = single ? tid : na + tid; j < nb; j += T) {", "                    for (int j = single ? tid : na + tid; j < nb && j < 0; j += T) {")],
 }
@@ -29,6 +31,8 @@ def build():
     objs = [os.path.join(CSRC, "build", f) for f in sorted(os.listdir(os.path.join(CSRC, "build"))) if f.endswith(".o") and f != "scan_pieces.o"]
     os.makedirs(os.path.join(ROOT, "tools", "bin"), exist_ok=True)
     for name, patches in ABL.items():
+        if sys.argv[2:] and name not in sys.argv[2:]:
+            continue
         s = open(os.path.join(CSRC, "scan_pieces.hip")).read()
         for old, new in patches:
             assert s.count(old) == 1, (name, s.count(old), old[:60])
@@ -44,7 +48,7 @@ def build():
 
 
 def run():
-    for name in ["hip"] + list(ABL):
+    for name in ["hip"] + [n for n in ABL if not sys.argv[2:] or n in sys.argv[2:]]:
         env = dict(os.environ)
         if name != "hip":
             env["EPS_LIB_PATH"] = os.path.join(ROOT, "tools", "bin", f"libeps_abl_{name}.so")
@@ -58,4 +62,4 @@ def run():
 
 
 if __name__ == "__main__":
-    build() if sys.argv[1:] == ["build"] else run()
+    build() if sys.argv[1:2] == ["build"] else run()

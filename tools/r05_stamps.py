@@ -9,7 +9,8 @@ OUT = os.path.join(ROOT, "tools", "bin", "libeps_stamps.so")
 NAMES = ["column set-up (ticket, header, rows, plan records) until the piece loop", "piece preamble + known edges in", "describe until its barrier has passed",
          "walk: start bits + word ranks", "walk: first look-up + row load until it ARRIVED", "walk: table updates, further units, end barrier",
          "table sweep + barrier", "ticket hand-over / column end", "(count) columns", "(count) pieces", "(count) columns with pieces",
-         "(count) dead or empty columns"]
+         "(count) dead or empty columns", "  of the walk: wave 0 waiting at the walk's end barrier", "  walk (all of it) in PACKED pieces", "  walk (all of it) in direct pieces",
+         "(count) packed pieces"]
 
 
 def build():
@@ -36,7 +37,7 @@ struct sp_params {''')
     rep('                        const int total = (int)(s_alloc >> 32);\n', '                        XS(d1); XA(2, d0, d1);\n                        const int total = (int)(s_alloc >> 32);\n')
     rep('                            sp_unit fa[SP_G], fb[SP_G];\n                            fetch_group(0, fa);\n', '                            sp_unit fa[SP_G], fb[SP_G];\n                            XS(w1); if (ulo == 0u) XA(3, d1, w1);\n                            fetch_group(0, fa);\n                            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");\n                            XS(w2); XA(4, w1, w2);\n')
     rep('                        sp_barrier();        // the next round / the scan follows: descriptors and table updates are complete\n',
-        '                        sp_barrier();        // the next round / the scan follows: descriptors and table updates are complete\n                        XS(d2); XA(5, w2x, d2);\n')
+        '                        XS(w3);\n                        sp_barrier();        // the next round / the scan follows: descriptors and table updates are complete\n                        XS(d2); XA(5, w2x, d2); XA(12, w3, d2); XA(packed ? 13 : 14, d1, d2); xst[15] += packed ? 1 : 0;\n')
     rep('                            const int n_iter = (int)(uhi - ulo + T - 1) / T;      // uniform over the workgroup\n', '                            const int n_iter = (int)(uhi - ulo + T - 1) / T;      // uniform over the workgroup\n')
     # w2 lives in an inner scope: carry it out
     rep('                        const int total = (int)(s_alloc >> 32);\n', '                        const int total = (int)(s_alloc >> 32);\n                        unsigned long long w2x = d1;\n')
