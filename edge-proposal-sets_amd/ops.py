@@ -489,6 +489,21 @@ def _scan_scratch(dev, max_degree: int) -> torch.Tensor:
 SURVIVOR_SLOTS_MAX = (1 << 32) - (1 << 20)   # slots are 32-bit positions handed out in chunks: keep a chunk's worth of head-room
 
 
+_PINNED = {"buf": None, "i": 0}
+
+
+def _pinned_words(words) -> torch.Tensor:
+    """A pinned int64 host tensor holding ``words`` (<= 8), from a ring of 256 slots -- the source of an asynchronous host-to-device
+    copy must stay untouched until the stream has run it; 256 copies ahead of the device do not happen in this library."""
+    if _PINNED["buf"] is None:
+        _PINNED["buf"] = torch.empty((256, 8), dtype=torch.int64).pin_memory()
+    _PINNED["i"] = (_PINNED["i"] + 1) % 256
+    slot = _PINNED["buf"][_PINNED["i"]]
+    n = len(words)
+    slot[:n] = torch.tensor(words, dtype=torch.int64)
+    return slot[:n]
+
+
 class Survivors:
     """Device-resident eps_survivors record + its key / val arrays.  ``threshold`` may be a Python float or a 0-dim /
     1-element float32 DEVICE tensor (copied on the stream: no host round trip)."""
@@ -521,7 +536,10 @@ class Survivors:
             self.val = torch.empty(self.capacity, dtype=torch.float32, device=device)
         thr_host = float(threshold) if not isinstance(threshold, torch.Tensor) else 0.0
         head = struct.unpack("<q", struct.pack("<fI", thr_host, self.capacity))[0]
-        self.rec = torch.tensor([head, 0, self.key.data_ptr(), self.val.data_ptr(), 0], dtype=torch.int64, device=device)
+        # (the 40-byte record goes up through a pinned staging slot, asynchronously on the stream: torch.tensor(..., device=) is a
+        #  blocking copy, and a filter step builds three of these between its launches)
+        self.rec = torch.empty(5, dtype=torch.int64, device=device)
+        self.rec.copy_(_pinned_words([head, 0, self.key.data_ptr(), self.val.data_ptr(), 0]), non_blocking=True)
         if isinstance(threshold, torch.Tensor):
             self.rec.view(torch.float32)[0:1].copy_(threshold.reshape(1).to(torch.float32))
 
