@@ -290,16 +290,21 @@ def run(args) -> str:
         # --keep_top with a heuristic filter on a symmetric graph (unit-valued, or collab's summed multi-edge weights): one
         # threshold scan of the whole candidate set (csrc/scan_pieces.hip / filter_scan.hip) instead of candidate blocks +
         # streaming top-K; every rank ends with the same list
-        st = {}
+        # (count=False: a launch with skipped heads counts the candidates its walk TOUCHES; the exact size of the candidate set
+        #  would be one more scan of the graph -- a fifth of this one-shot run -- for a number that is only printed)
+        st = {"count": False}
         with torch.no_grad():
             # (the file is written by rank 0: the ordered rows travel there alone)
             best_pairs, best_scores = scan.scan_topk(data.adj_t, scan_w, keep, rank, world, stats=st, relabel=True,
                                                      rows_on=0 if world > 1 else None)
-        dt = watch.stop(st["candidates"])
+        n_seen = st["candidates"] if st["candidates"] is not None else st["touched"]
+        dt = watch.stop(n_seen)
         bar = None if st["bar"] is None else float(st["bar"])
-        print(f'threshold scan ({args.model}): bar {bar}, {st["survivors"]} survivors, {st["launches"]} launches')
-        print(f'using {st["candidates"]} edges; scored in {dt:.2f} s ({st["candidates"] / max(dt, 1e-9):.3e} candidate edges/s '
-              f'incl. generation)')
+        print(f'threshold scan ({args.model}): bar {bar}, {st["survivors"]} survivors, {st["launches"]} launches'
+              + (f', heads skipped under a budget of {st["head_budget"]:.4f}' if st.get("heads") else ''))
+        print(f'using {"at least " if st["candidates"] is None else ""}{n_seen} edges; scored in {dt:.2f} s '
+              f'({n_seen / max(dt, 1e-9):.3e} candidate edges/s incl. generation)'
+              + (' -- every 2-hop non-edge is covered by the bound; the count is of those the walk touched' if st["candidates"] is None else ''))
         return _save(args, spec, sorted_edge_path, num_sorted_edge, run_id, rank, world,
                      None if best_pairs is None else torch.cat([best_pairs.t().to(torch.float32), best_scores.unsqueeze(1)], 1))
     full_w = (fused_node_weights(args, data.adj_t, ra_graph)

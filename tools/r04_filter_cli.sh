@@ -6,6 +6,6 @@ W=$(mktemp -d); cd $W
 for spec in "ppa adamic_ogb 4000000" "collab adamic_ogb 150000" "ddi simple 100000"; do
   set -- $spec
   for rep in 1 2 3; do
-    python3 $GRAFT_REPO_ROOT/filter.py --dataset $1 --model $2 --checkpoint "$1_$2||0|$rep.pt" --synthetic --keep_top $3 2>&1 | grep -E "threshold scan|using [0-9]+ edges|fused" | sed "s/^/$1 $2 keep_top $3 run $rep: /"
+    python3 $GRAFT_REPO_ROOT/filter.py --dataset $1 --model $2 --checkpoint "$1_$2||0|$rep.pt" --synthetic --keep_top $3 2>&1 | grep -E "threshold scan|using (at least )?[0-9]+ edges|fused|dense" | sed "s/^/$1 $2 keep_top $3 run $rep: /"
   done
 done
