@@ -45,7 +45,9 @@ MAX_SCREEN_SHIFT = 30
 HEADS = True               # under a bar a column does not walk its heaviest hub rows (csrc/scan_heads.hip; see head_tables)
 HEAD_BETA = 0.5            # ... as long as their screening weights sum to at most this share of the bar
 HEAD_KEEP = (0.3, 0.58)    # a head table is used again while its budget stays within this range of the current bar
-HEAD_LIST = 6              # the walked list (slots that pass at bar - T_v) is sized this many times the survivor list
+HEAD_LIST = 2              # the walked list (slots that pass at bar - T_v) is sized this many times the survivor list (16 M slots of 49 M
+                           # on the ppa-like graph; an overflow doubles it and repeats.  6 x was 1.8 GB of first-time hipMalloc in a one-shot run)
+HEAD_MIN_PATHS = 1 << 30   # graphs with fewer two-hop half paths are scanned without heads: their tables cost more than they save
 HEAD_CACHE = 4             # head tables kept per (graph, weight table)
 ROW_RECORDS = True            # the launch gathers a row's cuts, first entry and weight out of ONE 128-byte line (ops.scan_row_records)
 BATCH_MIN_COLUMNS = 1 << 16   # lists shorter than this are handed out one column at a time throughout
@@ -353,13 +355,30 @@ class HeadTables:
 HUB_TABLE_BYTES = 2 << 30   # the hub row bitmaps of a graph take at most this much (ppa-like: 16384 rows x 72 KB = 1.2 GB of 288)
 
 
+HUB_FIRST = 4096            # hub rows of a graph's FIRST scan: a one-shot filter.py run pays ~25 ms of first-time hipMalloc per GB,
+                            # more than the 1.3 ms the wider table saves its one launch; the second scan of a graph builds the full table
+
+
 def hub_rows(g: CSRGraph) -> torch.Tensor:
     """int32-bits [n_hub, words], cached per graph: the adjacency rows of the first n_hub ids (the hubs, under hubs-first
-    labels) as bitmaps over the id space -- where eps_scan_refine looks a pair's skipped rows up."""
+    labels) as bitmaps over the id space -- where eps_scan_refine looks a pair's skipped rows up.  HUB_FIRST rows while the
+    graph has been scanned once, ops.HUB_MAX from its second scan on (``_count_scan`` drops the narrow table)."""
     if "hub_rows" not in g._cache:
-        n_hub = min(ops.HUB_MAX, g.n_rows, HUB_TABLE_BYTES // (4 * ops.scan_hub_row_words(g.n_rows)))
+        most = ops.HUB_MAX if g._cache.get("scan_calls", 0) > 1 else min(ops.HUB_MAX, HUB_FIRST)
+        n_hub = min(most, g.n_rows, HUB_TABLE_BYTES // (4 * ops.scan_hub_row_words(g.n_rows)))
         g._cache["hub_rows"] = ops.scan_hub_rows(g.rowptr, g.col, n_hub)
     return g._cache["hub_rows"]
+
+
+def _count_scan(g: CSRGraph, screen) -> None:
+    """One more scan_topk call on this (scanned) graph; at the second, the hub table of the first -- and the head tables built
+    against it -- make room for the full-width ones."""
+    g._cache["scan_calls"] = g._cache.get("scan_calls", 0) + 1
+    if g._cache["scan_calls"] == 2 and "hub_rows" in g._cache and g._cache["hub_rows"].shape[0] < min(ops.HUB_MAX, g.n_rows):
+        del g._cache["hub_rows"]
+        if screen is not None:
+            screen.heads.clear()
+            screen.head_cur = None
 
 
 def head_budget(bar_units: float) -> int:
@@ -850,7 +869,9 @@ def scan_topk(g: CSRGraph, node_w: torch.Tensor, k: int, rank: int = 0, world: i
     capacity = _capacity(wanted, slack)
     neg_inf = torch.full((1,), float("-inf"), device=dev)
     # skipped heads (csrc/scan_heads.hip): unit-valued graphs with a plan table, under a bar
-    use_heads = HEADS and screen is not None and screen.plan is not None and screen.ssum is not None and g.val is None
+    use_heads = (HEADS and screen is not None and screen.plan is not None and screen.ssum is not None and g.val is None
+                 and total_half >= HEAD_MIN_PATHS)
+    _count_scan(g, screen)
     head_list, head_trouble = HEAD_LIST, 0
     ht = None
     while True:

@@ -130,6 +130,7 @@ def test_scan_topk_same_rows_with_and_without_heads(eps, dev, monkeypatch, kind)
     g = synth.rmat_graph(14, 12, 3, dev)
     w = _weights(eps, g, kind)
     monkeypatch.setattr(scan, "SMALL_SET", 0)                    # (the estimate -> scan -> verify path: heads need a bar)
+    monkeypatch.setattr(scan, "HEAD_MIN_PATHS", 0)               # (... and this graph is smaller than the ones heads are used on)
     monkeypatch.setattr(scan, "RELABEL_MIN_NODES", 0)
     for k in (2000, 150_000):
         monkeypatch.setattr(scan, "HEADS", False)
@@ -155,6 +156,7 @@ def test_scan_topk_voids_a_launch_with_unusable_heads(eps, dev, monkeypatch):
     g = synth.rmat_graph(14, 12, 3, dev)
     w = _weights(eps, g, "aa")
     monkeypatch.setattr(scan, "SMALL_SET", 0)
+    monkeypatch.setattr(scan, "HEAD_MIN_PATHS", 0)
     monkeypatch.setattr(scan, "RELABEL_MIN_NODES", 0)
     monkeypatch.setattr(scan, "HEADS", False)
     want = {k: scan.scan_topk(g, w, k, relabel=True) for k in (200, 400_000)}

@@ -157,6 +157,7 @@ def _relabelled_scan_rank_main(rank, world, port, workdir, dist_rows_min=0, rows
     from eps_amd.heuristics import node_weight_table
     epd.init_from_env("gloo", 0)
     scan.RELABEL_MIN_NODES = 0
+    scan.HEAD_MIN_PATHS = 0                          # (skipped heads on this small graph too: the sharded step runs them)
     scan.SMALL_SET = 0                               # the estimated-bar path
     scan.DIST_ROWS_MIN = dist_rows_min               # 0: the final ordering is dealt over the ranks by score range
     dev = torch.device("cuda:0")

@@ -11,6 +11,7 @@ dev = torch.device("cuda:0")
 g0 = synth.ppa_like(seed=3, device=dev)
 w = node_weight_table(g0, ops.W_AA)
 g, perm = g0.degree_ordered()[:2]
+g._cache["scan_calls"] = 2          # (the full-width hub table of a graph that is scanned repeatedly: scan.hub_rows)
 sc = scan.screen_weights(g0, g, perm, w)
 bar = float(os.environ.get("BAR", 2.876))
 scan.HEAD_BETA = float(os.environ.get("BETA", 0.5))

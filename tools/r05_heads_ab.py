@@ -16,6 +16,7 @@ kind = os.environ.get("KIND", "aa")
 w = (torch.ones(g0.n_rows, dtype=torch.float32, device=dev) if kind == "cn" else
      node_weight_table(g0, {"aa": ops.W_AA, "ra": ops.W_RA}[kind]))
 g, perm = g0.degree_ordered()[:2]
+g._cache["scan_calls"] = 2          # (the full-width hub table of a graph that is scanned repeatedly: scan.hub_rows)
 order = scan.column_order(g)
 reps = int(os.environ.get("REPS", "5"))
 if "HUB" in os.environ:

@@ -12,6 +12,7 @@ g0 = synth.ppa_like(seed=3, device=dev)
 kind = os.environ.get("KIND", "aa")
 w = (torch.ones(g0.n_rows, dtype=torch.float32, device=dev) if kind == "cn" else node_weight_table(g0, {"aa": ops.W_AA, "ra": ops.W_RA}[kind]))
 g, perm = g0.degree_ordered()[:2]
+g._cache["scan_calls"] = 2          # (the full-width hub table of a graph that is scanned repeatedly: scan.hub_rows)
 sc = scan.screen_weights(g0, g, perm, w)
 bar = float(os.environ.get("BAR", 2.876))
 bounds = scan.screen_tables(g)[0].cpu()

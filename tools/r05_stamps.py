@@ -72,6 +72,8 @@ def run():
     g0 = synth.ppa_like(seed=3, device=dev)
     w = node_weight_table(g0, ops.W_AA)
     g, perm = g0.degree_ordered()[:2]
+    g._cache["scan_calls"] = 2
+g._cache["scan_calls"] = 2          # (the full-width hub table of a graph that is scanned repeatedly: scan.hub_rows)
     order = scan.column_order(g)
     sc = scan.screen_weights(g0, g, perm, w)
     bounds, cuts = scan.screen_tables(g)
