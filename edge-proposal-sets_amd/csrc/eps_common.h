@@ -32,6 +32,8 @@ int eps_num_cus();
 
 // A zeroed device word for a kernel's dynamic work hand-out (see eps_common.hip).
 int eps_take_counter(unsigned int **counter, hipStream_t stream, const char *who);
+// ... eight consecutive zeroed words (a hand-out with one counter per XCD)
+int eps_take_counters8(unsigned int **counters, hipStream_t stream, const char *who);
 
 #if defined(__HIPCC__)
 // ---- wave-level reductions (all 64 lanes receive the total) --------------------------

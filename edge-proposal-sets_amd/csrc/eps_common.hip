@@ -74,6 +74,24 @@ int eps_take_counter(unsigned int **counter, hipStream_t stream, const char *who
     return EPS_OK;
 }
 
+// Eight counters in one go (a hand-out sharded by XCD: eps_rescore_runs), zeroed on the caller's stream.
+__device__ unsigned int g_work_counter8[EPS_COUNTER_SLOTS][8];
+static std::atomic<unsigned int> g_counter8_turn{0};
+
+int eps_take_counters8(unsigned int **counters, hipStream_t stream, const char *who)
+{
+    if (hipGetSymbolAddress((void **)counters, HIP_SYMBOL(g_work_counter8)) != hipSuccess) {
+        eps_set_error("%s: cannot resolve the work counters", who);
+        return EPS_ELAUNCH;
+    }
+    *counters += 8 * (g_counter8_turn.fetch_add(1) % EPS_COUNTER_SLOTS);
+    if (hipMemsetAsync(*counters, 0, 8 * sizeof(unsigned int), stream) != hipSuccess) {
+        eps_set_error("%s: cannot reset the work counters", who);
+        return EPS_ELAUNCH;
+    }
+    return EPS_OK;
+}
+
 // ---- loading the library's code objects ahead of their first use ---------------------------------------------------------------
 // The HIP runtime loads a translation unit's code object at the first launch of one of its kernels; a fresh process pays 10-30 ms
 // for each of the larger ones (the rocPRIM sorts) inside whatever step happens to come first -- and filter.py is one fresh

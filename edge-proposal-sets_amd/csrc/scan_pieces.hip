@@ -1154,10 +1154,15 @@ extern "C" int eps_scan_row_sums(const int64_t *rowptr, const int32_t *col, cons
 // run against it -- one wave per pair, coalesced -- and sums the exact weights of the hits in float64.  The weights are
 // multiples of 2^-40 below 2^12, so the float64 sum is exact whatever the order: (float)sum is eps_filter_scan's score, bit
 // for bit (adamic_utils.py:13-25 / train_and_eval.py:195-216 / models.py:536-542 with the engine's fixed-point definition).
+#ifndef RS_THREADS
 #define RS_THREADS 1024
+#endif
 #define RS_CHUNK 256
 #define RS_BITS (1 << 20)       // ids per bitmap window: 128 KiB of LDS
 #define RS_SHORT 512            // rows up to this long go through rescore_short_kernel
+#ifndef RS_GROUP
+#define RS_GROUP 128            // consecutive 256-pair chunks that go to the same XCD (32 k pairs: most of a block of 2^9 v)
+#endif
 #ifndef RS_NB
 #define RS_NB 16                // entries of N(v) a lane has in flight per trip: a trip is three dependent latencies (row, bitmap,
 #endif                          // weights) and the survivors' rows are long (~1100 entries on the ppa-like graph: 2.2 G entries to stream
@@ -1175,12 +1180,34 @@ __global__ __launch_bounds__(RS_THREADS) void rescore_runs_kernel(const int64_t 
     const int tid = threadIdx.x, lane = tid & 63, wib = tid >> 6;
     constexpr int W = RS_THREADS / 64;
     const int words = (n_nodes < RS_BITS ? (n_nodes + 31) >> 5 : RS_BITS >> 5);
+    // (one descriptor over all of col[]: 16-byte loads at 4-byte-aligned offsets, out-of-range lanes read zeros at a far offset)
+    const __amdgpu_buffer_rsrc_t col_rs = __builtin_amdgcn_make_buffer_rsrc((void *)col, 0, (int)(uint32_t)(rowptr[n_nodes] * 4), 0x00020000);
     for (int i = tid; i < words; i += RS_THREADS) bm[i] = 0u;
     const int64_t n_chunks = (n + RS_CHUNK - 1) / RS_CHUNK;
+    // XCD-aware hand-out (r05).  The pairs come sorted by (block of 2^9 consecutive v, u, v): neighbouring chunks stream the rows of
+    // the same few hundred v -- 2 MB, which an XCD's 4 MB of L2 holds, if the workgroups of that XCD work on the same chunks.  So
+    // groups of RS_GROUP consecutive chunks are dealt round-robin over the eight XCDs, each XCD draws from ITS counter (the id from
+    // HW_REG_XCC_ID: blockIdx says which blocks share an XCD, not which), and an XCD that runs out helps the next one.  Placement is
+    // speed only: any workgroup may score any chunk.
+    unsigned int xcc = 0;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    xcc &= 7u;
     for (;;) {
-        if (tid == 0) s_c = atomicAdd(next_chunk, 1u);
+        if (tid == 0) {
+            unsigned int got = 0xFFFFFFFFu;
+            for (unsigned int j = 0; j < 8u; ++j) {
+                const unsigned int y = (xcc + j) & 7u;
+                const unsigned int t = atomicAdd(&next_chunk[y], 1u);
+                const unsigned long long c = ((unsigned long long)(t / RS_GROUP) * 8ull + y) * RS_GROUP + t % RS_GROUP;
+                if (c < (unsigned long long)n_chunks) {
+                    got = (unsigned int)c;
+                    break;
+                }
+            }
+            s_c = got;
+        }
         __syncthreads();
-        const int64_t c = s_c;
+        const int64_t c = s_c == 0xFFFFFFFFu ? n_chunks : (int64_t)s_c;
         if (c >= n_chunks) break;
         const int64_t c0 = c * RS_CHUNK;
         const int cn = (int)(n - c0 < RS_CHUNK ? n - c0 : RS_CHUNK);
@@ -1233,19 +1260,23 @@ __global__ __launch_bounds__(RS_THREADS) void rescore_runs_kernel(const int64_t 
                         const int64_t o = __shfl_xor(longest, 32);
                         longest = o > longest ? o : longest;
                     }
+                    // (16-byte loads, four entries a lane: a quarter of the vector-memory instructions of one-entry loads for the
+                    //  same bytes -- the rows are what this kernel streams, 8.8 GB per step on the bench graph)
                     for (int64_t off = 0; off < longest; off += 32 * RS_NB) {     // (uniform trip count over the wave)
-                        int32_t wv[RS_NB];
+                        sp_v4i wv[RS_NB / 4];
 #pragma unroll
-                        for (int b = 0; b < RS_NB; ++b) {
-                            const int64_t i = vb + off + b * 32 + hl;
-                            wv[b] = i < ve ? col[i] : -1;
+                        for (int b = 0; b < RS_NB / 4; ++b) {
+                            const int64_t i = vb + off + b * 128 + 4 * hl;
+                            wv[b] = __builtin_amdgcn_raw_buffer_load_b128(col_rs, (int)(i < ve ? (uint32_t)(i * 4) : 0xFFFFFFF0u), 0, 0);
                         }
                         long long add[RS_NB];
 #pragma unroll
                         for (int b = 0; b < RS_NB; ++b) {
-                            const uint32_t x = (uint32_t)(wv[b] - wlo);
-                            const bool hit = wv[b] >= 0 && x < (uint32_t)RS_BITS && ((bm[x >> 5] >> (x & 31)) & 1u);
-                            add[b] = hit ? (long long)fixw[wv[b]] : 0ll;
+                            const int64_t i = vb + off + (b >> 2) * 128 + 4 * hl + (b & 3);
+                            const int32_t w = wv[b >> 2][b & 3];
+                            const uint32_t x = (uint32_t)(w - wlo);
+                            const bool hit = i < ve && x < (uint32_t)RS_BITS && ((bm[x >> 5] >> (x & 31)) & 1u);
+                            add[b] = hit ? (long long)fixw[w] : 0ll;
                         }
 #pragma unroll
                         for (int b = 0; b < RS_NB; ++b) acc += add[b];
@@ -1355,12 +1386,12 @@ __global__ __launch_bounds__(256) void rescore_weighted_kernel(const int64_t *__
 extern "C" int eps_rescore_runs(const int64_t *rowptr, const int32_t *col, const int64_t *fixw, int64_t n_nodes,
                                 const int64_t *keys, int64_t n, float *out, void *stream)
 {
-    EPS_REQUIRE(n >= 0 && n_nodes >= 0 && n_nodes < (1ll << 31), "eps_rescore_runs: bad size");
+    EPS_REQUIRE(n >= 0 && n_nodes >= 0 && n_nodes < (1ll << 31), "eps_rescore_runs: bad size");      // (col[] is addressed with 32-bit byte offsets: nnz < 2^30, like eps_scan_screen)
     if (n == 0) return EPS_OK;
     EPS_REQUIRE(rowptr && col && fixw && keys && out, "eps_rescore_runs: null pointer");
     hipStream_t s = (hipStream_t)stream;
     unsigned int *counter = nullptr;
-    const int rc = eps_take_counter(&counter, s, "eps_rescore_runs");
+    const int rc = eps_take_counters8(&counter, s, "eps_rescore_runs");
     if (rc) return rc;
     const size_t lds = (size_t)(n_nodes < RS_BITS ? ((n_nodes + 31) >> 5) : (RS_BITS >> 5)) * 4 + 16;
     if (hipFuncSetAttribute((const void *)rescore_runs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {

@@ -701,9 +701,10 @@ def select_topk_torch(keys: torch.Tensor, vals: torch.Tensor, k: int) -> Tuple[t
     return keys[o], vals[o]
 
 
-RESCORE_V_BLOCK = 12         # the survivors are re-scored in blocks of 2^12 consecutive v (then u, then v): the workgroups that run side
-                             # by side stream the rows of one block of v out of the L2 -- eps_rescore_runs 2.92 -> 2.60 ms on the ppa-like
-                             # graph for 0.06 ms more sorting (2^8: 3.32, 2^10: 2.78, 2^14: 2.77; profiles/r04/step_timeline.txt)
+RESCORE_V_BLOCK = 10         # the survivors are re-scored in blocks of 2^10 consecutive v (then u, then v): the workgroups that run side
+                             # by side stream the rows of one block of v out of the L2.  r04 (one hand-out counter): 2^8 3.32, 2^10 2.78,
+                             # 2^12 2.60, 2^14 2.77 ms; r05 (chunks dealt to the XCDs in groups, 16-byte row loads): 2^9 2.80, 2^10 2.45,
+                             # 2^12 2.64 -- the XCD-aware hand-out moved the optimum, not the floor (profiles/r05/rescore_variants.txt)
 DIST_ROWS_MIN = 1 << 15      # selected pairs from which the final ordering of a sharded step is dealt over the ranks
 
 
