@@ -73,7 +73,6 @@ def run():
     w = node_weight_table(g0, ops.W_AA)
     g, perm = g0.degree_ordered()[:2]
     g._cache["scan_calls"] = 2
-g._cache["scan_calls"] = 2          # (the full-width hub table of a graph that is scanned repeatedly: scan.hub_rows)
     order = scan.column_order(g)
     sc = scan.screen_weights(g0, g, perm, w)
     bounds, cuts = scan.screen_tables(g)
@@ -89,7 +88,8 @@ g._cache["scan_calls"] = 2          # (the full-width hub table of a graph that 
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         ops.scan_screen(g.rowptr, g.col, scan.reverse_positions(g), sc.fx32, cuts, bounds, g.n_rows, order, sc.shift, wk, status, scan.screen_variant(g),
-                        wpaths=ht.wpaths, ssum=sc.ssum, smax=sc.smax, plan=ht.plan, heads=ht.heads, batch_from=scan.batch_from(g, order))
+                        wpaths=ht.wpaths, ssum=sc.ssum, smax=sc.smax, plan=ht.plan, heads=ht.heads, batch_from=scan.batch_from(g, order), rowrec=sc.rowrec,
+                        colrec=scan.column_records(g, sc, order, ht.plan, ht.heads, ht.live, 'stamps'))
         e1.record(); torch.cuda.synchronize()
         lib.eps_debug_piece_stamps(buf, 0)
     vals = list(buf)
