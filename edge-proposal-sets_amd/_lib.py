@@ -53,7 +53,7 @@ SIGNATURES = {
     "eps_scan_window_paths": (_int, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp]),
     "eps_scan_screen": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _i64, _i64, _i32, _i32, _vp, _vp, _vp]),
     "eps_scan_row_records": (_int, [_vp, _vp, _vp, _i64, _vp, _vp]),
-    "eps_scan_heads": (_int, [_vp, _vp, _vp, _i64, _i32, _c.c_uint32, _vp, _vp]),
+    "eps_scan_heads": (_int, [_vp, _vp, _vp, _i64, _i32, _c.c_uint32, _i32, _vp, _vp]),
     "eps_scan_hub_rows": (_int, [_vp, _vp, _i64, _i32, _vp, _vp]),
     "eps_scan_hub_row_words": (_i64, [_i64]),
     "eps_scan_refine": (_int, [_vp, _vp, _vp, _i32, _vp, _vp, _vp, _i64, _i32, _vp, _vp]),

@@ -18,16 +18,18 @@
 // eps_scan_screen reports without heads -- screening sums of all paths, same units -- for half the table updates.
 #include "scan_common.h"
 
-// heads[v] = {x_v, T_v}: the longest prefix of row v with ids < n_hub whose screening weights sum to <= budget (x_v < 65536).
+// heads[v] = {x_v, T_v}: the longest prefix of row v with ids < n_hub whose screening weights sum to <= budget, at most max_rows
+// entries (the first rows of a column carry most of its paths; eps_scan_refine pays for every skipped row of a slot that passes:
+// resource allocation, where a hub weighs next to nothing, would skip hundreds).
 __global__ __launch_bounds__(256) void sp_heads_kernel(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col,
                                                        const uint32_t *__restrict__ fx32, int64_t n_nodes, int32_t n_hub,
-                                                       uint32_t budget, uint2 *__restrict__ heads)
+                                                       uint32_t budget, uint32_t max_rows, uint2 *__restrict__ heads)
 {
     const int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= n_nodes) return;
     const int64_t b = rowptr[v], e = rowptr[v + 1];
     uint32_t x = 0u, t = 0u;
-    for (int64_t i = b; i < e && x < 65535u; ++i) {
+    for (int64_t i = b; i < e && x < max_rows; ++i) {
         const int32_t w = col[i];
         if (w >= n_hub) break;
         const uint32_t f = fx32[w];
@@ -39,13 +41,13 @@ __global__ __launch_bounds__(256) void sp_heads_kernel(const int64_t *__restrict
 }
 
 extern "C" int eps_scan_heads(const int64_t *rowptr, const int32_t *col, const uint32_t *fx32, int64_t n_nodes, int32_t n_hub,
-                              uint32_t budget, uint32_t *heads, void *stream)
+                              uint32_t budget, int32_t max_rows, uint32_t *heads, void *stream)
 {
-    EPS_REQUIRE(n_nodes >= 0 && n_nodes < (1ll << 31) && n_hub >= 0, "eps_scan_heads: bad size");
+    EPS_REQUIRE(n_nodes >= 0 && n_nodes < (1ll << 31) && n_hub >= 0 && max_rows >= 0 && max_rows <= 65535, "eps_scan_heads: bad size");
     if (n_nodes == 0) return EPS_OK;
     EPS_REQUIRE(rowptr && col && fx32 && heads && ((uintptr_t)heads & 7) == 0, "eps_scan_heads: null or misaligned pointer");
     hipLaunchKernelGGL(sp_heads_kernel, dim3((unsigned)((n_nodes + 255) / 256)), dim3(256), 0, (hipStream_t)stream, rowptr, col, fx32,
-                       n_nodes, n_hub, budget, (uint2 *)heads);
+                       n_nodes, n_hub, budget, (uint32_t)max_rows, (uint2 *)heads);
     EPS_CHECK_LAUNCH("eps_scan_heads");
     return EPS_OK;
 }

@@ -1557,10 +1557,17 @@ extern "C" int eps_scan_screen_weighted(const int64_t *rowptr, const int32_t *co
 }
 
 static const int sp_threads_of[3] = {512, 1024, 256}, sp_bits_of[3] = {13, 14, 12}, sp_per_cu[3] = {2, 1, 4};
+// `variant` arguments carry the geometry in their low byte and, in byte 1, an optional limit on the low weight bits a packed /
+// 16-bit direct piece may drop: (dmax + 1) << 8, 0 = the default (shift - 8).  The caller lowers it when the smallest weight
+// of the graph is small next to 2^(dmax - shift): the bound on (screening score - exact score) per path is (2^d + 1) units, and
+// the pre-filter in front of the exact re-scoring is only as sharp as that unit is small next to a path's weight (resource
+// allocation on a graph with hubs: weights of 1 / 13 230 -- r05: 13.5 ms of re-scoring at d = 13, a third of it at d = 11).
+#define SP_VARIANT_GEOM(v) ((v) & 0xFF)
+#define SP_VARIANT_DMAX(v) ((((v) >> 8) & 0xFF) - 1)
 
 // what the planner reads of the geometry: the scan launch and the plan-table launch must agree on it
 static void sp_plan_geometry(sp_params &p, const uint16_t *cuts, const uint32_t *wpaths, const uint32_t *ssum, const uint32_t *smax,
-                             const int32_t *bounds, int64_t n_nodes, int32_t shift, int32_t variant)
+                             const int32_t *bounds, int64_t n_nodes, int32_t shift, int32_t variant, int32_t dmax_arg)
 {
     const int bits = sp_bits_of[variant];
     p.cuts = cuts;
@@ -1572,7 +1579,8 @@ static void sp_plan_geometry(sp_params &p, const uint16_t *cuts, const uint32_t 
     p.ssum = ssum;
     p.smax = smax;
     p.packed_paths = (SP_PACKED_X8 << bits) / 8u;      // (8: load factor 1/2 of the 2^(bits + 1)-word table)
-    p.packed_dmax = shift > 8 ? (shift - 8 < 24 ? shift - 8 : 24) : 0;      // (weights keep at least 2^-8 resolution)
+    p.packed_dmax = shift > 8 ? (shift - 8 < 24 ? shift - 8 : 24) : 0;      // (weights keep at least 2^-8 resolution ...
+    if (dmax_arg >= 0 && dmax_arg < p.packed_dmax) p.packed_dmax = dmax_arg;   //  ... or what the caller asks for: see SP_VARIANT_DMAX)
     // measured on the ppa-like graph (tools/r03_screen_ab.py): 1500 -> 23.8 ms, 2270 -> 23.5, 4000 -> 23.7; packed_paths 3584 / 4096 /
     // 5120 -> 24.0 / 23.5 / 24.1 ms
     p.mode_ratio = SP_MODE_RATIO;
@@ -1625,11 +1633,13 @@ extern "C" int eps_scan_plan(const int64_t *rowptr, const uint16_t *cuts, const 
     EPS_REQUIRE((ssum_or_null == nullptr) == (smax_or_null == nullptr), "eps_scan_plan: ssum and smax come together");
     EPS_REQUIRE((pptr_or_null == nullptr) == (plan_or_null == nullptr), "eps_scan_plan: pptr and plan come together");
     EPS_REQUIRE(pptr_or_null || pcount, "eps_scan_plan: nowhere to put the counts");
+    const int32_t dmax_arg = SP_VARIANT_DMAX(variant);
+    variant = SP_VARIANT_GEOM(variant);
     EPS_REQUIRE(shift >= 0 && shift <= 40 && variant >= 0 && variant <= 2, "eps_scan_plan: bad shift / variant");
     EPS_REQUIRE(((uintptr_t)plan_or_null & 15) == 0, "eps_scan_plan: plan must be 16-byte aligned");
     sp_params p;
     memset(&p, 0, sizeof p);
-    sp_plan_geometry(p, cuts, wpaths, ssum_or_null, smax_or_null, bounds, n_nodes, shift, variant);
+    sp_plan_geometry(p, cuts, wpaths, ssum_or_null, smax_or_null, bounds, n_nodes, shift, variant, dmax_arg);
     p.heads = (const uint2 *)heads_or_null;
     hipLaunchKernelGGL(sp_plan_kernel, dim3((unsigned)((n_nodes + 3) / 4)), dim3(256), 0, (hipStream_t)stream, p, rowptr,
                        2u << sp_bits_of[variant], pcount, pptr_or_null, (uint4 *)plan_or_null, d_used_or_null);
@@ -1703,6 +1713,8 @@ static int sp_launch(const int64_t *rowptr, const int32_t *col, const float *val
     EPS_REQUIRE(rowptr && col && revpos && cuts && wpaths && bounds && columns && out, "eps_scan_screen: null pointer");
     EPS_REQUIRE(nnz < (1ll << 30), "eps_scan_screen: col[] is addressed with 32-bit byte offsets (nnz < 2^30)");
     EPS_REQUIRE(n_nodes < (1ll << 31) && n_columns < (1ll << 31), "eps_scan_screen: too many nodes / columns");
+    const int32_t dmax_arg = SP_VARIANT_DMAX(variant);
+    variant = SP_VARIANT_GEOM(variant);
     EPS_REQUIRE(shift >= 0 && shift <= 40 && variant >= 0 && variant <= 2, "eps_scan_screen: bad shift / variant");
     EPS_REQUIRE(((uintptr_t)cuts & 15) == 0, "eps_scan_screen: cuts must be 16-byte aligned");
     EPS_REQUIRE(((uintptr_t)colrec & 15) == 0 && ((uintptr_t)rowrec & 127) == 0, "eps_scan_screen: misaligned column / row records");
@@ -1721,7 +1733,7 @@ static int sp_launch(const int64_t *rowptr, const int32_t *col, const float *val
     p.val = val;
     p.node_w = node_w;
     p.up = ldexpf(1.0f, shift) * (1.0f + ldexpf(1.0f, -20));
-    sp_plan_geometry(p, cuts, wpaths, ssum, smax, bounds, n_nodes, shift, variant);
+    sp_plan_geometry(p, cuts, wpaths, ssum, smax, bounds, n_nodes, shift, variant, dmax_arg);
     p.pptr = pptr;
     p.plan = (const uint4 *)plan;
     p.heads = (const uint2 *)heads;

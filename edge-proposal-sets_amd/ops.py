@@ -659,7 +659,7 @@ def scan_row_records(cuts: torch.Tensor, rowptr: torch.Tensor, fx32: torch.Tenso
     return out
 
 
-def scan_heads(rowptr, col, fx32: torch.Tensor, n_hub: int, budget: int) -> torch.Tensor:
+def scan_heads(rowptr, col, fx32: torch.Tensor, n_hub: int, budget: int, max_rows: int = 65535) -> torch.Tensor:
     """int32-bits [N, 2] (x_v, T_v): per column the longest prefix of its row with ids < ``n_hub`` whose screening weights sum
     to T_v <= ``budget`` (table units) -- the rows eps_scan_screen does not walk under a bar (eps_scan_heads)."""
     dev = _need_gpu(rowptr, col, fx32)
@@ -669,8 +669,8 @@ def scan_heads(rowptr, col, fx32: torch.Tensor, n_hub: int, budget: int) -> torc
         raise _lib.EpsError("scan_heads: fx32 does not match the graph, or budget outside [0, 2^31)")
     out = torch.empty((n, 2), dtype=torch.int32, device=dev)
     with torch.cuda.device(dev):
-        _lib.check(_lib.load().eps_scan_heads(_ptr(rowptr), _ptr(col), _ptr(fx32), n, int(n_hub), int(budget), _ptr(out), _stream(dev)),
-                   "eps_scan_heads")
+        _lib.check(_lib.load().eps_scan_heads(_ptr(rowptr), _ptr(col), _ptr(fx32), n, int(n_hub), int(budget), int(max_rows), _ptr(out),
+                                              _stream(dev)), "eps_scan_heads")
     return out
 
 
@@ -773,6 +773,12 @@ def scan_row_sums(rowptr, col, fx32: torch.Tensor, bounds: torch.Tensor, n_nodes
         _lib.check(_lib.load().eps_scan_row_sums(_ptr(rowptr), _ptr(col), _ptr(fx32), _ptr(bounds), n_nodes, _ptr(ssum), _ptr(smax),
                                                  _ptr(min_fx), _ptr(ws), _stream(dev)), "eps_scan_row_sums")
     return ssum, smax, min_fx
+
+
+def scan_variant_word(variant: int, dmax: Optional[int] = None) -> int:
+    """The ``variant`` argument of eps_scan_plan / eps_scan_screen: geometry in the low byte, (dmax + 1) << 8 above it when the
+    caller limits the low weight bits a packed / 16-bit direct piece may drop (include/eps_abi.h)."""
+    return int(variant) | ((min(int(dmax), 254) + 1) << 8 if dmax is not None else 0)
 
 
 def scan_plan(rowptr, cuts, wpaths, ssum, smax, bounds, n_nodes: int, shift: int, variant: int, with_d: bool = False,

@@ -48,7 +48,9 @@ HEAD_KEEP = (0.3, 0.58)    # a head table is used again while its budget stays w
 HEAD_LIST = 2              # the walked list (slots that pass at bar - T_v) is sized this many times the survivor list (16 M slots of 49 M
                            # on the ppa-like graph; an overflow doubles it and repeats.  6 x was 1.8 GB of first-time hipMalloc in a one-shot run)
 HEAD_MIN_PATHS = 1 << 30   # graphs with fewer two-hop half paths are scanned without heads: their tables cost more than they save
+HEAD_MAX_ROWS = 1024       # rows a column's head holds at most (eps_scan_refine probes each of them for every slot that passes; 48 cost resource allocation 2 ms of scan for 0.15 of refine)
 HEAD_CACHE = 4             # head tables kept per (graph, weight table)
+DMAX_MARGIN = 5               # a piece drops low weight bits only down to this many bits below the graph's smallest weight (screen_weights)
 ROW_RECORDS = True            # the launch gathers a row's cuts, first entry and weight out of ONE 128-byte line (ops.scan_row_records)
 BATCH_MIN_COLUMNS = 1 << 16   # lists shorter than this are handed out one column at a time throughout
 BATCH_PATHS = 1 << 13      # columns of a heaviest-first list with fewer half paths are handed out eight per ticket (see batch_from)
@@ -254,7 +256,7 @@ def screen_shift(bound: float, max_deg: int, weighted: bool = False) -> int:
 
 class Screen:
     """What a launch of the piece kernel and the exact re-scoring of its survivors need, for one (graph, weight table)."""
-    __slots__ = ("fx32", "shift", "fixw", "val", "node_w", "usable", "ssum", "smax", "plan", "d_used", "w_min", "heads", "head_cur", "rowrec")
+    __slots__ = ("fx32", "shift", "fixw", "val", "node_w", "usable", "ssum", "smax", "plan", "d_used", "w_min", "heads", "head_cur", "rowrec", "vword")
 
     def __init__(self, fx32, shift, fixw, val, node_w, usable, ssum=None, smax=None, plan=None, d_used=0, w_min=0.0):
         self.fx32, self.shift, self.fixw, self.val, self.node_w, self.usable = fx32, shift, fixw, val, node_w, usable
@@ -264,6 +266,7 @@ class Screen:
         self.heads = {}              # budget (table units) -> HeadTables (see head_tables)
         self.head_cur = None         # the HeadTables the last launch under a bar used
         self.rowrec = None           # ops.scan_row_records: one 128-byte line per node with what the walk gathers per row
+        self.vword = None            # the `variant` word the plan was built with (geometry + the limit on dropped weight bits)
 
     def lower_bound(self, s: torch.Tensor, max_deg: int) -> torch.Tensor:
         """A lower bound of the exact score of a pair whose screening score is ``s`` (monotone in s).  A path's screening term
@@ -315,11 +318,18 @@ def screen_weights(g0: CSRGraph, g: CSRGraph, perm, node_w: torch.Tensor) -> Scr
         one_pass = fits and one_pass_available(g)
         ssum, smax, min_fx = _sum_bounds(g, fx32) if one_pass and PACKED_PIECES else (None, None, None)
         plan, d_word = None, None
+        vword = screen_variant(g)
         if one_pass and PLAN_TABLE:
+            # How many low weight bits a piece may drop: a screening score exceeds the exact one by up to 2^d + 1 units per path, and
+            # the pre-filter in front of the exact re-scoring (lower_params) is as sharp as that is small next to the smallest
+            # weight -- DMAX_MARGIN bits below it (one host read; resource allocation on a graph with hubs weighs 1 / 13 230: at the
+            # default d = 13 a tenth of every score was slack and the re-scoring took 13.5 ms, r05)
+            lowest = int(min_fx.item()) & 0xFFFFFFFF if min_fx is not None else 0xFFFFFFFF
+            if lowest not in (0, 0xFFFFFFFF):
+                vword = ops.scan_variant_word(screen_variant(g), max(0, lowest.bit_length() - 1 - DMAX_MARGIN))
             # every column's pieces, planned once per (graph, weight table): a launch reads them instead of planning (5 %)
             bounds, cuts = screen_tables(g)
-            pptr, recs, d_word = ops.scan_plan(g.rowptr, cuts, window_paths(g), ssum, smax, bounds, g.n_rows, shift, screen_variant(g),
-                                               with_d=True)
+            pptr, recs, d_word = ops.scan_plan(g.rowptr, cuts, window_paths(g), ssum, smax, bounds, g.n_rows, shift, vword, with_d=True)
             plan = (pptr, recs)
         zero = torch.zeros(1, dtype=torch.int32, device=g.device)
         bad_h, d_h, min_h = torch.cat([bad.view(torch.int32), d_word if d_word is not None else zero,
@@ -337,6 +347,7 @@ def screen_weights(g0: CSRGraph, g: CSRGraph, perm, node_w: torch.Tensor) -> Scr
             w_min = 0.0 if lowest == 0xFFFFFFFF else max(0, lowest - 1) * 2.0 ** -shift
         sc = Screen(fx32, shift, fixw, None, None, usable, ssum, smax, plan, d_used, w_min)
         sc.rowrec = rowrec
+        sc.vword = vword
         return sc
     # (one entry per labelling: the tables are indexed by the SCANNED graph's node ids)
     return g0.weight_cached("screen_weights" if perm is None else "screen_weights_relabelled", node_w, build)
@@ -397,11 +408,11 @@ def head_tables(g: CSRGraph, screen: Screen, budget: int) -> HeadTables:
     level; one host read (the plan's size and dropped bits)."""
     if budget not in screen.heads:
         n_hub = hub_rows(g).shape[0]
-        heads = ops.scan_heads(g.rowptr, g.col, screen.fx32, n_hub, budget)
+        heads = ops.scan_heads(g.rowptr, g.col, screen.fx32, n_hub, budget, HEAD_MAX_ROWS)
         bounds, cuts = screen_tables(g)
         wp = ops.scan_window_paths(g.rowptr, g.col, reverse_positions(g), cuts, heads)
-        pptr, recs, d_word = ops.scan_plan(g.rowptr, cuts, wp, screen.ssum, screen.smax, bounds, g.n_rows, screen.shift, screen_variant(g),
-                                           with_d=True, heads=heads)
+        pptr, recs, d_word = ops.scan_plan(g.rowptr, cuts, wp, screen.ssum, screen.smax, bounds, g.n_rows, screen.shift,
+                                           screen.vword if screen.vword is not None else screen_variant(g), with_d=True, heads=heads)
         while len(screen.heads) >= HEAD_CACHE:
             screen.heads.pop(next(iter(screen.heads)))
         screen.heads[budget] = HeadTables(budget, heads, wp, (pptr, recs), int(d_word.item()))
@@ -874,6 +885,7 @@ def scan_topk(g: CSRGraph, node_w: torch.Tensor, k: int, rank: int = 0, world: i
                  and total_half >= HEAD_MIN_PATHS)
     _count_scan(g, screen)
     head_list, head_trouble = HEAD_LIST, 0
+    n_rescored = None
     ht = None
     while True:
         if launches >= MAX_LAUNCHES:
@@ -908,6 +920,7 @@ def scan_topk(g: CSRGraph, node_w: torch.Tensor, k: int, rank: int = 0, world: i
                                                                     room=min(res.capacity, nv))
                 nv = int(n_valid.item())
             l_keys, l_vals = rescore_exact(g, screen, c_keys[:nv], bar)
+            n_rescored = nv
             status = res.status
         # the job-wide cut: the k2-th best survivor score over all ranks (-inf when fewer survived); untouched slots are -inf
         zero = torch.zeros(1, dtype=torch.int64, device=dev)
@@ -1040,7 +1053,7 @@ def scan_topk(g: CSRGraph, node_w: torch.Tensor, k: int, rank: int = 0, world: i
             n_all = 2 * candidate_count(g, screen, fixw, rank, world) if stats.get("count", True) else None
         stats.update(candidates=n_all, touched=touched, launches=launches, survivors=2 * n_sel_all, heads=ht is not None,
                      head_budget=None if ht is None else ht.budget * 2.0 ** -screen.shift,
-                     walked_slots=sum(t[6] for t in table) if ht is not None else None,
+                     walked_slots=sum(t[6] for t in table) if ht is not None else None, rescored=n_rescored,
                      survivor_slots=sum(min(s_, capacity) for s_ in slots_r), bar=bar)
     if keys is None:
         return None, None

@@ -267,7 +267,11 @@ int eps_filter_scan(const int64_t *rowptr, const int32_t *col, const int32_t *re
  *                           batch_from: columns[0 .. batch_from) are handed to the workgroups one at a time, the rest eight per
  *                           draw (the hand-out is an atomic on one word, ~11 ns each: light columns -- give the list
  *                           heaviest first -- would wait for it); n_columns or more, or negative: one at a time throughout;
- *                           variant 0: 512 threads / 8192-slot table (2 workgroups per CU), 1: 1024 / 16384 (1), 2: 256 / 4096 (4);
+ *                           variant (low byte) 0: 512 threads / 8192-slot table (2 workgroups per CU), 1: 1024 / 16384 (1), 2: 256 /
+ *                           4096 (4); byte 1 of `variant` (eps_scan_plan and eps_scan_screen alike): 0, or dmax + 1 = a limit on
+ *                           the low weight bits a packed / 16-bit direct piece may drop (default shift - 8).  Lower it when the
+ *                           graph's smallest weight is small: the screening score exceeds the exact one by up to 2^d + 1 units
+ *                           per path, and the pre-filter before the exact re-scoring is as sharp as that is small next to a weight;
  *                           *status (device word, cleared by the call): value 2 (bit 1) = a table filled up (results
  *                           invalid; cannot happen within the planner's piece limits: a backstop). */
 int32_t eps_scan_windows(void);
@@ -303,7 +307,8 @@ int eps_scan_row_records(const uint16_t *cuts, const int64_t *rowptr, const uint
 /* ---- skipped heads (r05; csrc/scan_heads.hip): half of all two-hop paths run through a few thousand hub rows whose weights are
  * the smallest there are, so under a bar a column need not walk them (still filter.py:96-142 + :160-161 under --keep_top) ------
  *   eps_scan_heads     : heads[2 v] = x_v, heads[2 v + 1] = T_v (uint32 pairs, 8-byte aligned): the longest prefix of row v with
- *                        ids < n_hub whose screening weights fx32 sum to T_v <= budget.  Built per (graph, weight table, budget);
+ *                        ids < n_hub whose screening weights fx32 sum to T_v <= budget, at most max_rows (<= 65535) of them.  Built per
+ *                        (graph, weight table, budget);
  *                        the budget is a fraction of the bar IN TABLE UNITS (bar x 2^shift).
  *   eps_scan_window_paths / eps_scan_plan / eps_scan_screen with heads: the column walks its rows from x_v on (window paths and
  *                        plan count those rows only; the three tables go together, and a head table needs the plan table built
@@ -319,7 +324,7 @@ int eps_scan_row_records(const uint16_t *cuts, const int64_t *rowptr, const uint
  *                        (compact: out->count = their number; val = sum x 2^-shift) -- the list a launch without heads reports,
  *                        in another order.  out->count must be zeroed by the caller. */
 int eps_scan_heads(const int64_t *rowptr, const int32_t *col, const uint32_t *fx32, int64_t n_nodes, int32_t n_hub,
-                   uint32_t budget, uint32_t *heads, void *stream);
+                   uint32_t budget, int32_t max_rows, uint32_t *heads, void *stream);
 int64_t eps_scan_hub_row_words(int64_t n_nodes);
 int eps_scan_hub_rows(const int64_t *rowptr, const int32_t *col, int64_t n_nodes, int32_t n_hub, uint32_t *hubrows, void *stream);
 int eps_scan_refine(const eps_survivors *walked, const uint32_t *heads, const uint32_t *hubrows, int32_t n_hub,

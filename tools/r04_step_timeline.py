@@ -10,8 +10,11 @@ from eps_amd import ops, scan, synth
 from eps_amd.heuristics import node_weight_table
 dev = torch.device("cuda:0")
 g0 = synth.ppa_like(seed=3, device=dev, n_nodes=int(os.environ.get("NODES", 576289)), n_undirected=int(os.environ.get("EDGES", 21231931)))
-w = node_weight_table(g0, ops.W_AA)
+kind = os.environ.get('KIND', 'aa')
+w = torch.ones(g0.n_rows, dtype=torch.float32, device=dev) if kind == 'cn' else node_weight_table(g0, ops.W_RA if kind == 'ra' else ops.W_AA)
 K = int(os.environ.get("K", 4_000_000))
+if 'DMAX_MARGIN' in os.environ:
+    scan.DMAX_MARGIN = int(os.environ['DMAX_MARGIN'])
 steps = int(os.environ.get("STEPS", 10))
 for _ in range(3):
     scan.scan_topk(g0, w, K, relabel=True)
@@ -47,7 +50,9 @@ for _ in range(steps):
         tot[name] = tot.get(name, 0.0) + e0.elapsed_time(e1)
         prev = e1
     gaps += prev.elapsed_time(s1)
-print(f"step (host wall) {wall / steps:.3f} ms; on the stream:")
+st = {"count": False}
+scan.scan_topk(g0, w, K, stats=st)
+print(f"[{kind}] step (host wall) {wall / steps:.3f} ms; survivors {st.get('survivors')}, walked slots {st.get('walked_slots')}, launches {st.get('launches')}, bar {float(st['bar']) if st.get('bar') is not None else None}; on the stream:")
 acc = 0.0
 for name, t in tot.items():
     print(f"  {name:28s} {t / steps:7.3f} ms")
