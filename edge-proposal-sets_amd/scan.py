@@ -712,10 +712,12 @@ def select_topk_torch(keys: torch.Tensor, vals: torch.Tensor, k: int) -> Tuple[t
     return keys[o], vals[o]
 
 
-RESCORE_V_BLOCK = 10         # the survivors are re-scored in blocks of 2^10 consecutive v (then u, then v): the workgroups that run side
+RESCORE_V_BLOCK = 12         # the survivors are re-scored in blocks of 2^12 consecutive v (then u, then v): the workgroups that run side
                              # by side stream the rows of one block of v out of the L2.  r04 (one hand-out counter): 2^8 3.32, 2^10 2.78,
-                             # 2^12 2.60, 2^14 2.77 ms; r05 (chunks dealt to the XCDs in groups, 16-byte row loads): 2^9 2.80, 2^10 2.45,
-                             # 2^12 2.64 -- the XCD-aware hand-out moved the optimum, not the floor (profiles/r05/rescore_variants.txt)
+                             # 2^12 2.60, 2^14 2.77 ms.  r05 (chunks dealt to the XCDs in groups, 16-byte row loads), measured INSIDE the
+                             # step, same box: 2^9 2.69, 2^10 2.65, 2^11 2.58, 2^12 2.40, 2^14 2.61, 2^16 2.60, 2^20 2.72; the stand-alone
+                             # timing of the same kernel preferred 2^10 (2.45 vs 2.64): the step's L2 arrives full of the scan's tables,
+                             # and the step is what counts (profiles/r05/rescore_variants.txt)
 DIST_ROWS_MIN = 1 << 15      # selected pairs from which the final ordering of a sharded step is dealt over the ranks
 
 

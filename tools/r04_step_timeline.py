@@ -13,6 +13,8 @@ g0 = synth.ppa_like(seed=3, device=dev, n_nodes=int(os.environ.get("NODES", 5762
 kind = os.environ.get('KIND', 'aa')
 w = torch.ones(g0.n_rows, dtype=torch.float32, device=dev) if kind == 'cn' else node_weight_table(g0, ops.W_RA if kind == 'ra' else ops.W_AA)
 K = int(os.environ.get("K", 4_000_000))
+if 'VBLOCK' in os.environ:
+    scan.RESCORE_V_BLOCK = int(os.environ['VBLOCK'])
 if 'DMAX_MARGIN' in os.environ:
     scan.DMAX_MARGIN = int(os.environ['DMAX_MARGIN'])
 steps = int(os.environ.get("STEPS", 10))
