@@ -21,6 +21,9 @@ ABL = {
                ("                            sp_unit fa[SP_G], fb[SP_G];\n                            fetch_group(0, fa);\n                            if (n_iter <= SP_G) {", "                            sp_unit fa[SP_G], fb[SP_G];\n                            if (n_iter > 0) fetch_group(0, fa);\n                            if (n_iter == 0) {} else if (n_iter <= SP_G) {")],
     # the packed walk without its straggler loop (entries that missed two probes are dropped): what deferring them could save at most
     "nostraggle": [("                                uint32_t ch = 0u, cstep = 0u, clid = 0u, cfx = 0u, tries = 0u;\n                                bool have = false;\n                                while (__ballot(have || pend != 0u)) {", "                                uint32_t ch = 0u, cstep = 0u, clid = 0u, cfx = 0u, tries = 0u;\n                                bool have = false;\n                                pend = 0u;\n                                while (__ballot(have || pend != 0u)) {")],
+    # (correct results) three / two workgroups per CU instead of four: what the launch loses per workgroup slot given to something else
+    "percu3": [("sp_per_cu[3] = {2, 1, 4};", "sp_per_cu[3] = {2, 1, 3};")],
+    "percu2": [("sp_per_cu[3] = {2, 1, 4};", "sp_per_cu[3] = {2, 1, 2};")],
     # no known-edge marking
     "noknown": [("                    for (int j = single ? tid : na + tid; j < nb; j += T) {", "                    for (int j = single ? tid : na + tid; j < nb && j < 0; j += T) {")],
 }
