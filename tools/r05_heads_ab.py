@@ -2,7 +2,7 @@
 """Skipped heads (csrc/scan_heads.hip) against the plain launch on the ppa-like graph at a fixed bar: kernel ms of the main
 launch (HIP events, min / median of REPS), the refine kernel, the walked list's length, the half paths still walked, the pieces of
 the plan -- and a digest of the survivor list after exact re-scoring, which must be the same for every beta (0 = no heads).
-usage: r05_heads_ab.py [beta ...]; env: BAR, REPS, NODES, EDGES, KIND (aa / cn / ra), HUB (bits per mask row)"""
+usage: r05_heads_ab.py [beta ...]; env: BAR, REPS, NODES, EDGES, KIND (aa / cn / ra), HUB (bits per mask row), VARIANT"""
 import hashlib, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -17,6 +17,8 @@ w = (torch.ones(g0.n_rows, dtype=torch.float32, device=dev) if kind == "cn" else
      node_weight_table(g0, {"aa": ops.W_AA, "ra": ops.W_RA}[kind]))
 g, perm = g0.degree_ordered()[:2]
 g._cache["scan_calls"] = 2          # (the full-width hub table of a graph that is scanned repeatedly: scan.hub_rows)
+if "VARIANT" in os.environ:          # force a table geometry (0: 512 threads / 64 KB, 1: 1024 / 128 KB, 2: 256 / 32 KB)
+    g._cache["screen_variant"] = int(os.environ["VARIANT"])
 order = scan.column_order(g)
 reps = int(os.environ.get("REPS", "5"))
 if "HUB" in os.environ:
