@@ -718,6 +718,8 @@ RESCORE_V_BLOCK = 12         # the survivors are re-scored in blocks of 2^12 con
                              # step, same box: 2^9 2.69, 2^10 2.65, 2^11 2.58, 2^12 2.40, 2^14 2.61, 2^16 2.60, 2^20 2.72; the stand-alone
                              # timing of the same kernel preferred 2^10 (2.45 vs 2.64): the step's L2 arrives full of the scan's tables,
                              # and the step is what counts (profiles/r05/rescore_variants.txt)
+                             # Blocks multiply the RUNS of equal u (one LDS bitmap each): eps_sort_pairs_by_u keeps them only while a run
+                             # still averages 64 pairs (AA / CN: 500; RA, 168 k distinct u: 1.8 -- 6.7 ms blocked, 2.1 ms by (u, v))
 DIST_ROWS_MIN = 1 << 15      # selected pairs from which the final ordering of a sharded step is dealt over the ranks
 
 

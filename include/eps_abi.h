@@ -504,8 +504,9 @@ int eps_kth_pick(void *state, int32_t shift, float *out_or_null, void *stream);
  * eps_sort_pairs_by_u: survivor keys v << 32 | u (u < v) -> u << 32 | v sorted by (u, v) (two stable radix sorts over the
  * id_bits bits of v, then of u): runs of equal u with ascending v, the input eps_rescore_runs wants.  v_block_shift > 0: by
  * (v >> v_block_shift, u, v) instead -- blocks of consecutive v first, so that concurrent workgroups of eps_rescore_runs stream
- * the same rows (0: off).  workspace: eps_sort_pairs_by_u_workspace_bytes(n) bytes,
- * 256-byte aligned. */
+ * the same rows (0: off) -- WHEN the runs of equal (block, u) still average 64 pairs; otherwise the (u, v) order is returned
+ * (eps_rescore_runs pays one bitmap of N(u) per run; counted and decided on the device).  workspace:
+ * eps_sort_pairs_by_u_workspace_bytes(n) bytes, 256-byte aligned. */
 /* eps_compact_between: the entries (key >= 0) whose score lies in [*lo, *hi) (DEVICE floats; either may be NULL: open end),
  * compacted in arbitrary order; *n_out (DEVICE int64) = how many.  A sharded filter step deals its final ordering over the
  * ranks by score range. */

@@ -231,3 +231,29 @@ def test_round5_entry_points_on_empty_and_tiny_inputs(eps, dev):
         k, _ = res.valid(res.counts()[0])
         got.append((torch.sort(k).values, res.counts()[1]))
     assert torch.equal(got[0][0], got[2][0]) and got[0][1] == got[2][1] and 0 < got[1][1] <= got[0][1]
+
+
+@pytest.mark.parametrize("n_u,shift", [(8, 12), (3, 10), (200000, 12), (1, 12)])
+def test_sort_pairs_by_u_keeps_blocks_only_while_runs_are_long(eps, dev, n_u, shift):
+    """eps_sort_pairs_by_u with a v block: (v >> shift, u, v) when the runs of equal (block, u) average >= 64 pairs, else (u, v)
+    -- eps_rescore_runs (filter.py:113-142's scores, exactly, for the K best) pays one bitmap per run; the decision is made on
+    the device.  Either order holds the same pairs; both are checked against tensor ops."""
+    from eps_amd import ops
+    gen = torch.Generator(device=dev).manual_seed(n_u + shift)
+    n = 60000
+    u = torch.randint(0, n_u, (n,), generator=gen, device=dev)
+    v = u + 1 + torch.randint(0, 1 << 16, (n,), generator=gen, device=dev)
+    keys = torch.unique((v << 32) | u)                                   # v << 32 | u, u < v, distinct pairs
+    keys = keys[torch.randperm(keys.numel(), generator=gen, device=dev)]
+    bits = int(v.max()).bit_length()
+    out = ops.sort_pairs_by_u(keys, bits, shift)
+    uu, vv = keys & 0xFFFFFFFF, keys >> 32
+    runs = torch.unique(((vv >> shift) << 32) | uu).numel()
+    blocked = runs * 64 <= keys.numel()
+    assert blocked == (n_u <= 8)                                         # (the cases straddle the rule)
+    major = (vv >> shift) if blocked else torch.zeros_like(vv)
+    o = torch.argsort((major << 52) | (uu << 26) | vv)                  # ids below 2^26 here
+    assert torch.equal(out, ((uu << 32) | vv)[o])
+    # and no block at all is the plain (u, v) order
+    o2 = torch.argsort((uu << 26) | vv)
+    assert torch.equal(ops.sort_pairs_by_u(keys, bits, 0), ((uu << 32) | vv)[o2])
