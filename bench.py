@@ -461,14 +461,29 @@ def run(args):
 
     for _ in range(args.warmup):
         step()
-    ops.KERNEL_EVENTS = []                         # HIP events around every eps_filter_scan launch, on its stream
+    # the timed region: HIP events around the scan launches only (the dominant kernel: `roofline.kernel_ms`), on their stream.
+    # The interpreter's cyclic collector is off inside the timed loops, as in `timeit`: a generation-2 pass of this process
+    # (torch + the graph objects) stops the host for 30-45 ms, which lands in one step out of a hundred and moved the 100-step
+    # average by 0.3-0.4 ms from run to run (tools/r05_loop_probe.py: median step 14.21 ms with and without it)
+    import gc
+    gc.collect()
+    gc.disable()
+    ops.KERNEL_EVENTS, ops.EVENT_NAMES = [], ()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     barrier()
     dt = time.perf_counter() - t0
-    events, ops.KERNEL_EVENTS = ops.KERNEL_EVENTS, None
+    events, ops.KERNEL_EVENTS, ops.EVENT_NAMES = ops.KERNEL_EVENTS, None, None
+    # where the rest of a step goes (`step_breakdown_ms`, `sharded_ms_per_rank`): a second, short loop with events around EVERY
+    # library call -- some forty event records per step, which cost the host 0.4 ms a step when they sat in the timed region
+    bd_steps = max(1, min(args.steps, 20))
+    ops.KERNEL_EVENTS = []
+    for _ in range(bd_steps):
+        step()
+    barrier()
+    bd_events, ops.KERNEL_EVENTS = ops.KERNEL_EVENTS, None
     # what the FIRST scan of a fresh graph object costs: hubs-first copy and every per-graph table included.  Measured after the
     # timed loop, i.e. with the process's code objects loaded and its allocator warm (a fresh process adds ~1 GiB of first-time
     # hipMalloc and ~10 ms per torch operator it is the first to use: 0.1-0.25 s box to box -- profiles/r03/cold_scan.txt)
@@ -504,8 +519,8 @@ def run(args):
     samp = sum(samp_ms) / max(1, len(samp_ms))
     # what a rank does on ITS share (shrinks with N): both scan launches, the local selects, the sort + exact re-scoring of its survivors
     per_step = {}
-    for name, a, b, _ in events:
-        per_step[name] = per_step.get(name, 0.0) + a.elapsed_time(b) / args.steps
+    for name, a, b, _ in bd_events:
+        per_step[name] = per_step.get(name, 0.0) + a.elapsed_time(b) / bd_steps
     sharded_ms = sum(per_step.values())
     per_rank = [[kern_ms, samp, sharded_ms]]
     if world > 1:
@@ -534,6 +549,8 @@ def run(args):
     # the same step over >= `--sustain` seconds (the timed region above is 20 steps = 0.5 s in a driver run): clocks settle, the
     # figure is what a long job sees
     sustained = None
+    if args.sustain <= 0:
+        gc.enable()
     if args.sustain > 0:
         est = max(dt / args.steps, 1e-4)
         n_sus = max(args.steps, int(args.sustain / est) + 1)
@@ -548,6 +565,7 @@ def run(args):
             tt = torch.tensor([ts], device=dev, dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             ts = tt.item()
+        gc.enable()
         sustained = {"steps": n_sus, "seconds": ts, "ms_per_step": ts / n_sus * 1e3, "value": job_cand * n_sus / ts,
                      "sclk_mhz_mean": (sum(clk.samples) / len(clk.samples)) if clk.samples else None,
                      "sclk_mhz_min": min(clk.samples) if clk.samples else None, "sclk_samples": len(clk.samples)}
@@ -632,9 +650,14 @@ def run(args):
                                          "and the published 53.24 (README.md:11-17) is reachable only through the $EPS_DATA_ROOT/ppa.pt "
                                          "hook (legs.real_ppa)",
                                  "replicated_ms": "ms_per_step minus the slowest rank's sharded work (both scan launches, its local "
-                                                  "selects, the sort and exact re-scoring of its survivors -- HIP events, step_breakdown_ms): "
+                                                  "selects, the sort and exact re-scoring of its survivors -- HIP events, step_breakdown_ms, taken in a "
+                                                  "second loop of <= 20 steps right after the timed region, which itself carries events around "
+                                                  "the scan launches only): "
                                                   "collectives, host reads, the gathered selection and this rank's range of the final "
                                                   "ordering -- what does not shrink with N",
+                                 "gc": "the interpreter's cyclic garbage collector is off inside the timed and the sustained loop (gc.collect() "
+                                       "before, re-enabled after), as `timeit` does: a generation-2 pass stops this process's host thread "
+                                       "for 30-45 ms, one step in a hundred or so (tools/r05_loop_probe.py)",
                                  "sustained": "the same step repeated for >= --sustain seconds after the timed region; sclk from rocm-smi "
                                               "samples taken by a child process during the loop (null when the tool is unavailable)",
                                  "prep_ms": "hubs-first relabelled copy + revpos / half paths / column order / fixed-point "

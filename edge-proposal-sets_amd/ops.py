@@ -454,6 +454,8 @@ def fixed_weights(node_w: torch.Tensor) -> torch.Tensor:
 
 _SCAN_WS = {}
 KERNEL_EVENTS = None      # a list while bench.py times kernels: (kernel name, start event, end event, work size) per launch
+EVENT_NAMES = None        # None: every library call is bracketed while KERNEL_EVENTS is a list; a collection of names: only those (the
+                          # scan launches always are) -- bench.py's timed region carries the dominant kernel's events alone
 
 
 class _timed:
@@ -463,7 +465,7 @@ class _timed:
         self.dev, self.name, self.size, self.ev = dev, name, int(size), None
 
     def __enter__(self):
-        if KERNEL_EVENTS is not None:
+        if KERNEL_EVENTS is not None and (EVENT_NAMES is None or self.name in EVENT_NAMES):
             self.ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             self.ev[0].record(torch.cuda.current_stream(self.dev))
         return self
