@@ -256,7 +256,7 @@ def screen_shift(bound: float, max_deg: int, weighted: bool = False) -> int:
 
 class Screen:
     """What a launch of the piece kernel and the exact re-scoring of its survivors need, for one (graph, weight table)."""
-    __slots__ = ("fx32", "shift", "fixw", "val", "node_w", "usable", "ssum", "smax", "plan", "d_used", "w_min", "heads", "head_cur", "rowrec", "vword")
+    __slots__ = ("fx32", "shift", "fixw", "val", "node_w", "usable", "ssum", "smax", "plan", "d_used", "w_min", "heads", "head_cur", "rowrec", "vword", "exact")
 
     def __init__(self, fx32, shift, fixw, val, node_w, usable, ssum=None, smax=None, plan=None, d_used=0, w_min=0.0):
         self.fx32, self.shift, self.fixw, self.val, self.node_w, self.usable = fx32, shift, fixw, val, node_w, usable
@@ -267,6 +267,8 @@ class Screen:
         self.head_cur = None         # the HeadTables the last launch under a bar used
         self.rowrec = None           # ops.scan_row_records: one 128-byte line per node with what the walk gathers per row
         self.vword = None            # the `variant` word the plan was built with (geometry + the limit on dropped weight bits)
+        self.exact = False           # screening sums ARE the exact scores (one weight for every node, a multiple of every unit a piece
+                                     # may round to -- common neighbours): the survivors need no re-scoring
 
     def lower_bound(self, s: torch.Tensor, max_deg: int) -> torch.Tensor:
         """A lower bound of the exact score of a pair whose screening score is ``s`` (monotone in s).  A path's screening term
@@ -332,8 +334,11 @@ def screen_weights(g0: CSRGraph, g: CSRGraph, perm, node_w: torch.Tensor) -> Scr
             pptr, recs, d_word = ops.scan_plan(g.rowptr, cuts, window_paths(g), ssum, smax, bounds, g.n_rows, shift, vword, with_d=True)
             plan = (pptr, recs)
         zero = torch.zeros(1, dtype=torch.int32, device=g.device)
-        bad_h, d_h, min_h = torch.cat([bad.view(torch.int32), d_word if d_word is not None else zero,
-                                       min_fx if min_fx is not None else zero - 1]).tolist()
+        f_lo, f_hi = (fixw.min(), fixw.max()) if fixw.numel() else (torch.zeros((), dtype=torch.int64, device=g.device),) * 2
+        bad_h, d_h, min_h, f_lo, f_hi = torch.cat([bad.view(torch.int32).to(torch.int64), (d_word if d_word is not None else zero).to(torch.int64),
+                                                   (min_fx if min_fx is not None else zero - 1).to(torch.int64),
+                                                   f_lo.view(1), f_hi.view(1)]).tolist()
+        bad_h, d_h, min_h = bad_h & 0xFFFFFFFF, d_h & 0xFFFFFFFF, min_h & 0xFFFFFFFF
         usable = fits and bad_h == 0
         rowrec = ops.scan_row_records(screen_tables(g)[1], g.rowptr, fx32) if usable and one_pass and ROW_RECORDS else None
         if not usable:
@@ -348,6 +353,13 @@ def screen_weights(g0: CSRGraph, g: CSRGraph, perm, node_w: torch.Tensor) -> Scr
         sc = Screen(fx32, shift, fixw, None, None, usable, ssum, smax, plan, d_used, w_min)
         sc.rowrec = rowrec
         sc.vword = vword
+        # One weight for all nodes (common neighbours: 1.0), a whole number of screening units that stays whole under every low bit a
+        # piece may drop (csrc/scan_pieces.hip: packed_dmax <= min(24, shift - 8)): a path's screening term is then its exact 2^-40
+        # term, a pair's screening sum c x fx x 2^-shift converts to the same float32 as eps_rescore_runs' c x fixw x 2^-40
+        # (c < 2^24 paths), and scan_topk skips the re-scoring (2.3 of 15.4 ms on the ppa-like graph).
+        down, dm = 40 - shift, max(0, min(24, shift - 8))
+        sc.exact = bool(ssum is not None and 0 < f_lo == f_hi and down >= 0 and f_lo % (1 << down) == 0
+                        and (f_lo >> down) % (1 << dm) == 0 and (f_lo >> down) < (1 << 31) and EXACT_SCREENING)
         return sc
     # (one entry per labelling: the tables are indexed by the SCANNED graph's node ids)
     return g0.weight_cached("screen_weights" if perm is None else "screen_weights_relabelled", node_w, build)
@@ -712,6 +724,7 @@ def select_topk_torch(keys: torch.Tensor, vals: torch.Tensor, k: int) -> Tuple[t
     return keys[o], vals[o]
 
 
+EXACT_SCREENING = True       # uniform weights whose screening sums are exact skip the re-scoring (Screen.exact; tests switch it off to compare)
 RESCORE_V_BLOCK = 12         # the survivors are re-scored in blocks of 2^12 consecutive v (then u, then v): the workgroups that run side
                              # by side stream the rows of one block of v out of the L2.  r04 (one hand-out counter): 2^8 3.32, 2^10 2.78,
                              # 2^12 2.60, 2^14 2.77 ms.  r05 (chunks dealt to the XCDs in groups, 16-byte row loads), measured INSIDE the
@@ -917,14 +930,17 @@ def scan_topk(g: CSRGraph, node_w: torch.Tensor, k: int, rank: int = 0, world: i
             # (the outputs hold 2 x k_pre pairs -- lower() keeps ~10 % more than k_pre -- not a copy of the list's worst-case size;
             #  a level of tied scores at the threshold may hold more: then the call is repeated with room for all of them)
             room = res.capacity if rescore_all else min(res.capacity, 2 * k_pre + (1 << 16))
-            c_keys, _, n_valid, _, pre_thr = ops.select_compact(l_keys, l_vals, k_pre, res.count_ptr, mode=2, params=(a, b, 4e-6), room=room)
+            c_keys, c_vals, n_valid, _, pre_thr = ops.select_compact(l_keys, l_vals, k_pre, res.count_ptr, mode=2, params=(a, b, 4e-6), room=room)
             nv = int(n_valid.item())                                                      # (one word: sizes the re-scoring)
             if nv > room:
-                c_keys, _, n_valid, _, pre_thr = ops.select_compact(l_keys, l_vals, k_pre, res.count_ptr, mode=2, params=(a, b, 4e-6),
-                                                                    room=min(res.capacity, nv))
+                c_keys, c_vals, n_valid, _, pre_thr = ops.select_compact(l_keys, l_vals, k_pre, res.count_ptr, mode=2, params=(a, b, 4e-6),
+                                                                         room=min(res.capacity, nv))
                 nv = int(n_valid.item())
-            l_keys, l_vals = rescore_exact(g, screen, c_keys[:nv], bar)
-            n_rescored = nv
+            if screen.exact:
+                l_keys, l_vals = c_keys[:nv], c_vals[:nv]        # (screening sums that ARE the exact scores: Screen.exact)
+            else:
+                l_keys, l_vals = rescore_exact(g, screen, c_keys[:nv], bar)
+            n_rescored = 0 if screen.exact else nv
             status = res.status
         # the job-wide cut: the k2-th best survivor score over all ranks (-inf when fewer survived); untouched slots are -inf
         zero = torch.zeros(1, dtype=torch.int64, device=dev)

@@ -199,3 +199,31 @@ def test_full_size_heads_properties(eps, dev):
     finally:
         scan.HEADS = True
     assert torch.equal(p0, p1) and torch.equal(s0, s1)
+
+
+@pytest.mark.parametrize("w0", [1.0, 0.5, 0.3])
+def test_uniform_weights_skip_the_rescoring_with_the_same_rows(eps, dev, monkeypatch, w0):
+    """One weight for every node whose screening sums are exact (common neighbours, models.py:536-542: weight 1; 0.5 likewise;
+    0.3 is no whole number of screening units): scan_topk then takes the survivors' scores as they are -- the rows and scores
+    must be those of the run that re-scores them, bit for bit, with and without skipped heads."""
+    from eps_amd import scan, synth
+    g = synth.rmat_graph(14, 12, 3, dev)
+    monkeypatch.setattr(scan, "SMALL_SET", 0)
+    monkeypatch.setattr(scan, "HEAD_MIN_PATHS", 0)
+    monkeypatch.setattr(scan, "RELABEL_MIN_NODES", 0)
+    for heads in (False, True):
+        monkeypatch.setattr(scan, "HEADS", heads)
+        for k in (2000, 150_000):
+            monkeypatch.setattr(scan, "EXACT_SCREENING", False)
+            wa = torch.full((g.n_rows,), w0, dtype=torch.float32, device=dev)        # (tables are cached per weight TENSOR)
+            st0 = {}
+            p0, s0 = scan.scan_topk(g, wa, k, stats=st0, relabel=True)
+            monkeypatch.setattr(scan, "EXACT_SCREENING", True)
+            wb = wa.clone()
+            st1 = {}
+            p1, s1 = scan.scan_topk(g, wb, k, stats=st1, relabel=True)
+            assert torch.equal(p0, p1) and torch.equal(s0, s1)
+            gs, perm = scan.scan_graph(g)
+            exact = scan.screen_weights(g, gs, perm, wb).exact
+            assert exact == (w0 in (1.0, 0.5)) and not scan.screen_weights(g, gs, perm, wa).exact
+            assert st0["rescored"] > 0 and (st1["rescored"] == 0) == exact and st1["heads"] == heads
