@@ -360,7 +360,8 @@ def reverse_positions_symmetric(rowptr: torch.Tensor, col: torch.Tensor):
     out = torch.empty(col.numel(), dtype=torch.int32, device=dev)
     hp = torch.empty(n, dtype=torch.int64, device=dev)
     # one small buffer for everything the caller reads back: [asymmetric flag (low word), max degree, max half paths, their sum]
-    info = torch.empty(4, dtype=torch.int64, device=dev)
+    # (zeros: the library clears the flag as the 32-bit word it is -- the high half of info[0] is nobody's)
+    info = torch.zeros(4, dtype=torch.int64, device=dev)
     with torch.cuda.device(dev):
         _lib.check(_lib.load().eps_reverse_positions_symmetric(_ptr(rowptr), _ptr(col), n, col.numel(), _ptr(out), _ptr(hp),
                                                                info.data_ptr(), info.data_ptr() + 8, _stream(dev)),
