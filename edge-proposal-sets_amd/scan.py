@@ -853,9 +853,10 @@ def scan_topk(g: CSRGraph, node_w: torch.Tensor, k: int, rank: int = 0, world: i
 
     Per call, in the steady state (tables cached on the graph): sample launch -> bar (device; the lowest of the ranks' own
     estimates) -> main launch, under a bar with skipped heads + eps_scan_refine -> LOCAL pre-filter of this rank's list (its
-    k2 / world-th best screening score, lowered to what such a score can be worth exactly; no collective) -> exact re-scoring of
-    what passed -> job-wide cut (the ceil(k/2)-th best exact score: one launch on one rank, all-reduced histograms on a job) +
-    compaction -> ONE host read of a status vector (slots, candidates, selected, cut, kernel status, the rank's pre-filter
+    k2 / world-th best screening score, lowered to what such a score can be worth exactly; no collective; its count, one word, is
+    read to size what follows) -> exact re-scoring of what passed (not for uniform weights whose screening sums are exact:
+    Screen.exact) -> job-wide cut (the ceil(k/2)-th best exact score: one launch on one rank; on a job one all-gather of the
+    ranks' scores behind their status words, every rank finds the same cut) + compaction -> ONE host read of a status vector (slots, candidates, selected, cut, kernel status, the rank's pre-filter
     threshold, walked slots, the bar; all-gathered when world > 1), which VERIFIES the step: enough survivors, no list overflow,
     the cut at or above every rank's pre-filter threshold, usable heads -- else the launch repeats with what was learnt -> the
     selected pairs of all ranks gathered -> mirrored + ordered, the ordering dealt over the ranks by score range, the rows sent
