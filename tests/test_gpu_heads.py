@@ -227,3 +227,42 @@ def test_uniform_weights_skip_the_rescoring_with_the_same_rows(eps, dev, monkeyp
             exact = scan.screen_weights(g, gs, perm, wb).exact
             assert exact == (w0 in (1.0, 0.5)) and not scan.screen_weights(g, gs, perm, wa).exact
             assert st0["rescored"] > 0 and (st1["rescored"] == 0) == exact and st1["heads"] == heads
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_scan_topk_with_heads_on_odd_graph_shapes(eps, dev, monkeypatch, seed):
+    """Skipped heads far from the graph they were sized on: a few hubs over a sparse random graph, a clique glued to a star, rows
+    that are ALL hubs (n_hub >= N), isolated nodes -- rows and scores of scan_topk with heads equal those without, for AA / RA / CN
+    in turn, and the launch did use heads (filter.py:96-142 + :160-161 under --keep_top)."""
+    import scipy.sparse as ssp
+    from eps_amd import scan
+    rng = np.random.default_rng(900 + seed)
+    n = int(rng.integers(600, 5000))
+    m = int(n * rng.uniform(3, 10))
+    r, c = rng.integers(0, n, m), rng.integers(0, n, m)
+    hubs = rng.integers(0, n, max(2, n // 150))
+    r = np.concatenate([r, np.repeat(hubs, n // 3)]); c = np.concatenate([c, rng.integers(0, n, len(hubs) * (n // 3))])
+    if seed % 2:                                                       # a clique of 40 glued to the first hub, and a tail of isolated ids
+        q = rng.choice(n - 50, 40, replace=False)
+        qa, qb = np.meshgrid(q, q)
+        r = np.concatenate([r, qa.ravel(), np.full(40, hubs[0])]); c = np.concatenate([c, qb.ravel(), q])
+        keep = (r < n - 50) & (c < n - 50)
+        r, c = r[keep], c[keep]
+    A = ssp.coo_matrix((np.ones(len(r), dtype=np.float32), (r, c)), shape=(n, n)).tocsr()
+    A = ((A + A.T) > 0).astype(np.float32).tocsr()
+    A.setdiag(0); A.eliminate_zeros(); A.sort_indices()
+    g = eps.CSRGraph.from_scipy(A, device=dev, keep_values=False)
+    w = _weights(eps, g, ("aa", "ra", "cn")[seed % 3])
+    monkeypatch.setattr(scan, "SMALL_SET", 0)
+    monkeypatch.setattr(scan, "HEAD_MIN_PATHS", 0)
+    monkeypatch.setattr(scan, "RELABEL_MIN_NODES", 0)
+    used = 0
+    for k in (500, 20_000):
+        monkeypatch.setattr(scan, "HEADS", False)
+        p0, s0 = scan.scan_topk(g, w, k, relabel=True)
+        monkeypatch.setattr(scan, "HEADS", True)
+        st = {"count": False}
+        p1, s1 = scan.scan_topk(g, w, k, stats=st, relabel=True)
+        assert torch.equal(p0, p1) and torch.equal(s0, s1), (seed, k, st)
+        used += bool(st["heads"])
+    assert used, "no launch of this graph ran with skipped heads"
