@@ -15,6 +15,10 @@ w = torch.ones(g0.n_rows, dtype=torch.float32, device=dev) if kind == 'cn' else 
 K = int(os.environ.get("K", 4_000_000))
 if 'VBLOCK' in os.environ:
     scan.RESCORE_V_BLOCK = int(os.environ['VBLOCK'])
+if 'HEAD_MAX_ROWS' in os.environ:
+    scan.HEAD_MAX_ROWS = int(os.environ['HEAD_MAX_ROWS'])
+if 'HEAD_BETA' in os.environ:
+    scan.HEAD_BETA = float(os.environ['HEAD_BETA'])
 if 'DMAX_MARGIN' in os.environ:
     scan.DMAX_MARGIN = int(os.environ['DMAX_MARGIN'])
 steps = int(os.environ.get("STEPS", 10))
