@@ -148,21 +148,34 @@ __global__ __launch_bounds__(256) void sp_refine_kernel(const eps_survivors *__r
             const uint2 hd = heads[v];
             // the head term: the skipped rows of column v are its first hd.x neighbours (hubs, ids < n_hub); row w counts iff u
             // is a neighbour of hub w -- bit u of hub w's bitmap row, four rows in flight
-            uint32_t c = 0u;
+            // From the END of the head -- ids ascend, degrees fall, weights grow: its heaviest rows first -- and only as far as the
+            // pair can still reach the bar: `rem` is the weight of the rows not looked at yet (hd.y = their sum at the start), and a
+            // slot whose walked sum + found + rem falls below the bar is out.  Most slots pass the walk's lowered threshold by
+            // little and share none of the first few rows: they leave after one trip (resource allocation skips dozens of rows
+            // per column: every slot used to pay for each).
+            uint32_t c = 0u, rem = hd.y;
+            const uint32_t s_walk = in_val[i];
             const int32_t *__restrict__ vcol = col + rowptr[v];
             const uint32_t *__restrict__ ubit = hubrows + ((uint32_t)u >> 5);
-            for (uint32_t j0 = 0; j0 < hd.x; j0 += 4u) {
-                uint32_t wq[4], mq[4];
+            bool out_of_reach = thr32 >= SP_FLAG;
+            for (int j1 = (int)hd.x; j1 > 0 && !out_of_reach; j1 -= 4) {
+                uint32_t wq[4], mq[4], fq[4];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) wq[q] = j0 + q < hd.x ? (uint32_t)vcol[j0 + q] : 0u;
+                for (int q = 0; q < 4; ++q) wq[q] = j1 - 1 - q >= 0 ? (uint32_t)vcol[j1 - 1 - q] : 0u;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) mq[q] = ubit[(size_t)wq[q] * words];
+                for (int q = 0; q < 4; ++q) {
+                    mq[q] = ubit[(size_t)wq[q] * words];
+                    fq[q] = j1 - 1 - q >= 0 ? (fx_lds ? s_fx[wq[q]] : fx32[wq[q]]) : 0u;
+                }
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    if (j0 + q < hd.x && ((mq[q] >> ((uint32_t)u & 31u)) & 1u)) c += fx_lds ? s_fx[wq[q]] : fx32[wq[q]];
+                for (int q = 0; q < 4; ++q) {
+                    rem -= fq[q];
+                    if ((mq[q] >> ((uint32_t)u & 31u)) & 1u) c += fq[q];
+                }
+                out_of_reach = (unsigned long long)s_walk + c + rem < (unsigned long long)thr32;
             }
-            total = in_val[i] + c;
-            pass = total >= thr32 && thr32 < SP_FLAG;
+            total = s_walk + c;
+            pass = !out_of_reach && total >= thr32;
         }
         const unsigned long long m = __ballot(pass);
         if (m) {
