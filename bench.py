@@ -373,10 +373,19 @@ def main():
         import traceback
         tb = traceback.format_exc()
         sys.stderr.write(tb)
-        print(json.dumps({"metric": "candidate edges scored/sec on ogbl-ppa (ppa-like synthetic)", "value": None, "unit": "edges/s",
-                          "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True,
-                          "error": f"{type(exc).__name__}: {exc}", "rank": int(os.environ.get("RANK", "0")),
-                          "traceback_tail": tb.strip().splitlines()[-6:]}), flush=True)
+        my_rank = int(os.environ.get("RANK", "0"))
+        text = json.dumps({"metric": "candidate edges scored/sec on ogbl-ppa (ppa-like synthetic)", "value": None, "unit": "edges/s",
+                           "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True,
+                           "error": f"{type(exc).__name__}: {exc}", "rank": my_rank,
+                           "traceback_tail": tb.strip().splitlines()[-6:]})
+        # ONE line on the job's stdout: rank 0 reports at once; any other rank first gives rank 0 (and lower ranks) the time to do
+        # so and to bring the launcher down on everybody -- when all ranks fail alike (a bad argument) only rank 0's line appears,
+        # when rank 0 is healthy the failing rank's does.  The line goes out in a single write (line + newline: `print` makes two,
+        # and two ranks writing at once produced `{...}{...}` on one line in the r05 suite).
+        if my_rank:
+            time.sleep(1.0 + 0.25 * my_rank)
+        sys.stdout.write(text + "\n")
+        sys.stdout.flush()
         # (no re-exec, no clean-up collectives: the other ranks are torn down by the launcher when this one exits non-zero)
         os._exit(1)
 

@@ -17,6 +17,8 @@ if 'VBLOCK' in os.environ:
     scan.RESCORE_V_BLOCK = int(os.environ['VBLOCK'])
 if 'HEAD_MAX_ROWS' in os.environ:
     scan.HEAD_MAX_ROWS = int(os.environ['HEAD_MAX_ROWS'])
+if 'HEAD_KEEP_HI' in os.environ:
+    scan.HEAD_KEEP = (scan.HEAD_KEEP[0], float(os.environ['HEAD_KEEP_HI']))
 if 'HEAD_BETA' in os.environ:
     scan.HEAD_BETA = float(os.environ['HEAD_BETA'])
 if 'DMAX_MARGIN' in os.environ:
