@@ -24,6 +24,11 @@ ABL = {
     # (correct results) three / two workgroups per CU instead of four: what the launch loses per workgroup slot given to something else
     "percu3": [("sp_per_cu[3] = {2, 1, 4};", "sp_per_cu[3] = {2, 1, 3};")],
     "percu2": [("sp_per_cu[3] = {2, 1, 4};", "sp_per_cu[3] = {2, 1, 2};")],
+    # kind-specialised bodies (timing + registers; results incomplete by construction): only the direct pieces / only the packed ones
+    # (the skip sits behind the per-row segment bookkeeping, so the pieces that ARE processed see the segments they would)
+    "directonly": [("                const bool packed = !HV && (info >> 30) == 1u;\n", "                const bool packed = false;\n"),
+                   ("                for (uint32_t part = 0; part < parts; ++part) {\n", "                if (!direct) continue;\n                __builtin_assume(direct);\n                for (uint32_t part = 0; part < parts; ++part) {\n")],
+    "packedonly": [("                for (uint32_t part = 0; part < parts; ++part) {\n", "                if (!packed) continue;\n                __builtin_assume(packed && !direct && !d16);\n                for (uint32_t part = 0; part < parts; ++part) {\n")],
     # no known-edge marking
     "noknown": [("                    for (int j = single ? tid : na + tid; j < nb; j += T) {", "                    for (int j = single ? tid : na + tid; j < nb && j < 0; j += T) {")],
 }
