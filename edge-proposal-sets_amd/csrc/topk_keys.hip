@@ -8,6 +8,7 @@
 // (any algorithm, any sharding) then yields exactly that order, which is what makes the
 // multi-GPU top-K merge shard-count invariant.
 #include "eps_common.h"
+#include <stdlib.h>
 
 __device__ __forceinline__ uint32_t ordered_bits(float f)
 {
@@ -462,10 +463,16 @@ extern "C" int eps_select_compact(const int64_t *keys, const float *vals, int64_
     const int64_t cap = (int64_t)eps_num_cus();                // one workgroup per CU at most
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
-    // A COOPERATIVE launch: the runtime places the whole grid at once or not at all, so the hand-over between the rounds cannot
-    // wait for a workgroup that a persistent kernel of another stream -- or another process on the same device (ranks sharing a
-    // GPU) -- keeps off the CUs (r04 launched it plainly and relied on "one workgroup per CU is always resident").  Should the
-    // device refuse the grid, one workgroup does the job: slow, never stuck.
+    // A COOPERATIVE launch: the runtime validates that the whole grid fits the device at once, so the hand-over between the rounds
+    // cannot wait for a workgroup of THIS launch that was never placed (r04 launched it plainly and relied on "one workgroup per
+    // CU is always resident").  That is a guarantee about this process's launch only: CUs held by a persistent
+    // kernel of ANOTHER process on the same device (ranks sharing a GPU: the --one-device tests) are not reserved against, and a
+    // hand-over can then stall until that kernel lets go.  For that set-up EPS_SELECT_ONE_WORKGROUP=1 in the environment selects
+    // the single-workgroup grid (no hand-over between workgroups at all: slow, never stuck) -- also what a refused grid falls back to.
+    {
+        static const int one = [] { const char *e = getenv("EPS_SELECT_ONE_WORKGROUP"); return e && e[0] == '1' ? 1 : 0; }();
+        if (one) blocks = 1;
+    }
     uint64_t k64 = (uint64_t)k;
     int mode_i = (int)mode;
     fsel_state *st = (fsel_state *)state;

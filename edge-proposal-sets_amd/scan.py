@@ -368,10 +368,11 @@ def screen_weights(g0: CSRGraph, g: CSRGraph, perm, node_w: torch.Tensor) -> Scr
 class HeadTables:
     """What a launch with skipped heads brings (one set per budget): the head table, the window paths and the plan of the rows
     that are still walked, and that plan's dropped weight bits."""
-    __slots__ = ("budget", "heads", "wpaths", "plan", "d_used", "live")
+    __slots__ = ("budget", "heads", "wpaths", "plan", "d_used", "live", "n_hub")
 
-    def __init__(self, budget, heads, wpaths, plan, d_used):
+    def __init__(self, budget, heads, wpaths, plan, d_used, n_hub=0):
         self.budget, self.heads, self.wpaths, self.plan, self.d_used = budget, heads, wpaths, plan, d_used
+        self.n_hub = n_hub           # hub rows the heads were cut from (a graph's second scan widens the table: rebuilt then)
         self.live = {}               # (rank, world) -> this rank's columns without the DEAD ones (see live_columns)
 
 
@@ -418,8 +419,12 @@ def head_tables(g: CSRGraph, screen: Screen, budget: int) -> HeadTables:
     """The tables of a launch whose columns skip heads of at most ``budget`` (table units), cached on the Screen: the head table
     (eps_scan_heads), the window paths and the plan table of the walked rows.  ~1.5 ms on the ppa-like graph, once per bar
     level; one host read (the plan's size and dropped bits)."""
+    n_hub = hub_rows(g).shape[0]
+    if budget in screen.heads and screen.heads[budget].n_hub != n_hub:
+        # built against the narrow hub table of the graph's first scan (HUB_FIRST): still correct -- the wider bitmaps are a
+        # superset -- but its heads stop at the old width; every weight table of the graph gets the full-width heads (ADVICE r05)
+        del screen.heads[budget]
     if budget not in screen.heads:
-        n_hub = hub_rows(g).shape[0]
         heads = ops.scan_heads(g.rowptr, g.col, screen.fx32, n_hub, budget, HEAD_MAX_ROWS)
         bounds, cuts = screen_tables(g)
         wp = ops.scan_window_paths(g.rowptr, g.col, reverse_positions(g), cuts, heads)
@@ -427,7 +432,7 @@ def head_tables(g: CSRGraph, screen: Screen, budget: int) -> HeadTables:
                                            screen.vword if screen.vword is not None else screen_variant(g), with_d=True, heads=heads)
         while len(screen.heads) >= HEAD_CACHE:
             screen.heads.pop(next(iter(screen.heads)))
-        screen.heads[budget] = HeadTables(budget, heads, wp, (pptr, recs), int(d_word.item()))
+        screen.heads[budget] = HeadTables(budget, heads, wp, (pptr, recs), int(d_word.item()), n_hub)
     return screen.heads[budget]
 
 
@@ -470,6 +475,8 @@ def _heads_for(g: CSRGraph, screen: Screen, bar) -> Optional[HeadTables]:
     """The head tables for a launch under ``bar`` (1-element device tensor): the set the last launch used, without looking at the
     bar -- the kernel itself refuses a head as heavy as the bar (status bit 2), and scan_topk compares budget and bar after
     the step's one host read --, or, the first time, a set built for the bar (one host read of it)."""
+    if screen.head_cur is not None and screen.head_cur.n_hub != hub_rows(g).shape[0]:
+        screen.head_cur = None                       # (cut from a narrower hub table than the graph has now)
     if screen.head_cur is None:
         b = float(bar)
         if not (b > 0.0 and b < float("inf")):
@@ -562,10 +569,16 @@ def batch_from(g: CSRGraph, columns: torch.Tensor) -> int:
     light column is ~10 us of one of 1024 workgroups: singly, the tickets would set the pace).  Cached per list (one host read)."""
     if columns.numel() < BATCH_MIN_COLUMNS:          # (a short list -- the bar sample -- has fewer columns than workgroups to feed)
         return columns.numel()
-    key = ("batch_from", columns.data_ptr(), columns.numel(), BATCH_PATHS)
-    if key not in g._cache:
-        g._cache[key] = int((half_paths(g)[columns.long()] >= BATCH_PATHS).sum().item())
-    return g._cache[key]
+    # (keyed by the list OBJECT, which the entry keeps alive: a raw device pointer is handed out again once its list is freed --
+    #  the live-column lists of evicted head tables -- and would then answer for another list of the same length; ADVICE r05)
+    memo = g._cache.setdefault("batch_from", {})
+    key = (id(columns), BATCH_PATHS)
+    hit = memo.get(key)
+    if hit is None or hit[0] is not columns:
+        while len(memo) >= 4 * HEAD_CACHE + 8:
+            memo.pop(next(iter(memo)))
+        hit = memo[key] = (columns, int((half_paths(g)[columns.long()] >= BATCH_PATHS).sum().item()))
+    return hit[1]
 
 
 def candidate_count(g: CSRGraph, screen: Optional[Screen], fixw, rank: int = 0, world: int = 1) -> int:
@@ -902,7 +915,7 @@ def scan_topk(g: CSRGraph, node_w: torch.Tensor, k: int, rank: int = 0, world: i
     use_heads = (HEADS and screen is not None and screen.plan is not None and screen.ssum is not None and g.val is None
                  and total_half >= HEAD_MIN_PATHS)
     _count_scan(g, screen)
-    head_list, head_trouble = HEAD_LIST, 0
+    head_list, head_trouble, head_stale = HEAD_LIST, 0, 0
     n_rescored = None
     ht = None
     while True:
@@ -996,13 +1009,20 @@ def scan_topk(g: CSRGraph, node_w: torch.Tensor, k: int, rank: int = 0, world: i
             # dropped: the next _heads_for reads the bar), the list grows; twice in a row: this call goes on without heads.
             bar_units = _f32_from_bits(table[0][7]) * 2.0 ** screen.shift
             # (... or the bar fell below the lowest one the table -- and its list of live columns -- was built for)
-            void = any(t[4] & 4 for t in table) or any(t[6] > walked_cap for t in table) or ht.budget > HEAD_KEEP[1] * bar_units
+            overflow = any(t[6] > walked_cap for t in table)
+            stale = any(t[4] & 4 for t in table) or ht.budget > HEAD_KEEP[1] * bar_units
+            void = overflow or stale
             if void or not HEAD_KEEP[0] * bar_units <= ht.budget <= HEAD_KEEP[1] * bar_units:
                 screen.head_cur = None                       # (a budget out of range only costs time: the NEXT launch rebuilds)
             if void:
-                head_trouble += 1
-                head_list *= 2
-                use_heads = head_trouble < 2
+                # (two causes, two remedies -- ADVICE r05: a table built for another bar is simply rebuilt; only an overflowing
+                #  walked list grows the list and counts toward giving heads up for this call)
+                if overflow:
+                    head_trouble += 1
+                    head_list *= 2
+                else:
+                    head_stale += 1
+                use_heads = head_trouble < 2 and head_stale < 3
                 launches -= 1                                # (the repeat is the same launch again, not a corrected bar)
                 if launches + 2 > MAX_LAUNCHES:
                     raise ops._lib.EpsError("scan_topk: launches with skipped heads kept failing")

@@ -126,11 +126,16 @@ def test_dense_kernels_ragged_shapes(eps, oracle, dev, seed):
     assert float(np.abs(logit - logit_o).max()) <= 2e-5 * max(1.0, float(np.abs(logit_o).max())), (H, L, E)
 
 
+_FUZZ_HEADS = {}
+
+
+@pytest.mark.parametrize("heads", [False, True], ids=["default", "heads"])
 @pytest.mark.parametrize("seed", range(8))
-def test_scan_topk_fuzz(eps, oracle, dev, seed, monkeypatch):
+def test_scan_topk_fuzz(eps, oracle, dev, seed, monkeypatch, heads):
     """The production filter path on random graphs: scan_topk (estimated bar or none, labels as given or hubs first) equals
     the first K rows of the declared order over the oracle's full candidate scoring -- pairs exactly wherever the K-th score is
-    not tied within float rounding of a neighbour, scores within the gate."""
+    not tied within float rounding of a neighbour, scores within the gate.  ``heads``: HEAD_MIN_PATHS = 0, so the hubs-first run
+    under a bar is the full-size step's configuration (skipped heads + refine + row / column records) against the ORACLE."""
     import scipy.sparse as ssp
     from eps_amd import scan
     from eps_amd.heuristics import node_weight_table
@@ -155,12 +160,19 @@ def test_scan_topk_fuzz(eps, oracle, dev, seed, monkeypatch):
     monkeypatch.setattr(scan, "SMALL_SET", 0 if seed % 3 else scan.SMALL_SET)      # mostly the estimated-bar path
     monkeypatch.setattr(scan, "SAMPLE_STRIDE", int(rng.integers(2, 40)))
     monkeypatch.setattr(scan, "RELABEL_MIN_NODES", 0)
+    if heads:
+        monkeypatch.setattr(scan, "HEAD_MIN_PATHS", 0)
     k = int(rng.integers(1, max(2, len(cand))))
     got = {}
     for relabel in (False, True):
-        pairs, scores = scan.scan_topk(g, wt, k, relabel=relabel)
+        st = {}
+        pairs, scores = scan.scan_topk(g, wt, k, relabel=relabel, stats=st)
         got[relabel] = (pairs.cpu().numpy(), scores.cpu().numpy())
         assert (scan.scan_graph(g)[1] is not None) == relabel
+        assert st["candidates"] == len(cand)
+        if not heads:
+            assert not st["heads"]
+        _FUZZ_HEADS[seed, heads, relabel] = bool(st["heads"])
     assert np.array_equal(got[False][0], got[True][0]) and np.array_equal(got[False][1], got[True][1]), "labels must not matter"
     p, s = got[False]
     assert p.shape[1] == min(k, len(cand)) and bool((s[:-1] >= s[1:]).all())
@@ -173,3 +185,12 @@ def test_scan_topk_fuzz(eps, oracle, dev, seed, monkeypatch):
     # equal scores come out in candidate order (key ascending)
     same = s[:-1] == s[1:]
     assert bool((pos[:-1][same] < pos[1:][same]).all())
+
+
+def test_scan_topk_fuzz_ran_with_heads():
+    """(runs after the fuzz above) some of its graphs went through launches with skipped heads (how many is printed with -s)."""
+    ran = [k for k, v in _FUZZ_HEADS.items() if v]
+    if not _FUZZ_HEADS:
+        pytest.skip("the fuzz did not run in this session")
+    print("fuzz runs with skipped heads:", sorted(ran))
+    assert len(ran) >= 1, sorted(_FUZZ_HEADS.items())

@@ -162,11 +162,17 @@ def test_scan_bar_and_column_subsets(eps, oracle, dev, seed, scale, ef):
         assert got == want_cn
 
 
-def test_scan_topk_is_exact(eps, oracle, dev, monkeypatch):
+@pytest.mark.parametrize("heads", [False, True], ids=["default", "heads"])
+def test_scan_topk_is_exact(eps, oracle, dev, monkeypatch, heads):
     """scan_topk == the first K rows of the declared order over the full candidate list, on the direct path (small
-    set, no bar) and on the estimate -> scan -> verify path, incl. a bar that is too high and one that is too low."""
+    set, no bar) and on the estimate -> scan -> verify path, incl. a bar that is too high and one that is too low.
+    ``heads``: HEAD_MIN_PATHS = 0 -- with hubs-first labels the production configuration of the full-size step (plan table, row /
+    column records, skipped heads + eps_scan_refine) runs on this small graph as well, against the same full list."""
     from eps_amd import scan, synth
     from eps_amd.heuristics import node_weight_table
+    if heads:
+        monkeypatch.setattr(scan, "HEAD_MIN_PATHS", 0)
+    ran_heads = 0
     g = synth.rmat_graph(12, 12, 3, "cpu")
     A = g.to_scipy()
     g = g.to(dev)
@@ -199,6 +205,8 @@ def test_scan_topk_is_exact(eps, oracle, dev, monkeypatch):
             pairs, scores = scan.scan_topk(g, wt, k, stats=st)
             assert torch.equal(pairs, torch.stack([cu[order[:k]], cv[order[:k]]]).long()), (stride, safety, st)
             assert torch.equal(scores, sc[order[:k]])
+            ran_heads += int(bool(st["heads"]))
+    assert (ran_heads > 0) == heads, "skipped heads are expected exactly when HEAD_MIN_PATHS lets this graph have them"
     # the oracle's float32 scores agree within the gate on the selected rows
     rp, col = A.indptr.astype(np.int64), A.indices.astype(np.int32)
     w = oracle.node_weights(oracle.col_sums(rp, col, None, g.n_rows), oracle.W_AA)
@@ -290,18 +298,27 @@ def test_scan_full_size_properties(eps, dev, oracle):
     assert int(hit.sum()) >= pairs.shape[1] - 2                                 # at most the K-th tie loses its mirror
     p2, s2 = scan.scan_topk(g, wt, 1_000_000)
     assert torch.equal(p2, pairs) and torch.equal(s2, scores)
-    _full_size_oracle_columns(eps, g, wt, pairs, scores, bar)
-    # the same scan under hubs-first labels (what a repeatedly scanned graph runs on): ids mapped back, bit-identical list
-    p3, s3 = scan.scan_topk(g, wt, 1_000_000, relabel=True)
-    assert scan.scan_graph(g)[1] is not None
-    assert torch.equal(p3, pairs) and torch.equal(s3, scores)
+    # the same scan under hubs-first labels (what a repeatedly scanned graph runs on): the PRODUCTION configuration -- plan table,
+    # row / column records, skipped heads + refine -- faces the oracle's candidate set and scores itself, not only
+    # through equality with the as-labelled run: twice, because a graph's second scan widens the hub table (HUB_FIRST -> HUB_MAX)
+    checked = [(pairs, scores, bar)]
+    for _ in range(2):
+        st3 = {}
+        p3, s3 = scan.scan_topk(g, wt, 1_000_000, relabel=True, stats=st3)
+        assert scan.scan_graph(g)[1] is not None
+        assert st3["heads"], "the relabelled full-size scan is expected to run with skipped heads"
+        assert st3["candidates"] == st["candidates"]
+        checked.append((p3, s3, float(s3[-1])))
+        assert torch.equal(p3, pairs) and torch.equal(s3, scores)
+    _full_size_oracle_columns(eps, g, wt, checked)
 
 
-def _full_size_oracle_columns(eps, g, wt, pairs, scores, bar):
-    """The full-size scan against the ORACLE directly (not against the build's own expansion kernel): for a dozen columns --
+def _full_size_oracle_columns(eps, g, wt, results):
+    """Full-size scans against the ORACLE directly (not against the build's own expansion kernel): for a dozen columns --
     hubs, median-degree, tail -- the restated filter.py:96-109 candidate set (oracle.candidates_scipy_columns) scored by the
-    oracle's pair_scores; the scan's rows of those columns must be exactly the oracle's candidates above the bar (ids exact,
-    scores <= 1e-5 relative).  Rows whose oracle score is within 1e-5 of the bar may fall on either side."""
+    oracle's pair_scores; each result's rows of those columns ((pairs, scores, bar) triples: the as-labelled run and the
+    hubs-first runs with skipped heads) must be exactly the oracle's candidates above the bar (ids exact, scores <= 1e-5
+    relative).  Rows whose oracle score is within 1e-5 of the bar may fall on either side."""
     from oracle import eps_oracle as orc
     deg = g.degree()
     by_deg = torch.argsort(deg, descending=True)
@@ -310,19 +327,24 @@ def _full_size_oracle_columns(eps, g, wt, pairs, scores, bar):
     A = g.to_scipy()
     rp, col = A.indptr.astype(np.int64), A.indices.astype(np.int32)
     w = orc.node_weights(orc.col_sums(rp, col, None, n), orc.W_AA)
-    pu, pv, ps = pairs[0].cpu().numpy(), pairs[1].cpu().numpy(), scores.cpu().numpy()
+    truth = {}
     for c in cols:
         cand, _ = orc.candidates_scipy_columns(A, c, c + 1)
         _, _, sc = orc.pair_scores(rp, col, None, w, cand[:, 0], cand[:, 1])
-        sure = sc > bar * (1 + 2e-5)
-        maybe = sc > bar * (1 - 2e-5)
-        m = pv == c
-        got = dict(zip(pu[m].tolist(), ps[m].tolist()))
-        want_sure = dict(zip(cand[sure, 0].tolist(), sc[sure].tolist()))
-        want_maybe = set(cand[maybe, 0].tolist())
-        assert set(want_sure) <= set(got) <= want_maybe, f"column {c}: rows differ from the oracle's"
-        for u, s_ in want_sure.items():
-            assert abs(got[u] - s_) <= 1e-5 * max(abs(s_), abs(got[u])), (c, u, got[u], s_)
+        truth[c] = (cand, sc)
+    for pairs, scores, bar in results:
+        pu, pv, ps = pairs[0].cpu().numpy(), pairs[1].cpu().numpy(), scores.cpu().numpy()
+        for c in cols:
+            cand, sc = truth[c]
+            sure = sc > bar * (1 + 2e-5)
+            maybe = sc > bar * (1 - 2e-5)
+            m = pv == c
+            got = dict(zip(pu[m].tolist(), ps[m].tolist()))
+            want_sure = dict(zip(cand[sure, 0].tolist(), sc[sure].tolist()))
+            want_maybe = set(cand[maybe, 0].tolist())
+            assert set(want_sure) <= set(got) <= want_maybe, f"column {c}: rows differ from the oracle's"
+            for u, s_ in want_sure.items():
+                assert abs(got[u] - s_) <= 1e-5 * max(abs(s_), abs(got[u])), (c, u, got[u], s_)
 
 
 def test_scan_wide_id_space_in_windows(eps, oracle, dev):
