@@ -90,11 +90,19 @@ SIGNATURES = {
     "eps_select_topk_cut": (_int, [_vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _i64, _vp]),
     "eps_select_topk_rows_workspace_bytes": (_i64, [_i64]),
     "eps_select_topk_rows": (_int, [_vp, _vp, _i64, _i64, _i32, _vp, _vp, _vp, _i64, _vp]),
+    "eps_tail_state_bytes": (_i64, []),
+    "eps_score_hist": (_int, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
+    "eps_score_pick_compact": (_int, [_vp, _vp, _i64, _vp, _vp, _vp, _i64, _i32, _c.c_float, _c.c_float, _c.c_float, _i32, _vp, _vp, _vp,
+                                      _vp, _i64, _vp, _vp, _vp]),
+    "eps_radix_sort_workspace_bytes": (_i64, [_i64]),
+    "eps_radix_sort_by_u": (_int, [_vp, _i64, _vp, _i32, _i32, _vp, _vp, _i64, _vp, _vp]),
+    "eps_radix_sort_rows": (_int, [_vp, _vp, _i64, _vp, _i64, _i32, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _vp]),
+    "eps_rescore_runs_dev": (_int, [_vp, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp]),
     "eps_pack_keys": (_int, [_vp, _vp, _i64, _i64, _vp, _vp]),
     "eps_unpack_keys": (_int, [_vp, _i64, _vp, _vp, _vp]),
 }
 
-ABI_VERSION = 6        # include/eps_abi.h EPS_ABI_VERSION
+ABI_VERSION = 7        # include/eps_abi.h EPS_ABI_VERSION
 _lib = None
 _load_lock = threading.RLock()
 

@@ -34,6 +34,9 @@ int eps_num_cus();
 int eps_take_counter(unsigned int **counter, hipStream_t stream, const char *who);
 // ... eight consecutive zeroed words (a hand-out with one counter per XCD)
 int eps_take_counters8(unsigned int **counters, hipStream_t stream, const char *who);
+// ... eight zeroed words EPS_SPREAD_STRIDE words apart (each on a 256-byte line of its own: counter y at [y * EPS_SPREAD_STRIDE])
+#define EPS_SPREAD_STRIDE 64
+int eps_take_counters8_spread(unsigned int **counters, hipStream_t stream, const char *who);
 
 #if defined(__HIPCC__)
 // ---- wave-level reductions (all 64 lanes receive the total) --------------------------

@@ -1171,8 +1171,13 @@ extern "C" int eps_scan_row_sums(const int64_t *rowptr, const int32_t *col, cons
 __global__ __launch_bounds__(RS_THREADS) void rescore_runs_kernel(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col,
                                                                  const int64_t *__restrict__ fixw, int32_t n_nodes,
                                                                  const int64_t *__restrict__ keys, int64_t n,
-                                                                 float *__restrict__ out, unsigned int *__restrict__ next_chunk)
+                                                                 float *__restrict__ out, unsigned int *__restrict__ next_chunk,
+                                                                 const int64_t *__restrict__ n_dev)
 {
+    if (n_dev) {                 // (r06: the list's length lives on the device -- the sorts in front read it there too)
+        const int64_t c = *n_dev;
+        n = c < 0 ? 0 : (c < n ? c : n);
+    }
     extern __shared__ __attribute__((aligned(16))) uint32_t bm[];          // RS_BITS / 32 words
     __shared__ unsigned long long s_starts[RS_CHUNK / 64];
     __shared__ long long s_sum[RS_CHUNK];
@@ -1309,8 +1314,12 @@ __global__ __launch_bounds__(RS_THREADS) void rescore_runs_kernel(const int64_t 
 #define RSS_THREADS 256
 __global__ __launch_bounds__(RSS_THREADS) void rescore_short_kernel(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col,
                                                                   const int64_t *__restrict__ fixw, const int64_t *__restrict__ keys,
-                                                                  int64_t n, float *__restrict__ out)
+                                                                  int64_t n, float *__restrict__ out, const int64_t *__restrict__ n_dev)
 {
+    if (n_dev) {
+        const int64_t c = *n_dev;
+        n = c < 0 ? 0 : (c < n ? c : n);
+    }
     __shared__ int32_t s_stage[RSS_THREADS / 64][RS_SHORT];
     const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
     int32_t *stage = s_stage[wib];
@@ -1383,8 +1392,25 @@ __global__ __launch_bounds__(256) void rescore_weighted_kernel(const int64_t *__
 
 // keys: (u << 32) | v sorted ascending (runs of equal u); fixw[i] = the 2^-40 fixed-point weight of node i (eps_fixed_weights);
 // out[i] = score of pair i as float32 of the exact sum.  Unit-valued adjacency.
+static int rescore_runs_launch(const int64_t *rowptr, const int32_t *col, const int64_t *fixw, int64_t n_nodes, const int64_t *keys,
+                               int64_t n, const int64_t *n_dev, float *out, void *stream);
+
 extern "C" int eps_rescore_runs(const int64_t *rowptr, const int32_t *col, const int64_t *fixw, int64_t n_nodes,
                                 const int64_t *keys, int64_t n, float *out, void *stream)
+{
+    return rescore_runs_launch(rowptr, col, fixw, n_nodes, keys, n, nullptr, out, stream);
+}
+
+// The same with the list's length read on the DEVICE: min(*n_dev, n_max) pairs (the grid is sized for n_max).
+extern "C" int eps_rescore_runs_dev(const int64_t *rowptr, const int32_t *col, const int64_t *fixw, int64_t n_nodes,
+                                    const int64_t *keys, int64_t n_max, const int64_t *n_dev, float *out, void *stream)
+{
+    EPS_REQUIRE(n_dev, "eps_rescore_runs_dev: null count");
+    return rescore_runs_launch(rowptr, col, fixw, n_nodes, keys, n_max, n_dev, out, stream);
+}
+
+static int rescore_runs_launch(const int64_t *rowptr, const int32_t *col, const int64_t *fixw, int64_t n_nodes, const int64_t *keys,
+                               int64_t n, const int64_t *n_dev, float *out, void *stream)
 {
     EPS_REQUIRE(n >= 0 && n_nodes >= 0 && n_nodes < (1ll << 31), "eps_rescore_runs: bad size");      // (col[] is addressed with 32-bit byte offsets: nnz < 2^30, like eps_scan_screen)
     if (n == 0) return EPS_OK;
@@ -1403,12 +1429,12 @@ extern "C" int eps_rescore_runs(const int64_t *rowptr, const int32_t *col, const
     const int64_t cap = (int64_t)eps_num_cus() * (per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu));
     if (blocks > cap) blocks = cap;
     hipLaunchKernelGGL(rescore_runs_kernel, dim3((unsigned)blocks), dim3(RS_THREADS), lds, s, rowptr, col, fixw, (int32_t)n_nodes, keys,
-                       n, out, counter);
+                       n, out, counter, n_dev);
     {
         int64_t sb = (n + RSS_THREADS / 64 - 1) / (RSS_THREADS / 64);
         const int64_t scap = (int64_t)eps_num_cus() * 8;
         if (sb > scap) sb = scap;
-        hipLaunchKernelGGL(rescore_short_kernel, dim3((unsigned)sb), dim3(RSS_THREADS), 0, s, rowptr, col, fixw, keys, n, out);
+        hipLaunchKernelGGL(rescore_short_kernel, dim3((unsigned)sb), dim3(RSS_THREADS), 0, s, rowptr, col, fixw, keys, n, out, n_dev);
     }
     EPS_CHECK_LAUNCH("eps_rescore_runs");
     return EPS_OK;

@@ -1121,6 +1121,121 @@ def select_rows(sel_keys: torch.Tensor, sel_vals: torch.Tensor, k: int, id_bits:
     return out_k, out_v
 
 
+# ---- the tail of the filter step with device-side sizes (csrc/tail_sort.hip, r06) ------------------------------------------------
+_TAIL_STATE = {}
+
+
+def tail_state(dev) -> torch.Tensor:
+    """The state block of the tail kernels for (device, current stream): zeroed ONCE here -- the kernels that consume it leave it
+    zeroed, so a step issues no memset for it."""
+    key = (dev.type, dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    st = _TAIL_STATE.get(key)
+    if st is None:
+        st = _TAIL_STATE[key] = torch.zeros((int(_lib.load().eps_tail_state_bytes()) + 7) // 8 + 32, dtype=torch.int64, device=dev)
+    return st
+
+
+def _tail_state_ptr(dev):
+    st = tail_state(dev)
+    return ctypes.c_void_p(st.data_ptr() + (-st.data_ptr()) % 256)
+
+
+def tail_state_reset(dev) -> None:
+    """Zero the state again (after a failed call that may have left a histogram or a hand-over counter half way)."""
+    tail_state(dev).zero_()
+
+
+def _dev_count(n_dev):
+    """A device count argument: None, a raw device address (Survivors.count_ptr), or a 1-element int64 tensor."""
+    if n_dev is None or isinstance(n_dev, int):
+        return n_dev
+    return n_dev.data_ptr()
+
+
+def score_hist(keys: Optional[torch.Tensor], vals: torch.Tensor, n_dev, base: torch.Tensor, above: Optional[torch.Tensor] = None) -> None:
+    """Add the histogram of the list's live scores (buckets of their distance to ``base``, a 1-element float32 device tensor) to
+    the tail state (eps_score_hist).  ``n_dev``: device count that bounds the list (None: its length)."""
+    dev = _need_gpu(keys, vals, base, above)
+    _chk(keys, torch.int64, "keys"); _chk(vals, torch.float32, "vals"); _chk(base, torch.float32, "base"); _chk(above, torch.float32, "above")
+    with torch.cuda.device(dev), _timed(dev, "select_compact", vals.numel()):
+        _lib.check(_lib.load().eps_score_hist(_ptr(keys), _ptr(vals), vals.numel(), _dev_count(n_dev), _ptr(base), _ptr(above),
+                                              _tail_state_ptr(dev), _stream(dev)), "eps_score_hist")
+
+
+def score_pick_compact(keys: Optional[torch.Tensor], vals: torch.Tensor, n_dev, base: torch.Tensor, k: int, above: Optional[torch.Tensor] = None,
+                       mode: int = 0, params=(0.0, 0.0, 0.0), swap_halves: bool = False, room: Optional[int] = None,
+                       want_vals: bool = True):
+    """The selection behind ``score_hist`` (eps_score_pick_compact): -> (out_keys, out_vals, n_out, kth, thr), all device tensors.
+    ``kth`` is the lower edge of the bucket that holds the k-th best live value (<= the exact k-th, by at most 2^-8 of its distance
+    to ``base``), ``thr`` derived from it as in ``select_compact``; the live entries with value >= thr are compacted into arrays
+    of ``room`` entries (more are counted in n_out, not stored); ``swap_halves`` exchanges the key halves on the way."""
+    dev = _need_gpu(keys, vals, base, above)
+    n = vals.numel()
+    kth = torch.empty(2, dtype=torch.float32, device=dev)
+    out_k = out_v = n_out = None
+    if keys is not None:
+        room = max(1, n if room is None else min(int(room), max(n, 1)))
+        out_k = torch.empty(room, dtype=torch.int64, device=dev)
+        out_v = torch.empty(room, dtype=torch.float32, device=dev) if want_vals else None
+        n_out = torch.empty(1, dtype=torch.int64, device=dev)
+    with torch.cuda.device(dev), _timed(dev, "select_compact", n):
+        _lib.check(_lib.load().eps_score_pick_compact(_ptr(keys), _ptr(vals), n, _dev_count(n_dev), _ptr(base), _ptr(above), int(k), int(mode),
+                                                      float(params[0]), float(params[1]), float(params[2]), int(bool(swap_halves)),
+                                                      kth.data_ptr(), kth.data_ptr() + 4, _ptr(out_k), _ptr(out_v),
+                                                      0 if out_k is None else int(room), _ptr(n_out), _tail_state_ptr(dev), _stream(dev)),
+                   "eps_score_pick_compact")
+    return out_k, out_v, n_out, kth[0:1], kth[1:2]
+
+
+def radix_sort_by_u(keys: torch.Tensor, n_dev, id_bits: int = 32, v_block_shift: int = 0) -> torch.Tensor:
+    """``sort_pairs_by_u`` in one cooperative launch with the list's length read on the device (eps_radix_sort_by_u): the first
+    min(*n_dev, len(keys)) keys v << 32 | u -> u << 32 | v in the order eps_rescore_runs wants; the rest of the output is undefined."""
+    dev = _need_gpu(keys)
+    _chk(keys, torch.int64, "keys")
+    n = keys.numel()
+    out = torch.empty(n, dtype=torch.int64, device=dev)
+    if n:
+        lib = _lib.load()
+        with torch.cuda.device(dev), _timed(dev, "sort_pairs_by_u", n):
+            _, wsp, wsb = _aligned_ws(dev, lib.eps_radix_sort_workspace_bytes(n))
+            _lib.check(lib.eps_radix_sort_by_u(_ptr(keys), n, _dev_count(n_dev), int(id_bits), int(v_block_shift), _ptr(out), wsp, wsb,
+                                               _tail_state_ptr(dev), _stream(dev)), "eps_radix_sort_by_u")
+    return out
+
+
+def radix_sort_rows(sel_keys: torch.Tensor, sel_vals: torch.Tensor, m_dev, k: int, id_bits: int = 32, perm: Optional[torch.Tensor] = None):
+    """``select_rows`` in one cooperative launch with the number of selected pairs read on the device (eps_radix_sort_rows):
+    -> (pairs int64 [2, cap] as (u; v), scores float32 [cap], n_rows 1-element int64 device tensor) with cap = min(k, 2 len);
+    the first n_rows = min(k, 2 m) columns are the rows of the declared order, the rest undefined."""
+    dev = _need_gpu(sel_keys, sel_vals, perm)
+    _chk(sel_keys, torch.int64, "sel_keys"); _chk(sel_vals, torch.float32, "sel_vals"); _chk(perm, torch.int64, "perm")
+    m_max, k = sel_keys.numel(), int(k)
+    cap = min(k, 2 * m_max)
+    pairs = torch.empty((2, cap), dtype=torch.int64, device=dev)
+    scores = torch.empty(cap, dtype=torch.float32, device=dev)
+    n_rows = torch.zeros(1, dtype=torch.int64, device=dev) if cap == 0 else torch.empty(1, dtype=torch.int64, device=dev)
+    if cap:
+        lib = _lib.load()
+        with torch.cuda.device(dev), _timed(dev, "select_rows", m_max):
+            _, wsp, wsb = _aligned_ws(dev, lib.eps_radix_sort_workspace_bytes(2 * m_max))
+            _lib.check(lib.eps_radix_sort_rows(_ptr(sel_keys), _ptr(sel_vals), m_max, _dev_count(m_dev), k, int(id_bits), _ptr(perm),
+                                               _ptr(pairs), cap, _ptr(scores), _ptr(n_rows), wsp, wsb, _tail_state_ptr(dev), _stream(dev)),
+                       "eps_radix_sort_rows")
+    return pairs, scores, n_rows
+
+
+def rescore_runs_dev(rowptr, col, fixw: torch.Tensor, n_nodes: int, keys_by_u: torch.Tensor, n_dev: torch.Tensor) -> torch.Tensor:
+    """``rescore_runs`` over the first min(*n_dev, len) keys (eps_rescore_runs_dev); the other outputs are undefined."""
+    dev = _need_gpu(rowptr, col, fixw, keys_by_u, n_dev)
+    _chk(keys_by_u, torch.int64, "keys_by_u"); _chk(fixw, torch.int64, "fixw"); _chk(n_dev, torch.int64, "n_dev")
+    out = torch.empty(keys_by_u.numel(), dtype=torch.float32, device=dev)
+    if keys_by_u.numel():
+        with torch.cuda.device(dev), _timed(dev, "rescore_runs", keys_by_u.numel()):
+            _lib.check(_lib.load().eps_rescore_runs_dev(_ptr(rowptr), _ptr(col), _ptr(fixw), int(n_nodes), _ptr(keys_by_u), keys_by_u.numel(),
+                                                        _ptr(n_dev), _ptr(out), _stream(dev)), "eps_rescore_runs_dev")
+    return out
+
+
 _SELECT_WS = {}
 
 

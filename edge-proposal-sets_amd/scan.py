@@ -737,6 +737,7 @@ def select_topk_torch(keys: torch.Tensor, vals: torch.Tensor, k: int) -> Tuple[t
     return keys[o], vals[o]
 
 
+TAIL_DEVICE = True           # one rank, under a bar: the step's tail runs on the device with device-side sizes (csrc/tail_sort.hip)
 EXACT_SCREENING = True       # uniform weights whose screening sums are exact skip the re-scoring (Screen.exact; tests switch it off to compare)
 RESCORE_V_BLOCK = 12         # the survivors are re-scored in blocks of 2^12 consecutive v (then u, then v): the workgroups that run side
                              # by side stream the rows of one block of v out of the L2.  r04 (one hand-out counter): 2^8 3.32, 2^10 2.78,
@@ -928,7 +929,43 @@ def scan_topk(g: CSRGraph, node_w: torch.Tensor, k: int, rank: int = 0, world: i
         launches += 1
         l_keys, l_vals = res.key, res.val
         status, pre_thr = None, None
-        if screen is not None:
+        rows = None
+        fast = (TAIL_DEVICE and world == 1 and screen is not None and g.val is None and bar is not None and not rescore_all
+                and k2 + (1 << 16) < (1 << 30))
+        if fast:
+            # r06: the whole tail on the device, sizes included -- score-bucket histograms instead of four-round radix selects, the
+            # two orderings as one cooperative radix sort each, the rows sorted BEFORE the step's one host read (which then only
+            # confirms them).  The cut is the lower edge of the bucket that holds the k2-th best exact score (<= the exact cut, a few
+            # pairs more are mirrored and sorted; the K rows are the same), the pre-filter threshold likewise.
+            a, b = screen.lower_params(max_degree(g), None if ht is None else ht.d_used)
+            bits = max(1, min(32, int(g.n_rows - 1).bit_length()))
+            room = min(res.capacity, 2 * k2 + (1 << 16))
+            while True:
+                ops.score_hist(res.key, res.val, res.count_ptr, bar)
+                c_keys, c_vals, n_valid, _, pre_thr = ops.score_pick_compact(res.key, res.val, res.count_ptr, bar, k2, mode=2,
+                                                                             params=(a, b, 4e-6), room=room, want_vals=screen.exact)
+                if screen.exact:                     # (screening sums that ARE the exact scores: Screen.exact)
+                    x_keys, x_vals, swap = c_keys, c_vals, False
+                else:
+                    x_keys = ops.radix_sort_by_u(c_keys, n_valid, bits, RESCORE_V_BLOCK)          # (u << 32 | v): runs of equal u
+                    x_vals = ops.rescore_runs_dev(g.rowptr, g.col, screen.fixw, g.n_rows, x_keys, n_valid)
+                    swap = True
+                ops.score_hist(x_keys, x_vals, n_valid, bar, above=bar)
+                sel_k, sel_v, n_sel, cut, _ = ops.score_pick_compact(x_keys, x_vals, n_valid, bar, k2, above=bar, swap_halves=swap, room=room)
+                r_pairs, r_scores, n_rows = ops.radix_sort_rows(sel_k, sel_v, n_sel, k, bits, perm)
+                zero = torch.zeros(1, dtype=torch.int64, device=dev)
+                st = torch.cat([res.rec[1:2], res.rec[4:5], n_sel, cut.view(torch.int32).to(torch.int64), res.status.to(torch.int64),
+                                pre_thr.view(torch.int32).to(torch.int64), res.walked_slots if res.walked_slots is not None else zero,
+                                bar.view(torch.int32).to(torch.int64) if ht is not None else zero, n_valid, n_rows])
+                row = st.tolist()                                                                # the host read of the step
+                nv = row[8]
+                if nv <= room:
+                    break
+                room = min(res.capacity, nv)        # (a level of tied scores at the pre-filter threshold holds more than the room: once more)
+            table = [row[:8]]
+            n_rescored = 0 if screen.exact else nv
+            rows = (r_pairs, r_scores, row[9])
+        elif screen is not None:
             # the one-pass kernel screens with upper bounds: its survivors are re-scored exactly (those that do not exceed the
             # bar after all drop out), so from here on the list holds eps_filter_scan's scores bit for bit.
             # Not all of them need it: a screening score s exceeds the exact one by less than what `screen.lower_bound` takes
@@ -963,7 +1000,9 @@ def scan_topk(g: CSRGraph, node_w: torch.Tensor, k: int, rank: int = 0, world: i
                    res.walked_slots if res.walked_slots is not None else zero,                      # slots of the walked list,
                    bar.view(torch.int32).to(torch.int64) if ht is not None else zero]               # the bar's bits (head launches)
         scores_all = None
-        if world > 1 and screen is not None and not rescore_all:
+        if fast:
+            pass
+        elif world > 1 and screen is not None and not rescore_all:
             # ONE exchange for the cut AND the step's status: every rank's re-scored scores (at most `room`, -inf beyond its own) behind
             # six status words, all-gathered.  Each rank then finds the job-wide cut itself -- one select launch over the gathered
             # scores: the same values in the same order everywhere, so the same cut without a broadcast -- and knows every rank's
@@ -1065,7 +1104,9 @@ def scan_topk(g: CSRGraph, node_w: torch.Tensor, k: int, rank: int = 0, world: i
         break
     keys, vals = sel_k[:nsel_r[rank]], sel_v[:nsel_r[rank]]      # (still in the scanned graph's labels: select_rows maps them back)
     bits = max(1, min(32, int(g.n_rows - 1).bit_length()))
-    if world > 1 and scores_all is not None and n_sel_all >= DIST_ROWS_MIN:
+    if rows is not None:
+        keys = vals = None                          # (the device tail has ordered the rows already)
+    elif world > 1 and scores_all is not None and n_sel_all >= DIST_ROWS_MIN:
         keys, vals = _deal_rows(keys.contiguous(), vals.contiguous(), deal_sp, deal_c, k, bits, perm, rank, world, rows_on)
     elif world > 1:
         keys, vals = epd.gather_ragged(keys, nsel_r), epd.gather_ragged(vals, nsel_r)
@@ -1096,6 +1137,8 @@ def scan_topk(g: CSRGraph, node_w: torch.Tensor, k: int, rank: int = 0, world: i
                      head_budget=None if ht is None else ht.budget * 2.0 ** -screen.shift,
                      walked_slots=sum(t[6] for t in table) if ht is not None else None, rescored=n_rescored,
                      survivor_slots=sum(min(s_, capacity) for s_ in slots_r), bar=bar)
+    if rows is not None:
+        return rows[0][:, :rows[2]], rows[1][:rows[2]]
     if keys is None:
         return None, None
     return torch.stack([keys & 0xFFFFFFFF, keys >> 32]), vals

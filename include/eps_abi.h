@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define EPS_ABI_VERSION 6   /* 6: skipped heads -- eps_scan_heads / _hub_rows / _refine; eps_scan_window_paths / _plan / _screen take a head table (r05); 2: eps_col_sums / eps_node_weights_f64 signatures (r02); 3: 64-bit survivor count, eps_scan_* (r03); 4: eps_scan_screen takes ssum / smax; 5: eps_select_compact, eps_scan_screen marks unused slots itself (r04) */
+#define EPS_ABI_VERSION 7   /* 7: the tail of the filter step with device-side sizes -- eps_score_hist / _pick_compact, eps_radix_sort_by_u / _rows, eps_rescore_runs_dev (r06); 6: skipped heads -- eps_scan_heads / _hub_rows / _refine; eps_scan_window_paths / _plan / _screen take a head table (r05); 2: eps_col_sums / eps_node_weights_f64 signatures (r02); 3: 64-bit survivor count, eps_scan_* (r03); 4: eps_scan_screen takes ssum / smax; 5: eps_select_compact, eps_scan_screen marks unused slots itself (r04) */
 
 #define EPS_OK 0
 #define EPS_EINVAL (-1)   /* bad argument (null pointer, negative size, unsupported shape) */
@@ -531,6 +531,39 @@ int eps_select_topk_cut(const int64_t *keys, const float *vals, int64_t n, int64
 int64_t eps_select_topk_rows_workspace_bytes(int64_t m);
 int eps_select_topk_rows(const int64_t *sel_keys, const float *sel_vals, int64_t m, int64_t k, int32_t id_bits,
                          int64_t *out_keys, float *out_vals, void *workspace, int64_t workspace_bytes, void *stream);
+/* ---- the tail of the filter step with DEVICE-side sizes (r06; csrc/tail_sort.hip) ------------------------------------------
+ * What follows the scan under `--keep_top K` -- the pre-filter in front of the exact re-scoring, the cut, and the two orderings
+ * of filter.py:160-161 for the K rows rank.py:294 reads -- without a host read in between: every count stays in device memory.
+ *   state: eps_tail_state_bytes() bytes, 256-byte aligned, ZEROED once by the caller and owned by one stream; the kernels that
+ *          consume it leave it zeroed (no memset launches per step).
+ *   eps_score_hist: adds the histogram of a list's live scores (key >= 0 when keys are given, value > -inf and > *above_or_null)
+ *          over order-preserving buckets of their distance to *base (DEVICE floats) to the state; n = min(*n_dev_or_null, n_max).
+ *   eps_score_pick_compact: *kth = the lower edge of the highest bucket with at least k values at or above it (at most 2^-8 of the
+ *          distance to *base below the exact k-th best value; -inf when fewer than k values or k == 0), *thr derived as
+ *          eps_select_compact derives it (mode 0 / 1 / 2); the live entries with value >= *thr go to out_keys / out_vals
+ *          (arbitrary order; swap_halves: key halves exchanged, v << 32 | u -> u << 32 | v and back), *n_out (DEVICE) = how many
+ *          -- beyond out_cap counted, not stored.  Leaves the state's histogram zeroed.
+ *   eps_radix_sort_by_u: the order eps_sort_pairs_by_u produces, in ONE cooperative launch, n read from the device.
+ *   eps_radix_sort_rows: eps_select_topk_rows[_relabelled] in ONE cooperative launch, m read from the device; writes the
+ *          proposal tensor itself: out_pairs[i] = u, out_pairs[out_ld + i] = v, out_scores[i] for the first min(k, 2 m) rows of
+ *          the declared order; *n_rows_out_or_null (DEVICE) = that number.  workspace: eps_radix_sort_workspace_bytes(records)
+ *          bytes (records = n_max resp. 2 m_max), 256-byte aligned.
+ *   eps_rescore_runs_dev: eps_rescore_runs over min(*n_dev, n_max) pairs. */
+int64_t eps_tail_state_bytes(void);
+int eps_score_hist(const int64_t *keys_or_null, const float *vals, int64_t n_max, const unsigned long long *n_dev_or_null,
+                   const float *base, const float *above_or_null, void *state, void *stream);
+int eps_score_pick_compact(const int64_t *keys_or_null, const float *vals, int64_t n_max, const unsigned long long *n_dev_or_null,
+                           const float *base, const float *above_or_null, int64_t k, int32_t mode, float pa, float pb, float pc,
+                           int32_t swap_halves, float *kth_or_null, float *thr_or_null, int64_t *out_keys_or_null,
+                           float *out_vals_or_null, int64_t out_cap, int64_t *n_out_or_null, void *state, void *stream);
+int64_t eps_radix_sort_workspace_bytes(int64_t n_records);
+int eps_radix_sort_by_u(const int64_t *keys, int64_t n_max, const int64_t *n_dev_or_null, int32_t id_bits, int32_t v_block_shift,
+                        int64_t *out_by_u, void *workspace, int64_t workspace_bytes, void *state, void *stream);
+int eps_radix_sort_rows(const int64_t *sel_keys, const float *sel_vals, int64_t m_max, const int64_t *m_dev_or_null, int64_t k,
+                        int32_t id_bits, const int64_t *perm_or_null, int64_t *out_pairs, int64_t out_ld, float *out_scores,
+                        int64_t *n_rows_out_or_null, void *workspace, int64_t workspace_bytes, void *state, void *stream);
+int eps_rescore_runs_dev(const int64_t *rowptr, const int32_t *col, const int64_t *fixw, int64_t n_nodes, const int64_t *keys,
+                         int64_t n_max, const int64_t *n_dev, float *out, void *stream);
 int eps_pack_keys(const float *score, const int64_t *ids_or_null, int64_t id_base, int64_t n,
                   int64_t *keys, void *stream);
 int eps_unpack_keys(const int64_t *keys, int64_t n, float *score_or_null, int64_t *id_or_null,

@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol(eps):
     lib = eps.load()
     for s in declared_symbols():
         assert hasattr(lib, s), f"{s} declared in eps_abi.h but not exported"
-    assert lib.eps_version() == eps._lib.ABI_VERSION == 6
+    assert lib.eps_version() == eps._lib.ABI_VERSION == 7
 
 
 def test_python_signatures_cover_header(eps):
