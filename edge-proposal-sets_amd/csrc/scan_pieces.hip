@@ -38,6 +38,7 @@
 #include "eps_common.h"
 #include "scan_common.h"
 #include <string.h>
+#include <stdlib.h>
 
 #define SP_EMPTY 0u             // an empty key word; a key is stored as id + 1, so a clean table is all zeros in BOTH modes
 #define SP_MAXP (SP_M + 1)
@@ -96,6 +97,10 @@ struct sp_params {
     const uint32_t *rowrec;     // [n_nodes][32] or NULL: per node ONE 128-byte line with everything the walk wants of a row -- words
                                 //        0..15 its 32 cuts, word 16 its first entry (rowptr), word 17 its screening weight (eps_scan_row_records)
     uint32_t batch_from;        // tickets below stand for one column, tickets from here on for SP_BATCH consecutive ones (>= n_columns: none)
+    const uint4 *pack;          // [nnz][2] or NULL (r06; with plan + row records): per stored entry (v, j), in CSR order, everything a
+                                //        single-round column's set-up gathers for it: {w, rowptr[w], fx32[w], revpos | cut of v's FIRST piece in
+                                //        row w << 16} {cuts of v's pieces 1..8 in row w, 16 bits each} -- one contiguous stream per column
+                                //        instead of neighbour ids -> one 128-byte row-record line per neighbour (eps_scan_column_pack)
     const uint2 *heads;         // [n_nodes] or NULL: column v does NOT walk its first heads[v].x rows (its heaviest hub neighbours under
                                 //        hubs-first labels); heads[v].y = the sum of their screening weights.  See eps_scan_heads.
 };
@@ -227,7 +232,10 @@ __device__ __forceinline__ int sp_plan_column(const sp_params &p, int32_t v, int
 // (r05: the per-graph window paths are mandatory.  Until r04 a launch without them summed the window paths of every column
 //  itself -- 32 counters per thread, the one code path of this kernel that spilled vector registers, reached by no caller of the
 //  Python host.)
-template <int T, bool HV>
+// FULL (r06): the main launch of the filter step always comes with the plan table, row and column records, sum bounds and a head
+// table; compiled for exactly that, the body carries none of the fall-back pointers (cuts, fx32, pptr, columns, heads[v], ssum[v])
+// and none of the branches on them -- scalar registers, which the generic body spills by the hundred (111 in r05).
+template <int T, bool HV, bool FULL, bool PACK>
 __global__ __launch_bounds__(T, 4) void scan_piece_kernel(sp_params p)      // (4 waves per SIMD: <= 128 VGPRs, the LDS share decides the rest)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
@@ -268,7 +276,7 @@ __global__ __launch_bounds__(T, 4) void scan_piece_kernel(sp_params p)      // (
     // chunk holds a whole piece's yield.  With one, survivors are rare: a piece asks for room for 1024, and a survivor that
     // does not fit its workgroup's reservation takes a slot of its own (one more global atomic: rare).
     const bool no_bar = thr32 <= 1u;
-    const bool raw_sums = p.heads != nullptr;
+    const bool raw_sums = FULL || p.heads != nullptr;
     const uint32_t chunk = no_bar && direct_ids > 8192u ? direct_ids : 8192u;
     const int32_t my_bound = p.bounds[lane <= SP_M ? lane : SP_M];      // lane k holds window boundary k (the plan runs in wave 0)
 
@@ -300,7 +308,7 @@ __global__ __launch_bounds__(T, 4) void scan_piece_kernel(sp_params p)      // (
         int32_t v, dv;
         uint32_t vb;
         uint4 cra = make_uint4(0u, 0u, 0u, 0u), crb = make_uint4(0u, 0u, 0u, 0u);
-        if (p.colrec) {
+        if (FULL || p.colrec) {
             cra = p.colrec[2 * (size_t)t];
             crb = p.colrec[2 * (size_t)t + 1];
             v = (int32_t)cra.x;
@@ -322,8 +330,8 @@ __global__ __launch_bounds__(T, 4) void scan_piece_kernel(sp_params p)      // (
         //  the column out and says so in the status word)
         uint32_t xv = 0u, thr_v = thr32;
         bool bad_head = false;
-        if (p.heads) {
-            const uint2 hd = p.colrec ? make_uint2(cra.w, crb.x) : p.heads[v];
+        if (FULL || p.heads) {
+            const uint2 hd = (FULL || p.colrec) ? make_uint2(cra.w, crb.x) : p.heads[v];
             xv = hd.x;
             if (thr32 < SP_FLAG) {
                 bad_head = hd.y >= thr32;
@@ -333,23 +341,33 @@ __global__ __launch_bounds__(T, 4) void scan_piece_kernel(sp_params p)      // (
             // a DEAD column: no pair of v sums to more than the row sum of v's screening weights -- below the bar, nothing of
             // this column can pass (a quarter of the ppa-like graph's columns at K = 4 M: a tenth of the pieces, 4 % of the paths.
             // Launches with heads only: a plain launch counts every candidate of its columns)
-            if (p.ssum && thr32 < SP_FLAG && (p.colrec ? crb.y : p.ssum[v]) < thr32) bad_head = true;
+            if ((FULL || p.ssum) && thr32 < SP_FLAG && ((FULL || p.colrec) ? crb.y : p.ssum[v]) < thr32) bad_head = true;
         }
         if (dv > 0 && v > 0 && !bad_head) {
             uint32_t my_w = 0, my_rev = 0, my_base = 0, my_fx = 0;      // this thread's row (of the last round)
-            if (single && tid < dv) {
+            uint32_t cut_first = 0u;
+            if (PACK && single && tid < dv) {
+                // (r06: ONE 16-byte load from the column's own stretch of the pack -- the chain neighbour id -> row record is gone)
+                const uint4 pa = p.pack[2 * ((size_t)vb + (size_t)tid)];
+                my_w = pa.x;
+                my_base = pa.y;
+                my_fx = pa.z;
+                my_rev = pa.w & 0xFFFFu;
+                cut_first = pa.w >> 16;
+            }
+            if (!PACK && single && tid < dv) {
                 my_w = (uint32_t)vcol[tid];
                 my_rev = (uint32_t)vrev[tid];
             }
-            if (single && tid < dv) {
+            if (!PACK && single && tid < dv) {
                 // (with row records the row's first entry, its weight and -- below -- its cuts come out of ONE 128-byte line: three
                 //  gathers into three tables were 384 bytes of fabric traffic per walked row for 24 bytes wanted)
-                my_base = p.rowrec ? p.rowrec[(size_t)my_w * 32 + 16] : rowptr_lo[2 * (size_t)my_w];
+                my_base = (FULL || p.rowrec) ? p.rowrec[(size_t)my_w * 32 + 16] : rowptr_lo[2 * (size_t)my_w];
                 my_fx = HV ? __builtin_bit_cast(uint32_t, (p.val[vb + tid] * p.node_w[my_w]) * p.up)
-                           : (p.rowrec ? p.rowrec[(size_t)my_w * 32 + 17] : p.fx32[my_w]);
+                           : ((FULL || p.rowrec) ? p.rowrec[(size_t)my_w * 32 + 17] : p.fx32[my_w]);
             }
             // ---- plan: merge windows into pieces.  Wave 0, lane k = window k: the extents are ballots over monotone predicates -
-            if (wib == 0 && !p.plan) {
+            if (!FULL && wib == 0 && !p.plan) {
                 const uint32_t pwk = lane < SP_M ? p.wpaths[(size_t)v * SP_M + lane] : 0u;
                 // lane k: neighbours of v below window boundary k (row v's own cuts: cuts[v][k - 1]; 0 for k = 0)
                 const int32_t nbk = lane >= 1 && lane <= SP_M ? (int32_t)p.cuts[(size_t)v * SP_M + lane - 1] : 0;
@@ -367,10 +385,10 @@ __global__ __launch_bounds__(T, 4) void scan_piece_kernel(sp_params p)      // (
                                                   }
                                               });
                 if (lane == 0) s_np = np;
-            } else if (p.plan) {
+            } else if (FULL || p.plan) {
                 // the per-graph plan table: this column's records (one uint4 per piece) go straight into the piece arrays
-                const uint32_t pb = p.colrec ? crb.z : p.pptr[v];
-                const int np = p.colrec ? (int)crb.w : (int)(p.pptr[v + 1] - pb);
+                const uint32_t pb = (FULL || p.colrec) ? crb.z : p.pptr[v];
+                const int np = (FULL || p.colrec) ? (int)crb.w : (int)(p.pptr[v + 1] - pb);
                 if (tid < np) {
                     const uint4 rec = p.plan[pb + (uint32_t)tid];
                     const int k1 = (int)((rec.y >> 8) & 0xFFu);
@@ -392,9 +410,11 @@ __global__ __launch_bounds__(T, 4) void scan_piece_kernel(sp_params p)      // (
             // starts where its segment in the previous piece ended (runs that were skipped hold no entry of any row), and the
             // one cut a piece needs per row -- its end -- is loaded a piece ahead.
             uint32_t cut_ahead = 0u, seg_from = 0u;
-            const uint16_t *__restrict__ cut_tab = p.rowrec ? (const uint16_t *)p.rowrec : p.cuts;      // (a row's cuts: 64 B of its record,
-            const size_t cut_ld = p.rowrec ? 64u : (size_t)SP_M;                                        //  or its row of the cut table)
-            if (single && tid < dv && np > 0) cut_ahead = cut_tab[(size_t)my_w * cut_ld + s_pk1[0] - 1];
+            const uint16_t *__restrict__ cut_tab = (FULL || p.rowrec) ? (const uint16_t *)p.rowrec : p.cuts;      // (a row's cuts: 64 B of its record,
+            const size_t cut_ld = (FULL || p.rowrec) ? 64u : (size_t)SP_M;                                        //  or its row of the cut table)
+            const uint16_t *__restrict__ pack16 = (const uint16_t *)p.pack;
+            if (PACK) cut_ahead = cut_first;
+            else if (single && tid < dv && np > 0) cut_ahead = cut_tab[(size_t)my_w * cut_ld + s_pk1[0] - 1];
 
             for (int pi = 0; pi < np; ++pi) {
                 const int k0 = s_pk0[pi], k1 = s_pk1[pi];
@@ -452,7 +472,9 @@ __global__ __launch_bounds__(T, 4) void scan_piece_kernel(sp_params p)      // (
                     seg_a = seg_from;
                     seg_len = (uint32_t)tid < xv ? 0u : b - seg_from;
                     seg_from = b;
-                    if (pi + 1 < np) cut_ahead = cut_tab[(size_t)my_w * cut_ld + s_pk1[pi + 1] - 1];
+                    if (pi + 1 < np)
+                        cut_ahead = PACK && pi + 1 <= 8 ? pack16[((size_t)vb + (size_t)tid) * 16 + 7 + (pi + 1)]
+                                                        : cut_tab[(size_t)my_w * cut_ld + s_pk1[pi + 1] - 1];
                 }
                 for (uint32_t part = 0; part < parts; ++part) {
                     // ---- known edges in: the neighbours of v inside the piece take their slots BEFORE the walk, with the flag bit
@@ -504,9 +526,9 @@ __global__ __launch_bounds__(T, 4) void scan_piece_kernel(sp_params p)      // (
                         } else if (j < dv) {
                             w = (uint32_t)vcol[j];
                             rev = (uint32_t)vrev[j];
-                            base = p.rowrec ? p.rowrec[(size_t)w * 32 + 16] : rowptr_lo[2 * (size_t)w];
+                            base = (FULL || p.rowrec) ? p.rowrec[(size_t)w * 32 + 16] : rowptr_lo[2 * (size_t)w];
                             fx = HV ? __builtin_bit_cast(uint32_t, (p.val[vb + j] * p.node_w[w]) * p.up)
-                                    : (p.rowrec ? p.rowrec[(size_t)w * 32 + 17] : p.fx32[w]);
+                                    : ((FULL || p.rowrec) ? p.rowrec[(size_t)w * 32 + 17] : p.fx32[w]);
                             const uint16_t *crow = cut_tab + (size_t)w * cut_ld;
                             uint32_t b = crow[k1 - 1];
                             if (k0 > 0) a = crow[k0 - 1];
@@ -1163,12 +1185,18 @@ extern "C" int eps_scan_row_sums(const int64_t *rowptr, const int32_t *col, cons
 #ifndef RS_GROUP
 #define RS_GROUP 128            // consecutive 256-pair chunks that go to the same XCD (32 k pairs: most of a block of 2^9 v)
 #endif
+#ifndef RS_GB
+#define RS_GB 4                 // weight gathers of a trip issued together (r06: 16 x 64-bit partial sums in flight were 32 of the kernel's 94 VGPRs)
+#endif
+#ifndef RS_MINW
+#define RS_MINW 8               // waves per SIMD the kernel is compiled for: 8 = two 1024-thread workgroups per CU (<= 64 VGPRs)
+#endif
 #ifndef RS_NB
-#define RS_NB 16                // entries of N(v) a lane has in flight per trip: a trip is three dependent latencies (row, bitmap,
+#define RS_NB 8                 // entries of N(v) a lane has in flight per trip: a trip is three dependent latencies (row, bitmap,
 #endif                          // weights) and the survivors' rows are long (~1100 entries on the ppa-like graph: 2.2 G entries to stream
                                 // for 2 M pairs -- 4 / 8 / 12 / 16 in flight: 6.4 / 5.5 / 5.4 / 5.1 ms for all 4.85 M pairs)
 
-__global__ __launch_bounds__(RS_THREADS) void rescore_runs_kernel(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+__global__ __launch_bounds__(RS_THREADS, RS_MINW) void rescore_runs_kernel(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col,
                                                                  const int64_t *__restrict__ fixw, int32_t n_nodes,
                                                                  const int64_t *__restrict__ keys, int64_t n,
                                                                  float *__restrict__ out, unsigned int *__restrict__ next_chunk,
@@ -1257,34 +1285,42 @@ __global__ __launch_bounds__(RS_THREADS) void rescore_runs_kernel(const int64_t 
                     const int pi = p0 + (lane >> 5);
                     const bool live = pi < e;
                     const int32_t v = live ? (int32_t)(keys[c0 + pi] & 0xFFFFFFFFll) : 0;
-                    const int64_t vb = live ? rowptr[v] : 0, ve = live ? rowptr[v + 1] : 0;
+                    // (32-bit entry indices: nnz < 2^30 -- r06: the 64-bit index arithmetic and sixteen 64-bit partial sums per lane
+                    //  had the kernel at 94 VGPRs = ONE 1024-thread workgroup per CU; at <= 64 two are resident and the waves that
+                    //  hide this kernel's three dependent latencies per trip double)
+                    const uint32_t vb = live ? (uint32_t)rowptr[v] : 0u, ve = live ? (uint32_t)rowptr[v + 1] : 0u;
                     const int hl = lane & 31;
                     long long acc = 0ll;
-                    int64_t longest = ve - vb;
+                    uint32_t longest = ve - vb;
                     {
-                        const int64_t o = __shfl_xor(longest, 32);
+                        const uint32_t o = (uint32_t)__shfl_xor((int)longest, 32);
                         longest = o > longest ? o : longest;
                     }
                     // (16-byte loads, four entries a lane: a quarter of the vector-memory instructions of one-entry loads for the
                     //  same bytes -- the rows are what this kernel streams, 8.8 GB per step on the bench graph)
-                    for (int64_t off = 0; off < longest; off += 32 * RS_NB) {     // (uniform trip count over the wave)
+                    for (uint32_t off = 0; off < longest; off += 32 * RS_NB) {     // (uniform trip count over the wave)
                         sp_v4i wv[RS_NB / 4];
 #pragma unroll
                         for (int b = 0; b < RS_NB / 4; ++b) {
-                            const int64_t i = vb + off + b * 128 + 4 * hl;
-                            wv[b] = __builtin_amdgcn_raw_buffer_load_b128(col_rs, (int)(i < ve ? (uint32_t)(i * 4) : 0xFFFFFFF0u), 0, 0);
+                            const uint32_t i = vb + off + (uint32_t)(b * 128 + 4 * hl);
+                            wv[b] = __builtin_amdgcn_raw_buffer_load_b128(col_rs, (int)(i < ve ? i * 4u : 0xFFFFFFF0u), 0, 0);
                         }
-                        long long add[RS_NB];
+                        // (the weight gathers of a trip in batches of RS_GB: all of a batch's loads issued before any is added)
 #pragma unroll
-                        for (int b = 0; b < RS_NB; ++b) {
-                            const int64_t i = vb + off + (b >> 2) * 128 + 4 * hl + (b & 3);
-                            const int32_t w = wv[b >> 2][b & 3];
-                            const uint32_t x = (uint32_t)(w - wlo);
-                            const bool hit = i < ve && x < (uint32_t)RS_BITS && ((bm[x >> 5] >> (x & 31)) & 1u);
-                            add[b] = hit ? (long long)fixw[w] : 0ll;
+                        for (int h = 0; h < RS_NB / RS_GB; ++h) {
+                            long long add[RS_GB];
+#pragma unroll
+                            for (int bb = 0; bb < RS_GB; ++bb) {
+                                const int b = h * RS_GB + bb;
+                                const uint32_t i = vb + off + (uint32_t)((b >> 2) * 128 + 4 * hl + (b & 3));
+                                const int32_t w = wv[b >> 2][b & 3];
+                                const uint32_t x = (uint32_t)(w - wlo);
+                                const bool hit = i < ve && x < (uint32_t)RS_BITS && ((bm[x >> 5] >> (x & 31)) & 1u);
+                                add[bb] = hit ? (long long)fixw[w] : 0ll;
+                            }
+#pragma unroll
+                            for (int bb = 0; bb < RS_GB; ++bb) acc += add[bb];
                         }
-#pragma unroll
-                        for (int b = 0; b < RS_NB; ++b) acc += add[b];
                     }
 #pragma unroll
                     for (int d = 16; d >= 1; d >>= 1) acc += __shfl_xor(acc, d);
@@ -1541,6 +1577,56 @@ extern "C" int eps_scan_screen_weights(const int64_t *fixw, int64_t n, int32_t s
     return EPS_OK;
 }
 
+// ---- the per-column pack (r06) ---------------------------------------------------------------------------------------------
+// pack[e] for stored entry e = (v, j) of the scanned graph, CSR order (two uint4): what a single-round column's set-up wants of its
+// j-th neighbour w -- id, first entry, screening weight (row record words 16, 17), the reverse position, and the cuts of row w at
+// the ends of column v's first nine pieces (row record words 0..15, indexed by the plan's k1 - 1).  One wave per column.
+__global__ __launch_bounds__(256) void sp_pack_kernel(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+                                                      const int32_t *__restrict__ revpos, const uint32_t *__restrict__ rowrec,
+                                                      const uint32_t *__restrict__ pptr, const uint4 *__restrict__ plan, int64_t n_nodes,
+                                                      uint4 *__restrict__ pack)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t v = wave; v < n_nodes; v += n_waves) {
+        const int64_t vb = rowptr[v], ve = rowptr[v + 1];
+        const uint32_t pb = pptr[v];
+        const int np = (int)(pptr[v + 1] - pb);
+        int k1 = 1;
+        if (lane < np && lane < 9) k1 = (int)((plan[pb + (uint32_t)lane].y >> 8) & 0xFFu);
+        int kk[9];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) kk[i] = __shfl(k1, i);
+        for (int64_t e = vb + lane; e < ve; e += 64) {
+            const uint32_t w = (uint32_t)col[e];
+            const uint32_t *__restrict__ rr = rowrec + (size_t)w * 32;
+            const uint16_t *__restrict__ cc = (const uint16_t *)rr;
+            uint32_t c[9];
+#pragma unroll
+            for (int i = 0; i < 9; ++i) c[i] = i < np ? (uint32_t)cc[kk[i] - 1] : 0u;
+            pack[2 * e] = make_uint4(w, rr[16], rr[17], ((uint32_t)revpos[e] & 0xFFFFu) | (c[0] << 16));
+            pack[2 * e + 1] = make_uint4(c[1] | (c[2] << 16), c[3] | (c[4] << 16), c[5] | (c[6] << 16), c[7] | (c[8] << 16));
+        }
+    }
+}
+
+extern "C" int eps_scan_column_pack(const int64_t *rowptr, const int32_t *col, const int32_t *revpos, const uint32_t *rowrec,
+                                    const uint32_t *pptr, const uint32_t *plan, int64_t n_nodes, uint32_t *pack, void *stream)
+{
+    EPS_REQUIRE(n_nodes >= 0, "eps_scan_column_pack: negative size");
+    if (n_nodes == 0) return EPS_OK;
+    EPS_REQUIRE(rowptr && col && revpos && rowrec && pptr && plan && pack, "eps_scan_column_pack: null pointer");
+    EPS_REQUIRE(((uintptr_t)plan & 15) == 0 && ((uintptr_t)pack & 15) == 0 && ((uintptr_t)rowrec & 127) == 0,
+                "eps_scan_column_pack: misaligned table");
+    int64_t blocks = (n_nodes + 3) / 4;
+    const int64_t cap = (int64_t)eps_num_cus() * 16;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(sp_pack_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, rowptr, col, revpos, rowrec, pptr,
+                       (const uint4 *)plan, n_nodes, (uint4 *)pack);
+    EPS_CHECK_LAUNCH("eps_scan_column_pack");
+    return EPS_OK;
+}
+
 // ---- launch -------------------------------------------------------------------------------------------------------------
 // variant: 0 = 512 threads, 8192-slot table (two workgroups per CU); 1 = 1024 threads, 16384 slots (one per CU);
 //          2 = 256 threads, 4096 slots (four per CU).  Also measured (27.8 ms for variant 2 at the time): 256 threads / 8192 slots
@@ -1549,25 +1635,27 @@ extern "C" int eps_scan_screen_weights(const int64_t *fixw, int64_t n, int32_t s
 //          registers, 16 spilled) with the 4096-slot table: 21.8 ms against 17.9.
 static int sp_launch(const int64_t *rowptr, const int32_t *col, const float *val, const int32_t *revpos, const uint32_t *fx32,
                      const float *node_w, const uint16_t *cuts, const uint32_t *wpaths, const uint32_t *ssum, const uint32_t *smax,
-                     const uint32_t *pptr, const uint32_t *plan, const uint32_t *heads, const uint32_t *rowrec, const int32_t *bounds,
-                     int64_t n_nodes, int64_t nnz, const int32_t *columns, const uint32_t *colrec, int64_t n_columns, int64_t batch_from,
+                     const uint32_t *pptr, const uint32_t *plan, const uint32_t *heads, const uint32_t *rowrec, const uint32_t *pack,
+                     const int32_t *bounds, int64_t n_nodes, int64_t nnz, const int32_t *columns, const uint32_t *colrec, int64_t n_columns, int64_t batch_from,
                      int32_t shift, int32_t variant, eps_survivors *out, uint32_t *status, void *stream);
 
 extern "C" int eps_scan_screen(const int64_t *rowptr, const int32_t *col, const int32_t *revpos, const uint32_t *fx32,
                                const uint16_t *cuts, const uint32_t *wpaths, const uint32_t *ssum_or_null,
                                const uint32_t *smax_or_null, const uint32_t *pptr_or_null, const uint32_t *plan_or_null,
-                               const uint32_t *heads_or_null, const uint32_t *rowrec_or_null, const int32_t *bounds, int64_t n_nodes,
-                               int64_t nnz,
+                               const uint32_t *heads_or_null, const uint32_t *rowrec_or_null, const uint32_t *pack_or_null,
+                               const int32_t *bounds, int64_t n_nodes, int64_t nnz,
                                const int32_t *columns, const uint32_t *colrec_or_null, int64_t n_columns, int64_t batch_from, int32_t shift,
                                int32_t variant,
                                eps_survivors *out, uint32_t *status, void *stream)
 {
+    EPS_REQUIRE(!pack_or_null || (plan_or_null && rowrec_or_null && ((uintptr_t)pack_or_null & 15) == 0),
+                "eps_scan_screen: the column pack comes with the plan table and the row records it was built from, 16-byte aligned");
     EPS_REQUIRE(n_columns == 0 || n_nodes == 0 || fx32, "eps_scan_screen: null pointer");
     EPS_REQUIRE((ssum_or_null == nullptr) == (smax_or_null == nullptr), "eps_scan_screen: ssum and smax come together");
     EPS_REQUIRE(!heads_or_null || plan_or_null, "eps_scan_screen: a head table comes with the plan table built for it");
     return sp_launch(rowptr, col, nullptr, revpos, fx32, nullptr, cuts, wpaths, ssum_or_null, smax_or_null, pptr_or_null,
-                     plan_or_null, heads_or_null, rowrec_or_null, bounds, n_nodes, nnz, columns, colrec_or_null, n_columns, batch_from, shift,
-                     variant, out, status, stream);
+                     plan_or_null, heads_or_null, rowrec_or_null, pack_or_null, bounds, n_nodes, nnz, columns, colrec_or_null, n_columns,
+                     batch_from, shift, variant, out, status, stream);
 }
 
 // The same scan on a SYMMETRIC adjacency with stored values (val[e] == val[mirror of e]); node_w = the float node weights.
@@ -1578,8 +1666,8 @@ extern "C" int eps_scan_screen_weighted(const int64_t *rowptr, const int32_t *co
                                         void *stream)
 {
     EPS_REQUIRE(n_columns == 0 || n_nodes == 0 || (val && node_w), "eps_scan_screen_weighted: null pointer");
-    return sp_launch(rowptr, col, val, revpos, nullptr, node_w, cuts, wpaths, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, bounds,
-                     n_nodes, nnz, columns, nullptr, n_columns, n_columns, shift, variant, out, status, stream);
+    return sp_launch(rowptr, col, val, revpos, nullptr, node_w, cuts, wpaths, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                     bounds, n_nodes, nnz, columns, nullptr, n_columns, n_columns, shift, variant, out, status, stream);
 }
 
 static const int sp_threads_of[3] = {512, 1024, 256}, sp_bits_of[3] = {13, 14, 12}, sp_per_cu[3] = {2, 1, 4};
@@ -1724,8 +1812,8 @@ extern "C" int eps_scan_plan_rewalk(const uint32_t *plan, int64_t n_rec, int32_t
 
 static int sp_launch(const int64_t *rowptr, const int32_t *col, const float *val, const int32_t *revpos, const uint32_t *fx32,
                      const float *node_w, const uint16_t *cuts, const uint32_t *wpaths, const uint32_t *ssum, const uint32_t *smax,
-                     const uint32_t *pptr, const uint32_t *plan, const uint32_t *heads, const uint32_t *rowrec, const int32_t *bounds,
-                     int64_t n_nodes, int64_t nnz, const int32_t *columns, const uint32_t *colrec, int64_t n_columns, int64_t batch_from,
+                     const uint32_t *pptr, const uint32_t *plan, const uint32_t *heads, const uint32_t *rowrec, const uint32_t *pack,
+                     const int32_t *bounds, int64_t n_nodes, int64_t nnz, const int32_t *columns, const uint32_t *colrec, int64_t n_columns, int64_t batch_from,
                      int32_t shift, int32_t variant, eps_survivors *out, uint32_t *status, void *stream)
 {
     EPS_REQUIRE(n_nodes >= 0 && n_columns >= 0 && nnz >= 0, "eps_scan_screen: negative size");
@@ -1764,6 +1852,7 @@ static int sp_launch(const int64_t *rowptr, const int32_t *col, const float *val
     p.plan = (const uint4 *)plan;
     p.heads = (const uint2 *)heads;
     p.rowrec = rowrec;
+    p.pack = (const uint4 *)pack;
     p.colrec = (const uint4 *)colrec;
     p.columns = columns;
     p.n_columns = (int32_t)n_columns;
@@ -1777,8 +1866,16 @@ static int sp_launch(const int64_t *rowptr, const int32_t *col, const float *val
     if (blocks > n_columns) blocks = n_columns;
     const size_t lds = ((size_t)(2 << bits) + 4 * (size_t)(T + 1) + 8) * 4 + (SP_UBITS / 32) * 6 + 32;
     void (*kern)(sp_params) =
-        val ? (variant == 0 ? scan_piece_kernel<512, true> : variant == 1 ? scan_piece_kernel<1024, true> : scan_piece_kernel<256, true>)
-            : (variant == 0 ? scan_piece_kernel<512, false> : variant == 1 ? scan_piece_kernel<1024, false> : scan_piece_kernel<256, false>);
+        val ? (variant == 0 ? scan_piece_kernel<512, true, false, false> : variant == 1 ? scan_piece_kernel<1024, true, false, false>
+                                                                                       : scan_piece_kernel<256, true, false, false>)
+            : (variant == 0 ? scan_piece_kernel<512, false, false, false> : variant == 1 ? scan_piece_kernel<1024, false, false, false>
+                                                                                         : scan_piece_kernel<256, false, false, false>);
+    // (the step's main launch: every table present -> the body compiled for exactly that; with the column pack, its set-up as well)
+    // (EPS_SCAN_GENERIC=1 in the environment keeps the generic body for same-box A/Bs: tools/r05_heads_ab.py)
+    static const bool generic_only = [] { const char *e = getenv("EPS_SCAN_GENERIC"); return e && e[0] == '1'; }();
+    const bool full = !generic_only && !val && variant == 2 && plan && colrec && rowrec && heads && ssum;
+    EPS_REQUIRE(!pack || full || generic_only, "eps_scan_screen: the column pack serves the main launch only (variant 2, plan, records, heads, sum bounds)");
+    if (full) kern = pack ? scan_piece_kernel<256, false, true, true> : scan_piece_kernel<256, false, true, false>;
     if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
         eps_set_error("eps_scan_screen: cannot reserve %zu bytes of LDS", lds);
         return EPS_ELAUNCH;

@@ -67,9 +67,8 @@ struct ts_sort_state {          // per (device, stream); zero at allocation, lef
     uint32_t arrive;            // grid hand-over counter (monotone inside a launch)
     uint32_t leave;
     unsigned long long runs;    // runs of equal (v block, u) of the by-u order
-    uint32_t skip[TS_MAXPASS];  // pass p is trivial (one digit holds every record): skip[p] = 1
-    uint32_t totals[256];       // digit totals of the current pass
-    uint32_t hist[TS_MAXG][256];
+    uint32_t totals[TS_MAXPASS][256];   // digit totals of every pass (they do not depend on the order: counted once, up front)
+    uint32_t hist[TS_MAXG][256];        // a pass's digit counts per workgroup, each word tagged with the pass: (pass + 1) << 24 | count
 };
 
 extern "C" int64_t eps_tail_state_bytes(void)
@@ -369,6 +368,8 @@ __global__ __launch_bounds__(TS_T) void ts_sort_kernel(ts_sort_params p)
     __shared__ uint32_t s_off[256];             // running output position per digit of this workgroup
     __shared__ uint32_t s_hist[256];
     __shared__ uint32_t s_scan[TS_T];
+    __shared__ uint32_t s_tot[TS_MAXPASS][256];
+    __shared__ uint32_t s_last;
     const int tid = threadIdx.x, lane = tid & 63, wib = tid >> 6;
     const unsigned G = gridDim.x, b = blockIdx.x;
     ts_sort_state *st = p.st;
@@ -387,31 +388,55 @@ __global__ __launch_bounds__(TS_T) void ts_sort_kernel(ts_sort_params p)
     const int64_t lo = (int64_t)b * per < n ? (int64_t)b * per : n;
     const int64_t hi = lo + per < n ? lo + per : n;
 
-    // ---- phase 0: the input transform fills buffer 0 ---------------------------------------------------------------------
-    for (int64_t i = lo + tid; i < hi; i += TS_T) {
-        if (!rows) {
-            const uint64_t k = (uint64_t)p.in_keys[i];                // v << 32 | u  ->  u << 32 | v
-            p.buf_k[0][i] = (k << 32) | (k >> 32);
-        } else {
-            const int64_t j = i < n_in ? i : i - n_in;
-            const uint64_t k = (uint64_t)p.in_keys[j];
-            uint64_t a = k & 0xFFFFFFFFull, c = k >> 32;
-            if (p.perm) {      // ids of a relabelled graph back to the caller's; the larger one is "v" again
-                a = (uint64_t)p.perm[a];
-                c = (uint64_t)p.perm[c];
+    // ---- phase 0: the input transform fills buffer 0, and every pass's digit totals are counted (they do not depend on the
+    // order of the records: once, here, instead of a grid-wide exchange per pass) ---------------------------------------------
+    for (int i = tid; i < p.n_pass * 256; i += TS_T) (&s_tot[0][0])[i] = 0u;
+    __syncthreads();
+    for (int64_t i0 = lo + (tid & ~63); i0 < hi; i0 += TS_T) {
+        const int64_t i = i0 + lane;
+        const bool live = i < hi;
+        uint64_t key = 0ull;
+        uint32_t val = 0u;
+        if (live) {
+            if (!rows) {
+                const uint64_t k = (uint64_t)p.in_keys[i];                // v << 32 | u  ->  u << 32 | v
+                key = (k << 32) | (k >> 32);
+                p.buf_k[0][i] = key;
+            } else {
+                const int64_t j = i < n_in ? i : i - n_in;
+                const uint64_t k = (uint64_t)p.in_keys[j];
+                uint64_t a = k & 0xFFFFFFFFull, c = k >> 32;
+                if (p.perm) {      // ids of a relabelled graph back to the caller's; the larger one is "v" again
+                    a = (uint64_t)p.perm[a];
+                    c = (uint64_t)p.perm[c];
+                }
+                const uint64_t small = a < c ? a : c, large = a < c ? c : a;
+                // row of proposal (u, v) sorts by (v, u): the direct row has v = large, the mirrored one v = small
+                const uint64_t vv = i < n_in ? large : small, uu = i < n_in ? small : large;
+                key = (vv << p.id_bits) | uu;
+                val = ~ts_ordered(p.in_vals[j]);                          // ascending in this = descending in the score
+                p.buf_k[0][i] = key;
+                p.buf_v[0][i] = val;
             }
-            const uint64_t small = a < c ? a : c, large = a < c ? c : a;
-            // row of proposal (u, v) sorts by (v, u): the direct row has v = large, the mirrored one v = small
-            const uint64_t vv = i < n_in ? large : small, uu = i < n_in ? small : large;
-            p.buf_k[0][i] = (vv << p.id_bits) | uu;
-            p.buf_v[0][i] = ~ts_ordered(p.in_vals[j]);                // ascending in this = descending in the score
         }
+        for (int ip = 0; ip < p.n_pass; ++ip) {
+            const uint32_t d = ts_digit(p.pass[ip], key, val);
+            const unsigned long long peers = ts_match8(d, live);
+            if (live && (peers & ((1ull << lane) - 1ull)) == 0ull) atomicAdd(&s_tot[ip][d], (uint32_t)__popcll(peers));
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < p.n_pass * 256; i += TS_T) {
+        const uint32_t c = (&s_tot[0][0])[i];
+        if (c) atomicAdd(&(&st->totals[0][0])[i], c);
     }
     int cur = 0;
     bool blocked = false;
     bool decided = false;
     epoch += 1;
     ts_grid_sync(&st->arrive, epoch * G);
+    for (int i = tid; i < p.n_pass * 256; i += TS_T) (&s_tot[0][0])[i] = __atomic_load_n(&(&st->totals[0][0])[i], __ATOMIC_RELAXED);
+    __syncthreads();
 
     for (int ip = 0; ip < p.n_pass; ++ip) {
         const ts_pass ps = p.pass[ip];
@@ -432,11 +457,22 @@ __global__ __launch_bounds__(TS_T) void ts_sort_kernel(ts_sort_params p)
             decided = true;
         }
         if (ps.blocked && !blocked) continue;                  // (uniform over the grid)
+        // a pass whose digit is the same for every record is the identity: skipped (the same totals for everyone: uniform)
+        {
+            if (tid == 0) s_last = 0u;
+            __syncthreads();
+            if (tid < 256 && n > 0 && (int64_t)s_tot[ip][tid] == n) s_last = 1u;
+            __syncthreads();
+            const bool trivial = s_last != 0u;
+            __syncthreads();
+            if (trivial) continue;
+        }
         const uint64_t *src_k = p.buf_k[cur];
         const uint32_t *src_v = has_val ? p.buf_v[cur] : nullptr;
-        // ---- A: digit histogram of this workgroup's chunk -----------------------------------------------------------------
+        // ---- A: digit histogram of this workgroup's chunk, published with the pass's tag ---------------------------------------
         if (tid < 256) s_hist[tid] = 0u;
         __syncthreads();
+#ifndef TS_ABL_NOHIST
         for (int64_t i0 = lo + (tid & ~63); i0 < hi; i0 += TS_T) {
             const int64_t i = i0 + lane;
             const bool live = i < hi;
@@ -446,35 +482,27 @@ __global__ __launch_bounds__(TS_T) void ts_sort_kernel(ts_sort_params p)
             const unsigned long long peers = ts_match8(d, live);
             if (live && (peers & ((1ull << lane) - 1ull)) == 0ull) atomicAdd(&s_hist[d], (uint32_t)__popcll(peers));
         }
+#endif
         __syncthreads();
-        if (tid < 256) st->hist[b][tid] = s_hist[tid];
-        epoch += 1;
-        ts_grid_sync(&st->arrive, epoch * G);
-        // ---- B1: workgroup j scans digit columns j, j + G, ... over the workgroups (exclusive, in place) --------------------
-        for (unsigned d = b; d < 256u; d += G) {
-            const uint32_t x = tid < (int)G ? st->hist[tid][d] : 0u;
-            s_scan[tid] = x;
-            __syncthreads();
-            for (int s = 1; s < TS_MAXG; s <<= 1) {
-                const uint32_t add = tid >= s && tid < TS_MAXG ? s_scan[tid - s] : 0u;
-                __syncthreads();
-                if (tid < TS_MAXG) s_scan[tid] += add;
-                __syncthreads();
-            }
-            if (tid < (int)G) st->hist[tid][d] = s_scan[tid] - x;
-            if (tid == 0) {
-                const uint32_t total = s_scan[TS_MAXG - 1];
-                st->totals[d] = total;
-                if (n > 0 && (int64_t)total == n) st->skip[ip] = 1u;         // one digit holds every record: the pass is the identity
-            }
-            __syncthreads();
-        }
-        epoch += 1;
-        ts_grid_sync(&st->arrive, epoch * G);
-        if (__atomic_load_n(&st->skip[ip], __ATOMIC_RELAXED)) continue;       // (uniform: the same word for everyone)
-        // ---- B2: this workgroup's first output position per digit ----------------------------------------------------------
+        const uint32_t tag = (uint32_t)(ip + 1) << 24;
+        if (tid < 256) __atomic_store_n(&st->hist[b][tid], tag | s_hist[tid], __ATOMIC_RELAXED);
+        // ---- B: this workgroup's first output position per digit = digits below (totals) + the same digit in the workgroups
+        // before this one (their published counts: four threads per digit, each a quarter of the predecessors, spinning on the tag)
         {
-            const uint32_t x = tid < 256 ? st->totals[tid] : 0u;
+            const int d = tid & 255, q = tid >> 8;
+            uint32_t sum = 0u;
+            for (unsigned bb = (unsigned)q; bb < b; bb += 4u) {
+                uint32_t w;
+                do {
+                    w = __atomic_load_n(&st->hist[bb][d], __ATOMIC_RELAXED);
+                } while ((w & 0xFF000000u) != tag);
+                sum += w & 0x00FFFFFFu;
+            }
+            s_scan[tid] = sum;
+            __syncthreads();
+            const uint32_t x = tid < 256 ? s_tot[ip][tid] : 0u;
+            const uint32_t before = tid < 256 ? s_scan[tid] + s_scan[tid + 256] + s_scan[tid + 512] + s_scan[tid + 768] : 0u;
+            __syncthreads();
             s_scan[tid] = x;
             __syncthreads();
             for (int s = 1; s < 256; s <<= 1) {
@@ -483,12 +511,13 @@ __global__ __launch_bounds__(TS_T) void ts_sort_kernel(ts_sort_params p)
                 if (tid < 256) s_scan[tid] += add;
                 __syncthreads();
             }
-            if (tid < 256) s_off[tid] = s_scan[tid] - x + st->hist[b][tid];
+            if (tid < 256) s_off[tid] = s_scan[tid] - x + before;
             __syncthreads();
         }
         // ---- C: stable ranking + scatter, tile by tile -----------------------------------------------------------------------
         uint64_t *dst_k = p.buf_k[cur ^ 1];
         uint32_t *dst_v = has_val ? p.buf_v[cur ^ 1] : nullptr;
+#ifndef TS_ABL_NOSCATTER
         for (int64_t t0 = lo; t0 < hi; t0 += TS_TILE) {
             for (int i = lane; i < 256; i += 64) s_cnt[wib][i] = 0u;
             uint64_t key[TS_KPT];
@@ -536,6 +565,7 @@ __global__ __launch_bounds__(TS_T) void ts_sort_kernel(ts_sort_params p)
                 }
             __syncthreads();
         }
+#endif
         cur ^= 1;
         epoch += 1;
         ts_grid_sync(&st->arrive, epoch * G);
@@ -559,14 +589,21 @@ __global__ __launch_bounds__(TS_T) void ts_sort_kernel(ts_sort_params p)
             if (b == 0 && tid == 0 && p.n_rows_out) *p.n_rows_out = take;
         }
     }
-    // the last workgroup to leave clears the state (nobody waits on `arrive` any more once everyone has passed the last hand-over)
+    // the last workgroup to leave clears the state (nobody waits on `arrive` or reads a count any more once everyone is past the
+    // last hand-over)
     __syncthreads();
     if (tid == 0) {
         __threadfence();
-        if (atomicAdd(&st->leave, 1u) + 1u == G) {
+        s_last = atomicAdd(&st->leave, 1u) + 1u == G ? 1u : 0u;
+    }
+    __syncthreads();
+    if (s_last) {
+        for (int i = tid; i < TS_MAXPASS * 256; i += TS_T) (&st->totals[0][0])[i] = 0u;
+        for (int i = tid; i < (int)G * 256; i += TS_T) (&st->hist[0][0])[i] = 0u;
+        __syncthreads();
+        if (tid == 0) {
             st->arrive = 0u;
             st->runs = 0ull;
-            for (int i = 0; i < TS_MAXPASS; ++i) st->skip[i] = 0u;
             __threadfence();
             st->leave = 0u;
         }

@@ -662,6 +662,24 @@ def scan_row_records(cuts: torch.Tensor, rowptr: torch.Tensor, fx32: torch.Tenso
     return out
 
 
+def scan_column_pack(rowptr, col, revpos, rowrec: torch.Tensor, plan) -> torch.Tensor:
+    """int32 [nnz, 8]: the per-column pack of eps_scan_screen's main launch (eps_scan_column_pack): per stored entry, in CSR order,
+    what a column's set-up gathers for that neighbour -- id, first entry, weight, reverse position and the cuts of the column's
+    first nine pieces in the neighbour's row.  Built from ``plan`` = (pptr, records) and the row records ``rowrec``."""
+    pptr, recs = plan
+    dev = _need_gpu(rowptr, col, revpos, rowrec, pptr, recs)
+    _chk(rowptr, torch.int64, "rowptr"); _chk(col, torch.int32, "col"); _chk(revpos, torch.int32, "revpos")
+    _chk(rowrec, torch.int32, "rowrec"); _chk(pptr, torch.int32, "pptr"); _chk(recs, torch.int32, "plan")
+    n_nodes = rowptr.numel() - 1
+    if pptr.numel() != n_nodes + 1 or revpos.numel() != col.numel() or rowrec.numel() != n_nodes * 32:
+        raise _lib.EpsError("scan_column_pack: the tables do not match the graph")
+    pack = torch.empty((max(col.numel(), 1), 8), dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.load().eps_scan_column_pack(_ptr(rowptr), _ptr(col), _ptr(revpos), _ptr(rowrec), _ptr(pptr), _ptr(recs), n_nodes,
+                                                    _ptr(pack), _stream(dev)), "eps_scan_column_pack")
+    return pack
+
+
 def scan_heads(rowptr, col, fx32: torch.Tensor, n_hub: int, budget: int, max_rows: int = 65535) -> torch.Tensor:
     """int32-bits [N, 2] (x_v, T_v): per column the longest prefix of its row with ids < ``n_hub`` whose screening weights sum
     to T_v <= ``budget`` (table units) -- the rows eps_scan_screen does not walk under a bar (eps_scan_heads)."""
@@ -817,7 +835,7 @@ def scan_screen(rowptr, col, revpos, fx32, cuts, bounds, n_nodes: int, columns: 
                 node_w: Optional[torch.Tensor] = None, wpaths: Optional[torch.Tensor] = None,
                 ssum: Optional[torch.Tensor] = None, smax: Optional[torch.Tensor] = None, plan=None,
                 heads: Optional[torch.Tensor] = None, batch_from: Optional[int] = None, rowrec: Optional[torch.Tensor] = None,
-                colrec: Optional[torch.Tensor] = None) -> None:
+                colrec: Optional[torch.Tensor] = None, pack: Optional[torch.Tensor] = None) -> None:
     """Launch eps_scan_screen over ``columns``; survivors (screening scores) accumulate in ``out``.  ``val`` / ``node_w``
     (float32 stored values / node weights): the weighted flavour (eps_scan_screen_weighted; ``fx32`` unused).
     ``ssum`` / ``smax`` (int32-bits [N] / [M + 1]; unit-valued graphs): per-node sums of fx32 over the row and their
@@ -827,7 +845,8 @@ def scan_screen(rowptr, col, revpos, fx32, cuts, bounds, n_nodes: int, columns: 
     the walked sums as raw bits -- ``scan_refine`` turns that list into the one a launch without heads reports.
     ``batch_from``: ``columns[batch_from:]`` are handed out eight per draw (light columns at the end of a heaviest-first list).
     ``rowrec`` (``scan_row_records``): per node one 128-byte line with its cuts, first entry and weight.
-    ``colrec`` (int32 [len(columns), 8]; ``scan.column_records``): the columns' headers in hand-out order."""
+    ``colrec`` (int32 [len(columns), 8]; ``scan.column_records``): the columns' headers in hand-out order.
+    ``pack`` (``scan_column_pack``; main launch only): the per-column pack built from this plan table and these row records."""
     pptr, recs = plan if plan is not None else (None, None)
     dev = _need_gpu(rowptr, col, revpos, fx32, cuts, bounds, columns, status, val, node_w, wpaths, ssum, smax, pptr, recs, heads)
     _chk_heads(heads, n_nodes)
@@ -858,7 +877,7 @@ def scan_screen(rowptr, col, revpos, fx32, cuts, bounds, n_nodes: int, columns: 
             ev[0].record(torch.cuda.current_stream(dev))
         if val is None:
             _lib.check(lib.eps_scan_screen(_ptr(rowptr), _ptr(col), _ptr(revpos), _ptr(fx32), _ptr(cuts), _ptr(wpaths), _ptr(ssum),
-                                           _ptr(smax), _ptr(pptr), _ptr(recs), _ptr(heads), _ptr(rowrec), _ptr(bounds), n_nodes,
+                                           _ptr(smax), _ptr(pptr), _ptr(recs), _ptr(heads), _ptr(rowrec), _ptr(pack), _ptr(bounds), n_nodes,
                                            col.numel(), _ptr(columns), _ptr(colrec), columns.numel(), -1 if batch_from is None else int(batch_from),
                                            int(shift), variant, _ptr(out.rec), _ptr(status), _stream(dev)), "eps_scan_screen")
         else:

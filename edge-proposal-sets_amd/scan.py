@@ -368,11 +368,12 @@ def screen_weights(g0: CSRGraph, g: CSRGraph, perm, node_w: torch.Tensor) -> Scr
 class HeadTables:
     """What a launch with skipped heads brings (one set per budget): the head table, the window paths and the plan of the rows
     that are still walked, and that plan's dropped weight bits."""
-    __slots__ = ("budget", "heads", "wpaths", "plan", "d_used", "live", "n_hub")
+    __slots__ = ("budget", "heads", "wpaths", "plan", "d_used", "live", "n_hub", "pack")
 
     def __init__(self, budget, heads, wpaths, plan, d_used, n_hub=0):
         self.budget, self.heads, self.wpaths, self.plan, self.d_used = budget, heads, wpaths, plan, d_used
         self.n_hub = n_hub           # hub rows the heads were cut from (a graph's second scan widens the table: rebuilt then)
+        self.pack = None             # ops.scan_column_pack of this plan (see column_pack)
         self.live = {}               # (rank, world) -> this rank's columns without the DEAD ones (see live_columns)
 
 
@@ -471,6 +472,20 @@ def column_records(g: CSRGraph, screen: Screen, columns: torch.Tensor, plan, hea
     return cache[key]
 
 
+COLUMN_PACK = True            # the main launch sets a column up from ONE stream of 32-byte records (ops.scan_column_pack) -- from a
+                              # graph's second scan on: 32 B per stored entry (1.4 GB on the ppa-like graph, 1.5 ms to build per head
+                              # table) is not what a one-shot filter.py run should pay
+
+
+def column_pack(g: CSRGraph, screen: Screen, ht: HeadTables) -> Optional[torch.Tensor]:
+    """The per-column pack of the head table's plan (cached on it), or None: not for a graph's first scan, not without row records."""
+    if not COLUMN_PACK or screen.rowrec is None or g._cache.get("scan_calls", 0) < 2:
+        return None
+    if ht.pack is None:
+        ht.pack = ops.scan_column_pack(g.rowptr, g.col, reverse_positions(g), screen.rowrec, ht.plan)
+    return ht.pack
+
+
 def _heads_for(g: CSRGraph, screen: Screen, bar) -> Optional[HeadTables]:
     """The head tables for a launch under ``bar`` (1-element device tensor): the set the last launch used, without looking at the
     bar -- the kernel itself refuses a head as heavy as the bar (status bit 2), and scan_topk compares budget and bar after
@@ -549,7 +564,8 @@ def _launch(g, fixw, columns, threshold, capacity, scores_only: bool = False, bo
             ops.scan_screen(g.rowptr, g.col, reverse_positions(g), screen.fx32, cuts, bounds, g.n_rows, columns, screen.shift, walked,
                             out.status, screen_variant(g), None, None, heads.wpaths, screen.ssum, screen.smax, heads.plan, heads.heads,
                             batch_from(g, columns), screen.rowrec,
-                            column_records(g, screen, columns, heads.plan, heads.heads, heads.live, ("colrec", columns.data_ptr(), columns.numel())))
+                            column_records(g, screen, columns, heads.plan, heads.heads, heads.live, ("colrec", columns.data_ptr(), columns.numel())),
+                            column_pack(g, screen, heads) if variant_is_main(g, screen) else None)
             ops.scan_refine(walked, heads.heads, hub_rows(g), screen.fx32, g.rowptr, g.col, g.n_rows, screen.shift, out)
             out.rec[4:5].copy_(walked.rec[4:5])              # (candidates the walk touched)
             out.walked_slots = walked.rec[1:2]
@@ -561,6 +577,12 @@ def _launch(g, fixw, columns, threshold, capacity, scores_only: bool = False, bo
         else:
             ops.filter_scan(g.rowptr, g.col, reverse_positions(g), fixw, g.n_rows, columns, out, max_degree(g), window_splits(g))
     return out
+
+
+def variant_is_main(g: CSRGraph, screen: Screen) -> bool:
+    """The launch is the one the specialised body serves (csrc/scan_pieces.hip FULL): 256-thread geometry, plan, records, sum bounds."""
+    return bool(screen_variant(g) == 2 and screen.plan is not None and screen.rowrec is not None and screen.ssum is not None
+                and COLUMN_RECORDS)
 
 
 def batch_from(g: CSRGraph, columns: torch.Tensor) -> int:
@@ -737,7 +759,10 @@ def select_topk_torch(keys: torch.Tensor, vals: torch.Tensor, k: int) -> Tuple[t
     return keys[o], vals[o]
 
 
-TAIL_DEVICE = True           # one rank, under a bar: the step's tail runs on the device with device-side sizes (csrc/tail_sort.hip)
+TAIL_DEVICE = True           # one rank, under a bar: the step's selections come from score-bucket histograms (csrc/tail_sort.hip)
+TAIL_SORT = "library"        # ... and its two orderings from the library sorts ("library": sizes from the host, two host reads per step) or
+                             # from the one-launch cooperative radix sorts with device-side sizes ("radix": one host read, but slower on
+                             # MI355X -- see scan_topk)
 EXACT_SCREENING = True       # uniform weights whose screening sums are exact skip the re-scoring (Screen.exact; tests switch it off to compare)
 RESCORE_V_BLOCK = 12         # the survivors are re-scored in blocks of 2^12 consecutive v (then u, then v): the workgroups that run side
                              # by side stream the rows of one block of v out of the L2.  r04 (one hand-out counter): 2^8 3.32, 2^10 2.78,
@@ -940,7 +965,35 @@ def scan_topk(g: CSRGraph, node_w: torch.Tensor, k: int, rank: int = 0, world: i
             a, b = screen.lower_params(max_degree(g), None if ht is None else ht.d_used)
             bits = max(1, min(32, int(g.n_rows - 1).bit_length()))
             room = min(res.capacity, 2 * k2 + (1 << 16))
-            while True:
+            while TAIL_SORT == "library":
+                # The selections from score-bucket histograms (two launches each instead of a four-round cooperative select), the two
+                # orderings by the library sorts: those take their sizes from the host, so the pre-filter's count is read back (the
+                # second host read of the step is the status vector below).  Measured faster than the one-launch cooperative radix sorts
+                # of TAIL_SORT = "radix" on MI355X: a grid-wide hand-over inside a kernel costs ~50 us there, a kernel boundary ~10
+                # (profiles/r06/sort_probe.txt).
+                ops.score_hist(res.key, res.val, res.count_ptr, bar)
+                c_keys, c_vals, n_valid, _, pre_thr = ops.score_pick_compact(res.key, res.val, res.count_ptr, bar, k2, mode=2,
+                                                                             params=(a, b, 4e-6), room=room, want_vals=screen.exact)
+                nv = int(n_valid.item())                                                         # (one word: sizes the sorts)
+                if nv > room:
+                    room = min(res.capacity, nv)
+                    continue
+                if screen.exact:
+                    x_keys, x_vals, swap = c_keys[:nv], c_vals[:nv], False
+                else:
+                    x_keys = ops.sort_pairs_by_u(c_keys[:nv], bits, RESCORE_V_BLOCK)              # (u << 32 | v): runs of equal u
+                    x_vals = ops.rescore_runs(g.rowptr, g.col, screen.fixw, g.n_rows, x_keys)
+                    swap = True
+                ops.score_hist(x_keys, x_vals, None, bar, above=bar)
+                sel_k, sel_v, n_sel, cut, _ = ops.score_pick_compact(x_keys, x_vals, None, bar, k2, above=bar, swap_halves=swap, room=max(nv, 1))
+                zero = torch.zeros(1, dtype=torch.int64, device=dev)
+                st = torch.cat([res.rec[1:2], res.rec[4:5], n_sel, cut.view(torch.int32).to(torch.int64), res.status.to(torch.int64),
+                                pre_thr.view(torch.int32).to(torch.int64), res.walked_slots if res.walked_slots is not None else zero,
+                                bar.view(torch.int32).to(torch.int64) if ht is not None else zero])
+                table = [st.tolist()]                                                            # the host read of the step
+                n_rescored = 0 if screen.exact else nv
+                break
+            while TAIL_SORT != "library":
                 ops.score_hist(res.key, res.val, res.count_ptr, bar)
                 c_keys, c_vals, n_valid, _, pre_thr = ops.score_pick_compact(res.key, res.val, res.count_ptr, bar, k2, mode=2,
                                                                              params=(a, b, 4e-6), room=room, want_vals=screen.exact)
@@ -960,11 +1013,11 @@ def scan_topk(g: CSRGraph, node_w: torch.Tensor, k: int, rank: int = 0, world: i
                 row = st.tolist()                                                                # the host read of the step
                 nv = row[8]
                 if nv <= room:
+                    table = [row[:8]]
+                    n_rescored = 0 if screen.exact else nv
+                    rows = (r_pairs, r_scores, row[9])
                     break
                 room = min(res.capacity, nv)        # (a level of tied scores at the pre-filter threshold holds more than the room: once more)
-            table = [row[:8]]
-            n_rescored = 0 if screen.exact else nv
-            rows = (r_pairs, r_scores, row[9])
         elif screen is not None:
             # the one-pass kernel screens with upper bounds: its survivors are re-scored exactly (those that do not exceed the
             # bar after all drop out), so from here on the list holds eps_filter_scan's scores bit for bit.

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define EPS_ABI_VERSION 7   /* 7: the tail of the filter step with device-side sizes -- eps_score_hist / _pick_compact, eps_radix_sort_by_u / _rows, eps_rescore_runs_dev (r06); 6: skipped heads -- eps_scan_heads / _hub_rows / _refine; eps_scan_window_paths / _plan / _screen take a head table (r05); 2: eps_col_sums / eps_node_weights_f64 signatures (r02); 3: 64-bit survivor count, eps_scan_* (r03); 4: eps_scan_screen takes ssum / smax; 5: eps_select_compact, eps_scan_screen marks unused slots itself (r04) */
+#define EPS_ABI_VERSION 7   /* 7: the tail of the filter step with device-side sizes -- eps_score_hist / _pick_compact, eps_radix_sort_by_u / _rows, eps_rescore_runs_dev; eps_scan_screen takes a column pack, eps_scan_column_pack (r06); 6: skipped heads -- eps_scan_heads / _hub_rows / _refine; eps_scan_window_paths / _plan / _screen take a head table (r05); 2: eps_col_sums / eps_node_weights_f64 signatures (r02); 3: 64-bit survivor count, eps_scan_* (r03); 4: eps_scan_screen takes ssum / smax; 5: eps_select_compact, eps_scan_screen marks unused slots itself (r04) */
 
 #define EPS_OK 0
 #define EPS_EINVAL (-1)   /* bad argument (null pointer, negative size, unsupported shape) */
@@ -292,9 +292,17 @@ int eps_scan_window_paths(const int64_t *rowptr, const int32_t *col, const int32
 int eps_scan_screen(const int64_t *rowptr, const int32_t *col, const int32_t *revpos, const uint32_t *fx32,
                     const uint16_t *cuts, const uint32_t *wpaths, const uint32_t *ssum_or_null,
                     const uint32_t *smax_or_null, const uint32_t *pptr_or_null, const uint32_t *plan_or_null,
-                    const uint32_t *heads_or_null, const uint32_t *rowrec_or_null, const int32_t *bounds, int64_t n_nodes, int64_t nnz,
+                    const uint32_t *heads_or_null, const uint32_t *rowrec_or_null, const uint32_t *pack_or_null, const int32_t *bounds,
+                    int64_t n_nodes, int64_t nnz,
                     const int32_t *columns, const uint32_t *colrec_or_null, int64_t n_columns, int64_t batch_from, int32_t shift,
                     int32_t variant, eps_survivors *out, uint32_t *status, void *stream);
+/* pack (optional, r06; the main launch only: variant 2 with plan table, row / column records, heads and sum bounds; 16-byte
+ * aligned): eps_scan_column_pack's table -- 32 bytes per stored entry (v, j) in CSR order: {col, rowptr[col] (low word), fx32[col],
+ * revpos | cut of column v's FIRST piece in row col << 16} {the cuts of v's pieces 1..8 in that row, 16 bits each}.  A column of
+ * at most 256 rows then sets up from ONE contiguous stream (a 16-byte load per row) instead of neighbour ids -> one 128-byte
+ * row-record line per neighbour.  Built per (graph, weights, plan table): filter.py:96-142 reads no such table -- it is the scan's. */
+int eps_scan_column_pack(const int64_t *rowptr, const int32_t *col, const int32_t *revpos, const uint32_t *rowrec, const uint32_t *pptr,
+                         const uint32_t *plan, int64_t n_nodes, uint32_t *pack, void *stream);
 /* colrec (optional; needs the plan table; 16-byte aligned): 8 words per entry of `columns`, in the same order -- {v, rowptr[v] (low
  * word), degree, heads[2 v], heads[2 v + 1], ssum[v], pptr[v], pptr[v + 1] - pptr[v]} (zeros where a table is absent) -- what a
  * column's set-up otherwise reads through a chain id -> five tables, as ONE 32-byte load at the hand-out index.  The caller builds

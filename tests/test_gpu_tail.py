@@ -84,6 +84,10 @@ def test_radix_sort_by_u_matches_library_sort(eps, dev, n, id_bits, shift):
         want = eps.ops.sort_pairs_by_u(keys, id_bits, shift)
         n_dev = torch.tensor([m], dtype=torch.int64, device=dev)
         got = eps.ops.radix_sort_by_u(keys, n_dev, id_bits, shift)
+        if shift == 0:          # (u < 2^31: the swapped key is a non-negative int64 whose order is (u, v unsigned))
+            ref = torch.sort(((keys & 0xFFFFFFFF) << 32) | ((keys >> 32) & 0xFFFFFFFF)).values
+            assert torch.equal(got, ref), "radix sort differs from torch.sort"
+            assert torch.equal(want, ref), "library sort differs from torch.sort"
         assert torch.equal(got, want)
         # a device count shorter than the array
         part = max(1, m - m // 3)
@@ -145,8 +149,8 @@ def test_rescore_with_a_device_count(eps, dev):
 
 @pytest.mark.parametrize("kind", ["aa", "ra", "cn"])
 def test_scan_topk_device_tail_is_bit_identical(eps, dev, kind, monkeypatch):
-    """scan_topk with the device tail == scan_topk on the r05 tail (four-round selects, library sorts, two host reads): the same
-    rows and scores, as labelled and under hubs-first labels with skipped heads, incl. a K whose cut level is heavily tied (CN)."""
+    """scan_topk with the r06 tail -- score-bucket selections with the library sorts ("library", the default) or with the one-launch
+    cooperative radix sorts and device-side sizes ("radix") -- == scan_topk on the r05 tail (four-round selects): the same rows and scores, as labelled and under hubs-first labels with skipped heads, incl. a K whose cut level is heavily tied (CN)."""
     from eps_amd import scan, synth
     from eps_amd.heuristics import node_weight_table
     g = synth.rmat_graph(15, 14, 7, dev)
@@ -158,11 +162,13 @@ def test_scan_topk_device_tail_is_bit_identical(eps, dev, kind, monkeypatch):
     for relabel in (False, True):
         for k in (1, 5000, 200_001):
             out = {}
-            for tail in (False, True):
-                monkeypatch.setattr(scan, "TAIL_DEVICE", tail)
+            for tail in (None, "library", "radix"):
+                monkeypatch.setattr(scan, "TAIL_DEVICE", tail is not None)
+                monkeypatch.setattr(scan, "TAIL_SORT", tail or "library")
                 st = {}
                 pairs, scores = scan.scan_topk(g, wt, k, relabel=relabel, stats=st)
                 out[tail] = (pairs, scores, st)
-            assert torch.equal(out[True][0], out[False][0]) and torch.equal(out[True][1], out[False][1]), (kind, relabel, k)
-            assert out[True][2]["candidates"] == out[False][2]["candidates"]
+            for tail in ("library", "radix"):
+                assert torch.equal(out[tail][0], out[None][0]) and torch.equal(out[tail][1], out[None][1]), (kind, relabel, k, tail)
+                assert out[tail][2]["candidates"] == out[None][2]["candidates"]
     assert _state_is_clean(eps, dev)

@@ -21,6 +21,12 @@ if 'HEAD_KEEP_HI' in os.environ:
     scan.HEAD_KEEP = (scan.HEAD_KEEP[0], float(os.environ['HEAD_KEEP_HI']))
 if 'HEAD_BETA' in os.environ:
     scan.HEAD_BETA = float(os.environ['HEAD_BETA'])
+if 'TAIL_SORT' in os.environ:
+    scan.TAIL_SORT = os.environ['TAIL_SORT']
+if 'TAIL_DEVICE' in os.environ:
+    scan.TAIL_DEVICE = os.environ['TAIL_DEVICE'] == '1'
+if 'COLUMN_PACK' in os.environ:
+    scan.COLUMN_PACK = os.environ['COLUMN_PACK'] == '1'
 if 'DMAX_MARGIN' in os.environ:
     scan.DMAX_MARGIN = int(os.environ['DMAX_MARGIN'])
 steps = int(os.environ.get("STEPS", 10))
@@ -38,7 +44,8 @@ def wrap(mod, name, label=None):
         return r
     setattr(mod, name, inner)
 for n in ("scan_screen", "scan_refine", "filter_scan", "kth_largest_dist", "compact_at_least", "rescore_runs", "rescore_weighted", "select_rows",
-          "select_compact", "sort_pairs_by_u", "select_splitters", "compact_range"):
+          "select_compact", "sort_pairs_by_u", "select_splitters", "compact_range", "score_hist", "score_pick_compact", "radix_sort_by_u",
+          "radix_sort_rows", "rescore_runs_dev"):
     if hasattr(ops, n):
         wrap(ops, n)
 wrap(ops, "Survivors", "Survivors (list fills)")

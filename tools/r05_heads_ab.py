@@ -79,13 +79,21 @@ for beta in [float(x) for x in (sys.argv[1:] or ["0", "0.25", "0.5", "0.625"])]:
         e1.record(); torch.cuda.synchronize()
         t_tables = e0.elapsed_time(e1)
         walked_paths = int(ht.wpaths.view(torch.int32).to(torch.int64).bitwise_and(0xFFFFFFFF).sum())
+        pack, t_pack = None, 0.0
+        if os.environ.get('PACK', '0') == '1':          # (r06: the per-column pack; with COLREC / ROWREC on, the specialised body)
+            p0, p1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            p0.record()
+            pack = ops.scan_column_pack(g.rowptr, g.col, scan.reverse_positions(g), sc.rowrec, ht.plan)
+            p1.record(); torch.cuda.synchronize()
+            t_pack = p0.elapsed_time(p1)
+        cols = scan.live_columns(g, sc, ht, 0, 1) if os.environ.get('LIVE', '0') == '1' else order
         def run():
             wk = ops.Survivors(256 << 20, bar, dev, prefill=False)
-            ops.scan_screen(g.rowptr, g.col, scan.reverse_positions(g), sc.fx32, cuts, bounds, g.n_rows, order, sc.shift, wk, status, variant,
+            ops.scan_screen(g.rowptr, g.col, scan.reverse_positions(g), sc.fx32, cuts, bounds, g.n_rows, cols, sc.shift, wk, status, variant,
                             wpaths=ht.wpaths, ssum=sc.ssum, smax=sc.smax, plan=ht.plan, heads=ht.heads,
-                            colrec=None if os.environ.get('COLREC', '1') == '0' else scan.column_records(g, sc, order, ht.plan, ht.heads, ht.live, "ab"),
-                            batch_from=int(os.environ['BATCH_FROM']) if 'BATCH_FROM' in os.environ else scan.batch_from(g, order),
-                            rowrec=None if os.environ.get('ROWREC', '1') == '0' else sc.rowrec)
+                            colrec=None if os.environ.get('COLREC', '1') == '0' else scan.column_records(g, sc, cols, ht.plan, ht.heads, ht.live, ("ab", cols.numel())),
+                            batch_from=int(os.environ['BATCH_FROM']) if 'BATCH_FROM' in os.environ else scan.batch_from(g, cols),
+                            rowrec=None if os.environ.get('ROWREC', '1') == '0' else sc.rowrec, pack=pack)
             return wk
         wk, tmin, tmed = timed(run)
         def fin():
@@ -98,7 +106,9 @@ for beta in [float(x) for x in (sys.argv[1:] or ["0", "0.25", "0.5", "0.625"])]:
         row = {"beta": beta, "budget": ht.budget * 2.0 ** -sc.shift, "kernel_min_ms": round(tmin, 3), "kernel_median_ms": round(tmed, 3),
                "refine_min_ms": round(rmin, 3), "tables_ms": round(t_tables, 3), "walked_slots": wk.counts()[0], "walked_paths": walked_paths,
                "walked_share": round(walked_paths / scan.total_half_paths(g), 4), "pieces": int(ht.plan[1].shape[0]), "d_used": ht.d_used,
-               "rows_skipped_mean": round(float(hx.float().mean()), 2), "rows_skipped_max": int(hx.max()), "hub_rows": masks.shape[0]}
+               "rows_skipped_mean": round(float(hx.float().mean()), 2), "rows_skipped_max": int(hx.max()), "hub_rows": masks.shape[0],
+               "pack": pack is not None, "pack_build_ms": round(t_pack, 3), "live_columns_only": cols is not order,
+               "generic_body": os.environ.get("EPS_SCAN_GENERIC", "0") == "1"}
     row.update(status=int(status), digest=d[0], screened=d[1], exact=d[2], counted=d[3])
     out.append(row)
     print(json.dumps(row), flush=True)
