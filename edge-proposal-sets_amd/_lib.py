@@ -92,6 +92,9 @@ SIGNATURES = {
     "eps_select_topk_rows_workspace_bytes": (_i64, [_i64]),
     "eps_select_topk_rows": (_int, [_vp, _vp, _i64, _i64, _i32, _vp, _vp, _vp, _i64, _vp]),
     "eps_tail_state_bytes": (_i64, []),
+    "eps_score_bins": (_i32, []),
+    "eps_score_hist_into": (_int, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
+    "eps_score_deal_plan": (_int, [_vp, _i64, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "eps_score_hist": (_int, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
     "eps_score_pick_compact": (_int, [_vp, _vp, _i64, _vp, _vp, _vp, _i64, _i32, _c.c_float, _c.c_float, _c.c_float, _i32, _vp, _vp, _vp,
                                       _vp, _i64, _vp, _vp, _vp]),

@@ -28,7 +28,10 @@
 #define PI_CAP 1024          // long-row entries staged per wave and pass (4 KiB of LDS per wave)
 #define PI_QCAP 256          // per-wave hit queue (1 KiB): deferred node_w gathers
 #define PI_INPLACE_RATIO 32  // long row searched in place when long > PI_CAP && long >= ratio*short
+#ifndef PI_SMALL
 #define PI_SMALL 256         // pairs whose LONGER row has at most this many entries are scored four at a time (16 lanes each)
+#endif
+#define PI_SMALL_LG (PI_SMALL == 256 ? 8 : PI_SMALL == 128 ? 7 : 6)
 
 // Lower bound over a sorted LDS array of 2^lg entries (padded with INT_MAX): fully unrolled, branch-free steps,
 // trip count selected by a wave-uniform switch.  Returns pos in [0, 2^lg - 1]; the caller tests L[pos] == t.
@@ -50,6 +53,8 @@ __device__ __forceinline__ int lb_pow2(const int32_t *L, int lg, int t)
     }
     return pos;
 }
+
+typedef int v4i_a4 __attribute__((ext_vector_type(4), aligned(4)));
 
 __device__ __forceinline__ v4i pad_tail(v4i x, int idx, int n)
 {
@@ -189,17 +194,27 @@ __global__ __launch_bounds__(PI_WAVES * 64) void pair_scores_kernel(
                 const int32_t slen = swapped ? djv : dju, llen = swapped ? dju : djv;
                 const int32_t *__restrict__ srow = col + (swapped ? bjv : bju), *__restrict__ lrow = col + (swapped ? bju : bjv);
                 int32_t *Lg = L + g * PI_SMALL;
-                // the longer row of each group, every load issued before the first LDS write; INT_MAX beyond its end
-                int32_t x[PI_SMALL / 16];
+                // the longer row of each group, every load issued before the first LDS write; INT_MAX beyond its end.
+                // (r06: 16-byte loads -- a lane takes four consecutive entries, a group 64 per instruction: a quarter of the vector-memory
+                //  instructions of the one-entry loads for the same bytes; one descriptor over all of col[], offsets per lane)
+                v4i x[PI_SMALL / 64];
 #pragma unroll
-                for (int r = 0; r < PI_SMALL / 16; ++r) {
-                    const int idx = r * 16 + gl;
-                    x[r] = idx < llen ? lrow[idx] : 0x7fffffff;
+                for (int r = 0; r < PI_SMALL / 64; ++r) {
+                    const int idx = r * 64 + 4 * gl;
+                    const int big = 0x7fffffff;
+                    if (idx + 4 <= llen) {
+                        x[r] = *reinterpret_cast<const v4i_a4 *>(lrow + idx);      // (4-byte aligned: global_load_dwordx4 takes it)
+                    } else {                                                       // (the row's last entries: never past its end)
+                        x[r].x = idx < llen ? lrow[idx] : big;
+                        x[r].y = idx + 1 < llen ? lrow[idx + 1] : big;
+                        x[r].z = idx + 2 < llen ? lrow[idx + 2] : big;
+                        x[r].w = big;
+                    }
                 }
                 const int32_t t0 = gl < slen ? srow[gl] : 0;                    // (the first slice of the shorter row rides along)
                 __builtin_amdgcn_wave_barrier();
 #pragma unroll
-                for (int r = 0; r < PI_SMALL / 16; ++r) Lg[r * 16 + gl] = x[r];
+                for (int r = 0; r < PI_SMALL / 64; ++r) *reinterpret_cast<v4i *>(&Lg[r * 64 + 4 * gl]) = pad_tail(x[r], r * 64 + 4 * gl, llen);
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -211,7 +226,7 @@ __global__ __launch_bounds__(PI_WAVES * 64) void pair_scores_kernel(
                 for (int s0 = 0; s0 < s_max; s0 += 16) {
                     const int si = s0 + gl;
                     const int32_t t = s0 == 0 ? t0 : (si < slen ? srow[si] : 0);
-                    const int pos = lb_pow2(Lg, 8, t);
+                    const int pos = lb_pow2(Lg, PI_SMALL_LG, t);
                     if (si < slen && Lg[pos] == t) {
                         ++cnt;
                         if (HAS_W) acc += (float)node_w[t];

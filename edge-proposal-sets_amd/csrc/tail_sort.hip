@@ -84,7 +84,7 @@ static ts_sort_state *ts_sort_of(void *state) { return (ts_sort_state *)((char *
 // `above` -- val > *above.  Values below *base count in bucket 0.
 __global__ __launch_bounds__(TS_T) void ts_hist_kernel(const int64_t *__restrict__ keys, const float *__restrict__ vals, int64_t n_max,
                                                        const unsigned long long *__restrict__ n_dev, const float *__restrict__ base,
-                                                       const float *__restrict__ above, ts_sel_state *__restrict__ st)
+                                                       const float *__restrict__ above, uint32_t *__restrict__ hist)
 {
     __shared__ uint32_t h[TS_BINS];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -118,7 +118,7 @@ __global__ __launch_bounds__(TS_T) void ts_hist_kernel(const int64_t *__restrict
     }
     __syncthreads();
     for (int i = tid; i < TS_BINS; i += TS_T)
-        if (h[i]) atomicAdd(&st->hist[i], h[i]);
+        if (h[i]) atomicAdd(&hist[i], h[i]);
 }
 
 static unsigned ts_blocks(int64_t n_max, int per_block)
@@ -136,8 +136,139 @@ extern "C" int eps_score_hist(const int64_t *keys_or_null, const float *vals, in
     EPS_REQUIRE(state && base && (n_max == 0 || vals), "eps_score_hist: null pointer");
     if (n_max == 0) return EPS_OK;
     hipLaunchKernelGGL(ts_hist_kernel, dim3(ts_blocks(n_max, TS_T * 16)), dim3(TS_T), 0, (hipStream_t)stream, keys_or_null, vals, n_max,
-                       n_dev_or_null, base, above_or_null, ts_sel_of(state));
+                       n_dev_or_null, base, above_or_null, ts_sel_of(state)->hist);
     EPS_CHECK_LAUNCH("eps_score_hist");
+    return EPS_OK;
+}
+
+extern "C" int32_t eps_score_bins(void) { return TS_BINS; }
+
+// The same histogram added to an array of the caller's (eps_score_bins() words, zeroed by the caller): what a rank of a sharded
+// step sends to the others -- 25 KB instead of its re-scored scores (see eps_score_deal_plan).
+extern "C" int eps_score_hist_into(const int64_t *keys_or_null, const float *vals, int64_t n_max, const unsigned long long *n_dev_or_null,
+                                   const float *base, const float *above_or_null, uint32_t *hist, void *stream)
+{
+    EPS_REQUIRE(n_max >= 0 && n_max < (1ll << 32), "eps_score_hist_into: bad size");
+    EPS_REQUIRE(hist && base && (n_max == 0 || vals), "eps_score_hist_into: null pointer");
+    if (n_max == 0) return EPS_OK;
+    hipLaunchKernelGGL(ts_hist_kernel, dim3(ts_blocks(n_max, TS_T * 16)), dim3(TS_T), 0, (hipStream_t)stream, keys_or_null, vals, n_max,
+                       n_dev_or_null, base, above_or_null, hist);
+    EPS_CHECK_LAUNCH("eps_score_hist_into");
+    return EPS_OK;
+}
+
+// ---- eps_score_deal_plan: the job-wide cut and the final ordering's deal of a sharded step, from the ranks' histograms ------------
+// hists[r * row_stride + b] = rank r's histogram (eps_score_hist_into over its re-scored scores, the same *base on every rank).
+// Every rank runs this on the same gathered table and gets the same answers without another exchange:
+//   *cut          = lower edge of the highest bucket with at least k values at or above it job-wide (-inf: fewer than k);
+//   splitters[q]  = lower edge of the bucket where range q ends (q = 0 .. world - 2, descending): range q holds the selected scores in
+//                   [splitters[q], splitters[q - 1]) -- bucket edges, so equal scores never straddle a boundary -- cut so that the
+//                   ranges hold about equal numbers of selected pairs;
+//   counts[r * world + q] = selected pairs of rank r in range q;  nsel[r] = selected pairs of rank r.
+// One workgroup.  filter.py:160-161 (sort all rows on one host) dealt over the ranks: rank q orders range q.
+#define TS_MAXWORLD 64
+__global__ __launch_bounds__(TS_T) void ts_deal_plan_kernel(const uint32_t *__restrict__ hists, int64_t row_stride, int world, uint64_t k,
+                                                            const float *__restrict__ base, float *__restrict__ cut,
+                                                            float *__restrict__ splitters, int64_t *__restrict__ counts,
+                                                            int64_t *__restrict__ nsel)
+{
+    __shared__ uint32_t s_suf[TS_BINS + 1];        // s_suf[b] = values in buckets >= b (job-wide); s_suf[TS_BINS] = 0
+    __shared__ uint32_t s_part[TS_T];
+    __shared__ uint32_t s_edge[TS_MAXWORLD + 1];   // s_edge[q] = first bucket of ranges < q, i.e. range q = [s_edge[q + 1], s_edge[q]); s_edge[0] = TS_BINS
+    const int tid = threadIdx.x;
+    constexpr int PER = (TS_BINS + TS_T - 1) / TS_T;
+    // thread t owns the buckets TS_BINS - 1 - (t PER + j), j = 0 .. PER - 1 (from the top)
+    uint32_t c[PER];
+    uint32_t mine = 0u;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const int b = TS_BINS - 1 - (tid * PER + j);
+        uint32_t x = 0u;
+        if (b >= 0)
+            for (int r = 0; r < world; ++r) x += hists[(size_t)r * row_stride + b];
+        c[j] = x;
+        mine += x;
+    }
+    s_part[tid] = mine;
+    __syncthreads();
+    for (int d = 1; d < TS_T; d <<= 1) {
+        const uint32_t add = tid >= d ? s_part[tid - d] : 0u;
+        __syncthreads();
+        s_part[tid] += add;
+        __syncthreads();
+    }
+    {
+        uint32_t run = s_part[tid] - mine;
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            const int b = TS_BINS - 1 - (tid * PER + j);
+            run += c[j];
+            if (b >= 0) s_suf[b] = run;
+        }
+        if (tid == 0) s_suf[TS_BINS] = 0u;
+    }
+    __syncthreads();
+    // b* = the highest bucket with at least k values at or above it; none: everything live is selected (bucket 0 up)
+    if (tid == 0) s_edge[world] = 0u;
+    __syncthreads();
+    for (int b = tid; b < TS_BINS; b += TS_T)
+        if (k != 0 && (uint64_t)s_suf[b] >= k && (uint64_t)s_suf[b + 1] < k) s_edge[world] = (uint32_t)b;
+    __syncthreads();
+    const uint32_t bstar = s_edge[world];
+    const bool none = k == 0 || (uint64_t)s_suf[0] < k;
+    const uint32_t lowest = none ? 0u : bstar;
+    const uint64_t total = s_suf[lowest];
+    if (tid == 0) s_edge[0] = TS_BINS;
+    if (tid >= 1 && tid < world) s_edge[tid] = lowest;       // (ranges that no boundary is found for stay empty)
+    __syncthreads();
+    // boundary q (1 .. world - 1): the highest bucket e > lowest with at least q total / world values at or above it
+    for (int b = tid; b < TS_BINS; b += TS_T) {
+        if ((uint32_t)b <= lowest) continue;
+        for (int q = 1; q < world; ++q) {
+            const uint64_t target = (uint64_t)q * total / (uint64_t)world;
+            if (target != 0 && (uint64_t)s_suf[b] >= target && (uint64_t)s_suf[b + 1] < target) s_edge[q] = (uint32_t)b;
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        // (boundaries must not ascend: a target of 0 or a gap leaves the default `lowest`; make the sequence monotone from the top)
+        for (int q = 1; q < world; ++q)
+            if (s_edge[q] > s_edge[q - 1]) s_edge[q] = s_edge[q - 1];
+        s_edge[world] = lowest;
+        const uint32_t ob = ts_ordered(*base);
+        auto edge_value = [&](uint32_t b) -> float {
+            if (b == 0u) return -__builtin_inff();
+            if (b >= (uint32_t)TS_BINS) return __builtin_inff();
+            const uint64_t o = (uint64_t)ob + ts_bucket_floor(b);
+            return ts_unordered(o > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)o);
+        };
+        *cut = none ? -__builtin_inff() : edge_value(bstar);
+        for (int q = 1; q < world; ++q) splitters[q - 1] = edge_value(s_edge[q]);
+    }
+    __syncthreads();
+    // counts[r][q] = rank r's values in the buckets [s_edge[q + 1], s_edge[q])
+    for (int i = tid; i < world * world; i += TS_T) {
+        const int r = i / world, q = i % world;
+        unsigned long long x = 0ull;
+        for (uint32_t b = s_edge[q + 1]; b < s_edge[q]; ++b) x += hists[(size_t)r * row_stride + b];
+        counts[i] = (int64_t)x;
+    }
+    __syncthreads();
+    if (tid < world) {
+        unsigned long long x = 0ull;
+        for (uint32_t b = lowest; b < (uint32_t)TS_BINS; ++b) x += hists[(size_t)tid * row_stride + b];
+        nsel[tid] = (int64_t)x;
+    }
+}
+
+extern "C" int eps_score_deal_plan(const uint32_t *hists, int64_t row_stride, int32_t world, int64_t k, const float *base, float *cut,
+                                   float *splitters, int64_t *counts, int64_t *nsel, void *stream)
+{
+    EPS_REQUIRE(world >= 1 && world <= TS_MAXWORLD && k >= 0 && row_stride >= TS_BINS, "eps_score_deal_plan: bad argument");
+    EPS_REQUIRE(hists && base && cut && counts && nsel && (world == 1 || splitters), "eps_score_deal_plan: null pointer");
+    hipLaunchKernelGGL(ts_deal_plan_kernel, dim3(1), dim3(TS_T), 0, (hipStream_t)stream, hists, row_stride, (int)world, (uint64_t)k, base, cut,
+                       splitters, counts, nsel);
+    EPS_CHECK_LAUNCH("eps_score_deal_plan");
     return EPS_OK;
 }
 

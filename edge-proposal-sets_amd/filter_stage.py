@@ -44,6 +44,9 @@ def make_parser():
     parser.add_argument('--dist_backend', type=str, default=None, choices=[None, 'nccl', 'gloo'])
     parser.add_argument('--synthetic', action="store_true", default=False)
     parser.add_argument('--keep_top', type=int, default=0)
+    parser.add_argument('--shard_proposals', action='store_true',
+                        help='sharded runs (torchrun) under --keep_top: every rank writes the chunk of the sorted list it ordered '
+                             '(<file>.shard{r}of{N}; rank.py reads the shards in rank order) instead of sending its rows to rank 0')
     return parser
 
 
@@ -296,8 +299,9 @@ def run(args) -> str:
         st = {"count": False}
         with torch.no_grad():
             # (the file is written by rank 0: the ordered rows travel there alone)
+            shards = world > 1 and bool(getattr(args, "shard_proposals", False))
             best_pairs, best_scores = scan.scan_topk(data.adj_t, scan_w, keep, rank, world, stats=st, relabel=True,
-                                                     rows_on=0 if world > 1 else None)
+                                                     rows_on="shards" if shards else (0 if world > 1 else None))
         n_seen = st["candidates"] if st["candidates"] is not None else st["touched"]
         dt = watch.stop(n_seen)
         bar = None if st["bar"] is None else float(st["bar"])
@@ -307,7 +311,8 @@ def run(args) -> str:
               f'({n_seen / max(dt, 1e-9):.3e} candidate edges/s incl. generation)'
               + (' -- every 2-hop non-edge is covered by the bound; the count is of those the walk touched' if st["candidates"] is None else ''))
         return _save(args, spec, sorted_edge_path, num_sorted_edge, run_id, rank, world,
-                     None if best_pairs is None else torch.cat([best_pairs.t().to(torch.float32), best_scores.unsqueeze(1)], 1))
+                     None if best_pairs is None else torch.cat([best_pairs.t().to(torch.float32), best_scores.unsqueeze(1)], 1),
+                     sharded=shards)
     full_w = (fused_node_weights(args, data.adj_t, ra_graph)
               if keep == 0 and data.adj_t.val is None and scan.scan_available(data.adj_t) else None)
     if (full_w is not None and candidates.fused_scores_fit(data.adj_t, full_w)
@@ -408,9 +413,16 @@ def run(args) -> str:
     return _save(args, spec, sorted_edge_path, num_sorted_edge, run_id, rank, world, sorted_edges)
 
 
-def _save(args, spec, sorted_edge_path, num_sorted_edge, run_id, rank, world, sorted_edges) -> str:
+def _save(args, spec, sorted_edge_path, num_sorted_edge, run_id, rank, world, sorted_edges, sharded: bool = False) -> str:
     filename = f'filtered_edges/{spec}_{sorted_edge_path}_{num_sorted_edge}_{run_id}_sorted_edges.pt'
-    if rank == 0:
+    if sharded:
+        # (every rank holds the chunk of the sorted list it ordered: rank r's rows follow rank r - 1's -- proposals.load_sorted_edges)
+        import os
+        if rank == 0 and os.path.exists(filename):
+            os.remove(filename)                      # (a list of an earlier, unsharded run would shadow the shards)
+        proposals.save_sorted_edges_shard(filename, sorted_edges, rank, world)
+        print(f"rank {rank}: {sorted_edges.shape[0]} rows to {proposals.shard_path(filename, rank, world)}")
+    elif rank == 0:
         print(sorted_edges)
         proposals.save_sorted_edges(filename, sorted_edges)                    # filter.py:164-165
         print("Saving to ", filename)

@@ -1206,6 +1206,42 @@ def score_pick_compact(keys: Optional[torch.Tensor], vals: torch.Tensor, n_dev, 
     return out_k, out_v, n_out, kth[0:1], kth[1:2]
 
 
+def score_bins() -> int:
+    return int(_lib.load().eps_score_bins())
+
+
+def score_hist_into(keys: Optional[torch.Tensor], vals: torch.Tensor, n_dev, base: torch.Tensor, hist: torch.Tensor,
+                    above: Optional[torch.Tensor] = None) -> None:
+    """``score_hist`` into an int32 array of the caller's (``score_bins()`` words, zeroed by the caller): the histogram a rank of a
+    sharded step sends to the others (eps_score_hist_into)."""
+    dev = _need_gpu(keys, vals, base, above, hist)
+    _chk(keys, torch.int64, "keys"); _chk(vals, torch.float32, "vals"); _chk(base, torch.float32, "base"); _chk(above, torch.float32, "above")
+    _chk(hist, torch.int32, "hist")
+    if hist.numel() < score_bins() or not hist.is_contiguous():
+        raise _lib.EpsError("score_hist_into: hist must hold score_bins() contiguous words")
+    with torch.cuda.device(dev):
+        _lib.check(_lib.load().eps_score_hist_into(_ptr(keys), _ptr(vals), vals.numel(), _dev_count(n_dev), _ptr(base), _ptr(above),
+                                                   _ptr(hist), _stream(dev)), "eps_score_hist_into")
+
+
+def score_deal_plan(hists: torch.Tensor, k: int, base: torch.Tensor):
+    """(cut float32[1], splitters float32[world - 1], counts int64[world, world], nsel int64[world]) from the ranks' gathered score
+    histograms ``hists`` (int32 [world, >= score_bins()], row-contiguous): eps_score_deal_plan -- device tensors, no host read."""
+    dev = _need_gpu(hists, base)
+    _chk(hists, torch.int32, "hists"); _chk(base, torch.float32, "base")
+    if hists.dim() != 2 or hists.stride(1) != 1 or hists.shape[1] < score_bins():
+        raise _lib.EpsError("score_deal_plan: hists must be [world, >= score_bins()] with unit column stride")
+    world = hists.shape[0]
+    cut = torch.empty(1, dtype=torch.float32, device=dev)
+    sp = torch.empty(max(world - 1, 1), dtype=torch.float32, device=dev)
+    counts = torch.empty((world, world), dtype=torch.int64, device=dev)
+    nsel = torch.empty(world, dtype=torch.int64, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.load().eps_score_deal_plan(_ptr(hists), hists.stride(0), world, int(k), _ptr(base), _ptr(cut), _ptr(sp), _ptr(counts),
+                                                   _ptr(nsel), _stream(dev)), "eps_score_deal_plan")
+    return cut, sp[:world - 1], counts, nsel
+
+
 def radix_sort_by_u(keys: torch.Tensor, n_dev, id_bits: int = 32, v_block_shift: int = 0) -> torch.Tensor:
     """``sort_pairs_by_u`` in one cooperative launch with the list's length read on the device (eps_radix_sort_by_u): the first
     min(*n_dev, len(keys)) keys v << 32 | u -> u << 32 | v in the order eps_rescore_runs wants; the rest of the output is undefined."""

@@ -50,9 +50,37 @@ def save_sorted_edges(path: str, sorted_edges: torch.Tensor) -> None:
     torch.save(sorted_edges.cpu(), path)      # filter.py:164-165
 
 
+def shard_path(path: str, rank: int, world: int) -> str:
+    """File of rank ``rank``'s chunk of a proposal list that a sharded filter run left on the ranks that ordered it (r06)."""
+    return f"{path}.shard{rank}of{world}"
+
+
+def save_sorted_edges_shard(path: str, sorted_edges: torch.Tensor, rank: int, world: int) -> None:
+    torch.save(sorted_edges.cpu(), shard_path(path, rank, world))
+
+
+def load_sorted_edges(path: str) -> torch.Tensor:
+    """The [E,3] rows of a proposal file -- or, when a sharded run wrote ``path.shard{r}of{N}`` instead (each rank the chunk of the
+    declared order it ordered), the shards concatenated in rank order: the same rows."""
+    import glob
+    import os
+    import re
+    if os.path.exists(path):
+        return torch.load(path)
+    shards = glob.glob(glob.escape(path) + ".shard*of*")
+    if not shards:
+        raise FileNotFoundError(path)
+    worlds = {int(re.search(r"\.shard(\d+)of(\d+)$", f).group(2)) for f in shards}
+    if len(worlds) != 1:
+        raise ValueError(f"{path}: shards of runs with different numbers of ranks")
+    world = worlds.pop()
+    parts = [torch.load(shard_path(path, r, world)) for r in range(world)]          # (a missing shard raises: the list would have a hole)
+    return torch.cat(parts, 0)
+
+
 def load_proposals(path: str, num: int) -> torch.Tensor:
     """rank.py:219 + :294: the first ``num`` proposal rows as a LongTensor [2,num]."""
-    t = torch.load(path)
+    t = load_sorted_edges(path)
     return t[:int(num), :2].t().long()
 
 

@@ -772,6 +772,7 @@ RESCORE_V_BLOCK = 12         # the survivors are re-scored in blocks of 2^12 con
                              # and the step is what counts (profiles/r05/rescore_variants.txt)
                              # Blocks multiply the RUNS of equal u (one LDS bitmap each): eps_sort_pairs_by_u keeps them only while a run
                              # still averages 64 pairs (AA / CN: 500; RA, 168 k distinct u: 1.8 -- 6.7 ms blocked, 2.1 ms by (u, v))
+DIST_HIST = True             # a sharded step exchanges score HISTOGRAMS (25 KB per rank) for its cut and its deal plan, not the scores
 DIST_ROWS_MIN = 1 << 15      # selected pairs from which the final ordering of a sharded step is dealt over the ranks
 
 
@@ -860,6 +861,13 @@ def _deal_rows(keys: torch.Tensor, vals: torch.Tensor, sp: torch.Tensor, c: List
     m = mk.numel()
     rk, rv = ops.select_rows(mk, mv, 2 * m, bits, perm)                                # all 2 m rows of the range, ordered
     lens = [2 * sum(c[r][q] for r in range(world)) for q in range(world)]
+    if rows_on == "shards":
+        # (r06) the rows stay where they were ordered: this rank's chunk is rows [offset, offset + len) of the declared order, cut
+        # where the first k rows end -- no gather of 48 MB onto one rank; the proposal file is written as one shard per rank and
+        # read back in rank order (proposals.load_proposals)
+        offset = sum(lens[:rank])
+        keep = max(0, min(lens[rank], k - offset))
+        return rk[:keep], rv[:keep]
     if rows_on is None:
         rows_k, rows_v = epd.gather_ragged(rk, lens), epd.gather_ragged(rv, lens)
     else:
@@ -888,7 +896,9 @@ def scan_topk(g: CSRGraph, node_w: torch.Tensor, k: int, rank: int = 0, world: i
     ``stats`` (optional dict) receives ``candidates`` (directed candidates scored), ``launches``, ``survivors``, ``bar``.
     ``relabel``: build the hubs-first copy of a large graph if it does not exist yet (see ``scan_graph``).
     ``rows_on`` (world > 1): the rank that wants the rows -- every other rank returns (None, None) and the ordered chunks travel
-    to that rank alone (the proposal file is written by one rank); default: every rank gets them.
+    to that rank alone (the proposal file is written by one rank); default: every rank gets them; ``"shards"``: every rank keeps
+    the chunk of the declared order it ordered itself (rank r's rows follow rank r - 1's; together the first k rows) -- nothing is
+    gathered, ``stats["shard"]`` = (first row of this rank's chunk, rows of all chunks).
 
     Per call, in the steady state (tables cached on the graph): sample launch -> bar (device; the lowest of the ranks' own
     estimates) -> main launch, under a bar with skipped heads + eps_scan_refine -> LOCAL pre-filter of this rank's list (its
@@ -1034,6 +1044,7 @@ def scan_topk(g: CSRGraph, node_w: torch.Tensor, k: int, rank: int = 0, world: i
             # (the outputs hold 2 x k_pre pairs -- lower() keeps ~10 % more than k_pre -- not a copy of the list's worst-case size;
             #  a level of tied scores at the threshold may hold more: then the call is repeated with room for all of them)
             room = res.capacity if rescore_all else min(res.capacity, 2 * k_pre + (1 << 16))
+            room_x = room              # (what the r05 score exchange sends: the same on every rank -- a retry below grows `room` only)
             c_keys, c_vals, n_valid, _, pre_thr = ops.select_compact(l_keys, l_vals, k_pre, res.count_ptr, mode=2, params=(a, b, 4e-6), room=room)
             nv = int(n_valid.item())                                                      # (one word: sizes the re-scoring)
             if nv > room:
@@ -1055,7 +1066,38 @@ def scan_topk(g: CSRGraph, node_w: torch.Tensor, k: int, rank: int = 0, world: i
         scores_all = None
         if fast:
             pass
+        elif world > 1 and screen is not None and not rescore_all and bar is not None and DIST_HIST:
+            # r06 -- ONE exchange for the cut AND the step's status, 25 KB per rank whatever the lists hold: every rank's histogram of
+            # its re-scored scores over order-preserving buckets of their distance to the bar (ops.score_hist_into: the bar is the
+            # same on every rank) behind six status words, all-gathered.  From the same table every rank then derives, in ONE small
+            # launch (ops.score_deal_plan) and without asking again, the job-wide cut -- the lower edge of the bucket that holds the
+            # k2-th best score: a few pairs more than k2 are selected, the K rows are the same --, everybody's selection count, the
+            # splitters of the final ordering (bucket edges) and who sends how many pairs of which range to whom (_deal_rows).
+            # (r05: every rank's SCORES, 2.3 MB per rank, and a replicated select over all of them; r04: four all-reduced histogram
+            #  rounds for the cut, one all-gather for the status, two for the selected pairs.)
+            from . import dist as epd
+            bins = ops.score_bins()
+            head = torch.cat([res.rec[1:2], res.rec[4:5]] + st_tail).view(torch.int32)                 # 6 x int64
+            send = torch.zeros(_XCHG_HEAD + bins, dtype=torch.int32, device=dev)
+            send[:head.numel()] = head
+            ops.score_hist_into(l_keys, l_vals, None, bar, send[_XCHG_HEAD:], above=bar)
+            got = epd._gather_into(send, world).view(world, _XCHG_HEAD + bins)
+            cut, deal_sp, deal_counts, nsel_all = ops.score_deal_plan(got[:, _XCHG_HEAD:], k2, bar)
+            sel_k, sel_v, n_sel = ops.compact_at_least(l_keys, l_vals, cut)
+            heads6 = got[:, :12].contiguous().view(torch.int64)                                          # [world, 6]
+            st_all = torch.cat([heads6[:, :2], nsel_all.unsqueeze(1), cut.view(torch.int32).to(torch.int64).expand(world, 1),
+                                heads6[:, 2:]], 1)
+            flat = torch.cat([st_all.reshape(-1), deal_counts.reshape(-1)]).tolist()            # the host read of the step
+            table = [flat[r * 8:(r + 1) * 8] for r in range(world)]
+            deal_c = [flat[8 * world + r * world:8 * world + (r + 1) * world] for r in range(world)]
+            scores_all = True                     # (marks "the deal plan is at hand" for the ordering below)
         elif world > 1 and screen is not None and not rescore_all:
+            # (no bar -- small candidate sets -- or DIST_HIST off: the r05 exchange of the scores themselves.  Its length must be the
+            #  same on every rank and hold every rank's list: a level of tied scores at a rank's pre-filter threshold may have grown
+            #  that rank's list beyond the room it started with -- ADVICE r05 -- so the ranks agree on the longest list first: one
+            #  all-reduced word)
+            from . import dist as epd
+            room_x = max(room_x, -int(epd.all_reduce_min_(torch.tensor([-int(l_vals.numel())], dtype=torch.int64, device=dev)).item()))
             # ONE exchange for the cut AND the step's status: every rank's re-scored scores (at most `room`, -inf beyond its own) behind
             # six status words, all-gathered.  Each rank then finds the job-wide cut itself -- one select launch over the gathered
             # scores: the same values in the same order everywhere, so the same cut without a broadcast -- and knows every rank's
@@ -1063,10 +1105,10 @@ def scan_topk(g: CSRGraph, node_w: torch.Tensor, k: int, rank: int = 0, world: i
             # (r04: four all-reduced histogram rounds for the cut, one all-gather for the status, two for the selected pairs.)
             from . import dist as epd
             head = torch.cat([res.rec[1:2], res.rec[4:5]] + st_tail).view(torch.int32)                 # 6 x int64
-            send = torch.full((_XCHG_HEAD + room,), _NEG_INF_BITS, dtype=torch.int32, device=dev)
+            send = torch.full((_XCHG_HEAD + room_x,), _NEG_INF_BITS, dtype=torch.int32, device=dev)
             send[:head.numel()] = head
             send[_XCHG_HEAD:_XCHG_HEAD + l_vals.numel()] = l_vals.view(torch.int32)
-            got = epd._gather_into(send, world).view(world, _XCHG_HEAD + room)
+            got = epd._gather_into(send, world).view(world, _XCHG_HEAD + room_x)
             scores_all = got[:, _XCHG_HEAD:].contiguous().view(torch.float32)
             cut = ops.select_compact(None, scores_all.reshape(-1), k2, compact=False)[3]
             sel_k, sel_v, n_sel = ops.compact_at_least(l_keys, l_vals, cut)
@@ -1157,18 +1199,29 @@ def scan_topk(g: CSRGraph, node_w: torch.Tensor, k: int, rank: int = 0, world: i
         break
     keys, vals = sel_k[:nsel_r[rank]], sel_v[:nsel_r[rank]]      # (still in the scanned graph's labels: select_rows maps them back)
     bits = max(1, min(32, int(g.n_rows - 1).bit_length()))
+    shard_info = None
     if rows is not None:
         keys = vals = None                          # (the device tail has ordered the rows already)
     elif world > 1 and scores_all is not None and n_sel_all >= DIST_ROWS_MIN:
         keys, vals = _deal_rows(keys.contiguous(), vals.contiguous(), deal_sp, deal_c, k, bits, perm, rank, world, rows_on)
+        if rows_on == "shards":
+            lens = [2 * sum(deal_c[r][q] for r in range(world)) for q in range(world)]
+            shard_info = (min(sum(lens[:rank]), k), min(sum(lens), k))
     elif world > 1:
         keys, vals = epd.gather_ragged(keys, nsel_r), epd.gather_ragged(vals, nsel_r)
         if n_sel_all >= DIST_ROWS_MIN:
-            keys, vals = _ordered_rows_distributed(keys.contiguous(), vals.contiguous(), k, bits, perm, rank, world, rows_on)
-        elif rows_on is None or rows_on == rank:
+            keys, vals = _ordered_rows_distributed(keys.contiguous(), vals.contiguous(), k, bits, perm, rank, world,
+                                                   None if rows_on == "shards" else rows_on)
+        elif rows_on is None or rows_on == rank or rows_on == "shards":
             keys, vals = ops.select_rows(keys.contiguous(), vals.contiguous(), k, bits, perm)
         else:
             keys = vals = None
+        if rows_on == "shards" and keys is not None:
+            # (a short list, or the exchange without a deal plan: every rank holds all rows -- it keeps an even share of them)
+            n_rows = keys.numel()
+            lo_r, hi_r = rank * n_rows // world, (rank + 1) * n_rows // world
+            shard_info = (lo_r, n_rows)
+            keys, vals = keys[lo_r:hi_r], vals[lo_r:hi_r]
     elif rows_on is None or rows_on == rank or world == 1:
         keys, vals = ops.select_rows(keys.contiguous(), vals.contiguous(), k, bits, perm)
     else:
@@ -1186,7 +1239,7 @@ def scan_topk(g: CSRGraph, node_w: torch.Tensor, k: int, rank: int = 0, world: i
                 g._cache.setdefault("n_candidates", n_cand_all)
         else:
             n_all = 2 * candidate_count(g, screen, fixw, rank, world) if stats.get("count", True) else None
-        stats.update(candidates=n_all, touched=touched, launches=launches, survivors=2 * n_sel_all, heads=ht is not None,
+        stats.update(candidates=n_all, touched=touched, launches=launches, survivors=2 * n_sel_all, heads=ht is not None, shard=shard_info,
                      head_budget=None if ht is None else ht.budget * 2.0 ** -screen.shift,
                      walked_slots=sum(t[6] for t in table) if ht is not None else None, rescored=n_rescored,
                      survivor_slots=sum(min(s_, capacity) for s_ in slots_r), bar=bar)

@@ -558,6 +558,18 @@ int eps_select_topk_rows(const int64_t *sel_keys, const float *sel_vals, int64_t
  *          bytes (records = n_max resp. 2 m_max), 256-byte aligned.
  *   eps_rescore_runs_dev: eps_rescore_runs over min(*n_dev, n_max) pairs. */
 int64_t eps_tail_state_bytes(void);
+/* eps_score_bins / eps_score_hist_into / eps_score_deal_plan: the same selection for a SHARDED step.  Every rank adds the histogram
+ * of its re-scored scores to an array of its own (eps_score_bins() words, zeroed by the caller, the same *base on every rank) and
+ * the arrays are all-gathered -- 25 KB per rank instead of its scores; eps_score_deal_plan then gives every rank, from the same
+ * table hists[r * row_stride + bucket], the job-wide *cut (lower edge of the highest bucket with at least k values at or above it;
+ * -inf when fewer), the world - 1 descending splitters[] of the final ordering (bucket edges: equal scores never straddle one;
+ * range q = the selected scores in [splitters[q], splitters[q - 1]) holds about 1 / world of the selected pairs), counts[r * world
+ * + q] = selected pairs of rank r in range q, and nsel[r] -- without another exchange.  filter.py:160-161 dealt over the ranks. */
+int32_t eps_score_bins(void);
+int eps_score_hist_into(const int64_t *keys_or_null, const float *vals, int64_t n_max, const unsigned long long *n_dev_or_null,
+                        const float *base, const float *above_or_null, uint32_t *hist, void *stream);
+int eps_score_deal_plan(const uint32_t *hists, int64_t row_stride, int32_t world, int64_t k, const float *base, float *cut,
+                        float *splitters, int64_t *counts, int64_t *nsel, void *stream);
 int eps_score_hist(const int64_t *keys_or_null, const float *vals, int64_t n_max, const unsigned long long *n_dev_or_null,
                    const float *base, const float *above_or_null, void *state, void *stream);
 int eps_score_pick_compact(const int64_t *keys_or_null, const float *vals, int64_t n_max, const unsigned long long *n_dev_or_null,

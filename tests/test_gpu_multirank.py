@@ -147,7 +147,7 @@ def test_bench_self_launch_from_plain_shell(dev, tmp_path):
     assert 0 < line["roofline"]["frac"] <= 1 and line["value_unordered_pairs_per_s"] * 2 == pytest.approx(line["value"])
 
 
-def _relabelled_scan_rank_main(rank, world, port, workdir, dist_rows_min=0, rows_on=None):
+def _relabelled_scan_rank_main(rank, world, port, workdir, dist_rows_min=0, rows_on=None, kind="aa", k=30000, dist_hist=True):
     sys.path.insert(0, ROOT)
     os.chdir(workdir)
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
@@ -160,16 +160,20 @@ def _relabelled_scan_rank_main(rank, world, port, workdir, dist_rows_min=0, rows
     scan.HEAD_MIN_PATHS = 0                          # (skipped heads on this small graph too: the sharded step runs them)
     scan.SMALL_SET = 0                               # the estimated-bar path
     scan.DIST_ROWS_MIN = dist_rows_min               # 0: the final ordering is dealt over the ranks by score range
+    scan.DIST_HIST = dist_hist                       # the step's one exchange: score histograms (r06) or the scores themselves (r05)
     dev = torch.device("cuda:0")
     g = synth.rmat_graph(13, 10, 21, dev)
-    pairs, scores = scan.scan_topk(g, node_weight_table(g, ops.W_AA), 30000, rank, world, relabel=True, rows_on=rows_on)
+    w = torch.ones(g.n_rows, dtype=torch.float32, device=dev) if kind == "cn" else node_weight_table(g, ops.W_AA)
+    st = {}
+    pairs, scores = scan.scan_topk(g, w, k, rank, world, relabel=True, rows_on=rows_on, stats=st)
     assert scan.scan_graph(g)[1] is not None
-    assert (pairs is None) == (rows_on is not None and rank != rows_on)
-    torch.save(None if pairs is None else (pairs.cpu(), scores.cpu()), f"scan_rank{rank}.pt")
+    assert (pairs is None) == (rows_on is not None and rows_on != "shards" and rank != rows_on)
+    torch.save(None if pairs is None else (pairs.cpu(), scores.cpu(), st.get("shard")), f"scan_rank{rank}.pt")
     torch.distributed.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,dist_rows_min,rows_on", [(2, 0, None), (4, 0, None), (2, 1 << 30, None), (3, 0, 0), (2, 1 << 30, 1)])
+@pytest.mark.parametrize("world,dist_rows_min,rows_on", [(2, 0, None), (4, 0, None), (2, 1 << 30, None), (3, 0, 0), (2, 1 << 30, 1),
+                                                         (2, 0, "shards"), (3, 0, "shards"), (4, 0, "shards"), (2, 1 << 30, "shards")])
 def test_scan_two_ranks_hubs_first_labels(eps, dev, tmp_path, world, dist_rows_min, rows_on):
     """The sharded threshold scan on the hubs-first relabelled copy (what bench.py --scaling strong runs): every rank ends
     with the single-process list as scanned under the original labels, bit for bit -- with the final ordering dealt over the
@@ -181,12 +185,41 @@ def test_scan_two_ranks_hubs_first_labels(eps, dev, tmp_path, world, dist_rows_m
     want_p, want_s = scan.scan_topk(g, node_weight_table(g, eps.ops.W_AA), 30000)
     assert scan.scan_graph(g)[1] is None
     mp.spawn(_relabelled_scan_rank_main, args=(world, _free_port(), str(tmp_path), dist_rows_min, rows_on), nprocs=world, join=True)
+    if rows_on == "shards":
+        # (r06) every rank keeps the chunk of the declared order it ordered: the chunks, in rank order, ARE the single-process rows
+        parts = [torch.load(os.path.join(tmp_path, f"scan_rank{r}.pt")) for r in range(world)]
+        total = parts[0][2][1]
+        at = 0
+        for p, s, shard in parts:
+            assert shard == (at, total)
+            at += p.shape[1]
+        assert at == total == want_p.shape[1]
+        assert torch.equal(torch.cat([p for p, _, _ in parts], 1), want_p.cpu())
+        assert torch.equal(torch.cat([s for _, s, _ in parts]), want_s.cpu())
+        return
     for r in range(world):
         got = torch.load(os.path.join(tmp_path, f"scan_rank{r}.pt"))
         if rows_on is not None and r != rows_on:          # (the rows travel to one rank only)
             assert got is None
             continue
-        p, s = got
+        p, s, _ = got
+        assert torch.equal(p, want_p.cpu()) and torch.equal(s, want_s.cpu())
+
+
+@pytest.mark.parametrize("dist_hist", [True, False], ids=["histograms", "scores"])
+@pytest.mark.parametrize("world", [2, 3])
+def test_scan_ranks_tied_levels_beyond_the_room(eps, dev, tmp_path, world, dist_hist):
+    """common-neighbour counts tie by the hundred thousand, so a rank's pre-filter threshold level holds far more pairs
+    than the 2 k_pre + 65536 entries its outputs start with and that rank repeats the pre-filter with more room -- the step's
+    exchange must still have one length on every rank.  With the histogram exchange (fixed 25 KB) and with the r05 score
+    exchange (the ranks agree on the longest list first): the single-process rows on every rank."""
+    from eps_amd import scan, synth
+    g = synth.rmat_graph(13, 10, 21, dev)
+    ones = torch.ones(g.n_rows, dtype=torch.float32, device=dev)
+    want_p, want_s = scan.scan_topk(g, ones, 3000)
+    mp.spawn(_relabelled_scan_rank_main, args=(world, _free_port(), str(tmp_path), 0, None, "cn", 3000, dist_hist), nprocs=world, join=True)
+    for r in range(world):
+        p, s, _ = torch.load(os.path.join(tmp_path, f"scan_rank{r}.pt"))
         assert torch.equal(p, want_p.cpu()) and torch.equal(s, want_s.cpu())
 
 

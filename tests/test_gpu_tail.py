@@ -69,7 +69,7 @@ def test_score_selection_matches_torch(eps, dev, n, k, dist):
     assert _state_is_clean(eps, dev)
 
 
-@pytest.mark.parametrize("n,id_bits,shift", [(1, 5, 0), (1000, 10, 0), (70_000, 17, 9), (2_300_000, 20, 12), (300_000, 20, 12), (500_000, 32, 0)])
+@pytest.mark.parametrize("n,id_bits,shift", [(1, 5, 0), (1000, 10, 0), (70_000, 17, 9), (2_300_000, 20, 12), (300_000, 20, 12), (500_000, 31, 0)])
 def test_radix_sort_by_u_matches_library_sort(eps, dev, n, id_bits, shift):
     g = torch.Generator().manual_seed(n)
     hi = (1 << id_bits) - 1
@@ -172,3 +172,48 @@ def test_scan_topk_device_tail_is_bit_identical(eps, dev, kind, monkeypatch):
                 assert torch.equal(out[tail][0], out[None][0]) and torch.equal(out[tail][1], out[None][1]), (kind, relabel, k, tail)
                 assert out[tail][2]["candidates"] == out[None][2]["candidates"]
     assert _state_is_clean(eps, dev)
+
+
+@pytest.mark.parametrize("world,n,k", [(1, 5000, 100), (2, 100_000, 30_000), (3, 50_000, 200_000), (8, 400_000, 1_000_000), (4, 1000, 0)])
+def test_deal_plan_from_gathered_histograms(eps, dev, world, n, k):
+    """eps_score_hist_into + eps_score_deal_plan (what every rank of a sharded step computes from the all-gathered histograms):
+    the cut is the lower edge of the bucket of the job-wide k-th best score, nsel / counts are exactly what the ranks' lists hold
+    at or above the cut per score range, and the ranges are bucket-aligned (equal scores never straddle a splitter)."""
+    g = torch.Generator().manual_seed(world * 1000 + n)
+    base = torch.tensor([1.75], device=dev)
+    bins = eps.ops.score_bins()
+    lists = []
+    hists = torch.zeros((world, bins + 16), dtype=torch.int32, device=dev)
+    for r in range(world):
+        m = n // (r + 1)                                                   # uneven shards
+        vals = (1.75 + torch.empty(m).exponential_(1.5, generator=g)).to(dev)
+        if r % 2:
+            vals = torch.floor(vals * 8) / 8                                # tied levels
+        vals[torch.rand(m, generator=g).to(dev) < 0.05] = float("-inf")    # dropped slots
+        keys = torch.arange(m, device=dev, dtype=torch.int64)
+        keys[vals == float("-inf")] = -1
+        eps.ops.score_hist_into(keys, vals, None, base, hists[r, 16:], above=base)
+        lists.append(vals)
+    cut, sp, counts, nsel = eps.ops.score_deal_plan(hists[:, 16:], k, base)
+    live = [v[(v > float("-inf")) & (v > base)] for v in lists]
+    allv = torch.cat(live)
+    cut_f = float(cut)
+    if k == 0 or allv.numel() < k:
+        assert cut_f == float("-inf")
+    else:
+        exact = float(torch.sort(allv, descending=True).values[k - 1])
+        assert cut_f <= exact and int((allv >= cut_f).sum()) >= k
+        d = int(np.float32(exact).view(np.int32)) - int(np.float32(1.75).view(np.int32))
+        assert cut_f >= float(np.int32(int(np.float32(exact).view(np.int32)) - max(1, d >> 8) - 1).view(np.float32))
+    assert nsel.tolist() == [int((v >= cut_f).sum()) for v in live]
+    sp_l = sp.tolist()
+    assert all(a >= b for a, b in zip(sp_l, sp_l[1:])), "splitters descend"
+    want = torch.zeros((world, world), dtype=torch.int64)
+    for r, v in enumerate(live):
+        sel = v[v >= cut_f]
+        rng = (sel.unsqueeze(1) < sp.unsqueeze(0)).sum(1) if world > 1 else torch.zeros(sel.numel(), dtype=torch.int64, device=dev)
+        want[r] = torch.bincount(rng, minlength=world).cpu()
+    assert torch.equal(counts.cpu(), want)
+    tot = want.sum(0)
+    if world > 1 and int(tot.sum()) > 50 * world and not any(r % 2 for r in range(1, world)):
+        assert int(tot.max()) <= 2 * int(tot.sum()) // world + 8
