@@ -29,8 +29,8 @@
 #define PI_QCAP 256          // per-wave hit queue (1 KiB): deferred node_w gathers
 #define PI_INPLACE_RATIO 32  // long row searched in place when long > PI_CAP && long >= ratio*short
 #ifndef PI_SMALL
-#define PI_SMALL 256         // pairs whose LONGER row has at most this many entries are scored four at a time (16 lanes each)
-#endif
+#define PI_SMALL 128         // pairs whose LONGER row has at most this many entries are scored four at a time (16 lanes each).
+#endif                       // r06, 2^24 pairs of the ppa-like graph, uniform / stored edges: 64: 3.55 / 10.64 ms, 128: 3.33 / 10.41, 256: 5.20 / 11.81
 #define PI_SMALL_LG (PI_SMALL == 256 ? 8 : PI_SMALL == 128 ? 7 : 6)
 
 // Lower bound over a sorted LDS array of 2^lg entries (padded with INT_MAX): fully unrolled, branch-free steps,
@@ -170,6 +170,7 @@ __global__ __launch_bounds__(PI_WAVES * 64) void pair_scores_kernel(
             is_small = valid && mn > 0 && mx <= PI_SMALL;
             if (PART == 1 || is_small) du_left = dv_left = 0;                     // (the one-at-a-time loop below skips them)
         }
+#if PI_SMALL >= 64
         if (PART == 1) {
             uint64_t small = __ballot(is_small);
             if (!small) {                                                         // (wave-uniform: a chunk of longer rows is part 2's)
@@ -251,6 +252,7 @@ __global__ __launch_bounds__(PI_WAVES * 64) void pair_scores_kernel(
             }
         }
 
+#endif
         for (int j = 0; PART != 1 && j < 64; ++j) {
             const int32_t dju = __builtin_amdgcn_readlane(du_left, j);
             const int32_t djv = __builtin_amdgcn_readlane(dv_left, j);

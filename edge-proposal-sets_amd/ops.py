@@ -1227,7 +1227,7 @@ def score_hist_into(keys: Optional[torch.Tensor], vals: torch.Tensor, n_dev, bas
 def score_deal_plan(hists: torch.Tensor, k: int, base: torch.Tensor):
     """(cut float32[1], splitters float32[world - 1], counts int64[world, world], nsel int64[world]) from the ranks' gathered score
     histograms ``hists`` (int32 [world, >= score_bins()], row-contiguous): eps_score_deal_plan -- device tensors, no host read."""
-    dev = _need_gpu(hists, base)
+    dev = _need_gpu(hists, base, row_strided=(hists,))
     _chk(hists, torch.int32, "hists"); _chk(base, torch.float32, "base")
     if hists.dim() != 2 or hists.stride(1) != 1 or hists.shape[1] < score_bins():
         raise _lib.EpsError("score_deal_plan: hists must be [world, >= score_bins()] with unit column stride")

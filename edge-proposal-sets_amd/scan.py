@@ -256,7 +256,8 @@ def screen_shift(bound: float, max_deg: int, weighted: bool = False) -> int:
 
 class Screen:
     """What a launch of the piece kernel and the exact re-scoring of its survivors need, for one (graph, weight table)."""
-    __slots__ = ("fx32", "shift", "fixw", "val", "node_w", "usable", "ssum", "smax", "plan", "d_used", "w_min", "heads", "head_cur", "rowrec", "vword", "exact")
+    __slots__ = ("fx32", "shift", "fixw", "val", "node_w", "usable", "ssum", "smax", "plan", "d_used", "w_min", "heads", "head_cur", "rowrec", "vword", "exact",
+                 "bar_hint")
 
     def __init__(self, fx32, shift, fixw, val, node_w, usable, ssum=None, smax=None, plan=None, d_used=0, w_min=0.0):
         self.fx32, self.shift, self.fixw, self.val, self.node_w, self.usable = fx32, shift, fixw, val, node_w, usable
@@ -267,6 +268,7 @@ class Screen:
         self.head_cur = None         # the HeadTables the last launch under a bar used
         self.rowrec = None           # ops.scan_row_records: one 128-byte line per node with what the walk gathers per row
         self.vword = None            # the `variant` word the plan was built with (geometry + the limit on dropped weight bits)
+        self.bar_hint = {}           # (k, stride, safety) -> the bar (host float) the last scan with these settings ended with
         self.exact = False           # screening sums ARE the exact scores (one weight for every node, a multiple of every unit a piece
                                      # may round to -- common neighbours): the survivors need no re-scoring
 
@@ -669,6 +671,7 @@ def sample_columns(g: CSRGraph, stride: int, rank: int = 0, world: int = 1):
     return g._cache[key]
 
 
+BAR_FROM_HISTOGRAM = True  # repeated scans of a graph at the same K read the bar estimate off a score histogram around the previous bar
 SAMPLE_RANK = 4096         # the sample is thinned (stride doubled) while the rank read off it stays at least this large
 
 
@@ -713,7 +716,18 @@ def estimate_bar(g: CSRGraph, fixw: torch.Tensor, k: int, stride: Optional[int] 
     # takes the lowest of them (one all-reduce of a word).  Any bar is a valid bar: the verification after the main launch is
     # what makes the result exact.
     m_loc = m if world == 1 else (m + world - 1) // world
-    bar = ops.select_compact(None, res.val, m_loc, res.count_ptr, mode=1, compact=False)[4]
+    hint = screen.bar_hint.get((k, stride, float(safety))) if BAR_FROM_HISTOGRAM else None
+    if hint is not None and hint > 0.0:
+        # r06: a graph that is scanned again reads the bar off a score-bucket histogram around the bar its last scan at this K
+        # ended with (two short launches instead of the four-round select): buckets are 2^-8 of a score's distance to the base --
+        # half the old bar -- so the value is at most 0.4 % below the exact order statistic: an estimate either way, and the
+        # verification after the main launch is what makes the step exact.  A sample whose m-th best fell below the base answers
+        # -inf: the main launch then keeps everything, overflows its list and is corrected like any bar that was too low.
+        base = torch.full((1,), 0.5 * hint, dtype=torch.float32, device=g.device)
+        ops.score_hist(None, res.val, res.count_ptr, base)
+        bar = ops.score_pick_compact(None, res.val, res.count_ptr, base, m_loc, mode=1)[4]
+    else:
+        bar = ops.select_compact(None, res.val, m_loc, res.count_ptr, mode=1, compact=False)[4]
     if world > 1:
         from . import dist as epd
         # (a rank whose share of the sample holds fewer than m_loc candidates has no estimate: it does not vote)
@@ -999,7 +1013,7 @@ def scan_topk(g: CSRGraph, node_w: torch.Tensor, k: int, rank: int = 0, world: i
                 zero = torch.zeros(1, dtype=torch.int64, device=dev)
                 st = torch.cat([res.rec[1:2], res.rec[4:5], n_sel, cut.view(torch.int32).to(torch.int64), res.status.to(torch.int64),
                                 pre_thr.view(torch.int32).to(torch.int64), res.walked_slots if res.walked_slots is not None else zero,
-                                bar.view(torch.int32).to(torch.int64) if ht is not None else zero])
+                                bar.view(torch.int32).to(torch.int64) if bar is not None else zero])
                 table = [st.tolist()]                                                            # the host read of the step
                 n_rescored = 0 if screen.exact else nv
                 break
@@ -1019,7 +1033,7 @@ def scan_topk(g: CSRGraph, node_w: torch.Tensor, k: int, rank: int = 0, world: i
                 zero = torch.zeros(1, dtype=torch.int64, device=dev)
                 st = torch.cat([res.rec[1:2], res.rec[4:5], n_sel, cut.view(torch.int32).to(torch.int64), res.status.to(torch.int64),
                                 pre_thr.view(torch.int32).to(torch.int64), res.walked_slots if res.walked_slots is not None else zero,
-                                bar.view(torch.int32).to(torch.int64) if ht is not None else zero, n_valid, n_rows])
+                                bar.view(torch.int32).to(torch.int64) if bar is not None else zero, n_valid, n_rows])
                 row = st.tolist()                                                                # the host read of the step
                 nv = row[8]
                 if nv <= room:
@@ -1062,7 +1076,7 @@ def scan_topk(g: CSRGraph, node_w: torch.Tensor, k: int, rank: int = 0, world: i
         st_tail = [status.to(torch.int64) if status is not None else zero,                          # kernel status,
                    pre_thr.view(torch.int32).to(torch.int64) if pre_thr is not None else zero,      # pre-filter threshold bits,
                    res.walked_slots if res.walked_slots is not None else zero,                      # slots of the walked list,
-                   bar.view(torch.int32).to(torch.int64) if ht is not None else zero]               # the bar's bits (head launches)
+                   bar.view(torch.int32).to(torch.int64) if bar is not None else zero]               # the bar's bits (head launches)
         scores_all = None
         if fast:
             pass
@@ -1197,6 +1211,11 @@ def scan_topk(g: CSRGraph, node_w: torch.Tensor, k: int, rank: int = 0, world: i
                 capacity = _capacity(wanted, slack)
             continue
         break
+    if screen is not None and bar is not None and len(table[0]) > 7:
+        # (the bar this scan ended with, for the next scan's estimate at the same K: see estimate_bar)
+        bar_f = _f32_from_bits(table[0][7])
+        if 0.0 < bar_f < float("inf"):
+            screen.bar_hint[(k, sample_stride(k), float(SAFETY))] = bar_f
     keys, vals = sel_k[:nsel_r[rank]], sel_v[:nsel_r[rank]]      # (still in the scanned graph's labels: select_rows maps them back)
     bits = max(1, min(32, int(g.n_rows - 1).bit_length()))
     shard_info = None
