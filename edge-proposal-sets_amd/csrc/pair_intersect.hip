@@ -28,6 +28,9 @@
 #define PI_CAP 1024          // long-row entries staged per wave and pass (4 KiB of LDS per wave)
 #define PI_QCAP 256          // per-wave hit queue (1 KiB): deferred node_w gathers
 #define PI_INPLACE_RATIO 32  // long row searched in place when long > PI_CAP && long >= ratio*short
+#ifndef PI_TICKET
+#define PI_TICKET 4          // consecutive 64-pair chunks per ticket of the launch that scores the longer pairs (PART 2)
+#endif
 #ifndef PI_SMALL
 #define PI_SMALL 128         // pairs whose LONGER row has at most this many entries are scored four at a time (16 lanes each).
 #endif                       // r06, 2^24 pairs of the ppa-like graph, uniform / stored edges: 64: 3.55 / 10.64 ms, 128: 3.33 / 10.41, 256: 5.20 / 11.81
@@ -72,13 +75,19 @@ __device__ __forceinline__ v4i pad_tail(v4i x, int idx, int n)
 // entries paid for it (stored-edge positives 4.37 -> 5.73 ms, the R-MAT-24 share 0.64 -> 0.70 s: VERDICT r05 weak #8).  Two
 // launches over the same list now: part 1 at its own register count, part 2 = the r04 body at 8 waves per SIMD; each writes the
 // outputs of ITS pairs only; the list's 48 bytes of header per pair are read twice (3 M pairs: 0.03 ms).
-template <bool HAS_VAL, bool HAS_W, typename WT, int PART>
+template <bool HAS_VAL, bool HAS_W, typename WT, int PART, int TKC>
 __global__ __launch_bounds__(PI_WAVES * 64) void pair_scores_kernel(
     const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col, const float *__restrict__ val,
     const WT *__restrict__ node_w, const int32_t *__restrict__ pu, const int32_t *__restrict__ pv,
     int64_t n_pairs, unsigned int *__restrict__ next_chunk, int32_t *__restrict__ out_count,
-    float *__restrict__ out_cn, WT *__restrict__ out_ws)
+    float *__restrict__ out_cn, WT *__restrict__ out_ws, const unsigned int *__restrict__ cls)
 {
+    // (r06) cls = {small pairs, pairs} of a sample of the list (pair_classify_kernel) or NULL: the three launches of a unit-valued
+    // float32 list all go out, and each decides here -- the same two words for everyone -- whether it is the one that runs
+    if (cls) {
+        const bool split = (unsigned long long)cls[0] * 5ull > (unsigned long long)cls[1] * 3ull;      // >= 60 % small pairs
+        if (split != (PART != 0)) return;
+    }
     constexpr bool DEFER = HAS_W && !HAS_VAL && sizeof(WT) == 4;  // unit weights: node_w gathers resolved per 64 pairs
     __shared__ __attribute__((aligned(16))) int32_t s_rows[PI_WAVES][PI_CAP];
     __shared__ uint32_t s_q[PI_WAVES][PI_QCAP];
@@ -90,15 +99,14 @@ __global__ __launch_bounds__(PI_WAVES * 64) void pair_scores_kernel(
 
     // 64-pair chunks are handed out dynamically (pair costs are heavy-tailed); the next ticket is drawn while the
     // current chunk is being scored, so the atomic's round trip is off the critical path.
-    // r06: the small pairs (PART 1: bounded cost) are dealt statically -- no tickets at all --, and the tickets of the split
-    // launches come from EIGHT counters on lines of their own, one per XCD (ticket t of counter y = chunk 8 t + y; an XCD whose
-    // share is used up helps the next): one device word serves ~90 M atomics a second, and a list of 6 M stored-edge pairs in
-    // 64-pair tickets spent 1.0 of its 4.4 ms waiting for it (3 M uniform negatives: 0.5 of 1.0 ms).
-    unsigned int xcc = 0;
-    if (PART == 2) {
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        xcc &= 7u;
-    }
+    // r06: the small pairs (PART 1: bounded cost) are dealt statically -- no tickets at all.  The rest (PART 2) draws tickets of
+    // `tk` consecutive chunks (up to PI_TICKET; 1 for lists too short to give every wave eight tickets): one device word serves
+    // ~90 M atomics a second, and after the split most chunks of an evaluation list hold no work for this part -- 262 k
+    // single-chunk tickets were 2.9 ms for 2^24 uniform pairs.  The draw stays
+    // r04's (one word, the next ticket requested while the current one is scored, its value first looked at when that is done):
+    // eight per-XCD counters with a steal loop were tried twice and lost both times -- testing the drawn value at once cost every
+    // wave the atomic's round trip per chunk (10.7 vs 8.8 ms on 2^24 stored-edge pairs), and the lazy version's bookkeeping took
+    // the kernel from 62 to 71 VGPRs, 8 -> 7 waves per SIMD (11.4 ms): profiles/r06/eval_pairs_variants.txt.
     const int64_t wave_id = (int64_t)blockIdx.x * PI_WAVES + wib, n_waves = (int64_t)gridDim.x * PI_WAVES;
     int64_t static_next = wave_id;
     auto take = [&]() -> int64_t {
@@ -107,29 +115,11 @@ __global__ __launch_bounds__(PI_WAVES * 64) void pair_scores_kernel(
             static_next += n_waves;
             return c;
         }
-        if (PART == 2) {
-            long long got = (long long)n_chunks;
-            if (lane == 0) {
-                for (unsigned int j = 0; j < 8u; ++j) {
-                    const unsigned int y = (xcc + j) & 7u;
-                    const long long c = (long long)atomicAdd(&next_chunk[y * EPS_SPREAD_STRIDE], 1u) * 8ll + (long long)y;
-                    if (c < (long long)n_chunks) {
-                        got = c;
-                        break;
-                    }
-                }
-            }
-            const unsigned int glo = (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)got);
-            const unsigned int ghi = (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)((unsigned long long)got >> 32));
-            return (int64_t)(((unsigned long long)ghi << 32) | glo);
-        }
         unsigned int t = 0;
         if (lane == 0) t = atomicAdd(next_chunk, 1u);
         return (int64_t)(unsigned int)__builtin_amdgcn_readfirstlane((int)t);
     };
-    int64_t chunk = take();
-    while (chunk < n_chunks) {
-        const int64_t next = take();
+    auto do_chunk = [&](const int64_t chunk) {
         const int64_t p = chunk * 64 + lane;
         const bool valid = p < n_pairs;
         const int32_t nu = valid ? pu[p] : 0, nv = valid ? pv[p] : 0;
@@ -173,10 +163,7 @@ __global__ __launch_bounds__(PI_WAVES * 64) void pair_scores_kernel(
 #if PI_SMALL >= 64
         if (PART == 1) {
             uint64_t small = __ballot(is_small);
-            if (!small) {                                                         // (wave-uniform: a chunk of longer rows is part 2's)
-                chunk = next;
-                continue;
-            }
+            if (!small) return;                                                   // (wave-uniform: a chunk of longer rows is part 2's)
             const int g = lane >> 4, gl = lane & 15;
             while (small) {
                 int jg[4];
@@ -353,7 +340,47 @@ __global__ __launch_bounds__(PI_WAVES * 64) void pair_scores_kernel(
             if (out_cn) out_cn[p] = my_cn;
             if (HAS_W && out_ws) out_ws[p] = my_ws;
         }
-        chunk = next;
+    };
+    if (TKC == 1) {                  // (r04's loop, instruction for instruction: the next ticket is in flight while this chunk is scored)
+        int64_t chunk = take();
+        while (chunk < n_chunks) {
+            const int64_t next = take();
+            do_chunk(chunk);
+            chunk = next;
+        }
+    } else {
+        int64_t ticket = take();
+        while (ticket * TKC < n_chunks) {
+            const int64_t next = take();
+            for (int64_t chunk = ticket * TKC; chunk < (ticket + 1) * TKC && chunk < n_chunks; ++chunk) do_chunk(chunk);
+            ticket = next;
+        }
+    }
+}
+
+// {pairs whose longer row has at most PI_SMALL entries (and a non-empty shorter one), valid pairs} of every PI_CLS_STRIDE-th
+// 64-pair chunk of the list -> cls[0], cls[1]: what decides, on the device, which launch shape scores the list.
+#define PI_CLS_STRIDE 16
+__global__ __launch_bounds__(PI_WAVES * 64) void pair_classify_kernel(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ pu,
+                                                                      const int32_t *__restrict__ pv, int64_t n_pairs,
+                                                                      unsigned int *__restrict__ cls)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t n_chunks = (n_pairs + 63) >> 6;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    unsigned int small = 0u, all = 0u;
+    for (int64_t c = wave * PI_CLS_STRIDE; c < n_chunks; c += n_waves * PI_CLS_STRIDE) {
+        const int64_t p = c * 64 + lane;
+        const bool valid = p < n_pairs;
+        const int32_t nu = valid ? pu[p] : 0, nv = valid ? pv[p] : 0;
+        const int32_t du = valid ? (int32_t)(rowptr[nu + 1] - rowptr[nu]) : 0, dv = valid ? (int32_t)(rowptr[nv + 1] - rowptr[nv]) : 0;
+        const int32_t mx = du > dv ? du : dv, mn = du < dv ? du : dv;
+        small += (unsigned int)__popcll(__ballot(valid && mn > 0 && mx <= PI_SMALL));
+        all += (unsigned int)__popcll(__ballot(valid));
+    }
+    if (lane == 0 && all) {
+        atomicAdd(&cls[0], small);
+        atomicAdd(&cls[1], all);
     }
 }
 
@@ -367,30 +394,50 @@ static int launch_pair_scores(const int64_t *rowptr, const int32_t *col, const f
     int64_t blocks = (n_chunks + PI_WAVES - 1) / PI_WAVES;
     const int64_t max_blocks = (int64_t)eps_num_cus() * 8;  // 32 waves per CU
     if (blocks > max_blocks) blocks = max_blocks;
-    unsigned int *counter = nullptr, *counter2 = nullptr;
+    unsigned int *counter = nullptr, *counter2 = nullptr, *cls = nullptr;
     int crc = eps_take_counter(&counter, stream, "eps_pair_scores");
     if (crc) return crc;
     dim3 grid((unsigned)blocks), block(PI_WAVES * 64);
     const bool hv = val != nullptr, hw = node_w != nullptr && wsum != nullptr;
     constexpr bool F32 = sizeof(WT) == 4;
-#define PI_LAUNCH(HV, HW, PART, CTR) \
-    hipLaunchKernelGGL((pair_scores_kernel<HV, HW, WT, PART>), grid, block, 0, stream, rowptr, col, val, node_w, u, v, \
-                       n_pairs, CTR, count, cn, wsum)
-    if (hv && hw) PI_LAUNCH(true, true, 0, counter);
-    else if (hv) PI_LAUNCH(true, false, 0, counter);
+    const unsigned int *no_cls = nullptr;
+#define PI_LAUNCH(HV, HW, PART, CTR, CLS, TKV) \
+    hipLaunchKernelGGL((pair_scores_kernel<HV, HW, WT, PART, TKV>), grid, block, 0, stream, rowptr, col, val, node_w, u, v, \
+                       n_pairs, CTR, count, cn, wsum, CLS)
+    if (hv && hw) PI_LAUNCH(true, true, 0, counter, no_cls, 1);
+    else if (hv) PI_LAUNCH(true, false, 0, counter, no_cls, 1);
     else if (!F32) {
-        if (hw) PI_LAUNCH(false, true, 0, counter);
-        else PI_LAUNCH(false, false, 0, counter);
+        if (hw) PI_LAUNCH(false, true, 0, counter, no_cls, 1);
+        else PI_LAUNCH(false, false, 0, counter, no_cls, 1);
     } else {
-        // unit values, float32 weights: the small pairs four at a time, then the rest (see the kernel's PART)
-        crc = eps_take_counters8_spread(&counter2, stream, "eps_pair_scores");
+        // Unit values, float32 weights (the evaluation lists of train_and_eval.py:108-136).  Which shape wins depends on the list: mostly
+        // small pairs (uniform negatives) -> the split (small pairs four at a time in a launch of their own + the rest: 2^24 pairs
+        // 3.40 ms against 4.09 for one pair at a time); mostly stored edges (hub-heavy) -> every pair one at a time, r04's body
+        // (8.80 ms against 10.2 split).  A sample of the list is classified on the device (every 16th chunk: small pairs / pairs), all
+        // three launches go out, and each looks at the two words and runs or returns -- no host read.
+        crc = eps_take_counter(&counter2, stream, "eps_pair_scores");
         if (crc) return crc;
+        crc = eps_take_counters8(&cls, stream, "eps_pair_scores");
+        if (crc) return crc;
+        {
+            const int64_t sampled = (n_chunks + PI_CLS_STRIDE - 1) / PI_CLS_STRIDE;
+            int64_t cb = (sampled + PI_WAVES - 1) / PI_WAVES;
+            if (cb > max_blocks) cb = max_blocks;
+            hipLaunchKernelGGL(pair_classify_kernel, dim3((unsigned)cb), block, 0, stream, rowptr, u, v, n_pairs, cls);
+        }
+        // (tickets of PI_TICKET chunks once every wave still gets eight of them)
+        int64_t tk64 = n_chunks / (blocks * PI_WAVES * 8);
+        const int tk = (int)(tk64 < 1 ? 1 : (tk64 > PI_TICKET ? PI_TICKET : tk64));
         if (hw) {
-            PI_LAUNCH(false, true, F32 ? 1 : 0, counter);
-            PI_LAUNCH(false, true, F32 ? 2 : 0, counter2);
+            PI_LAUNCH(false, true, 1, counter, cls, 1);
+            if (tk >= PI_TICKET) PI_LAUNCH(false, true, 2, counter2, cls, PI_TICKET);
+            else PI_LAUNCH(false, true, 2, counter2, cls, 1);
+            PI_LAUNCH(false, true, 0, counter, cls, 1);
         } else {
-            PI_LAUNCH(false, false, F32 ? 1 : 0, counter);
-            PI_LAUNCH(false, false, F32 ? 2 : 0, counter2);
+            PI_LAUNCH(false, false, 1, counter, cls, 1);
+            if (tk >= PI_TICKET) PI_LAUNCH(false, false, 2, counter2, cls, PI_TICKET);
+            else PI_LAUNCH(false, false, 2, counter2, cls, 1);
+            PI_LAUNCH(false, false, 0, counter, cls, 1);
         }
     }
 #undef PI_LAUNCH

@@ -1316,7 +1316,11 @@ __global__ __launch_bounds__(RS_THREADS, RS_MINW) void rescore_runs_kernel(const
                                 const int32_t w = wv[b >> 2][b & 3];
                                 const uint32_t x = (uint32_t)(w - wlo);
                                 const bool hit = i < ve && x < (uint32_t)RS_BITS && ((bm[x >> 5] >> (x & 31)) & 1u);
+#ifdef RS_ABL_NOWEIGHT           /* (timing-only ablation, wrong results: what the dependent weight gathers of a trip cost) */
+                                add[bb] = hit ? 1ll : 0ll;
+#else
                                 add[bb] = hit ? (long long)fixw[w] : 0ll;
+#endif
                             }
 #pragma unroll
                             for (int bb = 0; bb < RS_GB; ++bb) acc += add[bb];
