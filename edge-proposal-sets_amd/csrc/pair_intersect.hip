@@ -100,7 +100,7 @@ __global__ __launch_bounds__(PI_WAVES * 64) void pair_scores_kernel(
     // 64-pair chunks are handed out dynamically (pair costs are heavy-tailed); the next ticket is drawn while the
     // current chunk is being scored, so the atomic's round trip is off the critical path.
     // r06: the small pairs (PART 1: bounded cost) are dealt statically -- no tickets at all.  The rest (PART 2) draws tickets of
-    // `tk` consecutive chunks (up to PI_TICKET; 1 for lists too short to give every wave eight tickets): one device word serves
+    // PI_TICKET consecutive chunks: one device word serves
     // ~90 M atomics a second, and after the split most chunks of an evaluation list hold no work for this part -- 262 k
     // single-chunk tickets were 2.9 ms for 2^24 uniform pairs.  The draw stays
     // r04's (one word, the next ticket requested while the current one is scored, its value first looked at when that is done):
@@ -425,18 +425,15 @@ static int launch_pair_scores(const int64_t *rowptr, const int32_t *col, const f
             if (cb > max_blocks) cb = max_blocks;
             hipLaunchKernelGGL(pair_classify_kernel, dim3((unsigned)cb), block, 0, stream, rowptr, u, v, n_pairs, cls);
         }
-        // (tickets of PI_TICKET chunks once every wave still gets eight of them)
-        int64_t tk64 = n_chunks / (blocks * PI_WAVES * 8);
-        const int tk = (int)(tk64 < 1 ? 1 : (tk64 > PI_TICKET ? PI_TICKET : tk64));
+        // (the split only runs on lists of mostly small pairs, where the launch of the longer pairs finds little to do: tickets of
+        //  PI_TICKET chunks whatever the list's length -- 3 M negatives drew 47 k single-chunk tickets for 0.5 of their 1.16 ms)
         if (hw) {
             PI_LAUNCH(false, true, 1, counter, cls, 1);
-            if (tk >= PI_TICKET) PI_LAUNCH(false, true, 2, counter2, cls, PI_TICKET);
-            else PI_LAUNCH(false, true, 2, counter2, cls, 1);
+            PI_LAUNCH(false, true, 2, counter2, cls, PI_TICKET);
             PI_LAUNCH(false, true, 0, counter, cls, 1);
         } else {
             PI_LAUNCH(false, false, 1, counter, cls, 1);
-            if (tk >= PI_TICKET) PI_LAUNCH(false, false, 2, counter2, cls, PI_TICKET);
-            else PI_LAUNCH(false, false, 2, counter2, cls, 1);
+            PI_LAUNCH(false, false, 2, counter2, cls, PI_TICKET);
             PI_LAUNCH(false, false, 0, counter, cls, 1);
         }
     }

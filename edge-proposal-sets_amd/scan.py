@@ -982,10 +982,10 @@ def scan_topk(g: CSRGraph, node_w: torch.Tensor, k: int, rank: int = 0, world: i
         fast = (TAIL_DEVICE and world == 1 and screen is not None and g.val is None and bar is not None and not rescore_all
                 and k2 + (1 << 16) < (1 << 30))
         if fast:
-            # r06: the whole tail on the device, sizes included -- score-bucket histograms instead of four-round radix selects, the
-            # two orderings as one cooperative radix sort each, the rows sorted BEFORE the step's one host read (which then only
-            # confirms them).  The cut is the lower edge of the bucket that holds the k2-th best exact score (<= the exact cut, a few
-            # pairs more are mirrored and sorted; the K rows are the same), the pre-filter threshold likewise.
+            # r06: the step's selections come from score-bucket histograms instead of four-round radix selects: the pre-filter
+            # threshold and the cut are the lower edges of the buckets that hold the k2-th best screening / exact score (<= the exact
+            # order statistics: a few pairs more are re-scored, mirrored and sorted; the K rows are the same -- both are verified
+            # below).  The two orderings: TAIL_SORT.
             a, b = screen.lower_params(max_degree(g), None if ht is None else ht.d_used)
             bits = max(1, min(32, int(g.n_rows - 1).bit_length()))
             room = min(res.capacity, 2 * k2 + (1 << 16))

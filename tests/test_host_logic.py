@@ -379,3 +379,24 @@ def test_deal_plan_partitions_the_selection_for_one_all_to_all(world, ties):
         got_k, got_v = torch.cat([ck for ck, _ in chunks])[:k], torch.cat([cv for _, cv in chunks])[:k]
         want_k, want_v = scan.select_topk_torch(all_k[all_v >= cut], all_v[all_v >= cut], k)
         assert torch.equal(got_k, want_k) and torch.equal(got_v, want_v), (world, ties, k2)
+
+
+def test_sharded_proposal_files_read_back_in_rank_order(tmp_path):
+    """filter.py --shard_proposals leaves <file>.shard{r}of{N} (each rank the chunk of the sorted list it ordered); the reader that
+    rank.py goes through (proposals.load_proposals, rank.py:219 + :294) concatenates them in rank order, prefers a plain file when
+    one exists, and refuses a list with a missing shard."""
+    import torch
+    from eps_amd import proposals
+    rows = torch.cat([torch.arange(30, dtype=torch.float32).view(10, 3), torch.arange(30, 60, dtype=torch.float32).view(10, 3)])
+    path = str(tmp_path / "x_sorted_edges.pt")
+    parts = [rows[:7], rows[7:7], rows[7:]]                           # (an empty shard in the middle)
+    for r, part in enumerate(parts):
+        proposals.save_sorted_edges_shard(path, part, r, 3)
+    assert torch.equal(proposals.load_sorted_edges(path), rows)
+    assert torch.equal(proposals.load_proposals(path, 9), rows[:9, :2].t().long())
+    import os
+    os.remove(proposals.shard_path(path, 1, 3))
+    with pytest.raises(FileNotFoundError):
+        proposals.load_sorted_edges(path)
+    proposals.save_sorted_edges(path, rows[:5])
+    assert torch.equal(proposals.load_sorted_edges(path), rows[:5])   # (a plain file wins)
