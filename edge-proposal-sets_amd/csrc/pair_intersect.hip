@@ -23,6 +23,7 @@
 //     binary search), so a degree-100k hub costs log2(d) probes per element of the short row instead of a full read.
 // HBM traffic is the algorithmic minimum: both rows once, coalesced; rowptr/pair/outputs once.
 #include "pair_common.h"
+#include <stdlib.h>
 
 #define PI_WAVES 4           // waves per workgroup
 #define PI_CAP 1024          // long-row entries staged per wave and pass (4 KiB of LDS per wave)
@@ -419,7 +420,15 @@ static int launch_pair_scores(const int64_t *rowptr, const int32_t *col, const f
         if (crc) return crc;
         crc = eps_take_counters8(&cls, stream, "eps_pair_scores");
         if (crc) return crc;
-        {
+        // (EPS_PAIR_SHAPE=split | single in the environment pins the shape for same-box A/Bs: tools/eval_pairs_bench.py)
+        static const int pinned = [] { const char *e = getenv("EPS_PAIR_SHAPE"); return !e ? 0 : (e[0] == 's' && e[1] == 'p') ? 1 : 2; }();
+        if (pinned) {
+            const unsigned int words[2] = {pinned == 1 ? 1u : 0u, 1u};       // {small, all}: all small -> split; none -> one at a time
+            if (hipMemcpyAsync(cls, words, sizeof(words), hipMemcpyHostToDevice, stream) != hipSuccess) {
+                eps_set_error("eps_pair_scores: cannot pin the launch shape");
+                return EPS_ELAUNCH;
+            }
+        } else {
             const int64_t sampled = (n_chunks + PI_CLS_STRIDE - 1) / PI_CLS_STRIDE;
             int64_t cb = (sampled + PI_WAVES - 1) / PI_WAVES;
             if (cb > max_blocks) cb = max_blocks;

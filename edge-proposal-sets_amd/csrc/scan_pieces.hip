@@ -275,7 +275,9 @@ __global__ __launch_bounds__(T, 4) void scan_piece_kernel(sp_params p)      // (
     // Survivor slots are reserved in chunks (one global atomic each).  Without a bar every candidate of a piece survives: the
     // chunk holds a whole piece's yield.  With one, survivors are rare: a piece asks for room for 1024, and a survivor that
     // does not fit its workgroup's reservation takes a slot of its own (one more global atomic: rare).
-    const bool no_bar = thr32 <= 1u;
+    // (FULL: a launch with heads has a bar -- a column whose head cannot be honoured is left out below -- so the chunk size is a
+    //  constant there; a caller that passes heads without a bar still gets every survivor, through single slots)
+    const bool no_bar = !FULL && thr32 <= 1u;
     const bool raw_sums = FULL || p.heads != nullptr;
     const uint32_t chunk = no_bar && direct_ids > 8192u ? direct_ids : 8192u;
     const int32_t my_bound = p.bounds[lane <= SP_M ? lane : SP_M];      // lane k holds window boundary k (the plan runs in wave 0)

@@ -112,7 +112,8 @@ def _load_proposals(args, split_edge) -> torch.Tensor:
     """The proposal file of the filter stage (rank.py:214-257): float rows (u, v, score), best first."""
     if not args.sorted_edge_path:
         return torch.zeros(42, 2)
-    rows = torch.load(f"filtered_edges/{args.sorted_edge_path}")
+    from . import proposals                      # (a sharded filter run may have left <file>.shard{r}of{N}: read back in rank order)
+    rows = proposals.load_sorted_edges(f"filtered_edges/{args.sorted_edge_path}")
     print('sorted test edges', rows.size())
     return splice_valid_proposals(rows, split_edge['valid']['edge']) if args.valid_proposal else rows
 

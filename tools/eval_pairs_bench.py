@@ -7,7 +7,7 @@ dev = torch.device("cuda:0")
 g = synth.ppa_like(seed=3, device=dev)
 w = node_weight_table(g, ops.W_AA)
 gen = torch.Generator(device=dev).manual_seed(0)
-E = 1 << 24
+E = int(os.environ.get('E', 1 << 24))
 u = torch.randint(0, g.n_rows, (E,), generator=gen, device=dev, dtype=torch.int32)
 v = torch.randint(0, g.n_rows, (E,), generator=gen, device=dev, dtype=torch.int32)
 row, col, _ = g.coo()
