@@ -76,21 +76,38 @@ __global__ void sel_cut_kernel(const int64_t *__restrict__ keys, const float *__
 
 __global__ void sel_count_kernel(const sel_state *__restrict__ st, int64_t *__restrict__ n_sel) { *n_sel = (int64_t)st->n_sel; }
 
+// r06: the rows' sort key is PACKED -- (v << id_bits) | u instead of v << 32 | u -- so that ONE radix sort over 2 id_bits bits orders
+// the rows by (v, u): five 8-bit passes for 2^20 nodes instead of three for u and three for v (and one histogram launch instead of two)
 __global__ void sel_mirror_kernel(const int64_t *__restrict__ keys, const float *__restrict__ vals, int64_t m,
-                                  const int64_t *__restrict__ perm, int64_t *__restrict__ dkeys, float *__restrict__ dvals)
+                                  const int64_t *__restrict__ perm, int id_bits, int64_t *__restrict__ dkeys, float *__restrict__ dvals)
 {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += stride) {
-        int64_t k = keys[i];
+        const int64_t k = keys[i];
         const float s = vals[i];
+        uint64_t a = (uint64_t)k & 0xFFFFFFFFull, b = (uint64_t)k >> 32;          // (u, v): v the larger id
         if (perm) {      // ids of a relabelled graph back to the caller's: new id i is old id perm[i]; the larger one is "v" again
-            const int64_t a = perm[(uint64_t)k & 0xFFFFFFFFull], b = perm[(uint64_t)k >> 32];
-            k = a < b ? ((b << 32) | a) : ((a << 32) | b);
+            const uint64_t pa = (uint64_t)perm[a], pb = (uint64_t)perm[b];
+            a = pa < pb ? pa : pb;
+            b = pa < pb ? pb : pa;
         }
-        dkeys[i] = k;
-        dkeys[m + i] = (int64_t)((((uint64_t)k & 0xFFFFFFFFull) << 32) | ((uint64_t)k >> 32));
+        dkeys[i] = (int64_t)((b << id_bits) | a);                                 // row (u = a, v = b)
+        dkeys[m + i] = (int64_t)((a << id_bits) | b);                             // its mirror (u = b, v = a)
         dvals[i] = s;
         dvals[m + i] = s;
+    }
+}
+
+// the first `take` sorted rows: packed key -> v << 32 | u, score alongside
+__global__ void sel_unpack_rows_kernel(const int64_t *__restrict__ pk, const float *__restrict__ pv, int64_t take, int id_bits,
+                                       int64_t *__restrict__ out_keys, float *__restrict__ out_vals)
+{
+    const uint64_t idm = id_bits >= 64 ? ~0ull : (1ull << id_bits) - 1ull;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < take; i += stride) {
+        const uint64_t k = (uint64_t)pk[i];
+        out_keys[i] = (int64_t)(((k >> id_bits) << 32) | (k & idm));
+        out_vals[i] = pv[i];
     }
 }
 
@@ -255,28 +272,18 @@ static int sel_rows(const int64_t *sel_keys, const float *sel_vals, int64_t m, i
     float *v1 = (float *)w;                            w += sel_align(rows * 4);
     void *temp = w;
     size_t temp_bytes = sel_sort_temp_bytes((int64_t)rows);
-    hipLaunchKernelGGL(sel_mirror_kernel, dim3(sel_blocks(m)), dim3(256), 0, s, sel_keys, sel_vals, m, perm, k0, v0);
-    // stable LSD sorts, least significant criterion first: u (low id bits), v (high id bits), then the score, descending
-    hipError_t e;
-    if (id_bits >= 24) {         // (nearly) all bits count: one sort over the whole key (non-negative: the sign bit is idle)
-        e = rocprim::radix_sort_pairs(temp, temp_bytes, k0, k1, v0, v1, rows, 0u, 63u, s);
-        if (e == hipSuccess) e = hipMemcpyAsync(k0, k1, rows * 8, hipMemcpyDeviceToDevice, s);
-        if (e == hipSuccess) e = hipMemcpyAsync(v0, v1, rows * 4, hipMemcpyDeviceToDevice, s);
-    } else {
-        e = rocprim::radix_sort_pairs(temp, temp_bytes, k0, k1, v0, v1, rows, 0u, (unsigned)id_bits, s);
-        if (e == hipSuccess) e = rocprim::radix_sort_pairs(temp, temp_bytes, k1, k0, v1, v0, rows, 32u, 32u + (unsigned)id_bits, s);
-    }
-    if (e != hipSuccess ||
-        rocprim::radix_sort_pairs_desc(temp, temp_bytes, v0, v1, k0, k1, rows, 0u, 32u, s) != hipSuccess) {
+    hipLaunchKernelGGL(sel_mirror_kernel, dim3(sel_blocks(m)), dim3(256), 0, s, sel_keys, sel_vals, m, perm, (int)id_bits, k0, v0);
+    // stable LSD sorts, least significant criterion first: (v, u) as ONE packed key of 2 id_bits bits, then the score, descending
+    // (2 id_bits = 64 only for id_bits = 32, whose keys are non-negative int64 with an idle sign bit: 63 bits suffice there)
+    const unsigned key_bits = 2u * (unsigned)id_bits > 63u ? 63u : 2u * (unsigned)id_bits;
+    if (rocprim::radix_sort_pairs(temp, temp_bytes, k0, k1, v0, v1, rows, 0u, key_bits, s) != hipSuccess ||
+        rocprim::radix_sort_pairs_desc(temp, temp_bytes, v1, v0, k1, k0, rows, 0u, 32u, s) != hipSuccess) {
         eps_set_error("eps_select_topk_rows: radix sort failed");
         return EPS_ELAUNCH;
     }
     const size_t take = (size_t)k < rows ? (size_t)k : rows;
-    if (hipMemcpyAsync(out_keys, k1, take * 8, hipMemcpyDeviceToDevice, s) != hipSuccess ||
-        hipMemcpyAsync(out_vals, v1, take * 4, hipMemcpyDeviceToDevice, s) != hipSuccess) {
-        eps_set_error("eps_select_topk_rows: cannot copy the rows out");
-        return EPS_ELAUNCH;
-    }
+    hipLaunchKernelGGL(sel_unpack_rows_kernel, dim3(sel_blocks((int64_t)take)), dim3(256), 0, s, k0, v0, (int64_t)take, (int)id_bits, out_keys,
+                       out_vals);
     EPS_CHECK_LAUNCH("eps_select_topk_rows");
     return EPS_OK;
 }
@@ -284,12 +291,15 @@ static int sel_rows(const int64_t *sel_keys, const float *sel_vals, int64_t m, i
 // ---- survivor keys grouped by their smaller endpoint, for eps_rescore_runs ------------------------------------------------------
 // keys = v << 32 | u (u < v, any order) -> out = u << 32 | v sorted by (u, v): runs of equal u, v ascending inside a run -- two
 // stable radix sorts over the id bits of v, then of u (six passes for 2^20 nodes instead of the eight of a 64-bit sort).
-__global__ void sel_swap_kernel(const int64_t *__restrict__ keys, int64_t n, int64_t *__restrict__ out)
+// r06: the sort key is PACKED -- (u << id_bits) | v -- so that ONE radix sort over 2 id_bits bits gives the (u, v) order (five 8-bit
+// passes for 2^20 nodes instead of three for v and three for u); the result is unpacked to (u << 32) | v by the kernel that also
+// decides between the (u, v) and the (v block, u, v) order.
+__global__ void sel_swap_kernel(const int64_t *__restrict__ keys, int64_t n, int id_bits, int64_t *__restrict__ out)
 {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const uint64_t k = (uint64_t)keys[i];
-        out[i] = (int64_t)((k << 32) | (k >> 32));
+        const uint64_t k = (uint64_t)keys[i];                                     // v << 32 | u
+        out[i] = (int64_t)(((k & 0xFFFFFFFFull) << id_bits) | (k >> 32));         // (u << id_bits) | v
     }
 }
 
@@ -298,27 +308,36 @@ __global__ void sel_swap_kernel(const int64_t *__restrict__ keys, int64_t n, int
 // with 1529 distinct u -- 4157 runs in blocks of 2^12 v, 500 pairs each, and the blocks save 0.3 of 2.7 ms; resource allocation:
 // 168 k distinct u -- 1.16 M runs of 1.8 pairs, 6.7 ms against 2.1 ms without blocks.  The call sorts both ways and keeps the
 // blocked order only when its runs average at least SEL_BLOCK_MIN_RUN pairs: counted and decided on the device, no host read.
+// (keys here are packed: u = key >> id_bits, v = key & (2^id_bits - 1))
 #define SEL_BLOCK_MIN_RUN 64ull
-__global__ __launch_bounds__(256) void sel_count_runs_kernel(const int64_t *__restrict__ by_block, int64_t n, int shift,
+__global__ __launch_bounds__(256) void sel_count_runs_kernel(const int64_t *__restrict__ by_block, int64_t n, int shift, int id_bits,
                                                              unsigned long long *__restrict__ runs)
 {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const uint64_t idm = id_bits >= 64 ? ~0ull : (1ull << id_bits) - 1ull;
     unsigned int c = 0u;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         const uint64_t k = (uint64_t)by_block[i], kp = i ? (uint64_t)by_block[i - 1] : ~k;
-        c += (k >> 32) != (kp >> 32) || ((uint32_t)k >> shift) != ((uint32_t)kp >> shift) ? 1u : 0u;
+        c += (k >> id_bits) != (kp >> id_bits) || ((k & idm) >> shift) != ((kp & idm) >> shift) ? 1u : 0u;
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) c += __shfl_xor(c, d);
     if ((threadIdx.x & 63) == 0 && c) atomicAdd(runs, (unsigned long long)c);
 }
 
-__global__ __launch_bounds__(256) void sel_take_blocked_kernel(const int64_t *__restrict__ by_block, int64_t n,
-                                                               const unsigned long long *__restrict__ runs, int64_t *__restrict__ out)
+// out[i] = (u << 32) | v of the order that is kept: the blocked one while its runs stay long (runs given), else the (u, v) one
+__global__ __launch_bounds__(256) void sel_take_unpack_kernel(const int64_t *__restrict__ by_uv, const int64_t *__restrict__ by_block,
+                                                              int64_t n, int id_bits, const unsigned long long *__restrict__ runs,
+                                                              int64_t *__restrict__ out)
 {
-    if (*runs * SEL_BLOCK_MIN_RUN > (unsigned long long)n) return;       // short runs: the (u, v) order stays
+    const bool blocked = by_block != nullptr && *runs * SEL_BLOCK_MIN_RUN <= (unsigned long long)n;
+    const int64_t *__restrict__ src = blocked ? by_block : by_uv;
+    const uint64_t idm = id_bits >= 64 ? ~0ull : (1ull << id_bits) - 1ull;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = by_block[i];
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const uint64_t k = (uint64_t)src[i];
+        out[i] = (int64_t)(((k >> id_bits) << 32) | (k & idm));
+    }
 }
 
 static size_t sel_by_u_temp_bytes(int64_t n)
@@ -331,7 +350,7 @@ static size_t sel_by_u_temp_bytes(int64_t n)
 extern "C" int64_t eps_sort_pairs_by_u_workspace_bytes(int64_t n)
 {
     if (n <= 0) return 256;
-    return (int64_t)(sel_align((size_t)n * 8) + 256 + sel_align(sel_by_u_temp_bytes(n)));      // (256: the run counter)
+    return (int64_t)(2 * sel_align((size_t)n * 8) + 256 + sel_align(sel_by_u_temp_bytes(n)));      // (two key buffers; 256: the run counter)
 }
 
 extern "C" int eps_sort_pairs_by_u(const int64_t *keys, int64_t n, int32_t id_bits, int32_t v_block_shift, int64_t *out_by_u,
@@ -344,40 +363,44 @@ extern "C" int eps_sort_pairs_by_u(const int64_t *keys, int64_t n, int32_t id_bi
     EPS_REQUIRE(workspace && ((uintptr_t)workspace & 255) == 0 && workspace_bytes >= eps_sort_pairs_by_u_workspace_bytes(n),
                 "eps_sort_pairs_by_u: needs a 256-byte aligned workspace of eps_sort_pairs_by_u_workspace_bytes(n) bytes");
     hipStream_t s = (hipStream_t)stream;
-    int64_t *swapped = (int64_t *)workspace;
-    unsigned long long *runs = (unsigned long long *)((char *)workspace + sel_align((size_t)n * 8));
-    void *temp = (char *)workspace + sel_align((size_t)n * 8) + 256;
-    size_t temp_bytes = (size_t)workspace_bytes - sel_align((size_t)n * 8) - 256;
+    int64_t *buf_a = (int64_t *)workspace;
+    int64_t *buf_b = (int64_t *)((char *)workspace + sel_align((size_t)n * 8));
+    unsigned long long *runs = (unsigned long long *)((char *)workspace + 2 * sel_align((size_t)n * 8));
+    void *temp = (char *)workspace + 2 * sel_align((size_t)n * 8) + 256;
+    size_t temp_bytes = (size_t)workspace_bytes - 2 * sel_align((size_t)n * 8) - 256;
+    const bool want_blocks = v_block_shift > 0 && v_block_shift < id_bits;
+    // (2 id_bits = 64 only for id_bits = 32: u < 2^31 there, the top bit is idle)
+    const unsigned key_bits = 2u * (unsigned)id_bits > 63u ? 63u : 2u * (unsigned)id_bits;
     {   // (the workspace was sized by a query over all 64 bits; the passes below sort narrower ranges -- ask rocPRIM about each of
         //  them instead of trusting that its temporary storage does not depend on the range)
-        const unsigned ranges[3][2] = {{0u, (unsigned)id_bits}, {32u, 32u + (unsigned)id_bits}, {(unsigned)v_block_shift, (unsigned)id_bits}};
-        for (int r = 0; r < (v_block_shift > 0 && v_block_shift < id_bits ? 3 : 2); ++r) {
+        const unsigned ranges[2][2] = {{0u, key_bits}, {(unsigned)v_block_shift, (unsigned)id_bits}};
+        for (int r = 0; r < (want_blocks ? 2 : 1); ++r) {
             size_t need = 0;
             (void)rocprim::radix_sort_keys((void *)nullptr, need, (const int64_t *)nullptr, (int64_t *)nullptr, (size_t)n, ranges[r][0],
                                            ranges[r][1], (hipStream_t)0);
             EPS_REQUIRE(need <= temp_bytes, "eps_sort_pairs_by_u: the workspace is too small for a %u..%u-bit pass", ranges[r][0], ranges[r][1]);
         }
     }
-    hipLaunchKernelGGL(sel_swap_kernel, dim3(sel_blocks(n)), dim3(256), 0, s, keys, n, out_by_u);
-    // (LSD: v first, then u -- inside a run the rows N(v) are then streamed in ascending v, which is worth 0.4 of 3.3 ms to
-    //  eps_rescore_runs on the ppa-like graph: neighbouring pairs read neighbouring rows)
-    if (rocprim::radix_sort_keys(temp, temp_bytes, out_by_u, swapped, (size_t)n, 0u, (unsigned)id_bits, s) != hipSuccess ||
-        rocprim::radix_sort_keys(temp, temp_bytes, swapped, out_by_u, (size_t)n, 32u, 32u + (unsigned)id_bits, s) != hipSuccess) {
+    hipLaunchKernelGGL(sel_swap_kernel, dim3(sel_blocks(n)), dim3(256), 0, s, keys, n, (int)id_bits, out_by_u);
+    // (one sort over the packed key: inside a run of equal u the rows N(v) are then streamed in ascending v, which is worth 0.4 of
+    //  3.3 ms to eps_rescore_runs on the ppa-like graph: neighbouring pairs read neighbouring rows)
+    if (rocprim::radix_sort_keys(temp, temp_bytes, out_by_u, buf_a, (size_t)n, 0u, key_bits, s) != hipSuccess) {
         eps_set_error("eps_sort_pairs_by_u: radix sort failed");
         return EPS_ELAUNCH;
     }
-    if (v_block_shift > 0 && v_block_shift < id_bits) {
+    if (want_blocks) {
         // blocks of 2^v_block_shift consecutive v first: (v block, u, v) -- the workgroups that run side by side then stream the
         // rows of ONE block of v, which stay in the L2 (the same row is wanted by every u it is paired with) -- kept only
         // while the runs stay long (sel_count_runs_kernel)
         if (hipMemsetAsync(runs, 0, sizeof(unsigned long long), s) != hipSuccess ||
-            rocprim::radix_sort_keys(temp, temp_bytes, out_by_u, swapped, (size_t)n, (unsigned)v_block_shift, (unsigned)id_bits, s) != hipSuccess) {
+            rocprim::radix_sort_keys(temp, temp_bytes, buf_a, buf_b, (size_t)n, (unsigned)v_block_shift, (unsigned)id_bits, s) != hipSuccess) {
             eps_set_error("eps_sort_pairs_by_u: radix sort failed");
             return EPS_ELAUNCH;
         }
-        hipLaunchKernelGGL(sel_count_runs_kernel, dim3(sel_blocks(n)), dim3(256), 0, s, swapped, n, (int)v_block_shift, runs);
-        hipLaunchKernelGGL(sel_take_blocked_kernel, dim3(sel_blocks(n)), dim3(256), 0, s, swapped, n, runs, out_by_u);
+        hipLaunchKernelGGL(sel_count_runs_kernel, dim3(sel_blocks(n)), dim3(256), 0, s, buf_b, n, (int)v_block_shift, (int)id_bits, runs);
     }
+    hipLaunchKernelGGL(sel_take_unpack_kernel, dim3(sel_blocks(n)), dim3(256), 0, s, buf_a, want_blocks ? buf_b : (const int64_t *)nullptr, n,
+                       (int)id_bits, runs, out_by_u);
     EPS_CHECK_LAUNCH("eps_sort_pairs_by_u");
     return EPS_OK;
 }
