@@ -77,6 +77,7 @@ SIGNATURES = {
     "eps_kth_largest_workspace_bytes": (_i64, []),
     "eps_kth_largest_f32": (_int, [_vp, _i64, _i64, _vp, _vp, _vp]),
     "eps_select_topk_rows_relabelled": (_int, [_vp, _vp, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _i64, _vp]),
+    "eps_select_topk_rows_pairs": (_int, [_vp, _vp, _i64, _i64, _i32, _vp, _vp, _i64, _vp, _vp, _i64, _vp]),
     "eps_sort_pairs_by_u_workspace_bytes": (_i64, [_i64]),
     "eps_sort_pairs_by_u": (_int, [_vp, _i64, _i32, _i32, _vp, _vp, _i64, _vp]),
     "eps_compact_between": (_int, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),

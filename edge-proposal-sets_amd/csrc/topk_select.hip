@@ -111,6 +111,20 @@ __global__ void sel_unpack_rows_kernel(const int64_t *__restrict__ pk, const flo
     }
 }
 
+// ... or as the proposal tensor itself: pairs[i] = u, pairs[ld + i] = v (what rank.py:294 reads: `[:k, :2].t().long()`)
+__global__ void sel_unpack_pairs_kernel(const int64_t *__restrict__ pk, const float *__restrict__ pv, int64_t take, int id_bits,
+                                        int64_t *__restrict__ out_pairs, int64_t ld, float *__restrict__ out_vals)
+{
+    const uint64_t idm = id_bits >= 64 ? ~0ull : (1ull << id_bits) - 1ull;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < take; i += stride) {
+        const uint64_t k = (uint64_t)pk[i];
+        out_pairs[i] = (int64_t)(k & idm);
+        out_pairs[ld + i] = (int64_t)(k >> id_bits);
+        out_vals[i] = pv[i];
+    }
+}
+
 static size_t sel_align(size_t x) { return (x + 255) & ~(size_t)255; }
 
 static size_t sel_sort_temp_bytes(int64_t rows)
@@ -236,7 +250,8 @@ extern "C" int64_t eps_select_topk_rows_workspace_bytes(int64_t m)
 // Step 2: the m selected pairs (m read back by the caller) -> both orientations, sorted by the declared rule; the first
 // min(k, 2 m) rows go to out_keys / out_vals.  id_bits: every id is below 2^id_bits (1..32): the key sort skips the other bits.
 static int sel_rows(const int64_t *sel_keys, const float *sel_vals, int64_t m, int64_t k, int32_t id_bits, const int64_t *perm,
-                    int64_t *out_keys, float *out_vals, void *workspace, int64_t workspace_bytes, void *stream);
+                    int64_t *out_keys, float *out_vals, void *workspace, int64_t workspace_bytes, void *stream, int64_t *out_pairs = nullptr,
+                    int64_t pairs_ld = 0);
 
 extern "C" int eps_select_topk_rows(const int64_t *sel_keys, const float *sel_vals, int64_t m, int64_t k, int32_t id_bits,
                                     int64_t *out_keys, float *out_vals, void *workspace, int64_t workspace_bytes, void *stream)
@@ -254,12 +269,23 @@ extern "C" int eps_select_topk_rows_relabelled(const int64_t *sel_keys, const fl
     return sel_rows(sel_keys, sel_vals, m, k, id_bits, perm, out_keys, out_vals, workspace, workspace_bytes, stream);
 }
 
+// The same rows written as the [2, k] proposal tensor (u row, v row; row stride pairs_ld >= min(k, 2 m)) -- r06: the split of the
+// sorted keys into two id rows was three tensor kernels over 4 M rows per step
+extern "C" int eps_select_topk_rows_pairs(const int64_t *sel_keys, const float *sel_vals, int64_t m, int64_t k, int32_t id_bits,
+                                          const int64_t *perm_or_null, int64_t *out_pairs, int64_t pairs_ld, float *out_vals,
+                                          void *workspace, int64_t workspace_bytes, void *stream)
+{
+    EPS_REQUIRE(m <= 0 || k <= 0 || (out_pairs && pairs_ld >= (k < 2 * m ? k : 2 * m)), "eps_select_topk_rows_pairs: out_pairs / pairs_ld too small");
+    return sel_rows(sel_keys, sel_vals, m, k, id_bits, perm_or_null, nullptr, out_vals, workspace, workspace_bytes, stream, out_pairs, pairs_ld);
+}
+
 static int sel_rows(const int64_t *sel_keys, const float *sel_vals, int64_t m, int64_t k, int32_t id_bits, const int64_t *perm,
-                    int64_t *out_keys, float *out_vals, void *workspace, int64_t workspace_bytes, void *stream)
+                    int64_t *out_keys, float *out_vals, void *workspace, int64_t workspace_bytes, void *stream, int64_t *out_pairs,
+                    int64_t pairs_ld)
 {
     EPS_REQUIRE(m >= 0 && k >= 0 && id_bits >= 1 && id_bits <= 32, "eps_select_topk_rows: bad argument");
     if (m == 0 || k == 0) return EPS_OK;
-    EPS_REQUIRE(sel_keys && sel_vals && out_keys && out_vals, "eps_select_topk_rows: null pointer");
+    EPS_REQUIRE(sel_keys && sel_vals && (out_keys || out_pairs) && out_vals, "eps_select_topk_rows: null pointer");
     EPS_REQUIRE(m < (1ll << 30), "eps_select_topk_rows: list too long");
     EPS_REQUIRE(workspace && ((uintptr_t)workspace & 255) == 0 && workspace_bytes >= eps_select_topk_rows_workspace_bytes(m),
                 "eps_select_topk_rows: needs a 256-byte aligned workspace of eps_select_topk_rows_workspace_bytes(m) bytes");
@@ -282,8 +308,12 @@ static int sel_rows(const int64_t *sel_keys, const float *sel_vals, int64_t m, i
         return EPS_ELAUNCH;
     }
     const size_t take = (size_t)k < rows ? (size_t)k : rows;
-    hipLaunchKernelGGL(sel_unpack_rows_kernel, dim3(sel_blocks((int64_t)take)), dim3(256), 0, s, k0, v0, (int64_t)take, (int)id_bits, out_keys,
-                       out_vals);
+    if (out_pairs)
+        hipLaunchKernelGGL(sel_unpack_pairs_kernel, dim3(sel_blocks((int64_t)take)), dim3(256), 0, s, k0, v0, (int64_t)take, (int)id_bits,
+                           out_pairs, pairs_ld, out_vals);
+    else
+        hipLaunchKernelGGL(sel_unpack_rows_kernel, dim3(sel_blocks((int64_t)take)), dim3(256), 0, s, k0, v0, (int64_t)take, (int)id_bits,
+                           out_keys, out_vals);
     EPS_CHECK_LAUNCH("eps_select_topk_rows");
     return EPS_OK;
 }

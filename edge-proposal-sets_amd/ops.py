@@ -1291,6 +1291,25 @@ def rescore_runs_dev(rowptr, col, fixw: torch.Tensor, n_nodes: int, keys_by_u: t
     return out
 
 
+def select_rows_pairs(sel_keys: torch.Tensor, sel_vals: torch.Tensor, k: int, id_bits: int = 32,
+                      perm: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """``select_rows`` with the rows written as the proposal tensor itself: (pairs int64 [2, min(k, 2 m)] as (u; v), scores)
+    (eps_select_topk_rows_pairs) -- no tensor ops over the K rows afterwards."""
+    dev = _need_gpu(sel_keys, sel_vals, perm)
+    _chk(sel_keys, torch.int64, "sel_keys"); _chk(sel_vals, torch.float32, "sel_vals"); _chk(perm, torch.int64, "perm")
+    m, k = sel_keys.numel(), int(k)
+    take = min(k, 2 * m)
+    pairs = torch.empty((2, take), dtype=torch.int64, device=dev)
+    out_v = torch.empty(take, dtype=torch.float32, device=dev)
+    if take:
+        lib = _lib.load()
+        with torch.cuda.device(dev), _timed(dev, "select_rows", m):
+            _, wsp, wsb = _aligned_ws(dev, lib.eps_select_topk_rows_workspace_bytes(m))
+            _lib.check(lib.eps_select_topk_rows_pairs(_ptr(sel_keys), _ptr(sel_vals), m, k, int(id_bits), _ptr(perm), _ptr(pairs), take,
+                                                      _ptr(out_v), wsp, wsb, _stream(dev)), "eps_select_topk_rows_pairs")
+    return pairs, out_v
+
+
 _SELECT_WS = {}
 
 

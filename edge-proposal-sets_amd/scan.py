@@ -558,7 +558,7 @@ def _launch(g, fixw, columns, threshold, capacity, scores_only: bool = False, bo
     out = ops.Survivors(capacity, threshold, g.device, scores_only, both, prefill=screen is None)
     out.walked_slots = None
     if screen is not None:
-        out.status = torch.zeros(1, dtype=torch.int32, device=g.device)
+        out.status = torch.empty(1, dtype=torch.int32, device=g.device)      # (cleared by eps_scan_screen itself)
     if columns.numel():
         if screen is not None and heads is not None:
             bounds, cuts = screen_tables(g)
@@ -723,7 +723,9 @@ def estimate_bar(g: CSRGraph, fixw: torch.Tensor, k: int, stride: Optional[int] 
         # half the old bar -- so the value is at most 0.4 % below the exact order statistic: an estimate either way, and the
         # verification after the main launch is what makes the step exact.  A sample whose m-th best fell below the base answers
         # -inf: the main launch then keeps everything, overflows its list and is corrected like any bar that was too low.
-        base = torch.full((1,), 0.5 * hint, dtype=torch.float32, device=g.device)
+        base = screen.bar_hint.get(("base", hint))
+        if base is None:
+            base = screen.bar_hint[("base", hint)] = torch.full((1,), 0.5 * hint, dtype=torch.float32, device=g.device)
         ops.score_hist(None, res.val, res.count_ptr, base)
         bar = ops.score_pick_compact(None, res.val, res.count_ptr, base, m_loc, mode=1)[4]
     else:
@@ -1010,11 +1012,15 @@ def scan_topk(g: CSRGraph, node_w: torch.Tensor, k: int, rank: int = 0, world: i
                     swap = True
                 ops.score_hist(x_keys, x_vals, None, bar, above=bar)
                 sel_k, sel_v, n_sel, cut, _ = ops.score_pick_compact(x_keys, x_vals, None, bar, k2, above=bar, swap_halves=swap, room=max(nv, 1))
-                zero = torch.zeros(1, dtype=torch.int64, device=dev)
-                st = torch.cat([res.rec[1:2], res.rec[4:5], n_sel, cut.view(torch.int32).to(torch.int64), res.status.to(torch.int64),
-                                pre_thr.view(torch.int32).to(torch.int64), res.walked_slots if res.walked_slots is not None else zero,
-                                bar.view(torch.int32).to(torch.int64) if bar is not None else zero])
-                table = [st.tolist()]                                                            # the host read of the step
+                # (the status vector as 32-bit words -- views, ONE cat launch, no dtype conversions: [slots lo hi, candidates lo hi,
+                #  n_sel lo hi, cut, kernel status, pre-filter threshold, walked slots lo hi, bar])
+                w32 = torch.cat([res.rec[1:2].view(torch.int32), res.rec[4:5].view(torch.int32), n_sel.view(torch.int32),
+                                 cut.view(torch.int32), res.status, pre_thr.view(torch.int32),
+                                 (res.walked_slots if res.walked_slots is not None else res.rec[1:2]).view(torch.int32),
+                                 bar.view(torch.int32)]).tolist()                                 # the host read of the step
+                u32 = lambda x: x & 0xFFFFFFFF                                                   # noqa: E731
+                table = [[u32(w32[0]) | (w32[1] << 32), u32(w32[2]) | (w32[3] << 32), u32(w32[4]) | (w32[5] << 32), w32[6], w32[7], w32[8],
+                          (u32(w32[9]) | (w32[10] << 32)) if res.walked_slots is not None else 0, w32[11]]]
                 n_rescored = 0 if screen.exact else nv
                 break
             while TAIL_SORT != "library":
@@ -1072,12 +1078,13 @@ def scan_topk(g: CSRGraph, node_w: torch.Tensor, k: int, rank: int = 0, world: i
             n_rescored = 0 if screen.exact else nv
             status = res.status
         # the job-wide cut: the k2-th best survivor score over all ranks (-inf when fewer survived); untouched slots are -inf
-        zero = torch.zeros(1, dtype=torch.int64, device=dev)
-        st_tail = [status.to(torch.int64) if status is not None else zero,                          # kernel status,
-                   pre_thr.view(torch.int32).to(torch.int64) if pre_thr is not None else zero,      # pre-filter threshold bits,
-                   res.walked_slots if res.walked_slots is not None else zero,                      # slots of the walked list,
-                   bar.view(torch.int32).to(torch.int64) if bar is not None else zero]               # the bar's bits (head launches)
         scores_all = None
+        if not (fast and rows is None and TAIL_SORT == "library" or fast and rows is not None):
+            zero = torch.zeros(1, dtype=torch.int64, device=dev)
+            st_tail = [status.to(torch.int64) if status is not None else zero,                          # kernel status,
+                       pre_thr.view(torch.int32).to(torch.int64) if pre_thr is not None else zero,      # pre-filter threshold bits,
+                       res.walked_slots if res.walked_slots is not None else zero,                      # slots of the walked list,
+                       bar.view(torch.int32).to(torch.int64) if bar is not None else zero]               # the bar's bits (head launches)
         if fast:
             pass
         elif world > 1 and screen is not None and not rescore_all and bar is not None and DIST_HIST:
@@ -1241,6 +1248,11 @@ def scan_topk(g: CSRGraph, node_w: torch.Tensor, k: int, rank: int = 0, world: i
             lo_r, hi_r = rank * n_rows // world, (rank + 1) * n_rows // world
             shard_info = (lo_r, n_rows)
             keys, vals = keys[lo_r:hi_r], vals[lo_r:hi_r]
+    elif world == 1 and keys.is_cuda:
+        # (one rank: the rows are written as the [2, K] proposal tensor by the sort's last kernel)
+        rows = ops.select_rows_pairs(keys.contiguous(), vals.contiguous(), k, bits, perm)
+        rows = (rows[0], rows[1], rows[0].shape[1])
+        keys = vals = None
     elif rows_on is None or rows_on == rank or world == 1:
         keys, vals = ops.select_rows(keys.contiguous(), vals.contiguous(), k, bits, perm)
     else:

@@ -523,6 +523,11 @@ int eps_compact_between(const int64_t *keys, const float *vals, int64_t n, const
 int eps_select_topk_rows_relabelled(const int64_t *sel_keys, const float *sel_vals, int64_t m, int64_t k, int32_t id_bits,
                                     const int64_t *perm, int64_t *out_keys, float *out_vals, void *workspace,
                                     int64_t workspace_bytes, void *stream);
+/* eps_select_topk_rows_pairs (r06): the same rows written as the [2, k] proposal tensor rank.py:294 reads -- out_pairs[i] = u,
+ * out_pairs[pairs_ld + i] = v (pairs_ld >= min(k, 2 m)) -- instead of packed keys; perm_or_null as in _relabelled. */
+int eps_select_topk_rows_pairs(const int64_t *sel_keys, const float *sel_vals, int64_t m, int64_t k, int32_t id_bits,
+                               const int64_t *perm_or_null, int64_t *out_pairs, int64_t pairs_ld, float *out_vals, void *workspace,
+                               int64_t workspace_bytes, void *stream);
 int64_t eps_sort_pairs_by_u_workspace_bytes(int64_t n);
 int eps_sort_pairs_by_u(const int64_t *keys, int64_t n, int32_t id_bits, int32_t v_block_shift, int64_t *out_by_u, void *workspace,
                         int64_t workspace_bytes, void *stream);

@@ -117,6 +117,8 @@ def test_radix_sort_rows_matches_library_and_torch(eps, dev, m, nodes, ties):
             assert take == min(k, 2 * m) == wk.numel()
             assert torch.equal(pairs[0, :take], wk & 0xFFFFFFFF) and torch.equal(pairs[1, :take], wk >> 32)
             assert torch.equal(scores[:take], wv)
+            pp, ps = eps.ops.select_rows_pairs(keys, vals, k, id_bits, pm)       # (the library sorts writing the [2, K] tensor themselves)
+            assert pp.shape == (2, take) and torch.equal(pp[0], wk & 0xFFFFFFFF) and torch.equal(pp[1], wk >> 32) and torch.equal(ps, wv)
     # against torch.sort directly (declared order: score descending, then (v, u) ascending), with a device count below the length
     part = max(1, m - m // 4)
     pairs, scores, n_rows = eps.ops.radix_sort_rows(keys, vals, torch.tensor([part], dtype=torch.int64, device=dev), 2 * m, id_bits, None)
