@@ -725,6 +725,8 @@ def estimate_bar(g: CSRGraph, fixw: torch.Tensor, k: int, stride: Optional[int] 
         # -inf: the main launch then keeps everything, overflows its list and is corrected like any bar that was too low.
         base = screen.bar_hint.get(("base", hint))
         if base is None:
+            if len(screen.bar_hint) > 32:
+                screen.bar_hint.clear()                  # (K and bars of a long-lived graph object change: start over)
             base = screen.bar_hint[("base", hint)] = torch.full((1,), 0.5 * hint, dtype=torch.float32, device=g.device)
         ops.score_hist(None, res.val, res.count_ptr, base)
         bar = ops.score_pick_compact(None, res.val, res.count_ptr, base, m_loc, mode=1)[4]
@@ -1079,7 +1081,7 @@ def scan_topk(g: CSRGraph, node_w: torch.Tensor, k: int, rank: int = 0, world: i
             status = res.status
         # the job-wide cut: the k2-th best survivor score over all ranks (-inf when fewer survived); untouched slots are -inf
         scores_all = None
-        if not (fast and rows is None and TAIL_SORT == "library" or fast and rows is not None):
+        if not fast:                   # (the fast path assembles its own status vector: no conversions on its stream)
             zero = torch.zeros(1, dtype=torch.int64, device=dev)
             st_tail = [status.to(torch.int64) if status is not None else zero,                          # kernel status,
                        pre_thr.view(torch.int32).to(torch.int64) if pre_thr is not None else zero,      # pre-filter threshold bits,

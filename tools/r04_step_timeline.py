@@ -44,7 +44,7 @@ def wrap(mod, name, label=None):
         return r
     setattr(mod, name, inner)
 for n in ("scan_screen", "scan_refine", "filter_scan", "kth_largest_dist", "compact_at_least", "rescore_runs", "rescore_weighted", "select_rows",
-          "select_compact", "sort_pairs_by_u", "select_splitters", "compact_range", "score_hist", "score_pick_compact", "radix_sort_by_u",
+          "select_rows_pairs", "select_compact", "sort_pairs_by_u", "select_splitters", "compact_range", "score_hist", "score_pick_compact", "radix_sort_by_u",
           "radix_sort_rows", "rescore_runs_dev"):
     if hasattr(ops, n):
         wrap(ops, n)

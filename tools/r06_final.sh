@@ -11,3 +11,5 @@ SEEDS=3,11 KS=4000000,150000 python tools/r03_two_kernels_same_list.py > $O/two_
 python tools/eval_pairs_bench.py > $O/eval_pairs.txt 2>&1; grep -v amdgpu.ids $O/eval_pairs.txt
 tools/r04_filter_cli.sh > $O/filter_cli.txt 2>&1; grep -v amdgpu.ids $O/filter_cli.txt | cut -c1-200
 tools/r06_profile_bench.sh > $O/profile_bench.log 2>&1; tail -14 $O/profile_bench.log | cut -c1-200
+tools/r06_pmc_scan.sh r06/pmc_scan > $O/pmc_scan.log 2>&1; tail -3 $O/pmc_scan.log
+python tools/r05_soak.py > $O/soak.txt 2>&1; grep -v amdgpu.ids $O/soak.txt | tail -1
