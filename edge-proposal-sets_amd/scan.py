@@ -919,15 +919,18 @@ def scan_topk(g: CSRGraph, node_w: torch.Tensor, k: int, rank: int = 0, world: i
     gathered, ``stats["shard"]`` = (first row of this rank's chunk, rows of all chunks).
 
     Per call, in the steady state (tables cached on the graph): sample launch -> bar (device; the lowest of the ranks' own
-    estimates) -> main launch, under a bar with skipped heads + eps_scan_refine -> LOCAL pre-filter of this rank's list (its
-    k2 / world-th best screening score, lowered to what such a score can be worth exactly; no collective; its count, one word, is
-    read to size what follows) -> exact re-scoring of what passed (not for uniform weights whose screening sums are exact:
-    Screen.exact) -> job-wide cut (the ceil(k/2)-th best exact score: one launch on one rank; on a job one all-gather of the
-    ranks' scores behind their status words, every rank finds the same cut) + compaction -> ONE host read of a status vector (slots, candidates, selected, cut, kernel status, the rank's pre-filter
-    threshold, walked slots, the bar; all-gathered when world > 1), which VERIFIES the step: enough survivors, no list overflow,
-    the cut at or above every rank's pre-filter threshold, usable heads -- else the launch repeats with what was learnt -> the
-    selected pairs of all ranks gathered -> mirrored + ordered, the ordering dealt over the ranks by score range, the rows sent
-    to ``rows_on`` alone (ops.select_rows, _ordered_rows_distributed)."""
+    estimates; r06: read off a score histogram around the previous bar when the graph was scanned at this K before) -> main launch,
+    under a bar with skipped heads + eps_scan_refine (r06: the body compiled for its tables, the per-column pack from the graph's
+    second scan on) -> LOCAL pre-filter of this rank's list (r06, one rank under a bar: a score-bucket histogram + pick-and-compact;
+    its count -- one word -- is read to size the library sorts: host read 1) -> exact re-scoring of what passed (not for uniform
+    weights whose screening sums are exact: Screen.exact) -> job-wide cut (one rank: the lower edge of the bucket of the
+    ceil(k/2)-th best exact score; on a job one all-gather of the ranks' score HISTOGRAMS behind their status words, every rank
+    derives the same cut and deal plan: ops.score_deal_plan) + compaction -> host read 2 of a status vector (slots, candidates,
+    selected, cut, kernel status, the rank's pre-filter threshold, walked slots, the bar; all-gathered when world > 1), which
+    VERIFIES the step: enough survivors, no list overflow, the cut at or above every rank's pre-filter threshold, usable heads --
+    else the launch repeats with what was learnt -> mirrored + ordered (one rank: ops.select_rows_pairs writes the [2, K] tensor),
+    on a job the ordering dealt over the ranks by score range, the rows sent to ``rows_on`` or left where they were ordered
+    (ops.select_rows, _deal_rows).  TAIL_SORT = "radix": the same with one-launch cooperative sorts, sizes on the device, ONE host read."""
     if relabel and scan_plausible(g):
         scan_graph(g, build=True)        # (first: the symmetry check below then reads the copy's table, the one the scan needs)
     if not scan_available(g):
