@@ -51,6 +51,7 @@ SIGNATURES = {
     "eps_scan_cuts": (_int, [_vp, _vp, _i64, _vp, _vp, _vp]),
     "eps_scan_screen_weights": (_int, [_vp, _i64, _i32, _vp, _vp, _vp]),
     "eps_scan_window_paths": (_int, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp]),
+    "eps_scan_window_paths_columns": (_int, [_vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _vp]),
     "eps_scan_screen": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _i64, _i64, _i32, _i32, _vp, _vp, _vp]),
     "eps_scan_column_pack": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp]),
     "eps_scan_row_records": (_int, [_vp, _vp, _vp, _i64, _vp, _vp]),

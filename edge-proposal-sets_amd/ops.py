@@ -622,14 +622,24 @@ def scan_cuts(rowptr: torch.Tensor, col: torch.Tensor, bounds: torch.Tensor) -> 
     return out
 
 
-def scan_window_paths(rowptr, col, revpos, cuts, heads: Optional[torch.Tensor] = None) -> torch.Tensor:
+def scan_window_paths(rowptr, col, revpos, cuts, heads: Optional[torch.Tensor] = None, columns: Optional[torch.Tensor] = None) -> torch.Tensor:
     """uint32 table [N, M] (int32 bits): two-hop half paths of every column per id window (per-graph table of the scan).
-    ``heads`` (``scan_heads``): the paths of the rows a column still walks."""
-    dev = _need_gpu(rowptr, col, revpos, cuts, heads)
+    ``heads`` (``scan_heads``): the paths of the rows a column still walks.
+    ``columns`` (int32 ids; without heads): only these rows are computed, the rest of the table stays uninitialised
+    (eps_scan_window_paths_columns: the bar sample of a graph whose whole-graph table has not been needed yet)."""
+    dev = _need_gpu(rowptr, col, revpos, cuts, heads, columns)
     _chk(rowptr, torch.int64, "rowptr"); _chk(col, torch.int32, "col"); _chk(revpos, torch.int32, "revpos"); _chk(cuts, torch.int16, "cuts")
     n = rowptr.numel() - 1
     _chk_heads(heads, n)
     out = torch.empty((n, scan_windows()), dtype=torch.int32, device=dev)
+    if columns is not None:
+        _chk(columns, torch.int32, "columns")
+        if heads is not None:
+            raise _lib.EpsError("scan_window_paths: a column subset comes without a head table")
+        with torch.cuda.device(dev):
+            _lib.check(_lib.load().eps_scan_window_paths_columns(_ptr(rowptr), _ptr(col), _ptr(revpos), _ptr(cuts), n, _ptr(columns),
+                                                                 columns.numel(), _ptr(out), _stream(dev)), "eps_scan_window_paths_columns")
+        return out
     with torch.cuda.device(dev):
         _lib.check(_lib.load().eps_scan_window_paths(_ptr(rowptr), _ptr(col), _ptr(revpos), _ptr(cuts), n, _ptr(heads), _ptr(out),
                                                      _stream(dev)), "eps_scan_window_paths")

@@ -51,6 +51,7 @@ HEAD_MIN_PATHS = 1 << 30   # graphs with fewer two-hop half paths are scanned wi
 HEAD_MAX_ROWS = 1024       # rows a column's head holds at most (eps_scan_refine probes each of them for every slot that passes; 48 cost resource allocation 2 ms of scan for 0.15 of refine)
 HEAD_CACHE = 4             # head tables kept per (graph, weight table)
 DMAX_MARGIN = 5               # a piece drops low weight bits only down to this many bits below the graph's smallest weight (screen_weights)
+LAZY_PLAN = True              # the whole-graph plan table (no skipped heads) is built when a launch first wants it; the bar sample plans itself
 ROW_RECORDS = True            # the launch gathers a row's cuts, first entry and weight out of ONE 128-byte line (ops.scan_row_records)
 BATCH_MIN_COLUMNS = 1 << 16   # lists shorter than this are handed out one column at a time throughout
 BATCH_PATHS = 1 << 13      # columns of a heaviest-first list with fewer half paths are handed out eight per ticket (see batch_from)
@@ -256,12 +257,14 @@ def screen_shift(bound: float, max_deg: int, weighted: bool = False) -> int:
 
 class Screen:
     """What a launch of the piece kernel and the exact re-scoring of its survivors need, for one (graph, weight table)."""
-    __slots__ = ("fx32", "shift", "fixw", "val", "node_w", "usable", "ssum", "smax", "plan", "d_used", "w_min", "heads", "head_cur", "rowrec", "vword", "exact",
-                 "bar_hint")
+    __slots__ = ("fx32", "shift", "fixw", "val", "node_w", "usable", "ssum", "smax", "_plan", "_plan_build", "d_used", "w_min", "heads", "head_cur",
+                 "rowrec", "vword", "exact", "bar_hint")
 
     def __init__(self, fx32, shift, fixw, val, node_w, usable, ssum=None, smax=None, plan=None, d_used=0, w_min=0.0):
         self.fx32, self.shift, self.fixw, self.val, self.node_w, self.usable = fx32, shift, fixw, val, node_w, usable
-        self.ssum, self.smax, self.plan = ssum, smax, plan
+        self.ssum, self.smax, self._plan = ssum, smax, plan
+        self._plan_build = None      # r06: () -> ((pptr, records), bits dropped): the whole-graph plan is built when a launch WITHOUT
+                                     # skipped heads first asks for it (see `plan`); a one-shot run under a bar never does
         self.d_used = d_used         # most low bits any packed / 16-bit direct piece drops from the screening weights
         self.w_min = w_min           # smallest weight of a node that can be a common neighbour (0: no relative bound)
         self.heads = {}              # budget (table units) -> HeadTables (see head_tables)
@@ -271,6 +274,21 @@ class Screen:
         self.bar_hint = {}           # (k, stride, safety) -> the bar (host float) the last scan with these settings ended with
         self.exact = False           # screening sums ARE the exact scores (one weight for every node, a multiple of every unit a piece
                                      # may round to -- common neighbours): the survivors need no re-scoring
+
+    @property
+    def has_plan(self) -> bool:
+        """Launches of this (graph, weight table) read their pieces from plan tables (built or still to be built)."""
+        return self._plan is not None or self._plan_build is not None
+
+    @property
+    def plan(self):
+        """(pptr, records) of the whole graph WITHOUT skipped heads, built on first use (0.7 ms of window paths + 1.0 ms of planning on
+        the ppa-like graph, one host read): the launches of a step under a bar bring the plan of their head table, and the bar sample
+        plans its ~1000 columns inside the launch (`_launch(sample_wp=...)`)."""
+        if self._plan is None and self._plan_build is not None:
+            self._plan, self.d_used = self._plan_build()
+            self._plan_build = None
+        return self._plan
 
     def lower_bound(self, s: torch.Tensor, max_deg: int) -> torch.Tensor:
         """A lower bound of the exact score of a pair whose screening score is ``s`` (monotone in s).  A path's screening term
@@ -321,8 +339,9 @@ def screen_weights(g0: CSRGraph, g: CSRGraph, perm, node_w: torch.Tensor) -> Scr
         # smallest weight come back in ONE host read at the end (tables built from unusable weights are simply not used).
         one_pass = fits and one_pass_available(g)
         ssum, smax, min_fx = _sum_bounds(g, fx32) if one_pass and PACKED_PIECES else (None, None, None)
-        plan, d_word = None, None
+        plan, d_word, plan_build = None, None, None
         vword = screen_variant(g)
+        dmax_limit = max(0, min(24, shift - 8))                   # (csrc/scan_pieces.hip: packed_dmax)
         if one_pass and PLAN_TABLE:
             # How many low weight bits a piece may drop: a screening score exceeds the exact one by up to 2^d + 1 units per path, and
             # the pre-filter in front of the exact re-scoring (lower_params) is as sharp as that is small next to the smallest
@@ -330,11 +349,20 @@ def screen_weights(g0: CSRGraph, g: CSRGraph, perm, node_w: torch.Tensor) -> Scr
             # default d = 13 a tenth of every score was slack and the re-scoring took 13.5 ms, r05)
             lowest = int(min_fx.item()) & 0xFFFFFFFF if min_fx is not None else 0xFFFFFFFF
             if lowest not in (0, 0xFFFFFFFF):
+                dmax_limit = min(dmax_limit, max(0, lowest.bit_length() - 1 - DMAX_MARGIN))
                 vword = ops.scan_variant_word(screen_variant(g), max(0, lowest.bit_length() - 1 - DMAX_MARGIN))
-            # every column's pieces, planned once per (graph, weight table): a launch reads them instead of planning (5 %)
-            bounds, cuts = screen_tables(g)
-            pptr, recs, d_word = ops.scan_plan(g.rowptr, cuts, window_paths(g), ssum, smax, bounds, g.n_rows, shift, vword, with_d=True)
-            plan = (pptr, recs)
+            # every column's pieces, planned once per (graph, weight table): a launch reads them instead of planning (5 %) -- r06:
+            # planned when a launch without skipped heads first wants them (Screen.plan); LAZY_PLAN off: here and now, as in r05
+            vword_plan = vword
+
+            def plan_build():
+                bounds, cuts = screen_tables(g)
+                pptr, recs, dw = ops.scan_plan(g.rowptr, cuts, window_paths(g), ssum, smax, bounds, g.n_rows, shift, vword_plan, with_d=True)
+                return (pptr, recs), int(dw.item()) & 0xFFFFFFFF
+            if not LAZY_PLAN:
+                bounds, cuts = screen_tables(g)
+                pptr, recs, d_word = ops.scan_plan(g.rowptr, cuts, window_paths(g), ssum, smax, bounds, g.n_rows, shift, vword, with_d=True)
+                plan, plan_build = (pptr, recs), None
         zero = torch.zeros(1, dtype=torch.int32, device=g.device)
         f_lo, f_hi = (fixw.min(), fixw.max()) if fixw.numel() else (torch.zeros((), dtype=torch.int64, device=g.device),) * 2
         bad_h, d_h, min_h, f_lo, f_hi = torch.cat([bad.view(torch.int32).to(torch.int64), (d_word if d_word is not None else zero).to(torch.int64),
@@ -344,15 +372,16 @@ def screen_weights(g0: CSRGraph, g: CSRGraph, perm, node_w: torch.Tensor) -> Scr
         usable = fits and bad_h == 0
         rowrec = ops.scan_row_records(screen_tables(g)[1], g.rowptr, fx32) if usable and one_pass and ROW_RECORDS else None
         if not usable:
-            ssum = smax = plan = None
+            ssum = smax = plan = plan_build = None
         d_used, w_min = 0, 0.0
         if ssum is not None:
-            # the launch's limit (csrc/scan_pieces.hip: packed_dmax), or what the plan really uses
-            d_used = d_h if plan is not None else max(0, min(24, shift - 8))
+            # the launch's limit (csrc/scan_pieces.hip: packed_dmax; what a launch that plans itself may drop), or what the plan really uses
+            d_used = d_h if plan is not None else dmax_limit
             # fx32 rounds the exact weight x 2^shift UP: one unit less is a floor under every common neighbour's exact weight
             lowest = min_h & 0xFFFFFFFF
             w_min = 0.0 if lowest == 0xFFFFFFFF else max(0, lowest - 1) * 2.0 ** -shift
         sc = Screen(fx32, shift, fixw, None, None, usable, ssum, smax, plan, d_used, w_min)
+        sc._plan_build = plan_build if one_pass and PLAN_TABLE and usable else None
         sc.rowrec = rowrec
         sc.vword = vword
         # One weight for all nodes (common neighbours: 1.0), a whole number of screening units that stays whole under every low bit a
@@ -549,7 +578,7 @@ def one_pass_available(g: CSRGraph) -> bool:
 
 
 def _launch(g, fixw, columns, threshold, capacity, scores_only: bool = False, both: bool = False, screen=None,
-            heads: Optional[HeadTables] = None, walked_capacity: int = 0) -> ops.Survivors:
+            heads: Optional[HeadTables] = None, walked_capacity: int = 0, sample_key=None) -> ops.Survivors:
     """``screen`` (a Screen) -> the one-pass kernel (screening scores in ``val``), else eps_filter_scan (exact scores).
     ``heads``: the launch skips the columns' heads (its list -- ``walked_capacity`` slots -- holds walked sums) and
     eps_scan_refine completes them into the list that is returned: the same survivors and scores as without heads, compact;
@@ -573,8 +602,15 @@ def _launch(g, fixw, columns, threshold, capacity, scores_only: bool = False, bo
             out.walked_slots = walked.rec[1:2]
         elif screen is not None:
             bounds, cuts = screen_tables(g)
+            if sample_key is not None and screen.val is None and screen._plan is None and screen._plan_build is not None:
+                # the bar sample of a graph whose whole-graph plan has not been needed yet: the launch plans its ~1000 columns itself
+                # (the same planner, the same pieces) from the window paths of THOSE columns -- no 0.7 + 1.0 ms of whole-graph tables
+                wp, plan = sample_window_paths(g, columns, sample_key), None
+            else:
+                wp, plan = window_paths(g), screen.plan
             ops.scan_screen(g.rowptr, g.col, reverse_positions(g), screen.fx32, cuts, bounds, g.n_rows, columns, screen.shift, out,
-                            out.status, screen_variant(g), screen.val, screen.node_w, window_paths(g), screen.ssum, screen.smax, screen.plan,
+                            out.status, screen.vword if screen.vword is not None and screen.val is None else screen_variant(g),
+                            screen.val, screen.node_w, wp, screen.ssum, screen.smax, plan,
                             None, batch_from(g, columns), screen.rowrec)
         else:
             ops.filter_scan(g.rowptr, g.col, reverse_positions(g), fixw, g.n_rows, columns, out, max_degree(g), window_splits(g))
@@ -583,8 +619,16 @@ def _launch(g, fixw, columns, threshold, capacity, scores_only: bool = False, bo
 
 def variant_is_main(g: CSRGraph, screen: Screen) -> bool:
     """The launch is the one the specialised body serves (csrc/scan_pieces.hip FULL): 256-thread geometry, plan, records, sum bounds."""
-    return bool(screen_variant(g) == 2 and screen.plan is not None and screen.rowrec is not None and screen.ssum is not None
+    return bool(screen_variant(g) == 2 and screen.has_plan and screen.rowrec is not None and screen.ssum is not None
                 and COLUMN_RECORDS)
+
+
+def sample_window_paths(g: CSRGraph, columns: torch.Tensor, key) -> torch.Tensor:
+    """The window-path rows of the bar sample's columns alone (cached per sample; the table is whole-graph sized, uninitialised elsewhere)."""
+    ck = ("sample_wpaths",) + tuple(key)
+    if ck not in g._cache:
+        g._cache[ck] = ops.scan_window_paths(g.rowptr, g.col, reverse_positions(g), screen_tables(g)[1], columns=columns)
+    return g._cache[ck]
 
 
 def batch_from(g: CSRGraph, columns: torch.Tensor) -> int:
@@ -705,7 +749,8 @@ def estimate_bar(g: CSRGraph, fixw: torch.Tensor, k: int, stride: Optional[int] 
         return None
     slack = _CHUNK_SLACK if screen is None else _PIECE_SLACK
     # (room for every candidate of the sample: at most its half paths -- a list that still overflows only thins the sample)
-    res = _launch(g, fixw, mine, float("-inf"), min(bound_mine + slack, ops.SURVIVOR_SLOTS_MAX), scores_only=True, screen=screen)
+    res = _launch(g, fixw, mine, float("-inf"), min(bound_mine + slack, ops.SURVIVOR_SLOTS_MAX), scores_only=True, screen=screen,
+                  sample_key=("scan_sample", stride, rank, world))
     # no bar: every candidate of the sample holds a slot, untouched slots are -inf (fewer than m candidates -> bar -inf).
     # (one-pass kernel: screening scores, at most a few 2^-shift above the exact ones -- an estimate either way)
     if screen is None:
@@ -969,7 +1014,7 @@ def scan_topk(g: CSRGraph, node_w: torch.Tensor, k: int, rank: int = 0, world: i
     capacity = _capacity(wanted, slack)
     neg_inf = torch.full((1,), float("-inf"), device=dev)
     # skipped heads (csrc/scan_heads.hip): unit-valued graphs with a plan table, under a bar
-    use_heads = (HEADS and screen is not None and screen.plan is not None and screen.ssum is not None and g.val is None
+    use_heads = (HEADS and screen is not None and screen.has_plan and screen.ssum is not None and g.val is None
                  and total_half >= HEAD_MIN_PATHS)
     _count_scan(g, screen)
     head_list, head_trouble, head_stale = HEAD_LIST, 0, 0

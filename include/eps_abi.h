@@ -289,6 +289,11 @@ int eps_scan_cuts(const int64_t *rowptr, const int32_t *col, int64_t n_nodes, co
 int eps_scan_screen_weights(const int64_t *fixw, int64_t n, int32_t shift, uint32_t *fx32, uint32_t *bad, void *stream);
 int eps_scan_window_paths(const int64_t *rowptr, const int32_t *col, const int32_t *revpos, const uint16_t *cuts,
                           int64_t n_nodes, const uint32_t *heads_or_null, uint32_t *wpaths, void *stream);
+/* eps_scan_window_paths_columns (r06): the rows of that table for the listed columns only (the other rows are left untouched; no
+ * head table): what a launch without a plan table over a few columns -- the bar sample, filter.py:96-142 on every 512-th column --
+ * needs, so that a one-shot run builds the whole-graph table and its plan only if a launch without skipped heads asks for them. */
+int eps_scan_window_paths_columns(const int64_t *rowptr, const int32_t *col, const int32_t *revpos, const uint16_t *cuts, int64_t n_nodes,
+                                  const int32_t *columns, int64_t n_columns, uint32_t *wpaths, void *stream);
 int eps_scan_screen(const int64_t *rowptr, const int32_t *col, const int32_t *revpos, const uint32_t *fx32,
                     const uint16_t *cuts, const uint32_t *wpaths, const uint32_t *ssum_or_null,
                     const uint32_t *smax_or_null, const uint32_t *pptr_or_null, const uint32_t *plan_or_null,
