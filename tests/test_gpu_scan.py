@@ -565,3 +565,37 @@ def test_select_compact_one_launch(eps, dev, n, k):
     # selection only, scores alone (the bar estimate's call)
     _, _, _, kth, thr = eps.ops.select_compact(None, vals, k, count.data_ptr(), mode=1, compact=False)
     assert float(kth) == want_kth
+
+
+def test_window_paths_of_a_column_subset_and_the_lazy_plan(eps, dev, monkeypatch):
+    """r06: eps_scan_window_paths_columns fills exactly the rows of the listed columns with what the whole-graph table holds; a step
+    under a bar with skipped heads leaves the whole-graph plan table unbuilt (the bar sample plans its own columns inside the
+    launch), a launch without heads builds it on demand -- and the rows are the same with LAZY_PLAN on and off."""
+    from eps_amd import scan, synth
+    from eps_amd.graph import CSRGraph
+    from eps_amd.heuristics import node_weight_table
+    g0 = synth.rmat_graph(13, 12, 9, dev)
+    gs, perm = g0.degree_ordered()[:2]
+    bounds, cuts = scan.screen_tables(gs)
+    full = eps.ops.scan_window_paths(gs.rowptr, gs.col, scan.reverse_positions(gs), cuts)
+    cols = scan.column_order(gs)[3::41].contiguous()
+    part = eps.ops.scan_window_paths(gs.rowptr, gs.col, scan.reverse_positions(gs), cuts, columns=cols)
+    assert torch.equal(part[cols.long()], full[cols.long()])
+    monkeypatch.setattr(scan, "SMALL_SET", 0)
+    monkeypatch.setattr(scan, "RELABEL_MIN_NODES", 0)
+    monkeypatch.setattr(scan, "HEAD_MIN_PATHS", 0)
+    out = {}
+    for lazy in (True, False):
+        monkeypatch.setattr(scan, "LAZY_PLAN", lazy)
+        g = CSRGraph(g0.rowptr, g0.col, None, g0.n_rows, g0.n_cols)
+        w = node_weight_table(g, eps.ops.W_AA)
+        st = {"count": False}
+        out[lazy] = scan.scan_topk(g, w, 20_000, relabel=True, stats=st)
+        assert st["heads"]
+        sc = scan.screen_weights(g, *scan.scan_graph(g), w)
+        assert sc.has_plan and (sc._plan is None) == lazy, "the whole-graph plan is built eagerly only with LAZY_PLAN off"
+        st2 = {}
+        again = scan.scan_topk(g, w, 20_000, relabel=True, stats=st2)          # (counts the candidates: a launch without heads -> the plan)
+        assert sc._plan is not None and st2["candidates"] > 0
+        assert torch.equal(again[0], out[lazy][0]) and torch.equal(again[1], out[lazy][1])
+    assert torch.equal(out[True][0], out[False][0]) and torch.equal(out[True][1], out[False][1])
