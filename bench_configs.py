@@ -311,56 +311,79 @@ def leg_config3(torch, min_candidates=1_000_000_000):
 
 def leg_full_list(torch):
     """The literal filter.py:113-165 on the bench graph: EVERY candidate gets its exact score, written out in candidate order
-    (no bar, no top-K): eps_expand_unit_count + eps_expand_unit_fill over column blocks of < 2^31 two-hop paths -- column-major,
-    both orientations, u ascending, float32 of the exact 2^-40 fixed-point sums.  The list itself is 8 bytes per candidate
-    (u + score; v is the block's column pointer): 102 GB leave the chip for 12.7 G candidates, which is why the production
-    path never writes it."""
+    (no bar, no top-K), in ONE pass over the two-hop paths: eps_expand_unit_list (r06) over column blocks of < 2^33 paths --
+    column-major, both orientations, u ascending, float32 of the exact 2^-40 fixed-point sums; segments sized by
+    min(two-hop paths, N) per column (no counting launch, no host read before a launch), the counts come back with the list.
+    The list itself is 8 bytes per candidate (u + score; v is the segment that holds the slot): 102 GB leave the chip for
+    12.7 G candidates, which is why the production path never writes it.  The r02-r05 two-pass form (eps_expand_unit_count +
+    _fill, exact layout) is timed beside it."""
     from eps_amd import candidates, ops, scan, synth
     from eps_amd.heuristics import node_weight_table
     dev = torch.device("cuda", torch.cuda.current_device())
     g = synth.ppa_like(seed=3, device=dev)
     w = node_weight_table(g, ops.W_AA)
     md, sp = scan.max_degree(g), scan.window_splits(g)
-    blocks = list(candidates.column_blocks(g))
+    blocks = list(candidates.column_blocks(g, 1 << 33))
+    blocks2 = list(candidates.column_blocks(g))
+    pre, pre_host = candidates.segment_bounds(g)
 
-    def all_blocks():
-        n = 0
+    def one_pass():
+        parts = []
         for v_lo, v_hi in blocks:
+            ub = (pre[v_lo:v_hi + 1] - pre[v_lo]).contiguous()
+            r = ops.expand_unit(g.rowptr, g.col, w, g.n_rows, v_lo, v_hi, md, sp, want_score=True, want_v=False,
+                                col_order=candidates.heaviest_first(g, v_lo, v_hi), colptr_ub=ub,
+                                total_ub=int(pre_host[v_hi] - pre_host[v_lo]))
+            parts.append(torch.cat([r.counts.sum().view(1), r.status.view(1).to(torch.int64)]))
+            del r
+        t = torch.stack(parts).cpu()                  # ONE host read, after the last launch: the counts and the status words
+        if int(t[:, 1].sum()):
+            raise RuntimeError("full-list leg: status %s" % t[:, 1].tolist())
+        return int(t[:, 0].sum())
+
+    def two_pass():
+        n = 0
+        for v_lo, v_hi in blocks2:
             r = ops.expand_unit(g.rowptr, g.col, w, g.n_rows, v_lo, v_hi, md, sp, want_score=True, want_v=False,
                                 col_order=candidates.heaviest_first(g, v_lo, v_hi))
-            n += int(r[1].numel())                    # (cand_u; the column of candidate i is the colptr range that holds i)
+            n += int(r[1].numel())
             del r
         return n
-    all_blocks()
-    _sync(torch)
-    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    a.record()
-    n_cand = all_blocks()
-    b.record()
-    _sync(torch)
-    wall = time.perf_counter() - t0
-    ms = a.elapsed_time(b)
+
+    def timed(fn):
+        fn()
+        _sync(torch)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        a.record()
+        n = fn()
+        b.record()
+        _sync(torch)
+        return n, a.elapsed_time(b), time.perf_counter() - t0
+
+    n2, ms2, _ = timed(two_pass)
+    torch.cuda.empty_cache()
+    n_cand, ms, wall = timed(one_pass)
+    assert n_cand == n2
     paths = int(candidates.path_counts(g).sum().item())
-    abytes = 4 * paths * 2 + 8 * n_cand + 24 * g.nnz()      # every two-hop path read in the counting and in the fill pass + the list
+    abytes = 4 * paths + 8 * n_cand + 24 * g.nnz()      # every two-hop path read ONCE + the list + the graph's own arrays
     return {"workload": "full list (filter.py:113-165 as written): every 2-hop non-edge of the ppa-like bench graph with its exact AA "
-                        "score, in candidate order, %d column blocks" % len(blocks),
-            "kernel": "filter_scan_kernel<FS_COUNT> + <FS_EMIT> (eps_expand_unit_count / _fill)", "candidates": n_cand,
+                        "score, in candidate order, one pass, %d launches" % len(blocks),
+            "kernel": "filter_scan_kernel<FS_EMIT> (eps_expand_unit_list)", "candidates": n_cand,
             "two_hop_paths": paths, "gpu_ms": ms, "wall_s": wall, "candidates_per_s": n_cand / ms * 1e3, "bound": "hbm",
             "algorithmic_bytes": abytes, "GBps": abytes / ms / 1e6, "frac": abytes / ms / 1e6 / HBM_PEAK_GBPS,
-            # what the literal list MUST move, whatever the algorithm: every path read once, every candidate written once
-            "one_pass_model": {"bytes": 4 * paths + 8 * n_cand + 24 * g.nnz(),
-                               "GBps": (4 * paths + 8 * n_cand + 24 * g.nnz()) / ms / 1e6,
-                               "frac": (4 * paths + 8 * n_cand + 24 * g.nnz()) / ms / 1e6 / HBM_PEAK_GBPS,
-                               "floor_ms_at_peak": (4 * paths + 8 * n_cand + 24 * g.nnz()) / HBM_PEAK_GBPS / 1e6},
-            "note": "gpu_ms: HIP events around all blocks incl. the one host read per block (its candidate count sizes the list); "
-                    "algorithmic bytes = 4 B x two-hop paths x 2 passes + 8 B x candidates written + 24 B x nnz (the kernel's own two "
-                    "passes); one_pass_model = the same with every path read ONCE -- what the list costs whatever the algorithm "
-                    "(VERDICT r04 #4).  Why the leg still runs on the r02 two-pass kernel: the one-pass piece kernel keeps 15 / 31-bit "
-                    "SCREENING sums in its LDS table; a list of exact scores needs the 2^-40 fixed-point sums (41-bit terms, 52-bit sums: "
-                    "two table words per candidate + its key), i.e. a third of the candidates per piece and no skipped heads (every "
-                    "candidate is wanted) -- by the piece kernel's measured cost per piece that is no faster than the two passes.  The "
-                    "102 GB of rows alone are 12.8 ms at the HBM peak; no production path writes them (rank.py:294 reads K rows)"}
+            "floor_ms_at_peak": abytes / HBM_PEAK_GBPS / 1e6,
+            "slots_allocated": int(pre_host[-1]),
+            "two_pass": {"gpu_ms": ms2, "candidates_per_s": n2 / ms2 * 1e3, "blocks": len(blocks2),
+                         "kernel": "filter_scan_kernel<FS_COUNT> + <FS_EMIT> (eps_expand_unit_count / _fill): the r02-r05 leg"},
+            "note": "gpu_ms: HIP events around all launches incl. allocation and the ONE host read at the end (counts + status); "
+                    "algorithmic bytes = the one-pass model of VERDICT r04 #4: 4 B x two-hop paths + 8 B x candidates written + "
+                    "24 B x nnz.  Inside a column the kernel still walks its paths twice (mark, then rank + bucket) and moves a "
+                    "4-byte record per path through a per-workgroup scratch that stays in L2 / MALL; what went away is the "
+                    "counting LAUNCH (20.7 ms) and the padding.  profiles/r06/full_list_*.txt: where the launch's time goes "
+                    "(stamps, ablations) and what was tried (id windows for direct accumulation: slower; LDS-staged u stores: "
+                    "slower -- the launch is bound by instruction issue at 4 waves per SIMD, not by bytes).  The 102 GB of rows "
+                    "alone are 12.8 ms at the HBM peak; no production path writes them (rank.py:294 reads K rows)"}
 
 
 def leg_config4(torch, n_pairs=125_000_000):

@@ -68,6 +68,7 @@ SIGNATURES = {
     "eps_expand_unit_count": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _i64, _vp]),
     "eps_expand_unit_fill": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                     _i64, _vp]),
+    "eps_expand_unit_list": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     "eps_spmm_csr": (_int, [_vp, _vp, _vp, _i64, _vp, _i64, _i32, _vp, _int, _int, _vp, _i64, _vp]),
     "eps_gcn_norm": (_int, [_vp, _vp, _vp, _i64, _vp, _vp, _vp]),
     "eps_gemm_f32": (_int, [_vp, _i64, _vp, _i64, _vp, _int, _int, _vp, _i64, _i64, _i32, _i32, _vp]),

@@ -28,6 +28,7 @@
 // candidate instead of the survivors above a bar.
 #include "eps_common.h"
 #include <string.h>
+#include <stdlib.h>
 
 // Geometry (compile-time; the shipped values are the measured best on the ppa-sized graphs).  FS_UR must be 2 * FS_THREADS.
 #ifndef FS_THREADS
@@ -58,7 +59,7 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 struct fs_layout {
     int words;      // bitmap words, a multiple of 1024
     int tile;       // candidate ranks per tile
-    int o_base32, o_pre8, o_acc, o_hist, o_rinfo, o_tile_r0, o_tile_base, o_tile_cur, o_ustart, o_rbase, o_rlen,
+    int o_base32, o_pre8, o_acc, o_hist, o_tile_r0, o_tile_base, o_tile_cur, o_ustart, o_rbase, o_rlen,
         o_ulist, o_vwfix, o_sv, total_words;
 };
 
@@ -72,7 +73,6 @@ __host__ __device__ static inline fs_layout fs_make_layout(int words, int tile_b
     L.o_pre8 = o;    o += words / 4;
     L.o_acc = o;     o += 2 * L.tile;
     L.o_hist = o;    o += FS_RANGES;
-    L.o_rinfo = o;   o += FS_RANGES;
     L.o_tile_r0 = o; o += FS_RANGES + 2;
     L.o_tile_base = o; o += FS_RANGES + 2;
     L.o_tile_cur = o;  o += FS_RANGES + 64;       // + one trash cursor per lane
@@ -115,6 +115,7 @@ struct fs_params {
     int32_t *cand_u, *cand_v; // ascending u inside a column; cand_v may be NULL
     float *out_score;         // NULL: the list only
     unsigned int *status;     // bit 1: a column outgrew its segment, bit 2: a sum left the fixed-point range
+    int32_t no_pad;           // FS_EMIT on an upper-bound layout: leave the unused tail of a segment unwritten (the counts say where it starts)
 };
 
 #define FS_SCAN 0             // report the candidates above a bar (symmetric half scheme)
@@ -177,11 +178,10 @@ __global__ __launch_bounds__(FS_THREADS) void filter_scan_kernel(fs_params p)
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const fs_layout L = fs_make_layout(p.words, p.tile_bits);
     uint32_t *bm = lds;                                   // bit u: u (< v) is a two-hop endpoint of the column
-    uint32_t *base32 = lds + L.o_base32;                  // rank of the first bit of every 8-word group; after the plan: ginfo
+    uint32_t *base32 = lds + L.o_base32;                  // rank of the first bit of every 8-word group
     uint8_t *pre8 = (uint8_t *)(lds + L.o_pre8);          // rank of a word's first bit within its group
     unsigned long long *acc = (unsigned long long *)(lds + L.o_acc);   // fixed-point sums of one tile; zero between uses
     uint32_t *hist = lds + L.o_hist;                      // paths per id range (pass A); zero between columns
-    uint32_t *rinfo = lds + L.o_rinfo;                    // tile of the id range
     uint32_t *tile_r0 = lds + L.o_tile_r0;                // first candidate rank of a tile; [n_tiles] = column total
     uint32_t *tile_base = lds + L.o_tile_base;            // paths of the column before the tile; [n_tiles] = all
     uint32_t *tile_cur = lds + L.o_tile_cur;              // next free record of the tile's bucket (window-relative)
@@ -201,7 +201,7 @@ __global__ __launch_bounds__(FS_THREADS) void filter_scan_kernel(fs_params p)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wib = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int grp = lane >> 4, gl = lane & 15;
-    const int words = p.words, TILE = L.tile, tile_half = TILE >> 1, range_shift = p.range_shift;
+    const int words = p.words, TILE = L.tile, range_shift = p.range_shift;
     const uint32_t tile_mask = (uint32_t)TILE - 1u;
     const float thr = MODE == FS_SCAN ? p.out->threshold : 0.f;
     // the bar in the accumulators' domain: the smallest sum whose float32 score exceeds thr (the conversion is monotone),
@@ -543,12 +543,21 @@ __global__ __launch_bounds__(FS_THREADS) void filter_scan_kernel(fs_params p)
             } else {
                 // the list: thread per bitmap word (neighbouring lanes -> neighbouring ranks), ascending u
                 fs_barrier();                             // rank tables complete
+#ifdef FS_ABL_NOULIST      // (timing-only ablations, tools/r06_full_list_ablate.sh: the outputs are wrong)
+                if (p.no_pad == 7)
+#endif
                 for (int wi = tid; wi < words_v; wi += FS_THREADS) {
                     uint32_t bits = bm[wi];
                     if (bits) {
                         uint32_t run = base32[wi >> 3] + pre8[wi];
                         do {
+#if defined(FS_ABL_ULIST_NOSTORE)
+                            asm volatile("" ::"v"(win_lo + wi * 32 + __builtin_ctz(bits)), "v"(run++));
+#elif defined(FS_ABL_ULIST_SMALL)
+                            p.cand_u[(obase + run++) & 0x3FFFF] = win_lo + wi * 32 + __builtin_ctz(bits);
+#else
                             p.cand_u[obase + run++] = win_lo + wi * 32 + __builtin_ctz(bits);
+#endif
                             bits &= bits - 1;
                         } while (bits);
                     }
@@ -569,13 +578,22 @@ __global__ __launch_bounds__(FS_THREADS) void filter_scan_kernel(fs_params p)
         }
         fs_barrier();
 
-        // ---- plan: id ranges -> tiles of <= TILE candidate ranks; bucket offsets from the path histogram -------------------
+        // ---- plan: tiles of TILE consecutive candidate ranks (the last one partial); bucket room from the path histogram ----
+        // A path's tile is its rank >> tile_bits.  The paths per id range are known (pass A), the paths per TILE are not -- a range
+        // whose ranks straddle a tile boundary (at most one boundary: a range holds at most half a tile of ids) splits unknowably --
+        // so a straddling range reserves its paths in BOTH buckets: range i owns [pbase, pbase + paths) for its first tile and, when
+        // it straddles, [pbase + paths, pbase + 2 paths) for the next.  The bucket of tile t starts where the range that holds rank
+        // t * TILE puts it: at its own start when that rank is its first, at its second copy otherwise.
         {
             const bool in = tid < n_ranges;
-            const uint32_t rs = in ? base32[tid << (range_shift - 8)] : 0u;   // rank at the start of the range
+            const uint32_t rs = in ? base32[tid << (range_shift - 8)] : 0u;   // rank at the start of the range ...
+            const uint32_t re = !in ? 0u : tid + 1 < n_ranges ? base32[(tid + 1) << (range_shift - 8)] : (uint32_t)total;   // ... and past its end
             const uint32_t paths = in ? (hist[tid] + 3u) & ~3u : 0u;   // buckets start on 16-byte lines (D2 reads 4 records per load)
             if (in) hist[tid] = 0u;
-            const int pin = fs_wave_incl_scan((int)paths, lane);
+            const uint32_t tile = rs >> p.tile_bits;
+            const bool straddle = re > rs && ((re - 1u) >> p.tile_bits) != tile;
+            const uint32_t room = straddle ? 2u * paths : paths;
+            const int pin = fs_wave_incl_scan((int)room, lane);
             if (lane == 63) s_wtot[wib] = pin;
             fs_barrier();
             uint32_t pbase = 0, ptotal = 0;
@@ -585,25 +603,14 @@ __global__ __launch_bounds__(FS_THREADS) void filter_scan_kernel(fs_params p)
                 if (i < wib) pbase += t;
                 ptotal += t;
             }
-            pbase += (uint32_t)pin - paths;
-            const uint32_t tile = rs / (uint32_t)tile_half;
-            const uint32_t rs_prev = (in && tid > 0) ? base32[(tid - 1) << (range_shift - 8)] : 0u;
-            if (in && (tid == 0 || rs_prev / (uint32_t)tile_half != tile)) {
-                tile_r0[tile] = rs;
-                tile_base[tile] = pbase;
-            }
-            if (tid == n_ranges - 1) {
-                s_ntiles = (int)tile + 1;
-                tile_r0[tile + 1] = (uint32_t)total;
-                tile_base[tile + 1] = ptotal;
-            }
-            if (in) rinfo[tid] = tile;
-            fs_barrier();
-            // the group table turns from absolute ranks into (tile << 16 | rank of the group's first bit inside its tile):
-            // one look-up per path gives both (a group of 256 ids never straddles a range, hence never a tile)
-            for (int gi = tid; gi < n_groups; gi += FS_THREADS) {
-                const uint32_t tl = rinfo[gi >> (range_shift - 8)];
-                base32[gi] = (tl << 16) | (base32[gi] - tile_r0[tl]);
+            pbase += (uint32_t)pin - room;
+            if (re > rs && (rs & tile_mask) == 0u) tile_base[tile] = pbase;
+            if (straddle) tile_base[tile + 1] = pbase + paths;
+            const int nt = (total + TILE - 1) >> p.tile_bits;
+            if (tid <= nt) tile_r0[tid] = (uint32_t)(tid << p.tile_bits) < (uint32_t)total ? (uint32_t)(tid << p.tile_bits) : (uint32_t)total;
+            if (tid == 0) {
+                s_ntiles = nt;
+                tile_base[nt] = ptotal;
             }
             fs_barrier();
         }
@@ -616,7 +623,7 @@ __global__ __launch_bounds__(FS_THREADS) void filter_scan_kernel(fs_params p)
         // chain of ~25 dependent LDS reads.  Done on the spot it sits on the critical path of its tile (one lane works, fifteen
         // waves wait at the barrier), so survivors are parked in LDS and resolved together when the column's tiles are done.
         auto resolve = [&](uint32_t r, float sc) {
-            auto first_rank = [&](int gi) { const uint32_t x = ginfo[gi]; return tile_r0[x >> 16] + (x & 0xFFFFu); };
+            auto first_rank = [&](int gi) { return ginfo[gi]; };
             int glo = 0, ghi = n_groups;                     // groups [glo, ghi): invariant first_rank(glo) <= r
             while (ghi - glo > 1) {
                 const int mid = (glo + ghi) >> 1;
@@ -658,8 +665,13 @@ __global__ __launch_bounds__(FS_THREADS) void filter_scan_kernel(fs_params p)
                     // bounds the graph's scores before it takes this path -- candidates.fused_scores_fit)
                     if ((a0 | a1) < 0) atomicOr(p.status, 4u);
                     float *o = p.out_score + obase + r0 + i;
+#ifdef FS_ABL_NOSCORESTORE
+                    if (a0 == 0x7fffffffffffffffll)
+#endif
+                    {
                     o[0] = (float)((double)a0 * (1.0 / (double)(1ll << FS_FIXED_SHIFT)));
                     if (i + 1 < nslots) o[1] = (float)((double)a1 * (1.0 / (double)(1ll << FS_FIXED_SHIFT)));
+                    }
                 } else {
                     if (a0 >= thr_fix) survivor(i, a0);
                     if (a1 >= thr_fix && i + 1 < nslots) survivor(i + 1, a1);
@@ -716,9 +728,10 @@ __global__ __launch_bounds__(FS_THREADS) void filter_scan_kernel(fs_params p)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const uint32_t b = f_u[e] & 31u;
-                        tl[e] = (gi[e] >> 16) - (uint32_t)t_lo;                     // tile, relative to the window
+                        rank[e] += gi[e] + __popc(word[e] & ((1u << b) - 1u));      // rank in the window's list ...
+                        tl[e] = (rank[e] >> p.tile_bits) - (uint32_t)t_lo;           // ... its tile, relative to the tile window ...
+                        rank[e] &= tile_mask;                                         // ... and the rank inside the tile
                         cand[e] = (e < f.nvalid && tl[e] < span) ? (word[e] >> b) & 1u : 0u;
-                        rank[e] += (gi[e] & 0xFFFFu) + __popc(word[e] & ((1u << b) - 1u));   // rank inside its tile
                         ncand += cand[e];
                     }
                     return ncand;
@@ -745,6 +758,9 @@ __global__ __launch_bounds__(FS_THREADS) void filter_scan_kernel(fs_params p)
                             // the common lane: four candidates of one tile -> four consecutive records, ONE 16-byte store
                             // (dword-aligned; four scattered 4-byte stores cost four write requests per 64-byte chunk)
                             const uint32_t p0 = atomicAdd(&tile_cur[(uint32_t)t_lo + tfirst], 4u);
+#ifdef FS_ABL_NORECSTORE
+                            if (p0 == 0xdeadbeefu)
+#endif
                             fs_store4(my_scratch + p0, rank[0] | krec, rank[1] | krec, rank[2] | krec, rank[3] | krec);
                         } else {
                         if (tfirst == tlast || ncand == 0) {
@@ -759,7 +775,11 @@ __global__ __launch_bounds__(FS_THREADS) void filter_scan_kernel(fs_params p)
                         }
                         // one store per entry, no branch: what is not a candidate of the window lands in the trash line
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) my_scratch[cand[e] ? pos[e] : p.cap_records + lane] = rank[e] | krec;
+                        for (int e = 0; e < 4; ++e)
+#ifdef FS_ABL_NORECSTORE
+                            if (pos[e] == 0xdeadbeefu)
+#endif
+                            my_scratch[cand[e] ? pos[e] : p.cap_records + lane] = rank[e] | krec;
                         }
                     });
                 }
@@ -784,6 +804,9 @@ __global__ __launch_bounds__(FS_THREADS) void filter_scan_kernel(fs_params p)
                 };
                 auto add = [&](uint32_t r, bool live) {
                     if (!live) return;                       // (mostly whole waves: the tail of a bucket)
+#ifdef FS_ABL_NOACC
+                    if (r != 0xdeadbeefu) return;
+#endif
                     const uint32_t k = r >> p.tile_bits;
                     const long long fx = single ? vwfix[k] : my_gfix[k];
                     atomicAdd(&acc[r & tile_mask], (unsigned long long)fx);
@@ -827,7 +850,7 @@ __global__ __launch_bounds__(FS_THREADS) void filter_scan_kernel(fs_params p)
         }
         if (MODE != FS_SCAN) {
             if (p.cand_count && tid == 0 && !seg_overflow) p.cand_count[v - p.col_base] = col_off;
-            if (MODE == FS_EMIT && !seg_overflow)
+            if (MODE == FS_EMIT && !seg_overflow && !p.no_pad)
                 for (int64_t i = col_off + tid; i < seg_len; i += FS_THREADS) {   // padding of an upper-bound segment
                     p.cand_u[seg_base + i] = -1;
                     if (p.cand_v) p.cand_v[seg_base + i] = v;
@@ -961,8 +984,10 @@ static int fs_range_shift(int64_t ids, int tile_bits)
 
 static bool fs_pick_geometry(int64_t n_nodes, fs_geometry *g)
 {
+    // (EPS_FS_MIN_WIN: geometry experiments -- more, narrower id windows than the LDS asks for)
+    static const int64_t min_win = [] { const char *e = getenv("EPS_FS_MIN_WIN"); return e && atoi(e) > 0 ? (int64_t)atoi(e) : (int64_t)1; }();
     for (int tile_bits = FS_MAX_TILE_BITS; tile_bits >= 9; --tile_bits)
-        for (int64_t n_win = 1; n_win <= 4096; ++n_win) {
+        for (int64_t n_win = min_win; n_win <= 4096; ++n_win) {
             const int64_t words = (((n_nodes + n_win - 1) / n_win + 31) / 32 + 1023) / 1024 * 1024;
             const int64_t win_ids = words * 32;
             if ((n_nodes + win_ids - 1) / win_ids != n_win) continue;        // rounding made a window superfluous
@@ -1153,6 +1178,39 @@ extern "C" int eps_expand_unit_fill(const int64_t *rowptr, const int32_t *col, c
     p.status = status;
     p.revpos = revpos_or_null;
     return fs_launch("eps_expand_unit_fill", p, FS_EMIT, splits, n_nodes, nnz, max_degree, v_hi - v_lo, workspace,
+                     workspace_bytes, stream, revpos_or_null != nullptr);
+}
+
+// The list in ONE pass over the two-hop paths (no counting launch, no host read before the launch): the caller sizes the
+// segments by an upper bound of every column's candidate count (min(two-hop paths, N): colptr_ub), the kernel fills the front of
+// each segment, reports the real counts and leaves the rest of the segment unwritten.
+extern "C" int eps_expand_unit_list(const int64_t *rowptr, const int32_t *col, const int32_t *revpos_or_null,
+                                    const int64_t *fixw, const int32_t *splits, int64_t n_nodes, int64_t nnz, int64_t max_degree,
+                                    int64_t v_lo, int64_t v_hi, const int32_t *col_order, const int64_t *colptr_ub,
+                                    int64_t *cand_count, int32_t *cand_u, float *score, uint32_t *status, void *workspace,
+                                    int64_t workspace_bytes, void *stream)
+{
+    EPS_REQUIRE(n_nodes >= 0 && nnz >= 0 && v_lo >= 0 && v_lo <= v_hi && v_hi <= n_nodes, "eps_expand_unit_list: bad range");
+    if (v_hi == v_lo) return EPS_OK;
+    EPS_REQUIRE(rowptr && col && colptr_ub && cand_count && cand_u && status && (fixw || !score), "eps_expand_unit_list: null pointer");
+    if (hipMemsetAsync(status, 0, sizeof(uint32_t), (hipStream_t)stream) != hipSuccess) {
+        eps_set_error("eps_expand_unit_list: cannot clear the status word");
+        return EPS_ELAUNCH;
+    }
+    fs_params p = fs_blank_params();
+    p.rowptr = rowptr;
+    p.col = col;
+    p.fixw = fixw;
+    p.columns = col_order;
+    p.col_base = (int32_t)v_lo;
+    p.colptr = colptr_ub;
+    p.cand_count = cand_count;
+    p.cand_u = cand_u;
+    p.out_score = score;
+    p.status = status;
+    p.revpos = revpos_or_null;
+    p.no_pad = 1;
+    return fs_launch("eps_expand_unit_list", p, FS_EMIT, splits, n_nodes, nnz, max_degree, v_hi - v_lo, workspace,
                      workspace_bytes, stream, revpos_or_null != nullptr);
 }
 

@@ -188,6 +188,7 @@ class ExpandResult(tuple):
     pairs = None
     counts = None
     survivors = None
+    status = None
 
 
 _EXPAND_WS_LIMIT = 96 << 30       # bytes of bucket scratch we are willing to hold on a 288 GB device
@@ -199,14 +200,46 @@ def expand_workspace_fits(max_paths: int) -> bool:
 
 
 def expand_unit(rowptr, col, node_w, n_nodes: int, v_lo: int, v_hi: int, max_degree: int, splits=None, want_score=True,
-                want_v=True, col_order=None, revpos=None):
+                want_v=True, col_order=None, revpos=None, colptr_ub=None, total_ub=None):
     """The candidate list of columns [v_lo, v_hi) of a graph WITHOUT stored values, on the threshold scan's structure
     (eps_expand_unit_count / eps_expand_unit_fill, csrc/filter_scan.hip): same tuple and same bits as
     ``expand_candidates(rowptr, col, None, node_w, ...)`` with ``want_cn=False`` -- (colptr, cand_u, cand_v | None, None,
     score | None) -- at about half the time.  ``node_w`` None with ``want_score``: all-ones weights (the score is the
     common-neighbour count).  ``max_degree`` / ``splits``: the per-graph figures ``filter_scan`` takes.  ``revpos``
-    (``reverse_positions``; symmetric pattern) selects the HALF list: column v holds its candidates u < v only."""
-    dev = _need_gpu(rowptr, col, node_w, col_order, splits, revpos)
+    (``reverse_positions``; symmetric pattern) selects the HALF list: column v holds its candidates u < v only.
+
+    ``colptr_ub`` (int64[n_cols + 1] on the device: an exclusive prefix of upper bounds of the columns' candidate counts,
+    ``candidates.segment_bounds``) + ``total_ub`` (its last entry as a Python int) select the ONE-PASS list
+    (eps_expand_unit_list): no counting launch, no host read before the launch; column v fills the front of its segment, the rest
+    of the segment is NOT written, ``.counts`` (int64[n_cols]) holds the real counts and there is no cand_v."""
+    dev = _need_gpu(rowptr, col, node_w, col_order, splits, revpos, colptr_ub)
+    if colptr_ub is not None:
+        _chk(colptr_ub, torch.int64, "colptr_ub")
+        if total_ub is None or want_v or colptr_ub.numel() != v_hi - v_lo + 1:
+            raise ValueError("expand_unit: the one-pass list takes colptr_ub[n_cols + 1] + total_ub and writes no cand_v")
+        _chk(rowptr, torch.int64, "rowptr"); _chk(col, torch.int32, "col"); _chk(node_w, torch.float32, "node_w")
+        _chk(col_order, torch.int32, "col_order"); _chk(splits, torch.int32, "splits"); _chk(revpos, torch.int32, "revpos")
+        if col_order is not None and col_order.numel() != v_hi - v_lo:
+            raise ValueError("col_order must have one entry per column of the range")
+        lib = _lib.load()
+        with torch.cuda.device(dev):
+            ws = _scan_scratch(dev, int(max_degree))
+            counts = torch.zeros(v_hi - v_lo, dtype=torch.int64, device=dev)
+            cand_u = torch.empty(int(total_ub), dtype=torch.int32, device=dev)
+            score = torch.empty(int(total_ub), dtype=torch.float32, device=dev) if want_score else None
+            status = torch.empty(1, dtype=torch.int32, device=dev)
+            fixw = None
+            if want_score:
+                fixw = fixed_weights(node_w if node_w is not None else torch.ones(n_nodes, dtype=torch.float32, device=dev))
+            if v_hi > v_lo:
+                _lib.check(lib.eps_expand_unit_list(_ptr(rowptr), _ptr(col), _ptr(revpos), _ptr(fixw), _ptr(splits), n_nodes, col.numel(),
+                                                    int(max_degree), v_lo, v_hi, _ptr(col_order), _ptr(colptr_ub), _ptr(counts),
+                                                    _ptr(cand_u), _ptr(score), _ptr(status), _ptr(ws), ws.numel() * 8, _stream(dev)),
+                           "eps_expand_unit_list")
+        out = ExpandResult((colptr_ub, cand_u, None, None, score))
+        out.counts = counts
+        out.status = status           # (device word: bit 1 = a bound was too small, bit 2 = a sum left the fixed-point range)
+        return out
     _chk(revpos, torch.int32, "revpos")
     _chk(rowptr, torch.int64, "rowptr"); _chk(col, torch.int32, "col"); _chk(node_w, torch.float32, "node_w")
     _chk(col_order, torch.int32, "col_order"); _chk(splits, torch.int32, "splits")

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define EPS_ABI_VERSION 7   /* 7: the tail of the filter step with device-side sizes -- eps_score_hist / _pick_compact, eps_radix_sort_by_u / _rows, eps_rescore_runs_dev; eps_scan_screen takes a column pack, eps_scan_column_pack (r06); 6: skipped heads -- eps_scan_heads / _hub_rows / _refine; eps_scan_window_paths / _plan / _screen take a head table (r05); 2: eps_col_sums / eps_node_weights_f64 signatures (r02); 3: 64-bit survivor count, eps_scan_* (r03); 4: eps_scan_screen takes ssum / smax; 5: eps_select_compact, eps_scan_screen marks unused slots itself (r04) */
+#define EPS_ABI_VERSION 7   /* 7: the tail of the filter step with device-side sizes -- eps_score_hist / _pick_compact, eps_radix_sort_by_u / _rows, eps_rescore_runs_dev; eps_scan_screen takes a column pack, eps_scan_column_pack, eps_expand_unit_list (r06); 6: skipped heads -- eps_scan_heads / _hub_rows / _refine; eps_scan_window_paths / _plan / _screen take a head table (r05); 2: eps_col_sums / eps_node_weights_f64 signatures (r02); 3: 64-bit survivor count, eps_scan_* (r03); 4: eps_scan_screen takes ssum / smax; 5: eps_select_compact, eps_scan_screen marks unused slots itself (r04) */
 
 #define EPS_OK 0
 #define EPS_EINVAL (-1)   /* bad argument (null pointer, negative size, unsupported shape) */
@@ -400,6 +400,17 @@ int eps_expand_unit_fill(const int64_t *rowptr, const int32_t *col, const int32_
                          int64_t n_nodes, int64_t nnz, int64_t max_degree, int64_t v_lo, int64_t v_hi,
                          const int32_t *col_order, const int64_t *colptr, int64_t *cand_count, int32_t *cand_u,
                          int32_t *cand_v, float *score, uint32_t *status, void *workspace, int64_t workspace_bytes,
+                         void *stream);
+/* eps_expand_unit_list (r06): the same list in ONE pass over the two-hop paths -- what filter.py:96-142 does once per candidate
+ * -- without the counting launch and without a host read before the launch: colptr_ub[v_hi - v_lo + 1] is an exclusive
+ * prefix of UPPER BOUNDS of the columns' candidate counts (min(two-hop paths of the column, n_nodes) always holds), column v
+ * fills the front of [colptr_ub[v], colptr_ub[v + 1]) with its candidates (u ascending) and their scores -- the same values
+ * as eps_expand_unit_fill, bit for bit --, cand_count[v] receives how many, and the rest of the segment is left unwritten
+ * (no cand_v: the column of slot i is the segment that holds it).  status / workspace / splits / revpos_or_null as above. */
+int eps_expand_unit_list(const int64_t *rowptr, const int32_t *col, const int32_t *revpos_or_null, const int64_t *fixw,
+                         const int32_t *splits_or_null, int64_t n_nodes, int64_t nnz, int64_t max_degree, int64_t v_lo,
+                         int64_t v_hi, const int32_t *col_order, const int64_t *colptr_ub, int64_t *cand_count,
+                         int32_t *cand_u, float *score, uint32_t *status, void *workspace, int64_t workspace_bytes,
                          void *stream);
 
 /* ---- K4/K5: CSR x dense SpMM with fused epilogue -----------------------------------------

@@ -348,6 +348,22 @@ def _unit_vs_expand(eps, g, wt, lo, hi, col_order=None):
         per_col = torch.zeros(hi - lo, dtype=torch.int64, device=want[1].device)
         per_col.index_add_(0, (want[2][keep] - lo).long(), torch.ones(int(keep.sum()), dtype=torch.int64, device=want[1].device))
         assert torch.equal(half[0][1:] - half[0][:-1], per_col)
+    # the ONE-PASS list (eps_expand_unit_list: upper-bound segments, no counting launch): the front of every segment holds the
+    # column's candidates and scores -- same bits --, the counts come back, nothing is written behind them
+    from eps_amd import candidates as _cand
+    pre = _cand.segment_bounds(g)[0]
+    ub = (pre[lo:hi + 1] - pre[lo]).contiguous()
+    total_ub = int(ub[-1]) if hi > lo else 0
+    one = eps.ops.expand_unit(g.rowptr, g.col, wt, g.n_rows, lo, hi, md, sp, want_v=False, col_order=col_order, colptr_ub=ub,
+                              total_ub=total_ub)
+    assert int(one.status) == 0 or hi == lo
+    assert torch.equal(one.counts, want[0][1:] - want[0][:-1]), "one-pass counts"
+    if total_ub:
+        slot = torch.arange(total_ub, device=ub.device)
+        seg = torch.searchsorted(ub[1:], slot, right=True)
+        real = slot - ub[seg] < one.counts[seg]
+        assert int(real.sum()) == int(want[0][-1])
+        assert torch.equal(one[1][real], want[1]) and torch.equal(one[4][real], want[4]), "one-pass list: same bits"
     cn = eps.ops.expand_unit(g.rowptr, g.col, None, g.n_rows, lo, hi, md, sp)         # all-ones weights: the CN count
     ref_cn = eps.ops.expand_candidates(g.rowptr, g.col, None, None, g.n_rows, lo, hi, want_cn=True, want_score=False)[3]
     assert torch.equal(cn[4], ref_cn.to(torch.float32))
