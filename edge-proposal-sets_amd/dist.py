@@ -24,6 +24,12 @@ import torch
 import torch.distributed as dist
 
 
+# Tests on a 1-GPU box: run every helper's collective even in a job of ONE rank (they normally return early), so that the calls --
+# dtypes, shapes, split lists -- go through RCCL itself (`init_process_group("nccl", world_size=1)`); scan.FORCE_SHARDED sends the
+# sharded filter step through them.  tests/test_gpu_rccl_world1.py
+FORCE_COLLECTIVES = False
+
+
 def init_from_env(backend: Optional[str] = None, device_index: Optional[int] = None,
                   host_only: bool = False) -> Tuple[int, int, torch.device]:
     """Join the job described by RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* (torchrun).  -> (rank, world, device).
@@ -60,7 +66,7 @@ def all_gather_list(t: torch.Tensor) -> List[torch.Tensor]:
     """Every rank's copy of an equally shaped tensor, in rank order.  RCCL moves device tensors directly; gloo (CPU
     jobs and the one-device test hook) gathers through host memory."""
     rank, world = world_info()
-    if world == 1:
+    if world == 1 and not FORCE_COLLECTIVES:
         return [t]
     if dist.get_backend() == "gloo" and t.device.type != "cpu":
         parts = [torch.empty_like(t, device="cpu") for _ in range(world)]
@@ -74,7 +80,7 @@ def all_gather_list(t: torch.Tensor) -> List[torch.Tensor]:
 def all_reduce_min_(t: torch.Tensor) -> torch.Tensor:
     """In-place minimum over the ranks of a small device tensor (the ranks' bar estimates); transport as ``all_reduce_sum_``."""
     rank, world = world_info()
-    if world == 1:
+    if world == 1 and not FORCE_COLLECTIVES:
         return t
     if dist.get_backend() == "gloo" and t.device.type != "cpu":
         h = t.cpu()
@@ -89,7 +95,7 @@ def all_reduce_sum_(t: torch.Tensor) -> torch.Tensor:
     """In-place sum over the ranks of a small device tensor (histograms, counters).  RCCL reduces device memory directly and
     stays on the stream; gloo (the one-device test hook) goes through host memory."""
     rank, world = world_info()
-    if world == 1:
+    if world == 1 and not FORCE_COLLECTIVES:
         return t
     if dist.get_backend() == "gloo" and t.device.type != "cpu":
         h = t.cpu()
@@ -104,7 +110,7 @@ def gather_ragged(t: torch.Tensor, lens: Sequence[int]) -> torch.Tensor:
     """All ranks' 1-D tensors concatenated in rank order when every rank already KNOWS all lengths (they travelled with an
     earlier exchange): one padded all-gather, no length round trip, no host synchronisation."""
     rank, world = world_info()
-    if world == 1:
+    if world == 1 and not FORCE_COLLECTIVES:
         return t[:lens[0]]
     mx = max(max(lens), 1)
     pad = torch.zeros(mx, dtype=t.dtype, device=t.device)
@@ -118,7 +124,7 @@ def gather_ragged_to(t: torch.Tensor, lens: Sequence[int], dst: int) -> Optional
     written by one rank -- filter.py:160-165 -- so the K rows need not travel to all of them: at N = 8 an all-gather of the 4 M
     rows puts 48 MB on every rank's links, a gather 42 MB on one rank's seven)."""
     rank, world = world_info()
-    if world == 1:
+    if world == 1 and not FORCE_COLLECTIVES:
         return t[:lens[0]]
     mx = max(max(lens), 1)
     pad = torch.zeros(mx, dtype=t.dtype, device=t.device)
@@ -138,7 +144,7 @@ def all_to_all_ragged(t: torch.Tensor, send_counts: Sequence[int], recv_counts: 
     and receives ``recv_counts[r]`` elements from rank r, concatenated in rank order.  Every rank knows both count lists already
     (no length round trip).  RCCL moves device memory directly; gloo (the one-device test hook) goes through host memory."""
     rank, world = world_info()
-    if world == 1:
+    if world == 1 and not FORCE_COLLECTIVES:
         return t[:send_counts[0]]
     via_host = dist.get_backend() == "gloo" and t.device.type != "cpu"
     src = (t.cpu() if via_host else t).contiguous()
@@ -203,7 +209,7 @@ def all_gather_rows(local: torch.Tensor, bounds: Sequence[int]) -> torch.Tensor:
     """All-gather a row-partitioned [N,F] matrix: rank r holds rows [bounds[r], bounds[r+1]).  One collective
     (ragged shards are padded to the largest)."""
     rank, world = world_info()
-    if world == 1:
+    if world == 1 and not FORCE_COLLECTIVES:
         return local
     sizes = [bounds[r + 1] - bounds[r] for r in range(world)]
     mx = max(sizes)
@@ -222,7 +228,7 @@ def all_gather_keys(keys: torch.Tensor, k: int) -> List[torch.Tensor]:
     """Gather every rank's (<= k) sorted int64 keys.  The true lengths travel with the lists (every int64 bit pattern
     is a legal key, so no value can serve as a padding sentinel)."""
     rank, world = world_info()
-    if world == 1:
+    if world == 1 and not FORCE_COLLECTIVES:
         return [keys]
     n = min(int(keys.numel()), k)
     pad = torch.zeros((k + 1,), dtype=torch.int64, device=keys.device)

@@ -1071,8 +1071,8 @@ def kth_largest_dist(x: torch.Tensor, k: int, world: int = 1) -> torch.Tensor:
         _lib.check(lib.eps_kth_begin(_ptr(state), int(k), st), "eps_kth_begin")
         for shift in (24, 16, 8, 0):
             _lib.check(lib.eps_kth_hist_f32(_ptr(x), x.numel(), _ptr(state), shift, st), "eps_kth_hist_f32")
-            if world > 1:
-                from . import dist as epd
+            from . import dist as epd
+            if world > 1 or epd.FORCE_COLLECTIVES:
                 epd.all_reduce_sum_(state[4:260])
             _lib.check(lib.eps_kth_pick(_ptr(state), shift, _ptr(out), st), "eps_kth_pick")
     return out

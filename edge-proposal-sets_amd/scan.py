@@ -51,6 +51,14 @@ HEAD_MIN_PATHS = 1 << 30   # graphs with fewer two-hop half paths are scanned wi
 HEAD_MAX_ROWS = 1024       # rows a column's head holds at most (eps_scan_refine probes each of them for every slot that passes; 48 cost resource allocation 2 ms of scan for 0.15 of refine)
 HEAD_CACHE = 4             # head tables kept per (graph, weight table)
 DMAX_MARGIN = 5               # a piece drops low weight bits only down to this many bits below the graph's smallest weight (screen_weights)
+FORCE_SHARDED = False         # tests on a 1-GPU box: a job of ONE rank takes the sharded step's control flow (its exchanges over the process
+                              # group -- with dist.FORCE_COLLECTIVES through RCCL itself; tests/test_gpu_rccl_world1.py)
+
+
+def _sharded(world: int) -> bool:
+    return world > 1 or FORCE_SHARDED
+
+
 LAZY_PLAN = True              # the whole-graph plan table (no skipped heads) is built when a launch first wants it; the bar sample plans itself
 ROW_RECORDS = True            # the launch gathers a row's cuts, first entry and weight out of ONE 128-byte line (ops.scan_row_records)
 BATCH_MIN_COLUMNS = 1 << 16   # lists shorter than this are handed out one column at a time throughout
@@ -655,7 +663,7 @@ def candidate_count(g: CSRGraph, screen: Optional[Screen], fixw, rank: int = 0, 
     if "n_candidates" not in g._cache:
         res = _launch(g, fixw, shard_columns(g, rank, world), float("inf"), 1 << 16, screen=screen)
         n = res.rec[4:5].clone()
-        if world > 1:
+        if _sharded(world):
             from . import dist as epd
             n = epd.all_reduce_sum_(n)
         g._cache["n_candidates"] = int(n.item())
@@ -777,7 +785,7 @@ def estimate_bar(g: CSRGraph, fixw: torch.Tensor, k: int, stride: Optional[int] 
         bar = ops.score_pick_compact(None, res.val, res.count_ptr, base, m_loc, mode=1)[4]
     else:
         bar = ops.select_compact(None, res.val, m_loc, res.count_ptr, mode=1, compact=False)[4]
-    if world > 1:
+    if _sharded(world):
         from . import dist as epd
         # (a rank whose share of the sample holds fewer than m_loc candidates has no estimate: it does not vote)
         inf = torch.full_like(bar, float("inf"))
@@ -1031,7 +1039,7 @@ def scan_topk(g: CSRGraph, node_w: torch.Tensor, k: int, rank: int = 0, world: i
         l_keys, l_vals = res.key, res.val
         status, pre_thr = None, None
         rows = None
-        fast = (TAIL_DEVICE and world == 1 and screen is not None and g.val is None and bar is not None and not rescore_all
+        fast = (TAIL_DEVICE and not _sharded(world) and screen is not None and g.val is None and bar is not None and not rescore_all
                 and k2 + (1 << 16) < (1 << 30))
         if fast:
             # r06: the step's selections come from score-bucket histograms instead of four-round radix selects: the pre-filter
@@ -1137,7 +1145,7 @@ def scan_topk(g: CSRGraph, node_w: torch.Tensor, k: int, rank: int = 0, world: i
                        bar.view(torch.int32).to(torch.int64) if bar is not None else zero]               # the bar's bits (head launches)
         if fast:
             pass
-        elif world > 1 and screen is not None and not rescore_all and bar is not None and DIST_HIST:
+        elif _sharded(world) and screen is not None and not rescore_all and bar is not None and DIST_HIST:
             # r06 -- ONE exchange for the cut AND the step's status, 25 KB per rank whatever the lists hold: every rank's histogram of
             # its re-scored scores over order-preserving buckets of their distance to the bar (ops.score_hist_into: the bar is the
             # same on every rank) behind six status words, all-gathered.  From the same table every rank then derives, in ONE small
@@ -1162,7 +1170,7 @@ def scan_topk(g: CSRGraph, node_w: torch.Tensor, k: int, rank: int = 0, world: i
             table = [flat[r * 8:(r + 1) * 8] for r in range(world)]
             deal_c = [flat[8 * world + r * world:8 * world + (r + 1) * world] for r in range(world)]
             scores_all = True                     # (marks "the deal plan is at hand" for the ordering below)
-        elif world > 1 and screen is not None and not rescore_all:
+        elif _sharded(world) and screen is not None and not rescore_all:
             # (no bar -- small candidate sets -- or DIST_HIST off: the r05 exchange of the scores themselves.  Its length must be the
             #  same on every rank and hold every rank's list: a level of tied scores at a rank's pre-filter threshold may have grown
             #  that rank's list beyond the room it started with -- ADVICE r05 -- so the ranks agree on the longest list first: one
@@ -1194,13 +1202,13 @@ def scan_topk(g: CSRGraph, node_w: torch.Tensor, k: int, rank: int = 0, world: i
             table = [flat[r * 8:(r + 1) * 8] for r in range(world)]
             deal_c = [flat[8 * world + r * world:8 * world + (r + 1) * world] for r in range(world)]
         else:
-            if world == 1 and screen is not None:
+            if not _sharded(world) and screen is not None:
                 sel_k, sel_v, n_sel, cut, _ = ops.select_compact(l_keys, l_vals, k2)          # (one launch: select + compaction)
             else:
                 cut = ops.kth_largest_dist(l_vals, k2, world)
                 sel_k, sel_v, n_sel = ops.compact_at_least(l_keys, l_vals, cut)
             st = torch.cat([res.rec[1:2], res.rec[4:5], n_sel, cut.view(torch.int32).to(torch.int64)] + st_tail)
-            if world > 1:
+            if _sharded(world):
                 from . import dist as epd
                 table = torch.stack(epd.all_gather_list(st)).tolist()                          # the host read of the step
             else:
@@ -1278,12 +1286,13 @@ def scan_topk(g: CSRGraph, node_w: torch.Tensor, k: int, rank: int = 0, world: i
     shard_info = None
     if rows is not None:
         keys = vals = None                          # (the device tail has ordered the rows already)
-    elif world > 1 and scores_all is not None and n_sel_all >= DIST_ROWS_MIN:
+    elif _sharded(world) and scores_all is not None and n_sel_all >= DIST_ROWS_MIN:
         keys, vals = _deal_rows(keys.contiguous(), vals.contiguous(), deal_sp, deal_c, k, bits, perm, rank, world, rows_on)
         if rows_on == "shards":
             lens = [2 * sum(deal_c[r][q] for r in range(world)) for q in range(world)]
             shard_info = (min(sum(lens[:rank]), k), min(sum(lens), k))
-    elif world > 1:
+    elif _sharded(world):
+        from . import dist as epd
         keys, vals = epd.gather_ragged(keys, nsel_r), epd.gather_ragged(vals, nsel_r)
         if n_sel_all >= DIST_ROWS_MIN:
             keys, vals = _ordered_rows_distributed(keys.contiguous(), vals.contiguous(), k, bits, perm, rank, world,
@@ -1298,7 +1307,7 @@ def scan_topk(g: CSRGraph, node_w: torch.Tensor, k: int, rank: int = 0, world: i
             lo_r, hi_r = rank * n_rows // world, (rank + 1) * n_rows // world
             shard_info = (lo_r, n_rows)
             keys, vals = keys[lo_r:hi_r], vals[lo_r:hi_r]
-    elif world == 1 and keys.is_cuda:
+    elif not _sharded(world) and keys.is_cuda:
         # (one rank: the rows are written as the [2, K] proposal tensor by the sort's last kernel)
         rows = ops.select_rows_pairs(keys.contiguous(), vals.contiguous(), k, bits, perm)
         rows = (rows[0], rows[1], rows[0].shape[1])
