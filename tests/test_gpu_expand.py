@@ -340,7 +340,7 @@ def _unit_vs_expand(eps, g, wt, lo, hi, col_order=None):
     lst = eps.ops.expand_unit(g.rowptr, g.col, None, g.n_rows, lo, hi, md, sp, want_score=False, want_v=False)
     assert torch.equal(lst[0], want[0]) and torch.equal(lst[1], want[1]) and lst[2] is None and lst[4] is None
     # the HALF list (revpos given; symmetric patterns): exactly the u < v part of every column, same score bits
-    from eps_amd import scan as _scan
+    from eps_amd import candidates as _cand, scan as _scan
     if _scan.is_symmetric(g):
         half = eps.ops.expand_unit(g.rowptr, g.col, wt, g.n_rows, lo, hi, md, sp, col_order=col_order, revpos=_scan.reverse_positions(g))
         keep = want[1] < want[2]
@@ -348,6 +348,16 @@ def _unit_vs_expand(eps, g, wt, lo, hi, col_order=None):
         per_col = torch.zeros(hi - lo, dtype=torch.int64, device=want[1].device)
         per_col.index_add_(0, (want[2][keep] - lo).long(), torch.ones(int(keep.sum()), dtype=torch.int64, device=want[1].device))
         assert torch.equal(half[0][1:] - half[0][:-1], per_col)
+        if hi > lo:                                  # ... and the one-pass form of the half list (the same bounds hold)
+            pre_h = _cand.segment_bounds(g)[0]
+            ub_h = (pre_h[lo:hi + 1] - pre_h[lo]).contiguous()
+            one_h = eps.ops.expand_unit(g.rowptr, g.col, wt, g.n_rows, lo, hi, md, sp, want_v=False, col_order=col_order,
+                                        revpos=_scan.reverse_positions(g), colptr_ub=ub_h, total_ub=int(ub_h[-1]))
+            assert int(one_h.status) == 0 and torch.equal(one_h.counts, per_col)
+            slot_h = torch.arange(int(ub_h[-1]), device=ub_h.device)
+            seg_h = torch.searchsorted(ub_h[1:], slot_h, right=True)
+            real_h = slot_h - ub_h[seg_h] < one_h.counts[seg_h]
+            assert torch.equal(one_h[1][real_h], half[1]) and torch.equal(one_h[4][real_h], half[4])
     # the ONE-PASS list (eps_expand_unit_list: upper-bound segments, no counting launch): the front of every segment holds the
     # column's candidates and scores -- same bits --, the counts come back, nothing is written behind them
     from eps_amd import candidates as _cand
