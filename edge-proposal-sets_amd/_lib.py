@@ -39,6 +39,8 @@ SIGNATURES = {
     "eps_relabel_graph_workspace_bytes": (_i64, [_i64, _i64, _i32]),
     "eps_relabel_graph": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _vp, _vp, _vp, _i64, _vp]),
     "eps_reverse_positions_symmetric": (_int, [_vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp]),
+    "eps_reverse_positions_sorted_workspace_bytes": (_i64, [_i64, _i64]),
+    "eps_reverse_positions_sorted": (_int, [_vp, _vp, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     "eps_node_order_workspace_bytes": (_i64, [_i64]),
     "eps_node_order": (_int, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     "eps_score_bound": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp]),

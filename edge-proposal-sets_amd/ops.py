@@ -383,6 +383,10 @@ def reverse_positions(rowptr: torch.Tensor, col: torch.Tensor, with_stats: bool 
     return (out, hp, flag) if with_stats else out
 
 
+REVPOS_SORT_MIN = 1 << 62      # stored entries from which the reverse positions come out of a sort instead of searches: never by default --
+                               # measured 3.56 vs 3.37 ms on the ppa-like graph (tools/r06_revpos_time.py, profiles/r06/revpos_sorted.txt)
+
+
 def reverse_positions_symmetric(rowptr: torch.Tensor, col: torch.Tensor):
     """(revpos, half_paths, asymmetric flag) as ``reverse_positions(with_stats=True)`` for a SYMMETRIC pattern, with one search
     per unordered stored pair (eps_reverse_positions_symmetric); the flag comes back 1 on any other pattern and revpos is then
@@ -395,6 +399,15 @@ def reverse_positions_symmetric(rowptr: torch.Tensor, col: torch.Tensor):
     # one small buffer for everything the caller reads back: [asymmetric flag (low word), max degree, max half paths, their sum]
     # (zeros: the library clears the flag as the 32-bit word it is -- the high half of info[0] is nobody's)
     info = torch.zeros(4, dtype=torch.int64, device=dev)
+    if col.numel() >= REVPOS_SORT_MIN:
+        # (r06: no search at all -- the mirror entries come out of a stable sort of the entry indices by column id)
+        lib = _lib.load()
+        with torch.cuda.device(dev):
+            _keep, wsp, wsb = _aligned_ws(dev, lib.eps_reverse_positions_sorted_workspace_bytes(n, col.numel()))
+            _lib.check(lib.eps_reverse_positions_sorted(_ptr(rowptr), _ptr(col), n, col.numel(), max(1, int(n - 1).bit_length()), _ptr(out),
+                                                        _ptr(hp), info.data_ptr(), info.data_ptr() + 8, wsp, wsb, _stream(dev)),
+                       "eps_reverse_positions_sorted")
+        return out, hp, info
     with torch.cuda.device(dev):
         _lib.check(_lib.load().eps_reverse_positions_symmetric(_ptr(rowptr), _ptr(col), n, col.numel(), _ptr(out), _ptr(hp),
                                                                info.data_ptr(), info.data_ptr() + 8, _stream(dev)),

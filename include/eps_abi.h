@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define EPS_ABI_VERSION 7   /* 7: the tail of the filter step with device-side sizes -- eps_score_hist / _pick_compact, eps_radix_sort_by_u / _rows, eps_rescore_runs_dev; eps_scan_screen takes a column pack, eps_scan_column_pack, eps_expand_unit_list (r06); 6: skipped heads -- eps_scan_heads / _hub_rows / _refine; eps_scan_window_paths / _plan / _screen take a head table (r05); 2: eps_col_sums / eps_node_weights_f64 signatures (r02); 3: 64-bit survivor count, eps_scan_* (r03); 4: eps_scan_screen takes ssum / smax; 5: eps_select_compact, eps_scan_screen marks unused slots itself (r04) */
+#define EPS_ABI_VERSION 7   /* 7: the tail of the filter step with device-side sizes -- eps_score_hist / _pick_compact, eps_radix_sort_by_u / _rows, eps_rescore_runs_dev; eps_scan_screen takes a column pack, eps_scan_column_pack, eps_expand_unit_list, eps_reverse_positions_sorted (r06); 6: skipped heads -- eps_scan_heads / _hub_rows / _refine; eps_scan_window_paths / _plan / _screen take a head table (r05); 2: eps_col_sums / eps_node_weights_f64 signatures (r02); 3: 64-bit survivor count, eps_scan_* (r03); 4: eps_scan_screen takes ssum / smax; 5: eps_select_compact, eps_scan_screen marks unused slots itself (r04) */
 
 #define EPS_OK 0
 #define EPS_EINVAL (-1)   /* bad argument (null pointer, negative size, unsupported shape) */
@@ -218,6 +218,15 @@ int eps_relabel_graph(const int64_t *rowptr, const int32_t *col, const float *va
                       float *out_val_or_null, void *workspace, int64_t workspace_bytes, void *stream);
 int eps_reverse_positions_symmetric(const int64_t *rowptr, const int32_t *col, int64_t n_nodes, int64_t nnz, int32_t *revpos,
                                     int64_t *half_paths, uint32_t *asymmetric, unsigned long long *stats_or_null, void *stream);
+/* eps_reverse_positions_sorted (r06): the same outputs without a search -- a stable radix sort of the entry indices by column id
+ * puts the mirror of the CSR's j-th entry at place j (symmetric patterns), one pass scatters the positions and checks the
+ * pattern on the way; id_bits = bits of the largest id; workspace: eps_reverse_positions_sorted_workspace_bytes() bytes,
+ * 256-byte aligned.  (filter.py:96-109 leaves the adjacency as it loaded it; this table is the scan's: the position of v in
+ * row w for every stored (v, w) -- what lets column v walk only the endpoints u < v of its rows.) */
+int64_t eps_reverse_positions_sorted_workspace_bytes(int64_t n_nodes, int64_t nnz);
+int eps_reverse_positions_sorted(const int64_t *rowptr, const int32_t *col, int64_t n_nodes, int64_t nnz, int32_t id_bits,
+                                 int32_t *revpos, int64_t *half_paths, uint32_t *asymmetric, unsigned long long *stats_or_null,
+                                 void *workspace, int64_t workspace_bytes, void *stream);
 /* eps_node_order: order[i] (int32) = the node with the i-th largest key, ties by ascending id (a stable descending radix sort)
  * -- keys = the degrees (rowptr given: the hubs-first labels) or keys[] (int64, non-negative: the scan's heaviest-first column
  * order from the half paths).  Optional by-products for eps_relabel_graph: perm64[i] = order[i], inv32[order[i]] = i,

@@ -31,10 +31,14 @@ def test_relabel_graph_is_the_same_graph(eps, dev, valued, scale, ef, seed):
     assert torch.equal(back, g.col[g.rowptr[i]:g.rowptr[i + 1]].long())
 
 
+@pytest.mark.parametrize("how", ["searches", "sorted"])
 @pytest.mark.parametrize("scale,ef,seed", [(10, 8, 1), (13, 12, 4), (8, 40, 9)])
-def test_reverse_positions_symmetric_vs_general(eps, dev, scale, ef, seed):
+def test_reverse_positions_symmetric_vs_general(eps, dev, scale, ef, seed, how, monkeypatch):
+    """eps_reverse_positions_symmetric (one search per unordered stored pair) and eps_reverse_positions_sorted (r06: no search -- a stable
+    sort of the entry indices by column id) against the general table: same positions, half paths, statistics and flag."""
     from eps_amd import synth
     from eps_amd.graph import CSRGraph
+    monkeypatch.setattr(eps.ops, "REVPOS_SORT_MIN", 0 if how == "sorted" else 1 << 62)
     g = synth.rmat_graph(scale, ef, seed, dev)
     r0, h0, f0 = eps.ops.reverse_positions(g.rowptr, g.col, with_stats=True)
     r1, h1, f1 = eps.ops.reverse_positions_symmetric(g.rowptr, g.col)
