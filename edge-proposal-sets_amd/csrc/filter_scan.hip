@@ -992,9 +992,10 @@ static bool fs_pick_geometry(int64_t n_nodes, fs_geometry *g)
             const int64_t win_ids = words * 32;
             if ((n_nodes + win_ids - 1) / win_ids != n_win) continue;        // rounding made a window superfluous
             const int rs = fs_range_shift(win_ids < n_nodes ? win_ids : n_nodes, tile_bits);
-            // (four group trips per thread at most; the ranks of a window are packed in 20 bits)
+            // (four group trips per thread at most; the ranks of a window are packed in 20 bits; a window's tiles -- one per
+            //  2^tile_bits ranks -- fit the tile tables)
             if ((size_t)fs_make_layout((int)words, tile_bits).total_words * 4 <= FS_LDS_LIMIT && rs >= 8 &&
-                words / 8 <= 4 * FS_THREADS && win_ids <= (1 << 20)) {
+                words / 8 <= 4 * FS_THREADS && win_ids <= (1 << 20) && (win_ids >> tile_bits) <= FS_RANGES) {
                 g->n_win = (int)n_win;
                 g->words = (int)words;
                 g->tile_bits = tile_bits;

@@ -227,7 +227,7 @@ def expand_unit(rowptr, col, node_w, n_nodes: int, v_lo: int, v_hi: int, max_deg
             counts = torch.zeros(v_hi - v_lo, dtype=torch.int64, device=dev)
             cand_u = torch.empty(int(total_ub), dtype=torch.int32, device=dev)
             score = torch.empty(int(total_ub), dtype=torch.float32, device=dev) if want_score else None
-            status = torch.empty(1, dtype=torch.int32, device=dev)
+            status = torch.zeros(1, dtype=torch.int32, device=dev)       # (the call clears it itself; an empty range makes no call)
             fixw = None
             if want_score:
                 fixw = fixed_weights(node_w if node_w is not None else torch.ones(n_nodes, dtype=torch.float32, device=dev))

@@ -366,7 +366,7 @@ def _unit_vs_expand(eps, g, wt, lo, hi, col_order=None):
     total_ub = int(ub[-1]) if hi > lo else 0
     one = eps.ops.expand_unit(g.rowptr, g.col, wt, g.n_rows, lo, hi, md, sp, want_v=False, col_order=col_order, colptr_ub=ub,
                               total_ub=total_ub)
-    assert int(one.status) == 0 or hi == lo
+    assert int(one.status) == 0
     assert torch.equal(one.counts, want[0][1:] - want[0][:-1]), "one-pass counts"
     if total_ub:
         slot = torch.arange(total_ub, device=ub.device)
