@@ -233,6 +233,70 @@ def test_expand_full_size_properties(eps, dev):
     assert torch.equal(sc[pos], sc[inside]) and torch.equal(cn[pos], cn[inside])
 
 
+def test_one_pass_list_full_size(eps, dev):
+    """BASELINE scale (ppa-like, N = 576,289): the ONE-PASS list (eps_expand_unit_list) over the WHOLE graph in blocks of 2^33 two-hop
+    paths.  (1) its per-column counts sum to the candidate set's size as a counting scan reports it independently; (2) on the first
+    production-sized block (2^31 paths) the list and the scores are bit-identical to eps_expand_unit_count / _fill AND to
+    eps_expand_count / _fill (expand_score.hip: a different kernel); (3) for a dozen columns -- hubs, median degree, tail -- the
+    rows are the ORACLE's restated filter.py:96-109 candidates with its pair scores (ids exact, scores <= 1e-5 relative)."""
+    from eps_amd import candidates, scan, synth
+    from eps_amd.heuristics import node_weight_table
+    from oracle import eps_oracle as orc
+    g = synth.ppa_like(seed=3, device=dev)
+    wt = node_weight_table(g, eps.ops.W_AA)
+    n = g.n_rows
+    md, sp = scan.max_degree(g), scan.window_splits(g)
+    pre, pre_host = candidates.segment_bounds(g)
+    deg = g.degree()
+    by_deg = torch.argsort(deg, descending=True)
+    cols = sorted({int(by_deg[i]) for i in (0, 3, 50, 1000, n // 4, n // 2, 3 * n // 4, n - 1000, n - 2)} | {7, n - 1})
+    counts, kept = [], {}
+    for lo, hi in candidates.column_blocks(g, 1 << 33):
+        ub = (pre[lo:hi + 1] - pre[lo]).contiguous()
+        r = eps.ops.expand_unit(g.rowptr, g.col, wt, n, lo, hi, md, sp, want_v=False, col_order=candidates.heaviest_first(g, lo, hi),
+                                colptr_ub=ub, total_ub=int(pre_host[hi] - pre_host[lo]))
+        assert int(r.status) == 0
+        counts.append(r.counts)
+        for c in cols:
+            if lo <= c < hi:
+                a, m = int(ub[c - lo]), int(r.counts[c - lo])
+                kept[c] = (r[1][a:a + m].cpu().numpy(), r[4][a:a + m].cpu().numpy())
+        del r
+    counts = torch.cat(counts)
+    assert bool((counts <= pre[1:] - pre[:-1]).all())
+    # (1) the whole candidate set: both orientations of every unordered 2-hop non-edge
+    fixw = scan.fixed_weights(g, wt)
+    assert int(counts.sum()) == 2 * scan.candidate_count(g, None, fixw)
+    # (2) block 0 of the production block size, bit for bit, against both two-pass kernels
+    lo, hi = next(iter(candidates.column_blocks(g)))
+    order = candidates.heaviest_first(g, lo, hi)
+    ub = (pre[lo:hi + 1] - pre[lo]).contiguous()
+    one = eps.ops.expand_unit(g.rowptr, g.col, wt, n, lo, hi, md, sp, want_v=False, col_order=order, colptr_ub=ub,
+                              total_ub=int(pre_host[hi] - pre_host[lo]))
+    two = eps.ops.expand_unit(g.rowptr, g.col, wt, n, lo, hi, md, sp, want_v=False, col_order=order)
+    assert torch.equal(one.counts, two[0][1:] - two[0][:-1]) and torch.equal(one.counts, counts[lo:hi])
+    slot = torch.arange(int(ub[-1]), device=dev)
+    seg = torch.searchsorted(ub[1:], slot, right=True)
+    real = slot - ub[seg] < one.counts[seg]
+    del slot, seg
+    assert torch.equal(one[1][real], two[1]) and torch.equal(one[4][real], two[4])
+    del one, real
+    old = eps.ops.expand_candidates(g.rowptr, g.col, None, wt, n, lo, hi, want_cn=False, want_v=False, col_order=order,
+                                    max_paths=candidates.max_paths_of(g))
+    assert torch.equal(old[0], two[0]) and torch.equal(old[1], two[1]) and torch.equal(old[4], two[4])
+    del old, two
+    # (3) the oracle's own candidate set and scores for the sampled columns
+    A = g.to_scipy()
+    rp, col = A.indptr.astype(np.int64), A.indices.astype(np.int32)
+    w = orc.node_weights(orc.col_sums(rp, col, None, n), orc.W_AA)
+    for c in cols:
+        cand, _ = orc.candidates_scipy_columns(A, c, c + 1)
+        _, _, sc = orc.pair_scores(rp, col, None, w, cand[:, 0], cand[:, 1])
+        u, s_ = kept[c]
+        assert np.array_equal(u, cand[:, 0].astype(np.int32)), f"column {c}: candidates differ from the oracle's"
+        assert rel_err(s_, sc) <= 1e-5, f"column {c}"
+
+
 def test_expand_falls_back_when_buckets_would_not_fit(eps, dev, monkeypatch):
     """A graph whose heaviest column needs more bucket scratch than the budget is not offered to the fused kernels:
     the same block then comes from the tensor-op expansion + the column-run intersection kernel, with equal results."""
