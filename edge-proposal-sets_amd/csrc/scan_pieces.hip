@@ -56,6 +56,7 @@
 #define SP_BATCH 8              // columns per ticket in the light tail of the column order
 #endif
 #ifndef SP_G
+#define SP_EM 128               // slots of the per-workgroup set of ids a SKETCH piece has reported (a power of two)
 #define SP_G 1                  // units (of 4 entries) a lane looks up, loads and inserts together
 #endif
 
@@ -90,12 +91,14 @@ struct sp_params {
     unsigned int *next_col;
     eps_survivors *out;
     unsigned int *status;       // bit 1: a hash table filled up (cannot happen within the piece limits; backstop); bit 2: a column's
-                                //        skipped head weighs as much as the bar (the head table was built for a higher bar: nothing valid)
+                                //        skipped head weighs as much as the bar (the head table was built for a higher bar: nothing valid);
+                                //        bit 3: a sketch piece's set of reported ids filled up (the launch is void); bit 4: sketch pieces ran
     const uint4 *colrec;        // [n_columns][2] or NULL: what a column's set-up reads of five tables, in hand-out order (one 32-byte load
                                 //        at the ticket's index instead of a chain id -> row start / head / row sum / plan pointer):
                                 //        {v, rowptr[v], degree, head rows | head weight, row sum, first plan record, pieces}
     const uint32_t *rowrec;     // [n_nodes][32] or NULL: per node ONE 128-byte line with everything the walk wants of a row -- words
                                 //        0..15 its 32 cuts, word 16 its first entry (rowptr), word 17 its screening weight (eps_scan_row_records)
+    uint32_t sketch;            // r06: PACKED pieces of single-round columns under a bar keep no keys (see SP_EM): 0 = off
     uint32_t batch_from;        // tickets below stand for one column, tickets from here on for SP_BATCH consecutive ones (>= n_columns: none)
     const uint4 *pack;          // [nnz][2] or NULL (r06; with plan + row records): per stored entry (v, j), in CSR order, everything a
                                 //        single-round column's set-up gathers for it: {w, rowptr[w], fx32[w], revpos | cut of v's FIRST piece in
@@ -130,6 +133,7 @@ typedef short sp_v2s __attribute__((ext_vector_type(2)));
 // middle, the pass of a partitioned window from the bottom.  (A full-rate 24 x 24-bit multiply was measured instead of the
 // quarter-rate 32-bit one: its weaker mixing lengthens the probe sequences -- 38.0 vs 30.7 ms per launch.)
 __device__ __forceinline__ uint32_t sp_mix(uint32_t x) { return x * 0x9E3779B1u; }
+__device__ __forceinline__ uint32_t sp_mix2(uint32_t x) { return x * 0x85EBCA6Bu; }      // (the sketch pieces' second table)
 
 struct sp_unit {
     sp_v4i u4;
@@ -260,6 +264,7 @@ __global__ __launch_bounds__(T, 4) void scan_piece_kernel(sp_params p)      // (
     __shared__ unsigned int s_ticket;
     __shared__ unsigned int s_out_cur, s_out_end;
     __shared__ unsigned int s_fill_lo, s_fill_hi;       // what is left of an abandoned reservation: filled with "no survivor"
+    __shared__ uint32_t s_em[SP_EM];         // sketch pieces: id + 1 of every candidate reported so far (a path per report: the set dedupes)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wib = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -284,6 +289,7 @@ __global__ __launch_bounds__(T, 4) void scan_piece_kernel(sp_params p)      // (
 
     for (int i = tid; i < 2 * slots; i += T) lds[i] = 0u;
     for (int i = tid; i < SP_UBITS / 32; i += T) ubits[i] = 0u;
+    for (int i = tid; i < SP_EM; i += T) s_em[i] = 0u;
     if (tid == 0) {
         s_out_cur = 0u;
         s_out_end = 0u;
@@ -291,6 +297,7 @@ __global__ __launch_bounds__(T, 4) void scan_piece_kernel(sp_params p)      // (
         s_fill_hi = 0u;
         s_alloc = 0ull;
     }
+    bool sketch_seen = false;
     unsigned long long n_cand = 0;           // candidates seen by this thread
     uint32_t new_keys = 0u;                  // ... of the current hash piece: candidate keys this thread inserted
     const unsigned int ncol = (unsigned int)p.n_columns;
@@ -424,7 +431,18 @@ __global__ __launch_bounds__(T, 4) void scan_piece_kernel(sp_params p)      // (
                 const uint32_t info = s_pinfo[pi];
                 const bool direct = (info >> 31) != 0u;                                   // direct, either kind
                 const bool d16 = !HV && (info >> 30) == 3u;
-                const bool packed = !HV && (info >> 30) == 1u;
+                // r06 -- SKETCH: a packed piece of a single-round column under a bar keeps NO keys.  What a packed piece pays is not the
+                // walk but the returning CAS per path and what hangs on its result (1.9 of the launch's 9.0 ms: a non-returning add
+                // in its place, wrong results, 7.1 ms -- profiles/r06/scan_structures.txt).  A screening sum only has to be an UPPER
+                // bound: every path adds its weight to one slot of each of two half tables under two independent hashes, a
+                // candidate's sum is at most the smaller of its two slots (a count-min sketch; slots are shared, so the estimate only
+                // ever errs upwards: no candidate is lost, and next to a bar of twenty path weights a tail candidate of one or two
+                // paths does not get there on collisions), and a second look at the piece's paths -- two reads and a compare each --
+                // reports the ids whose estimate reaches the bar, once each (s_em), unless they are neighbours of v.  Exact
+                // re-scoring follows as for every survivor.  Such a piece does not count its candidates.
+                const bool packed_kind = !HV && (info >> 30) == 1u;
+                const bool sketch = packed_kind && single && p.sketch != 0u && thr_v < SP_FLAG;      // (uniform)
+                const bool packed = packed_kind && !sketch;
                 const bool quant = packed || d16;                                        // weights drop pk_d low bits
                 const uint32_t ppaths = info & 0x3FFFFFFFu;
                 const uint32_t pq = quant ? s_pq[pi] : 0u;
@@ -436,7 +454,7 @@ __global__ __launch_bounds__(T, 4) void scan_piece_kernel(sp_params p)      // (
                 const uint32_t pkeys = ppaths + (uint32_t)(nb - na);           // slots the piece can need: paths + known edges
                 // (closed forms, no loops: hipcc unrolls and vectorises even a three-trip scalar loop into a hundred instructions)
                 int plog = 0;                                            // parts = 2^plog
-                if (!direct && !packed && pkeys > p.piece_paths) {
+                if (!direct && !packed && !sketch && pkeys > p.piece_paths) {
                     const uint32_t q = (pkeys + p.piece_paths - 1u) / p.piece_paths;      // >= 2 (piece_paths is a power of two: a shift)
                     plog = 32 - __clz((int)(q - 1u)) + 1;                // next power of two, doubled (random split: aim at a quarter load)
                 }
@@ -444,7 +462,7 @@ __global__ __launch_bounds__(T, 4) void scan_piece_kernel(sp_params p)      // (
                 int bits;
                 {
                     const uint32_t per = (pkeys + parts - 1u) >> plog;
-                    const int max_bits = packed ? p.table_bits + 1 : p.table_bits;
+                    const int max_bits = packed || sketch ? p.table_bits + 1 : p.table_bits;
                     const int want = per > 1u ? 33 - __clz((int)(per - 1u)) : 1;          // smallest b with 2^b >= 2 * per
                     bits = want < 10 ? 10 : (want > max_bits ? max_bits : want);
                 }
@@ -478,13 +496,26 @@ __global__ __launch_bounds__(T, 4) void scan_piece_kernel(sp_params p)      // (
                         cut_ahead = PACK && pi + 1 <= 8 ? pack16[((size_t)vb + (size_t)tid) * 16 + 7 + (pi + 1)]
                                                         : cut_tab[(size_t)my_w * cut_ld + s_pk1[pi + 1] - 1];
                 }
+                // (a survivor's slot: out of the workgroup's reservation, or one of its own)
+                auto emit = [&](uint32_t u, uint32_t sum) {
+                    uint32_t pos = atomicAdd(&s_out_cur, 1u);
+                    if (pos >= s_out_end) {                          // past the reservation: a slot of its own
+                        const unsigned long long q = atomicAdd(&p.out->count, 1ull);
+                        pos = q < (unsigned long long)out_cap ? (uint32_t)q : out_cap;
+                    }
+                    if (pos < out_cap) {
+                        out_key[pos] = ((int64_t)v << 32) | (int64_t)u;
+                        // (a launch with skipped heads reports the WALKED sum as it is: eps_scan_refine completes it)
+                        out_val[pos] = raw_sums ? __builtin_bit_cast(float, sum) : (float)sum * p.scale;
+                    }
+                };
                 for (uint32_t part = 0; part < parts; ++part) {
                     // ---- known edges in: the neighbours of v inside the piece take their slots BEFORE the walk, with the flag bit
                     // in the value word -- whatever the paths add on top, the sweep sees that this id is no candidate (rows ascend:
                     // the neighbours inside the piece's windows are vcol[na, nb)).  The first barrier of the describe orders this
                     // against the walk.
                     // (a column of one round holds its rows in registers: lane j's row IS neighbour j)
-                    for (int j = single ? tid : na + tid; j < nb; j += T) {
+                    for (int j = sketch ? nb : single ? tid : na + tid; j < nb; j += T) {      // (a sketch piece looks them up when it reports)
                         const uint32_t u = single ? my_w : (uint32_t)vcol[j];
                         if (j >= na && (int32_t)u >= lo_id && (int32_t)u < hi_id) {
                             if (d16) {
@@ -631,7 +662,18 @@ __global__ __launch_bounds__(T, 4) void scan_piece_kernel(sp_params p)      // (
                             return (uint32_t)__builtin_ceilf(f.a4[e] * __builtin_bit_cast(float, f.fx)) + 1u;
                         };
                         auto consume_group = [&](const sp_unit (&f)[SP_G]) {
-                            if (d16) {
+                            if (sketch) {
+                                const uint32_t half = 1u << (bits - 1);
+#pragma unroll
+                                for (int q = 0; q < SP_G; ++q)
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e)
+                                        if (e < f[q].nvalid) {
+                                            const uint32_t id = (uint32_t)f[q].u4[e];
+                                            atomicAdd(&lds[sp_mix(id) >> (33 - bits)], f[q].fx);
+                                            atomicAdd(&lds[half + (sp_mix2(id) >> (33 - bits))], f[q].fx);
+                                        }
+                            } else if (d16) {
 #pragma unroll
                                 for (int q = 0; q < SP_G; ++q)
 #pragma unroll
@@ -808,6 +850,58 @@ __global__ __launch_bounds__(T, 4) void scan_piece_kernel(sp_params p)      // (
                                 }
                             }
                         }
+                        if (sketch) {
+                            // the second look (one range: a piece of <= packed_paths paths has fewer than SP_UBITS units)
+                            if (tid == 0 && !sketch_seen) atomicOr(p.status, 16u);      // (informational: sketch pieces ran in this launch)
+                            sketch_seen = true;
+                            sp_barrier();
+                            const uint32_t half = 1u << (bits - 1);
+                            const int n_iter = (int)(uhi - ulo + T - 1) / T;
+                            auto report = [&](uint32_t u, uint32_t est) {
+                                int a = na, b = nb;                       // a neighbour of v is no candidate (rows ascend: vcol[na, nb))
+                                while (a < b) {
+                                    const int mid = (a + b) >> 1;
+                                    if (vcol[mid] < (int32_t)u) a = mid + 1; else b = mid;
+                                }
+                                if (a < nb && vcol[a] == (int32_t)u) return;
+                                const uint32_t em_mask = (p.sketch >> 1 ? p.sketch >> 1 : (uint32_t)SP_EM) - 1u;      // (a smaller set: tests)
+                                uint32_t h = (sp_mix(u) >> 9) & em_mask;
+                                for (uint32_t tries = 0; tries <= em_mask; ++tries) {
+                                    const uint32_t old = atomicCAS(&s_em[h], 0u, u + 1u);
+                                    if (old == 0u) {                      // the first path of u that gets here reports it
+                                        emit(u, est);
+                                        return;
+                                    }
+                                    if (old == u + 1u) return;
+                                    h = (h + 1u) & em_mask;
+                                }
+                                atomicOr(p.status, 8u);                   // the set is full: the launch is void (the host repeats it without sketch pieces)
+                            };
+                            auto look = [&](const sp_unit (&f)[SP_G]) {
+                                uint32_t est[4 * SP_G];
+#pragma unroll
+                                for (int i = 0; i < 4 * SP_G; ++i) {
+                                    const uint32_t id = (uint32_t)f[i >> 2].u4[i & 3];
+                                    const uint32_t ea = lds[sp_mix(id) >> (33 - bits)], eb = lds[half + (sp_mix2(id) >> (33 - bits))];
+                                    est[i] = ea < eb ? ea : eb;
+                                }
+#pragma unroll
+                                for (int i = 0; i < 4 * SP_G; ++i)
+                                    if ((i & 3) < f[i >> 2].nvalid && est[i] >= thr_v) report((uint32_t)f[i >> 2].u4[i & 3], est[i]);
+                            };
+                            sp_unit fa[SP_G], fb[SP_G];
+                            fetch_group(0, fa);
+                            if (n_iter <= SP_G) {
+                                look(fa);
+                            } else {
+                                for (int it0 = 0; it0 < n_iter; it0 += 2 * SP_G) {
+                                    fetch_group(it0 + SP_G, fb);
+                                    look(fa);
+                                    fetch_group(it0 + 2 * SP_G, fa);
+                                    look(fb);
+                                }
+                            }
+                        }
                             if (uhi < (uint32_t)total) sp_barrier();       // (the next range rewrites the start bits)
                         }
                         sp_barrier();        // the next round / the scan follows: descriptors and table updates are complete
@@ -821,18 +915,6 @@ __global__ __launch_bounds__(T, 4) void scan_piece_kernel(sp_params p)      // (
                         if (r + 1 < rounds) sp_barrier();
                     }
                     // ---- scan the table: count the candidates, report the survivors, leave it clean --------------------------
-                    auto emit = [&](uint32_t u, uint32_t sum) {
-                        uint32_t pos = atomicAdd(&s_out_cur, 1u);
-                        if (pos >= s_out_end) {                          // past the reservation: a slot of its own
-                            const unsigned long long q = atomicAdd(&p.out->count, 1ull);
-                            pos = q < (unsigned long long)out_cap ? (uint32_t)q : out_cap;
-                        }
-                        if (pos < out_cap) {
-                            out_key[pos] = ((int64_t)v << 32) | (int64_t)u;
-                            // (a launch with skipped heads reports the WALKED sum as it is: eps_scan_refine completes it)
-                            out_val[pos] = raw_sums ? __builtin_bit_cast(float, sum) : (float)sum * p.scale;
-                        }
-                    };
                     // (the sweeps read in batches of SP_SB uint4 per thread before they look at any of them: one LDS round trip per
                     //  batch instead of one per 16 bytes; the trip counts are uniform over the workgroup)
                     // A word is tested as a SIGNED number: a known edge's flag is its sign bit, so `(int)word >= bar` is false for it
@@ -900,6 +982,10 @@ __global__ __launch_bounds__(T, 4) void scan_piece_kernel(sp_params p)      // (
                                 }
                             }
                         }
+                    } else if (sketch) {
+                        // (nothing to read: the second look reported what there was; both half tables and the set go back to zero)
+                        for (uint32_t i = 4u * (uint32_t)tid; i < scan_slots; i += 4u * T) *(uint4 *)(lds + i) = make_uint4(0u, 0u, 0u, 0u);
+                        for (int i = tid; i < SP_EM; i += T) s_em[i] = 0u;
                     } else if (packed) {
                         // (shifted left by the key bits a word is flag | sum at the top: signed again)
                         const uint32_t kb = 32u - pk_sb;
@@ -1707,6 +1793,8 @@ static const int sp_threads_of[3] = {512, 1024, 256}, sp_bits_of[3] = {13, 14, 1
 // allocation on a graph with hubs: weights of 1 / 13 230 -- r05: 13.5 ms of re-scoring at d = 13, a third of it at d = 11).
 #define SP_VARIANT_GEOM(v) ((v) & 0xFF)
 #define SP_VARIANT_DMAX(v) ((((v) >> 8) & 0xFF) - 1)
+// ... and in bit 16 (eps_scan_screen only; r06): packed pieces of single-round columns run as SKETCH pieces (see the kernel)
+#define SP_VARIANT_SKETCH(v) (((v) >> 16) & 0xFF)      // bit 0: on; bits 1..7: slots of the reported-id set (a power of two <= SP_EM; 0 = SP_EM)
 
 // what the planner reads of the geometry: the scan launch and the plan-table launch must agree on it
 static void sp_plan_geometry(sp_params &p, const uint16_t *cuts, const uint32_t *wpaths, const uint32_t *ssum, const uint32_t *smax,
@@ -1856,6 +1944,7 @@ static int sp_launch(const int64_t *rowptr, const int32_t *col, const float *val
     EPS_REQUIRE(rowptr && col && revpos && cuts && wpaths && bounds && columns && out, "eps_scan_screen: null pointer");
     EPS_REQUIRE(nnz < (1ll << 30), "eps_scan_screen: col[] is addressed with 32-bit byte offsets (nnz < 2^30)");
     EPS_REQUIRE(n_nodes < (1ll << 31) && n_columns < (1ll << 31), "eps_scan_screen: too many nodes / columns");
+    const uint32_t sketch_arg = (uint32_t)SP_VARIANT_SKETCH(variant);
     const int32_t dmax_arg = SP_VARIANT_DMAX(variant);
     variant = SP_VARIANT_GEOM(variant);
     EPS_REQUIRE(shift >= 0 && shift <= 40 && variant >= 0 && variant <= 2, "eps_scan_screen: bad shift / variant");
@@ -1886,6 +1975,7 @@ static int sp_launch(const int64_t *rowptr, const int32_t *col, const float *val
     p.columns = columns;
     p.n_columns = (int32_t)n_columns;
     p.batch_from = batch_from < 0 || batch_from > n_columns ? (uint32_t)n_columns : (uint32_t)batch_from;
+    p.sketch = val || !(sketch_arg & 1u) ? 0u : sketch_arg;
     p.col_bytes = (uint32_t)(nnz * 4);
     p.scale = ldexpf(1.0f, -shift);
     p.next_col = counter;

@@ -852,6 +852,9 @@ def scan_row_sums(rowptr, col, fx32: torch.Tensor, bounds: torch.Tensor, n_nodes
     return ssum, smax, min_fx
 
 
+SCAN_SKETCH = 1 << 16      # eps_scan_screen's `variant` word, bit 16: packed pieces of single-round columns run as sketch pieces (r06)
+
+
 def scan_variant_word(variant: int, dmax: Optional[int] = None) -> int:
     """The ``variant`` argument of eps_scan_plan / eps_scan_screen: geometry in the low byte, (dmax + 1) << 8 above it when the
     caller limits the low weight bits a packed / 16-bit direct piece may drop (include/eps_abi.h)."""

@@ -59,6 +59,9 @@ def _sharded(world: int) -> bool:
     return world > 1 or FORCE_SHARDED
 
 
+SKETCH_PIECES = True          # r06: in the main launch (heads, under a bar) the packed pieces of single-round columns keep no keys -- a
+                              # count-min sketch of two half tables, non-returning adds, a second look at the paths (csrc/scan_pieces.hip)
+SKETCH_SET = 0                # slots of a sketch piece's set of reported ids (a power of two <= 64; 0 = the kernel's 128): tests shrink it
 LAZY_PLAN = True              # the whole-graph plan table (no skipped heads) is built when a launch first wants it; the bar sample plans itself
 ROW_RECORDS = True            # the launch gathers a row's cuts, first entry and weight out of ONE 128-byte line (ops.scan_row_records)
 BATCH_MIN_COLUMNS = 1 << 16   # lists shorter than this are handed out one column at a time throughout
@@ -586,7 +589,7 @@ def one_pass_available(g: CSRGraph) -> bool:
 
 
 def _launch(g, fixw, columns, threshold, capacity, scores_only: bool = False, both: bool = False, screen=None,
-            heads: Optional[HeadTables] = None, walked_capacity: int = 0, sample_key=None) -> ops.Survivors:
+            heads: Optional[HeadTables] = None, walked_capacity: int = 0, sample_key=None, sketch: bool = False) -> ops.Survivors:
     """``screen`` (a Screen) -> the one-pass kernel (screening scores in ``val``), else eps_filter_scan (exact scores).
     ``heads``: the launch skips the columns' heads (its list -- ``walked_capacity`` slots -- holds walked sums) and
     eps_scan_refine completes them into the list that is returned: the same survivors and scores as without heads, compact;
@@ -601,7 +604,8 @@ def _launch(g, fixw, columns, threshold, capacity, scores_only: bool = False, bo
             bounds, cuts = screen_tables(g)
             walked = ops.Survivors(walked_capacity, threshold, g.device, prefill=False)
             ops.scan_screen(g.rowptr, g.col, reverse_positions(g), screen.fx32, cuts, bounds, g.n_rows, columns, screen.shift, walked,
-                            out.status, screen_variant(g), None, None, heads.wpaths, screen.ssum, screen.smax, heads.plan, heads.heads,
+                            out.status, screen_variant(g) | ((ops.SCAN_SKETCH | SKETCH_SET << 17) if sketch else 0), None, None, heads.wpaths, screen.ssum, screen.smax,
+                            heads.plan, heads.heads,
                             batch_from(g, columns), screen.rowrec,
                             column_records(g, screen, columns, heads.plan, heads.heads, heads.live, ("colrec", columns.data_ptr(), columns.numel())),
                             column_pack(g, screen, heads) if variant_is_main(g, screen) else None)
@@ -1026,6 +1030,7 @@ def scan_topk(g: CSRGraph, node_w: torch.Tensor, k: int, rank: int = 0, world: i
                  and total_half >= HEAD_MIN_PATHS)
     _count_scan(g, screen)
     head_list, head_trouble, head_stale = HEAD_LIST, 0, 0
+    sketch, sketch_void, sketch_ran = SKETCH_PIECES, 0, False
     n_rescored = None
     ht = None
     while True:
@@ -1034,7 +1039,7 @@ def scan_topk(g: CSRGraph, node_w: torch.Tensor, k: int, rank: int = 0, world: i
         ht = _heads_for(g, screen, bar) if use_heads and bar is not None else None
         walked_cap = max(1, min(int(head_list * capacity), ops.SURVIVOR_SLOTS_MAX)) if ht is not None else 0
         res = _launch(g, fixw, mine if ht is None else live_columns(g, screen, ht, rank, world), float("-inf") if bar is None else bar,
-                      capacity, both=True, screen=screen, heads=ht, walked_capacity=walked_cap)
+                      capacity, both=True, screen=screen, heads=ht, walked_capacity=walked_cap, sketch=sketch and ht is not None)
         launches += 1
         l_keys, l_vals = res.key, res.val
         status, pre_thr = None, None
@@ -1214,7 +1219,17 @@ def scan_topk(g: CSRGraph, node_w: torch.Tensor, k: int, rank: int = 0, world: i
             else:
                 table = [st.tolist()]
         slots_r, ncand_r, nsel_r = [t[0] for t in table], [t[1] for t in table], [t[2] for t in table]
-        if any(t[4] & ~4 for t in table):
+        if any(t[4] & 8 for t in table):
+            # (status bit 3: a sketch piece had more ids to report than its set holds -- a bar far below what K asks for: the launch is
+            #  void, the call goes on with hashed packed pieces)
+            sketch = False
+            sketch_void += 1
+            launches -= 1                                    # (the repeat is the same launch again, not a corrected bar)
+            if launches + 2 > MAX_LAUNCHES:
+                raise ops._lib.EpsError("scan_topk: launches with sketch pieces kept failing")
+            continue
+        sketch_ran = any(t[4] & 16 for t in table)            # (status bit 4, informational: sketch pieces ran in this launch)
+        if any(t[4] & ~(4 | 16) for t in table):
             raise ops._lib.EpsError("scan_topk: eps_scan_screen reported a full hash table (status %s)" % [t[4] for t in table])
         if ht is not None:
             # The head table was taken without looking at the bar.  A head as heavy as the bar (status bit 2: the bar fell since the
@@ -1330,6 +1345,7 @@ def scan_topk(g: CSRGraph, node_w: torch.Tensor, k: int, rank: int = 0, world: i
         else:
             n_all = 2 * candidate_count(g, screen, fixw, rank, world) if stats.get("count", True) else None
         stats.update(candidates=n_all, touched=touched, launches=launches, survivors=2 * n_sel_all, heads=ht is not None, shard=shard_info,
+                     sketch=sketch_ran, sketch_void=sketch_void,
                      head_budget=None if ht is None else ht.budget * 2.0 ** -screen.shift,
                      walked_slots=sum(t[6] for t in table) if ht is not None else None, rescored=n_rescored,
                      survivor_slots=sum(min(s_, capacity) for s_ in slots_r), bar=bar)

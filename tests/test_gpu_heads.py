@@ -148,6 +148,86 @@ def test_scan_topk_same_rows_with_and_without_heads(eps, dev, monkeypatch, kind)
         assert torch.equal(p0, p2) and st2["candidates"] is None and 0 < st2["touched"] <= st1["candidates"]
 
 
+@pytest.mark.parametrize("kind", ["aa", "cn"])
+def test_sketch_pieces_at_the_kernel(eps, dev, kind):
+    """One launch with heads, packed pieces hashed vs as sketch pieces (eps_scan_screen's variant bit 16), on a graph whose id space
+    is wider than a direct piece: every id is reported once, every reported sum is an upper bound of the exact score (``_exact``
+    checks both), and after exact re-scoring the two lists are identical -- at a high and at a low bar.  With a set of ONE reported
+    id per piece (bits 17..23) the low bar voids the launch: status bit 3."""
+    from eps_amd import scan, synth
+    g0 = synth.rmat_graph(17, 10, 3, dev)
+    g, perm = _hubs_first(g0)
+    w = _weights(eps, g0, kind)
+    sc = scan.screen_weights(g0, g, perm, w)
+    assert sc.usable and sc.plan is not None
+    order = scan.column_order(g)
+    bounds, cuts = scan.screen_tables(g)
+    variant = scan.screen_variant(g)
+    hub = eps.ops.scan_hub_rows(g.rowptr, g.col, min(4096, g.n_rows))
+    voids = ran = 0
+    for k in (100_000, 6_000_000, 0):
+        # (k = 0: a bar far below what any K of interest asks for -- pieces of the tail report several ids each)
+        bar = float(scan.scan_topk(g0, w, k)[1][-1]) * 0.97 if k else {"aa": 1.6, "cn": 6.0}[kind]
+        units = bar * 2.0 ** sc.shift
+        heads = eps.ops.scan_heads(g.rowptr, g.col, sc.fx32, hub.shape[0], int(0.5 * units))
+        wp = eps.ops.scan_window_paths(g.rowptr, g.col, scan.reverse_positions(g), cuts, heads)
+        plan = eps.ops.scan_plan(g.rowptr, cuts, wp, sc.ssum, sc.smax, bounds, g.n_rows, sc.shift, variant, heads=heads)
+        assert int(((plan[1][:, 0].view(torch.int32).to(torch.int64) & 0xFFFFFFFF) >> 30 == 1).sum()) > 100, "no packed pieces in this plan"
+        lists = []
+        for word in (variant, variant | eps.ops.SCAN_SKETCH, variant | eps.ops.SCAN_SKETCH | 1 << 17):
+            walked = eps.ops.Survivors(1 << 26, bar, dev, prefill=False)
+            status = torch.zeros(1, dtype=torch.int32, device=dev)
+            eps.ops.scan_screen(g.rowptr, g.col, scan.reverse_positions(g), sc.fx32, cuts, bounds, g.n_rows, order, sc.shift, walked, status,
+                                word, wpaths=wp, ssum=sc.ssum, smax=sc.smax, plan=plan, heads=heads)
+            st = int(status)
+            if word & eps.ops.SCAN_SKETCH and st & 8:        # (a piece had more ids to report than its set holds: the launch is void)
+                voids += 1
+                continue
+            # (bit 4 = sketch pieces ran: never without the request; with it, whenever a live column has a packed piece -- under a
+            #  high bar the columns of the id space's tail are dead)
+            assert st & ~16 == 0 and (word & eps.ops.SCAN_SKETCH or not st & 16), (hex(word), st)
+            ran += (st >> 4) & 1
+            res = eps.ops.Survivors(walked.capacity, bar, dev, prefill=False)
+            eps.ops.scan_refine(walked, heads, hub, sc.fx32, g.rowptr, g.col, g.n_rows, sc.shift, res)
+            lists.append(_exact(g, sc, res, bar))
+        assert lists[0][0].numel() > 1000
+        for got in lists[1:]:
+            assert torch.equal(got[0], lists[0][0]) and torch.equal(got[1], lists[0][1]), (kind, k)
+    assert ran >= 1, "no launch ran sketch pieces"
+    assert voids >= 1, "a set of one id never filled up"
+
+
+@pytest.mark.parametrize("kind", ["aa", "ra", "cn"])
+def test_sketch_pieces_give_the_same_rows_and_fall_back(eps, dev, monkeypatch, kind):
+    """r06: in a launch with heads the packed pieces of single-round columns keep no keys (a count-min sketch: upper bounds only).
+    scan_topk with and without them returns bit-identical rows (the kernel's status word says that sketch pieces did run); with a
+    set of ONE reported id per piece the second survivor of a piece voids the launch (status bit 3) and the call finishes on
+    hashed pieces -- same rows again."""
+    from eps_amd import scan, synth
+    g = synth.rmat_graph(17, 10, 3, dev)                         # (131 K ids: the tail of the id space is wider than a direct piece)
+    w = _weights(eps, g, kind)
+    monkeypatch.setattr(scan, "SMALL_SET", 0)
+    monkeypatch.setattr(scan, "HEAD_MIN_PATHS", 0)
+    monkeypatch.setattr(scan, "RELABEL_MIN_NODES", 0)
+    ran = voids = 0
+    for k in (2000, 150_000, 3_000_000, -150_000, -3_000_000):
+        monkeypatch.setattr(scan, "SKETCH_SET", 1 if k < 0 else 0)
+        k = abs(k)
+        monkeypatch.setattr(scan, "SKETCH_PIECES", False)
+        st0 = {}
+        p0, s0 = scan.scan_topk(g, w, k, stats=st0, relabel=True)
+        monkeypatch.setattr(scan, "SKETCH_PIECES", True)
+        st1 = {}
+        p1, s1 = scan.scan_topk(g, w, k, stats=st1, relabel=True)
+        assert torch.equal(p0, p1) and torch.equal(s0, s1), (kind, k)
+        assert not st0["sketch"] and st0["sketch_void"] == 0 and st1["heads"] == st0["heads"]
+        ran += int(st1["sketch"])
+        voids += st1["sketch_void"]
+        assert not (st1["sketch"] and st1["sketch_void"]), st1
+    assert ran >= 1 or kind == "cn", "no launch ran sketch pieces"      # (common-neighbour counts: under these bars the tail's columns are dead)
+    # (whether the one-slot set fills up depends on where the survivors sit: test_sketch_pieces_at_the_kernel forces it)
+
+
 def test_scan_topk_voids_a_launch_with_unusable_heads(eps, dev, monkeypatch):
     """(i) the cached head table was built for a much higher bar (a small k first, then a large one): the kernel refuses it,
     scan_topk builds one for the bar at hand and repeats; (ii) the walked list overflows: the list grows, and after the second

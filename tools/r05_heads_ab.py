@@ -89,7 +89,8 @@ for beta in [float(x) for x in (sys.argv[1:] or ["0", "0.25", "0.5", "0.625"])]:
         cols = scan.live_columns(g, sc, ht, 0, 1) if os.environ.get('LIVE', '0') == '1' else order
         def run():
             wk = ops.Survivors(256 << 20, bar, dev, prefill=False)
-            ops.scan_screen(g.rowptr, g.col, scan.reverse_positions(g), sc.fx32, cuts, bounds, g.n_rows, cols, sc.shift, wk, status, variant,
+            ops.scan_screen(g.rowptr, g.col, scan.reverse_positions(g), sc.fx32, cuts, bounds, g.n_rows, cols, sc.shift, wk, status,
+                            variant | (ops.SCAN_SKETCH if os.environ.get('SKETCH', '0') == '1' else 0),
                             wpaths=ht.wpaths, ssum=sc.ssum, smax=sc.smax, plan=ht.plan, heads=ht.heads,
                             colrec=None if os.environ.get('COLREC', '1') == '0' else scan.column_records(g, sc, cols, ht.plan, ht.heads, ht.live, ("ab", cols.numel())),
                             batch_from=int(os.environ['BATCH_FROM']) if 'BATCH_FROM' in os.environ else scan.batch_from(g, cols),
@@ -108,7 +109,7 @@ for beta in [float(x) for x in (sys.argv[1:] or ["0", "0.25", "0.5", "0.625"])]:
                "walked_share": round(walked_paths / scan.total_half_paths(g), 4), "pieces": int(ht.plan[1].shape[0]), "d_used": ht.d_used,
                "rows_skipped_mean": round(float(hx.float().mean()), 2), "rows_skipped_max": int(hx.max()), "hub_rows": masks.shape[0],
                "pack": pack is not None, "pack_build_ms": round(t_pack, 3), "live_columns_only": cols is not order,
-               "generic_body": os.environ.get("EPS_SCAN_GENERIC", "0") == "1"}
+               "generic_body": os.environ.get("EPS_SCAN_GENERIC", "0") == "1", "sketch": os.environ.get("SKETCH", "0") == "1"}
     row.update(status=int(status), digest=d[0], screened=d[1], exact=d[2], counted=d[3])
     out.append(row)
     print(json.dumps(row), flush=True)
