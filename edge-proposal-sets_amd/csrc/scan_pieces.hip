@@ -264,6 +264,7 @@ __global__ __launch_bounds__(T, 4) void scan_piece_kernel(sp_params p)      // (
     __shared__ unsigned int s_ticket;
     __shared__ unsigned int s_out_cur, s_out_end;
     __shared__ unsigned int s_fill_lo, s_fill_hi;       // what is left of an abandoned reservation: filled with "no survivor"
+    __shared__ unsigned int s_hot;           // sketch pieces: some slot of the first half table reaches the bar (else nothing is looked at again)
     __shared__ uint32_t s_em[SP_EM];         // sketch pieces: id + 1 of every candidate reported so far (a path per report: the set dedupes)
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -471,6 +472,7 @@ __global__ __launch_bounds__(T, 4) void scan_piece_kernel(sp_params p)      // (
                 const uint32_t scan_slots = d16 ? (span + 1u) >> 1 : direct ? span : (1u << bits);      // table words to sweep
                 const uint32_t cand_max = direct ? span : (1u << bits);
                 if (tid == 0) {
+                    s_hot = 0u;
                     uint32_t need = ppaths < cand_max ? ppaths : cand_max;        // survivors <= distinct endpoints <= paths, slots
                     if (!no_bar && need > 1024u) need = 1024u;
                     if (need > chunk) need = chunk;                               // (a 16-bit direct piece without a bar: the rest takes single slots)
@@ -856,6 +858,20 @@ __global__ __launch_bounds__(T, 4) void scan_piece_kernel(sp_params p)      // (
                             sketch_seen = true;
                             sp_barrier();
                             const uint32_t half = 1u << (bits - 1);
+                            // An id's estimate is at most its slot in the FIRST half table: when no slot there reaches the bar -- the
+                            // usual case in the tail: survivors are a handful per thousand pieces -- nothing needs a second look.
+                            {
+                                uint32_t mx = 0u;
+                                for (uint32_t i = 4u * (uint32_t)tid; i < half; i += 4u * T) {
+                                    const uint4 a4 = *(const uint4 *)(lds + i);
+                                    const uint32_t m01 = a4.x > a4.y ? a4.x : a4.y, m23 = a4.z > a4.w ? a4.z : a4.w;
+                                    const uint32_t m = m01 > m23 ? m01 : m23;
+                                    mx = m > mx ? m : mx;
+                                }
+                                if (__ballot(mx >= thr_v) && lane == 0) s_hot = 1u;
+                            }
+                            sp_barrier();
+                            if (s_hot) {
                             const int n_iter = (int)(uhi - ulo + T - 1) / T;
                             auto report = [&](uint32_t u, uint32_t est) {
                                 int a = na, b = nb;                       // a neighbour of v is no candidate (rows ascend: vcol[na, nb))
@@ -900,6 +916,7 @@ __global__ __launch_bounds__(T, 4) void scan_piece_kernel(sp_params p)      // (
                                     fetch_group(it0 + 2 * SP_G, fa);
                                     look(fb);
                                 }
+                            }
                             }
                         }
                             if (uhi < (uint32_t)total) sp_barrier();       // (the next range rewrites the start bits)
