@@ -239,7 +239,9 @@ __device__ __forceinline__ int sp_plan_column(const sp_params &p, int32_t v, int
 // FULL (r06): the main launch of the filter step always comes with the plan table, row and column records, sum bounds and a head
 // table; compiled for exactly that, the body carries none of the fall-back pointers (cuts, fx32, pptr, columns, heads[v], ssum[v])
 // and none of the branches on them -- scalar registers, which the generic body spills by the hundred (111 in r05).
-template <int T, bool HV, bool FULL, bool PACK>
+// SK (r06): the launch may run packed pieces as SKETCH pieces (p.sketch); without it that code is compiled out -- it costs the
+// other pieces registers (VGPR spills 0 -> 4, SGPR 40 -> 75: a hashed-only launch 8.96 -> 9.1 ms).
+template <int T, bool HV, bool FULL, bool PACK, bool SK = false>
 __global__ __launch_bounds__(T, 4) void scan_piece_kernel(sp_params p)      // (4 waves per SIMD: <= 128 VGPRs, the LDS share decides the rest)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
@@ -442,7 +444,7 @@ __global__ __launch_bounds__(T, 4) void scan_piece_kernel(sp_params p)      // (
                 // reports the ids whose estimate reaches the bar, once each (s_em), unless they are neighbours of v.  Exact
                 // re-scoring follows as for every survivor.  Such a piece does not count its candidates.
                 const bool packed_kind = !HV && (info >> 30) == 1u;
-                const bool sketch = packed_kind && single && p.sketch != 0u && thr_v < SP_FLAG;      // (uniform)
+                const bool sketch = SK && packed_kind && single && p.sketch != 0u && thr_v < SP_FLAG;      // (uniform)
                 const bool packed = packed_kind && !sketch;
                 const bool quant = packed || d16;                                        // weights drop pk_d low bits
                 const uint32_t ppaths = info & 0x3FFFFFFFu;
@@ -2012,6 +2014,11 @@ static int sp_launch(const int64_t *rowptr, const int32_t *col, const float *val
     const bool full = !generic_only && !val && variant == 2 && plan && colrec && rowrec && heads && ssum;
     EPS_REQUIRE(!pack || full || generic_only, "eps_scan_screen: the column pack serves the main launch only (variant 2, plan, records, heads, sum bounds)");
     if (full) kern = pack ? scan_piece_kernel<256, false, true, true> : scan_piece_kernel<256, false, true, false>;
+    if (p.sketch && variant == 2)      // (the 256-thread geometry only: the one the step's main launch runs in)
+        kern = full ? (pack ? scan_piece_kernel<256, false, true, true, true> : scan_piece_kernel<256, false, true, false, true>)
+                    : scan_piece_kernel<256, false, false, false, true>;
+    else
+        p.sketch = 0u;
     if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
         eps_set_error("eps_scan_screen: cannot reserve %zu bytes of LDS", lds);
         return EPS_ELAUNCH;

@@ -61,6 +61,9 @@ def _sharded(world: int) -> bool:
 
 SKETCH_PIECES = True          # r06: in the main launch (heads, under a bar) the packed pieces of single-round columns keep no keys -- a
                               # count-min sketch of two half tables, non-returning adds, a second look at the paths (csrc/scan_pieces.hip)
+SKETCH_MIN_PATHS = 1.5        # ... when the bar is at least this many of the HEAVIEST node weight: a tail candidate then needs several paths to
+                              # reach it and most sketch pieces end at their read sweep; resource allocation (weights up to 1 under a bar of 0.085
+                              # on the ppa-like graph: one path through a light node passes) looks at nearly every piece again -- 10.3 vs 9.9 ms hashed
 SKETCH_SET = 0                # slots of a sketch piece's set of reported ids (a power of two <= 64; 0 = the kernel's 128): tests shrink it
 LAZY_PLAN = True              # the whole-graph plan table (no skipped heads) is built when a launch first wants it; the bar sample plans itself
 ROW_RECORDS = True            # the launch gathers a row's cuts, first entry and weight out of ONE 128-byte line (ops.scan_row_records)
@@ -269,7 +272,7 @@ def screen_shift(bound: float, max_deg: int, weighted: bool = False) -> int:
 class Screen:
     """What a launch of the piece kernel and the exact re-scoring of its survivors need, for one (graph, weight table)."""
     __slots__ = ("fx32", "shift", "fixw", "val", "node_w", "usable", "ssum", "smax", "_plan", "_plan_build", "d_used", "w_min", "heads", "head_cur",
-                 "rowrec", "vword", "exact", "bar_hint")
+                 "rowrec", "vword", "exact", "bar_hint", "w_max_units")
 
     def __init__(self, fx32, shift, fixw, val, node_w, usable, ssum=None, smax=None, plan=None, d_used=0, w_min=0.0):
         self.fx32, self.shift, self.fixw, self.val, self.node_w, self.usable = fx32, shift, fixw, val, node_w, usable
@@ -282,6 +285,7 @@ class Screen:
         self.head_cur = None         # the HeadTables the last launch under a bar used
         self.rowrec = None           # ops.scan_row_records: one 128-byte line per node with what the walk gathers per row
         self.vword = None            # the `variant` word the plan was built with (geometry + the limit on dropped weight bits)
+        self.w_max_units = float("inf")   # the heaviest node weight in screening units (unit-valued graphs: set by screen_weights)
         self.bar_hint = {}           # (k, stride, safety) -> the bar (host float) the last scan with these settings ended with
         self.exact = False           # screening sums ARE the exact scores (one weight for every node, a multiple of every unit a piece
                                      # may round to -- common neighbours): the survivors need no re-scoring
@@ -395,6 +399,7 @@ def screen_weights(g0: CSRGraph, g: CSRGraph, perm, node_w: torch.Tensor) -> Scr
         sc._plan_build = plan_build if one_pass and PLAN_TABLE and usable else None
         sc.rowrec = rowrec
         sc.vword = vword
+        sc.w_max_units = float(f_hi) * 2.0 ** (shift - 40)      # the heaviest node weight in screening units (see SKETCH_MIN_PATHS)
         # One weight for all nodes (common neighbours: 1.0), a whole number of screening units that stays whole under every low bit a
         # piece may drop (csrc/scan_pieces.hip: packed_dmax <= min(24, shift - 8)): a path's screening term is then its exact 2^-40
         # term, a pair's screening sum c x fx x 2^-shift converts to the same float32 as eps_rescore_runs' c x fixw x 2^-40
@@ -1039,7 +1044,8 @@ def scan_topk(g: CSRGraph, node_w: torch.Tensor, k: int, rank: int = 0, world: i
         ht = _heads_for(g, screen, bar) if use_heads and bar is not None else None
         walked_cap = max(1, min(int(head_list * capacity), ops.SURVIVOR_SLOTS_MAX)) if ht is not None else 0
         res = _launch(g, fixw, mine if ht is None else live_columns(g, screen, ht, rank, world), float("-inf") if bar is None else bar,
-                      capacity, both=True, screen=screen, heads=ht, walked_capacity=walked_cap, sketch=sketch and ht is not None)
+                      capacity, both=True, screen=screen, heads=ht, walked_capacity=walked_cap,
+                      sketch=sketch and ht is not None and ht.budget >= HEAD_BETA * SKETCH_MIN_PATHS * screen.w_max_units)
         launches += 1
         l_keys, l_vals = res.key, res.val
         status, pre_thr = None, None
