@@ -50,6 +50,7 @@
 #define SP_PACKED_X8 8u         // a packed piece holds at most this many eighths of 2^table_bits paths
 #endif
 #ifndef SP_MODE_RATIO
+#define SP_MODE_RATIO_WIDE 8000u   // ... in a plan for sketch launches (eps_scan_plan, variant bit 24)
 #define SP_MODE_RATIO 2270u     // fixed cost of a piece in hashed-path units (the planner's direct-vs-packed choice); r05: 1000 / 4000 re-measured
 #endif
 #ifndef SP_BATCH
@@ -98,6 +99,8 @@ struct sp_params {
                                 //        {v, rowptr[v], degree, head rows | head weight, row sum, first plan record, pieces}
     const uint32_t *rowrec;     // [n_nodes][32] or NULL: per node ONE 128-byte line with everything the walk wants of a row -- words
                                 //        0..15 its 32 cuts, word 16 its first entry (rowptr), word 17 its screening weight (eps_scan_row_records)
+    uint32_t wide_paths;        // r06, plans for sketch launches: a packed piece of a column of <= wide_rows rows may hold this many paths (it will
+    int32_t wide_rows;          //      run as a sketch piece: no keys, no sum field -- only the unit bitmap's range bounds it); 0 = off
     uint32_t sketch;            // r06: PACKED pieces of single-round columns under a bar keep no keys (see SP_EM): 0 = off
     uint32_t batch_from;        // tickets below stand for one column, tickets from here on for SP_BATCH consecutive ones (>= n_columns: none)
     const uint4 *pack;          // [nnz][2] or NULL (r06; with plan + row records): per stored entry (v, j), in CSR order, everything a
@@ -182,6 +185,12 @@ __device__ __forceinline__ int sp_plan_column(const sp_params &p, int32_t v, int
             const int kb = 32 - __clz((int)((span > 2u ? span : 2u) - 1u));
             const uint32_t cap = kb >= 30 ? 0u : (1u << (31 - kb)) - 1u;
             kp = k0 + __popcll(__ballot(in && (ek - e0) + (uint32_t)(nbk - nb0) <= p.packed_paths && need_s < cap));
+            // (a plan for a sketch launch: such a piece keeps no keys and full 32-bit sums -- neither the id span nor the known
+            //  edges nor the sum bound limit it, only its paths: one range of the unit bitmap)
+            if (p.wide_paths && dv <= p.wide_rows) {
+                const int kw = k0 + __popcll(__ballot(in && (ek - e0) <= p.wide_paths));
+                kp = kw > kp ? kw : kp;
+            }
         }
         int k1;
         uint32_t flag = 0u, pq = 0u;
@@ -209,10 +218,14 @@ __device__ __forceinline__ int sp_plan_column(const sp_params &p, int32_t v, int
             flag = 0x40000000u;
             const uint32_t span = (uint32_t)(__builtin_amdgcn_readlane(hi_k, k1) - lo);
             const int kb = 32 - __clz((int)((span > 2u ? span : 2u) - 1u));
-            const uint32_t cap = (1u << (31 - kb)) - 1u;
-            uint32_t d = 0u;
-            while ((ms >> d) + (uint32_t)dv + 2u >= cap) ++d;         // (<= packed_dmax: the run passed the test with it)
-            pq = d | ((uint32_t)kb << 8);
+            if (p.wide_paths && dv <= p.wide_rows) {
+                pq = (uint32_t)(kb < 31 ? kb : 31) << 8;              // (a sketch piece: nothing dropped, no sum field)
+            } else {
+                const uint32_t cap = (1u << (31 - kb)) - 1u;
+                uint32_t d = 0u;
+                while ((ms >> d) + (uint32_t)dv + 2u >= cap) ++d;     // (<= packed_dmax: the run passed the test with it)
+                pq = d | ((uint32_t)kb << 8);
+            }
         } else if (kh > k0) {
             k1 = kh;
         } else {
@@ -1813,6 +1826,7 @@ static const int sp_threads_of[3] = {512, 1024, 256}, sp_bits_of[3] = {13, 14, 1
 #define SP_VARIANT_GEOM(v) ((v) & 0xFF)
 #define SP_VARIANT_DMAX(v) ((((v) >> 8) & 0xFF) - 1)
 // ... and in bit 16 (eps_scan_screen only; r06): packed pieces of single-round columns run as SKETCH pieces (see the kernel)
+#define SP_VARIANT_WIDE(v) (((v) >> 24) & 1)          // (plans and launches) bit 24: packed pieces of single-round columns hold up to 2^(bits + 1) paths
 #define SP_VARIANT_SKETCH(v) (((v) >> 16) & 0xFF)      // bit 0: on; bits 1..7: slots of the reported-id set (a power of two <= SP_EM; 0 = SP_EM)
 
 // what the planner reads of the geometry: the scan launch and the plan-table launch must agree on it
@@ -1884,12 +1898,21 @@ extern "C" int eps_scan_plan(const int64_t *rowptr, const uint16_t *cuts, const 
     EPS_REQUIRE((pptr_or_null == nullptr) == (plan_or_null == nullptr), "eps_scan_plan: pptr and plan come together");
     EPS_REQUIRE(pptr_or_null || pcount, "eps_scan_plan: nowhere to put the counts");
     const int32_t dmax_arg = SP_VARIANT_DMAX(variant);
+    const bool wide_arg = SP_VARIANT_WIDE(variant) != 0;
     variant = SP_VARIANT_GEOM(variant);
     EPS_REQUIRE(shift >= 0 && shift <= 40 && variant >= 0 && variant <= 2, "eps_scan_plan: bad shift / variant");
     EPS_REQUIRE(((uintptr_t)plan_or_null & 15) == 0, "eps_scan_plan: plan must be 16-byte aligned");
     sp_params p;
     memset(&p, 0, sizeof p);
     sp_plan_geometry(p, cuts, wpaths, ssum_or_null, smax_or_null, bounds, n_nodes, shift, variant, dmax_arg);
+    if (wide_arg && ssum_or_null) {                      // (a plan for a sketch launch: eps_scan_screen with the same bit AND the sketch bit)
+        p.wide_paths = 2u << sp_bits_of[variant];        // (= SP_UBITS at the 256-thread geometry: one range of the unit bitmap)
+        if (p.wide_paths > SP_UBITS) p.wide_paths = SP_UBITS;
+        p.wide_rows = sp_threads_of[variant];
+        // (a sketch path costs about what a direct path costs, so a piece's fixed cost weighs more against the difference: the
+        //  longer packed run wins more often -- 5000 / 10000 / 20000: 6.47 / 6.47 / 6.52 ms against 6.75 at 2270 on the ppa-like graph)
+        p.mode_ratio = SP_MODE_RATIO_WIDE;
+    }
     p.heads = (const uint2 *)heads_or_null;
     hipLaunchKernelGGL(sp_plan_kernel, dim3((unsigned)((n_nodes + 3) / 4)), dim3(256), 0, (hipStream_t)stream, p, rowptr,
                        2u << sp_bits_of[variant], pcount, pptr_or_null, (uint4 *)plan_or_null, d_used_or_null);
@@ -1964,6 +1987,8 @@ static int sp_launch(const int64_t *rowptr, const int32_t *col, const float *val
     EPS_REQUIRE(nnz < (1ll << 30), "eps_scan_screen: col[] is addressed with 32-bit byte offsets (nnz < 2^30)");
     EPS_REQUIRE(n_nodes < (1ll << 31) && n_columns < (1ll << 31), "eps_scan_screen: too many nodes / columns");
     const uint32_t sketch_arg = (uint32_t)SP_VARIANT_SKETCH(variant);
+    EPS_REQUIRE(!SP_VARIANT_WIDE(variant) || ((sketch_arg & 1u) && plan && !val && SP_VARIANT_GEOM(variant) == 2),
+                "eps_scan_screen: a plan with wide packed pieces (variant bit 24) is for sketch launches (bit 16) of the 256-thread geometry");
     const int32_t dmax_arg = SP_VARIANT_DMAX(variant);
     variant = SP_VARIANT_GEOM(variant);
     EPS_REQUIRE(shift >= 0 && shift <= 40 && variant >= 0 && variant <= 2, "eps_scan_screen: bad shift / variant");

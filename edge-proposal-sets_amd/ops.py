@@ -852,6 +852,7 @@ def scan_row_sums(rowptr, col, fx32: torch.Tensor, bounds: torch.Tensor, n_nodes
     return ssum, smax, min_fx
 
 
+SCAN_WIDE = 1 << 24        # eps_scan_plan / eps_scan_screen `variant` word, bit 24: packed pieces of single-round columns hold 2^(bits + 1) paths (sketch launches)
 SCAN_SKETCH = 1 << 16      # eps_scan_screen's `variant` word, bit 16: packed pieces of single-round columns run as sketch pieces (r06)
 
 

@@ -64,6 +64,8 @@ SKETCH_PIECES = True          # r06: in the main launch (heads, under a bar) the
 SKETCH_MIN_PATHS = 1.5        # ... when the bar is at least this many of the HEAVIEST node weight: a tail candidate then needs several paths to
                               # reach it and most sketch pieces end at their read sweep; resource allocation (weights up to 1 under a bar of 0.085
                               # on the ppa-like graph: one path through a light node passes) looks at nearly every piece again -- 10.3 vs 9.9 ms hashed
+SKETCH_WIDE = True            # ... and their head tables carry a plan whose packed pieces hold 8192 paths instead of 4096 (a sketch piece has
+                              # no keys to run out of slots for): 1.20 M -> 0.98 M pieces on the ppa-like graph, 7.25 -> 6.75 ms
 SKETCH_SET = 0                # slots of a sketch piece's set of reported ids (a power of two <= 64; 0 = the kernel's 128): tests shrink it
 LAZY_PLAN = True              # the whole-graph plan table (no skipped heads) is built when a launch first wants it; the bar sample plans itself
 ROW_RECORDS = True            # the launch gathers a row's cuts, first entry and weight out of ONE 128-byte line (ops.scan_row_records)
@@ -415,10 +417,11 @@ def screen_weights(g0: CSRGraph, g: CSRGraph, perm, node_w: torch.Tensor) -> Scr
 class HeadTables:
     """What a launch with skipped heads brings (one set per budget): the head table, the window paths and the plan of the rows
     that are still walked, and that plan's dropped weight bits."""
-    __slots__ = ("budget", "heads", "wpaths", "plan", "d_used", "live", "n_hub", "pack")
+    __slots__ = ("budget", "heads", "wpaths", "plan", "d_used", "live", "n_hub", "pack", "wide")
 
-    def __init__(self, budget, heads, wpaths, plan, d_used, n_hub=0):
+    def __init__(self, budget, heads, wpaths, plan, d_used, n_hub=0, wide=False):
         self.budget, self.heads, self.wpaths, self.plan, self.d_used = budget, heads, wpaths, plan, d_used
+        self.wide = wide             # the plan's packed pieces hold up to 8192 paths: for SKETCH launches only (ops.SCAN_WIDE)
         self.n_hub = n_hub           # hub rows the heads were cut from (a graph's second scan widens the table: rebuilt then)
         self.pack = None             # ops.scan_column_pack of this plan (see column_pack)
         self.live = {}               # (rank, world) -> this rank's columns without the DEAD ones (see live_columns)
@@ -463,25 +466,28 @@ def head_budget(bar_units: float) -> int:
     return (b >> drop) << drop
 
 
-def head_tables(g: CSRGraph, screen: Screen, budget: int) -> HeadTables:
+def head_tables(g: CSRGraph, screen: Screen, budget: int, wide: bool = False) -> HeadTables:
     """The tables of a launch whose columns skip heads of at most ``budget`` (table units), cached on the Screen: the head table
     (eps_scan_heads), the window paths and the plan table of the walked rows.  ~1.5 ms on the ppa-like graph, once per bar
     level; one host read (the plan's size and dropped bits)."""
     n_hub = hub_rows(g).shape[0]
-    if budget in screen.heads and screen.heads[budget].n_hub != n_hub:
+    # (``wide``: a plan for sketch launches -- its packed pieces hold twice the paths, csrc/scan_pieces.hip -- is a table set of its own)
+    budget_key, budget = (budget, bool(wide)), int(budget)
+    if budget_key in screen.heads and screen.heads[budget_key].n_hub != n_hub:
         # built against the narrow hub table of the graph's first scan (HUB_FIRST): still correct -- the wider bitmaps are a
         # superset -- but its heads stop at the old width; every weight table of the graph gets the full-width heads (ADVICE r05)
-        del screen.heads[budget]
-    if budget not in screen.heads:
+        del screen.heads[budget_key]
+    if budget_key not in screen.heads:
         heads = ops.scan_heads(g.rowptr, g.col, screen.fx32, n_hub, budget, HEAD_MAX_ROWS)
         bounds, cuts = screen_tables(g)
         wp = ops.scan_window_paths(g.rowptr, g.col, reverse_positions(g), cuts, heads)
         pptr, recs, d_word = ops.scan_plan(g.rowptr, cuts, wp, screen.ssum, screen.smax, bounds, g.n_rows, screen.shift,
-                                           screen.vword if screen.vword is not None else screen_variant(g), with_d=True, heads=heads)
-        while len(screen.heads) >= HEAD_CACHE:
+                                           (screen.vword if screen.vword is not None else screen_variant(g)) | (ops.SCAN_WIDE if wide else 0),
+                                           with_d=True, heads=heads)
+        while len(screen.heads) >= 2 * HEAD_CACHE:
             screen.heads.pop(next(iter(screen.heads)))
-        screen.heads[budget] = HeadTables(budget, heads, wp, (pptr, recs), int(d_word.item()), n_hub)
-    return screen.heads[budget]
+        screen.heads[budget_key] = HeadTables(budget, heads, wp, (pptr, recs), int(d_word.item()), n_hub, bool(wide))
+    return screen.heads[budget_key]
 
 
 def live_columns(g: CSRGraph, screen: Screen, ht: HeadTables, rank: int, world: int) -> torch.Tensor:
@@ -609,7 +615,7 @@ def _launch(g, fixw, columns, threshold, capacity, scores_only: bool = False, bo
             bounds, cuts = screen_tables(g)
             walked = ops.Survivors(walked_capacity, threshold, g.device, prefill=False)
             ops.scan_screen(g.rowptr, g.col, reverse_positions(g), screen.fx32, cuts, bounds, g.n_rows, columns, screen.shift, walked,
-                            out.status, screen_variant(g) | ((ops.SCAN_SKETCH | SKETCH_SET << 17) if sketch else 0), None, None, heads.wpaths, screen.ssum, screen.smax,
+                            out.status, screen_variant(g) | ((ops.SCAN_SKETCH | SKETCH_SET << 17) if sketch else 0) | (ops.SCAN_WIDE if heads.wide else 0), None, None, heads.wpaths, screen.ssum, screen.smax,
                             heads.plan, heads.heads,
                             batch_from(g, columns), screen.rowrec,
                             column_records(g, screen, columns, heads.plan, heads.heads, heads.live, ("colrec", columns.data_ptr(), columns.numel())),
@@ -1042,10 +1048,15 @@ def scan_topk(g: CSRGraph, node_w: torch.Tensor, k: int, rank: int = 0, world: i
         if launches >= MAX_LAUNCHES:
             raise ops._lib.EpsError(f"scan_topk: no usable bar after {launches} launches (k = {k}, capacity {capacity})")
         ht = _heads_for(g, screen, bar) if use_heads and bar is not None else None
+        # sketch pieces (and the plan made for them: packed pieces of twice the paths) when the bar is several of the heaviest weight
+        want_sketch = (sketch and ht is not None and screen_variant(g) == 2
+                       and ht.budget >= HEAD_BETA * SKETCH_MIN_PATHS * screen.w_max_units)
+        if ht is not None and ht.wide != (want_sketch and SKETCH_WIDE):
+            ht = screen.head_cur = head_tables(g, screen, ht.budget, want_sketch and SKETCH_WIDE)
         walked_cap = max(1, min(int(head_list * capacity), ops.SURVIVOR_SLOTS_MAX)) if ht is not None else 0
         res = _launch(g, fixw, mine if ht is None else live_columns(g, screen, ht, rank, world), float("-inf") if bar is None else bar,
                       capacity, both=True, screen=screen, heads=ht, walked_capacity=walked_cap,
-                      sketch=sketch and ht is not None and ht.budget >= HEAD_BETA * SKETCH_MIN_PATHS * screen.w_max_units)
+                      sketch=want_sketch)
         launches += 1
         l_keys, l_vals = res.key, res.val
         status, pre_thr = None, None
