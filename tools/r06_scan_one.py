@@ -16,14 +16,14 @@ sc = scan.screen_weights(g0, g, perm, w)
 bounds, cuts = scan.screen_tables(g)
 bar = float(os.environ.get("BAR", "2.8758351802825928"))
 scan.HEAD_BETA = float(os.environ.get("BETA", scan.HEAD_BETA))
-ht = scan.head_tables(g, sc, scan.head_budget(bar * 2.0 ** sc.shift))
+ht = scan.head_tables(g, sc, scan.head_budget(bar * 2.0 ** sc.shift), wide=scan.SKETCH_PIECES and scan.SKETCH_WIDE)
 cols = scan.live_columns(g, sc, ht, 0, 1)
 hub = scan.hub_rows(g)
 pack = scan.column_pack(g, sc, ht) if os.environ.get('PACK', '1') == '1' else None
 for _ in range(int(os.environ.get("REPS", "1"))):
     wk = ops.Survivors(128 << 20, bar, dev, prefill=False)
     status = torch.zeros(1, dtype=torch.int32, device=dev)
-    ops.scan_screen(g.rowptr, g.col, scan.reverse_positions(g), sc.fx32, cuts, bounds, g.n_rows, cols, sc.shift, wk, status, scan.screen_variant(g) | (ops.SCAN_SKETCH if scan.SKETCH_PIECES else 0),
+    ops.scan_screen(g.rowptr, g.col, scan.reverse_positions(g), sc.fx32, cuts, bounds, g.n_rows, cols, sc.shift, wk, status, scan.screen_variant(g) | (ops.SCAN_SKETCH if scan.SKETCH_PIECES else 0) | (ops.SCAN_WIDE if ht.wide else 0),
                     wpaths=ht.wpaths, ssum=sc.ssum, smax=sc.smax, plan=ht.plan, heads=ht.heads, batch_from=scan.batch_from(g, cols), rowrec=sc.rowrec, colrec=scan.column_records(g, sc, cols, ht.plan, ht.heads, ht.live, 'one'), pack=pack)
     res = ops.Survivors(48 << 20, bar, dev, prefill=False)
     ops.scan_refine(wk, ht.heads, hub, sc.fx32, g.rowptr, g.col, g.n_rows, sc.shift, res)
