@@ -1049,7 +1049,9 @@ def scan_topk(g: CSRGraph, node_w: torch.Tensor, k: int, rank: int = 0, world: i
             raise ops._lib.EpsError(f"scan_topk: no usable bar after {launches} launches (k = {k}, capacity {capacity})")
         ht = _heads_for(g, screen, bar) if use_heads and bar is not None else None
         # sketch pieces (and the plan made for them: packed pieces of twice the paths) when the bar is several of the heaviest weight
-        want_sketch = (sketch and ht is not None and screen_variant(g) == 2
+        # (not when the screening sums ARE the scores -- Screen.exact, common neighbours: a sketch piece's sums are upper bounds, and
+        #  nothing re-scores them there)
+        want_sketch = (sketch and ht is not None and screen_variant(g) == 2 and not screen.exact
                        and ht.budget >= HEAD_BETA * SKETCH_MIN_PATHS * screen.w_max_units)
         if ht is not None and ht.wide != (want_sketch and SKETCH_WIDE):
             ht = screen.head_cur = head_tables(g, screen, ht.budget, want_sketch and SKETCH_WIDE)

@@ -224,6 +224,8 @@ def test_sketch_pieces_give_the_same_rows_and_fall_back(eps, dev, monkeypatch, k
         assert not st0["sketch"] and st0["sketch_void"] == 0 and st1["heads"] == st0["heads"]
         ran += int(st1["sketch"])
         voids += st1["sketch_void"]
+        if kind == "cn":            # (uniform weights: the screening sums are the scores -- Screen.exact -- so upper bounds will not do)
+            assert not st1["sketch"] and st1["sketch_void"] == 0
         assert not (st1["sketch"] and st1["sketch_void"]), st1
     assert ran >= 1 or kind == "cn", "no launch ran sketch pieces"      # (common-neighbour counts: under these bars the tail's columns are dead)
     # (whether the one-slot set fills up depends on where the survivors sit: test_sketch_pieces_at_the_kernel forces it)
