@@ -281,8 +281,19 @@ int eps_filter_scan(const int64_t *rowptr, const int32_t *col, const int32_t *re
  *                           the low weight bits a packed / 16-bit direct piece may drop (default shift - 8).  Lower it when the
  *                           graph's smallest weight is small: the screening score exceeds the exact one by up to 2^d + 1 units
  *                           per path, and the pre-filter before the exact re-scoring is as sharp as that is small next to a weight;
+ *                           bit 16 of `variant` (r06; eps_scan_screen, the 256-thread geometry, unit-valued graphs, a launch under a
+ *                           bar): packed pieces of single-round columns run as SKETCH pieces -- no keys: every path adds its
+ *                           weight to one slot of each of two half tables (two hashes, non-returning adds), a candidate's sum
+ *                           is at most the smaller of its two slots (an UPPER bound: what a screen needs and no more, so the
+ *                           reported sums are not exact even where hashed pieces' would be -- re-score), the ids that reach the
+ *                           bar are reported once each from a second look at the piece's paths; bits 17..23: slots of the
+ *                           per-workgroup set of reported ids (a power of two <= 64; 0 = 128); bit 24 (eps_scan_plan AND the
+ *                           eps_scan_screen launch that uses the plan, together with bit 16): a packed piece of a column of
+ *                           <= 256 rows holds up to 8192 paths -- without keys neither key bits, sum field nor table slots bound it;
  *                           *status (device word, cleared by the call): value 2 (bit 1) = a table filled up (results
- *                           invalid; cannot happen within the planner's piece limits: a backstop). */
+ *                           invalid; cannot happen within the planner's piece limits: a backstop); value 8 (bit 3) = a sketch
+ *                           piece had more ids to report than its set holds (results invalid: repeat the launch without
+ *                           bit 16, on a plan without bit 24); value 16 (bit 4) = sketch pieces ran (informational). */
 int32_t eps_scan_windows(void);
 /* eps_rescore_runs: exact scores of screened survivors.  keys = (u << 32) | v, sorted ascending (runs of equal u: the hubs
  * recur); fixw = eps_fixed_weights(node_w); out[i] = float32 of the exact int64 sum of the 2^-40 fixed-point weights over the
