@@ -653,7 +653,9 @@ def run(args):
                                           "rows are not walked at all -- their weights (at most half the bar per column) enter every "
                                           "pair of the column as a BOUND, and the slots that pass get the exact head term from the hub "
                                           "row bitmaps (eps_scan_refine) -- so a candidate reached through hub rows only is bounded, "
-                                          "never touched (roofline.skipped_heads); the K rows are identical to the exact "
+                                          "never touched (roofline.skipped_heads); r06: in the sparse tail of the id space a piece of a column keeps NO keys -- its paths add "
+                                          "into two hashed half tables and a candidate's sum is bounded by the smaller of its two slots (a count-min sketch: an "
+                                          "upper bound too; ids that reach the bar are reported from a second look at the paths and re-scored exactly); the K rows are identical to the exact "
                                           "scan's (eps_filter_scan: tests, profiles/r03/two_kernels_same_list.txt).  The literal "
                                           "filter.py:113-165 -- every candidate's exact score written out -- is the leg "
                                           "full_list_every_candidate_scored",
