@@ -604,7 +604,9 @@ def run(args):
                               "walked_half_paths": walked_paths, "walked_share": walked_paths / max(1, half_paths_total),
                               "rows_skipped": skipped_rows, "walked_list_slots_all_ranks": slots,
                               "pieces": int(ht.plan[1].shape[0]), "hub_rows": int(scan.hub_rows(gs_).shape[0]),
-                              "candidates_touched_by_the_walk": stats.get("touched")}
+                              # (counted where a piece keeps keys: direct and hashed pieces; the sketch pieces of the tail do not count theirs)
+                              "candidates_touched_by_the_walk": stats.get("touched"), "sketch_pieces": bool(stats.get("sketch")),
+                              "plan_for_sketch_launches": bool(ht.wide)}
         kmax = max(r[0] for r in per_rank)
         achieved = abytes / (kmax * 1e-3) / 1e9
         pmc = {}
