@@ -101,8 +101,6 @@ struct sp_params {
                                 //        0..15 its 32 cuts, word 16 its first entry (rowptr), word 17 its screening weight (eps_scan_row_records)
     uint32_t wide_paths;        // r06, plans for sketch launches: a packed piece of a column of <= wide_rows rows may hold this many paths (it will
     int32_t wide_rows;          //      run as a sketch piece: no keys, no sum field -- only the unit bitmap's range bounds it); 0 = off
-    uint32_t sketch_shift;      // ... low weight bits a sketch piece drops (rounding up): the caller keeps 8192 x the heaviest weight below 2^32,
-                                //     so that a slot cannot wrap whatever collides in it
     uint32_t sketch;            // r06: PACKED pieces of single-round columns under a bar keep no keys (see SP_EM): 0 = off
     uint32_t batch_from;        // tickets below stand for one column, tickets from here on for SP_BATCH consecutive ones (>= n_columns: none)
     const uint4 *pack;          // [nnz][2] or NULL (r06; with plan + row records): per stored entry (v, j), in CSR order, everything a
@@ -461,11 +459,10 @@ __global__ __launch_bounds__(T, 4) void scan_piece_kernel(sp_params p)      // (
                 const bool packed_kind = !HV && (info >> 30) == 1u;
                 const bool sketch = SK && packed_kind && single && p.sketch != 0u && thr_v < SP_FLAG;      // (uniform)
                 const bool packed = packed_kind && !sketch;
-                const bool quant = packed || d16 || sketch;                              // weights drop pk_d low bits
+                const bool quant = packed || d16;                                        // weights drop pk_d low bits
                 const uint32_t ppaths = info & 0x3FFFFFFFu;
-                const uint32_t pq = packed || d16 ? s_pq[pi] : 0u;
-                // weight bits dropped (a sketch piece: what keeps its slots from wrapping, see sp_params); bits of the flag + sum field
-                const uint32_t pk_d = sketch ? p.sketch_shift : pq & 0xFFu, pk_sb = packed || d16 ? 32u - (pq >> 8) : 16u;
+                const uint32_t pq = quant ? s_pq[pi] : 0u;
+                const uint32_t pk_d = pq & 0xFFu, pk_sb = quant ? 32u - (pq >> 8) : 16u;      // weight bits dropped; bits of the flag + sum field
                 const uint32_t pk_flag = quant ? 1u << (pk_sb - 1u) : 0u;
                 const uint32_t pk_thr = thr_v >= SP_FLAG ? 0xFFFFFFFFu : ((thr_v >> pk_d) ? (thr_v >> pk_d) : 1u);
                 const int32_t lo_id = s_plo[pi], hi_id = s_phi[pi];
@@ -886,7 +883,7 @@ __global__ __launch_bounds__(T, 4) void scan_piece_kernel(sp_params p)      // (
                                     const uint32_t m = m01 > m23 ? m01 : m23;
                                     mx = m > mx ? m : mx;
                                 }
-                                if (__ballot(mx >= pk_thr) && lane == 0) s_hot = 1u;
+                                if (__ballot(mx >= thr_v) && lane == 0) s_hot = 1u;
                             }
                             sp_barrier();
                             if (s_hot) {
@@ -921,7 +918,7 @@ __global__ __launch_bounds__(T, 4) void scan_piece_kernel(sp_params p)      // (
                                 }
 #pragma unroll
                                 for (int i = 0; i < 4 * SP_G; ++i)
-                                    if ((i & 3) < f[i >> 2].nvalid && est[i] >= pk_thr) report((uint32_t)f[i >> 2].u4[i & 3], (est[i] < (0x7FFFFFFFu >> pk_d) ? est[i] : 0x7FFFFFFFu >> pk_d) << pk_d);
+                                    if ((i & 3) < f[i >> 2].nvalid && est[i] >= thr_v) report((uint32_t)f[i >> 2].u4[i & 3], est[i]);
                             };
                             sp_unit fa[SP_G], fb[SP_G];
                             fetch_group(0, fa);
@@ -1830,7 +1827,6 @@ static const int sp_threads_of[3] = {512, 1024, 256}, sp_bits_of[3] = {13, 14, 1
 #define SP_VARIANT_DMAX(v) ((((v) >> 8) & 0xFF) - 1)
 // ... and in bit 16 (eps_scan_screen only; r06): packed pieces of single-round columns run as SKETCH pieces (see the kernel)
 #define SP_VARIANT_WIDE(v) (((v) >> 24) & 1)          // (plans and launches) bit 24: packed pieces of single-round columns hold up to 2^(bits + 1) paths
-#define SP_VARIANT_SKETCH_SHIFT(v) (((v) >> 25) & 0x1F)      // bits 25..29: low weight bits the sketch pieces drop
 #define SP_VARIANT_SKETCH(v) (((v) >> 16) & 0xFF)      // bit 0: on; bits 1..7: slots of the reported-id set (a power of two <= SP_EM; 0 = SP_EM)
 
 // what the planner reads of the geometry: the scan launch and the plan-table launch must agree on it
@@ -1990,7 +1986,7 @@ static int sp_launch(const int64_t *rowptr, const int32_t *col, const float *val
     EPS_REQUIRE(rowptr && col && revpos && cuts && wpaths && bounds && columns && out, "eps_scan_screen: null pointer");
     EPS_REQUIRE(nnz < (1ll << 30), "eps_scan_screen: col[] is addressed with 32-bit byte offsets (nnz < 2^30)");
     EPS_REQUIRE(n_nodes < (1ll << 31) && n_columns < (1ll << 31), "eps_scan_screen: too many nodes / columns");
-    const uint32_t sketch_arg = (uint32_t)SP_VARIANT_SKETCH(variant), sketch_shift_arg = (uint32_t)SP_VARIANT_SKETCH_SHIFT(variant);
+    const uint32_t sketch_arg = (uint32_t)SP_VARIANT_SKETCH(variant);
     EPS_REQUIRE(!SP_VARIANT_WIDE(variant) || ((sketch_arg & 1u) && plan && !val && SP_VARIANT_GEOM(variant) == 2),
                 "eps_scan_screen: a plan with wide packed pieces (variant bit 24) is for sketch launches (bit 16) of the 256-thread geometry");
     const int32_t dmax_arg = SP_VARIANT_DMAX(variant);
@@ -2024,7 +2020,6 @@ static int sp_launch(const int64_t *rowptr, const int32_t *col, const float *val
     p.n_columns = (int32_t)n_columns;
     p.batch_from = batch_from < 0 || batch_from > n_columns ? (uint32_t)n_columns : (uint32_t)batch_from;
     p.sketch = val || !(sketch_arg & 1u) ? 0u : sketch_arg;
-    p.sketch_shift = sketch_shift_arg;
     p.col_bytes = (uint32_t)(nnz * 4);
     p.scale = ldexpf(1.0f, -shift);
     p.next_col = counter;

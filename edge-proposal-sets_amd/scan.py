@@ -599,18 +599,6 @@ def one_pass_available(g: CSRGraph) -> bool:
     return screen_variant(g) is not None
 
 
-def _sketch_shift(screen: Screen) -> int:
-    """Low weight bits the sketch pieces of a launch drop (rounding up): 8192 paths of the heaviest weight -- a whole piece in one slot --
-    stay below 2^32, so no slot of a sketch table can wrap, whatever collides in it (csrc/scan_pieces.hip: sketch_shift)."""
-    w = screen.w_max_units
-    if not (w < float("inf")):
-        return 0
-    r = 0
-    while ((int(w) >> r) + 1) * 8192 >= 1 << 32:
-        r += 1
-    return min(31, r)
-
-
 def _launch(g, fixw, columns, threshold, capacity, scores_only: bool = False, both: bool = False, screen=None,
             heads: Optional[HeadTables] = None, walked_capacity: int = 0, sample_key=None, sketch: bool = False) -> ops.Survivors:
     """``screen`` (a Screen) -> the one-pass kernel (screening scores in ``val``), else eps_filter_scan (exact scores).
@@ -627,7 +615,7 @@ def _launch(g, fixw, columns, threshold, capacity, scores_only: bool = False, bo
             bounds, cuts = screen_tables(g)
             walked = ops.Survivors(walked_capacity, threshold, g.device, prefill=False)
             ops.scan_screen(g.rowptr, g.col, reverse_positions(g), screen.fx32, cuts, bounds, g.n_rows, columns, screen.shift, walked,
-                            out.status, screen_variant(g) | ((ops.SCAN_SKETCH | SKETCH_SET << 17 | _sketch_shift(screen) << 25) if sketch else 0) | (ops.SCAN_WIDE if heads.wide else 0), None, None, heads.wpaths, screen.ssum, screen.smax,
+                            out.status, screen_variant(g) | ((ops.SCAN_SKETCH | SKETCH_SET << 17) if sketch else 0) | (ops.SCAN_WIDE if heads.wide else 0), None, None, heads.wpaths, screen.ssum, screen.smax,
                             heads.plan, heads.heads,
                             batch_from(g, columns), screen.rowrec,
                             column_records(g, screen, columns, heads.plan, heads.heads, heads.live, ("colrec", columns.data_ptr(), columns.numel())),

@@ -90,7 +90,7 @@ for beta in [float(x) for x in (sys.argv[1:] or ["0", "0.25", "0.5", "0.625"])]:
         def run():
             wk = ops.Survivors(256 << 20, bar, dev, prefill=False)
             ops.scan_screen(g.rowptr, g.col, scan.reverse_positions(g), sc.fx32, cuts, bounds, g.n_rows, cols, sc.shift, wk, status,
-                            variant | ((ops.SCAN_SKETCH | scan._sketch_shift(sc) << 25) if os.environ.get('SKETCH', '0') == '1' else 0) | (ops.SCAN_WIDE if os.environ.get('WIDE', '0') == '1' else 0),
+                            variant | (ops.SCAN_SKETCH if os.environ.get('SKETCH', '0') == '1' else 0) | (ops.SCAN_WIDE if os.environ.get('WIDE', '0') == '1' else 0),
                             wpaths=ht.wpaths, ssum=sc.ssum, smax=sc.smax, plan=ht.plan, heads=ht.heads,
                             colrec=None if os.environ.get('COLREC', '1') == '0' else scan.column_records(g, sc, cols, ht.plan, ht.heads, ht.live, ("ab", cols.numel())),
                             batch_from=int(os.environ['BATCH_FROM']) if 'BATCH_FROM' in os.environ else scan.batch_from(g, cols),

@@ -23,7 +23,7 @@ pack = scan.column_pack(g, sc, ht) if os.environ.get('PACK', '1') == '1' else No
 for _ in range(int(os.environ.get("REPS", "1"))):
     wk = ops.Survivors(128 << 20, bar, dev, prefill=False)
     status = torch.zeros(1, dtype=torch.int32, device=dev)
-    ops.scan_screen(g.rowptr, g.col, scan.reverse_positions(g), sc.fx32, cuts, bounds, g.n_rows, cols, sc.shift, wk, status, scan.screen_variant(g) | ((ops.SCAN_SKETCH | scan._sketch_shift(sc) << 25) if scan.SKETCH_PIECES else 0) | (ops.SCAN_WIDE if ht.wide else 0),
+    ops.scan_screen(g.rowptr, g.col, scan.reverse_positions(g), sc.fx32, cuts, bounds, g.n_rows, cols, sc.shift, wk, status, scan.screen_variant(g) | (ops.SCAN_SKETCH if scan.SKETCH_PIECES else 0) | (ops.SCAN_WIDE if ht.wide else 0),
                     wpaths=ht.wpaths, ssum=sc.ssum, smax=sc.smax, plan=ht.plan, heads=ht.heads, batch_from=scan.batch_from(g, cols), rowrec=sc.rowrec, colrec=scan.column_records(g, sc, cols, ht.plan, ht.heads, ht.live, 'one'), pack=pack)
     res = ops.Survivors(48 << 20, bar, dev, prefill=False)
     ops.scan_refine(wk, ht.heads, hub, sc.fx32, g.rowptr, g.col, g.n_rows, sc.shift, res)
