@@ -271,6 +271,18 @@ def screen_shift(bound: float, max_deg: int, weighted: bool = False) -> int:
     return shift
 
 
+SKETCH_PIECE_PATHS = 8192      # paths a sketch piece holds at most (csrc/scan_pieces.hip: wide_paths <= SP_UBITS)
+
+
+def sketch_safe_shift(f_hi: int) -> int:
+    """The finest screening fixed point 2^-shift under which SKETCH_PIECE_PATHS paths of the heaviest node weight (``f_hi``, in the
+    2^-40 units of the exact scores; screening weights round up) sum to less than 2^32."""
+    shift = MAX_SCREEN_SHIFT
+    while shift > 0 and ((max(0, f_hi) >> (40 - shift)) + 2) * SKETCH_PIECE_PATHS >= 1 << 32:
+        shift -= 1
+    return shift
+
+
 class Screen:
     """What a launch of the piece kernel and the exact re-scoring of its survivors need, for one (graph, weight table)."""
     __slots__ = ("fx32", "shift", "fixw", "val", "node_w", "usable", "ssum", "smax", "_plan", "_plan_build", "d_used", "w_min", "heads", "head_cur",
@@ -351,6 +363,11 @@ def screen_weights(g0: CSRGraph, g: CSRGraph, perm, node_w: torch.Tensor) -> Scr
             nw = (node_w if perm is None else node_w[perm]).contiguous()
             return Screen(None, shift, None, g.val, nw, fits and bool((nw >= 0).all().item()))
         fixw = _scan_weights(g0, g, perm, node_w)
+        if fixw.numel():
+            # (r06) the heaviest screening weight stays below 2^19: 8192 of them -- a whole sketch piece hashed into ONE slot -- cannot
+            # wrap a 32-bit slot, so a sketch table's sums are upper bounds whatever collides (one more host read when a weight table's
+            # screen is built; Adamic-Adar on the ppa-like graph: 1 / ln 2 x 2^19 -> shift 18)
+            shift = min(shift, sketch_safe_shift(int(fixw.max().item())))
         fx32, bad = ops.scan_screen_weights(fixw, shift)
         # Everything is launched before anything is read back: the verdict on the weights (`bad`), the bits the plan drops and the
         # smallest weight come back in ONE host read at the end (tables built from unusable weights are simply not used).
@@ -1052,6 +1069,7 @@ def scan_topk(g: CSRGraph, node_w: torch.Tensor, k: int, rank: int = 0, world: i
         # (not when the screening sums ARE the scores -- Screen.exact, common neighbours: a sketch piece's sums are upper bounds, and
         #  nothing re-scores them there)
         want_sketch = (sketch and ht is not None and screen_variant(g) == 2 and not screen.exact
+                       and (int(screen.w_max_units) + 2) * SKETCH_PIECE_PATHS < 1 << 32          # (no slot can wrap: screen_weights saw to it)
                        and ht.budget >= HEAD_BETA * SKETCH_MIN_PATHS * screen.w_max_units)
         if ht is not None and ht.wide != (want_sketch and SKETCH_WIDE):
             ht = screen.head_cur = head_tables(g, screen, ht.budget, want_sketch and SKETCH_WIDE)

@@ -286,7 +286,8 @@ int eps_filter_scan(const int64_t *rowptr, const int32_t *col, const int32_t *re
  *                           weight to one slot of each of two half tables (two hashes, non-returning adds), a candidate's sum
  *                           is at most the smaller of its two slots (an UPPER bound: what a screen needs and no more, so the
  *                           reported sums are not exact even where hashed pieces' would be -- re-score), the ids that reach the
- *                           bar are reported once each from a second look at the piece's paths; bits 17..23: slots of the
+ *                           bar are reported once each from a second look at the piece's paths; the caller keeps 8192 x the heaviest
+ *                           fx32 below 2^32 (a coarser `shift` if need be), so that no slot can wrap; bits 17..23: slots of the
  *                           per-workgroup set of reported ids (a power of two <= 64; 0 = 128); bit 24 (eps_scan_plan AND the
  *                           eps_scan_screen launch that uses the plan, together with bit 16): a packed piece of a column of
  *                           <= 256 rows holds up to 8192 paths -- without keys neither key bits, sum field nor table slots bound it;
