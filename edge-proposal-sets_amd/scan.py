@@ -367,7 +367,11 @@ def screen_weights(g0: CSRGraph, g: CSRGraph, perm, node_w: torch.Tensor) -> Scr
             # (r06) the heaviest screening weight stays below 2^19: 8192 of them -- a whole sketch piece hashed into ONE slot -- cannot
             # wrap a 32-bit slot, so a sketch table's sums are upper bounds whatever collides (one more host read when a weight table's
             # screen is built; Adamic-Adar on the ppa-like graph: 1 / ln 2 x 2^19 -> shift 18)
-            shift = min(shift, sketch_safe_shift(int(fixw.max().item())))
+            # (... when that costs one bit at most: resource allocation -- weights from 1 down to 1 / 13 230 -- would lose three and
+            #  every small weight its resolution; its bar lies below its heaviest weight anyway: no sketch pieces there, SKETCH_MIN_PATHS)
+            safe = sketch_safe_shift(int(fixw.max().item()))
+            if shift - safe <= 1:
+                shift = min(shift, safe)
         fx32, bad = ops.scan_screen_weights(fixw, shift)
         # Everything is launched before anything is read back: the verdict on the weights (`bad`), the bits the plan drops and the
         # smallest weight come back in ONE host read at the end (tables built from unusable weights are simply not used).

@@ -227,7 +227,9 @@ def test_sketch_pieces_give_the_same_rows_and_fall_back(eps, dev, monkeypatch, k
         if kind == "cn":            # (uniform weights: the screening sums are the scores -- Screen.exact -- so upper bounds will not do)
             assert not st1["sketch"] and st1["sketch_void"] == 0
         assert not (st1["sketch"] and st1["sketch_void"]), st1
-    assert ran >= 1 or kind == "cn", "no launch ran sketch pieces"      # (common-neighbour counts: under these bars the tail's columns are dead)
+    # (common neighbours: an exact screen; resource allocation: weights whose heaviest would need three bits less of fixed point for
+    #  a slot never to wrap -- no sketch pieces for either, the same rows of course)
+    assert ran >= 1 or kind != "aa", "no launch ran sketch pieces"
     # (whether the one-slot set fills up depends on where the survivors sit: test_sketch_pieces_at_the_kernel forces it)
 
 
