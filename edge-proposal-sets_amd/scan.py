@@ -560,7 +560,7 @@ def column_pack(g: CSRGraph, screen: Screen, ht: HeadTables) -> Optional[torch.T
     return ht.pack
 
 
-def _heads_for(g: CSRGraph, screen: Screen, bar) -> Optional[HeadTables]:
+def _heads_for(g: CSRGraph, screen: Screen, bar, wide_for=None) -> Optional[HeadTables]:
     """The head tables for a launch under ``bar`` (1-element device tensor): the set the last launch used, without looking at the
     bar -- the kernel itself refuses a head as heavy as the bar (status bit 2), and scan_topk compares budget and bar after
     the step's one host read --, or, the first time, a set built for the bar (one host read of it)."""
@@ -573,7 +573,11 @@ def _heads_for(g: CSRGraph, screen: Screen, bar) -> Optional[HeadTables]:
         budget = head_budget(b * 2.0 ** screen.shift)
         if budget <= 0:
             return None
-        screen.head_cur = head_tables(g, screen, budget)
+        # (``wide_for(budget)``: whether the launch will run sketch pieces -- then the tables carry the plan made for them; asked
+        #  BEFORE anything is built: a first scan does not build a set it will not use)
+        screen.head_cur = head_tables(g, screen, budget, bool(wide_for(budget)) if wide_for is not None else False)
+    elif wide_for is not None and screen.head_cur.wide != bool(wide_for(screen.head_cur.budget)):
+        screen.head_cur = head_tables(g, screen, screen.head_cur.budget, bool(wide_for(screen.head_cur.budget)))
     return screen.head_cur
 
 
@@ -1068,15 +1072,15 @@ def scan_topk(g: CSRGraph, node_w: torch.Tensor, k: int, rank: int = 0, world: i
     while True:
         if launches >= MAX_LAUNCHES:
             raise ops._lib.EpsError(f"scan_topk: no usable bar after {launches} launches (k = {k}, capacity {capacity})")
-        ht = _heads_for(g, screen, bar) if use_heads and bar is not None else None
         # sketch pieces (and the plan made for them: packed pieces of twice the paths) when the bar is several of the heaviest weight
         # (not when the screening sums ARE the scores -- Screen.exact, common neighbours: a sketch piece's sums are upper bounds, and
         #  nothing re-scores them there)
-        want_sketch = (sketch and ht is not None and screen_variant(g) == 2 and not screen.exact
-                       and (int(screen.w_max_units) + 2) * SKETCH_PIECE_PATHS < 1 << 32          # (no slot can wrap: screen_weights saw to it)
-                       and ht.budget >= HEAD_BETA * SKETCH_MIN_PATHS * screen.w_max_units)
-        if ht is not None and ht.wide != (want_sketch and SKETCH_WIDE):
-            ht = screen.head_cur = head_tables(g, screen, ht.budget, want_sketch and SKETCH_WIDE)
+        def sketch_for(budget):
+            return bool(sketch and screen is not None and screen_variant(g) == 2 and not screen.exact
+                        and (int(screen.w_max_units) + 2) * SKETCH_PIECE_PATHS < 1 << 32     # (no slot can wrap: screen_weights saw to it)
+                        and budget >= HEAD_BETA * SKETCH_MIN_PATHS * screen.w_max_units)
+        ht = (_heads_for(g, screen, bar, lambda budget: sketch_for(budget) and SKETCH_WIDE) if use_heads and bar is not None else None)
+        want_sketch = ht is not None and sketch_for(ht.budget)
         walked_cap = max(1, min(int(head_list * capacity), ops.SURVIVOR_SLOTS_MAX)) if ht is not None else 0
         res = _launch(g, fixw, mine if ht is None else live_columns(g, screen, ht, rank, world), float("-inf") if bar is None else bar,
                       capacity, both=True, screen=screen, heads=ht, walked_capacity=walked_cap,
