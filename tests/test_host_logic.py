@@ -400,3 +400,19 @@ def test_sharded_proposal_files_read_back_in_rank_order(tmp_path):
         proposals.load_sorted_edges(path)
     proposals.save_sorted_edges(path, rows[:5])
     assert torch.equal(proposals.load_sorted_edges(path), rows[:5])   # (a plain file wins)
+
+
+def test_sketch_safe_shift_keeps_a_whole_piece_below_2_32():
+    """scan.sketch_safe_shift: under the returned fixed point SKETCH_PIECE_PATHS paths of the heaviest weight (2^-40 units, rounded
+    up to screening units) sum to less than 2^32 -- and one bit finer they would not, unless the screen's own maximum stops it."""
+    import math
+    from eps_amd import scan
+    for w in (1.0 / math.log(2.0), 1.0, 0.25, 7.5e-5, 1000.0, 22.0):
+        f_hi = int(round(w * 2.0 ** 40))
+        s = scan.sketch_safe_shift(f_hi)
+        assert 0 <= s <= scan.MAX_SCREEN_SHIFT
+        units = (f_hi >> (40 - s)) + 2                       # (what screen_weights rounds up to, and one to spare)
+        assert units * scan.SKETCH_PIECE_PATHS < 1 << 32, (w, s)
+        if s < scan.MAX_SCREEN_SHIFT:
+            assert ((f_hi >> (40 - s - 1)) + 2) * scan.SKETCH_PIECE_PATHS >= 1 << 32, (w, s)
+    assert scan.sketch_safe_shift(int(round(2.0 ** 40 / math.log(2.0)))) == 18      # Adamic-Adar: 1 / ln 2 is the heaviest weight
