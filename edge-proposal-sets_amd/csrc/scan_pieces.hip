@@ -722,6 +722,15 @@ __global__ __launch_bounds__(T, 4) void scan_piece_kernel(sp_params p)      // (
                                     lid[i] = id - (uint32_t)lo_id;
                                     h[i] = mixv[i] >> (32 - bits);
                                 }
+#ifdef SP_ABL_PACKED_NOHASH
+                                // (timing-only ablation, tools/r06_packed_nohash.sh: what a PERFECT table for the sparse tail -- one
+                                //  non-returning add per path, no key, no probing -- would leave of the launch; the results are wrong.
+                                //  This is the measurement the sketch pieces came from: 8.96 -> 7.10 ms, profiles/r06/scan_structures.txt)
+#pragma unroll
+                                for (int i = 0; i < E; ++i)
+                                    if (pend & (1u << i)) atomicAdd(&lds[h[i]], f[i >> 2].fx);
+                                pend = 0u;
+#endif
 #pragma unroll
                                 for (int wide = 0; wide < 2; ++wide) {           // (two wide rounds: a fifth of the entries miss the first)
 #pragma unroll

@@ -5,8 +5,8 @@
 mkdir -p gpurun_out/r06
 out=gpurun_out/r06/packed_nohash.txt
 : > $out
-for lib in "" tools/bin/libeps_nohash.so tools/bin/libeps_mock.so; do
+for lib in "" tools/bin/libeps_nohash.so; do
   echo "== ${lib:-product}" >> $out
-  EPS_LIB_PATH=$lib LIVE=1 PACK=1 REPS=7 timeout 280 python tools/r05_heads_ab.py 0.5 2>&1 | grep -v amdgpu.ids | grep kernel_min_ms >> $out
+  EPS_LIB_PATH=$lib SKETCH=0 LIVE=1 PACK=1 REPS=7 timeout 280 python tools/r05_heads_ab.py 0.5 2>&1 | grep -v amdgpu.ids | grep kernel_min_ms >> $out
 done
 cat $out | cut -c1-400
